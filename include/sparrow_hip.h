@@ -1,0 +1,223 @@
+/*
+ * sparrow_hip.h -- C ABI of libsparrow_hip.so: the MI355X (gfx950) CTR-ranking forward pass
+ * for SparrowRecSys's TFRecModel models.
+ *
+ * The reference has NO native/FFI interface for this path: every model is a stand-alone Keras
+ * script and the boundary a maintainer sees is `model.predict(x)` (reference
+ * TFRecModel/src/com/sparrowrecsys/offline/tensorflow/DeepFM.py:131, DIN.py:185,
+ * NeuralCF.py:91) and the TF-Serving REST call of the Jetty server
+ * (src/main/java/com/sparrowrecsys/online/recprocess/RecForYouProcess.java:113-138).
+ * This header is therefore the NEW seam those two call into: each entry
+ * point below names the reference construct it replaces.  The Python host
+ * (sparrowrecsys_amd/_lib.py) binds it with ctypes; INTEGRATION.md shows the binding.
+ *
+ * Conventions: plain C types only; every function returns 0 on success or a negative
+ * SPRK_E* code and never throws; sprk_last_error() returns a thread-local message.
+ * `ids`, `dense`, `aux`, `out`, `workspace` are DEVICE pointers owned by the caller (torch
+ * tensors in the Python host); the library owns only the tables/weights it was given through
+ * sprk_upload().  A finalized handle is immutable: sprk_forward*() may run concurrently on
+ * distinct streams; sprk_upload()/sprk_finalize() must not race with them.
+ */
+#ifndef SPARROW_HIP_H
+#define SPARROW_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SPRK_ABI_VERSION 1
+
+#define SPRK_OK 0
+#define SPRK_EINVAL (-1)    /* bad argument / malformed plan            */
+#define SPRK_EHIP (-2)      /* a HIP runtime call failed                */
+#define SPRK_ESTATE (-3)    /* wrong call order (e.g. forward before finalize) */
+#define SPRK_ERANGE (-4)    /* an id was outside its table (see sprk_check_ids) */
+#define SPRK_EKIND (-5)     /* forward_<model> called on a handle of another model */
+
+#define SPRK_TILE_M 64      /* samples per workgroup tile                */
+#define SPRK_MAX_SEGS 40
+#define SPRK_MAX_OPS 24
+#define SPRK_MAX_TAPS 8
+#define SPRK_MAX_PAIRS 32
+#define SPRK_MAX_BUFS 3
+
+/* model_kind: which reference script the plan restates (checked by sprk_forward_<model>) */
+enum sprk_model_kind {
+    SPRK_MODEL_GENERIC = 0,
+    SPRK_MODEL_EMBEDDING_MLP = 1, /* EmbeddingMLP.py:72-77  */
+    SPRK_MODEL_WIDE_DEEP = 2,     /* WideNDeep.py:99-108    */
+    SPRK_MODEL_NEURALCF = 3,      /* NeuralCF.py:45-70      */
+    SPRK_MODEL_DEEPFM = 4,        /* DeepFM.py:91-115       */
+    SPRK_MODEL_DEEPFM_V2 = 5,     /* DeepFM_v2.py:98-157    */
+    SPRK_MODEL_DIN = 6            /* DIN.py:125-169         */
+};
+
+/* Gather segments: how one sample's row of activation buffer 0 is assembled.  Together they
+ * replace tf.keras.layers.DenseFeatures + tf.feature_column.{embedding,indicator,numeric,
+ * crossed}_column (DeepFM.py:54-97, WideNDeep.py:72-73). */
+enum sprk_seg_kind {
+    SPRK_SEG_ROWS = 0,         /* embedding_column: copy table[id] (nvec float4); id<0 -> zeros */
+    SPRK_SEG_SCALAR = 1,       /* indicator_column x Dense(1): one weight table[id]; id<0 -> 0   */
+    SPRK_SEG_DENSE = 2,        /* numeric_column(s): copy `count` floats of the dense row       */
+    SPRK_SEG_ZERO = 3,         /* zero-fill `count` floats (K padding)                           */
+    SPRK_SEG_CROSS_SCALAR = 4, /* indicator(crossed_column) x Dense(1): table[hash(a,b) % vocab] */
+    SPRK_SEG_CROSS_ROWS = 5,   /* embedding_column(crossed_column): row table[hash(a,b) % vocab] */
+    SPRK_SEG_AUX = 6           /* copy `count` floats of the aux row (DIN pooled history)        */
+};
+
+typedef struct sprk_seg {
+    int32_t kind;
+    int32_t slot;       /* weight slot holding the table (ROWS/SCALAR/CROSS_*)            */
+    int32_t field;      /* ids column | first dense column | first aux column             */
+    int32_t field2;     /* second ids column (CROSS_*)                                    */
+    int32_t row_stride; /* floats per table row (multiple of 4 for ROWS)                  */
+    int32_t count;      /* ROWS/CROSS_ROWS: float4 per row; DENSE/ZERO/AUX: floats        */
+    int32_t dst;        /* destination float offset inside buffer 0 (multiple of 4 for ROWS) */
+    int32_t vocab;      /* table rows (bounds check) | number of hash buckets             */
+} sprk_seg;
+
+enum sprk_op_kind {
+    SPRK_OP_DENSE = 0,    /* tf.keras.layers.Dense: dst = act(src @ W + b) on fp32 MFMA        */
+    SPRK_OP_FM_SUMSQ = 1, /* DeepFM_v2.py:147-152: (sum_g v_g)^2 - sum_g v_g^2 over `groups`    */
+    SPRK_OP_PAIR_DOT = 2  /* tf.keras.layers.Dot(axes=1) for the plan's pair list (DeepFM.py:100-103) */
+};
+enum sprk_act { SPRK_ACT_NONE = 0, SPRK_ACT_RELU = 1, SPRK_ACT_PRELU = 2 };
+
+typedef struct sprk_op {
+    int32_t kind;
+    int32_t src_buf, src_off;
+    int32_t K;           /* DENSE: input width (multiple of 4); FM_SUMSQ: width per group; PAIR_DOT: vector length */
+    int32_t dst_buf, dst_off;
+    int32_t N;           /* DENSE: output width (multiple of 16)                           */
+    int32_t w_slot;      /* DENSE: W transposed+padded, [N][ldw] floats                    */
+    int32_t ldw;         /* DENSE: floats per W^T row (multiple of 4, >= K)                */
+    int32_t b_slot;      /* DENSE: bias [N]                                                */
+    int32_t alpha_slot;  /* DENSE+PRELU: alpha [N]                                         */
+    int32_t act;
+    int32_t groups;      /* FM_SUMSQ: number of fields                                     */
+    int32_t group_stride;/* FM_SUMSQ: floats between consecutive fields                    */
+} sprk_op;
+
+/* Output layer: z = head_bias + sum_t scale_t * (bias_t + sum_j w_t[j] * buf_t[off_t + j]);
+ * score = sigmoid(z).  Replaces the final concatenate + Dense(1, sigmoid)
+ * (DeepFM.py:111-113, DeepFM_v2.py:154-155, DIN.py:167, ...). */
+typedef struct sprk_tap {
+    int32_t buf, off, len;
+    int32_t w_slot;      /* weights [len]; -1 -> all ones                                  */
+    float scale;
+    float bias;
+} sprk_tap;
+
+/* DIN activation unit + weighted sum pooling (DIN.py:132-158), run by its own kernel before
+ * the tile kernel; its [B, out_cols] result is what SPRK_SEG_AUX segments read. */
+typedef struct sprk_din {
+    int32_t enabled;
+    int32_t T;           /* history length                                                 */
+    int32_t hist_col;    /* first of T consecutive ids columns                             */
+    int32_t cand_col;    /* candidate movieId ids column                                   */
+    int32_t table_slot;  /* shared movie Embedding table                                   */
+    int32_t row_stride;  /* floats per row (= Dp, multiple of 4)                           */
+    int32_t vocab;
+    int32_t hidden;      /* attention hidden width (multiple of 16; reference 32)          */
+    int32_t w_slot;      /* att0 kernel transposed [hidden][4*Dp] in [h-c | h | c | h*c] blocks */
+    int32_t b_slot;      /* att0 bias [hidden]                                             */
+    int32_t alpha_slot;  /* PReLU alpha [T][hidden]                                        */
+    int32_t w2_slot;     /* att1 kernel [hidden]                                           */
+    float b2;            /* att1 bias                                                      */
+} sprk_din;
+
+typedef struct sprk_plan {
+    int32_t abi_version;               /* SPRK_ABI_VERSION */
+    int32_t model_kind;
+    int32_t n_id_cols;                 /* F: int32 columns per ids row   */
+    int32_t n_dense;                   /* N: floats per dense row        */
+    int32_t n_aux;                     /* floats per aux row (0 if none) */
+    int32_t n_slots;                   /* weight slots used              */
+    int32_t n_bufs;
+    int32_t buf_width[SPRK_MAX_BUFS];  /* floats per sample in each LDS activation buffer */
+    int32_t n_segs;
+    sprk_seg segs[SPRK_MAX_SEGS];
+    int32_t n_ops;
+    sprk_op ops[SPRK_MAX_OPS];
+    int32_t n_pairs;                   /* pair list of the PAIR_DOT op (offsets in src buffer) */
+    int32_t pair_a[SPRK_MAX_PAIRS];
+    int32_t pair_b[SPRK_MAX_PAIRS];
+    int32_t n_taps;
+    sprk_tap taps[SPRK_MAX_TAPS];
+    float head_bias;
+    sprk_din din;
+} sprk_plan;
+
+typedef struct sprk_engine* sprk_handle;
+
+/* Library / device facts.  info[0]=ABI version, [1]=HIP device count (0 when no GPU is
+ * visible; never an error), [2]=compute units of the current device, [3]=1 if it is gfx950. */
+int sprk_runtime_info(int32_t info[4]);
+
+/* Replaces building the Keras graph (`tf.keras.Model(inputs, output_layer)`, DeepFM.py:115):
+ * validates and copies `plan`. */
+int sprk_create(const sprk_plan* plan, sprk_handle* out);
+
+/* Replaces Keras weight loading (`model.set_weights` / SavedModel restore, NeuralCF.py:97-105):
+ * copies `bytes` from `src` (host OR device pointer) into library-owned device memory for
+ * weight slot `slot`.  Layouts are the device layouts documented in DESIGN.md (tables padded
+ * to a multiple of 4 floats per row, Dense kernels transposed). */
+int sprk_upload(sprk_handle h, int32_t slot, const void* src, size_t bytes);
+
+/* Resolves slots to device pointers; must follow the last sprk_upload. */
+int sprk_finalize(sprk_handle h);
+
+/* Bytes of caller-provided device scratch sprk_forward needs for a batch of B (0 for models
+ * without a DIN stage). */
+size_t sprk_workspace_bytes(sprk_handle h, int32_t B);
+
+/* Replaces `model.predict(x)` for one device-resident batch (DeepFM.py:131):
+ *   ids   [B, n_id_cols] int32 row-major, -1 = missing / out-of-vocabulary (-> zero row)
+ *   dense [B, n_dense]   float32 row-major
+ *   out   [B]            float32 sigmoid scores
+ * Asynchronous on `stream` (a hipStream_t; NULL = default stream). */
+int sprk_forward(sprk_handle h, const int32_t* ids, const float* dense, float* out, int32_t B,
+                 void* workspace, size_t workspace_bytes, void* stream);
+
+/* Per-model entry points: identical to sprk_forward but fail with
+ * SPRK_EKIND unless the handle was created from that model's plan. */
+int sprk_forward_embedding_mlp(sprk_handle h, const int32_t* ids, const float* dense, float* out, int32_t B, void* ws, size_t ws_bytes, void* stream);
+int sprk_forward_widedeep(sprk_handle h, const int32_t* ids, const float* dense, float* out, int32_t B, void* ws, size_t ws_bytes, void* stream);
+int sprk_forward_neuralcf(sprk_handle h, const int32_t* ids, const float* dense, float* out, int32_t B, void* ws, size_t ws_bytes, void* stream);
+int sprk_forward_deepfm(sprk_handle h, const int32_t* ids, const float* dense, float* out, int32_t B, void* ws, size_t ws_bytes, void* stream);
+int sprk_forward_deepfm_v2(sprk_handle h, const int32_t* ids, const float* dense, float* out, int32_t B, void* ws, size_t ws_bytes, void* stream);
+int sprk_forward_din(sprk_handle h, const int32_t* ids, const float* dense, float* out, int32_t B, void* ws, size_t ws_bytes, void* stream);
+
+/* DIN stage alone (DIN.py:132-158): pooled [B, row_stride] and, if att != NULL, the attention
+ * weights att [B, T]. */
+int sprk_din_pool(sprk_handle h, const int32_t* ids, float* pooled, float* att, int32_t B, void* stream);
+
+/* Replaces TF's assert_greater_or_equal_0 / assert_less_than_num_buckets
+ * (categorical_column_with_identity, DeepFM.py:54,59): synchronises `stream` and returns
+ * SPRK_ERANGE if any forward since the last call saw an id >= its table size or < -1. */
+int sprk_check_ids(sprk_handle h, void* stream);
+
+void sprk_destroy(sprk_handle h);
+
+/* ---- stand-alone operators (same kernels' building blocks, for parity tests / reuse) ---- */
+
+/* tf.keras.layers.Embedding / embedding_column row gather (DIN.py:132-136, DeepFM.py:55):
+ * out[b, 0:D] = table[ids[b], 0:D]; ids[b] < 0 -> zeros.  table is [V, row_stride] floats,
+ * out is [B, D] floats; D and row_stride multiples of 4.  Bit-exact copy. */
+int sprk_embedding_gather(const float* table, int32_t V, int32_t D, int32_t row_stride,
+                          const int32_t* ids, int32_t B, float* out, void* stream);
+
+/* tf.feature_column.crossed_column([a, b], num_buckets) hashing (WideNDeep.py:72-73):
+ * out[b] = FingerprintCat64(FingerprintCat64(0xDECAFCAFFE, a[b]), b[b]) mod num_buckets. */
+int sprk_cross_hash(const int32_t* a, const int32_t* b, int32_t B, int64_t num_buckets,
+                    int64_t* out, void* stream);
+
+const char* sprk_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPARROW_HIP_H */

@@ -69,6 +69,12 @@ def vocab_ids(values, vocab: Sequence[str] = GENRE_VOCAB) -> np.ndarray:
     """categorical_column_with_vocabulary_list (DeepFM.py:68-69): index = position in the
     list; out-of-vocabulary -> -1 (default_value=-1, num_oov_buckets=0); the empty string is
     dropped by to_sparse_input(ignore_value='') -> also no id.  Returns -1 for both."""
+    arr = np.asarray(values)
+    if arr.dtype.kind in "iu":
+        # already-resolved indices (synthetic benchmarks skip the string lookup): pass through,
+        # anything outside the vocabulary is "no id"
+        arr = arr.astype(np.int64)
+        return np.where((arr < 0) | (arr >= len(vocab)), -1, arr)
     table = {v: i for i, v in enumerate(vocab)}
     out = np.empty(len(values), dtype=np.int64)
     for i, v in enumerate(values):

@@ -1,0 +1,152 @@
+"""ctypes binding of ``libsparrow_hip.so`` (C ABI: include/sparrow_hip.h) and its in-tree build.
+
+The product path has NO CPU fallback: if the shared library cannot be loaded, or no HIP device
+is visible when a forward is requested, the callers raise ``RuntimeError``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+REPO_ROOT = os.path.dirname(_HERE)
+LIB_PATH = os.path.join(_HERE, "libsparrow_hip.so")
+SRC_PATH = os.path.join(_HERE, "csrc", "sparrow_hip.hip")
+INCLUDE_DIR = os.path.join(REPO_ROOT, "include")
+
+ABI_VERSION = 1
+TILE_M = 64
+MAX_SEGS, MAX_OPS, MAX_TAPS, MAX_PAIRS, MAX_BUFS = 40, 24, 8, 32, 3
+
+OK, EINVAL, EHIP, ESTATE, ERANGE, EKIND = 0, -1, -2, -3, -4, -5
+
+MODEL_GENERIC, MODEL_EMBEDDING_MLP, MODEL_WIDE_DEEP, MODEL_NEURALCF, MODEL_DEEPFM, MODEL_DEEPFM_V2, MODEL_DIN = range(7)
+SEG_ROWS, SEG_SCALAR, SEG_DENSE, SEG_ZERO, SEG_CROSS_SCALAR, SEG_CROSS_ROWS, SEG_AUX = range(7)
+OP_DENSE, OP_FM_SUMSQ, OP_PAIR_DOT = range(3)
+ACT_NONE, ACT_RELU, ACT_PRELU = range(3)
+
+# every symbol include/sparrow_hip.h declares (tests check the .so exports all of them)
+EXPORTED_SYMBOLS = [
+    "sprk_runtime_info", "sprk_create", "sprk_upload", "sprk_finalize", "sprk_workspace_bytes",
+    "sprk_forward", "sprk_forward_embedding_mlp", "sprk_forward_widedeep", "sprk_forward_neuralcf",
+    "sprk_forward_deepfm", "sprk_forward_deepfm_v2", "sprk_forward_din", "sprk_din_pool",
+    "sprk_check_ids", "sprk_destroy", "sprk_embedding_gather", "sprk_cross_hash", "sprk_last_error",
+]
+
+
+class Seg(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("slot", C.c_int32), ("field", C.c_int32), ("field2", C.c_int32),
+                ("row_stride", C.c_int32), ("count", C.c_int32), ("dst", C.c_int32), ("vocab", C.c_int32)]
+
+
+class Op(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("src_buf", C.c_int32), ("src_off", C.c_int32), ("K", C.c_int32),
+                ("dst_buf", C.c_int32), ("dst_off", C.c_int32), ("N", C.c_int32), ("w_slot", C.c_int32),
+                ("ldw", C.c_int32), ("b_slot", C.c_int32), ("alpha_slot", C.c_int32), ("act", C.c_int32),
+                ("groups", C.c_int32), ("group_stride", C.c_int32)]
+
+
+class Tap(C.Structure):
+    _fields_ = [("buf", C.c_int32), ("off", C.c_int32), ("len", C.c_int32), ("w_slot", C.c_int32),
+                ("scale", C.c_float), ("bias", C.c_float)]
+
+
+class Din(C.Structure):
+    _fields_ = [("enabled", C.c_int32), ("T", C.c_int32), ("hist_col", C.c_int32), ("cand_col", C.c_int32),
+                ("table_slot", C.c_int32), ("row_stride", C.c_int32), ("vocab", C.c_int32),
+                ("hidden", C.c_int32), ("w_slot", C.c_int32), ("b_slot", C.c_int32),
+                ("alpha_slot", C.c_int32), ("w2_slot", C.c_int32), ("b2", C.c_float)]
+
+
+class Plan(C.Structure):
+    _fields_ = [("abi_version", C.c_int32), ("model_kind", C.c_int32), ("n_id_cols", C.c_int32),
+                ("n_dense", C.c_int32), ("n_aux", C.c_int32), ("n_slots", C.c_int32),
+                ("n_bufs", C.c_int32), ("buf_width", C.c_int32 * MAX_BUFS),
+                ("n_segs", C.c_int32), ("segs", Seg * MAX_SEGS),
+                ("n_ops", C.c_int32), ("ops", Op * MAX_OPS),
+                ("n_pairs", C.c_int32), ("pair_a", C.c_int32 * MAX_PAIRS), ("pair_b", C.c_int32 * MAX_PAIRS),
+                ("n_taps", C.c_int32), ("taps", Tap * MAX_TAPS),
+                ("head_bias", C.c_float), ("din", Din)]
+
+
+_lock = threading.Lock()
+_lib = None
+
+
+def build_library(force: bool = False, verbose: bool = False) -> str:
+    """Compile csrc/sparrow_hip.hip for gfx950 into the in-tree libsparrow_hip.so
+    (hipcc cross-compiles without a GPU)."""
+    if not force and os.path.exists(LIB_PATH) and os.path.getmtime(LIB_PATH) >= max(
+            os.path.getmtime(SRC_PATH), os.path.getmtime(os.path.join(INCLUDE_DIR, "sparrow_hip.h"))):
+        return LIB_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not os.path.exists(hipcc):
+        hipcc = "hipcc"
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+           "-I", INCLUDE_DIR, SRC_PATH, "-o", LIB_PATH + ".tmp"]
+    if verbose:
+        print(" ".join(cmd))
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError("hipcc failed:\n%s\n%s" % (res.stdout, res.stderr))
+    os.replace(LIB_PATH + ".tmp", LIB_PATH)
+    return LIB_PATH
+
+
+def load_library():
+    """Load libsparrow_hip.so (never builds implicitly; never falls back)."""
+    global _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("libsparrow_hip.so is missing (%s): run `python -c 'import __graft_entry__ as g; "
+                               "g.build()'` or sparrowrecsys_amd._lib.build_library(); there is no CPU fallback" % LIB_PATH)
+        lib = C.CDLL(LIB_PATH)
+        vp, i32, sz = C.c_void_p, C.c_int32, C.c_size_t
+        lib.sprk_last_error.restype = C.c_char_p
+        lib.sprk_last_error.argtypes = []
+        lib.sprk_runtime_info.argtypes = [C.POINTER(i32 * 4)]
+        lib.sprk_create.argtypes = [C.POINTER(Plan), C.POINTER(vp)]
+        lib.sprk_upload.argtypes = [vp, i32, vp, sz]
+        lib.sprk_finalize.argtypes = [vp]
+        lib.sprk_workspace_bytes.argtypes = [vp, i32]
+        lib.sprk_workspace_bytes.restype = sz
+        fwd = [vp, vp, vp, vp, i32, vp, sz, vp]
+        for name in ("sprk_forward", "sprk_forward_embedding_mlp", "sprk_forward_widedeep", "sprk_forward_neuralcf",
+                     "sprk_forward_deepfm", "sprk_forward_deepfm_v2", "sprk_forward_din"):
+            getattr(lib, name).argtypes = fwd
+        lib.sprk_din_pool.argtypes = [vp, vp, vp, vp, i32, vp]
+        lib.sprk_check_ids.argtypes = [vp, vp]
+        lib.sprk_destroy.argtypes = [vp]
+        lib.sprk_destroy.restype = None
+        lib.sprk_embedding_gather.argtypes = [vp, i32, i32, i32, vp, i32, vp, vp]
+        lib.sprk_cross_hash.argtypes = [vp, vp, i32, C.c_int64, vp, vp]
+        for name in EXPORTED_SYMBOLS:
+            if name not in ("sprk_last_error", "sprk_destroy", "sprk_workspace_bytes"):
+                getattr(lib, name).restype = C.c_int
+        _lib = lib
+        return lib
+
+
+class SparrowHipError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__("libsparrow_hip error %d: %s" % (code, message))
+        self.code = code
+
+
+def check(rc: int):
+    if rc != OK:
+        msg = load_library().sprk_last_error().decode("utf-8", "replace")
+        if rc == ERANGE:
+            raise ValueError(msg)
+        raise SparrowHipError(rc, msg)
+
+
+def runtime_info():
+    lib = load_library()
+    info = (C.c_int32 * 4)()
+    check(lib.sprk_runtime_info(C.byref(info)))
+    return {"abi_version": info[0], "device_count": info[1], "compute_units": info[2], "is_gfx950": bool(info[3])}

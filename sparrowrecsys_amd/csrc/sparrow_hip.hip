@@ -1,0 +1,922 @@
+// sparrow_hip.hip -- MI355X (gfx950 / CDNA4) CTR-ranking forward engine behind include/sparrow_hip.h.
+//
+// Two hand-written kernels carry the hot path (DESIGN.md has the full data-layout story):
+//
+//   k_tile_forward  one 256-thread workgroup per tile of 64 samples.  Phase 1 gathers every sparse
+//                   slot's embedding row (16-B lanes, 64-B..256-B rows), the first-order weights and
+//                   the numeric columns of the tile into an LDS activation buffer; phase 2 runs the
+//                   model's small op list over LDS (fp32 MFMA 16x16x4 Dense layers with the weights
+//                   as the A operand so every epilogue store is a 16-B ds_write, FM sum-of-squares,
+//                   pairwise dots); phase 3 applies the output layer + sigmoid and stores one score
+//                   per sample.  Activations never leave the CU; HBM traffic is the algorithmic
+//                   minimum (ids + rows + numerics in, scores out).
+//   k_din_pool      DIN's activation unit + weighted sum pooling: the T history rows of a few samples
+//                   are gathered ONCE into LDS, the [h-c, h, c, h*c] -> Dense(hidden) contraction runs
+//                   on fp32 MFMA with the B operand built on the fly from LDS, PReLU/Dense(1)/sigmoid
+//                   finish in registers + two cross-lane adds, and the pooled vector is reduced from
+//                   the same LDS rows.
+//
+// Reference constructs each piece replaces are cited in include/sparrow_hip.h.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "sparrow_hip.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                      \
+    do {                                                                                   \
+        hipError_t e_ = (expr);                                                            \
+        if (e_ != hipSuccess) return fail(SPRK_EHIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// device-side plan (slots resolved to pointers); lives in device memory, read through scalar loads
+// ---------------------------------------------------------------------------------------------
+struct DevSeg {
+    int kind, field, field2, row_stride, count, dst, vocab, pad_;
+    const float* table;
+};
+struct DevOp {
+    int kind, src_buf, src_off, K, dst_buf, dst_off, N, ldw, act, groups, group_stride, pad_;
+    const float* W;
+    const float* bias;
+    const float* alpha;
+};
+struct DevTap {
+    int buf, off, len, pad_;
+    float scale, bias;
+    const float* w;
+};
+struct DevDin {
+    int enabled, T, hist_col, cand_col, row_stride, vocab, hidden, pad_;
+    float b2;
+    float pad2_;
+    const float* table;
+    const float* W;      // [hidden][4*row_stride]
+    const float* bias;   // [hidden]
+    const float* alpha;  // [T][hidden]
+    const float* w2;     // [hidden]
+};
+struct DevPlan {
+    int F, ND, NA, n_segs, n_ops, n_taps, n_pairs, n_bufs;
+    int buf_stride[SPRK_MAX_BUFS];
+    int buf_base[SPRK_MAX_BUFS];   // float offset of each buffer inside dynamic LDS
+    int pad_[2];
+    float head_bias;
+    float pad2_;
+    int pair_a[SPRK_MAX_PAIRS];
+    int pair_b[SPRK_MAX_PAIRS];
+    DevSeg segs[SPRK_MAX_SEGS];
+    DevOp ops[SPRK_MAX_OPS];
+    DevTap taps[SPRK_MAX_TAPS];
+    DevDin din;
+};
+
+// ---------------------------------------------------------------------------------------------
+// FingerprintCat64 chain of tf.feature_column.crossed_column (WideNDeep.py:72-73)
+// ---------------------------------------------------------------------------------------------
+__host__ __device__ __forceinline__ uint64_t shift_mix(uint64_t v) { return v ^ (v >> 47); }
+__host__ __device__ __forceinline__ uint64_t fingerprint_cat64(uint64_t fp1, uint64_t fp2) {
+    const uint64_t kMul = 0xc6a4a7935bd1e995ULL;
+    uint64_t result = fp1 ^ kMul;
+    result ^= shift_mix(fp2 * kMul) * kMul;
+    result *= kMul;
+    result = shift_mix(result) * kMul;
+    result = shift_mix(result);
+    return result;
+}
+__host__ __device__ __forceinline__ uint64_t cross_bucket(int a, int b, uint64_t buckets) {
+    uint64_t h = 0xDECAFCAFFEULL;
+    h = fingerprint_cat64(h, (uint64_t)(int64_t)a);
+    h = fingerprint_cat64(h, (uint64_t)(int64_t)b);
+    return h % buckets;
+}
+
+__device__ __forceinline__ float sigmoidf_acc(float z) {
+    // 1/(1+exp(-z)); expf overflow -> inf -> 0, no NaN for finite z
+    return 1.0f / (1.0f + expf(-z));
+}
+
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+
+__device__ __forceinline__ f32x4 mfma4(f32x4 a, f32x4 b, f32x4 c) {
+    // four K-steps of v_mfma_f32_16x16x4_f32; lane (r = lane&15, q = lane>>4) feeds k = 4q+s at step s
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, c, 0, 0, 0);
+    return c;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Dense layer on one wave: output block rows n = nb*16.., sample sub-tiles mi0..mi0+MI-1
+//   D[n][m] = sum_k Wt[n][k] * X[m][k]   (A operand = W^T rows from global/L1, B operand = LDS rows)
+// C layout of 16x16x4: lane holds D[row = 4q + j][col = r], j = 0..3 -> four consecutive output
+// features of one sample -> one 16-B LDS store.
+// ---------------------------------------------------------------------------------------------
+template <int MI>
+__device__ __forceinline__ void dense_unit(const DevOp& op, const float* __restrict__ src, int sstride,
+                                           float* __restrict__ dst, int dstride, int nb, int mi0, int lane) {
+    const int r = lane & 15, q = lane >> 4;
+    const int K = op.K;
+    const float* wrow = op.W + (size_t)(nb * 16 + r) * op.ldw + 4 * q;
+    const float* xrow = src + (mi0 * 16 + r) * sstride + op.src_off + 4 * q;
+    f32x4 acc[MI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 a = (4 * q < K) ? ld4(wrow) : zero;
+    for (int k = 0; k < K; k += 16) {
+        const bool ok = (k + 4 * q) < K;
+        const bool okn = (k + 16 + 4 * q) < K;
+        const f32x4 an = okn ? ld4(wrow + k + 16) : zero;   // prefetch next W fragment
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const f32x4 b = ok ? ld4(xrow + i * 16 * sstride + k) : zero;
+            acc[i] = mfma4(a, b, acc[i]);
+        }
+        a = an;
+    }
+    const int n = nb * 16 + 4 * q;
+    f32x4 bias = ld4(op.bias + n);
+    f32x4 alpha = zero;
+    if (op.act == SPRK_ACT_PRELU) alpha = ld4(op.alpha + n);
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        f32x4 v = acc[i] + bias;
+        if (op.act == SPRK_ACT_RELU) {
+            v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        } else if (op.act == SPRK_ACT_PRELU) {
+            v.x = fmaxf(v.x, 0.f) + alpha.x * fminf(v.x, 0.f);
+            v.y = fmaxf(v.y, 0.f) + alpha.y * fminf(v.y, 0.f);
+            v.z = fmaxf(v.z, 0.f) + alpha.z * fminf(v.z, 0.f);
+            v.w = fmaxf(v.w, 0.f) + alpha.w * fminf(v.w, 0.f);
+        }
+        st4(dst + ((mi0 + i) * 16 + r) * dstride + op.dst_off + n, v);
+    }
+}
+
+__device__ __forceinline__ void run_dense(const DevOp& op, const float* src, int sstride, float* dst,
+                                          int dstride, int wave, int lane) {
+    const int NB = op.N >> 4;
+    if (NB >= 3) {
+        for (int nb = wave; nb < NB; nb += 4) dense_unit<4>(op, src, sstride, dst, dstride, nb, 0, lane);
+    } else if (NB == 2) {
+        dense_unit<2>(op, src, sstride, dst, dstride, wave >> 1, (wave & 1) * 2, lane);
+    } else {
+        dense_unit<1>(op, src, sstride, dst, dstride, 0, wave, lane);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_tile_forward
+// ---------------------------------------------------------------------------------------------
+extern __shared__ __attribute__((aligned(16))) float smem[];
+
+__global__ __launch_bounds__(256) void k_tile_forward(const DevPlan* __restrict__ P,
+                                                      const int* __restrict__ ids,
+                                                      const float* __restrict__ dense,
+                                                      const float* __restrict__ aux,
+                                                      float* __restrict__ out, int B,
+                                                      int* __restrict__ err) {
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int F = P->F, ND = P->ND, NA = P->NA;
+    float* buf0 = smem + P->buf_base[0];
+    const int stride0 = P->buf_stride[0];
+    const int ntiles = (B + SPRK_TILE_M - 1) / SPRK_TILE_M;
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int m0 = tile * SPRK_TILE_M;
+        const int mvalid = min(SPRK_TILE_M, B - m0);
+
+        // ---------------- phase 1: gather the tile into LDS buffer 0 ----------------
+        const int n_segs = P->n_segs;
+        for (int s = 0; s < n_segs; ++s) {
+            const DevSeg& sg = P->segs[s];
+            const int kind = sg.kind;
+            if (kind == SPRK_SEG_ROWS || kind == SPRK_SEG_CROSS_ROWS) {
+                const int nvec = sg.count;
+                const int total = SPRK_TILE_M * nvec;
+                for (int idx = tid; idx < total; idx += 256) {
+                    const int m = idx / nvec;
+                    const int c = idx - m * nvec;
+                    f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (m < mvalid) {
+                        const int* idrow = ids + (size_t)(m0 + m) * F;
+                        long long row;
+                        if (kind == SPRK_SEG_ROWS) {
+                            const int id = idrow[sg.field];
+                            row = id;
+                            if ((unsigned)id >= (unsigned)sg.vocab) {
+                                row = -1;
+                                if (id != -1) atomicOr(err, 1);
+                            }
+                        } else {
+                            const int a = idrow[sg.field], b = idrow[sg.field2];
+                            row = (long long)cross_bucket(a, b, (uint64_t)sg.vocab);
+                        }
+                        if (row >= 0) v = ld4(sg.table + (size_t)row * sg.row_stride + 4 * c);
+                    }
+                    st4(buf0 + m * stride0 + sg.dst + 4 * c, v);
+                }
+            } else if (kind == SPRK_SEG_SCALAR || kind == SPRK_SEG_CROSS_SCALAR) {
+                if (tid < SPRK_TILE_M) {
+                    const int m = tid;
+                    float v = 0.f;
+                    if (m < mvalid) {
+                        const int* idrow = ids + (size_t)(m0 + m) * F;
+                        if (kind == SPRK_SEG_SCALAR) {
+                            const int id = idrow[sg.field];
+                            if ((unsigned)id < (unsigned)sg.vocab) v = sg.table[id];
+                            else if (id != -1) atomicOr(err, 1);
+                        } else {
+                            const int a = idrow[sg.field], b = idrow[sg.field2];
+                            v = sg.table[cross_bucket(a, b, (uint64_t)sg.vocab)];
+                        }
+                    }
+                    buf0[m * stride0 + sg.dst] = v;
+                }
+            } else if (kind == SPRK_SEG_DENSE || kind == SPRK_SEG_AUX) {
+                const int cnt = sg.count;
+                const int total = SPRK_TILE_M * cnt;
+                const float* base = (kind == SPRK_SEG_DENSE) ? dense : aux;
+                const int rw = (kind == SPRK_SEG_DENSE) ? ND : NA;
+                for (int idx = tid; idx < total; idx += 256) {
+                    const int m = idx / cnt;
+                    const int j = idx - m * cnt;
+                    float v = 0.f;
+                    if (m < mvalid) v = base[(size_t)(m0 + m) * rw + sg.field + j];
+                    buf0[m * stride0 + sg.dst + j] = v;
+                }
+            } else {  // SPRK_SEG_ZERO
+                const int cnt = sg.count;
+                const int total = SPRK_TILE_M * cnt;
+                for (int idx = tid; idx < total; idx += 256) {
+                    const int m = idx / cnt;
+                    const int j = idx - m * cnt;
+                    buf0[m * stride0 + sg.dst + j] = 0.f;
+                }
+            }
+        }
+        __syncthreads();
+
+        // ---------------- phase 2: op list over LDS ----------------
+        const int n_ops = P->n_ops;
+        for (int o = 0; o < n_ops; ++o) {
+            const DevOp& op = P->ops[o];
+            const float* src = smem + P->buf_base[op.src_buf];
+            const int sstride = P->buf_stride[op.src_buf];
+            float* dst = smem + P->buf_base[op.dst_buf];
+            const int dstride = P->buf_stride[op.dst_buf];
+            if (op.kind == SPRK_OP_DENSE) {
+                run_dense(op, src, sstride, dst, dstride, wave, lane);
+            } else if (op.kind == SPRK_OP_FM_SUMSQ) {
+                const int K = op.K;
+                const int total = SPRK_TILE_M * K;
+                for (int idx = tid; idx < total; idx += 256) {
+                    const int m = idx / K;
+                    const int j = idx - m * K;
+                    const float* p = src + m * sstride + op.src_off + j;
+                    float s = 0.f, sq = 0.f;
+                    for (int g = 0; g < op.groups; ++g) {
+                        const float v = p[g * op.group_stride];
+                        s += v;
+                        sq += v * v;
+                    }
+                    dst[m * dstride + op.dst_off + j] = s * s - sq;
+                }
+            } else {  // SPRK_OP_PAIR_DOT
+                const int np = P->n_pairs;
+                const int total = SPRK_TILE_M * np;
+                for (int idx = tid; idx < total; idx += 256) {
+                    const int m = idx / np;
+                    const int p = idx - m * np;
+                    const float* xa = src + m * sstride + P->pair_a[p];
+                    const float* xb = src + m * sstride + P->pair_b[p];
+                    float s = 0.f;
+                    for (int d = 0; d < op.K; d += 4) {
+                        const f32x4 va = ld4(xa + d), vb = ld4(xb + d);
+                        s += va.x * vb.x; s += va.y * vb.y; s += va.z * vb.z; s += va.w * vb.w;
+                    }
+                    dst[m * dstride + op.dst_off + p] = s;
+                }
+            }
+            __syncthreads();
+        }
+
+        // ---------------- phase 3: output layer + sigmoid (4 lanes per sample) ----------------
+        {
+            const int m = tid >> 2, part = tid & 3;
+            float z = 0.f;
+            const int n_taps = P->n_taps;
+            for (int t = 0; t < n_taps; ++t) {
+                const DevTap& tp = P->taps[t];
+                const float* x = smem + P->buf_base[tp.buf] + m * P->buf_stride[tp.buf] + tp.off;
+                float s = 0.f;
+                if (tp.w) {
+                    for (int j = part; j < tp.len; j += 4) s += tp.w[j] * x[j];
+                } else {
+                    for (int j = part; j < tp.len; j += 4) s += x[j];
+                }
+                if (part == 0) s += tp.bias;
+                z += tp.scale * s;
+            }
+            z += __shfl_xor(z, 1);
+            z += __shfl_xor(z, 2);
+            if (part == 0 && m < mvalid) out[m0 + m] = sigmoidf_acc(z + P->head_bias);
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_din_pool: DIN activation unit + weighted sum pooling (DIN.py:132-158)
+//   LDS: Hs[rows][hs] history rows, Cs[MS][hs] candidate rows, Ws[rows] attention weights
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_din_pool(const DevPlan* __restrict__ P, const int* __restrict__ ids,
+                                                  float* __restrict__ pooled, float* __restrict__ att,
+                                                  int B, int MS, int* __restrict__ err) {
+    const DevDin& dn = P->din;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int T = dn.T, F = P->F, Dp = dn.row_stride, nvec = Dp >> 2, hs = Dp + 4;
+    const int hidden = dn.hidden;
+    const int rows_cap = MS * T;
+    float* Hs = smem;
+    float* Cs = Hs + (size_t)rows_cap * hs;
+    float* Ws = Cs + (size_t)MS * hs;
+    const int r = lane & 15, q = lane >> 4;
+    const int K = 4 * Dp;
+    const int nchunks = (B + MS - 1) / MS;
+    const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+        const int s0 = chunk * MS;
+        const int ms = min(MS, B - s0);
+        const int nrows = ms * T;
+
+        // ---- phase 1: gather history + candidate rows into LDS (each row read from HBM once) ----
+        for (int idx = tid; idx < nrows * nvec; idx += 256) {
+            const int row = idx / nvec;
+            const int c = idx - row * nvec;
+            const int m = row / T;
+            const int t = row - m * T;
+            const int id = ids[(size_t)(s0 + m) * F + dn.hist_col + t];
+            f32x4 v = zero;
+            if ((unsigned)id < (unsigned)dn.vocab) v = ld4(dn.table + (size_t)id * Dp + 4 * c);
+            else atomicOr(err, 1);
+            st4(Hs + row * hs + 4 * c, v);
+        }
+        for (int idx = tid; idx < ms * nvec; idx += 256) {
+            const int m = idx / nvec;
+            const int c = idx - m * nvec;
+            const int id = ids[(size_t)(s0 + m) * F + dn.cand_col];
+            f32x4 v = zero;
+            if ((unsigned)id < (unsigned)dn.vocab) v = ld4(dn.table + (size_t)id * Dp + 4 * c);
+            else atomicOr(err, 1);
+            st4(Cs + m * hs + 4 * c, v);
+        }
+        __syncthreads();
+
+        // ---- phase 2: attention logits on fp32 MFMA, 16 (sample, slot) rows per step ----
+        const int ngroups = (nrows + 15) >> 4;
+        for (int g = wave; g < ngroups; g += 4) {
+            const int row = g * 16 + r;
+            const bool valid = row < nrows;
+            const int rowc = valid ? row : 0;
+            const int m = rowc / T;
+            const int t = rowc - m * T;
+            const float* hrow = Hs + rowc * hs;
+            const float* crow = Cs + m * hs;
+            float sum = 0.f;
+            for (int nb0 = 0; nb0 < (hidden >> 4); nb0 += 2) {
+                const bool two = (nb0 + 1) < (hidden >> 4);
+                f32x4 acc0 = zero, acc1 = zero;
+                const float* w0 = dn.W + (size_t)(nb0 * 16 + r) * K + 4 * q;
+                const float* w1 = w0 + (size_t)16 * K;
+                for (int k = 0; k < K; k += 16) {
+                    const int kk = k + 4 * q;
+                    const bool ok = kk < K;
+                    f32x4 b = zero, a0 = zero, a1 = zero;
+                    if (ok) {
+                        const int blk = kk / Dp;
+                        const int d = kk - blk * Dp;
+                        const f32x4 hv = ld4(hrow + d), cv = ld4(crow + d);
+                        b = (blk == 0) ? (hv - cv) : (blk == 1) ? hv : (blk == 2) ? cv : (hv * cv);
+                        if (!valid) b = zero;
+                        a0 = ld4(w0 + k);
+                        if (two) a1 = ld4(w1 + k);
+                    }
+                    acc0 = mfma4(a0, b, acc0);
+                    if (two) acc1 = mfma4(a1, b, acc1);
+                }
+                // epilogue: + bias, PReLU(alpha[t][n]), dot with att1 kernel
+                {
+                    const int n = nb0 * 16 + 4 * q;
+                    const f32x4 bias = ld4(dn.bias + n), al = ld4(dn.alpha + (size_t)t * hidden + n), w2 = ld4(dn.w2 + n);
+                    f32x4 u = acc0 + bias;
+                    sum += w2.x * (fmaxf(u.x, 0.f) + al.x * fminf(u.x, 0.f));
+                    sum += w2.y * (fmaxf(u.y, 0.f) + al.y * fminf(u.y, 0.f));
+                    sum += w2.z * (fmaxf(u.z, 0.f) + al.z * fminf(u.z, 0.f));
+                    sum += w2.w * (fmaxf(u.w, 0.f) + al.w * fminf(u.w, 0.f));
+                }
+                if (two) {
+                    const int n = (nb0 + 1) * 16 + 4 * q;
+                    const f32x4 bias = ld4(dn.bias + n), al = ld4(dn.alpha + (size_t)t * hidden + n), w2 = ld4(dn.w2 + n);
+                    f32x4 u = acc1 + bias;
+                    sum += w2.x * (fmaxf(u.x, 0.f) + al.x * fminf(u.x, 0.f));
+                    sum += w2.y * (fmaxf(u.y, 0.f) + al.y * fminf(u.y, 0.f));
+                    sum += w2.z * (fmaxf(u.z, 0.f) + al.z * fminf(u.z, 0.f));
+                    sum += w2.w * (fmaxf(u.w, 0.f) + al.w * fminf(u.w, 0.f));
+                }
+            }
+            sum += __shfl_xor(sum, 16);
+            sum += __shfl_xor(sum, 32);
+            if (q == 0 && valid) {
+                const float wgt = sigmoidf_acc(sum + dn.b2);
+                Ws[row] = wgt;
+                if (att) att[(size_t)(s0 + m) * T + t] = wgt;
+            }
+        }
+        __syncthreads();
+
+        // ---- phase 3: pooled[m] = sum_t w[m,t] * h[m,t,:]  (t ascending, as the reference sums) ----
+        for (int idx = tid; idx < ms * nvec; idx += 256) {
+            const int m = idx / nvec;
+            const int c = idx - m * nvec;
+            f32x4 acc = zero;
+            const float* hp = Hs + (size_t)m * T * hs + 4 * c;
+            const float* wp = Ws + m * T;
+            for (int t = 0; t < T; ++t) {
+                const float w = wp[t];
+                acc += w * ld4(hp + t * hs);
+            }
+            st4(pooled + (size_t)(s0 + m) * Dp + 4 * c, acc);
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// stand-alone operators
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_embedding_gather(const float* __restrict__ table, int V, int nvec,
+                                                          int row_stride, const int* __restrict__ ids, int B,
+                                                          float* __restrict__ out) {
+    const long long total = (long long)B * nvec;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const int b = (int)(idx / nvec);
+        const int c = (int)(idx - (long long)b * nvec);
+        const int id = ids[b];
+        f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+        if ((unsigned)id < (unsigned)V) v = ld4(table + (size_t)id * row_stride + 4 * c);
+        st4(out + (size_t)b * nvec * 4 + 4 * c, v);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_cross_hash(const int* __restrict__ a, const int* __restrict__ b, int B,
+                                                    unsigned long long buckets, long long* __restrict__ out) {
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < B; i += gridDim.x * 256)
+        out[i] = (long long)cross_bucket(a[i], b[i], buckets);
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+struct sprk_engine {
+    sprk_plan plan;
+    std::vector<void*> slot_ptr;
+    std::vector<size_t> slot_bytes;
+    DevPlan* dev_plan = nullptr;
+    int* dev_err = nullptr;
+    bool finalized = false;
+    int device = 0;
+    int num_cus = 256;
+    int buf_stride[SPRK_MAX_BUFS] = {0, 0, 0};
+    int buf_base[SPRK_MAX_BUFS] = {0, 0, 0};
+    size_t tile_lds_bytes = 0;
+    int tile_grid_cap = 0;
+    // DIN launch geometry
+    int din_ms = 0;
+    size_t din_lds_bytes = 0;
+    int din_grid_cap = 0;
+};
+
+namespace {
+
+int lds_stride(int width) {
+    // floats per sample row in LDS: multiple of 4 with (stride/4) odd, so the 16-B slots of the 16
+    // rows a ds_read_b128 lane group touches spread over the 256-B bank row
+    int s = (width + 3) & ~3;
+    if (((s >> 2) & 1) == 0) s += 4;
+    return s;
+}
+
+int check_slot(const sprk_plan& p, int slot, bool allow_none, const char* what) {
+    if (slot == -1 && allow_none) return 0;
+    if (slot < 0 || slot >= p.n_slots) return fail(SPRK_EINVAL, "%s: slot %d outside [0,%d)", what, slot, p.n_slots);
+    return 0;
+}
+
+int validate_plan(const sprk_plan& p) {
+    if (p.abi_version != SPRK_ABI_VERSION) return fail(SPRK_EINVAL, "plan abi_version %d != %d", p.abi_version, SPRK_ABI_VERSION);
+    if (p.n_id_cols < 0 || p.n_dense < 0 || p.n_aux < 0) return fail(SPRK_EINVAL, "negative column count");
+    if (p.n_bufs < 1 || p.n_bufs > SPRK_MAX_BUFS) return fail(SPRK_EINVAL, "n_bufs %d outside [1,%d]", p.n_bufs, SPRK_MAX_BUFS);
+    if (p.n_segs < 0 || p.n_segs > SPRK_MAX_SEGS) return fail(SPRK_EINVAL, "n_segs %d too large", p.n_segs);
+    if (p.n_ops < 0 || p.n_ops > SPRK_MAX_OPS) return fail(SPRK_EINVAL, "n_ops %d too large", p.n_ops);
+    if (p.n_taps < 0 || p.n_taps > SPRK_MAX_TAPS) return fail(SPRK_EINVAL, "n_taps %d too large", p.n_taps);
+    if (p.n_pairs < 0 || p.n_pairs > SPRK_MAX_PAIRS) return fail(SPRK_EINVAL, "n_pairs %d too large", p.n_pairs);
+    if (p.n_slots < 0 || p.n_slots > 4096) return fail(SPRK_EINVAL, "n_slots %d out of range", p.n_slots);
+    for (int b = 0; b < p.n_bufs; ++b)
+        if (p.buf_width[b] <= 0 || (p.buf_width[b] & 3)) return fail(SPRK_EINVAL, "buf_width[%d]=%d must be a positive multiple of 4", b, p.buf_width[b]);
+    for (int i = 0; i < p.n_segs; ++i) {
+        const sprk_seg& s = p.segs[i];
+        int width = 0;
+        switch (s.kind) {
+            case SPRK_SEG_ROWS:
+            case SPRK_SEG_CROSS_ROWS:
+                if (check_slot(p, s.slot, false, "segment table")) return SPRK_EINVAL;
+                if (s.row_stride <= 0 || (s.row_stride & 3) || s.count <= 0 || 4 * s.count > s.row_stride || (s.dst & 3))
+                    return fail(SPRK_EINVAL, "segment %d: bad row geometry (row_stride %d, count %d, dst %d)", i, s.row_stride, s.count, s.dst);
+                width = 4 * s.count;
+                break;
+            case SPRK_SEG_SCALAR:
+            case SPRK_SEG_CROSS_SCALAR:
+                if (check_slot(p, s.slot, false, "segment table")) return SPRK_EINVAL;
+                width = 1;
+                break;
+            case SPRK_SEG_DENSE:
+                if (s.count <= 0 || s.field < 0 || s.field + s.count > p.n_dense) return fail(SPRK_EINVAL, "segment %d: dense columns out of range", i);
+                width = s.count;
+                break;
+            case SPRK_SEG_AUX:
+                if (s.count <= 0 || s.field < 0 || s.field + s.count > p.n_aux) return fail(SPRK_EINVAL, "segment %d: aux columns out of range", i);
+                width = s.count;
+                break;
+            case SPRK_SEG_ZERO:
+                if (s.count <= 0) return fail(SPRK_EINVAL, "segment %d: empty zero fill", i);
+                width = s.count;
+                break;
+            default:
+                return fail(SPRK_EINVAL, "segment %d: unknown kind %d", i, s.kind);
+        }
+        if (s.kind == SPRK_SEG_ROWS || s.kind == SPRK_SEG_SCALAR) {
+            if (s.field < 0 || s.field >= p.n_id_cols) return fail(SPRK_EINVAL, "segment %d: ids column %d out of range", i, s.field);
+            if (s.vocab <= 0) return fail(SPRK_EINVAL, "segment %d: vocab must be positive", i);
+        }
+        if (s.kind == SPRK_SEG_CROSS_ROWS || s.kind == SPRK_SEG_CROSS_SCALAR) {
+            if (s.field < 0 || s.field >= p.n_id_cols || s.field2 < 0 || s.field2 >= p.n_id_cols)
+                return fail(SPRK_EINVAL, "segment %d: cross ids columns out of range", i);
+            if (s.vocab <= 0) return fail(SPRK_EINVAL, "segment %d: bucket count must be positive", i);
+        }
+        if (s.dst < 0 || s.dst + width > p.buf_width[0]) return fail(SPRK_EINVAL, "segment %d: writes [%d,%d) outside buffer 0 (width %d)", i, s.dst, s.dst + width, p.buf_width[0]);
+    }
+    for (int i = 0; i < p.n_ops; ++i) {
+        const sprk_op& o = p.ops[i];
+        if (o.src_buf < 0 || o.src_buf >= p.n_bufs || o.dst_buf < 0 || o.dst_buf >= p.n_bufs) return fail(SPRK_EINVAL, "op %d: buffer index out of range", i);
+        if (o.kind == SPRK_OP_DENSE) {
+            if (o.src_buf == o.dst_buf) return fail(SPRK_EINVAL, "op %d: Dense must not run in place", i);
+            if (o.K <= 0 || (o.K & 3) || o.N <= 0 || (o.N & 15) || o.ldw < o.K || (o.ldw & 3)) return fail(SPRK_EINVAL, "op %d: bad Dense geometry K=%d N=%d ldw=%d", i, o.K, o.N, o.ldw);
+            if ((o.src_off & 3) || (o.dst_off & 3)) return fail(SPRK_EINVAL, "op %d: offsets must be multiples of 4", i);
+            if (o.src_off < 0 || o.src_off + o.K > p.buf_width[o.src_buf] || o.dst_off < 0 || o.dst_off + o.N > p.buf_width[o.dst_buf]) return fail(SPRK_EINVAL, "op %d: Dense slice outside its buffer", i);
+            if (check_slot(p, o.w_slot, false, "Dense kernel") || check_slot(p, o.b_slot, false, "Dense bias")) return SPRK_EINVAL;
+            if (o.act == SPRK_ACT_PRELU && check_slot(p, o.alpha_slot, false, "PReLU alpha")) return SPRK_EINVAL;
+            if (o.act < 0 || o.act > SPRK_ACT_PRELU) return fail(SPRK_EINVAL, "op %d: unknown activation", i);
+        } else if (o.kind == SPRK_OP_FM_SUMSQ) {
+            if (o.K <= 0 || o.groups <= 0 || o.group_stride < o.K) return fail(SPRK_EINVAL, "op %d: bad FM geometry", i);
+            if (o.src_off < 0 || o.src_off + (o.groups - 1) * o.group_stride + o.K > p.buf_width[o.src_buf] || o.dst_off < 0 || o.dst_off + o.K > p.buf_width[o.dst_buf]) return fail(SPRK_EINVAL, "op %d: FM slice outside its buffer", i);
+            if (o.src_buf == o.dst_buf && o.dst_off < o.src_off + (o.groups - 1) * o.group_stride + o.K && o.dst_off + o.K > o.src_off) return fail(SPRK_EINVAL, "op %d: FM output overlaps its input", i);
+        } else if (o.kind == SPRK_OP_PAIR_DOT) {
+            if (o.K <= 0 || (o.K & 3) || p.n_pairs <= 0) return fail(SPRK_EINVAL, "op %d: bad pair-dot geometry", i);
+            for (int j = 0; j < p.n_pairs; ++j)
+                if (p.pair_a[j] < 0 || (p.pair_a[j] & 3) || p.pair_a[j] + o.K > p.buf_width[o.src_buf] || p.pair_b[j] < 0 || (p.pair_b[j] & 3) || p.pair_b[j] + o.K > p.buf_width[o.src_buf]) return fail(SPRK_EINVAL, "op %d: pair %d outside its buffer", i, j);
+            if (o.dst_off < 0 || o.dst_off + p.n_pairs > p.buf_width[o.dst_buf]) return fail(SPRK_EINVAL, "op %d: pair-dot output outside its buffer", i);
+        } else {
+            return fail(SPRK_EINVAL, "op %d: unknown kind %d", i, o.kind);
+        }
+    }
+    for (int i = 0; i < p.n_taps; ++i) {
+        const sprk_tap& t = p.taps[i];
+        if (t.buf < 0 || t.buf >= p.n_bufs || t.off < 0 || t.len <= 0 || t.off + t.len > p.buf_width[t.buf]) return fail(SPRK_EINVAL, "tap %d outside its buffer", i);
+        if (check_slot(p, t.w_slot, true, "tap weights")) return SPRK_EINVAL;
+    }
+    if (p.din.enabled) {
+        const sprk_din& d = p.din;
+        if (d.T <= 0 || d.T > 256) return fail(SPRK_EINVAL, "DIN history length %d outside [1,256]", d.T);
+        if (d.hist_col < 0 || d.hist_col + d.T > p.n_id_cols || d.cand_col < 0 || d.cand_col >= p.n_id_cols) return fail(SPRK_EINVAL, "DIN ids columns out of range");
+        if (d.row_stride <= 0 || (d.row_stride & 3) || d.vocab <= 0) return fail(SPRK_EINVAL, "DIN bad table geometry");
+        if (d.hidden <= 0 || (d.hidden & 15)) return fail(SPRK_EINVAL, "DIN hidden width must be a multiple of 16");
+        if (p.n_aux != d.row_stride) return fail(SPRK_EINVAL, "DIN: n_aux (%d) must equal row_stride (%d)", p.n_aux, d.row_stride);
+        if (check_slot(p, d.table_slot, false, "DIN table") || check_slot(p, d.w_slot, false, "DIN att0 kernel") || check_slot(p, d.b_slot, false, "DIN att0 bias") || check_slot(p, d.alpha_slot, false, "DIN alpha") || check_slot(p, d.w2_slot, false, "DIN att1 kernel")) return SPRK_EINVAL;
+    } else if (p.n_aux != 0) {
+        return fail(SPRK_EINVAL, "n_aux %d without a DIN stage", p.n_aux);
+    }
+    return SPRK_OK;
+}
+
+int need_bytes(const sprk_engine* h, int slot, size_t bytes, const char* what) {
+    if (!h->slot_ptr[slot]) return fail(SPRK_ESTATE, "%s: slot %d was never uploaded", what, slot);
+    if (h->slot_bytes[slot] < bytes) return fail(SPRK_EINVAL, "%s: slot %d holds %zu bytes, needs %zu", what, slot, h->slot_bytes[slot], bytes);
+    return SPRK_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* sprk_last_error(void) { return g_err.c_str(); }
+
+int sprk_runtime_info(int32_t info[4]) {
+    if (!info) return fail(SPRK_EINVAL, "info is NULL");
+    info[0] = SPRK_ABI_VERSION;
+    info[1] = info[2] = info[3] = 0;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); n = 0; }
+    info[1] = n;
+    if (n > 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) {
+            info[2] = prop.multiProcessorCount;
+            info[3] = strncmp(prop.gcnArchName, "gfx950", 6) == 0 ? 1 : 0;
+        }
+    }
+    return SPRK_OK;
+}
+
+int sprk_create(const sprk_plan* plan, sprk_handle* out) {
+    if (!plan || !out) return fail(SPRK_EINVAL, "plan/out is NULL");
+    *out = nullptr;
+    int rc = validate_plan(*plan);
+    if (rc) return rc;
+    sprk_engine* h = new (std::nothrow) sprk_engine();
+    if (!h) return fail(SPRK_EHIP, "out of host memory");
+    h->plan = *plan;
+    h->slot_ptr.assign(plan->n_slots, nullptr);
+    h->slot_bytes.assign(plan->n_slots, 0);
+    int off = 0;
+    for (int b = 0; b < plan->n_bufs; ++b) {
+        h->buf_stride[b] = lds_stride(plan->buf_width[b]);
+        h->buf_base[b] = off;
+        off += SPRK_TILE_M * h->buf_stride[b];
+    }
+    h->tile_lds_bytes = (size_t)off * sizeof(float);
+    if (h->tile_lds_bytes > 160 * 1024) {
+        size_t need = h->tile_lds_bytes;
+        delete h;
+        return fail(SPRK_EINVAL, "plan needs %zu bytes of LDS per tile (> 160 KiB)", need);
+    }
+    *out = h;
+    return SPRK_OK;
+}
+
+int sprk_upload(sprk_handle h, int32_t slot, const void* src, size_t bytes) {
+    if (!h || !src || bytes == 0) return fail(SPRK_EINVAL, "bad upload arguments");
+    if (slot < 0 || slot >= h->plan.n_slots) return fail(SPRK_EINVAL, "slot %d outside [0,%d)", slot, h->plan.n_slots);
+    if (h->finalized) return fail(SPRK_ESTATE, "upload after finalize");
+    if (h->slot_ptr[slot]) { (void)hipFree(h->slot_ptr[slot]); h->slot_ptr[slot] = nullptr; }
+    // 16 spare bytes so a float4 tail read of a [len]-float vector never leaves the allocation
+    HIP_TRY(hipMalloc(&h->slot_ptr[slot], bytes + 16));
+    HIP_TRY(hipMemset(h->slot_ptr[slot], 0, bytes + 16));
+    HIP_TRY(hipMemcpy(h->slot_ptr[slot], src, bytes, hipMemcpyDefault));
+    h->slot_bytes[slot] = bytes;
+    return SPRK_OK;
+}
+
+int sprk_finalize(sprk_handle h) {
+    if (!h) return fail(SPRK_EINVAL, "handle is NULL");
+    if (h->finalized) return SPRK_OK;
+    const sprk_plan& p = h->plan;
+    DevPlan* dp = new (std::nothrow) DevPlan();
+    if (!dp) return fail(SPRK_EHIP, "out of host memory");
+    memset(dp, 0, sizeof(DevPlan));
+    struct Guard { DevPlan* p; ~Guard() { delete p; } } guard{dp};
+    dp->F = p.n_id_cols; dp->ND = p.n_dense; dp->NA = p.n_aux;
+    dp->n_segs = p.n_segs; dp->n_ops = p.n_ops; dp->n_taps = p.n_taps; dp->n_pairs = p.n_pairs; dp->n_bufs = p.n_bufs;
+    dp->head_bias = p.head_bias;
+    for (int b = 0; b < SPRK_MAX_BUFS; ++b) { dp->buf_stride[b] = h->buf_stride[b]; dp->buf_base[b] = h->buf_base[b]; }
+    for (int i = 0; i < p.n_pairs; ++i) { dp->pair_a[i] = p.pair_a[i]; dp->pair_b[i] = p.pair_b[i]; }
+    int rc;
+    for (int i = 0; i < p.n_segs; ++i) {
+        const sprk_seg& s = p.segs[i];
+        DevSeg& d = dp->segs[i];
+        d.kind = s.kind; d.field = s.field; d.field2 = s.field2; d.row_stride = s.row_stride; d.count = s.count; d.dst = s.dst; d.vocab = s.vocab;
+        d.table = nullptr;
+        if (s.kind == SPRK_SEG_ROWS || s.kind == SPRK_SEG_CROSS_ROWS) {
+            if ((rc = need_bytes(h, s.slot, (size_t)s.vocab * s.row_stride * 4, "embedding table"))) return rc;
+            d.table = (const float*)h->slot_ptr[s.slot];
+        } else if (s.kind == SPRK_SEG_SCALAR || s.kind == SPRK_SEG_CROSS_SCALAR) {
+            if ((rc = need_bytes(h, s.slot, (size_t)s.vocab * 4, "first-order table"))) return rc;
+            d.table = (const float*)h->slot_ptr[s.slot];
+        }
+    }
+    for (int i = 0; i < p.n_ops; ++i) {
+        const sprk_op& o = p.ops[i];
+        DevOp& d = dp->ops[i];
+        d.kind = o.kind; d.src_buf = o.src_buf; d.src_off = o.src_off; d.K = o.K; d.dst_buf = o.dst_buf; d.dst_off = o.dst_off;
+        d.N = o.N; d.ldw = o.ldw; d.act = o.act; d.groups = o.groups; d.group_stride = o.group_stride;
+        if (o.kind == SPRK_OP_DENSE) {
+            if ((rc = need_bytes(h, o.w_slot, (size_t)o.N * o.ldw * 4, "Dense kernel"))) return rc;
+            if ((rc = need_bytes(h, o.b_slot, (size_t)o.N * 4, "Dense bias"))) return rc;
+            d.W = (const float*)h->slot_ptr[o.w_slot];
+            d.bias = (const float*)h->slot_ptr[o.b_slot];
+            if (o.act == SPRK_ACT_PRELU) {
+                if ((rc = need_bytes(h, o.alpha_slot, (size_t)o.N * 4, "PReLU alpha"))) return rc;
+                d.alpha = (const float*)h->slot_ptr[o.alpha_slot];
+            }
+        }
+    }
+    for (int i = 0; i < p.n_taps; ++i) {
+        const sprk_tap& t = p.taps[i];
+        DevTap& d = dp->taps[i];
+        d.buf = t.buf; d.off = t.off; d.len = t.len; d.scale = t.scale; d.bias = t.bias; d.w = nullptr;
+        if (t.w_slot >= 0) {
+            if ((rc = need_bytes(h, t.w_slot, (size_t)t.len * 4, "tap weights"))) return rc;
+            d.w = (const float*)h->slot_ptr[t.w_slot];
+        }
+    }
+    HIP_TRY(hipGetDevice(&h->device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, h->device));
+    h->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (p.din.enabled) {
+        const sprk_din& s = p.din;
+        DevDin& d = dp->din;
+        d.enabled = 1; d.T = s.T; d.hist_col = s.hist_col; d.cand_col = s.cand_col; d.row_stride = s.row_stride; d.vocab = s.vocab; d.hidden = s.hidden; d.b2 = s.b2;
+        if ((rc = need_bytes(h, s.table_slot, (size_t)s.vocab * s.row_stride * 4, "DIN table"))) return rc;
+        if ((rc = need_bytes(h, s.w_slot, (size_t)s.hidden * 4 * s.row_stride * 4, "DIN att0 kernel"))) return rc;
+        if ((rc = need_bytes(h, s.b_slot, (size_t)s.hidden * 4, "DIN att0 bias"))) return rc;
+        if ((rc = need_bytes(h, s.alpha_slot, (size_t)s.T * s.hidden * 4, "DIN alpha"))) return rc;
+        if ((rc = need_bytes(h, s.w2_slot, (size_t)s.hidden * 4, "DIN att1 kernel"))) return rc;
+        d.table = (const float*)h->slot_ptr[s.table_slot];
+        d.W = (const float*)h->slot_ptr[s.w_slot];
+        d.bias = (const float*)h->slot_ptr[s.b_slot];
+        d.alpha = (const float*)h->slot_ptr[s.alpha_slot];
+        d.w2 = (const float*)h->slot_ptr[s.w2_slot];
+        // samples per workgroup pass: about 256 (sample, slot) rows in LDS
+        int ms = 256 / s.T;
+        if (ms < 1) ms = 1;
+        if (ms > 64) ms = 64;
+        h->din_ms = ms;
+        const int hs = s.row_stride + 4;
+        h->din_lds_bytes = ((size_t)ms * s.T * hs + (size_t)ms * hs + (size_t)ms * s.T) * sizeof(float);
+        if (h->din_lds_bytes > 160 * 1024) return fail(SPRK_EINVAL, "DIN stage needs %zu bytes of LDS", h->din_lds_bytes);
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_din_pool), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->din_lds_bytes));
+        int per_cu = (int)(160 * 1024 / h->din_lds_bytes);
+        if (per_cu > 8) per_cu = 8;
+        if (per_cu < 1) per_cu = 1;
+        h->din_grid_cap = h->num_cus * per_cu;
+    }
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile_forward), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->tile_lds_bytes));
+    {
+        int per_cu = (int)(160 * 1024 / (h->tile_lds_bytes ? h->tile_lds_bytes : 1));
+        if (per_cu > 8) per_cu = 8;
+        if (per_cu < 1) per_cu = 1;
+        h->tile_grid_cap = h->num_cus * per_cu;
+    }
+    HIP_TRY(hipMalloc((void**)&h->dev_plan, sizeof(DevPlan)));
+    HIP_TRY(hipMemcpy(h->dev_plan, dp, sizeof(DevPlan), hipMemcpyHostToDevice));
+    HIP_TRY(hipMalloc((void**)&h->dev_err, sizeof(int)));
+    HIP_TRY(hipMemset(h->dev_err, 0, sizeof(int)));
+    h->finalized = true;
+    return SPRK_OK;
+}
+
+size_t sprk_workspace_bytes(sprk_handle h, int32_t B) {
+    if (!h || B <= 0 || !h->plan.din.enabled) return 0;
+    return (size_t)B * h->plan.n_aux * sizeof(float);
+}
+
+static int launch_din(sprk_handle h, const int32_t* ids, float* pooled, float* att, int32_t B, hipStream_t st) {
+    const int nchunks = (B + h->din_ms - 1) / h->din_ms;
+    const int grid = nchunks < h->din_grid_cap ? nchunks : h->din_grid_cap;
+    hipLaunchKernelGGL(k_din_pool, dim3(grid), dim3(256), h->din_lds_bytes, st, h->dev_plan, ids, pooled, att, B, h->din_ms, h->dev_err);
+    HIP_TRY(hipGetLastError());
+    return SPRK_OK;
+}
+
+int sprk_din_pool(sprk_handle h, const int32_t* ids, float* pooled, float* att, int32_t B, void* stream) {
+    if (!h || !ids || !pooled) return fail(SPRK_EINVAL, "NULL argument");
+    if (!h->finalized) return fail(SPRK_ESTATE, "din_pool before finalize");
+    if (!h->plan.din.enabled) return fail(SPRK_EKIND, "handle has no DIN stage");
+    if (B <= 0) return B == 0 ? SPRK_OK : fail(SPRK_EINVAL, "negative batch");
+    return launch_din(h, ids, pooled, att, B, (hipStream_t)stream);
+}
+
+int sprk_forward(sprk_handle h, const int32_t* ids, const float* dense, float* out, int32_t B,
+                 void* workspace, size_t workspace_bytes, void* stream) {
+    if (!h) return fail(SPRK_EINVAL, "handle is NULL");
+    if (!h->finalized) return fail(SPRK_ESTATE, "forward before finalize");
+    if (B < 0) return fail(SPRK_EINVAL, "negative batch");
+    if (B == 0) return SPRK_OK;
+    if (!out) return fail(SPRK_EINVAL, "out is NULL");
+    if (h->plan.n_id_cols > 0 && !ids) return fail(SPRK_EINVAL, "ids is NULL");
+    if (h->plan.n_dense > 0 && !dense) return fail(SPRK_EINVAL, "dense is NULL");
+    hipStream_t st = (hipStream_t)stream;
+    const float* aux = nullptr;
+    if (h->plan.din.enabled) {
+        const size_t need = sprk_workspace_bytes(h, B);
+        if (!workspace || workspace_bytes < need) return fail(SPRK_EINVAL, "workspace too small: %zu < %zu bytes", workspace_bytes, need);
+        int rc = launch_din(h, ids, (float*)workspace, nullptr, B, st);
+        if (rc) return rc;
+        aux = (const float*)workspace;
+    }
+    const int ntiles = (B + SPRK_TILE_M - 1) / SPRK_TILE_M;
+    const int grid = ntiles < h->tile_grid_cap ? ntiles : h->tile_grid_cap;
+    hipLaunchKernelGGL(k_tile_forward, dim3(grid), dim3(256), h->tile_lds_bytes, st, h->dev_plan, ids, dense, aux, out, B, h->dev_err);
+    HIP_TRY(hipGetLastError());
+    return SPRK_OK;
+}
+
+#define SPRK_FORWARD_KIND(name, kind)                                                                      \
+    int name(sprk_handle h, const int32_t* ids, const float* dense, float* out, int32_t B, void* ws,      \
+             size_t ws_bytes, void* stream) {                                                              \
+        if (!h) return fail(SPRK_EINVAL, "handle is NULL");                                                \
+        if (h->plan.model_kind != kind) return fail(SPRK_EKIND, #name ": handle holds model kind %d", h->plan.model_kind); \
+        return sprk_forward(h, ids, dense, out, B, ws, ws_bytes, stream);                                  \
+    }
+SPRK_FORWARD_KIND(sprk_forward_embedding_mlp, SPRK_MODEL_EMBEDDING_MLP)
+SPRK_FORWARD_KIND(sprk_forward_widedeep, SPRK_MODEL_WIDE_DEEP)
+SPRK_FORWARD_KIND(sprk_forward_neuralcf, SPRK_MODEL_NEURALCF)
+SPRK_FORWARD_KIND(sprk_forward_deepfm, SPRK_MODEL_DEEPFM)
+SPRK_FORWARD_KIND(sprk_forward_deepfm_v2, SPRK_MODEL_DEEPFM_V2)
+SPRK_FORWARD_KIND(sprk_forward_din, SPRK_MODEL_DIN)
+
+int sprk_check_ids(sprk_handle h, void* stream) {
+    if (!h) return fail(SPRK_EINVAL, "handle is NULL");
+    if (!h->finalized) return fail(SPRK_ESTATE, "check_ids before finalize");
+    int flag = 0;
+    HIP_TRY(hipMemcpyAsync(&flag, h->dev_err, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    if (flag) {
+        HIP_TRY(hipMemsetAsync(h->dev_err, 0, sizeof(int), (hipStream_t)stream));
+        HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+        return fail(SPRK_ERANGE, "an id was outside its table (TF would raise InvalidArgumentError: assert_less_than_num_buckets)");
+    }
+    return SPRK_OK;
+}
+
+void sprk_destroy(sprk_handle h) {
+    if (!h) return;
+    for (void* p : h->slot_ptr)
+        if (p) (void)hipFree(p);
+    if (h->dev_plan) (void)hipFree(h->dev_plan);
+    if (h->dev_err) (void)hipFree(h->dev_err);
+    delete h;
+}
+
+int sprk_embedding_gather(const float* table, int32_t V, int32_t D, int32_t row_stride, const int32_t* ids,
+                          int32_t B, float* out, void* stream) {
+    if (!table || !ids || !out) return fail(SPRK_EINVAL, "NULL argument");
+    if (V <= 0 || D <= 0 || (D & 3) || row_stride < D || (row_stride & 3)) return fail(SPRK_EINVAL, "bad gather geometry V=%d D=%d row_stride=%d", V, D, row_stride);
+    if (B < 0) return fail(SPRK_EINVAL, "negative batch");
+    if (B == 0) return SPRK_OK;
+    const long long total = (long long)B * (D / 4);
+    long long blocks = (total + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(k_embedding_gather, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, table, V, D / 4, row_stride, ids, B, out);
+    HIP_TRY(hipGetLastError());
+    return SPRK_OK;
+}
+
+int sprk_cross_hash(const int32_t* a, const int32_t* b, int32_t B, int64_t num_buckets, int64_t* out, void* stream) {
+    if (!a || !b || !out) return fail(SPRK_EINVAL, "NULL argument");
+    if (num_buckets <= 0) return fail(SPRK_EINVAL, "num_buckets must be positive");
+    if (B < 0) return fail(SPRK_EINVAL, "negative batch");
+    if (B == 0) return SPRK_OK;
+    int blocks = (B + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_cross_hash, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, b, B, (unsigned long long)num_buckets, (long long*)out);
+    HIP_TRY(hipGetLastError());
+    return SPRK_OK;
+}
+
+}  // extern "C"

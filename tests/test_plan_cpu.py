@@ -1,0 +1,102 @@
+"""Host logic on CPU: every model's compiled plan, run by the numpy plan interpreter
+(tests/plan_interp.py), must reproduce the oracle -- this checks layouts, permutations, padding,
+first-order offsets and tap scales without a GPU."""
+import numpy as np
+import pytest
+
+from oracle import ctr_oracle as O
+from sparrowrecsys_amd import models as M
+from sparrowrecsys_amd import synthetic as SY
+from tests.golden.make_golden import SEEDS, make_model
+from tests.plan_interp import din_pool, run_plan
+
+
+@pytest.mark.parametrize("name", sorted(SEEDS))
+def test_reference_models_plan_matches_oracle(samples, name):
+    model = make_model(name)
+    plan, slots = model.build_plan()
+    ids, dense = model.pack(samples)
+    got = run_plan(plan, slots, ids, dense, np.float64)
+    ref = O.FORWARDS[name](samples, model.weights, dtype=np.float64)[:, 0]
+    np.testing.assert_allclose(got, ref, atol=2e-7)
+
+
+def test_config2_deepfm_v2_shape():
+    B = 2048
+    feats = SY.synth_fields(B, SY.CONFIG2_FIELDS, seed=3)
+    model = M.DeepFMv2(seed=21, emb_dim=16, fields=SY.CONFIG2_FIELDS, proj_dim=16)
+    plan, slots = model.build_plan()
+    ids, dense = model.pack(feats)
+    assert ids.shape == (B, 6) and (ids[:, 3:] == -1).any() and (ids[:, 2] == 0).any()
+    got = run_plan(plan, slots, ids, dense, np.float64)
+    ref = O.deepfm_v2_forward(feats, model.weights, dtype=np.float64, fields=SY.CONFIG2_FIELDS,
+                              order=[k for k, _, _ in SY.CONFIG2_FIELDS])[:, 0]
+    np.testing.assert_allclose(got, ref, atol=2e-7)
+    assert ref.std() > 0.02
+
+
+def test_config2_deepfm_pairs_shape():
+    B = 1024
+    feats = SY.synth_fields(B, SY.CONFIG2_FIELDS, seed=4, dist="zipf")
+    model = M.DeepFM(seed=22, emb_dim=16, fields=SY.CONFIG2_FIELDS, pairs=SY.CONFIG2_PAIRS)
+    plan, slots = model.build_plan()
+    ids, dense = model.pack(feats)
+    got = run_plan(plan, slots, ids, dense, np.float64)
+    ref = O.deepfm_forward(feats, model.weights, dtype=np.float64, fields=SY.CONFIG2_FIELDS, pairs=SY.CONFIG2_PAIRS)[:, 0]
+    np.testing.assert_allclose(got, ref, atol=2e-7)
+
+
+def test_config3_din_shape():
+    B, T, D = 256, 50, 32
+    feats = SY.synth_din(B, T, 5000, 7000, seed=5)
+    model = M.DIN(seed=23, emb_dim=D, hist_len=T, movie_buckets=5000, user_buckets=7000)
+    plan, slots = model.build_plan()
+    ids, dense = model.pack(feats)
+    assert ids.shape == (B, T + 4)
+    got = run_plan(plan, slots, ids, dense, np.float64)
+    ref, parts = O.din_forward(feats, model.weights, dtype=np.float64, hist_len=T, movie_buckets=5000,
+                               user_buckets=7000, return_parts=True)
+    np.testing.assert_allclose(got, ref[:, 0], atol=2e-7)
+    pooled, att = din_pool(plan, slots, ids, np.float64)
+    np.testing.assert_allclose(att, parts["att"], atol=1e-7)
+    np.testing.assert_allclose(pooled[:, :D], parts["pooled"], atol=1e-6)
+
+
+def test_config5_wide_deep_cross_embedding():
+    B = 512
+    feats = SY.synth_embedding_mlp(B, 3000, 4000, seed=6, rated_vocab=3000)
+    model = M.WideNDeep(seed=24, emb_dim=32, movie_buckets=3000, user_buckets=4000, cross_buckets=50000, cross_dim=32)
+    plan, slots = model.build_plan()
+    ids, dense = model.pack(feats)
+    got = run_plan(plan, slots, ids, dense, np.float64)
+    ref = O.wide_n_deep_forward(feats, model.weights, dtype=np.float64, movie_buckets=3000, user_buckets=4000,
+                                cross_buckets=50000, rated_buckets=3000)[:, 0]
+    np.testing.assert_allclose(got, ref, atol=2e-7)
+
+
+def test_config4_deepfm_d64():
+    B = 512
+    fields = [("movieId", "id", 3000), ("userId", "id", 90000), ("userGenre1", "genre", 19), ("movieGenre1", "genre", 19)]
+    feats = SY.synth_fields(B, fields, seed=7)
+    model = M.DeepFMv2(seed=25, emb_dim=64, fields=fields, proj_dim=16)
+    plan, slots = model.build_plan()
+    ids, dense = model.pack(feats)
+    got = run_plan(plan, slots, ids, dense, np.float64)
+    ref = O.deepfm_v2_forward(feats, model.weights, dtype=np.float64, fields=fields, order=[k for k, _, _ in fields])[:, 0]
+    np.testing.assert_allclose(got, ref, atol=2e-7)
+
+
+def test_weight_validation():
+    m = M.NeuralCF(seed=1)
+    w = dict(m.weights)
+    w["dense0/kernel"] = np.zeros((3, 3), np.float32)
+    with pytest.raises(ValueError):
+        m.set_weights(w)
+    del w["dense0/kernel"]
+    with pytest.raises(KeyError):
+        m.set_weights(w)
+
+
+def test_first_order_offsets_literal():
+    offs = M.first_order_offsets(M._default_fields())
+    assert (offs["movieGenre1"], offs["movieId"], offs["userGenre1"], offs["userId"], offs["__total__"]) == (0, 19, 1020, 1039, 31040)
