@@ -1,0 +1,253 @@
+#!/usr/bin/env python
+"""bench.py -- CTR samples/sec of the HIP forward on synthetic MovieLens-20M-shaped batches.
+
+    python bench.py --gpus N --steps K --warmup W [--workload NAME]
+
+One "step" = one pass of the hot path over one batch (ids + dense already resident in HBM ->
+scores in HBM); at N>1 every rank scores its own B-row shard (weak scaling: global batch N*B) and
+the step ends with the RCCL all-gather of the score vector.  Rank 0 prints ONE JSON line.
+
+Workloads (BASELINE.json configs):
+  deepfm_v2_c2 (default) configs[1]: DeepFM (sum-of-squares FM cross, DeepFM_v2 graph), 6 sparse
+               fields, emb_dim 16, projection width 16, B = 65 536 per GPU
+  deepfm_c2    the pairwise-dot DeepFM graph on the same fields
+  din_c3       configs[2]: DIN, hist_len 50, emb_dim 32, B = 32 768 per GPU
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK = 8.0e12          # B/s, MI355X spec (MI355X_MICROARCH.md)
+MFMA_F32_PEAK = 157.3e12   # FLOP/s, fp32-input MFMA
+
+
+def build_workload(name, B, dist_name, seed_offset=0):
+    from sparrowrecsys_amd import models as M, synthetic as SY
+    NB = 8   # distinct input batches cycled through, so steps do not re-read identical ids
+    if name in ("deepfm_v2_c2", "deepfm_c2"):
+        F, D = 6, 16
+        if name == "deepfm_v2_c2":
+            model = M.DeepFMv2(seed=101, emb_dim=D, fields=SY.CONFIG2_FIELDS, proj_dim=16)
+            desc = "DeepFM sum-of-squares FM (DeepFM_v2 graph), F=6 sparse fields, emb_dim=16, proj=16, deep 32-16"
+        else:
+            model = M.DeepFM(seed=101, emb_dim=D, fields=SY.CONFIG2_FIELDS, pairs=SY.CONFIG2_PAIRS)
+            desc = "DeepFM pairwise-dot FM (DeepFM graph), F=6 sparse fields, emb_dim=16, 8 pairs, deep 64-64"
+        feats = [SY.synth_fields(B, SY.CONFIG2_FIELDS, seed=SY.SEED + 1000 * seed_offset + i, dist=dist_name) for i in range(NB)]
+        # fused kernel: ids + embedding rows + first-order weights + numerics in, one score out
+        bytes_per_sample = F * 4 + F * D * 4 + F * 4 + 7 * 4 + 4
+        roof = {"bound": "hbm", "kernel": "k_tile_forward", "bytes_per_sample": bytes_per_sample}
+    elif name == "din_c3":
+        T, D = 50, 32
+        model = M.DIN(seed=103, emb_dim=D, hist_len=T, movie_buckets=SY.ML20M_MOVIE_IDS, user_buckets=SY.ML20M_USER_IDS)
+        desc = "DIN, hist_len=50, emb_dim=32, attention 128->32->1, tail 167->128->64->1"
+        feats = [SY.synth_din(B, T, SY.ML20M_MOVIE_IDS, SY.ML20M_USER_IDS, seed=SY.SEED + 1000 * seed_offset + i, dist=dist_name) for i in range(NB)]
+        flops = T * (2 * 4 * D * 32 + 2 * 32 + 3 * 32)
+        roof = {"bound": "mfma", "kernel": "k_din_pool", "flops_per_sample": flops,
+                "bytes_per_sample": (T + 1) * 4 + (T + 1) * D * 4 + D * 4}
+    else:
+        raise SystemExit("unknown workload %r" % name)
+    return model, feats, desc, roof
+
+
+def oracle_forward(name, model, feats):
+    from oracle import ctr_oracle as O
+    from sparrowrecsys_amd import synthetic as SY
+    if name == "deepfm_v2_c2":
+        return O.deepfm_v2_forward(feats, model.weights, dtype=np.float32, fields=SY.CONFIG2_FIELDS,
+                                   order=[k for k, _, _ in SY.CONFIG2_FIELDS])
+    if name == "deepfm_c2":
+        return O.deepfm_forward(feats, model.weights, dtype=np.float32, fields=SY.CONFIG2_FIELDS, pairs=SY.CONFIG2_PAIRS)
+    return O.din_forward(feats, model.weights, dtype=np.float32, hist_len=model.hist_len,
+                         movie_buckets=model.movie_buckets, user_buckets=model.user_buckets)
+
+
+def cpu_baseline(name, model, feats, budget_s):
+    """The numpy oracle ("port": TensorFlow is not installable) timed on this host's cores over a
+    bounded sample of the same workload."""
+    try:
+        from threadpoolctl import threadpool_info
+        cores = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+    except Exception:
+        cores = 1
+    f = feats[0]
+    n = len(next(iter(f.values())))
+    sample = min(n, 16384)
+    fs = {k: v[:sample] for k, v in f.items()}
+    oracle_forward(name, model, fs)                      # warm-up
+    t0 = time.perf_counter()
+    done = 0
+    while True:
+        oracle_forward(name, model, fs)
+        done += sample
+        el = time.perf_counter() - t0
+        if el >= budget_s or done >= 64 * sample:
+            break
+    return {"value": done / el, "unit": "samples/s", "cores": cores, "kind": "port",
+            "sample": "numpy oracle (CPU restatement; TensorFlow unavailable), %d passes of %d rows of the same synthetic batch, %.1f s"
+                      % (done // sample, sample, el),
+            "host_cpus": os.cpu_count()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--warmup", type=int, default=40)
+    ap.add_argument("--workload", default="deepfm_v2_c2")
+    ap.add_argument("--batch", type=int, default=0, help="rows per GPU (default: the config's batch)")
+    ap.add_argument("--dist", default="uniform", choices=["uniform", "zipf"], help="id distribution")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget (0 = skip)")
+    ap.add_argument("--no-check", action="store_true", help="skip the oracle spot check of the outputs")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs one process per GPU: launch with python -m torch.distributed.run "
+                             "--nproc-per-node %d ..." % (args.gpus, args.gpus))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    B = args.batch or (32768 if args.workload == "din_c3" else 65536)
+    model, feats, desc, roof = build_workload(args.workload, B, args.dist, seed_offset=rank)
+    eng = model.engine
+    batches = []
+    for f in feats:
+        ids, dense = model.pack(f)
+        batches.append((torch.from_numpy(ids).cuda(), torch.from_numpy(dense).cuda()))
+    NB = len(batches)
+    outs = [torch.empty(B, dtype=torch.float32, device="cuda") for _ in range(NB)]
+    ws = torch.empty(max(eng.workspace_bytes(B) // 4, 1), dtype=torch.float32, device="cuda")
+    gathered = torch.empty(B * world, dtype=torch.float32, device="cuda") if world > 1 else None
+
+    def step(i):
+        ids_t, dense_t = batches[i % NB]
+        out = outs[i % NB]
+        eng.forward(ids_t, dense_t, out, ws)
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, out)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    fence()
+    eng.check_ids()
+
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    fence()
+    t0 = time.perf_counter()
+    ev0.record()
+    for i in range(args.steps):
+        step(i)
+    ev1.record()
+    fence()
+    elapsed = time.perf_counter() - t0
+    ev_ms = ev0.elapsed_time(ev1)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # kernel time for the roofline: HIP events on the launch stream.  N=1: the timed region IS K
+    # back-to-back forward launches.  N>1: the region also holds the all-gathers, so the forward
+    # launches are re-timed alone right after it.
+    region = "timed region"
+    if world > 1:
+        region = "forward-only loop after the timed region"
+        torch.cuda.synchronize()
+        ev0.record()
+        for i in range(args.steps):
+            ids_t, dense_t = batches[i % NB]
+            eng.forward(ids_t, dense_t, outs[i % NB], ws)
+        ev1.record()
+        torch.cuda.synchronize()
+        ev_ms = ev0.elapsed_time(ev1)
+    fwd_s = ev_ms * 1e-3 / args.steps          # avg forward duration (all kernels of one step)
+
+    # output spot check against the oracle (outside the timed region)
+    check = None
+    if rank == 0 and not args.no_check:
+        n = 4096
+        got = outs[0][:n].cpu().numpy()
+        ref = oracle_forward(args.workload, model, {k: v[:n] for k, v in feats[0].items()})[:, 0]
+        check = float(np.abs(got - ref).max())
+        if not check <= 1e-4:
+            raise SystemExit("bench outputs differ from the oracle: max|err| = %g" % check)
+
+    if rank == 0:
+        value = B * world * args.steps / elapsed
+        din_s = None
+        if roof["bound"] == "hbm":
+            achieved = roof["bytes_per_sample"] * B / fwd_s / 1e9
+            rl = {"bound": "hbm", "kernel": roof["kernel"], "achieved": achieved, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                  "frac": achieved * 1e9 / HBM_PEAK, "algorithmic_bytes_per_sample": roof["bytes_per_sample"],
+                  "avg_launch_us": fwd_s * 1e6, "timed_with": "HIP events, " + region}
+        else:
+            # DIN step = k_din_pool + k_tile_forward; time the attention kernel alone for its MFMA fraction
+            pooled = torch.empty((B, eng.n_aux), dtype=torch.float32, device="cuda")
+            torch.cuda.synchronize()
+            ev0.record()
+            for i in range(args.steps):
+                eng.din_pool(batches[i % NB][0], pooled)
+            ev1.record()
+            torch.cuda.synchronize()
+            din_s = ev0.elapsed_time(ev1) * 1e-3 / args.steps
+            achieved = roof["flops_per_sample"] * B / din_s / 1e12
+            rl = {"bound": "mfma", "kernel": roof["kernel"], "achieved": achieved, "peak": MFMA_F32_PEAK / 1e12,
+                  "unit": "TFLOP/s", "frac": achieved * 1e12 / MFMA_F32_PEAK,
+                  "algorithmic_flops_per_sample": roof["flops_per_sample"],
+                  "algorithmic_bytes_per_sample": roof["bytes_per_sample"],
+                  "algorithmic_GBps": roof["bytes_per_sample"] * B / din_s / 1e9,
+                  "avg_launch_us": din_s * 1e6, "step_us_all_kernels": fwd_s * 1e6,
+                  "timed_with": "HIP events, k_din_pool-only loop after the timed region"}
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(args.workload)
+            except Exception:
+                traffic = None
+        rl["traffic"] = traffic
+        line = {
+            "metric": "ctr_samples_per_sec", "value": value, "unit": "samples/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed * 1e3 / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%s: %s" % (args.workload, desc), "batch_per_gpu": B, "global_batch": B * world,
+                       "id_distribution": args.dist, "input_batches_cycled": NB,
+                       "parallelism": "rows sharded over %d GPU(s), tables replicated, all-gather of scores" % world,
+                       "oracle_check_max_abs_err": check},
+            "roofline": rl,
+        }
+        if world == 1 and args.cpu_seconds > 0:
+            line["cpu_baseline"] = cpu_baseline(args.workload, model, feats, args.cpu_seconds)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

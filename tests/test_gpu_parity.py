@@ -1,0 +1,278 @@
+"""Parity tests proper (``-m gpu``): the HIP path, called through the C ABI, against the oracle and
+the committed golden vectors.  Bar: bit-exact for index/integer work (row gather, cross hash),
+<= 1e-4 absolute on the post-sigmoid score for floating point (BASELINE.json north_star); the
+asserts below use a tighter 1e-5 because both sides are fp32-class on these inputs."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import ctr_oracle as O
+from sparrowrecsys_amd import _lib as L
+from sparrowrecsys_amd import models as M
+from sparrowrecsys_amd import synthetic as SY
+from tests.conftest import GOLDEN
+from tests.golden.make_golden import SEEDS, make_model
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4        # the stated bar
+TIGHT = 1e-5      # what we actually hold on non-saturating inputs
+
+
+@pytest.fixture(scope="module")
+def torch():
+    import torch as t
+    assert t.cuda.is_available(), "gpu tests need a HIP device"
+    assert os.path.exists(L.LIB_PATH), "libsparrow_hip.so must be built in-tree"
+    return t
+
+
+def _cuda(torch, a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+# --------------------------------------------------------------------------------------------
+# golden vectors, all seven reference graphs (BASELINE config 1 = embedding_mlp on the bundled batch)
+# --------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", sorted(SEEDS))
+def test_reference_models_match_golden(torch, samples, name):
+    g = np.load(os.path.join(GOLDEN, "oracle_%s.npz" % name))
+    model = make_model(name)
+    p = model.predict(samples)
+    assert p.shape == (256, 1) and p.dtype == np.float32
+    assert np.abs(p[:, 0] - g["pred32"]).max() <= TOL
+    assert np.abs(p[:, 0] - g["pred64"]).max() <= TIGHT
+    # predict(batch_size=12) (the reference's batch, DeepFM.py:17) gives the same rows
+    p12 = model.predict(samples, batch_size=12)
+    np.testing.assert_array_equal(p12, p)
+
+
+def test_trained_neuralcf_checkpoint_subset(torch):
+    """Weights TRAINED by the reference (modeldata/neuralcf/{001,002}), 2048 real test rows."""
+    g = np.load(os.path.join(GOLDEN, "neuralcf_ckpt.npz"))
+    feats = {"movieId": g["movieId"], "userId": g["userId"]}
+    for ver in ("001", "002"):
+        w = {k[len(ver) + 1:]: g[k] for k in g.files if k.startswith(ver + "/")}
+        table = np.zeros((30001, 10), np.float32)
+        table[g["users"]] = g["user_rows_" + ver]
+        w["emb/userId"] = table
+        p = M.NeuralCF(weights=w).predict(feats)[:, 0]
+        assert np.abs(p - g["pred_" + ver]).max() <= TIGHT
+    np.testing.assert_allclose(p[:3], [0.8525178, 0.51808727, 0.35965464], atol=TIGHT)
+
+
+# --------------------------------------------------------------------------------------------
+# ragged / edge sizes
+# --------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("B", [1, 2, 63, 64, 65, 127, 129, 1000])
+def test_ragged_batch_sizes(torch, samples, B):
+    reps = (B + 255) // 256
+    feats = {k: np.concatenate([v] * reps)[:B] for k, v in samples.items()}
+    for name in ("deepfm_v2", "din"):
+        model = make_model(name)
+        p = model.predict(feats)
+        ref = O.FORWARDS[name](feats, model.weights, dtype=np.float64)
+        assert p.shape == (B, 1)
+        assert np.abs(p - ref).max() <= TIGHT
+
+
+def test_empty_batch(torch, samples):
+    model = make_model("deepfm")
+    empty = {k: v[:0] for k, v in samples.items()}
+    p = model.predict(empty)
+    assert p.shape == (0, 1) and p.dtype == np.float32
+
+
+def test_out_of_range_ids_raise(torch, samples):
+    model = make_model("deepfm")
+    bad = dict(samples)
+    bad["userId"] = np.array(["30001"] * 256, dtype=object)
+    with pytest.raises(ValueError):
+        model.predict(bad)
+    # device-resident ids skip host packing: the kernel flags them (TF: assert_less_than_num_buckets)
+    ids, dense = model.pack(samples)
+    ids[5, 0] = 5000
+    model.predict_device(_cuda(torch, ids), _cuda(torch, dense))
+    with pytest.raises(ValueError):
+        model.engine.check_ids()
+    model.predict_device(_cuda(torch, model.pack(samples)[0]), _cuda(torch, dense))
+    model.engine.check_ids()        # flag was cleared; clean batch passes
+
+
+def test_missing_id_is_a_zero_row(torch, samples):
+    """-1 (OOV / missing) must behave exactly like an all-zero embedding row and zero first-order weight."""
+    model = make_model("deepfm_v2")
+    ids, dense = model.pack(samples)
+    ids[:, 2] = -1                                   # userGenre1 column
+    p = model.predict_device(_cuda(torch, ids), _cuda(torch, dense)).cpu().numpy()
+    w = dict(model.weights)
+    w["emb/userGenre1"] = np.zeros_like(w["emb/userGenre1"])
+    fk = w["fo_cat/kernel"].copy()
+    fk[model.fo["userGenre1"]:model.fo["userGenre1"] + 19] = 0
+    w["fo_cat/kernel"] = fk
+    ids2, _ = model.pack(samples)
+    ids2[:, 2] = np.where(ids2[:, 2] < 0, 0, ids2[:, 2])
+    q = M.DeepFMv2(weights=w).predict_device(_cuda(torch, ids2), _cuda(torch, dense)).cpu().numpy()
+    np.testing.assert_array_equal(p, q)
+
+
+# --------------------------------------------------------------------------------------------
+# integer / index work: bit-exact
+# --------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("V,D", [(1001, 10), (30001, 16), (5000, 32), (2000, 64)])
+def test_embedding_gather_bit_exact(torch, V, D):
+    from sparrowrecsys_amd.plan import pad_table
+    import ctypes as C
+    rng = np.random.default_rng(V + D)
+    table = rng.standard_normal((V, D)).astype(np.float32)
+    padded = pad_table(table)
+    Dp = padded.shape[1]
+    ids = rng.integers(0, V, size=4099).astype(np.int32)
+    ids[::7] = -1
+    ids[1], ids[2] = 0, V - 1
+    t, i = _cuda(torch, padded), _cuda(torch, ids)
+    out = torch.empty((len(ids), Dp), dtype=torch.float32, device="cuda")
+    lib = L.load_library()
+    L.check(lib.sprk_embedding_gather(C.c_void_p(t.data_ptr()), V, Dp, Dp, C.c_void_p(i.data_ptr()), len(ids),
+                                      C.c_void_p(out.data_ptr()), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    got = out.cpu().numpy()
+    want = O.embedding_lookup(table, ids.astype(np.int64))
+    assert got[:, :D].tobytes() == want.tobytes()          # bit-exact copy
+    assert not got[:, D:].any()
+
+
+def test_cross_hash_bit_exact(torch):
+    import ctypes as C
+    g = np.load(os.path.join(GOLDEN, "cross_hash.npz"))
+    rng = np.random.default_rng(9)
+    a = np.concatenate([g["a"], rng.integers(0, 2 ** 31, 100000)]).astype(np.int32)
+    b = np.concatenate([g["b"], rng.integers(0, 2 ** 31, 100000)]).astype(np.int32)
+    lib = L.load_library()
+    for buckets, key in ((10000, "b10000"), (10_000_000, "b10m")):
+        ta, tb = _cuda(torch, a), _cuda(torch, b)
+        out = torch.empty(len(a), dtype=torch.int64, device="cuda")
+        L.check(lib.sprk_cross_hash(C.c_void_p(ta.data_ptr()), C.c_void_p(tb.data_ptr()), len(a), buckets,
+                                    C.c_void_p(out.data_ptr()), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        got = out.cpu().numpy()
+        np.testing.assert_array_equal(got[:64], g[key])                                   # python-int golden
+        np.testing.assert_array_equal(got, O.crossed_bucket_np([a, b], buckets))           # uint64 numpy
+
+
+# --------------------------------------------------------------------------------------------
+# DIN stage
+# --------------------------------------------------------------------------------------------
+def test_din_attention_and_pooling_parts(torch, samples):
+    model = make_model("din")
+    ids, _ = model.pack(samples)
+    eng = model.engine
+    Dp = eng.n_aux
+    pooled = torch.empty((256, Dp), dtype=torch.float32, device="cuda")
+    att = torch.empty((256, 5), dtype=torch.float32, device="cuda")
+    eng.din_pool(_cuda(torch, ids), pooled, att)
+    _, parts = O.din_forward(samples, model.weights, dtype=np.float64, return_parts=True)
+    assert np.abs(att.cpu().numpy() - parts["att"]).max() <= TIGHT
+    assert np.abs(pooled.cpu().numpy()[:, :10] - parts["pooled"]).max() <= TIGHT
+    assert not pooled.cpu().numpy()[:, 10:].any()
+
+
+# --------------------------------------------------------------------------------------------
+# BASELINE configs at (near) full size
+# --------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def config2(torch):
+    B = 65536
+    feats = SY.synth_fields(B, SY.CONFIG2_FIELDS, seed=SY.SEED)
+    model = M.DeepFMv2(seed=31, emb_dim=16, fields=SY.CONFIG2_FIELDS, proj_dim=16)
+    ids, dense = model.pack(feats)
+    return model, feats, _cuda(torch, ids), _cuda(torch, dense)
+
+
+def test_config2_deepfm_v2_full_batch_vs_oracle(torch, config2):
+    model, feats, ids, dense = config2
+    p = model.predict_device(ids, dense).cpu().numpy()
+    model.engine.check_ids()
+    ref = O.deepfm_v2_forward(feats, model.weights, dtype=np.float64, fields=SY.CONFIG2_FIELDS,
+                              order=[k for k, _, _ in SY.CONFIG2_FIELDS])[:, 0]
+    ref32 = O.deepfm_v2_forward(feats, model.weights, dtype=np.float32, fields=SY.CONFIG2_FIELDS,
+                                order=[k for k, _, _ in SY.CONFIG2_FIELDS])[:, 0]
+    assert np.isfinite(p).all()
+    assert np.abs(p - ref32).max() <= TOL
+    assert np.abs(p - ref).max() <= TOL
+    assert 0.05 < ref.std()                     # the comparison is not vacuous (scores are spread out)
+
+
+def test_config2_size_independent_properties(torch, config2):
+    model, feats, ids, dense = config2
+    p = model.predict_device(ids, dense)
+    # determinism
+    assert torch.equal(p, model.predict_device(ids, dense))
+    # samples are independent: permuting rows permutes scores, bit for bit
+    perm = torch.randperm(ids.shape[0], device="cuda", generator=torch.Generator(device="cuda").manual_seed(1))
+    assert torch.equal(model.predict_device(ids[perm].contiguous(), dense[perm].contiguous()), p[perm])
+    # ... and a slice scored alone equals the slice of the full batch (ragged last tile included)
+    for lo, hi in ((0, 1000), (777, 40001), (65000, 65536)):
+        assert torch.equal(model.predict_device(ids[lo:hi].contiguous(), dense[lo:hi].contiguous()), p[lo:hi])
+
+
+def test_config2_pairwise_variant(torch):
+    B = 16384
+    feats = SY.synth_fields(B, SY.CONFIG2_FIELDS, seed=5, dist="zipf")
+    model = M.DeepFM(seed=32, emb_dim=16, fields=SY.CONFIG2_FIELDS, pairs=SY.CONFIG2_PAIRS)
+    p = model.predict(feats)[:, 0]
+    ref = O.deepfm_forward(feats, model.weights, dtype=np.float64, fields=SY.CONFIG2_FIELDS, pairs=SY.CONFIG2_PAIRS)[:, 0]
+    assert np.abs(p - ref).max() <= TOL
+
+
+def test_config3_din_t50_d32(torch):
+    B, T, D = 8192, 50, 32
+    feats = SY.synth_din(B, T, SY.ML20M_MOVIE_IDS, SY.ML20M_USER_IDS, seed=11)
+    model = M.DIN(seed=33, emb_dim=D, hist_len=T, movie_buckets=SY.ML20M_MOVIE_IDS, user_buckets=SY.ML20M_USER_IDS)
+    p = model.predict(feats)[:, 0]
+    ref, parts = O.din_forward(feats, model.weights, dtype=np.float64, hist_len=T, movie_buckets=SY.ML20M_MOVIE_IDS,
+                               user_buckets=SY.ML20M_USER_IDS, return_parts=True)
+    assert np.abs(p - ref[:, 0]).max() <= TOL
+    ids, dense = model.pack(feats)
+    ti, td = _cuda(torch, ids), _cuda(torch, dense)
+    full = model.predict_device(ti, td)
+    assert torch.equal(full[1000:5003], model.predict_device(ti[1000:5003].contiguous(), td[1000:5003].contiguous()))
+    assert 0.2 < parts["att"].mean() < 0.8
+
+
+def test_config4_deepfm_d64_wide_rows(torch):
+    B = 8192
+    fields = [("movieId", "id", SY.ML20M_MOVIE_IDS), ("userId", "id", 1_000_000),
+              ("userGenre1", "genre", 19), ("movieGenre1", "genre", 19)]
+    feats = SY.synth_fields(B, fields, seed=12)
+    model = M.DeepFMv2(seed=34, emb_dim=64, fields=fields, proj_dim=16)
+    p = model.predict(feats)[:, 0]
+    ref = O.deepfm_v2_forward(feats, model.weights, dtype=np.float64, fields=fields, order=[k for k, _, _ in fields])[:, 0]
+    assert np.abs(p - ref).max() <= TOL
+
+
+def test_config5_wide_deep_hashed_cross(torch):
+    B = 16384
+    feats = SY.synth_embedding_mlp(B, SY.ML20M_MOVIE_IDS, SY.ML20M_USER_IDS, seed=13, rated_vocab=SY.ML20M_MOVIE_IDS)
+    for kw in (dict(cross_buckets=10000, cross_dim=0), dict(cross_buckets=1_000_000, cross_dim=32)):
+        model = M.WideNDeep(seed=35, emb_dim=32, movie_buckets=SY.ML20M_MOVIE_IDS, user_buckets=SY.ML20M_USER_IDS, **kw)
+        p = model.predict(feats)[:, 0]
+        ref = O.wide_n_deep_forward(feats, model.weights, dtype=np.float64, movie_buckets=SY.ML20M_MOVIE_IDS,
+                                    user_buckets=SY.ML20M_USER_IDS, cross_buckets=kw["cross_buckets"],
+                                    rated_buckets=SY.ML20M_MOVIE_IDS)[:, 0]
+        assert np.abs(p - ref).max() <= TOL
+
+
+def test_concurrent_streams_share_a_handle(torch, config2):
+    model, feats, ids, dense = config2
+    ref = model.predict_device(ids, dense)
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    o1 = torch.empty_like(ref)
+    o2 = torch.empty_like(ref)
+    for _ in range(5):
+        with torch.cuda.stream(s1):
+            model.predict_device(ids, dense, out=o1)
+        with torch.cuda.stream(s2):
+            model.predict_device(ids, dense, out=o2)
+    torch.cuda.synchronize()
+    assert torch.equal(o1, ref) and torch.equal(o2, ref)
