@@ -103,7 +103,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=40)
     ap.add_argument("--workload", default="deepfm_v2_c2")
     ap.add_argument("--batch", type=int, default=0, help="rows per GPU (default: the config's batch)")
-    ap.add_argument("--dist", default="uniform", choices=["uniform", "zipf"], help="id distribution")
+    ap.add_argument("--dist", default="uniform", choices=["uniform", "zipf", "hot"], help="id distribution")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget (0 = skip)")
     ap.add_argument("--no-check", action="store_true", help="skip the oracle spot check of the outputs")
     args = ap.parse_args()

@@ -78,14 +78,15 @@ _lib = None
 def build_library(force: bool = False, verbose: bool = False) -> str:
     """Compile csrc/sparrow_hip.hip for gfx950 into the in-tree libsparrow_hip.so
     (hipcc cross-compiles without a GPU)."""
-    if not force and os.path.exists(LIB_PATH) and os.path.getmtime(LIB_PATH) >= max(
-            os.path.getmtime(SRC_PATH), os.path.getmtime(os.path.join(INCLUDE_DIR, "sparrow_hip.h"))):
+    csrc = os.path.dirname(SRC_PATH)
+    deps = [os.path.join(csrc, f) for f in os.listdir(csrc)] + [os.path.join(INCLUDE_DIR, "sparrow_hip.h")]
+    if not force and os.path.exists(LIB_PATH) and os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(d) for d in deps):
         return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     if not os.path.exists(hipcc):
         hipcc = "hipcc"
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-I", INCLUDE_DIR, SRC_PATH, "-o", LIB_PATH + ".tmp"]
+           "-I", INCLUDE_DIR, "-I", os.path.dirname(SRC_PATH), SRC_PATH, "-o", LIB_PATH + ".tmp"]
     if verbose:
         print(" ".join(cmd))
     res = subprocess.run(cmd, capture_output=True, text=True)

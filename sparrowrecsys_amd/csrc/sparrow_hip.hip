@@ -22,6 +22,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -483,6 +484,8 @@ __global__ __launch_bounds__(256) void k_din_pool(const DevPlan* __restrict__ P,
     }
 }
 
+#include "k_chain_v2.h"
+
 // ---------------------------------------------------------------------------------------------
 // stand-alone operators
 // ---------------------------------------------------------------------------------------------
@@ -528,6 +531,13 @@ struct sprk_engine {
     int din_ms = 0;
     size_t din_lds_bytes = 0;
     int din_grid_cap = 0;
+    // register-chained fast path (k_deepfm_v2_chain); -1 = use the tile interpreter
+    int v2_variant = -1;
+    V2Args v2;
+    V2Run v2run;
+    size_t v2_lds_bytes = 0;
+    int v2_grid_cap = 0;
+    float* v2_image = nullptr;     // pre-packed LDS weight image (device)
 };
 
 namespace {
@@ -640,6 +650,139 @@ int validate_plan(const sprk_plan& p) {
         return fail(SPRK_EINVAL, "n_aux %d without a DIN stage", p.n_aux);
     }
     return SPRK_OK;
+}
+
+
+// ---- fast-path dispatch table for k_deepfm_v2_chain<G_EMB, DV, KPC, H0C, H1C, WAVES> ----
+constexpr int V2_WAVES = 8;
+struct V2Variant {
+    int g_emb, dv, kpc, h0c, h1c;
+    bool hoist;
+    const void* fn;
+    size_t lds_bytes;
+    void (*launch)(const V2Run&, const int*, const float*, float*, int, int*, const float*, int, size_t, hipStream_t);
+    void (*pack)(const V2Args&, float*);
+};
+template <int G_EMB, int DV, int KPC, int H0C, int H1C, bool HOIST>
+void v2_launch(const V2Run& a, const int* ids, const float* dense, float* out, int B, int* err, const float* image,
+               int grid, size_t lds, hipStream_t st) {
+    hipLaunchKernelGGL((k_deepfm_v2_chain<G_EMB, DV, KPC, H0C, H1C, V2_WAVES, HOIST>), dim3(grid), dim3(V2_WAVES * 64), lds, st,
+                       a, ids, dense, out, B, err, image);
+}
+template <int G_EMB, int DV, int KPC, int H0C, int H1C>
+void v2_pack(const V2Args& a, float* image) {
+    hipLaunchKernelGGL((k_v2_pack_image<G_EMB, DV, KPC, H0C, H1C>), dim3(1), dim3(256), 0, 0, a, image);
+}
+#define V2_VARIANT(G_EMB, DV, KPC, H0C, H1C, HOIST)                                                        \
+    {G_EMB, DV, KPC, H0C, H1C, HOIST, reinterpret_cast<const void*>(&k_deepfm_v2_chain<G_EMB, DV, KPC, H0C, H1C, V2_WAVES, HOIST>), \
+     sizeof(float) * V2Lds<G_EMB, DV, KPC, H0C, H1C>::total, &v2_launch<G_EMB, DV, KPC, H0C, H1C, HOIST>,               \
+     &v2_pack<G_EMB, DV, KPC, H0C, H1C>}
+const V2Variant kV2Variants[] = {
+    V2_VARIANT(6, 4, 1, 2, 1, false),   // BASELINE config 2: 6 fields, D=16, projection 16, deep 32-16
+    V2_VARIANT(6, 4, 1, 2, 1, true),
+    V2_VARIANT(4, 4, 1, 2, 1, false),   // 4 fields, D=16
+    V2_VARIANT(4, 16, 1, 2, 1, false),  // config-4 shape: 4 fields, D=64, projection 16
+};
+
+// Recognise the plan models.DeepFMv2 emits (DeepFM_v2.py graph) and fill the fused kernel's arguments.
+bool match_v2_chain(sprk_engine* h) {
+    const sprk_plan& p = h->plan;
+    if (p.model_kind != SPRK_MODEL_DEEPFM_V2 || p.din.enabled || p.n_bufs != 2) return false;
+    V2Args a;
+    memset(&a, 0, sizeof(a));
+    int g_emb = 0;
+    while (g_emb < p.n_segs && p.segs[g_emb].kind == SPRK_SEG_ROWS) ++g_emb;
+    if (g_emb < 1 || g_emb > V2_MAX_FIELDS) return false;
+    const int Dp = p.segs[0].row_stride;
+    for (int g = 0; g < g_emb; ++g) {
+        const sprk_seg& s = p.segs[g];
+        if (s.row_stride != Dp || s.count * 4 != Dp || s.dst != g * Dp) return false;
+        // the fused kernel needs the all-zero row at index vocab and 32-bit element offsets
+        const size_t need = ((size_t)s.vocab + 1) * Dp * sizeof(float);
+        if (h->slot_bytes[s.slot] < need || need >= ((size_t)1 << 32)) return false;
+        a.emb_col[g] = s.field; a.emb_vocab[g] = s.vocab; a.table[g] = (const float*)h->slot_ptr[s.slot];
+    }
+    int si = g_emb;
+    if (si >= p.n_segs || p.segs[si].kind != SPRK_SEG_DENSE || p.segs[si].field != 0 || p.segs[si].count > 8) return false;
+    const int n_num = p.segs[si].count, num_off = p.segs[si].dst;
+    ++si;
+    if (si < p.n_segs && p.segs[si].kind == SPRK_SEG_ZERO) ++si;
+    const int n_fo = p.n_segs - si;
+    if (n_fo < 1 || n_fo > V2_MAX_FIELDS) return false;
+    const int scal_off = p.segs[si].dst;
+    for (int i = 0; i < n_fo; ++i) {
+        const sprk_seg& s = p.segs[si + i];
+        if (s.kind != SPRK_SEG_SCALAR || s.dst != scal_off + i) return false;
+        if (h->slot_bytes[s.slot] < ((size_t)s.vocab + 1) * sizeof(float)) return false;
+        a.fo_col[i] = s.field; a.fo_vocab[i] = s.vocab; a.w1[i] = (const float*)h->slot_ptr[s.slot];
+    }
+    if (p.n_ops != g_emb + 4 || p.n_taps != 4) return false;
+    const int Kp = p.ops[0].N, G = g_emb + 1;
+    for (int g = 0; g < g_emb; ++g) {
+        const sprk_op& o = p.ops[g];
+        if (o.kind != SPRK_OP_DENSE || o.act != SPRK_ACT_NONE || o.src_buf != 0 || o.src_off != g * Dp || o.K != Dp ||
+            o.dst_buf != 1 || o.dst_off != g * Kp || o.N != Kp || o.ldw != Dp) return false;
+        a.Wp[g] = (const float*)h->slot_ptr[o.w_slot]; a.bp[g] = (const float*)h->slot_ptr[o.b_slot];
+    }
+    {
+        const sprk_op& o = p.ops[g_emb];
+        if (o.kind != SPRK_OP_DENSE || o.act != SPRK_ACT_NONE || o.src_buf != 0 || o.src_off != num_off || o.K > 8 ||
+            o.K < n_num || o.dst_buf != 1 || o.dst_off != g_emb * Kp || o.N != Kp) return false;
+        a.Wp[g_emb] = (const float*)h->slot_ptr[o.w_slot]; a.bp[g_emb] = (const float*)h->slot_ptr[o.b_slot];
+        a.ldp_num = o.ldw;
+    }
+    a.ldp_emb = Dp;
+    const sprk_op& fm = p.ops[g_emb + 1];
+    if (fm.kind != SPRK_OP_FM_SUMSQ || fm.src_buf != 1 || fm.src_off != 0 || fm.groups != G || fm.group_stride != Kp ||
+        fm.K > Kp || fm.dst_buf != 0) return false;
+    const sprk_op& d0 = p.ops[g_emb + 2];
+    if (d0.kind != SPRK_OP_DENSE || d0.act != SPRK_ACT_RELU || d0.src_buf != 1 || d0.src_off != 0 || d0.K != G * Kp ||
+        d0.ldw != G * Kp || d0.dst_buf != 0 || d0.dst_off != 0) return false;
+    const sprk_op& d1 = p.ops[g_emb + 3];
+    if (d1.kind != SPRK_OP_DENSE || d1.act != SPRK_ACT_RELU || d1.src_buf != 0 || d1.src_off != 0 || d1.K != d0.N ||
+        d1.ldw != d0.N || d1.dst_buf != 1 || d1.dst_off != 0) return false;
+    a.W0 = (const float*)h->slot_ptr[d0.w_slot]; a.b0 = (const float*)h->slot_ptr[d0.b_slot];
+    a.W1 = (const float*)h->slot_ptr[d1.w_slot]; a.b1 = (const float*)h->slot_ptr[d1.b_slot];
+    const sprk_tap &t0 = p.taps[0], &t1 = p.taps[1], &t2 = p.taps[2], &t3 = p.taps[3];
+    if (t0.buf != 0 || t0.off != scal_off || t0.len != n_fo || t0.w_slot != -1) return false;
+    if (t1.buf != 0 || t1.off != num_off || t1.len != n_num || t1.w_slot < 0 || t1.scale != t0.scale) return false;
+    if (t2.buf != 0 || t2.off != fm.dst_off || t2.len != fm.K || t2.w_slot < 0 || t2.scale != 1.0f || t2.bias != 0.0f) return false;
+    if (t3.buf != 1 || t3.off != 0 || t3.len > d1.N || t3.w_slot < 0 || t3.scale != 1.0f || t3.bias != 0.0f) return false;
+    a.fo_num_w = (const float*)h->slot_ptr[t1.w_slot];
+    a.hfm = (const float*)h->slot_ptr[t2.w_slot]; a.n_hfm = t2.len;
+    a.hdeep = (const float*)h->slot_ptr[t3.w_slot]; a.n_hdeep = t3.len;
+    a.h0w = t0.scale; a.fo_bias = t0.bias + t1.bias; a.head_bias = p.head_bias;
+    a.F = p.n_id_cols; a.ND = p.n_dense; a.n_num = n_num; a.n_fo = n_fo;
+    const int dv = Dp / 4, kpc = Kp / 16, h0c = d0.N / 16, h1c = d1.N / 16;
+    const char* mode = getenv("SPRK_V2_HOIST");          // A/B switch: "1" = register-resident weights
+    const bool want_hoist = mode && mode[0] == '1';
+    for (size_t v = 0; v < sizeof(kV2Variants) / sizeof(kV2Variants[0]); ++v) {
+        const V2Variant& vv = kV2Variants[v];
+        if (vv.hoist != want_hoist) continue;
+        if (vv.g_emb == g_emb && vv.dv == dv && vv.kpc == kpc && vv.h0c == h0c && vv.h1c == h1c) {
+            // the fused kernel reads ONE id per field for both the embedding row and the first-order
+            // weight: the two field lists must be the same set of ids columns
+            if (n_fo != g_emb) return false;
+            V2Run run;
+            memset(&run, 0, sizeof(run));
+            for (int g = 0; g < g_emb; ++g) {
+                int hit = -1;
+                for (int i = 0; i < n_fo; ++i)
+                    if (a.fo_col[i] == a.emb_col[g] && a.fo_vocab[i] == a.emb_vocab[g]) hit = i;
+                if (hit < 0) return false;
+                run.col[g] = a.emb_col[g]; run.vocab[g] = a.emb_vocab[g];
+                run.table[g] = a.table[g]; run.w1[g] = a.w1[hit];
+            }
+            run.F = a.F; run.ND = a.ND; run.n_num = a.n_num;
+            run.h0w = a.h0w; run.fo_bias = a.fo_bias; run.head_bias = a.head_bias;
+            h->v2run = run;
+            h->v2 = a;
+            h->v2_variant = (int)v;
+            h->v2_lds_bytes = vv.lds_bytes;
+            return true;
+        }
+    }
+    return false;
 }
 
 int need_bytes(const sprk_engine* h, int slot, size_t bytes, const char* what) {
@@ -802,6 +945,24 @@ int sprk_finalize(sprk_handle h) {
         if (per_cu < 1) per_cu = 1;
         h->tile_grid_cap = h->num_cus * per_cu;
     }
+    {
+        const char* force = getenv("SPRK_FORCE_INTERPRETER");
+        if (!(force && force[0] == '1') && match_v2_chain(h)) {
+            const V2Variant& vv = kV2Variants[h->v2_variant];
+            HIP_TRY(hipFuncSetAttribute(vv.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)vv.lds_bytes));
+            int per_cu = (int)(160 * 1024 / vv.lds_bytes);
+            const int by_regs = (vv.hoist ? 2 : 4) * 4 / V2_WAVES;   // waves/SIMD the launch bounds allow
+            if (per_cu > by_regs) per_cu = by_regs;
+            const char* wg = getenv("SPRK_V2_WGS_PER_CU");           // tuning knob (1..by_regs)
+            if (wg && wg[0] >= '1' && wg[0] <= '9' && (wg[0] - '0') < per_cu) per_cu = wg[0] - '0';
+            if (per_cu < 1) per_cu = 1;
+            h->v2_grid_cap = h->num_cus * per_cu;
+            HIP_TRY(hipMalloc((void**)&h->v2_image, vv.lds_bytes));
+            vv.pack(h->v2, h->v2_image);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipDeviceSynchronize());
+        }
+    }
     HIP_TRY(hipMalloc((void**)&h->dev_plan, sizeof(DevPlan)));
     HIP_TRY(hipMemcpy(h->dev_plan, dp, sizeof(DevPlan), hipMemcpyHostToDevice));
     HIP_TRY(hipMalloc((void**)&h->dev_err, sizeof(int)));
@@ -849,6 +1010,14 @@ int sprk_forward(sprk_handle h, const int32_t* ids, const float* dense, float* o
         if (rc) return rc;
         aux = (const float*)workspace;
     }
+    if (h->v2_variant >= 0) {
+        const int ntasks = (B + 15) / 16;
+        int grid = (ntasks + V2_WAVES - 1) / V2_WAVES;
+        if (grid > h->v2_grid_cap) grid = h->v2_grid_cap;
+        kV2Variants[h->v2_variant].launch(h->v2run, ids, dense, out, B, h->dev_err, h->v2_image, grid, h->v2_lds_bytes, st);
+        HIP_TRY(hipGetLastError());
+        return SPRK_OK;
+    }
     const int ntiles = (B + SPRK_TILE_M - 1) / SPRK_TILE_M;
     const int grid = ntiles < h->tile_grid_cap ? ntiles : h->tile_grid_cap;
     hipLaunchKernelGGL(k_tile_forward, dim3(grid), dim3(256), h->tile_lds_bytes, st, h->dev_plan, ids, dense, aux, out, B, h->dev_err);
@@ -889,6 +1058,7 @@ void sprk_destroy(sprk_handle h) {
     for (void* p : h->slot_ptr)
         if (p) (void)hipFree(p);
     if (h->dev_plan) (void)hipFree(h->dev_plan);
+    if (h->v2_image) (void)hipFree(h->v2_image);
     if (h->dev_err) (void)hipFree(h->dev_err);
     delete h;
 }

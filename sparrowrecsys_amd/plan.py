@@ -31,13 +31,14 @@ def pad16(n: int) -> int:
 
 
 def pad_table(table: np.ndarray) -> np.ndarray:
+    """[V, D] -> device layout [V+1, Dp]: rows padded to whole 16-byte lanes, plus ONE all-zero row at
+    index V.  The fused kernels point a missing / out-of-vocabulary id at that row, so "no id ->
+    zero vector" (safe_embedding_lookup_sparse) costs no select; valid rows are copied bit-exactly."""
     table = np.ascontiguousarray(table, dtype=np.float32)
     V, D = table.shape
     Dp = pad4(D)
-    if Dp == D:
-        return table
-    out = np.zeros((V, Dp), dtype=np.float32)
-    out[:, :D] = table
+    out = np.zeros((V + 1, Dp), dtype=np.float32)
+    out[:V, :D] = table
     return out
 
 
@@ -110,7 +111,9 @@ class PlanBuilder:
 
     def seg_scalar(self, key: str, weights, dst: int) -> int:
         w = np.ascontiguousarray(weights, dtype=np.float32).reshape(-1)
-        self.segs.append(L.Seg(L.SEG_SCALAR, self.slot(w), self.col(key), 0, 1, 1, dst, w.shape[0]))
+        n = w.shape[0]
+        w = np.concatenate([w, np.zeros(1, np.float32)])       # zero entry at index V for "no id"
+        self.segs.append(L.Seg(L.SEG_SCALAR, self.slot(w), self.col(key), 0, 1, 1, dst, n))
         self._touch(0, dst + 1)
         return dst
 

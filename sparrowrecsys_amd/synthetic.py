@@ -29,6 +29,9 @@ CONFIG2_PAIRS = [(a, b) for a in ("movieId", "movieGenre1")
 def _draw_ids(rng, n, vocab, dist: str, low: int = 0):
     if dist == "uniform":
         return rng.integers(low, vocab, size=n, dtype=np.int64)
+    if dist == "hot":
+        # ablation only: every id inside a 1 k-row window, so all gathers hit L1/L2
+        return rng.integers(low, min(vocab, low + 1024), size=n, dtype=np.int64)
     if dist == "zipf":
         # Zipf(s=1.05) popularity over a fixed random permutation of the ids
         ranks = np.arange(1, vocab - low + 1, dtype=np.float64)

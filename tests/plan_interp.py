@@ -81,6 +81,7 @@ def run_plan(plan, slots, ids, dense, dtype=np.float64):
         elif s.kind in (L.SEG_SCALAR, L.SEG_CROSS_SCALAR):
             table = _slot(slots, s.slot).reshape(-1).astype(dtype)
             if s.kind == L.SEG_SCALAR:
+                assert table.shape[0] == s.vocab + 1 and table[s.vocab] == 0
                 idx = ids[:, s.field].astype(np.int64)
                 assert ((idx >= -1) & (idx < s.vocab)).all()
             else:

@@ -276,3 +276,30 @@ def test_concurrent_streams_share_a_handle(torch, config2):
             model.predict_device(ids, dense, out=o2)
     torch.cuda.synchronize()
     assert torch.equal(o1, ref) and torch.equal(o2, ref)
+
+
+# --------------------------------------------------------------------------------------------
+# the three execution paths of the DeepFM_v2 graph must agree with the oracle and with each other
+# --------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("env", [{}, {"SPRK_V2_HOIST": "1"}, {"SPRK_FORCE_INTERPRETER": "1"}],
+                         ids=["chain", "chain-hoist", "interpreter"])
+def test_deepfm_v2_execution_paths(torch, env, monkeypatch):
+    for k in ("SPRK_V2_HOIST", "SPRK_FORCE_INTERPRETER"):
+        monkeypatch.delenv(k, raising=False)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    B = 10007                                     # ragged: not a multiple of 16 or 64
+    order = [k for k, _, _ in SY.CONFIG2_FIELDS]
+    feats = SY.synth_fields(B, SY.CONFIG2_FIELDS, seed=77, dist="zipf")
+    model = M.DeepFMv2(seed=41, emb_dim=16, fields=SY.CONFIG2_FIELDS, proj_dim=16)
+    p = model.predict(feats)[:, 0]                # engine is created here, under the env above
+    ref = O.deepfm_v2_forward(feats, model.weights, dtype=np.float64, fields=SY.CONFIG2_FIELDS, order=order)[:, 0]
+    assert np.abs(p - ref).max() <= TIGHT
+    # 4-field D=16 and D=64 shapes (other template instantiations / interpreter)
+    for D, vocab_u in ((16, 50000), (64, 200000)):
+        fields = [("movieId", "id", 3000), ("userId", "id", vocab_u), ("userGenre1", "genre", 19), ("movieGenre1", "genre", 19)]
+        f2 = SY.synth_fields(3001, fields, seed=78)
+        m2 = M.DeepFMv2(seed=42, emb_dim=D, fields=fields, proj_dim=16)
+        p2 = m2.predict(f2)[:, 0]
+        r2 = O.deepfm_v2_forward(f2, m2.weights, dtype=np.float64, fields=fields, order=[k for k, _, _ in fields])[:, 0]
+        assert np.abs(p2 - r2).max() <= TIGHT
