@@ -32,7 +32,7 @@ EXPORTED_SYMBOLS = [
     "sprk_runtime_info", "sprk_create", "sprk_upload", "sprk_finalize", "sprk_workspace_bytes",
     "sprk_forward", "sprk_forward_embedding_mlp", "sprk_forward_widedeep", "sprk_forward_neuralcf",
     "sprk_forward_deepfm", "sprk_forward_deepfm_v2", "sprk_forward_din", "sprk_din_pool",
-    "sprk_check_ids", "sprk_destroy", "sprk_embedding_gather", "sprk_cross_hash", "sprk_last_error",
+    "sprk_check_ids", "sprk_debug_set_trace", "sprk_destroy", "sprk_embedding_gather", "sprk_cross_hash", "sprk_last_error",
 ]
 
 
@@ -121,6 +121,7 @@ def load_library():
             getattr(lib, name).argtypes = fwd
         lib.sprk_din_pool.argtypes = [vp, vp, vp, vp, i32, vp]
         lib.sprk_check_ids.argtypes = [vp, vp]
+        lib.sprk_debug_set_trace.argtypes = [vp, vp, sz]
         lib.sprk_destroy.argtypes = [vp]
         lib.sprk_destroy.restype = None
         lib.sprk_embedding_gather.argtypes = [vp, i32, i32, i32, vp, i32, vp, vp]

@@ -4,7 +4,7 @@
 //
 // One WAVE owns 16 samples from ids to score.  Lane (r = lane&15, q = lane>>4) is sample r's q-th
 // 16-byte column slot, which is at the same time
-//   * the natural unit of a coalesced embedding-row gather (4 lanes x 16 B = one 64-B row), and
+//   * the unit of the embedding-row gather (4 lanes x 16 B = one 64-B row), and
 //   * the B-operand layout of v_mfma_f32_16x16x4_f32 (lane supplies B[k=4q+s][col=r] at step s), and
 //   * the C/D layout of the previous layer's output (lane holds D[row=4q+j][col=r]).
 // So with the weights as the A operand (W^T rows, read from LDS), embedding rows are loaded from
@@ -13,6 +13,18 @@
 // Dense+ReLU -> Dense+ReLU -> output dot + sigmoid.  No activation ever touches LDS or HBM, there
 // is no barrier after the one-time weight staging, and waves progress independently, so gather
 // latency of one wave hides under the MFMAs of its neighbours.
+//
+// FOLD: a per-field Dense with no activation applied to a gathered row is itself a table:
+// (table_g @ Wp_g + bp_g)[id].  When the projection is not wider than the embedding the library
+// builds those projected tables once at sprk_finalize (k_v2_fold, same fp32 fmaf order as the
+// in-kernel MFMA chain, so bit-identical) and the kernel gathers P_g directly: same bytes per
+// sample, 24 of 92 MFMAs per 16 samples gone.
+//
+// Memory instructions per 16 samples: ONE coalesced 16-B/lane load brings the task's contiguous
+// ids block (lanes 0..4F-1) and numerics block (lanes 32..32+4ND-1); it is re-distributed to the
+// (r,q) layout through a 1-KB wave-private LDS slot.  Then G_EMB row gathers and two first-order
+// gathers (lane (r,q) fetches the weight of field q, then of field q+4; the cross-q sum rides the
+// output reduction).
 //
 // HBM traffic per sample = ids + gathered rows + first-order weights + numerics + score (the
 // algorithmic minimum, 464 B at F=6, D=16).
@@ -28,8 +40,8 @@ struct V2Args {
     int emb_vocab[V2_MAX_FIELDS];
     int fo_col[V2_MAX_FIELDS];            // ids column of first-order field i
     int fo_vocab[V2_MAX_FIELDS];
-    const float* table[V2_MAX_FIELDS];    // [vocab][4*DV] padded embedding tables
-    const float* w1[V2_MAX_FIELDS];       // [vocab] first-order weights
+    const float* table[V2_MAX_FIELDS];    // [vocab+1][4*DV] padded embedding tables (last row zero)
+    const float* w1[V2_MAX_FIELDS];       // [vocab+1] first-order weights (last zero)
     const float* Wp[V2_MAX_FIELDS + 1];   // projection W^T: [Kp][ldp] (group G_EMB = numerics, ldp_num)
     const float* bp[V2_MAX_FIELDS + 1];   // projection bias [Kp]
     int ldp_emb, ldp_num;
@@ -43,7 +55,7 @@ struct V2Args {
     float head_bias;
 };
 
-template <int G_EMB, int DV, int KPC, int H0C, int H1C>
+template <int G_EMB, int DV, int KPC, int H0C, int H1C, bool FOLD>
 struct V2Lds {
     static constexpr int G = G_EMB + 1;
     static constexpr int DPC = (DV + 3) / 4;          // 16-float chunks per embedding row
@@ -52,8 +64,8 @@ struct V2Lds {
     static constexpr int SN = 16 + 4;                 // ... of the numeric group
     static constexpr int S0 = G * KP + 4;             // deep0 W^T row stride
     static constexpr int S1 = H0C * 16 + 4;           // deep1 W^T row stride
-    static constexpr int off_wp = 0;                  // [G_EMB][KP][SP]
-    static constexpr int off_wn = off_wp + G_EMB * KP * SP;   // [KP][SN]
+    static constexpr int off_wp = 0;                  // [G_EMB][KP][SP]   (absent when FOLD)
+    static constexpr int off_wn = off_wp + (FOLD ? 0 : G_EMB * KP * SP);   // [KP][SN]
     static constexpr int off_bp = off_wn + KP * SN;   // [G][KP]
     static constexpr int off_w0 = off_bp + G * KP;    // [H0C*16][S0]
     static constexpr int off_b0 = off_w0 + H0C * 16 * S0;
@@ -62,7 +74,9 @@ struct V2Lds {
     static constexpr int off_hfm = off_b1 + H1C * 16; // [KP]
     static constexpr int off_hd = off_hfm + KP;       // [H1C*16]
     static constexpr int off_fn = off_hd + H1C * 16;  // [8]
-    static constexpr int total = off_fn + 8;          // floats
+    static constexpr int total = off_fn + 8;          // floats in the weight image
+    static constexpr int total_pad = (total + 255) & ~255;   // ... rounded up to whole 1-KB LDS-DMA pieces
+    static constexpr int stage_floats = 256;          // per-wave ids/numerics slot: ids [0,128), numerics [128,256)
 };
 
 // copy a [rows][ld] global matrix into LDS [rows_pad][stride], zero-filling everything outside
@@ -85,14 +99,15 @@ __device__ __forceinline__ f32x4 relu4(f32x4 v) {
 
 // One-time (finalize) kernel: lays every weight out exactly as the fused kernel wants it in LDS
 // (padded row strides, zero fill), so the per-launch staging is a flat copy.
-template <int G_EMB, int DV, int KPC, int H0C, int H1C>
+template <int G_EMB, int DV, int KPC, int H0C, int H1C, bool FOLD>
 __global__ __launch_bounds__(256) void k_v2_pack_image(const V2Args A, float* __restrict__ lds) {
-    using LD = V2Lds<G_EMB, DV, KPC, H0C, H1C>;
+    using LD = V2Lds<G_EMB, DV, KPC, H0C, H1C, FOLD>;
     constexpr int G = LD::G, KP = LD::KP;
     const int tid = threadIdx.x, NT = 256;
     static_assert(LD::total % 4 == 0, "LDS image must be a whole number of float4");
-    for (int g = 0; g < G_EMB; ++g)
-        stage_matrix(lds + LD::off_wp + g * KP * LD::SP, KP, LD::SP, A.Wp[g], KP, 4 * DV, A.ldp_emb, tid, NT);
+    if (!FOLD)
+        for (int g = 0; g < G_EMB; ++g)
+            stage_matrix(lds + LD::off_wp + g * KP * LD::SP, KP, LD::SP, A.Wp[g], KP, 4 * DV, A.ldp_emb, tid, NT);
     stage_matrix(lds + LD::off_wn, KP, LD::SN, A.Wp[G_EMB], KP, A.n_num, A.ldp_num, tid, NT);
     for (int g = 0; g < G; ++g) stage_vector(lds + LD::off_bp + g * KP, KP, A.bp[g], KP, tid, NT);
     stage_matrix(lds + LD::off_w0, H0C * 16, LD::S0, A.W0, H0C * 16, G * KP, G * KP, tid, NT);
@@ -104,15 +119,86 @@ __global__ __launch_bounds__(256) void k_v2_pack_image(const V2Args A, float* __
     stage_vector(lds + LD::off_fn, 8, A.fo_num_w, A.n_num, tid, NT);
 }
 
+// One-time (finalize) kernel: projected table P[v][n] = bp[n] + sum_k Wp^T[n][k] * table[v][k],
+// v in [0, rows) (the last row of `table` is the all-zero "missing id" row, so P's last row is the
+// bias).  The k order is the one the in-kernel MFMA chain uses (within each 16-chunk: k = 4q+s for
+// s outer, q inner), one fmaf per term, so folding does not change a single bit of P_g.
+// Output rows are [P (KP floats) | first-order weight w1[v] | 15 zero floats]: with KP = 16 one
+// 128-byte L2 line holds everything the forward needs for an id, so a lookup costs one line fetch
+// instead of two (64-B row + the line around a 4-B first-order weight).
+__global__ __launch_bounds__(256) void k_v2_fold(const float* __restrict__ table, int row_floats,
+                                                 const float* __restrict__ Wp, int ldp, const float* __restrict__ bp,
+                                                 const float* __restrict__ w1, float* __restrict__ out, int KP,
+                                                 long long rows) {
+    const int OS = KP + 16;
+    const long long total = rows * OS;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long v = i / OS;
+        const int n = (int)(i - v * OS);
+        float acc = 0.f;
+        if (n < KP) {
+            const float* x = table + v * row_floats;
+            const float* w = Wp + (size_t)n * ldp;
+            acc = bp[n];
+            for (int c = 0; c < row_floats; c += 16)
+                for (int s = 0; s < 4; ++s)
+                    for (int q = 0; q < 4; ++q) {
+                        const int k = c + 4 * q + s;
+                        if (k < row_floats) acc = fmaf(w[k], x[k], acc);
+                    }
+        } else if (n == KP) {
+            acc = w1[v];
+        }
+        out[i] = acc;
+    }
+}
+
 // Run-time arguments of the fused kernel (the weights travel through the packed image).
 struct V2Run {
     int F, ND, n_num;
     int col[V2_MAX_FIELDS];               // ids column of field g (embedding AND first-order weight)
     int vocab[V2_MAX_FIELDS];
-    const float* table[V2_MAX_FIELDS];    // [vocab][4*DV]
-    const float* w1[V2_MAX_FIELDS];       // [vocab]
+    unsigned fo_off[V2_MAX_FIELDS];       // not FOLD: start of field g's block inside fo_all
+    const float* table[V2_MAX_FIELDS];    // FOLD: [vocab+1][KP+16] rows {P | w1 | 0..}, else [vocab+1][4*DV]
+    const float* fo_all;                  // not FOLD: concatenated first-order blocks, each [vocab+1] (last entry 0)
     float h0w, fo_bias, head_bias;
+    unsigned long long* trace;            // TRACE instantiation only: per-wave phase timestamps (sprk_debug_set_trace)
+    int flags;                            // 1 = ids/dense not 16-byte aligned: stage element-wise
 };
+
+// cold path of the ids/numerics staging: a partial last task, or inputs that do not start on a
+// 16-byte boundary -- element-wise, rows past the end of the batch clamped to the last row
+__device__ __noinline__ void stage_task_slow(float* stage, const int* __restrict__ ids, const float* __restrict__ dense,
+                                             int F, int ND, int tk, int B, int lane) {
+    int* si = reinterpret_cast<int*>(stage);
+#pragma clang loop vectorize(disable) unroll(disable)
+    for (int e = lane; e < 16 * F; e += 64) {
+        const int mm = e / F, c = e - mm * F;
+        const int m = min(tk * 16 + mm, B - 1);
+        si[e] = ids[(size_t)m * F + c];
+    }
+#pragma clang loop vectorize(disable) unroll(disable)
+    for (int e = lane; e < 16 * ND; e += 64) {
+        const int mm = e / ND, c = e - mm * ND;
+        const int m = min(tk * 16 + mm, B - 1);
+        stage[128 + e] = dense[(size_t)m * ND + c];
+    }
+}
+
+// diagnostics (TRACE instantiation): lane 0 of every wave stamps the shader clock (s_memtime),
+// optionally after draining its loads
+template <bool TRACE>
+__device__ __forceinline__ void trace_stamp(unsigned long long* trace, int wave_global, int k, bool drain) {
+    if constexpr (TRACE) {
+        if (trace) {
+            if (drain) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            const unsigned long long t = __builtin_amdgcn_s_memtime();
+            if ((threadIdx.x & 63) == 0) trace[(size_t)wave_global * 16 + k] = t;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
 
 // two independent 4-step MFMA chains issued alternately (a 16x16x4 MFMA has a 40-cycle dependent
 // latency but a 32-cycle issue interval: alternating chains keeps the matrix pipe full from one wave)
@@ -126,24 +212,25 @@ __device__ __forceinline__ void mfma4x2(f32x4 a0, f32x4 b0, f32x4& c0, f32x4 a1,
     c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, b0.w, c0, 0, 0, 0);
     c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, b1.w, c1, 0, 0, 0);
 }
-__device__ __forceinline__ f32x4 sel4(bool ok, f32x4 v) {
-    return f32x4{ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f};
-}
 
-// HOIST = true : the LDS weight reads are loop-invariant, hipcc keeps every W^T fragment in VGPRs across
-//                tasks (no LDS traffic in the loop, ~230 VGPRs -> 2 waves/SIMD).
-// HOIST = false: the LDS offset is laundered through an empty asm each task, so fragments are re-read from
-//                LDS where used (~128 VGPRs -> 4 waves/SIMD hide gather latency by occupancy).
-template <int G_EMB, int DV, int KPC, int H0C, int H1C, int WAVES, bool HOIST>
-__global__ __launch_bounds__(WAVES * 64, HOIST ? 2 : 4) void k_deepfm_v2_chain(const V2Run A, const int* __restrict__ ids,
+// Each stage has ONE call site inside a software-pipelined task loop (trip i gathers task i, then
+// scores task i-1 whose rows were issued a trip earlier), which keeps the code small: at one
+// 16-sample task per wave (B = 65 536 fills the chip exactly once) every instruction runs once per
+// launch from a cold instruction cache.
+template <int G_EMB, int DV, int KPC, int H0C, int H1C, int WAVES, bool FOLD, bool TRACE>
+__global__ __launch_bounds__(WAVES * 64, 4) void k_deepfm_v2_chain(const V2Run A, const int* __restrict__ ids,
                                                                 const float* __restrict__ dense,
                                                                 float* __restrict__ out, int B,
                                                                 int* __restrict__ err,
                                                                 const float* __restrict__ image) {
-    using LD = V2Lds<G_EMB, DV, KPC, H0C, H1C>;
-    constexpr int G = LD::G, DPC = LD::DPC, KP = LD::KP;
+    using LD = V2Lds<G_EMB, DV, KPC, H0C, H1C, FOLD>;
+    constexpr int G = LD::G, KP = LD::KP;
+    constexpr int XC = FOLD ? KPC : LD::DPC;          // 16-float chunks per gathered row
+    constexpr int XV = FOLD ? 4 * KPC : DV;           // float4 per gathered row
+    constexpr int RS = FOLD ? KP + 16 : 4 * DV;       // floats between consecutive table rows
     constexpr int NT = WAVES * 64;
     static_assert(H0C % 2 == 0, "deep0 n-blocks are processed in interleaved pairs");
+    static_assert(G_EMB >= 1 && G_EMB <= V2_MAX_FIELDS, "field count");
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -151,206 +238,246 @@ __global__ __launch_bounds__(WAVES * 64, HOIST ? 2 : 4) void k_deepfm_v2_chain(c
     const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
     const int ntasks = (B + 15) >> 4;
     const int task_stride = gridDim.x * WAVES;
-    int task = blockIdx.x * WAVES + wave;
+    const int wave_global = blockIdx.x * WAVES + wave;
+    float* stage = smem + LD::total_pad + wave * LD::stage_floats;
+    const float* wq = smem + 4 * q;                       // this lane's 16-byte column slot of the weight image
 
-    // ---- gather in three branch-free stages, each consumed one phase after it was issued, so no
-    //      wait ever sits next to the loads it guards:
-    //        load_ids   : this task's ids + numerics                  (consumed by issue_rows)
-    //        issue_rows : embedding rows + first-order weights        (consumed by finish_rows)
-    //        finish_rows: sum the first-order weights
-    //      All addressing is a 32-bit offset from a wave-uniform (SGPR) base.  A missing (-1) or
-    //      out-of-range id is redirected to the all-zero row the host appended at index `vocab`, and a
-    //      row past the end of the batch is clamped to the last row (its score is never stored), so
-    //      nothing needs a select.  The numeric lane slots beyond n_num hold a duplicate finite value
-    //      that only ever meets zero weights in the packed image. ----
-    f32x4 x[G_EMB][DPC];
-    f32x4 xn;
-    float fo;
-    unsigned long long badmask = 0;   // wave-level (SALU) OR of "id outside its table" lanes
-    int idv[G_EMB];
-    f32x4 nvv;
-    float w1v[G_EMB];
-    auto load_ids = [&](int tk) {
-        int m = tk * 16 + r;
-        m = m < B ? m : (B - 1);
-        const unsigned ibase = (unsigned)m * (unsigned)A.F;
-#pragma unroll
-        for (int g = 0; g < G_EMB; ++g) idv[g] = (ids + A.col[g])[ibase];
-        const unsigned dbase = (unsigned)m * (unsigned)A.ND;
-        const unsigned c0 = 4 * q;
-        const unsigned last = (unsigned)A.n_num - 1;
-        nvv.x = dense[dbase + (c0 + 0 < last ? c0 + 0 : last)];
-        nvv.y = dense[dbase + (c0 + 1 < last ? c0 + 1 : last)];
-        nvv.z = dense[dbase + (c0 + 2 < last ? c0 + 2 : last)];
-        nvv.w = dense[dbase + (c0 + 3 < last ? c0 + 3 : last)];
+    // ---- gather stage, consumed one loop trip after it was issued:
+    //        ld_raw : the task's contiguous ids / numerics blocks, one 16-B load per lane (async)
+    //        gather : VGPR -> wave-private LDS slot -> the (r,q) lanes that need them, then the
+    //                 embedding rows + first-order weights                             (async)
+    //      A missing (-1) or out-of-range id is redirected to the all-zero row the host appended at
+    //      index `vocab`, so nothing needs a select. ----
+    f32x4 raw = zero;
+    f32x4 x[G_EMB][XC];
+    f32x4 xn = zero;
+    float w1a = 0.f, w1b = 0.f;
+    bool bad = false;
+    const bool aligned = !(A.flags & 1);
+    auto ld_raw = [&](int tk) {
+        if (aligned && tk * 16 + 16 <= B) {                       // wave-uniform
+            const bool isid = lane < 32;
+            const int j = isid ? lane : lane - 32;
+            const int n4 = 4 * (isid ? A.F : A.ND);
+            const float* src = isid ? reinterpret_cast<const float*>(ids) + (size_t)tk * 16 * A.F
+                                    : dense + (size_t)tk * 16 * A.ND;
+            raw = ld4(src + 4 * (j < n4 ? j : 0));
+        }
     };
-    auto issue_rows = [&]() {
-        xn = nvv;
+    auto gather = [&](int tk) {
+        if (aligned && tk * 16 + 16 <= B) {
+            const bool isid = lane < 32;
+            const int j = isid ? lane : lane - 32;
+            const int n4 = 4 * (isid ? A.F : A.ND);
+            if (j < n4) st4(stage + (isid ? 0 : 128) + 4 * j, raw);
+        } else {
+            stage_task_slow(stage, ids, dense, A.F, A.ND, tk, B, lane);
+        }
+        // one wave: LDS operations complete in issue order, no barrier needed
+        const int* sid_row = reinterpret_cast<const int*>(stage) + r * A.F;
+        unsigned sid[G_EMB];
 #pragma unroll
         for (int g = 0; g < G_EMB; ++g) {
-            const int id = idv[g];
+            const int id = sid_row[A.col[g]];
             const bool ok = (unsigned)id < (unsigned)A.vocab[g];
-            badmask |= __ballot(!ok && id != -1);
-            const unsigned sid = ok ? (unsigned)id : (unsigned)A.vocab[g];     // -> the zero row
-            w1v[g] = A.w1[g][sid];
-            const unsigned off = sid * (unsigned)(4 * DV) + 4u * q;
+            bad |= !ok && id != -1;
+            sid[g] = ok ? (unsigned)id : (unsigned)A.vocab[g];     // -> the zero row
+            if (A.flags & 16) sid[g] = 0;                          // experiment: every gather hits one hot row
+        }
+        {
+            const float* nrow = stage + 128 + r * A.ND;
+            const int c0 = 4 * q, last = A.n_num - 1;
+            // lane slots beyond n_num hold a duplicate finite value that only ever meets zero weights
+            xn.x = nrow[min(c0 + 0, last)];
+            xn.y = nrow[min(c0 + 1, last)];
+            xn.z = nrow[min(c0 + 2, last)];
+            xn.w = nrow[min(c0 + 3, last)];
+        }
 #pragma unroll
-            for (int c = 0; c < DPC; ++c) {
+        for (int g = 0; g < G_EMB; ++g) {
+            const unsigned rowoff = sid[g] * (unsigned)RS;
+#pragma unroll
+            for (int c = 0; c < XC; ++c) {
                 // this lane's 16-byte piece of the row; pieces past the row end re-read piece 0 and
                 // only ever meet zero weights
-                const unsigned o = (4 * c + 3 < DV || 4u * c + q < (unsigned)DV) ? off + 16u * c : sid * (unsigned)(4 * DV);
+                const unsigned o = (4 * c + 3 < XV || 4u * c + q < (unsigned)XV) ? rowoff + 16u * c + 4u * q : rowoff;
                 x[g][c] = ld4(A.table[g] + o);
             }
         }
-    };
-    auto finish_rows = [&]() {
-        fo = 0.f;
-#pragma unroll
-        for (int g = 0; g < G_EMB; ++g) fo += w1v[g];
-    };
-
-    // ---- prologue: ids first, then the weight image (independent of the ids, so both are in flight
-    //      together), then the rows ----
-    const bool have0 = task < ntasks;
-    if (have0) load_ids(task);
-    {
-        constexpr int total4 = LD::total / 4;
-#pragma unroll 1
-        for (int base = 0; base < total4; base += 4 * NT) {
-            f32x4 v[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int idx = base + u * NT + tid;
-                v[u] = ld4(image + 4 * (idx < total4 ? idx : 0));
-            }
-            if (base == 0 && have0) issue_rows();             // ids have landed; image loads still in flight
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int idx = base + u * NT + tid;
-                if (idx < total4) st4(smem + 4 * idx, v[u]);
-            }
-        }
-    }
-    if (have0 && task + task_stride < ntasks) load_ids(task + task_stride);
-    __syncthreads();
-
-    for (; task < ntasks; task += task_stride) {
-        const int m = task * 16 + r;
-        int lds_off = 0;
-        if (!HOIST) asm volatile("" : "+v"(lds_off));
-        const float* lds = smem + lds_off;
-        const float* wq = lds + 4 * q;                            // this lane's 16-byte column slot
-        finish_rows();
-        // first-order term: categorical weights (every q lane holds the same sum: count it once) +
-        // numeric Dense(1) partial (only lanes q<2 hold real numerics; the packed fo_num weights
-        // are zero beyond n_num)
-        float z1 = (q == 0) ? fo : 0.f;
+        // first-order weights: lane (r,q) fetches field q's, then field q+4's.  FOLD: the weight sits
+        // right behind the projected row (same 128-B line); else in the concatenated fo_all blocks.
         {
-            const float d = dot4(ld4(lds + LD::off_fn + 4 * (q & 1)), xn);
-            z1 += (q < 2) ? d : 0.f;
+#define V2_FO_PTR(g) (FOLD ? A.table[g] + (sid[g] * (unsigned)RS + KP) : A.fo_all + (A.fo_off[g] + sid[g]))
+            const float* pa = V2_FO_PTR(0);
+            if (G_EMB > 1) pa = q == 1 ? V2_FO_PTR(G_EMB > 1 ? 1 : 0) : pa;
+            if (G_EMB > 2) pa = q == 2 ? V2_FO_PTR(G_EMB > 2 ? 2 : 0) : pa;
+            if (G_EMB > 3) pa = q == 3 ? V2_FO_PTR(G_EMB > 3 ? 3 : 0) : pa;
+            w1a = *pa;                                        // lanes q >= G_EMB re-read field 0's (dropped below)
+            if (G_EMB > 4) {
+                const float* pb = V2_FO_PTR(G_EMB > 4 ? 4 : 0);
+                if (G_EMB > 5) pb = q == 1 ? V2_FO_PTR(G_EMB > 5 ? 5 : 0) : pb;
+                if (G_EMB > 6) pb = q == 2 ? V2_FO_PTR(G_EMB > 6 ? 6 : 0) : pb;
+                if (G_EMB > 7) pb = q == 3 ? V2_FO_PTR(G_EMB > 7 ? 7 : 0) : pb;
+                w1b = *pb;
+            }
+#undef V2_FO_PTR
         }
+    };
 
-        // ---- per-field Dense projections (DeepFM_v2.py:106-120); accumulators start at the bias; two
-        //      fields run as alternating MFMA chains; W^T fragments are fetched one step ahead ----
-        f32x4 P[G][KPC];
+    // ---- compute stage operands (the gathered rows of the task being scored) ----
+    f32x4 P[G_EMB][KPC];                                  // per-field projections (FOLD: the gathered rows)
+    f32x4 pnum = zero;                                    // raw numerics of the task being scored
+    float z1 = 0.f;                                       // first-order partial of this lane
+    auto compute = [&](int tk) {
+        // Every LDS read is issued at least one MFMA group (>= 128 matrix-pipe cycles) before its first
+        // use, so a wave's MFMAs are back to back and the W^T fragment reads ride in their shadow.
+        constexpr int NK = G * KPC;                           // 16-wide K chunks of deep0: chunk kk of group g = g*KPC+kk
+        // numeric group first (its operand arrived with the ids): Dense projection (DeepFM_v2.py:118-120)
+        f32x4 wn[KPC], pn[KPC];
 #pragma unroll
         for (int nb = 0; nb < KPC; ++nb) {
-#pragma unroll
-            for (int g = 0; g < G; ++g) P[g][nb] = ld4(wq + LD::off_bp + g * KP + nb * 16);
-            constexpr int NPAIR = G_EMB / 2;
-            f32x4 a0 = ld4(wq + LD::off_wp + (0 * KP + nb * 16 + r) * LD::SP);
-            f32x4 a1 = ld4(wq + LD::off_wp + ((G_EMB > 1 ? 1 : 0) * KP + nb * 16 + r) * LD::SP);
-#pragma unroll
-            for (int c = 0; c < DPC; ++c) {
-#pragma unroll
-                for (int pr = 0; pr < NPAIR; ++pr) {
-                    const int g = 2 * pr;
-                    // next fragment pair: (same c, next pair) or (next c, first pair)
-                    const int ng = (pr + 1 < NPAIR) ? g + 2 : 0;
-                    const int nc = (pr + 1 < NPAIR) ? c : c + 1;
-                    f32x4 b0 = a0, b1 = a1;
-                    if (nc < DPC) {
-                        a0 = ld4(wq + LD::off_wp + (ng * KP + nb * 16 + r) * LD::SP + 16 * nc);
-                        a1 = ld4(wq + LD::off_wp + ((ng + 1) * KP + nb * 16 + r) * LD::SP + 16 * nc);
-                    }
-                    mfma4x2(b0, x[g][c], P[g][nb], b1, x[g + 1][c], P[g + 1][nb]);
-                }
-            }
-            if (G_EMB & 1) {
-                constexpr int g = G_EMB - 1;
-#pragma unroll
-                for (int c = 0; c < DPC; ++c) {
-                    const f32x4 a = ld4(wq + LD::off_wp + (g * KP + nb * 16 + r) * LD::SP + 16 * c);
-                    P[g][nb] = mfma4(a, x[g][c], P[g][nb]);
-                }
-            }
-            const f32x4 an = ld4(wq + LD::off_wn + (nb * 16 + r) * LD::SN);
-            P[G_EMB][nb] = mfma4(an, xn, P[G_EMB][nb]);
+            wn[nb] = ld4(wq + LD::off_wn + (nb * 16 + r) * LD::SN);
+            pn[nb] = ld4(wq + LD::off_bp + G_EMB * KP + nb * 16);       // bias = initial accumulator
         }
-
-        // x is dead: issue the next task's row gathers (its ids arrived during the projections) and
-        // the ids of the task after that; both stay in flight under FM / deep0 / deep1 and are only
-        // consumed by finish_rows() at the top of the next iteration
-        const float z1_keep = z1;
-        if (task + task_stride < ntasks) {                    // wave-uniform
-            issue_rows();
-            if (task + 2 * task_stride < ntasks) load_ids(task + 2 * task_stride);
-        }
-
-        // ---- FM cross (sum)^2 - sum(squares) over the G fields (DeepFM_v2.py:147-152) + its output weights ----
-        float z = 0.f;
-#pragma unroll
-        for (int nb = 0; nb < KPC; ++nb) {
-            f32x4 s = zero, sq = zero;
-#pragma unroll
-            for (int g = 0; g < G; ++g) {
-                s += P[g][nb];
-                sq += P[g][nb] * P[g][nb];
-            }
-            const f32x4 fm = s * s - sq;
-            z += dot4(ld4(wq + LD::off_hfm + nb * 16), fm);
-        }
-
-        // ---- deep0: Dense(relu) over the flattened projections (DeepFM_v2.py:124-125); pairs of
-        //      n-blocks as alternating chains, W^T fragments double-buffered ----
         f32x4 h0[H0C];
 #pragma unroll
         for (int n0 = 0; n0 < H0C; ++n0) h0[n0] = ld4(wq + LD::off_b0 + n0 * 16);
+        const float* w0r = wq + LD::off_w0 + r * LD::S0;     // W0^T row (n0*16 + r), chunk c: w0r + n0*16*S0 + 16*c
+        f32x4 a[H0C], an[H0C];
 #pragma unroll
-        for (int n0 = 0; n0 < H0C; n0 += 2) {
-            const float* w0a = wq + LD::off_w0 + (n0 * 16 + r) * LD::S0;
-            const float* w0b = wq + LD::off_w0 + ((n0 + 1) * 16 + r) * LD::S0;
-            f32x4 a0 = ld4(w0a), a1 = ld4(w0b);
+        for (int n0 = 0; n0 < H0C; ++n0) a[n0] = ld4(w0r + n0 * 16 * LD::S0 + 16 * (G_EMB * KPC));
+        const f32x4 wfn = ld4(smem + LD::off_fn + 4 * (q & 1));
 #pragma unroll
-            for (int k = 0; k < G * KPC; ++k) {
-                f32x4 b0 = a0, b1 = a1;
-                if (k + 1 < G * KPC) {
-                    a0 = ld4(w0a + 16 * (k + 1));
-                    a1 = ld4(w0b + 16 * (k + 1));
-                }
-                mfma4x2(b0, P[k / KPC][k % KPC], h0[n0], b1, P[k / KPC][k % KPC], h0[n0 + 1]);
+        for (int nb = 0; nb < KPC; ++nb) pn[nb] = mfma4(wn[nb], pnum, pn[nb]);
+        // first-order: categorical weights gathered by this lane + numeric Dense(1) partial (lanes q<2
+        // hold real numerics; the packed fo_num weights are zero beyond n_num)
+        float zz = z1 + ((q < 2) ? dot4(wfn, pnum) : 0.f);
+        // FM cross (sum)^2 - sum(squares) (DeepFM_v2.py:147-152) and deep0 = Dense(relu) over the
+        // flattened projections (DeepFM_v2.py:124-125), accumulated chunk by chunk: numerics, then fields
+        f32x4 s[KPC], sq[KPC];
+#pragma unroll
+        for (int c = 0; c < NK; ++c) {
+            const int cc = (c < KPC) ? G_EMB * KPC + c : c - KPC;     // chunk processed at step c
+            const int cn = (c + 1 < KPC) ? G_EMB * KPC + c + 1 : c + 1 - KPC;
+            if (c + 1 < NK) {
+#pragma unroll
+                for (int n0 = 0; n0 < H0C; ++n0) an[n0] = ld4(w0r + n0 * 16 * LD::S0 + 16 * cn);
             }
-        }
+            const f32x4 p = (c < KPC) ? pn[c] : P[(c - KPC) / KPC][(c - KPC) % KPC];
+            const int nb = cc % KPC;
+            if (c < KPC) { s[nb] = p; sq[nb] = p * p; }
+            else { s[nb] += p; sq[nb] += p * p; }
 #pragma unroll
-        for (int n0 = 0; n0 < H0C; ++n0) h0[n0] = relu4(h0[n0]);
-
-        // ---- deep1: Dense(relu) (DeepFM_v2.py:126) + output weights ----
+            for (int n0 = 0; n0 < H0C; n0 += 2) mfma4x2(a[n0], p, h0[n0], a[n0 + 1], p, h0[n0 + 1]);
+#pragma unroll
+            for (int n0 = 0; n0 < H0C; ++n0) a[n0] = an[n0];
+        }
+        // deep1 operands, fetched under the last deep0 groups
+        f32x4 w1f[H1C][H0C], acc1[H1C], hd[H1C], hfm[KPC];
 #pragma unroll
         for (int n1 = 0; n1 < H1C; ++n1) {
-            f32x4 acc = ld4(wq + LD::off_b1 + n1 * 16);
-            f32x4 wv[H0C];
+            acc1[n1] = ld4(wq + LD::off_b1 + n1 * 16);
+            hd[n1] = ld4(wq + LD::off_hd + n1 * 16);
 #pragma unroll
-            for (int j = 0; j < H0C; ++j) wv[j] = ld4(wq + LD::off_w1 + (n1 * 16 + r) * LD::S1 + 16 * j);
-#pragma unroll
-            for (int j = 0; j < H0C; ++j) acc = mfma4(wv[j], h0[j], acc);
-            z += dot4(ld4(wq + LD::off_hd + n1 * 16), relu4(acc));
+            for (int j = 0; j < H0C; ++j) w1f[n1][j] = ld4(wq + LD::off_w1 + (n1 * 16 + r) * LD::S1 + 16 * j);
         }
-
-        // ---- output layer: concat([first, fm, deep]) . w + b -> sigmoid (DeepFM_v2.py:154-155) ----
-        z += A.h0w * z1_keep;
+#pragma unroll
+        for (int nb = 0; nb < KPC; ++nb) hfm[nb] = ld4(wq + LD::off_hfm + nb * 16);
+        float z = 0.f;
+#pragma unroll
+        for (int nb = 0; nb < KPC; ++nb) z += dot4(hfm[nb], s[nb] * s[nb] - sq[nb]);
+#pragma unroll
+        for (int n0 = 0; n0 < H0C; ++n0) h0[n0] = relu4(h0[n0]);
+        // deep1: Dense(relu) (DeepFM_v2.py:126) + output weights
+#pragma unroll
+        for (int n1 = 0; n1 < H1C; ++n1) {
+#pragma unroll
+            for (int j = 0; j < H0C; ++j) acc1[n1] = mfma4(w1f[n1][j], h0[j], acc1[n1]);
+            z += dot4(hd[n1], relu4(acc1[n1]));
+        }
+        // output layer: concat([first, fm, deep]) . w + b -> sigmoid (DeepFM_v2.py:154-155)
+        z += A.h0w * zz;
         z += __shfl_xor(z, 16);
         z += __shfl_xor(z, 32);
+        const int m = tk * 16 + r;
         if (q == 0 && m < B) out[m] = sigmoidf_acc(z + A.h0w * A.fo_bias + A.head_bias);
+    };
+
+    // ---- prologue: ids first, then the weight image (independent of the ids, so both are in flight
+    //      together with the row gathers) ----
+    if (A.flags & 32) return;                                 // experiment: launch cost only
+    trace_stamp<TRACE>(A.trace, wave_global, 0, false);       // entry
+    if (TRACE && A.trace && lane == 0) A.trace[(size_t)wave_global * 16 + 8] = wall_clock64();
+    int cur = wave_global, prev = -1;
+    if (cur < ntasks) ld_raw(cur);
+    if (A.flags & 4) {                                        // experiment: wake the matrix pipe while the ids are in flight
+        f32x4 acc = zero;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(1.0f, (float)lane, acc, 0, 0, 0);
+        asm volatile("" ::"v"(acc));
     }
-    if (badmask != 0 && lane == 0) atomicOr(err, 1);
+    trace_stamp<TRACE>(A.trace, wave_global, 1, true);        // trace only: ids/numerics block landed
+    bool first = true;
+    for (;;) {
+        const bool have_cur = cur < ntasks;                   // wave-uniform
+        if (have_cur) {
+            gather(cur);                                      // its ids arrived during the previous compute
+            if (cur + task_stride < ntasks) ld_raw(cur + task_stride);
+            if (prev == wave_global) trace_stamp<TRACE>(A.trace, wave_global, 11, false);   // second task's rows issued
+        }
+        if (first) {                                          // every wave of the workgroup passes here once
+            trace_stamp<TRACE>(A.trace, wave_global, 2, false);   // rows issued
+            // weight image -> LDS by LDS-DMA (no VGPRs, no ds_write pass): 1-KB pieces, wave w takes w, w+WAVES, ...
+            // (issued after the row gathers so that the ids wait above did not have to drain it)
+#pragma unroll 1
+            for (int c = wave; c < LD::total_pad / 256; c += WAVES)
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void*)(image + c * 256 + lane * 4),
+                    (__attribute__((address_space(3))) void*)(smem + c * 256), 16, 0, 0);
+            trace_stamp<TRACE>(A.trace, wave_global, 3, false);   // image copy issued by this wave
+            __syncthreads();                                      // (drains this wave's DMA and gathers first)
+            trace_stamp<TRACE>(A.trace, wave_global, 4, false);   // weight image staged by the whole workgroup
+            first = false;
+        }
+        if (prev >= 0) {
+            if (A.flags & 8) {                                    // experiment: no compute stage, keep the gathered data live
+                float zz = z1 + pnum.x;
+#pragma unroll
+                for (int g = 0; g < G_EMB; ++g) zz += P[g][0].x + P[g][0].w;
+                const int m = prev * 16 + r;
+                if (q == 0 && m < B) out[m] = zz;
+            } else
+            compute(prev);
+            if (prev == wave_global) trace_stamp<TRACE>(A.trace, wave_global, 6, false);                 // first task scored
+            else if (prev == wave_global + task_stride) trace_stamp<TRACE>(A.trace, wave_global, 10, false);   // second
+        }
+        if (!have_cur) break;
+        if (prev < 0) trace_stamp<TRACE>(A.trace, wave_global, 5, true);   // trace only: first task's rows landed
+        // hand the gathered rows to the compute stage
+        if (FOLD) {
+#pragma unroll
+            for (int g = 0; g < G_EMB; ++g)
+#pragma unroll
+                for (int nb = 0; nb < KPC; ++nb) P[g][nb] = x[g][nb < XC ? nb : 0];
+        } else {
+            // per-field Dense projections (DeepFM_v2.py:106-117): accumulators start at the bias
+#pragma unroll
+            for (int nb = 0; nb < KPC; ++nb)
+#pragma unroll
+                for (int g = 0; g < G_EMB; ++g) {
+                    f32x4 acc = ld4(wq + LD::off_bp + g * KP + nb * 16);
+#pragma unroll
+                    for (int c = 0; c < XC; ++c)
+                        acc = mfma4(ld4(wq + LD::off_wp + (g * KP + nb * 16 + r) * LD::SP + 16 * c), x[g][c], acc);
+                    P[g][nb] = acc;
+                }
+        }
+        pnum = xn;
+        z1 = ((q < G_EMB) ? w1a : 0.f) + ((q + 4 < G_EMB) ? w1b : 0.f);
+        prev = cur;
+        cur += task_stride;
+    }
+    trace_stamp<TRACE>(A.trace, wave_global, 7, true);
+    if (TRACE && A.trace && lane == 0) A.trace[(size_t)wave_global * 16 + 9] = wall_clock64();
+    if (__ballot(bad) != 0 && lane == 0) atomicOr(err, 1);
 }

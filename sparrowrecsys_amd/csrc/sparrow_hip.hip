@@ -538,6 +538,9 @@ struct sprk_engine {
     size_t v2_lds_bytes = 0;
     int v2_grid_cap = 0;
     float* v2_image = nullptr;     // pre-packed LDS weight image (device)
+    float* v2_fo_all = nullptr;    // concatenated first-order weight blocks (device)
+    float* v2_folded[V2_MAX_FIELDS] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // projected tables (device)
+    size_t v2_fo_floats = 0;
 };
 
 namespace {
@@ -653,35 +656,46 @@ int validate_plan(const sprk_plan& p) {
 }
 
 
-// ---- fast-path dispatch table for k_deepfm_v2_chain<G_EMB, DV, KPC, H0C, H1C, WAVES> ----
+// ---- fast-path dispatch table for k_deepfm_v2_chain<G_EMB, DV, KPC, H0C, H1C, WAVES, FOLD, TRACE> ----
 constexpr int V2_WAVES = 8;
+typedef void (*V2LaunchFn)(const V2Run&, const int*, const float*, float*, int, int*, const float*, int, size_t, hipStream_t);
 struct V2Variant {
-    int g_emb, dv, kpc, h0c, h1c;
-    bool hoist;
+    int g_emb, dv, kpc, h0c, h1c;     // dv is ignored for FOLD variants (they gather KP-wide projected rows)
+    bool fold;
     const void* fn;
+    const void* fn_trace;             // TRACE instantiation (diagnostics), or NULL
     size_t lds_bytes;
-    void (*launch)(const V2Run&, const int*, const float*, float*, int, int*, const float*, int, size_t, hipStream_t);
+    V2LaunchFn launch, launch_trace;
     void (*pack)(const V2Args&, float*);
 };
-template <int G_EMB, int DV, int KPC, int H0C, int H1C, bool HOIST>
+template <int G_EMB, int DV, int KPC, int H0C, int H1C, bool FOLD, bool TRACE>
 void v2_launch(const V2Run& a, const int* ids, const float* dense, float* out, int B, int* err, const float* image,
                int grid, size_t lds, hipStream_t st) {
-    hipLaunchKernelGGL((k_deepfm_v2_chain<G_EMB, DV, KPC, H0C, H1C, V2_WAVES, HOIST>), dim3(grid), dim3(V2_WAVES * 64), lds, st,
+    hipLaunchKernelGGL((k_deepfm_v2_chain<G_EMB, DV, KPC, H0C, H1C, V2_WAVES, FOLD, TRACE>), dim3(grid), dim3(V2_WAVES * 64), lds, st,
                        a, ids, dense, out, B, err, image);
 }
-template <int G_EMB, int DV, int KPC, int H0C, int H1C>
+template <int G_EMB, int DV, int KPC, int H0C, int H1C, bool FOLD>
 void v2_pack(const V2Args& a, float* image) {
-    hipLaunchKernelGGL((k_v2_pack_image<G_EMB, DV, KPC, H0C, H1C>), dim3(1), dim3(256), 0, 0, a, image);
+    hipLaunchKernelGGL((k_v2_pack_image<G_EMB, DV, KPC, H0C, H1C, FOLD>), dim3(1), dim3(256), 0, 0, a, image);
 }
-#define V2_VARIANT(G_EMB, DV, KPC, H0C, H1C, HOIST)                                                        \
-    {G_EMB, DV, KPC, H0C, H1C, HOIST, reinterpret_cast<const void*>(&k_deepfm_v2_chain<G_EMB, DV, KPC, H0C, H1C, V2_WAVES, HOIST>), \
-     sizeof(float) * V2Lds<G_EMB, DV, KPC, H0C, H1C>::total, &v2_launch<G_EMB, DV, KPC, H0C, H1C, HOIST>,               \
-     &v2_pack<G_EMB, DV, KPC, H0C, H1C>}
+#define V2_LDS(G_EMB, DV, KPC, H0C, H1C, FOLD) \
+    (sizeof(float) * (V2Lds<G_EMB, DV, KPC, H0C, H1C, FOLD>::total_pad + V2_WAVES * V2Lds<G_EMB, DV, KPC, H0C, H1C, FOLD>::stage_floats))
+#define V2_VARIANT(G_EMB, DV, KPC, H0C, H1C, FOLD)                                                                     \
+    {G_EMB, DV, KPC, H0C, H1C, FOLD,                                                                                   \
+     reinterpret_cast<const void*>(&k_deepfm_v2_chain<G_EMB, DV, KPC, H0C, H1C, V2_WAVES, FOLD, false>), nullptr,      \
+     V2_LDS(G_EMB, DV, KPC, H0C, H1C, FOLD), &v2_launch<G_EMB, DV, KPC, H0C, H1C, FOLD, false>, nullptr,               \
+     &v2_pack<G_EMB, DV, KPC, H0C, H1C, FOLD>}
+#define V2_VARIANT_TRACED(G_EMB, DV, KPC, H0C, H1C, FOLD)                                                              \
+    {G_EMB, DV, KPC, H0C, H1C, FOLD,                                                                                   \
+     reinterpret_cast<const void*>(&k_deepfm_v2_chain<G_EMB, DV, KPC, H0C, H1C, V2_WAVES, FOLD, false>),               \
+     reinterpret_cast<const void*>(&k_deepfm_v2_chain<G_EMB, DV, KPC, H0C, H1C, V2_WAVES, FOLD, true>),                \
+     V2_LDS(G_EMB, DV, KPC, H0C, H1C, FOLD), &v2_launch<G_EMB, DV, KPC, H0C, H1C, FOLD, false>,                        \
+     &v2_launch<G_EMB, DV, KPC, H0C, H1C, FOLD, true>, &v2_pack<G_EMB, DV, KPC, H0C, H1C, FOLD>}
 const V2Variant kV2Variants[] = {
-    V2_VARIANT(6, 4, 1, 2, 1, false),   // BASELINE config 2: 6 fields, D=16, projection 16, deep 32-16
-    V2_VARIANT(6, 4, 1, 2, 1, true),
-    V2_VARIANT(4, 4, 1, 2, 1, false),   // 4 fields, D=16
-    V2_VARIANT(4, 16, 1, 2, 1, false),  // config-4 shape: 4 fields, D=64, projection 16
+    V2_VARIANT_TRACED(6, 4, 1, 2, 1, true),   // BASELINE config 2: 6 fields, projection 16 (folded into the tables), deep 32-16
+    V2_VARIANT(6, 4, 1, 2, 1, false),         // ... with the projections computed per sample (D=16)
+    V2_VARIANT(4, 4, 1, 2, 1, true),          // 4 fields, projection 16 (config-4 shape gathers 64-B projected rows instead of 256-B)
+    V2_VARIANT(4, 4, 1, 2, 1, false),         // 4 fields, D=16
 };
 
 // Recognise the plan models.DeepFMv2 emits (DeepFM_v2.py graph) and fill the fused kernel's arguments.
@@ -693,6 +707,7 @@ bool match_v2_chain(sprk_engine* h) {
     int g_emb = 0;
     while (g_emb < p.n_segs && p.segs[g_emb].kind == SPRK_SEG_ROWS) ++g_emb;
     if (g_emb < 1 || g_emb > V2_MAX_FIELDS) return false;
+    if (p.n_id_cols > 8 || p.n_dense > 8 || p.n_dense < 1) return false;   // one 16-B/lane load stages a task's ids+numerics
     const int Dp = p.segs[0].row_stride;
     for (int g = 0; g < g_emb; ++g) {
         const sprk_seg& s = p.segs[g];
@@ -754,29 +769,42 @@ bool match_v2_chain(sprk_engine* h) {
     a.h0w = t0.scale; a.fo_bias = t0.bias + t1.bias; a.head_bias = p.head_bias;
     a.F = p.n_id_cols; a.ND = p.n_dense; a.n_num = n_num; a.n_fo = n_fo;
     const int dv = Dp / 4, kpc = Kp / 16, h0c = d0.N / 16, h1c = d1.N / 16;
-    const char* mode = getenv("SPRK_V2_HOIST");          // A/B switch: "1" = register-resident weights
-    const bool want_hoist = mode && mode[0] == '1';
+    // fold the per-field projections into the tables when that never widens a gathered row
+    const char* fmode = getenv("SPRK_V2_FOLD");              // A/B switch: "0" = compute projections per sample
+    const bool want_fold = Kp <= Dp && !(fmode && fmode[0] == '0');
+    // the fused kernel reads ONE id per field for both the embedding row and the first-order
+    // weight: the two field lists must be the same set of ids columns
+    if (n_fo != g_emb) return false;
     for (size_t v = 0; v < sizeof(kV2Variants) / sizeof(kV2Variants[0]); ++v) {
         const V2Variant& vv = kV2Variants[v];
-        if (vv.hoist != want_hoist) continue;
-        if (vv.g_emb == g_emb && vv.dv == dv && vv.kpc == kpc && vv.h0c == h0c && vv.h1c == h1c) {
-            // the fused kernel reads ONE id per field for both the embedding row and the first-order
-            // weight: the two field lists must be the same set of ids columns
-            if (n_fo != g_emb) return false;
+        if (vv.fold != want_fold) continue;
+        if (vv.g_emb == g_emb && (vv.fold || vv.dv == dv) && vv.kpc == kpc && vv.h0c == h0c && vv.h1c == h1c) {
             V2Run run;
             memset(&run, 0, sizeof(run));
+            size_t fo_floats = 0;
             for (int g = 0; g < g_emb; ++g) {
                 int hit = -1;
                 for (int i = 0; i < n_fo; ++i)
                     if (a.fo_col[i] == a.emb_col[g] && a.fo_vocab[i] == a.emb_vocab[g]) hit = i;
                 if (hit < 0) return false;
                 run.col[g] = a.emb_col[g]; run.vocab[g] = a.emb_vocab[g];
-                run.table[g] = a.table[g]; run.w1[g] = a.w1[hit];
+                run.table[g] = a.table[g];
+                run.fo_off[g] = (unsigned)fo_floats;
+                fo_floats += (size_t)a.emb_vocab[g] + 1;
             }
+            if (fo_floats >= ((size_t)1 << 31)) return false;
+            // w1 pointers in embedding-group order
+            const float* w1g[V2_MAX_FIELDS];
+            for (int g = 0; g < g_emb; ++g) {
+                for (int i = 0; i < n_fo; ++i)
+                    if (a.fo_col[i] == a.emb_col[g] && a.fo_vocab[i] == a.emb_vocab[g]) w1g[g] = a.w1[i];
+            }
+            for (int g = 0; g < g_emb; ++g) a.w1[g] = w1g[g];
             run.F = a.F; run.ND = a.ND; run.n_num = a.n_num;
             run.h0w = a.h0w; run.fo_bias = a.fo_bias; run.head_bias = a.head_bias;
             h->v2run = run;
             h->v2 = a;
+            h->v2_fo_floats = fo_floats;
             h->v2_variant = (int)v;
             h->v2_lds_bytes = vv.lds_bytes;
             return true;
@@ -951,13 +979,34 @@ int sprk_finalize(sprk_handle h) {
             const V2Variant& vv = kV2Variants[h->v2_variant];
             HIP_TRY(hipFuncSetAttribute(vv.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)vv.lds_bytes));
             int per_cu = (int)(160 * 1024 / vv.lds_bytes);
-            const int by_regs = (vv.hoist ? 2 : 4) * 4 / V2_WAVES;   // waves/SIMD the launch bounds allow
+            if (vv.fn_trace) HIP_TRY(hipFuncSetAttribute(vv.fn_trace, hipFuncAttributeMaxDynamicSharedMemorySize, (int)vv.lds_bytes));
+            const int by_regs = 4 * 4 / V2_WAVES;                    // waves/SIMD the launch bounds allow
             if (per_cu > by_regs) per_cu = by_regs;
             const char* wg = getenv("SPRK_V2_WGS_PER_CU");           // tuning knob (1..by_regs)
             if (wg && wg[0] >= '1' && wg[0] <= '9' && (wg[0] - '0') < per_cu) per_cu = wg[0] - '0';
             if (per_cu < 1) per_cu = 1;
             h->v2_grid_cap = h->num_cus * per_cu;
+            { const char* gc = getenv("SPRK_V2_GRID_CAP"); if (gc && atoi(gc) > 0 && atoi(gc) < h->v2_grid_cap) h->v2_grid_cap = atoi(gc); }
+            // first-order weight blocks back to back, so one gather instruction can serve several fields
+            HIP_TRY(hipMalloc((void**)&h->v2_fo_all, h->v2_fo_floats * sizeof(float)));
+            for (int g = 0; g < vv.g_emb; ++g)
+                HIP_TRY(hipMemcpy(h->v2_fo_all + h->v2run.fo_off[g], h->v2.w1[g], ((size_t)h->v2run.vocab[g] + 1) * sizeof(float), hipMemcpyDeviceToDevice));
+            h->v2run.fo_all = h->v2_fo_all;
+            if (vv.fold) {
+                const int KP = vv.kpc * 16;
+                for (int g = 0; g < vv.g_emb; ++g) {
+                    const long long rows = (long long)h->v2run.vocab[g] + 1;
+                    HIP_TRY(hipMalloc((void**)&h->v2_folded[g], (size_t)rows * (KP + 16) * sizeof(float)));
+                    long long blocks = (rows * (KP + 16) + 255) / 256;
+                    if (blocks > 65536) blocks = 65536;
+                    hipLaunchKernelGGL(k_v2_fold, dim3((unsigned)blocks), dim3(256), 0, 0, h->v2.table[g], h->v2.ldp_emb,
+                                       h->v2.Wp[g], h->v2.ldp_emb, h->v2.bp[g], h->v2.w1[g], h->v2_folded[g], KP, rows);
+                    HIP_TRY(hipGetLastError());
+                    h->v2run.table[g] = h->v2_folded[g];
+                }
+            }
             HIP_TRY(hipMalloc((void**)&h->v2_image, vv.lds_bytes));
+            HIP_TRY(hipMemset(h->v2_image, 0, vv.lds_bytes));
             vv.pack(h->v2, h->v2_image);
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipDeviceSynchronize());
@@ -1014,7 +1063,11 @@ int sprk_forward(sprk_handle h, const int32_t* ids, const float* dense, float* o
         const int ntasks = (B + 15) / 16;
         int grid = (ntasks + V2_WAVES - 1) / V2_WAVES;
         if (grid > h->v2_grid_cap) grid = h->v2_grid_cap;
-        kV2Variants[h->v2_variant].launch(h->v2run, ids, dense, out, B, h->dev_err, h->v2_image, grid, h->v2_lds_bytes, st);
+        V2Run run = h->v2run;
+        run.flags = (((uintptr_t)ids | (uintptr_t)dense) & 15) ? 1 : 0;    // unaligned inputs: element-wise staging
+        { const char* xf = getenv("SPRK_V2_XFLAGS"); if (xf) run.flags |= atoi(xf); }   // experiment switches
+        const V2Variant& vv = kV2Variants[h->v2_variant];
+        (run.trace ? vv.launch_trace : vv.launch)(run, ids, dense, out, B, h->dev_err, h->v2_image, grid, h->v2_lds_bytes, st);
         HIP_TRY(hipGetLastError());
         return SPRK_OK;
     }
@@ -1053,12 +1106,25 @@ int sprk_check_ids(sprk_handle h, void* stream) {
     return SPRK_OK;
 }
 
+int sprk_debug_set_trace(sprk_handle h, void* dev_buf, size_t bytes) {
+    if (!h) return fail(SPRK_EINVAL, "handle is NULL");
+    if (!h->finalized) return fail(SPRK_ESTATE, "set_trace before finalize");
+    if (h->v2_variant < 0 || !kV2Variants[h->v2_variant].launch_trace) return fail(SPRK_EKIND, "handle does not run a traceable kernel");
+    if (dev_buf && bytes < (size_t)h->v2_grid_cap * V2_WAVES * 16 * sizeof(unsigned long long))
+        return fail(SPRK_EINVAL, "trace buffer too small: %zu bytes for %d waves", bytes, h->v2_grid_cap * V2_WAVES);
+    h->v2run.trace = (unsigned long long*)dev_buf;
+    return SPRK_OK;
+}
+
 void sprk_destroy(sprk_handle h) {
     if (!h) return;
     for (void* p : h->slot_ptr)
         if (p) (void)hipFree(p);
     if (h->dev_plan) (void)hipFree(h->dev_plan);
     if (h->v2_image) (void)hipFree(h->v2_image);
+    if (h->v2_fo_all) (void)hipFree(h->v2_fo_all);
+    for (float* p : h->v2_folded)
+        if (p) (void)hipFree(p);
     if (h->dev_err) (void)hipFree(h->dev_err);
     delete h;
 }

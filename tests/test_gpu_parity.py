@@ -1,7 +1,7 @@
 """Parity tests proper (``-m gpu``): the HIP path, called through the C ABI, against the oracle and
 the committed golden vectors.  Bar: bit-exact for index/integer work (row gather, cross hash),
 <= 1e-4 absolute on the post-sigmoid score for floating point (BASELINE.json north_star); the
-asserts below use a tighter 1e-5 because both sides are fp32-class on these inputs."""
+asserts below use a tighter 3e-5 because both sides are fp32-class on these inputs."""
 import os
 
 import numpy as np
@@ -17,7 +17,7 @@ from tests.golden.make_golden import SEEDS, make_model
 pytestmark = pytest.mark.gpu
 
 TOL = 1e-4        # the stated bar
-TIGHT = 1e-5      # what we actually hold on non-saturating inputs
+TIGHT = 3e-5      # what we actually hold on non-saturating inputs (fp32 summation-order noise is ~1e-5)
 
 
 @pytest.fixture(scope="module")
@@ -281,10 +281,10 @@ def test_concurrent_streams_share_a_handle(torch, config2):
 # --------------------------------------------------------------------------------------------
 # the three execution paths of the DeepFM_v2 graph must agree with the oracle and with each other
 # --------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("env", [{}, {"SPRK_V2_HOIST": "1"}, {"SPRK_FORCE_INTERPRETER": "1"}],
-                         ids=["chain", "chain-hoist", "interpreter"])
+@pytest.mark.parametrize("env", [{}, {"SPRK_V2_FOLD": "0"}, {"SPRK_FORCE_INTERPRETER": "1"}],
+                         ids=["chain-folded", "chain-unfolded", "interpreter"])
 def test_deepfm_v2_execution_paths(torch, env, monkeypatch):
-    for k in ("SPRK_V2_HOIST", "SPRK_FORCE_INTERPRETER"):
+    for k in ("SPRK_V2_FOLD", "SPRK_FORCE_INTERPRETER"):
         monkeypatch.delenv(k, raising=False)
     for k, v in env.items():
         monkeypatch.setenv(k, v)
@@ -303,3 +303,30 @@ def test_deepfm_v2_execution_paths(torch, env, monkeypatch):
         p2 = m2.predict(f2)[:, 0]
         r2 = O.deepfm_v2_forward(f2, m2.weights, dtype=np.float64, fields=fields, order=[k for k, _, _ in fields])[:, 0]
         assert np.abs(p2 - r2).max() <= TIGHT
+
+
+def test_deepfm_v2_folded_tables_do_not_change_scores(torch, monkeypatch):
+    """Folding the per-field Dense projections into the tables at finalize (k_v2_fold) must give the
+    scores of the per-sample projection path (same fmaf order; we hold 1e-6, normally bit-equal)."""
+    B = 20000
+    feats = SY.synth_fields(B, SY.CONFIG2_FIELDS, seed=91)
+    outs = []
+    for fold in ("1", "0"):
+        monkeypatch.setenv("SPRK_V2_FOLD", fold)
+        monkeypatch.delenv("SPRK_FORCE_INTERPRETER", raising=False)
+        model = M.DeepFMv2(seed=43, emb_dim=16, fields=SY.CONFIG2_FIELDS, proj_dim=16)
+        outs.append(model.predict(feats)[:, 0])
+    assert np.abs(outs[0] - outs[1]).max() <= 1e-6
+
+
+def test_deepfm_v2_unaligned_views_and_tails(torch, config2):
+    """ids/dense views that do not start on a 16-byte boundary take the element-wise staging path;
+    every batch length mod 16 exercises the partial last task.  Pure data movement: bit-equal."""
+    model, feats, ids, dense = config2
+    p = model.predict_device(ids, dense)
+    for lo in (1, 2, 3, 5):
+        vi, vd = ids[lo:lo + 4099], dense[lo:lo + 4099]          # views, not copies
+        assert vi.is_contiguous() and vd.is_contiguous()
+        assert torch.equal(model.predict_device(vi, vd), p[lo:lo + 4099])
+    for n in range(1, 34):
+        assert torch.equal(model.predict_device(ids[:n].contiguous(), dense[:n].contiguous()), p[:n])
