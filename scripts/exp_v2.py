@@ -19,7 +19,7 @@ def make(env):
     import torch
     torch.cuda.init()
     from sparrowrecsys_amd import models as M, synthetic as SY
-    for k in ("SPRK_V2_XFLAGS", "SPRK_V2_GRID_CAP", "SPRK_V2_FOLD", "SPRK_V2_WGS_PER_CU", "SPRK_FORCE_INTERPRETER", "SPRK_V2_PRIO", "SPRK_V2_WAVES"):
+    for k in ("SPRK_V2_REG", "SPRK_V2_XFLAGS", "SPRK_V2_GRID_CAP", "SPRK_V2_FOLD", "SPRK_V2_WGS_PER_CU", "SPRK_FORCE_INTERPRETER", "SPRK_V2_PRIO", "SPRK_V2_WAVES"):
         os.environ.pop(k, None)
     os.environ.update({k: str(v) for k, v in env.items()})
     model = M.DeepFMv2(seed=101, emb_dim=16, fields=SY.CONFIG2_FIELDS, proj_dim=16)
@@ -61,10 +61,10 @@ def inputs(model, B, nb=4, dist="uniform"):
 
 def sweep():
     variants = [
-        ("fold", {}),
-        ("nocompute", {"SPRK_V2_XFLAGS": 8}),
-        ("hotrow", {"SPRK_V2_XFLAGS": 16}),
-        ("fold,1wg", {"SPRK_V2_WGS_PER_CU": 1}),
+        ("reg", {}),
+        ("reg,hotrow", {"SPRK_V2_XFLAGS": 16}),
+        ("reg,nocompute", {"SPRK_V2_XFLAGS": 8}),
+        ("unfolded", {"SPRK_V2_FOLD": 0}),
     ]
     sizes = [16384, 65536, 262144, 1048576]
     # clock ramp check: the same launch timed over longer and longer runs

@@ -97,6 +97,19 @@ __device__ __forceinline__ f32x4 relu4(f32x4 v) {
     return f32x4{fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f)};
 }
 
+// single-instruction ReLU: v_med3_f32(v, 0, +inf) (fmaxf() first canonicalises its operand with a second
+// v_max; an inline-asm v_max would hide the VALU-write -> MFMA-read hazard from the compiler)
+__device__ __forceinline__ float relu1_fast(float v) {
+    return __builtin_amdgcn_fmed3f(v, 0.f, __builtin_inff());
+}
+__device__ __forceinline__ f32x4 relu4_fast(f32x4 v) {
+    return f32x4{relu1_fast(v.x), relu1_fast(v.y), relu1_fast(v.z), relu1_fast(v.w)};
+}
+// 1/(1+exp(-z)) on the hardware exp2/rcp units (4 VALU instructions; |err| < 3e-7 absolute on the score)
+__device__ __forceinline__ float sigmoidf_fast(float z) {
+    return __builtin_amdgcn_rcpf(1.0f + __expf(-z));
+}
+
 // One-time (finalize) kernel: lays every weight out exactly as the fused kernel wants it in LDS
 // (padded row strides, zero fill), so the per-launch staging is a flat copy.
 template <int G_EMB, int DV, int KPC, int H0C, int H1C, bool FOLD>
@@ -117,24 +130,29 @@ __global__ __launch_bounds__(256) void k_v2_pack_image(const V2Args A, float* __
     stage_vector(lds + LD::off_hfm, KP, A.hfm, A.n_hfm, tid, NT);
     stage_vector(lds + LD::off_hd, H1C * 16, A.hdeep, A.n_hdeep, tid, NT);
     stage_vector(lds + LD::off_fn, 8, A.fo_num_w, A.n_num, tid, NT);
+    if (FOLD) {                                               // FOLD kernels expect h0w * fo_num (see k_v2_fold)
+        __syncthreads();
+        if (tid < 8) lds[LD::off_fn + tid] *= A.h0w;
+    }
 }
 
 // One-time (finalize) kernel: projected table P[v][n] = bp[n] + sum_k Wp^T[n][k] * table[v][k],
 // v in [0, rows) (the last row of `table` is the all-zero "missing id" row, so P's last row is the
 // bias).  The k order is the one the in-kernel MFMA chain uses (within each 16-chunk: k = 4q+s for
 // s outer, q inner), one fmaf per term, so folding does not change a single bit of P_g.
-// Output rows are [P (KP floats) | first-order weight w1[v] | 15 zero floats]: with KP = 16 one
-// 128-byte L2 line holds everything the forward needs for an id, so a lookup costs one line fetch
-// instead of two (64-B row + the line around a 4-B first-order weight).
+// Output rows are [P (KP floats) | row scalar | 15 zero floats]: with KP = 16 one 128-byte L2 line
+// holds everything the forward needs for an id.  The row scalar collects every term of the logit
+// that depends on this id alone:
+//     h0w * w1[v]                      first-order weight times its output-layer weight
+//   - sum_n hfm[n] * P[v][n]^2         this field's share of the FM "sum of squares"
+// so the kernel only has to accumulate S = sum_g P_g for the FM cross.
 __global__ __launch_bounds__(256) void k_v2_fold(const float* __restrict__ table, int row_floats,
                                                  const float* __restrict__ Wp, int ldp, const float* __restrict__ bp,
-                                                 const float* __restrict__ w1, float* __restrict__ out, int KP,
-                                                 long long rows) {
+                                                 const float* __restrict__ w1, const float* __restrict__ hfm, int n_hfm,
+                                                 float h0w, float* __restrict__ out, int KP, long long rows) {
     const int OS = KP + 16;
-    const long long total = rows * OS;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        const long long v = i / OS;
-        const int n = (int)(i - v * OS);
+    for (long long v = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); v < rows; v += (long long)gridDim.x * 4) {
+        const int n = threadIdx.x & 63;                       // one wave per row, lane = output column
         float acc = 0.f;
         if (n < KP) {
             const float* x = table + v * row_floats;
@@ -146,10 +164,13 @@ __global__ __launch_bounds__(256) void k_v2_fold(const float* __restrict__ table
                         const int k = c + 4 * q + s;
                         if (k < row_floats) acc = fmaf(w[k], x[k], acc);
                     }
-        } else if (n == KP) {
-            acc = w1[v];
         }
-        out[i] = acc;
+        float sqw = (n < n_hfm && n < KP) ? hfm[n] * acc * acc : 0.f;
+        for (int d = 32; d >= 1; d >>= 1) sqw += __shfl_xor(sqw, d);
+        float* o = out + v * OS;
+        if (n < KP) o[n] = acc;
+        else if (n == KP) o[n] = h0w * w1[v] - sqw;
+        else if (n < OS) o[n] = 0.f;
     }
 }
 
@@ -159,8 +180,10 @@ struct V2Run {
     int col[V2_MAX_FIELDS];               // ids column of field g (embedding AND first-order weight)
     int vocab[V2_MAX_FIELDS];
     unsigned fo_off[V2_MAX_FIELDS];       // not FOLD: start of field g's block inside fo_all
-    const float* table[V2_MAX_FIELDS];    // FOLD: [vocab+1][KP+16] rows {P | w1 | 0..}, else [vocab+1][4*DV]
+    const float* table[V2_MAX_FIELDS];    // not FOLD: [vocab+1][4*DV] embedding tables
     const float* fo_all;                  // not FOLD: concatenated first-order blocks, each [vocab+1] (last entry 0)
+    const float* tab0;                    // FOLD: ONE buffer of [KP+16]-float rows {P | row scalar | 0..}, all fields back to back
+    unsigned rowbase[V2_MAX_FIELDS];      // FOLD: first row of field g inside tab0 (its block has vocab+1 rows)
     float h0w, fo_bias, head_bias;
     unsigned long long* trace;            // TRACE instantiation only: per-wave phase timestamps (sprk_debug_set_trace)
     int flags;                            // 1 = ids/dense not 16-byte aligned: stage element-wise
@@ -217,8 +240,14 @@ __device__ __forceinline__ void mfma4x2(f32x4 a0, f32x4 b0, f32x4& c0, f32x4 a1,
 // scores task i-1 whose rows were issued a trip earlier), which keeps the code small: at one
 // 16-sample task per wave (B = 65 536 fills the chip exactly once) every instruction runs once per
 // launch from a cold instruction cache.
-template <int G_EMB, int DV, int KPC, int H0C, int H1C, int WAVES, bool FOLD, bool TRACE>
-__global__ __launch_bounds__(WAVES * 64, 4) void k_deepfm_v2_chain(const V2Run A, const int* __restrict__ ids,
+//
+// REG: register-resident weights.  The wave copies its (r,q) slice of every W^T fragment from the LDS
+// image into VGPRs once (96 registers at config 2), runs at 2 waves per SIMD, and its scoring stage is
+// then pure MFMA issue -- four independent accumulator chains (deep0's two n-blocks x even/odd K
+// chunks) pinned in round-robin order by sched_barriers -- with no LDS traffic at all, so ONE wave
+// keeps the matrix pipe full while its SIMD partner gathers.
+template <int G_EMB, int DV, int KPC, int H0C, int H1C, int WAVES, bool FOLD, bool TRACE, bool REG>
+__global__ __launch_bounds__(WAVES * 64, REG ? 2 : 4) void k_deepfm_v2_chain(const V2Run A, const int* __restrict__ ids,
                                                                 const float* __restrict__ dense,
                                                                 float* __restrict__ out, int B,
                                                                 int* __restrict__ err,
@@ -231,6 +260,7 @@ __global__ __launch_bounds__(WAVES * 64, 4) void k_deepfm_v2_chain(const V2Run A
     constexpr int NT = WAVES * 64;
     static_assert(H0C % 2 == 0, "deep0 n-blocks are processed in interleaved pairs");
     static_assert(G_EMB >= 1 && G_EMB <= V2_MAX_FIELDS, "field count");
+    static_assert(FOLD == REG, "folded tables carry the row scalars only the register-resident scoring stage understands");
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -279,10 +309,10 @@ __global__ __launch_bounds__(WAVES * 64, 4) void k_deepfm_v2_chain(const V2Run A
 #pragma unroll
         for (int g = 0; g < G_EMB; ++g) {
             const int id = sid_row[A.col[g]];
-            const bool ok = (unsigned)id < (unsigned)A.vocab[g];
-            bad |= !ok && id != -1;
-            sid[g] = ok ? (unsigned)id : (unsigned)A.vocab[g];     // -> the zero row
-            if (A.flags & 16) sid[g] = 0;                          // experiment: every gather hits one hot row
+            bad |= (unsigned)(id + 1) > (unsigned)A.vocab[g];      // neither a table row nor the "missing" marker -1
+            sid[g] = min((unsigned)id, (unsigned)A.vocab[g]);      // -1 / out of range -> the zero row at index vocab
+            if (FOLD) sid[g] += A.rowbase[g];
+            if (A.flags & 16) sid[g] = FOLD ? A.rowbase[g] : 0;    // experiment: every gather hits one hot row
         }
         {
             const float* nrow = stage + 128 + r * A.ND;
@@ -293,34 +323,53 @@ __global__ __launch_bounds__(WAVES * 64, 4) void k_deepfm_v2_chain(const V2Run A
             xn.z = nrow[min(c0 + 2, last)];
             xn.w = nrow[min(c0 + 3, last)];
         }
+        if constexpr (FOLD) {
+            // one SGPR base + 32-bit byte offsets: row (sid << 7 for KP = 16), this lane's piece q << 4
+            const char* tb = reinterpret_cast<const char*>(A.tab0);
+            constexpr unsigned RB = RS * 4;                        // bytes per row
 #pragma unroll
-        for (int g = 0; g < G_EMB; ++g) {
-            const unsigned rowoff = sid[g] * (unsigned)RS;
+            for (int g = 0; g < G_EMB; ++g)
 #pragma unroll
-            for (int c = 0; c < XC; ++c) {
-                // this lane's 16-byte piece of the row; pieces past the row end re-read piece 0 and
-                // only ever meet zero weights
-                const unsigned o = (4 * c + 3 < XV || 4u * c + q < (unsigned)XV) ? rowoff + 16u * c + 4u * q : rowoff;
-                x[g][c] = ld4(A.table[g] + o);
-            }
-        }
-        // first-order weights: lane (r,q) fetches field q's, then field q+4's.  FOLD: the weight sits
-        // right behind the projected row (same 128-B line); else in the concatenated fo_all blocks.
-        {
-#define V2_FO_PTR(g) (FOLD ? A.table[g] + (sid[g] * (unsigned)RS + KP) : A.fo_all + (A.fo_off[g] + sid[g]))
-            const float* pa = V2_FO_PTR(0);
-            if (G_EMB > 1) pa = q == 1 ? V2_FO_PTR(G_EMB > 1 ? 1 : 0) : pa;
-            if (G_EMB > 2) pa = q == 2 ? V2_FO_PTR(G_EMB > 2 ? 2 : 0) : pa;
-            if (G_EMB > 3) pa = q == 3 ? V2_FO_PTR(G_EMB > 3 ? 3 : 0) : pa;
-            w1a = *pa;                                        // lanes q >= G_EMB re-read field 0's (dropped below)
+                for (int c = 0; c < XC; ++c)
+                    x[g][c] = *reinterpret_cast<const f32x4*>(tb + (sid[g] * RB + 64u * c + 16u * q));
+            // row scalars: lane (r,q) fetches field q's, then field q+4's (lanes beyond the field count are dropped at hand-off)
+            unsigned sa = sid[0];
+            if (G_EMB > 1) sa = q == 1 ? sid[G_EMB > 1 ? 1 : 0] : sa;
+            if (G_EMB > 2) sa = q == 2 ? sid[G_EMB > 2 ? 2 : 0] : sa;
+            if (G_EMB > 3) sa = q == 3 ? sid[G_EMB > 3 ? 3 : 0] : sa;
+            w1a = *reinterpret_cast<const float*>(tb + (sa * RB + 4u * KP));
             if (G_EMB > 4) {
-                const float* pb = V2_FO_PTR(G_EMB > 4 ? 4 : 0);
-                if (G_EMB > 5) pb = q == 1 ? V2_FO_PTR(G_EMB > 5 ? 5 : 0) : pb;
-                if (G_EMB > 6) pb = q == 2 ? V2_FO_PTR(G_EMB > 6 ? 6 : 0) : pb;
-                if (G_EMB > 7) pb = q == 3 ? V2_FO_PTR(G_EMB > 7 ? 7 : 0) : pb;
-                w1b = *pb;
+                unsigned sb = sid[G_EMB > 4 ? 4 : 0];
+                if (G_EMB > 5) sb = q == 1 ? sid[G_EMB > 5 ? 5 : 0] : sb;
+                if (G_EMB > 6) sb = q == 2 ? sid[G_EMB > 6 ? 6 : 0] : sb;
+                if (G_EMB > 7) sb = q == 3 ? sid[G_EMB > 7 ? 7 : 0] : sb;
+                w1b = *reinterpret_cast<const float*>(tb + (sb * RB + 4u * KP));
             }
-#undef V2_FO_PTR
+        } else {
+#pragma unroll
+            for (int g = 0; g < G_EMB; ++g) {
+                const unsigned rowoff = sid[g] * (unsigned)RS;
+#pragma unroll
+                for (int c = 0; c < XC; ++c) {
+                    // this lane's 16-byte piece of the row; pieces past the row end re-read piece 0 and
+                    // only ever meet zero weights
+                    const unsigned o = (4 * c + 3 < XV || 4u * c + q < (unsigned)XV) ? rowoff + 16u * c + 4u * q : rowoff;
+                    x[g][c] = ld4(A.table[g] + o);
+                }
+            }
+            // first-order weights: lane (r,q) fetches field q's, then field q+4's
+            unsigned oa = A.fo_off[0] + sid[0];
+            if (G_EMB > 1) oa = q == 1 ? A.fo_off[G_EMB > 1 ? 1 : 0] + sid[G_EMB > 1 ? 1 : 0] : oa;
+            if (G_EMB > 2) oa = q == 2 ? A.fo_off[G_EMB > 2 ? 2 : 0] + sid[G_EMB > 2 ? 2 : 0] : oa;
+            if (G_EMB > 3) oa = q == 3 ? A.fo_off[G_EMB > 3 ? 3 : 0] + sid[G_EMB > 3 ? 3 : 0] : oa;
+            w1a = A.fo_all[oa];
+            if (G_EMB > 4) {
+                unsigned ob = A.fo_off[G_EMB > 4 ? 4 : 0] + sid[G_EMB > 4 ? 4 : 0];
+                if (G_EMB > 5) ob = q == 1 ? A.fo_off[G_EMB > 5 ? 5 : 0] + sid[G_EMB > 5 ? 5 : 0] : ob;
+                if (G_EMB > 6) ob = q == 2 ? A.fo_off[G_EMB > 6 ? 6 : 0] + sid[G_EMB > 6 ? 6 : 0] : ob;
+                if (G_EMB > 7) ob = q == 3 ? A.fo_off[G_EMB > 7 ? 7 : 0] + sid[G_EMB > 7 ? 7 : 0] : ob;
+                w1b = A.fo_all[ob];
+            }
         }
     };
 
@@ -328,7 +377,7 @@ __global__ __launch_bounds__(WAVES * 64, 4) void k_deepfm_v2_chain(const V2Run A
     f32x4 P[G_EMB][KPC];                                  // per-field projections (FOLD: the gathered rows)
     f32x4 pnum = zero;                                    // raw numerics of the task being scored
     float z1 = 0.f;                                       // first-order partial of this lane
-    auto compute = [&](int tk) {
+    auto compute = [&]() -> float {
         // Every LDS read is issued at least one MFMA group (>= 128 matrix-pipe cycles) before its first
         // use, so a wave's MFMAs are back to back and the W^T fragment reads ride in their shadow.
         constexpr int NK = G * KPC;                           // 16-wide K chunks of deep0: chunk kk of group g = g*KPC+kk
@@ -399,13 +448,132 @@ __global__ __launch_bounds__(WAVES * 64, 4) void k_deepfm_v2_chain(const V2Run A
         z += A.h0w * zz;
         z += __shfl_xor(z, 16);
         z += __shfl_xor(z, 32);
-        const int m = tk * 16 + r;
-        if (q == 0 && m < B) out[m] = sigmoidf_acc(z + A.h0w * A.fo_bias + A.head_bias);
+        return sigmoidf_acc(z + A.h0w * A.fo_bias + A.head_bias);
+    };
+
+    // ---- REG: weight fragments held in registers (filled once, after the image barrier) ----
+    constexpr int NKR = G * KPC;                              // deep0 K chunks
+    f32x4 rW0[REG ? H0C : 1][REG ? NKR : 1], rW1[REG ? H1C : 1][REG ? H0C : 1];
+    f32x4 rwn[REG ? KPC : 1], rbpn[REG ? KPC : 1], rb0[REG ? H0C : 1], rb1[REG ? H1C : 1], rhfm[REG ? KPC : 1], rhd[REG ? H1C : 1];
+    f32x4 rfn = zero;
+    auto load_weights = [&]() {
+        if constexpr (REG) {
+            const float* w0r = wq + LD::off_w0 + r * LD::S0;
+#pragma unroll
+            for (int n0 = 0; n0 < H0C; ++n0)
+#pragma unroll
+                for (int c = 0; c < NKR; ++c) rW0[n0][c] = ld4(w0r + n0 * 16 * LD::S0 + 16 * c);
+#pragma unroll
+            for (int n1 = 0; n1 < H1C; ++n1) {
+#pragma unroll
+                for (int j = 0; j < H0C; ++j) rW1[n1][j] = ld4(wq + LD::off_w1 + (n1 * 16 + r) * LD::S1 + 16 * j);
+                rb1[n1] = ld4(wq + LD::off_b1 + n1 * 16);
+                rhd[n1] = ld4(wq + LD::off_hd + n1 * 16);
+            }
+#pragma unroll
+            for (int nb = 0; nb < KPC; ++nb) {
+                rwn[nb] = ld4(wq + LD::off_wn + (nb * 16 + r) * LD::SN);
+                rbpn[nb] = ld4(wq + LD::off_bp + G_EMB * KP + nb * 16);
+                rhfm[nb] = ld4(wq + LD::off_hfm + nb * 16);
+            }
+#pragma unroll
+            for (int n0 = 0; n0 < H0C; ++n0) rb0[n0] = ld4(wq + LD::off_b0 + n0 * 16);
+            rfn = ld4(smem + LD::off_fn + 4 * (q & 1));
+        }
+    };
+    auto compute_reg = [&]() -> float {
+        if constexpr (REG) {
+            // numeric group's Dense projection (DeepFM_v2.py:118-120): two chains (even / odd K step)
+            f32x4 pn[KPC];
+#pragma unroll
+            for (int nb = 0; nb < KPC; ++nb) {
+                f32x4 e = rbpn[nb], o = zero;
+                e = __builtin_amdgcn_mfma_f32_16x16x4f32(rwn[nb].x, pnum.x, e, 0, 0, 0);
+                o = __builtin_amdgcn_mfma_f32_16x16x4f32(rwn[nb].y, pnum.y, o, 0, 0, 0);
+                e = __builtin_amdgcn_mfma_f32_16x16x4f32(rwn[nb].z, pnum.z, e, 0, 0, 0);
+                o = __builtin_amdgcn_mfma_f32_16x16x4f32(rwn[nb].w, pnum.w, o, 0, 0, 0);
+                pn[nb] = e + o;
+            }
+            // this lane's share of the per-id logit terms (row scalars: first order and -sum hfm P^2, see
+            // k_v2_fold) + numeric first-order partial (rfn = h0w * fo_num weights, zero beyond n_num)
+            float zz = z1 + ((q < 2) ? dot4(rfn, pnum) : 0.f);
+            // deep0 (DeepFM_v2.py:124-125) over chunk pairs: accumulators hA (even position, starts at the
+            // bias) and hB (odd position) per n-block = 2*H0C independent chains, issued round robin.
+            // Every VALU instruction costs the f32 MFMA stream its issue time (they share the SIMD's
+            // vector ALU), so the FM cross only accumulates S here.
+            f32x4 hA[H0C], hB[H0C], s[KPC];
+#pragma unroll
+            for (int n0 = 0; n0 < H0C; ++n0) { hA[n0] = rb0[n0]; hB[n0] = zero; }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int c = 0; c < NKR; c += 2) {
+                // processing order: numeric chunks first, then the fields
+                const int ca = (c < KPC) ? G_EMB * KPC + c : c - KPC;
+                const int cb = (c + 1 < KPC) ? G_EMB * KPC + c + 1 : c + 1 - KPC;
+                const bool hb = c + 1 < NKR;
+                const f32x4 pa = (c < KPC) ? pn[c] : P[(c - KPC) / KPC][(c - KPC) % KPC];
+                const f32x4 pb = !hb ? zero : (c + 1 < KPC) ? pn[c + 1] : P[(c + 1 - KPC) / KPC][(c + 1 - KPC) % KPC];
+                {
+                    const int na = ca % KPC, nbb = cb % KPC;
+                    if (c < KPC) s[na] = pa; else s[na] += pa;
+                    if (hb) { if (c + 1 < KPC) s[nbb] = pb; else s[nbb] += pb; }
+                }
+#pragma unroll
+                for (int st = 0; st < 4; ++st) {
+#pragma unroll
+                    for (int n0 = 0; n0 < H0C; ++n0)
+                        hA[n0] = __builtin_amdgcn_mfma_f32_16x16x4f32(rW0[n0][ca][st], pa[st], hA[n0], 0, 0, 0);
+                    if (hb) {
+#pragma unroll
+                        for (int n0 = 0; n0 < H0C; ++n0)
+                            hB[n0] = __builtin_amdgcn_mfma_f32_16x16x4f32(rW0[n0][hb ? cb : ca][st], pb[st], hB[n0], 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            f32x4 h0[H0C];
+#pragma unroll
+            for (int n0 = 0; n0 < H0C; ++n0) h0[n0] = relu4_fast(hA[n0] + hB[n0]);
+            // FM cross (DeepFM_v2.py:147-152): sum_n hfm[n] (S_n^2 - sum_g P_g[n]^2); the fields' squares are in
+            // the row scalars, the numeric group's are subtracted here
+            float z = 0.f;
+#pragma unroll
+            for (int nb = 0; nb < KPC; ++nb) z += dot4(rhfm[nb], s[nb] * s[nb] - pn[nb] * pn[nb]);
+            // deep1: Dense(relu) (DeepFM_v2.py:126) + output weights; two chains (even / odd K step)
+#pragma unroll
+            for (int n1 = 0; n1 < H1C; ++n1) {
+                f32x4 e = rb1[n1], o = zero;
+#pragma unroll
+                for (int j = 0; j < H0C; ++j) {
+                    e = __builtin_amdgcn_mfma_f32_16x16x4f32(rW1[n1][j].x, h0[j].x, e, 0, 0, 0);
+                    o = __builtin_amdgcn_mfma_f32_16x16x4f32(rW1[n1][j].y, h0[j].y, o, 0, 0, 0);
+                    e = __builtin_amdgcn_mfma_f32_16x16x4f32(rW1[n1][j].z, h0[j].z, e, 0, 0, 0);
+                    o = __builtin_amdgcn_mfma_f32_16x16x4f32(rW1[n1][j].w, h0[j].w, o, 0, 0, 0);
+                }
+                z += dot4(rhd[n1], relu4_fast(e + o));
+            }
+            // output layer: concat([first, fm, deep]) . w + b -> sigmoid (DeepFM_v2.py:154-155)
+            z += zz;
+            z += __shfl_xor(z, 16);
+            z += __shfl_xor(z, 32);
+            return sigmoidf_fast(z + A.h0w * A.fo_bias + A.head_bias);
+        } else {
+            return 0.f;
+        }
     };
 
     // ---- prologue: ids first, then the weight image (independent of the ids, so both are in flight
     //      together with the row gathers) ----
     if (A.flags & 32) return;                                 // experiment: launch cost only
+    if (A.flags & 64) {                                       // experiment: static issue priorities per SIMD slot
+        if (REG) { if (wave >> 2) __builtin_amdgcn_s_setprio(1); }
+        else {
+            const int gen = (wave >> 2) + 2 * ((blockIdx.x >> 8) & 1);
+            if (gen == 1) __builtin_amdgcn_s_setprio(1);
+            else if (gen == 2) __builtin_amdgcn_s_setprio(2);
+            else if (gen == 3) __builtin_amdgcn_s_setprio(3);
+        }
+    }
     trace_stamp<TRACE>(A.trace, wave_global, 0, false);       // entry
     if (TRACE && A.trace && lane == 0) A.trace[(size_t)wave_global * 16 + 8] = wall_clock64();
     int cur = wave_global, prev = -1;
@@ -437,21 +605,31 @@ __global__ __launch_bounds__(WAVES * 64, 4) void k_deepfm_v2_chain(const V2Run A
             trace_stamp<TRACE>(A.trace, wave_global, 3, false);   // image copy issued by this wave
             __syncthreads();                                      // (drains this wave's DMA and gathers first)
             trace_stamp<TRACE>(A.trace, wave_global, 4, false);   // weight image staged by the whole workgroup
+            load_weights();                                       // REG: this wave's fragments -> VGPRs, once
             first = false;
         }
+        // The score is stored one stage late, right after the hand-off wait below: vmcnt also counts
+        // stores on gfx9, so a store issued straight after the scoring stage would sit in front of the
+        // next gather's "ids landed" wait and expose its full write-acknowledge latency every task.
+        float score = 0.f;
         if (prev >= 0) {
             if (A.flags & 8) {                                    // experiment: no compute stage, keep the gathered data live
-                float zz = z1 + pnum.x;
+                score = z1 + pnum.x;
 #pragma unroll
-                for (int g = 0; g < G_EMB; ++g) zz += P[g][0].x + P[g][0].w;
-                const int m = prev * 16 + r;
-                if (q == 0 && m < B) out[m] = zz;
-            } else
-            compute(prev);
+                for (int g = 0; g < G_EMB; ++g) score += P[g][0].x + P[g][0].w;
+            } else if (REG) {
+                score = compute_reg();
+            } else {
+                score = compute();
+            }
             if (prev == wave_global) trace_stamp<TRACE>(A.trace, wave_global, 6, false);                 // first task scored
             else if (prev == wave_global + task_stride) trace_stamp<TRACE>(A.trace, wave_global, 10, false);   // second
         }
-        if (!have_cur) break;
+        if (!have_cur) {
+            const int m = prev * 16 + r;
+            if (prev >= 0 && q == 0 && m < B) out[m] = score;
+            break;
+        }
         if (prev < 0) trace_stamp<TRACE>(A.trace, wave_global, 5, true);   // trace only: first task's rows landed
         // hand the gathered rows to the compute stage
         if (FOLD) {
@@ -471,6 +649,10 @@ __global__ __launch_bounds__(WAVES * 64, 4) void k_deepfm_v2_chain(const V2Run A
                         acc = mfma4(ld4(wq + LD::off_wp + (g * KP + nb * 16 + r) * LD::SP + 16 * c), x[g][c], acc);
                     P[g][nb] = acc;
                 }
+        }
+        {
+            const int m = prev * 16 + r;
+            if (prev >= 0 && q == 0 && m < B) out[m] = score;
         }
         pnum = xn;
         z1 = ((q < G_EMB) ? w1a : 0.f) + ((q + 4 < G_EMB) ? w1b : 0.f);

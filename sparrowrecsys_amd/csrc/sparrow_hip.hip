@@ -539,7 +539,7 @@ struct sprk_engine {
     int v2_grid_cap = 0;
     float* v2_image = nullptr;     // pre-packed LDS weight image (device)
     float* v2_fo_all = nullptr;    // concatenated first-order weight blocks (device)
-    float* v2_folded[V2_MAX_FIELDS] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // projected tables (device)
+    float* v2_folded = nullptr;    // projected tables of all fields, back to back (device)
     size_t v2_fo_floats = 0;
 };
 
@@ -656,22 +656,23 @@ int validate_plan(const sprk_plan& p) {
 }
 
 
-// ---- fast-path dispatch table for k_deepfm_v2_chain<G_EMB, DV, KPC, H0C, H1C, WAVES, FOLD, TRACE> ----
+// ---- fast-path dispatch table for k_deepfm_v2_chain<G_EMB, DV, KPC, H0C, H1C, WAVES, FOLD, TRACE, REG> ----
 constexpr int V2_WAVES = 8;
 typedef void (*V2LaunchFn)(const V2Run&, const int*, const float*, float*, int, int*, const float*, int, size_t, hipStream_t);
 struct V2Variant {
     int g_emb, dv, kpc, h0c, h1c;     // dv is ignored for FOLD variants (they gather KP-wide projected rows)
     bool fold;
+    bool reg;                         // register-resident weights, 2 waves per SIMD (one 8-wave workgroup per CU)
     const void* fn;
     const void* fn_trace;             // TRACE instantiation (diagnostics), or NULL
     size_t lds_bytes;
     V2LaunchFn launch, launch_trace;
     void (*pack)(const V2Args&, float*);
 };
-template <int G_EMB, int DV, int KPC, int H0C, int H1C, bool FOLD, bool TRACE>
+template <int G_EMB, int DV, int KPC, int H0C, int H1C, bool FOLD, bool TRACE, bool REG>
 void v2_launch(const V2Run& a, const int* ids, const float* dense, float* out, int B, int* err, const float* image,
                int grid, size_t lds, hipStream_t st) {
-    hipLaunchKernelGGL((k_deepfm_v2_chain<G_EMB, DV, KPC, H0C, H1C, V2_WAVES, FOLD, TRACE>), dim3(grid), dim3(V2_WAVES * 64), lds, st,
+    hipLaunchKernelGGL((k_deepfm_v2_chain<G_EMB, DV, KPC, H0C, H1C, V2_WAVES, FOLD, TRACE, REG>), dim3(grid), dim3(V2_WAVES * 64), lds, st,
                        a, ids, dense, out, B, err, image);
 }
 template <int G_EMB, int DV, int KPC, int H0C, int H1C, bool FOLD>
@@ -680,22 +681,22 @@ void v2_pack(const V2Args& a, float* image) {
 }
 #define V2_LDS(G_EMB, DV, KPC, H0C, H1C, FOLD) \
     (sizeof(float) * (V2Lds<G_EMB, DV, KPC, H0C, H1C, FOLD>::total_pad + V2_WAVES * V2Lds<G_EMB, DV, KPC, H0C, H1C, FOLD>::stage_floats))
-#define V2_VARIANT(G_EMB, DV, KPC, H0C, H1C, FOLD)                                                                     \
-    {G_EMB, DV, KPC, H0C, H1C, FOLD,                                                                                   \
-     reinterpret_cast<const void*>(&k_deepfm_v2_chain<G_EMB, DV, KPC, H0C, H1C, V2_WAVES, FOLD, false>), nullptr,      \
-     V2_LDS(G_EMB, DV, KPC, H0C, H1C, FOLD), &v2_launch<G_EMB, DV, KPC, H0C, H1C, FOLD, false>, nullptr,               \
+#define V2_KFN(G_EMB, DV, KPC, H0C, H1C, FOLD, TRACE, REG) \
+    reinterpret_cast<const void*>(&k_deepfm_v2_chain<G_EMB, DV, KPC, H0C, H1C, V2_WAVES, FOLD, TRACE, REG>)
+#define V2_VARIANT(G_EMB, DV, KPC, H0C, H1C, FOLD, REG)                                                                \
+    {G_EMB, DV, KPC, H0C, H1C, FOLD, REG, V2_KFN(G_EMB, DV, KPC, H0C, H1C, FOLD, false, REG), nullptr,                 \
+     V2_LDS(G_EMB, DV, KPC, H0C, H1C, FOLD), &v2_launch<G_EMB, DV, KPC, H0C, H1C, FOLD, false, REG>, nullptr,          \
      &v2_pack<G_EMB, DV, KPC, H0C, H1C, FOLD>}
-#define V2_VARIANT_TRACED(G_EMB, DV, KPC, H0C, H1C, FOLD)                                                              \
-    {G_EMB, DV, KPC, H0C, H1C, FOLD,                                                                                   \
-     reinterpret_cast<const void*>(&k_deepfm_v2_chain<G_EMB, DV, KPC, H0C, H1C, V2_WAVES, FOLD, false>),               \
-     reinterpret_cast<const void*>(&k_deepfm_v2_chain<G_EMB, DV, KPC, H0C, H1C, V2_WAVES, FOLD, true>),                \
-     V2_LDS(G_EMB, DV, KPC, H0C, H1C, FOLD), &v2_launch<G_EMB, DV, KPC, H0C, H1C, FOLD, false>,                        \
-     &v2_launch<G_EMB, DV, KPC, H0C, H1C, FOLD, true>, &v2_pack<G_EMB, DV, KPC, H0C, H1C, FOLD>}
+#define V2_VARIANT_TRACED(G_EMB, DV, KPC, H0C, H1C, FOLD, REG)                                                         \
+    {G_EMB, DV, KPC, H0C, H1C, FOLD, REG, V2_KFN(G_EMB, DV, KPC, H0C, H1C, FOLD, false, REG),                          \
+     V2_KFN(G_EMB, DV, KPC, H0C, H1C, FOLD, true, REG), V2_LDS(G_EMB, DV, KPC, H0C, H1C, FOLD),                        \
+     &v2_launch<G_EMB, DV, KPC, H0C, H1C, FOLD, false, REG>, &v2_launch<G_EMB, DV, KPC, H0C, H1C, FOLD, true, REG>,    \
+     &v2_pack<G_EMB, DV, KPC, H0C, H1C, FOLD>}
 const V2Variant kV2Variants[] = {
-    V2_VARIANT_TRACED(6, 4, 1, 2, 1, true),   // BASELINE config 2: 6 fields, projection 16 (folded into the tables), deep 32-16
-    V2_VARIANT(6, 4, 1, 2, 1, false),         // ... with the projections computed per sample (D=16)
-    V2_VARIANT(4, 4, 1, 2, 1, true),          // 4 fields, projection 16 (config-4 shape gathers 64-B projected rows instead of 256-B)
-    V2_VARIANT(4, 4, 1, 2, 1, false),         // 4 fields, D=16
+    V2_VARIANT_TRACED(6, 4, 1, 2, 1, true, true),    // BASELINE config 2: 6 fields, projection 16 (folded into the tables), deep 32-16
+    V2_VARIANT(6, 4, 1, 2, 1, false, false),         // ... with the projections computed per sample (D=16), weights in LDS
+    V2_VARIANT(4, 4, 1, 2, 1, true, true),           // 4 fields, projection 16 (config-4 shape gathers 128-B projected rows instead of 256-B)
+    V2_VARIANT(4, 4, 1, 2, 1, false, false),         // 4 fields, D=16
 };
 
 // Recognise the plan models.DeepFMv2 emits (DeepFM_v2.py graph) and fill the fused kernel's arguments.
@@ -771,13 +772,18 @@ bool match_v2_chain(sprk_engine* h) {
     const int dv = Dp / 4, kpc = Kp / 16, h0c = d0.N / 16, h1c = d1.N / 16;
     // fold the per-field projections into the tables when that never widens a gathered row
     const char* fmode = getenv("SPRK_V2_FOLD");              // A/B switch: "0" = compute projections per sample
-    const bool want_fold = Kp <= Dp && !(fmode && fmode[0] == '0');
+    size_t total_rows = 0;
+    for (int g = 0; g < g_emb; ++g) total_rows += (size_t)a.emb_vocab[g] + 1;
+    // (32-bit byte offsets into ONE buffer of folded rows: needs < 4 GiB)
+    const bool want_fold = Kp <= Dp && Kp + 16 <= 64 && total_rows * (size_t)(Kp + 16) * 4 < ((size_t)1 << 32) &&
+                           !(fmode && fmode[0] == '0');
+    const bool want_reg = want_fold;                         // folded tables <=> register-resident scoring stage
     // the fused kernel reads ONE id per field for both the embedding row and the first-order
     // weight: the two field lists must be the same set of ids columns
     if (n_fo != g_emb) return false;
     for (size_t v = 0; v < sizeof(kV2Variants) / sizeof(kV2Variants[0]); ++v) {
         const V2Variant& vv = kV2Variants[v];
-        if (vv.fold != want_fold) continue;
+        if (vv.fold != want_fold || vv.reg != want_reg) continue;
         if (vv.g_emb == g_emb && (vv.fold || vv.dv == dv) && vv.kpc == kpc && vv.h0c == h0c && vv.h1c == h1c) {
             V2Run run;
             memset(&run, 0, sizeof(run));
@@ -980,7 +986,7 @@ int sprk_finalize(sprk_handle h) {
             HIP_TRY(hipFuncSetAttribute(vv.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)vv.lds_bytes));
             int per_cu = (int)(160 * 1024 / vv.lds_bytes);
             if (vv.fn_trace) HIP_TRY(hipFuncSetAttribute(vv.fn_trace, hipFuncAttributeMaxDynamicSharedMemorySize, (int)vv.lds_bytes));
-            const int by_regs = 4 * 4 / V2_WAVES;                    // waves/SIMD the launch bounds allow
+            const int by_regs = (vv.reg ? 2 : 4) * 4 / V2_WAVES;     // workgroups/CU the launch bounds allow
             if (per_cu > by_regs) per_cu = by_regs;
             const char* wg = getenv("SPRK_V2_WGS_PER_CU");           // tuning knob (1..by_regs)
             if (wg && wg[0] >= '1' && wg[0] <= '9' && (wg[0] - '0') < per_cu) per_cu = wg[0] - '0';
@@ -994,16 +1000,19 @@ int sprk_finalize(sprk_handle h) {
             h->v2run.fo_all = h->v2_fo_all;
             if (vv.fold) {
                 const int KP = vv.kpc * 16;
+                size_t rows_total = 0;
+                for (int g = 0; g < vv.g_emb; ++g) { h->v2run.rowbase[g] = (unsigned)rows_total; rows_total += (size_t)h->v2run.vocab[g] + 1; }
+                HIP_TRY(hipMalloc((void**)&h->v2_folded, rows_total * (KP + 16) * sizeof(float)));
                 for (int g = 0; g < vv.g_emb; ++g) {
                     const long long rows = (long long)h->v2run.vocab[g] + 1;
-                    HIP_TRY(hipMalloc((void**)&h->v2_folded[g], (size_t)rows * (KP + 16) * sizeof(float)));
-                    long long blocks = (rows * (KP + 16) + 255) / 256;
+                    long long blocks = (rows + 3) / 4;
                     if (blocks > 65536) blocks = 65536;
                     hipLaunchKernelGGL(k_v2_fold, dim3((unsigned)blocks), dim3(256), 0, 0, h->v2.table[g], h->v2.ldp_emb,
-                                       h->v2.Wp[g], h->v2.ldp_emb, h->v2.bp[g], h->v2.w1[g], h->v2_folded[g], KP, rows);
+                                       h->v2.Wp[g], h->v2.ldp_emb, h->v2.bp[g], h->v2.w1[g], h->v2.hfm, h->v2.n_hfm, h->v2.h0w,
+                                       h->v2_folded + (size_t)h->v2run.rowbase[g] * (KP + 16), KP, rows);
                     HIP_TRY(hipGetLastError());
-                    h->v2run.table[g] = h->v2_folded[g];
                 }
+                h->v2run.tab0 = h->v2_folded;
             }
             HIP_TRY(hipMalloc((void**)&h->v2_image, vv.lds_bytes));
             HIP_TRY(hipMemset(h->v2_image, 0, vv.lds_bytes));
@@ -1123,8 +1132,7 @@ void sprk_destroy(sprk_handle h) {
     if (h->dev_plan) (void)hipFree(h->dev_plan);
     if (h->v2_image) (void)hipFree(h->v2_image);
     if (h->v2_fo_all) (void)hipFree(h->v2_fo_all);
-    for (float* p : h->v2_folded)
-        if (p) (void)hipFree(p);
+    if (h->v2_folded) (void)hipFree(h->v2_folded);
     if (h->dev_err) (void)hipFree(h->dev_err);
     delete h;
 }
