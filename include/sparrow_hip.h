@@ -182,6 +182,14 @@ size_t sprk_workspace_bytes(sprk_handle h, int32_t B);
 int sprk_forward(sprk_handle h, const int32_t* ids, const float* dense, float* out, int32_t B,
                  void* workspace, size_t workspace_bytes, void* stream);
 
+/* Replaces `model.predict(dataset)` looping over the dataset's batches (DeepFM.py:131 over the
+ * tf.data pipeline of DeepFM.py:14-22): enqueues n_batches forwards of B rows each on `stream`,
+ * batch i reading ids[i] / dense[i] and writing out[i] (arrays of DEVICE pointers held in HOST
+ * memory).  Exactly equivalent to n_batches calls of sprk_forward; it exists so that a serving or
+ * evaluation loop pays one foreign-function call per pass instead of one per batch. */
+int sprk_forward_many(sprk_handle h, int32_t n_batches, const int32_t* const* ids, const float* const* dense,
+                      float* const* out, int32_t B, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Per-model entry points: identical to sprk_forward but fail with
  * SPRK_EKIND unless the handle was created from that model's plan. */
 int sprk_forward_embedding_mlp(sprk_handle h, const int32_t* ids, const float* dense, float* out, int32_t B, void* ws, size_t ws_bytes, void* stream);

@@ -4,21 +4,21 @@ set -u
 mkdir -p gpurun_out
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 rocminfo | grep -E "Marketing Name|gfx|Compute Unit" | head -6 > gpurun_out/rocminfo.txt 2>&1
-echo "=== pytest -m gpu" 
-timeout 1200 python -m pytest tests -m gpu -q 2>&1 | tail -40 | tee gpurun_out/pytest_gpu.log
+echo "=== pytest -m gpu"
+timeout 1200 python -m pytest tests -m gpu -q 2>&1 | tail -5 | tee gpurun_out/pytest_gpu.log
 echo "=== smoke"
-timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -5 | tee gpurun_out/smoke.log
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3 | tee gpurun_out/smoke.log
 echo "=== bench"
-timeout 600 python bench.py --steps 400 --warmup 40 2>&1 | tail -3 | tee gpurun_out/bench_c2.json
-SPRK_V2_HOIST=1 timeout 600 python bench.py --steps 400 --warmup 40 --cpu-seconds 0 2>&1 | tail -1 | tee gpurun_out/bench_c2_hoist.json
-SPRK_FORCE_INTERPRETER=1 timeout 600 python bench.py --steps 400 --warmup 40 --cpu-seconds 0 2>&1 | tail -1 | tee gpurun_out/bench_c2_interp.json
-timeout 600 python bench.py --steps 400 --warmup 40 --cpu-seconds 0 --dist zipf 2>&1 | tail -1 | tee gpurun_out/bench_c2_zipf.json
-timeout 600 python bench.py --steps 400 --warmup 40 --workload deepfm_c2 --cpu-seconds 0 2>&1 | tail -3 | tee gpurun_out/bench_c2_pairs.json
-timeout 600 python bench.py --steps 100 --warmup 10 --workload din_c3 --cpu-seconds 0 2>&1 | tail -3 | tee gpurun_out/bench_c3.json
+timeout 600 python bench.py 2>&1 | tail -1 | tee gpurun_out/bench_c2.json
+SPRK_V2_FOLD=0 timeout 600 python bench.py --cpu-seconds 0 2>&1 | tail -1 | tee gpurun_out/bench_c2_unfolded.json
+SPRK_FORCE_INTERPRETER=1 timeout 600 python bench.py --cpu-seconds 0 2>&1 | tail -1 | tee gpurun_out/bench_c2_interp.json
+timeout 600 python bench.py --cpu-seconds 0 --dist zipf 2>&1 | tail -1 | tee gpurun_out/bench_c2_zipf.json
+timeout 600 python bench.py --cpu-seconds 0 --batch 1048576 --steps 400 --warmup 40 2>&1 | tail -1 | tee gpurun_out/bench_c2_b1m.json
+timeout 600 python bench.py --workload deepfm_c2 --cpu-seconds 0 2>&1 | tail -1 | tee gpurun_out/bench_c2_pairs.json
+timeout 600 python bench.py --steps 300 --warmup 30 --workload din_c3 --cpu-seconds 6 2>&1 | tail -1 | tee gpurun_out/bench_c3.json
 echo "=== rocprofv3 kernel trace"
 cd /tmp && export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_c2 -o c2 -- python $R/bench.py --steps 200 --warmup 20 --cpu-seconds 0 --no-check > $R/gpurun_out/prof_c2.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_c2 -o c2 -- python $R/bench.py --steps 400 --warmup 40 --cpu-seconds 0 --no-check > $R/gpurun_out/prof_c2.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_c3 -o c3 -- python $R/bench.py --steps 50 --warmup 5 --workload din_c3 --cpu-seconds 0 --no-check > $R/gpurun_out/prof_c3.log 2>&1
 cd $R
-ls -R gpurun_out | head -40
-for f in $(find gpurun_out -name "*kernel_stats.csv"); do echo "--- $f"; head -8 $f; done
+for f in $(find gpurun_out/prof_c2 gpurun_out/prof_c3 -name "*kernel_stats.csv"); do echo "--- $f"; head -6 $f | cut -c1-200; done

@@ -1087,6 +1087,19 @@ int sprk_forward(sprk_handle h, const int32_t* ids, const float* dense, float* o
     return SPRK_OK;
 }
 
+int sprk_forward_many(sprk_handle h, int32_t n_batches, const int32_t* const* ids, const float* const* dense,
+                      float* const* out, int32_t B, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!h) return fail(SPRK_EINVAL, "handle is NULL");
+    if (n_batches < 0) return fail(SPRK_EINVAL, "negative batch count");
+    if (n_batches > 0 && !out) return fail(SPRK_EINVAL, "out is NULL");
+    for (int32_t i = 0; i < n_batches; ++i) {
+        const int rc = sprk_forward(h, ids ? ids[i] : nullptr, dense ? dense[i] : nullptr, out[i], B, workspace,
+                                    workspace_bytes, stream);
+        if (rc) return rc;
+    }
+    return SPRK_OK;
+}
+
 #define SPRK_FORWARD_KIND(name, kind)                                                                      \
     int name(sprk_handle h, const int32_t* ids, const float* dense, float* out, int32_t B, void* ws,      \
              size_t ws_bytes, void* stream) {                                                              \

@@ -93,6 +93,31 @@ class Engine:
                               C.c_void_p(dense.data_ptr() if dense is not None else None),
                               C.c_void_p(out.data_ptr()), B, C.c_void_p(ws_ptr), ws_bytes, C.c_void_p(stream)))
 
+    def forward_many(self, ids_list, dense_list, out_list, workspace=None, stream: Optional[int] = None):
+        """``predict`` over a sequence of device-resident batches with ONE foreign call
+        (``sprk_forward_many``): batch i reads ids_list[i] / dense_list[i], writes out_list[i]."""
+        import torch
+        n = len(out_list)
+        if n == 0:
+            return
+        B = int(out_list[0].shape[0])
+        if any(int(o.shape[0]) != B for o in out_list):
+            raise ValueError("forward_many: every batch must have the same number of rows")
+        if stream is None:
+            stream = torch.cuda.current_stream().cuda_stream
+        ws_ptr, ws_bytes = None, 0
+        if self.has_din:
+            need = self.workspace_bytes(B)
+            if workspace is None or workspace.numel() * workspace.element_size() < need:
+                raise ValueError("DIN forward needs a %d-byte workspace tensor" % need)
+            ws_ptr, ws_bytes = workspace.data_ptr(), workspace.numel() * workspace.element_size()
+        arr = C.c_void_p * n
+        ids_a = arr(*[t.data_ptr() for t in ids_list]) if ids_list is not None else None
+        dense_a = arr(*[t.data_ptr() for t in dense_list]) if dense_list is not None else None
+        out_a = arr(*[t.data_ptr() for t in out_list])
+        L.check(self.lib.sprk_forward_many(self.handle, n, ids_a, dense_a, out_a, B, C.c_void_p(ws_ptr), ws_bytes,
+                                           C.c_void_p(stream)))
+
     def din_pool(self, ids, pooled, att=None, stream: Optional[int] = None):
         import torch
         if stream is None:

@@ -330,3 +330,17 @@ def test_deepfm_v2_unaligned_views_and_tails(torch, config2):
         assert torch.equal(model.predict_device(vi, vd), p[lo:lo + 4099])
     for n in range(1, 34):
         assert torch.equal(model.predict_device(ids[:n].contiguous(), dense[:n].contiguous()), p[:n])
+
+
+def test_forward_many_equals_forward(torch, config2):
+    """sprk_forward_many (the predict-over-batches loop in one foreign call) == n calls of sprk_forward."""
+    model, feats, ids, dense = config2
+    eng = model.engine
+    B = 8192
+    chunks = [(ids[i * B:(i + 1) * B].contiguous(), dense[i * B:(i + 1) * B].contiguous()) for i in range(4)]
+    outs = [torch.empty(B, dtype=torch.float32, device="cuda") for _ in chunks]
+    eng.forward_many([c[0] for c in chunks], [c[1] for c in chunks], outs)
+    eng.check_ids()
+    ref = model.predict_device(ids, dense)
+    for i, o in enumerate(outs):
+        assert torch.equal(o, ref[i * B:(i + 1) * B])
