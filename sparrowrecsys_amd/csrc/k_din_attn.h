@@ -1,0 +1,270 @@
+// k_din_attn.h -- DIN activation unit + weighted sum pooling (reference DIN.py:132-158), one WAVE per
+// sample.  Included inside sparrow_hip.hip's anonymous namespace.
+//
+// The reference feeds a = [h-c, h, c, h*c] (4D wide) of every (sample, history slot) through
+// Dense(hidden) -> PReLU -> Dense(1, sigmoid).  With the Dense kernel split in its four row blocks
+// W = [W1; W2; W3; W4] that first layer is
+//
+//     u[b,t,:] = (W1+W2)^T h[b,t] + W4^T (h[b,t] * c[b]) + (W3-W1)^T c[b] + bias
+//              = A_b h[b,t] + vc[cand_b]      with  A_b = W12 + W4 diag(c_b)   (hidden x D, per sample)
+//                                                   vc[id] = (W3-W1)^T E[id] + bias   (a table, per id)
+//
+// so the per-(b,t) contraction is K = D instead of 4D (a quarter of the FLOPs), the c-only term is one
+// extra 4*hidden-byte row gather per SAMPLE from a table built once at sprk_finalize (k_din_prep),
+// and the [B,T,4D] activation-unit input never exists.  (fp32 throughout; only the association of the
+// sums differs from the reference's einsum, i.e. rounding-level differences.)
+//
+// Mapping: a wave owns one sample at a time.  Its T history rows are gathered ONCE from the table
+// (16-B pieces, whole 128-B rows per 8 lanes) into a wave-private LDS tile; the attention logits run on
+// v_mfma_f32_16x16x4_f32 with A = A_b (built in registers from the resident W12 / W4 fragments and the
+// candidate row), B = 16 history rows per group read from LDS, C initialised with vc[cand] -- two groups
+// in flight = four independent accumulator chains.  PReLU(alpha[t][n]) / Dense(1) / sigmoid finish in
+// registers + two cross-lane adds, and the pooled vector sum_t w[t] h[t] is reduced from the same LDS
+// rows (each row is read from memory exactly once).  No workgroup barrier after the one-time alpha
+// staging: waves run independently, the next sample's ids are prefetched during the current one.
+
+struct DinRun {
+    int T, F, hist_col, cand_col, Dp, vocab;
+    float b2;
+    const float* table;   // [vocab][Dp]
+    const float* w12;     // [HC*16][KC*16]  (W1+W2)^T, zero padded
+    const float* w4;      // [HC*16][KC*16]  W4^T, zero padded
+    const float* vc;      // [vocab][HC*16]  (W3-W1)^T E[id] + bias
+    const float* alpha;   // [T][HC*16]
+    const float* w2;      // [HC*16]
+};
+
+// One-time (finalize) kernels.
+__global__ __launch_bounds__(256) void k_din_prep_w(const float* __restrict__ W, int hidden, int Dp, int KP,
+                                                    float* __restrict__ w12, float* __restrict__ w4) {
+    // W: [hidden][4*Dp] in [h-c | h | c | h*c] blocks (sprk_din.w_slot)
+    const int total = hidden * KP;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const int n = i / KP, k = i - n * KP;
+        float a = 0.f, b = 0.f;
+        if (k < Dp) {
+            const float* w = W + (size_t)n * 4 * Dp;
+            a = w[k] + w[Dp + k];
+            b = w[3 * Dp + k];
+        }
+        w12[i] = a;
+        w4[i] = b;
+    }
+}
+__global__ __launch_bounds__(256) void k_din_prep_vc(const float* __restrict__ W, const float* __restrict__ bias,
+                                                     const float* __restrict__ table, int hidden, int Dp,
+                                                     long long vocab, float* __restrict__ vc) {
+    // vc[v][n] = bias[n] + sum_k (W3[n][k] - W1[n][k]) * E[v][k]
+    const long long total = vocab * hidden;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long v = i / hidden;
+        const int n = (int)(i - v * hidden);
+        const float* w = W + (size_t)n * 4 * Dp;
+        const float* e = table + v * Dp;
+        float acc = bias[n];
+        for (int k = 0; k < Dp; ++k) acc = fmaf(w[2 * Dp + k] - w[k], e[k], acc);
+        vc[i] = acc;
+    }
+}
+
+template <int KC, int HC>
+struct DinLds {
+    static constexpr int KP = KC * 16, HP = HC * 16;
+    static constexpr int hs = KP + 4;           // history-row stride (floats): 16-B aligned, (hs/4) odd
+    static constexpr int as = HP + 4;           // alpha-row stride
+    static constexpr int rows = 64;             // T <= 64, padded to whole 16-row groups
+    static constexpr int alpha_floats = rows * as;
+    static constexpr int wave_floats = rows * hs + rows;     // Hs tile + attention weights
+    static constexpr size_t bytes = sizeof(float) * (alpha_floats + 4 * wave_floats);
+};
+
+template <int KC, int HC, int NP>
+__global__ __launch_bounds__(256, 2) void k_din_attn(const DinRun A, const int* __restrict__ ids,
+                                                     float* __restrict__ pooled, float* __restrict__ att, int B,
+                                                     int* __restrict__ err) {
+    using LD = DinLds<KC, HC>;
+    constexpr int KP = LD::KP, HP = LD::HP, hs = LD::hs, as = LD::as;
+    static_assert(NP >= 1 && NP <= 8 && KC <= 2, "the 8-pass row gather covers 64 rows only for rows of <= 8 pieces");
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 15, q = lane >> 4;
+    const int T = A.T, F = A.F, Dp = A.Dp;
+    const int NV = Dp >> 2;                              // 16-B pieces per table row
+    const int RPP = 64 / NV;                             // rows per gather pass
+    const int lrow = lane / NV, piece = lane < RPP * NV ? lane - lrow * NV : 0;
+    const int G = (T + 15) >> 4;                         // 16-row groups
+    const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
+    float* alpha_s = smem;
+    float* Hs = smem + LD::alpha_floats + wave * LD::wave_floats;
+    float* Ws = Hs + LD::rows * hs;
+
+    // ---- one-time: zero the wave tile (padding columns / rows stay zero for ever), stage alpha ----
+    for (int i = lane; i < LD::wave_floats; i += 64) Hs[i] = 0.f;
+    for (int i = tid; i < LD::alpha_floats; i += 256) {
+        const int t = i / as, n = i - t * as;
+        alpha_s[i] = (t < T && n < HP) ? A.alpha[(size_t)t * HP + n] : 0.f;
+    }
+    // resident weight fragments: lane (r,q) holds W[n = nb*16 + r][k = 16c + 4q .. +3]
+    f32x4 w12f[HC][KC], w4f[HC][KC], w2f[HC];
+#pragma unroll
+    for (int nb = 0; nb < HC; ++nb) {
+#pragma unroll
+        for (int c = 0; c < KC; ++c) {
+            w12f[nb][c] = ld4(A.w12 + (size_t)(nb * 16 + r) * KP + 16 * c + 4 * q);
+            w4f[nb][c] = ld4(A.w4 + (size_t)(nb * 16 + r) * KP + 16 * c + 4 * q);
+        }
+        w2f[nb] = ld4(A.w2 + nb * 16 + 4 * q);
+    }
+    __syncthreads();
+    // the one-time loads above have landed before the pipelined loop starts: otherwise the compiler,
+    // which cannot count in-order vmcnt across the loop's back edge, drains the prefetched rows at the
+    // first use of a weight fragment inside the loop
+    __builtin_amdgcn_s_waitcnt(0x0F70);                      // s_waitcnt vmcnt(0)
+
+    const int stride = gridDim.x * 4;
+    int s = blockIdx.x * 4 + wave;
+    bool bad = false;
+    // Software pipeline over this wave's samples: the rows of sample n+1 are in flight (in registers)
+    // while sample n is scored from the LDS tile; its ids were fetched one sample earlier still.
+    // Gather pass p covers history slots p*RPP .. p*RPP+RPP-1, NV lanes (16-B pieces) per row.
+    // NP passes (compile time, >= ceil(T / RPP)): no control flow inside the gather, so every load of a
+    // sample is in flight together and the compiler can count them (s_waitcnt vmcnt is in-order).
+    int prow[NP];                         // this lane's history slot in pass p (clamped)
+    bool pok[NP];                         // ... and whether it stores what it loaded
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        const int row = p * RPP + lrow;
+        pok[p] = lrow < RPP && row < T;
+        prow[p] = row < T ? row : T - 1;
+    }
+    int hid[NP], cid = 0;                 // ids of the sample whose rows are issued next
+    f32x4 v[NP], cvn[KC], vcn[HC];         // rows / candidate row / vc row of the sample scored next
+    auto ld_ids = [&](int b) {
+        const int* row = ids + (size_t)b * F;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) hid[p] = row[A.hist_col + prow[p]];
+        cid = row[A.cand_col];
+    };
+    auto issue_rows = [&]() {
+        bad |= (unsigned)cid >= (unsigned)A.vocab;
+        const unsigned csafe = (unsigned)cid < (unsigned)A.vocab ? (unsigned)cid : 0u;
+        const float* crow = A.table + csafe * (unsigned)Dp;
+#pragma unroll
+        for (int c = 0; c < KC; ++c) cvn[c] = (16 * c + 4 * q < Dp) ? ld4(crow + 16 * c + 4 * q) : zero;
+        const float* vrow = A.vc + csafe * (unsigned)HP;
+#pragma unroll
+        for (int nb = 0; nb < HC; ++nb) vcn[nb] = ld4(vrow + nb * 16 + 4 * q);
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            bad |= (unsigned)hid[p] >= (unsigned)A.vocab;
+            const unsigned id = (unsigned)hid[p] < (unsigned)A.vocab ? (unsigned)hid[p] : 0u;
+            v[p] = ld4(A.table + (id * (unsigned)Dp + 4u * (unsigned)piece));   // 32-bit element offset (checked at finalize)
+        }
+    };
+    if (s < B) {
+        ld_ids(s);
+        issue_rows();
+        if (s + stride < B) ld_ids(s + stride);
+    }
+    for (; s < B; s += stride) {
+        // ---- hand-off: this sample's rows -> LDS tile, candidate-side operands -> registers ----
+#pragma unroll
+        for (int p = 0; p < NP; ++p)
+            if (pok[p]) st4(Hs + prow[p] * hs + 4 * piece, v[p]);
+        f32x4 cv[KC], acc_init[HC];
+#pragma unroll
+        for (int c = 0; c < KC; ++c) cv[c] = cvn[c];
+#pragma unroll
+        for (int nb = 0; nb < HC; ++nb) acc_init[nb] = vcn[nb];
+        if (s + stride < B) {                                    // next sample's rows fly under this sample's MFMAs
+            issue_rows();
+            if (s + 2 * stride < B) ld_ids(s + 2 * stride);
+        }
+        // A_b = W12 + W4 diag(c)
+        f32x4 Ab[HC][KC];
+#pragma unroll
+        for (int nb = 0; nb < HC; ++nb)
+#pragma unroll
+            for (int c = 0; c < KC; ++c) Ab[nb][c] = w4f[nb][c] * cv[c] + w12f[nb][c];
+
+        // ---- attention logits, two 16-row groups (= 2*HC accumulator chains) at a time ----
+        auto score_groups = [&](int g, auto two_tag) {
+            constexpr bool TWO = decltype(two_tag)::value;
+            f32x4 b0[KC], b1[KC], a0[HC], a1[HC];
+#pragma unroll
+            for (int c = 0; c < KC; ++c) {
+                b0[c] = ld4(Hs + (16 * g + r) * hs + 16 * c + 4 * q);
+                b1[c] = TWO ? ld4(Hs + (16 * g + 16 + r) * hs + 16 * c + 4 * q) : zero;
+            }
+            f32x4 al0[HC], al1[HC];                              // PReLU alpha[t][n] of the rows being scored
+#pragma unroll
+            for (int nb = 0; nb < HC; ++nb) {
+                al0[nb] = ld4(alpha_s + (16 * g + r) * as + nb * 16 + 4 * q);
+                al1[nb] = TWO ? ld4(alpha_s + (16 * g + 16 + r) * as + nb * 16 + 4 * q) : zero;
+                a0[nb] = acc_init[nb];
+                a1[nb] = acc_init[nb];
+            }
+#pragma unroll
+            for (int c = 0; c < KC; ++c)
+#pragma unroll
+                for (int st = 0; st < 4; ++st) {
+#pragma unroll
+                    for (int nb = 0; nb < HC; ++nb)
+                        a0[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(Ab[nb][c][st], b0[c][st], a0[nb], 0, 0, 0);
+                    if (TWO) {
+#pragma unroll
+                        for (int nb = 0; nb < HC; ++nb)
+                            a1[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(Ab[nb][c][st], b1[c][st], a1[nb], 0, 0, 0);
+                    }
+                }
+            // epilogue: PReLU(alpha[t][n]) -> Dense(1) -> sigmoid (DIN.py:150-151); lane (r,q) holds
+            // u[n = nb*16 + 4q + j] of row t = 16g + r
+#pragma unroll
+            for (int h = 0; h < (TWO ? 2 : 1); ++h) {
+                const int t = 16 * (g + h) + r;
+                float sum = 0.f;
+#pragma unroll
+                for (int nb = 0; nb < HC; ++nb) {
+                    const f32x4 al = h ? al1[nb] : al0[nb];
+                    const f32x4 u = h ? a1[nb] : a0[nb];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float pos = __builtin_amdgcn_fmed3f(u[j], 0.f, __builtin_inff());
+                        const float neg = __builtin_amdgcn_fmed3f(u[j], -__builtin_inff(), 0.f);   // min(u, 0), one instruction
+                        sum = fmaf(w2f[nb][j], fmaf(al[j], neg, pos), sum);
+                    }
+                }
+                sum += __shfl_xor(sum, 16);
+                sum += __shfl_xor(sum, 32);
+                const float wgt = sigmoidf_fast(sum + A.b2);
+                if (q == 0) {
+                    Ws[t] = wgt;
+                    if (att && t < T) att[(size_t)s * T + t] = wgt;
+                }
+            }
+        };
+        {
+            int g = 0;
+            for (; g + 1 < G; g += 2) score_groups(g, std::true_type{});
+            if (g < G) score_groups(g, std::false_type{});
+        }
+
+        // ---- weighted sum pooling (DIN.py:152-158): pooled[d] = sum_t w[t] h[t][d] ----
+        if (KP <= 16) {
+            const int d = lane & 15, h4 = lane >> 4;
+            float acc = 0.f;
+            for (int t = h4; t < T; t += 4) acc = fmaf(Ws[t], Hs[t * hs + d], acc);
+            acc += __shfl_xor(acc, 16);
+            acc += __shfl_xor(acc, 32);
+            if (h4 == 0 && d < Dp) pooled[(size_t)s * Dp + d] = acc;
+        } else {
+            const int d = lane & 31, h2 = lane >> 5;
+            float acc = 0.f;
+            for (int t = h2; t < T; t += 2) acc = fmaf(Ws[t], Hs[t * hs + d], acc);
+            acc += __shfl_xor(acc, 32);
+            if (h2 == 0 && d < Dp) pooled[(size_t)s * Dp + d] = acc;
+        }
+    }
+    if (__ballot(bad) != 0 && lane == 0) atomicOr(err, 1);
+}

@@ -26,6 +26,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "sparrow_hip.h"
@@ -485,6 +486,7 @@ __global__ __launch_bounds__(256) void k_din_pool(const DevPlan* __restrict__ P,
 }
 
 #include "k_chain_v2.h"
+#include "k_din_attn.h"
 
 // ---------------------------------------------------------------------------------------------
 // stand-alone operators
@@ -531,6 +533,14 @@ struct sprk_engine {
     int din_ms = 0;
     size_t din_lds_bytes = 0;
     int din_grid_cap = 0;
+    // wave-per-sample attention kernel (k_din_attn); -1 = the generic k_din_pool
+    int din_variant = -1;
+    DinRun din_run;
+    float* din_w12 = nullptr;      // (W1+W2)^T, W4^T fragments and the per-id c-term table (device)
+    float* din_w4 = nullptr;
+    float* din_vc = nullptr;
+    size_t din_attn_lds = 0;
+    int din_attn_grid_cap = 0;
     // register-chained fast path (k_deepfm_v2_chain); -1 = use the tile interpreter
     int v2_variant = -1;
     V2Args v2;
@@ -819,6 +829,27 @@ bool match_v2_chain(sprk_engine* h) {
     return false;
 }
 
+// ---- dispatch table for k_din_attn<KC, HC> ----
+typedef void (*DinLaunchFn)(const DinRun&, const int*, float*, float*, int, int*, int, size_t, hipStream_t);
+template <int KC, int HC, int NP>
+void din_launch(const DinRun& a, const int* ids, float* pooled, float* att, int B, int* err, int grid, size_t lds, hipStream_t st) {
+    hipLaunchKernelGGL((k_din_attn<KC, HC, NP>), dim3(grid), dim3(256), lds, st, a, ids, pooled, att, B, err);
+}
+struct DinVariant {
+    int kc, hc, np;                   // np: gather passes compiled in (each covers 64 / (row_stride/4) history slots)
+    const void* fn;
+    size_t lds_bytes;
+    DinLaunchFn launch;
+};
+#define DIN_VARIANT(KC, HC, NP) {KC, HC, NP, reinterpret_cast<const void*>(&k_din_attn<KC, HC, NP>), DinLds<KC, HC>::bytes, &din_launch<KC, HC, NP>}
+const DinVariant kDinVariants[] = {     // first match wins: smallest sufficient pass count first
+    DIN_VARIANT(2, 2, 2), DIN_VARIANT(2, 2, 4),
+    DIN_VARIANT(2, 2, 7),               // BASELINE config 3: emb_dim 32, 50 history slots, attention hidden 32
+    DIN_VARIANT(2, 2, 8),
+    DIN_VARIANT(1, 2, 1),               // the reference's own DIN.py: emb_dim 10 (rows padded to 12), 5 slots, hidden 32
+    DIN_VARIANT(1, 2, 4),
+};
+
 int need_bytes(const sprk_engine* h, int slot, size_t bytes, const char* what) {
     if (!h->slot_ptr[slot]) return fail(SPRK_ESTATE, "%s: slot %d was never uploaded", what, slot);
     if (h->slot_bytes[slot] < bytes) return fail(SPRK_EINVAL, "%s: slot %d holds %zu bytes, needs %zu", what, slot, h->slot_bytes[slot], bytes);
@@ -971,6 +1002,40 @@ int sprk_finalize(sprk_handle h) {
         if (per_cu > 8) per_cu = 8;
         if (per_cu < 1) per_cu = 1;
         h->din_grid_cap = h->num_cus * per_cu;
+        // wave-per-sample kernel when the shape has an instantiation (T <= 64 rows fit the wave's LDS tile)
+        const char* legacy = getenv("SPRK_DIN_LEGACY");          // A/B switch: "1" = generic k_din_pool
+        const int kc = (s.row_stride + 15) / 16, hc = s.hidden / 16;
+        const size_t vc_bytes = (size_t)s.vocab * s.hidden * sizeof(float);
+        if (!(legacy && legacy[0] == '1') && s.T <= 64 && vc_bytes < ((size_t)4 << 30) &&
+            (size_t)s.vocab * s.row_stride * sizeof(float) < ((size_t)4 << 30)) {   // 32-bit element offsets
+            for (size_t v = 0; v < sizeof(kDinVariants) / sizeof(kDinVariants[0]); ++v) {
+                const DinVariant& dv = kDinVariants[v];
+                if (dv.kc != kc || dv.hc != hc || dv.np * (64 / (s.row_stride / 4)) < s.T) continue;
+                const int KP = kc * 16;
+                HIP_TRY(hipMalloc((void**)&h->din_w12, (size_t)s.hidden * KP * sizeof(float)));
+                HIP_TRY(hipMalloc((void**)&h->din_w4, (size_t)s.hidden * KP * sizeof(float)));
+                HIP_TRY(hipMalloc((void**)&h->din_vc, vc_bytes));
+                hipLaunchKernelGGL(k_din_prep_w, dim3(8), dim3(256), 0, 0, d.W, s.hidden, s.row_stride, KP, h->din_w12, h->din_w4);
+                HIP_TRY(hipGetLastError());
+                long long blocks = ((long long)s.vocab * s.hidden + 255) / 256;
+                if (blocks > 65536) blocks = 65536;
+                hipLaunchKernelGGL(k_din_prep_vc, dim3((unsigned)blocks), dim3(256), 0, 0, d.W, d.bias, d.table, s.hidden,
+                                   s.row_stride, (long long)s.vocab, h->din_vc);
+                HIP_TRY(hipGetLastError());
+                HIP_TRY(hipDeviceSynchronize());
+                DinRun& r = h->din_run;
+                r.T = s.T; r.F = p.n_id_cols; r.hist_col = s.hist_col; r.cand_col = s.cand_col; r.Dp = s.row_stride; r.vocab = s.vocab;
+                r.b2 = s.b2; r.table = d.table; r.w12 = h->din_w12; r.w4 = h->din_w4; r.vc = h->din_vc; r.alpha = d.alpha; r.w2 = d.w2;
+                HIP_TRY(hipFuncSetAttribute(dv.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dv.lds_bytes));
+                int wgs = (int)(160 * 1024 / dv.lds_bytes);
+                if (wgs > 2) wgs = 2;                                // launch bounds: 2 waves per SIMD
+                if (wgs < 1) wgs = 1;
+                h->din_attn_grid_cap = h->num_cus * wgs;
+                h->din_attn_lds = dv.lds_bytes;
+                h->din_variant = (int)v;
+                break;
+            }
+        }
     }
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile_forward), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->tile_lds_bytes));
     {
@@ -1035,6 +1100,13 @@ size_t sprk_workspace_bytes(sprk_handle h, int32_t B) {
 }
 
 static int launch_din(sprk_handle h, const int32_t* ids, float* pooled, float* att, int32_t B, hipStream_t st) {
+    if (h->din_variant >= 0) {
+        int grid = (B + 3) / 4;
+        if (grid > h->din_attn_grid_cap) grid = h->din_attn_grid_cap;
+        kDinVariants[h->din_variant].launch(h->din_run, ids, pooled, att, B, h->dev_err, grid, h->din_attn_lds, st);
+        HIP_TRY(hipGetLastError());
+        return SPRK_OK;
+    }
     const int nchunks = (B + h->din_ms - 1) / h->din_ms;
     const int grid = nchunks < h->din_grid_cap ? nchunks : h->din_grid_cap;
     hipLaunchKernelGGL(k_din_pool, dim3(grid), dim3(256), h->din_lds_bytes, st, h->dev_plan, ids, pooled, att, B, h->din_ms, h->dev_err);
@@ -1146,6 +1218,9 @@ void sprk_destroy(sprk_handle h) {
     if (h->v2_image) (void)hipFree(h->v2_image);
     if (h->v2_fo_all) (void)hipFree(h->v2_fo_all);
     if (h->v2_folded) (void)hipFree(h->v2_folded);
+    if (h->din_w12) (void)hipFree(h->din_w12);
+    if (h->din_w4) (void)hipFree(h->din_w4);
+    if (h->din_vc) (void)hipFree(h->din_vc);
     if (h->dev_err) (void)hipFree(h->dev_err);
     delete h;
 }

@@ -176,6 +176,59 @@ def test_din_attention_and_pooling_parts(torch, samples):
     assert not pooled.cpu().numpy()[:, 10:].any()
 
 
+@pytest.mark.parametrize("T,D,B", [(50, 32, 4099), (64, 32, 515), (17, 32, 1000), (1, 32, 130), (33, 24, 700),
+                                   (50, 16, 1025), (20, 10, 900), (30, 10, 901), (5, 10, 64), (50, 8, 333)])
+def test_din_attention_kernel_shapes(torch, monkeypatch, T, D, B):
+    """k_din_attn (wave per sample, A_b = W12 + W4 diag(c), per-id c-term table) against the fp64 oracle's
+    attention weights and pooled vector, and against the generic k_din_pool (SPRK_DIN_LEGACY=1), over
+    history lengths / row widths that hit every instantiation, partial 16-row groups and ragged batches."""
+    V, U = 5000, 700
+    feats = SY.synth_din(B, T, V, U, seed=100 + T + D)
+    got = {}
+    for legacy in ("0", "1"):
+        monkeypatch.setenv("SPRK_DIN_LEGACY", legacy)
+        model = M.DIN(seed=50 + T, emb_dim=D, hist_len=T, movie_buckets=V, user_buckets=U)
+        ids, dense = model.pack(feats)
+        eng = model.engine
+        Dp = eng.n_aux
+        pooled = torch.full((B, Dp), float("nan"), dtype=torch.float32, device="cuda")
+        att = torch.full((B, T), float("nan"), dtype=torch.float32, device="cuda")
+        eng.din_pool(_cuda(torch, ids), pooled, att)
+        eng.check_ids()
+        score = model.predict_device(_cuda(torch, ids), _cuda(torch, dense)).cpu().numpy()
+        got[legacy] = (att.cpu().numpy(), pooled.cpu().numpy(), score)
+        eng.close()
+    ref, parts = O.din_forward(feats, model.weights, dtype=np.float64, hist_len=T, movie_buckets=V, user_buckets=U,
+                               return_parts=True)
+    for legacy in ("0", "1"):
+        a, p, sc = got[legacy]
+        assert np.isfinite(a).all() and np.isfinite(p).all()
+        assert np.abs(a - parts["att"]).max() <= TIGHT
+        assert np.abs(p[:, :D] - parts["pooled"]).max() <= TIGHT
+        assert not p[:, D:].any()
+        assert np.abs(sc - ref[:, 0]).max() <= TOL
+    assert np.abs(got["0"][0] - got["1"][0]).max() <= 2e-6      # two summation orders of the same fp32 math
+
+
+def test_din_attention_kernel_bad_ids_raise(torch):
+    """History / candidate ids outside the table: flagged (TF raises InvalidArgumentError), no wild read."""
+    T, D, V, U, B = 50, 32, 3000, 500, 257
+    feats = SY.synth_din(B, T, V, U, seed=7)
+    model = M.DIN(seed=8, emb_dim=D, hist_len=T, movie_buckets=V, user_buckets=U)
+    ids, dense = model.pack(feats)
+    eng = model.engine
+    for col, val in ((1 + 49, V), (1 + 3, -1), (0, V + 5)):
+        bad = ids.copy()
+        bad[200, col] = val
+        pooled = torch.empty((B, eng.n_aux), dtype=torch.float32, device="cuda")
+        eng.din_pool(_cuda(torch, bad), pooled, None)
+        with pytest.raises(ValueError):
+            eng.check_ids()
+    pooled = torch.empty((B, eng.n_aux), dtype=torch.float32, device="cuda")
+    eng.din_pool(_cuda(torch, ids), pooled, None)
+    eng.check_ids()
+
+
 # --------------------------------------------------------------------------------------------
 # BASELINE configs at (near) full size
 # --------------------------------------------------------------------------------------------
