@@ -19,8 +19,10 @@
 // v_mfma_f32_16x16x4_f32 with A = A_b (built in registers from the resident W12 / W4 fragments and the
 // candidate row), B = 16 history rows per group read from LDS, C initialised with vc[cand] -- two groups
 // in flight = four independent accumulator chains.  PReLU(alpha[t][n]) / Dense(1) / sigmoid finish in
-// registers + two cross-lane adds, and the pooled vector sum_t w[t] h[t] is reduced from the same LDS
-// rows (each row is read from memory exactly once).  No workgroup barrier after the one-time alpha
+// registers + two cross-lane adds, and the pooled vector sum_t w[t] h[t] is accumulated from the very
+// B-operand registers the MFMAs just consumed (lane (r,q) holds 4*KC floats of row t = 16g + r: one FMA
+// each with w[t]), then reduced over the 16 r-lanes with DPP adds -- each row is read from memory once
+// and from LDS once.  No workgroup barrier after the one-time alpha
 // staging: waves run independently, the next sample's ids are prefetched during the current one.
 
 struct DinRun {
@@ -67,6 +69,30 @@ __global__ __launch_bounds__(256) void k_din_prep_vc(const float* __restrict__ W
     }
 }
 
+// sum over the 16 lanes of a DPP row (lanes 16q .. 16q+15), result in every lane of the row:
+// quad_perm xor 1, xor 2, then row_half_mirror and row_mirror (after two steps a quad's lanes are equal)
+__device__ __forceinline__ float row16_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));
+    return v;
+}
+
+// sum over the four 16-lane rows (q = 0..3) of a wave, result in every lane: v_permlane16_swap /
+// v_permlane32_swap (gfx950) exchange rows inside the VALU, no LDS round trip as ds_bpermute would take
+__device__ __forceinline__ float rows4_sum(float v) {
+    // inline asm: hipcc 7.2's __builtin_amdgcn_permlane{16,32}_swap hands back its FIRST result for both
+    // elements of the returned pair (the sum became x + x).  s_nop 1 = the two wait states a VALU-written
+    // VGPR needs before a permlane swap reads it; the assembler inserts nothing inside asm statements.
+    float a = v, b = v;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));   // a = [v0 v0 v2 v2], b = [v1 v1 v3 v3]
+    a += b;
+    b = a;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));   // a = [lo lo], b = [hi hi]
+    return a + b;
+}
+
 template <int KC, int HC>
 struct DinLds {
     static constexpr int KP = KC * 16, HP = HC * 16;
@@ -74,7 +100,7 @@ struct DinLds {
     static constexpr int as = HP + 4;           // alpha-row stride
     static constexpr int rows = 64;             // T <= 64, padded to whole 16-row groups
     static constexpr int alpha_floats = rows * as;
-    static constexpr int wave_floats = rows * hs + rows;     // Hs tile + attention weights
+    static constexpr int wave_floats = rows * hs;            // Hs tile
     static constexpr size_t bytes = sizeof(float) * (alpha_floats + 4 * wave_floats);
 };
 
@@ -97,7 +123,6 @@ __global__ __launch_bounds__(256, 2) void k_din_attn(const DinRun A, const int* 
     const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
     float* alpha_s = smem;
     float* Hs = smem + LD::alpha_floats + wave * LD::wave_floats;
-    float* Ws = Hs + LD::rows * hs;
 
     // ---- one-time: zero the wave tile (padding columns / rows stay zero for ever), stage alpha ----
     for (int i = lane; i < LD::wave_floats; i += 64) Hs[i] = 0.f;
@@ -189,6 +214,9 @@ __global__ __launch_bounds__(256, 2) void k_din_attn(const DinRun A, const int* 
             for (int c = 0; c < KC; ++c) Ab[nb][c] = w4f[nb][c] * cv[c] + w12f[nb][c];
 
         // ---- attention logits, two 16-row groups (= 2*HC accumulator chains) at a time ----
+        f32x4 pacc[KC];                                          // this lane's share of sum_t w[t] h[t][16c + 4q .. +3]
+#pragma unroll
+        for (int c = 0; c < KC; ++c) pacc[c] = zero;
         auto score_groups = [&](int g, auto two_tag) {
             constexpr bool TWO = decltype(two_tag)::value;
             f32x4 b0[KC], b1[KC], a0[HC], a1[HC];
@@ -235,13 +263,11 @@ __global__ __launch_bounds__(256, 2) void k_din_attn(const DinRun A, const int* 
                         sum = fmaf(w2f[nb][j], fmaf(al[j], neg, pos), sum);
                     }
                 }
-                sum += __shfl_xor(sum, 16);
-                sum += __shfl_xor(sum, 32);
-                const float wgt = sigmoidf_fast(sum + A.b2);
-                if (q == 0) {
-                    Ws[t] = wgt;
-                    if (att && t < T) att[(size_t)s * T + t] = wgt;
-                }
+                const float wgt = sigmoidf_fast(rows4_sum(sum) + A.b2);
+                if (q == 0 && att && t < T) att[(size_t)s * T + t] = wgt;
+                // weighted sum pooling (DIN.py:152-158): rows past T are all-zero in the tile, so they add nothing
+#pragma unroll
+                for (int c = 0; c < KC; ++c) pacc[c] += wgt * (h ? b1[c] : b0[c]);
             }
         };
         {
@@ -250,20 +276,15 @@ __global__ __launch_bounds__(256, 2) void k_din_attn(const DinRun A, const int* 
             if (g < G) score_groups(g, std::false_type{});
         }
 
-        // ---- weighted sum pooling (DIN.py:152-158): pooled[d] = sum_t w[t] h[t][d] ----
-        if (KP <= 16) {
-            const int d = lane & 15, h4 = lane >> 4;
-            float acc = 0.f;
-            for (int t = h4; t < T; t += 4) acc = fmaf(Ws[t], Hs[t * hs + d], acc);
-            acc += __shfl_xor(acc, 16);
-            acc += __shfl_xor(acc, 32);
-            if (h4 == 0 && d < Dp) pooled[(size_t)s * Dp + d] = acc;
-        } else {
-            const int d = lane & 31, h2 = lane >> 5;
-            float acc = 0.f;
-            for (int t = h2; t < T; t += 2) acc = fmaf(Ws[t], Hs[t * hs + d], acc);
-            acc += __shfl_xor(acc, 32);
-            if (h2 == 0 && d < Dp) pooled[(size_t)s * Dp + d] = acc;
+        // ---- reduce the pooled partials over the 16 r-lanes of each q row (DPP adds, no LDS) ----
+#pragma unroll
+        for (int c = 0; c < KC; ++c)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) pacc[c][j] = row16_sum(pacc[c][j]);
+        if (r == 0) {
+#pragma unroll
+            for (int c = 0; c < KC; ++c)
+                if (16 * c + 4 * q < Dp) st4(pooled + (size_t)s * Dp + 16 * c + 4 * q, pacc[c]);
         }
     }
     if (__ballot(bad) != 0 && lane == 0) atomicOr(err, 1);
