@@ -43,7 +43,10 @@ def build_workload(name, B, dist_name, seed_offset=0):
         feats = [SY.synth_fields(B, SY.CONFIG2_FIELDS, seed=SY.SEED + 1000 * seed_offset + i, dist=dist_name) for i in range(NB)]
         # fused kernel: ids + embedding rows + first-order weights + numerics in, one score out
         bytes_per_sample = F * 4 + F * D * 4 + F * 4 + 7 * 4 + 4
-        roof = {"bound": "hbm", "kernel": "k_deepfm_v2_chain" if name == "deepfm_v2_c2" else "k_tile_forward",
+        v2_kernel = "k_deepfm_v2_chain" if (os.environ.get("SPRK_V2_JOINT") == "0" or os.environ.get("SPRK_V2_FOLD") == "0") else "k_deepfm_v2_joint"
+        if os.environ.get("SPRK_FORCE_INTERPRETER") == "1":
+            v2_kernel = "k_tile_forward"
+        roof = {"bound": "hbm", "kernel": v2_kernel if name == "deepfm_v2_c2" else "k_tile_forward",
                 "bytes_per_sample": bytes_per_sample}
     elif name == "din_c3":
         T, D = 50, 32

@@ -1,0 +1,320 @@
+// k_chain_v2j.h -- k_deepfm_v2_joint: the register-chained DeepFM_v2 forward (k_chain_v2.h, FOLD + REG)
+// with the SMALL-vocabulary fields folded one step further.  Included inside sparrow_hip.hip's
+// anonymous namespace, after k_chain_v2.h.
+//
+// Everything field g contributes to a score is a function of its id alone (DeepFM_v2.py:106-126,147-155):
+//     P_g[id]                       its projected embedding  -> FM sum S = sum_g P_g and deep0's input
+//     W0_g^T P_g[id]                its share of deep0's pre-activation (deep0 is linear in the concat)
+//     h0w*w1_g[id] - hfm.P_g[id]^2  its first-order weight and its share of the FM sum of squares
+// For a field with a handful of rows (the 19-entry genre vocabularies) all of that is a tiny table, and
+// for a GROUP of such fields the sums over the group are again a table, indexed by the tuple of ids
+// (20^3 = 8 000 rows at BASELINE config 2).  k_v2_fold_joint builds it once at sprk_finalize:
+//     joint row = [ sum P (KP floats) | b0 + sum W0_g^T P_g (H0 floats) | sum of row scalars | 0.. ]  (256 B)
+// so per sample the NJF small fields cost ONE 256-byte gather (L2 resident) instead of NJF row gathers +
+// NJF row-scalar gathers + NJF*8 f32 MFMAs + NJF*4 VALU adds: at config 2 deep0 shrinks from 7 K-chunks
+// to 4 (56 -> 32 MFMAs per 16 samples), the gather from 6+2 loads to 3+3+1.  Same fp32 arithmetic,
+// other association of the sums (the oracle comparison is tolerance based either way).
+//
+// Lane mapping, task pipeline and the "pure MFMA stream" scoring stage are those of k_deepfm_v2_chain
+// (see k_chain_v2.h): lane (r = lane&15, q = lane>>4) is sample r's q-th 16-byte column slot.
+
+#define V2J_MAX_BIG 4
+#define V2J_MAX_JF 3
+
+struct V2JRun {
+    int F, ND, n_num;
+    int big_col[V2J_MAX_BIG];             // ids column of big field b
+    int big_vocab[V2J_MAX_BIG];
+    unsigned big_rowbase[V2J_MAX_BIG];    // first row of field b inside tab0 ([KP+16]-float rows, vocab+1 rows per field)
+    int big_grp[V2J_MAX_BIG];             // its group index in the model's field order (selects the W0 K-chunk)
+    int j_col[V2J_MAX_JF];                // ids columns of the joint group's fields
+    int j_vocab[V2J_MAX_JF];
+    const float* tab0;                    // folded rows of the big fields {P | row scalar | 0..}
+    const float* jtab;                    // joint rows {sum P | b0 + sum W0 P | sum row scalars | 0..}, [KP + H0 + 16] floats each
+    float h0w, fo_bias, head_bias;
+    int flags;                            // 1 = ids/dense not 16-byte aligned: stage element-wise
+};
+
+// One-time (finalize) kernel: joint rows from the per-field folded rows (k_v2_fold output).
+// One wave per joint row; lane n < KP sums P, lane KP <= n < KP + H0 does deep0's share of output n - KP.
+__global__ __launch_bounds__(256) void k_v2_fold_joint(const float* __restrict__ folded, int KP, int H0, int njf,
+                                                       const unsigned* __restrict__ rowbase,   // [njf] first folded row of each joint field
+                                                       const int* __restrict__ vocab1,         // [njf] rows per field (vocab + 1)
+                                                       const int* __restrict__ grp,            // [njf] group index (W0 K-chunk)
+                                                       const float* __restrict__ W0, int ldw0, // deep0 W^T [H0][ldw0]
+                                                       const float* __restrict__ b0, float* __restrict__ out,
+                                                       long long rows) {
+    const int FS = KP + 16, OS = KP + H0 + 16;
+    for (long long v = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); v < rows; v += (long long)gridDim.x * 4) {
+        const int n = threadIdx.x & 63;
+        // tuple of ids, last field fastest
+        long long rem = v;
+        const float* prow[V2J_MAX_JF];
+        for (int f = njf - 1; f >= 0; --f) {
+            const int id = (int)(rem % vocab1[f]);
+            rem /= vocab1[f];
+            prow[f] = folded + ((size_t)rowbase[f] + id) * FS;
+        }
+        float* o = out + v * OS;
+        for (int col = n; col < OS; col += 64) {
+            float acc = 0.f;
+            if (col < KP) {
+                for (int f = 0; f < njf; ++f) acc += prow[f][col];
+            } else if (col < KP + H0) {
+                const int m = col - KP;
+                acc = b0[m];
+                for (int f = 0; f < njf; ++f) {
+                    const float* w = W0 + (size_t)m * ldw0 + grp[f] * KP;
+                    for (int k = 0; k < KP; ++k) acc = fmaf(w[k], prow[f][k], acc);
+                }
+            } else if (col == KP + H0) {
+                for (int f = 0; f < njf; ++f) acc += prow[f][KP];
+            }
+            o[col] = acc;
+        }
+    }
+}
+
+template <int G_BIG, int NJF, int KPC, int H0C, int H1C, int WAVES>
+__global__ __launch_bounds__(WAVES * 64, 2) void k_deepfm_v2_joint(const V2JRun A, const int* __restrict__ ids,
+                                                                   const float* __restrict__ dense,
+                                                                   float* __restrict__ out, int B,
+                                                                   int* __restrict__ err,
+                                                                   const float* __restrict__ image) {
+    constexpr int G_EMB = G_BIG + NJF;
+    using LD = V2Lds<G_EMB, 4, KPC, H0C, H1C, true>;          // the weight image is the FOLD image of the whole model
+    constexpr int KP = LD::KP, H0 = H0C * 16;
+    constexpr unsigned RB = (KP + 16) * 4;                    // bytes per folded row
+    constexpr unsigned JB = (KP + H0 + 16) * 4;               // bytes per joint row
+    constexpr int NKR = (G_BIG + 1) * KPC;                    // deep0 K chunks still computed per sample: numerics, then the big fields
+    static_assert(KPC == 1, "row layout: one 16-float chunk of projections per field");
+    static_assert(G_BIG >= 1 && G_BIG <= 3 && NJF >= 1 && NJF <= V2J_MAX_JF, "field split");
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 15, q = lane >> 4;
+    const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int ntasks = (B + 15) >> 4;
+    const int task_stride = gridDim.x * WAVES;
+    const int wave_global = blockIdx.x * WAVES + wave;
+    float* stage = smem + LD::total_pad + wave * LD::stage_floats;
+    const float* wq = smem + 4 * q;
+
+    // ---- gather stage (consumed one loop trip after it was issued) ----
+    f32x4 raw = zero;
+    f32x4 x[G_BIG], xs = zero, xq[H0C], xn = zero;
+    float w1a = 0.f;
+    bool bad = false;
+    const bool aligned = !(A.flags & 1);
+    auto ld_raw = [&](int tk) {
+        if (aligned && tk * 16 + 16 <= B) {                       // wave-uniform
+            const bool isid = lane < 32;
+            const int j = isid ? lane : lane - 32;
+            const int n4 = 4 * (isid ? A.F : A.ND);
+            const float* src = isid ? reinterpret_cast<const float*>(ids) + (size_t)tk * 16 * A.F
+                                    : dense + (size_t)tk * 16 * A.ND;
+            raw = ld4(src + 4 * (j < n4 ? j : 0));
+        }
+    };
+    auto gather = [&](int tk) {
+        if (aligned && tk * 16 + 16 <= B) {
+            const bool isid = lane < 32;
+            const int j = isid ? lane : lane - 32;
+            const int n4 = 4 * (isid ? A.F : A.ND);
+            if (j < n4) st4(stage + (isid ? 0 : 128) + 4 * j, raw);
+        } else {
+            stage_task_slow(stage, ids, dense, A.F, A.ND, tk, B, lane);
+        }
+        // one wave: LDS operations complete in issue order, no barrier needed
+        const int* sid_row = reinterpret_cast<const int*>(stage) + r * A.F;
+        unsigned sid[G_BIG];
+#pragma unroll
+        for (int b = 0; b < G_BIG; ++b) {
+            const int id = sid_row[A.big_col[b]];
+            bad |= (unsigned)(id + 1) > (unsigned)A.big_vocab[b];             // neither a table row nor the "missing" marker -1
+            sid[b] = min((unsigned)id, (unsigned)A.big_vocab[b]) + A.big_rowbase[b];   // -1 / out of range -> the zero row at index vocab
+        }
+        unsigned jidx = 0;                                        // tuple index, last field fastest
+#pragma unroll
+        for (int f = 0; f < NJF; ++f) {
+            const int id = sid_row[A.j_col[f]];
+            bad |= (unsigned)(id + 1) > (unsigned)A.j_vocab[f];
+            jidx = jidx * (unsigned)(A.j_vocab[f] + 1) + min((unsigned)id, (unsigned)A.j_vocab[f]);
+        }
+        {
+            const float* nrow = stage + 128 + r * A.ND;
+            const int c0 = 4 * q, last = A.n_num - 1;
+            // lane slots beyond n_num hold a duplicate finite value that only ever meets zero weights
+            xn.x = nrow[min(c0 + 0, last)];
+            xn.y = nrow[min(c0 + 1, last)];
+            xn.z = nrow[min(c0 + 2, last)];
+            xn.w = nrow[min(c0 + 3, last)];
+        }
+        const char* tb = reinterpret_cast<const char*>(A.tab0);
+        const char* jb = reinterpret_cast<const char*>(A.jtab);
+#pragma unroll
+        for (int b = 0; b < G_BIG; ++b) x[b] = *reinterpret_cast<const f32x4*>(tb + (sid[b] * RB + 16u * q));
+        const unsigned jo = jidx * JB;
+        xs = *reinterpret_cast<const f32x4*>(jb + (jo + 16u * q));
+#pragma unroll
+        for (int n0 = 0; n0 < H0C; ++n0) xq[n0] = *reinterpret_cast<const f32x4*>(jb + (jo + 4u * KP + 64u * n0 + 16u * q));
+        // per-id logit terms: lane (r,q) fetches big field q's row scalar, the lanes past the big fields the joint one
+        {
+            // (the offsets pass through an empty asm: left visible, the select chain over q is turned into a
+            // dynamically indexed private array -- scratch memory traffic in the gather)
+            unsigned s0 = sid[0] * RB, s1 = sid[G_BIG > 1 ? 1 : 0] * RB, s2 = sid[G_BIG > 2 ? 2 : 0] * RB;
+            asm("" : "+v"(s0), "+v"(s1), "+v"(s2));
+            unsigned so = s0;
+            if (G_BIG > 1) so = q == 1 ? s1 : so;
+            if (G_BIG > 2) so = q == 2 ? s2 : so;
+            so += 4u * KP;
+            const bool isj = q == G_BIG;                          // G_BIG <= 3, so one q row is left for the joint scalar
+            const char* base = isj ? jb : tb;
+            so = isj ? jo + 4u * (KP + H0) : so;
+            w1a = *reinterpret_cast<const float*>(base + so);
+        }
+    };
+
+    // ---- operands of the task being scored ----
+    f32x4 P[G_BIG], ps = zero, pq[H0C], pnum = zero;
+    float z1 = 0.f;
+
+    // ---- register-resident weights (filled once, after the image barrier) ----
+    f32x4 rW0[H0C][NKR], rW1[H1C][H0C];
+    f32x4 rwn[KPC], rbpn[KPC], rb1[H1C], rhfm[KPC], rhd[H1C];
+    f32x4 rfn = zero;
+    auto load_weights = [&]() {
+        const float* w0r = wq + LD::off_w0 + r * LD::S0;
+#pragma unroll
+        for (int n0 = 0; n0 < H0C; ++n0) {
+            rW0[n0][0] = ld4(w0r + n0 * 16 * LD::S0 + 16 * G_EMB);                     // numeric chunk
+#pragma unroll
+            for (int b = 0; b < G_BIG; ++b) rW0[n0][1 + b] = ld4(w0r + n0 * 16 * LD::S0 + 16 * A.big_grp[b]);
+        }
+#pragma unroll
+        for (int n1 = 0; n1 < H1C; ++n1) {
+#pragma unroll
+            for (int j = 0; j < H0C; ++j) rW1[n1][j] = ld4(wq + LD::off_w1 + (n1 * 16 + r) * LD::S1 + 16 * j);
+            rb1[n1] = ld4(wq + LD::off_b1 + n1 * 16);
+            rhd[n1] = ld4(wq + LD::off_hd + n1 * 16);
+        }
+#pragma unroll
+        for (int nb = 0; nb < KPC; ++nb) {
+            rwn[nb] = ld4(wq + LD::off_wn + (nb * 16 + r) * LD::SN);
+            rbpn[nb] = ld4(wq + LD::off_bp + G_EMB * KP + nb * 16);
+            rhfm[nb] = ld4(wq + LD::off_hfm + nb * 16);
+        }
+        rfn = ld4(smem + LD::off_fn + 4 * (q & 1));
+    };
+    auto compute = [&]() -> float {
+        // numeric group's Dense projection (DeepFM_v2.py:118-120): two chains (even / odd K step)
+        f32x4 pn;
+        {
+            f32x4 e = rbpn[0], o = zero;
+            e = __builtin_amdgcn_mfma_f32_16x16x4f32(rwn[0].x, pnum.x, e, 0, 0, 0);
+            o = __builtin_amdgcn_mfma_f32_16x16x4f32(rwn[0].y, pnum.y, o, 0, 0, 0);
+            e = __builtin_amdgcn_mfma_f32_16x16x4f32(rwn[0].z, pnum.z, e, 0, 0, 0);
+            o = __builtin_amdgcn_mfma_f32_16x16x4f32(rwn[0].w, pnum.w, o, 0, 0, 0);
+            pn = e + o;
+        }
+        // this lane's share of the per-id logit terms + numeric first-order partial (rfn = h0w * fo_num weights)
+        float zz = z1 + ((q < 2) ? dot4(rfn, pnum) : 0.f);
+        // deep0 (DeepFM_v2.py:124-125): accumulators start at the joint row's b0 + sum W0 P of the small fields;
+        // chunk order: numerics, big fields; even positions -> hA, odd -> hB (2*H0C independent chains)
+        f32x4 hA[H0C], hB[H0C];
+#pragma unroll
+        for (int n0 = 0; n0 < H0C; ++n0) { hA[n0] = pq[n0]; hB[n0] = zero; }
+        f32x4 s = ps + pn;                                        // FM sum: small fields (joint row) + numerics ...
+#pragma unroll
+        for (int b = 0; b < G_BIG; ++b) s += P[b];                // ... + big fields
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int c = 0; c < NKR; c += 2) {
+            const bool hb = c + 1 < NKR;
+            const f32x4 pa = c == 0 ? pn : P[c - 1];
+            const f32x4 pb = !hb ? zero : P[hb ? c : 0];
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+#pragma unroll
+                for (int n0 = 0; n0 < H0C; ++n0)
+                    hA[n0] = __builtin_amdgcn_mfma_f32_16x16x4f32(rW0[n0][c][st], pa[st], hA[n0], 0, 0, 0);
+                if (hb) {
+#pragma unroll
+                    for (int n0 = 0; n0 < H0C; ++n0)
+                        hB[n0] = __builtin_amdgcn_mfma_f32_16x16x4f32(rW0[n0][hb ? c + 1 : c][st], pb[st], hB[n0], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        f32x4 h0[H0C];
+#pragma unroll
+        for (int n0 = 0; n0 < H0C; ++n0) h0[n0] = relu4_fast(hA[n0] + hB[n0]);
+        // FM cross (DeepFM_v2.py:147-152): sum_n hfm[n] (S_n^2 - sum_g P_g[n]^2); the fields' squares are in the
+        // row scalars, the numeric group's are subtracted here
+        float z = dot4(rhfm[0], s * s - pn * pn);
+        // deep1: Dense(relu) (DeepFM_v2.py:126) + output weights; two chains (even / odd K step)
+#pragma unroll
+        for (int n1 = 0; n1 < H1C; ++n1) {
+            f32x4 e = rb1[n1], o = zero;
+#pragma unroll
+            for (int j = 0; j < H0C; ++j) {
+                e = __builtin_amdgcn_mfma_f32_16x16x4f32(rW1[n1][j].x, h0[j].x, e, 0, 0, 0);
+                o = __builtin_amdgcn_mfma_f32_16x16x4f32(rW1[n1][j].y, h0[j].y, o, 0, 0, 0);
+                e = __builtin_amdgcn_mfma_f32_16x16x4f32(rW1[n1][j].z, h0[j].z, e, 0, 0, 0);
+                o = __builtin_amdgcn_mfma_f32_16x16x4f32(rW1[n1][j].w, h0[j].w, o, 0, 0, 0);
+            }
+            z += dot4(rhd[n1], relu4_fast(e + o));
+        }
+        // output layer: concat([first, fm, deep]) . w + b -> sigmoid (DeepFM_v2.py:154-155)
+        z += zz;
+        z += __shfl_xor(z, 16);
+        z += __shfl_xor(z, 32);
+        return sigmoidf_fast(z + A.h0w * A.fo_bias + A.head_bias);
+    };
+
+    // ---- prologue + software-pipelined task loop (trip i gathers task i, then scores task i-1) ----
+    int cur = wave_global, prev = -1;
+    if (cur < ntasks) ld_raw(cur);
+    bool first = true;
+    for (;;) {
+        const bool have_cur = cur < ntasks;                   // wave-uniform
+        if (have_cur) {
+            gather(cur);                                      // its ids arrived during the previous compute
+            if (cur + task_stride < ntasks) ld_raw(cur + task_stride);
+        }
+        if (first) {                                          // every wave of the workgroup passes here once
+            // weight image -> LDS by LDS-DMA: 1-KB pieces, wave w takes w, w+WAVES, ...
+#pragma unroll 1
+            for (int c = wave; c < LD::total_pad / 256; c += WAVES)
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void*)(image + c * 256 + lane * 4),
+                    (__attribute__((address_space(3))) void*)(smem + c * 256), 16, 0, 0);
+            __syncthreads();                                  // (drains this wave's DMA and gathers first)
+            load_weights();
+            first = false;
+        }
+        // the score is stored one stage late (see k_deepfm_v2_chain)
+        float score = 0.f;
+        if (prev >= 0) score = compute();
+        if (!have_cur) {
+            const int m = prev * 16 + r;
+            if (prev >= 0 && q == 0 && m < B) out[m] = score;
+            break;
+        }
+        // hand the gathered rows to the compute stage
+#pragma unroll
+        for (int b = 0; b < G_BIG; ++b) P[b] = x[b];
+        ps = xs;
+#pragma unroll
+        for (int n0 = 0; n0 < H0C; ++n0) pq[n0] = xq[n0];
+        {
+            const int m = prev * 16 + r;
+            if (prev >= 0 && q == 0 && m < B) out[m] = score;
+        }
+        pnum = xn;
+        z1 = (q <= G_BIG) ? w1a : 0.f;
+        prev = cur;
+        cur += task_stride;
+    }
+    if (__ballot(bad) != 0 && lane == 0) atomicOr(err, 1);
+}

@@ -486,6 +486,7 @@ __global__ __launch_bounds__(256) void k_din_pool(const DevPlan* __restrict__ P,
 }
 
 #include "k_chain_v2.h"
+#include "k_chain_v2j.h"
 #include "k_din_attn.h"
 
 // ---------------------------------------------------------------------------------------------
@@ -551,6 +552,10 @@ struct sprk_engine {
     float* v2_fo_all = nullptr;    // concatenated first-order weight blocks (device)
     float* v2_folded = nullptr;    // projected tables of all fields, back to back (device)
     size_t v2_fo_floats = 0;
+    // ... with the small-vocabulary fields folded into one joint table (k_deepfm_v2_joint); -1 = not used
+    int v2j_variant = -1;
+    V2JRun v2j_run;
+    float* v2j_tab = nullptr;      // joint rows (device)
 };
 
 namespace {
@@ -707,6 +712,30 @@ const V2Variant kV2Variants[] = {
     V2_VARIANT(6, 4, 1, 2, 1, false, false),         // ... with the projections computed per sample (D=16), weights in LDS
     V2_VARIANT(4, 4, 1, 2, 1, true, true),           // 4 fields, projection 16 (config-4 shape gathers 128-B projected rows instead of 256-B)
     V2_VARIANT(4, 4, 1, 2, 1, false, false),         // 4 fields, D=16
+    V2_VARIANT(5, 4, 1, 2, 1, true, true),           // other field counts (folded only)
+    V2_VARIANT(3, 4, 1, 2, 1, true, true),
+    V2_VARIANT(2, 4, 1, 2, 1, true, true),
+};
+
+// ---- dispatch table for k_deepfm_v2_joint<G_BIG, NJF, KPC, H0C, H1C, WAVES> ----
+typedef void (*V2JLaunchFn)(const V2JRun&, const int*, const float*, float*, int, int*, const float*, int, size_t, hipStream_t);
+template <int G_BIG, int NJF>
+void v2j_launch(const V2JRun& a, const int* ids, const float* dense, float* out, int B, int* err, const float* image,
+                int grid, size_t lds, hipStream_t st) {
+    hipLaunchKernelGGL((k_deepfm_v2_joint<G_BIG, NJF, 1, 2, 1, V2_WAVES>), dim3(grid), dim3(V2_WAVES * 64), lds, st,
+                       a, ids, dense, out, B, err, image);
+}
+struct V2JVariant {
+    int g_big, njf;
+    const void* fn;
+    V2JLaunchFn launch;
+};
+#define V2J_VARIANT(G_BIG, NJF) \
+    {G_BIG, NJF, reinterpret_cast<const void*>(&k_deepfm_v2_joint<G_BIG, NJF, 1, 2, 1, V2_WAVES>), &v2j_launch<G_BIG, NJF>}
+const V2JVariant kV2JVariants[] = {
+    V2J_VARIANT(3, 3),    // BASELINE config 2: movieId, userId, userRatedMovie1 + a joint table of the three genre fields
+    V2J_VARIANT(2, 2),    // the reference's own four fields (movieId, userId + two genres), config-4 shape
+    V2J_VARIANT(3, 2), V2J_VARIANT(3, 1), V2J_VARIANT(2, 3), V2J_VARIANT(2, 1), V2J_VARIANT(1, 3), V2J_VARIANT(1, 2), V2J_VARIANT(1, 1),
 };
 
 // Recognise the plan models.DeepFMv2 emits (DeepFM_v2.py graph) and fill the fused kernel's arguments.
@@ -827,6 +856,62 @@ bool match_v2_chain(sprk_engine* h) {
         }
     }
     return false;
+}
+
+// Split the fields of a folded DeepFM_v2 engine into big ones (gathered per field) and a joint group of
+// small-vocabulary ones (one gather per sample), build the joint table.  Leaves v2j_variant = -1 when the
+// model has no small field or no instantiation fits.
+int setup_v2_joint(sprk_engine* h) {
+    const V2Variant& vv = kV2Variants[h->v2_variant];
+    const char* jm = getenv("SPRK_V2_JOINT");                 // A/B switch: "0" = per-field gathers only
+    if (!vv.fold || !vv.reg || vv.kpc != 1 || vv.h0c != 2 || vv.h1c != 1 || (jm && jm[0] == '0')) return SPRK_OK;
+    const int KP = 16, H0 = 32, G = vv.g_emb;
+    int big[V2_MAX_FIELDS], nbig = 0, jf[V2_MAX_FIELDS], njf = 0;
+    long long jrows = 1;
+    for (int g = 0; g < G; ++g) {
+        const long long v1 = (long long)h->v2run.vocab[g] + 1;
+        if (v1 <= 32 && njf < V2J_MAX_JF && jrows * v1 <= 32768) { jf[njf++] = g; jrows *= v1; }
+        else big[nbig++] = g;
+    }
+    if (njf < 1 || nbig < 1 || nbig > 3) return SPRK_OK;
+    int variant = -1;
+    for (size_t v = 0; v < sizeof(kV2JVariants) / sizeof(kV2JVariants[0]); ++v)
+        if (kV2JVariants[v].g_big == nbig && kV2JVariants[v].njf == njf) variant = (int)v;
+    if (variant < 0) return SPRK_OK;
+    V2JRun& r = h->v2j_run;
+    memset(&r, 0, sizeof(r));
+    r.F = h->v2run.F; r.ND = h->v2run.ND; r.n_num = h->v2run.n_num;
+    r.h0w = h->v2run.h0w; r.fo_bias = h->v2run.fo_bias; r.head_bias = h->v2run.head_bias;
+    for (int b = 0; b < nbig; ++b) {
+        r.big_col[b] = h->v2run.col[big[b]]; r.big_vocab[b] = h->v2run.vocab[big[b]];
+        r.big_rowbase[b] = h->v2run.rowbase[big[b]]; r.big_grp[b] = big[b];
+    }
+    unsigned rb[V2J_MAX_JF]; int v1[V2J_MAX_JF], grp[V2J_MAX_JF];
+    for (int f = 0; f < njf; ++f) {
+        r.j_col[f] = h->v2run.col[jf[f]]; r.j_vocab[f] = h->v2run.vocab[jf[f]];
+        rb[f] = h->v2run.rowbase[jf[f]]; v1[f] = h->v2run.vocab[jf[f]] + 1; grp[f] = jf[f];
+    }
+    const size_t OS = KP + H0 + 16;
+    HIP_TRY(hipMalloc((void**)&h->v2j_tab, (size_t)jrows * OS * sizeof(float)));
+    unsigned* d_rb = nullptr; int* d_v1 = nullptr; int* d_grp = nullptr;
+    HIP_TRY(hipMalloc((void**)&d_rb, sizeof(rb)));
+    HIP_TRY(hipMalloc((void**)&d_v1, sizeof(v1)));
+    HIP_TRY(hipMalloc((void**)&d_grp, sizeof(grp)));
+    HIP_TRY(hipMemcpy(d_rb, rb, sizeof(rb), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_v1, v1, sizeof(v1), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_grp, grp, sizeof(grp), hipMemcpyHostToDevice));
+    long long blocks = (jrows + 3) / 4;
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(k_v2_fold_joint, dim3((unsigned)blocks), dim3(256), 0, 0, h->v2_folded, KP, H0, njf, d_rb, d_v1, d_grp,
+                       h->v2.W0, (G + 1) * KP, h->v2.b0, h->v2j_tab, jrows);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    (void)hipFree(d_rb); (void)hipFree(d_v1); (void)hipFree(d_grp);
+    r.tab0 = h->v2_folded;
+    r.jtab = h->v2j_tab;
+    HIP_TRY(hipFuncSetAttribute(kV2JVariants[variant].fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)vv.lds_bytes));
+    h->v2j_variant = variant;
+    return SPRK_OK;
 }
 
 // ---- dispatch table for k_din_attn<KC, HC> ----
@@ -1078,6 +1163,8 @@ int sprk_finalize(sprk_handle h) {
                     HIP_TRY(hipGetLastError());
                 }
                 h->v2run.tab0 = h->v2_folded;
+                HIP_TRY(hipDeviceSynchronize());
+                if ((rc = setup_v2_joint(h))) return rc;
             }
             HIP_TRY(hipMalloc((void**)&h->v2_image, vv.lds_bytes));
             HIP_TRY(hipMemset(h->v2_image, 0, vv.lds_bytes));
@@ -1148,6 +1235,13 @@ int sprk_forward(sprk_handle h, const int32_t* ids, const float* dense, float* o
         run.flags = (((uintptr_t)ids | (uintptr_t)dense) & 15) ? 1 : 0;    // unaligned inputs: element-wise staging
         { const char* xf = getenv("SPRK_V2_XFLAGS"); if (xf) run.flags |= atoi(xf); }   // experiment switches
         const V2Variant& vv = kV2Variants[h->v2_variant];
+        if (h->v2j_variant >= 0 && !run.trace && !(run.flags & ~1)) {
+            V2JRun jr = h->v2j_run;
+            jr.flags = run.flags;
+            kV2JVariants[h->v2j_variant].launch(jr, ids, dense, out, B, h->dev_err, h->v2_image, grid, h->v2_lds_bytes, st);
+            HIP_TRY(hipGetLastError());
+            return SPRK_OK;
+        }
         (run.trace ? vv.launch_trace : vv.launch)(run, ids, dense, out, B, h->dev_err, h->v2_image, grid, h->v2_lds_bytes, st);
         HIP_TRY(hipGetLastError());
         return SPRK_OK;
@@ -1218,6 +1312,7 @@ void sprk_destroy(sprk_handle h) {
     if (h->v2_image) (void)hipFree(h->v2_image);
     if (h->v2_fo_all) (void)hipFree(h->v2_fo_all);
     if (h->v2_folded) (void)hipFree(h->v2_folded);
+    if (h->v2j_tab) (void)hipFree(h->v2j_tab);
     if (h->din_w12) (void)hipFree(h->din_w12);
     if (h->din_w4) (void)hipFree(h->din_w4);
     if (h->din_vc) (void)hipFree(h->din_vc);

@@ -332,12 +332,12 @@ def test_concurrent_streams_share_a_handle(torch, config2):
 
 
 # --------------------------------------------------------------------------------------------
-# the three execution paths of the DeepFM_v2 graph must agree with the oracle and with each other
+# the four execution paths of the DeepFM_v2 graph must agree with the oracle and with each other
 # --------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("env", [{}, {"SPRK_V2_FOLD": "0"}, {"SPRK_FORCE_INTERPRETER": "1"}],
-                         ids=["chain-folded-regs", "chain-unfolded-lds", "interpreter"])
+@pytest.mark.parametrize("env", [{}, {"SPRK_V2_JOINT": "0"}, {"SPRK_V2_FOLD": "0"}, {"SPRK_FORCE_INTERPRETER": "1"}],
+                         ids=["joint-small-fields", "chain-folded-regs", "chain-unfolded-lds", "interpreter"])
 def test_deepfm_v2_execution_paths(torch, env, monkeypatch):
-    for k in ("SPRK_V2_FOLD", "SPRK_V2_REG", "SPRK_FORCE_INTERPRETER"):
+    for k in ("SPRK_V2_FOLD", "SPRK_V2_REG", "SPRK_V2_JOINT", "SPRK_FORCE_INTERPRETER"):
         monkeypatch.delenv(k, raising=False)
     for k, v in env.items():
         monkeypatch.setenv(k, v)
@@ -364,12 +364,36 @@ def test_deepfm_v2_folded_tables_do_not_change_scores(torch, monkeypatch):
     B = 20000
     feats = SY.synth_fields(B, SY.CONFIG2_FIELDS, seed=91)
     outs = []
-    for fold in ("1", "0"):
+    for fold, joint in (("1", "1"), ("1", "0"), ("0", "0")):
         monkeypatch.setenv("SPRK_V2_FOLD", fold)
+        monkeypatch.setenv("SPRK_V2_JOINT", joint)
         monkeypatch.delenv("SPRK_FORCE_INTERPRETER", raising=False)
         model = M.DeepFMv2(seed=43, emb_dim=16, fields=SY.CONFIG2_FIELDS, proj_dim=16)
         outs.append(model.predict(feats)[:, 0])
-    assert np.abs(outs[0] - outs[1]).max() <= TIGHT
+    assert np.abs(outs[0] - outs[2]).max() <= TIGHT
+    assert np.abs(outs[1] - outs[2]).max() <= TIGHT
+
+
+@pytest.mark.parametrize("fields", [
+    [("movieId", "id", 3000), ("userGenre1", "genre", 19)],
+    [("movieId", "id", 3000), ("userGenre1", "genre", 19), ("userGenre2", "genre", 19), ("movieGenre1", "genre", 19)],
+    [("movieId", "id", 3000), ("userId", "id", 9000), ("userGenre1", "genre", 19)],
+    [("movieId", "id", 3000), ("userId", "id", 9000), ("userRatedMovie1", "id", 3000), ("userGenre1", "genre", 19), ("userGenre2", "genre", 19)],
+], ids=["1big+1small", "1big+3small", "2big+1small", "3big+2small"])
+def test_deepfm_v2_joint_field_splits(torch, monkeypatch, fields):
+    """Other big/small field splits of k_deepfm_v2_joint (joint table over 1..3 small-vocabulary fields),
+    missing ids (-1) included, against the fp64 oracle and the per-field path."""
+    B = 5003
+    feats = SY.synth_fields(B, fields, seed=55)
+    order = [k for k, _, _ in fields]
+    outs = []
+    for joint in ("1", "0"):
+        monkeypatch.setenv("SPRK_V2_JOINT", joint)
+        model = M.DeepFMv2(seed=44, emb_dim=16, fields=fields, proj_dim=16)
+        outs.append(model.predict(feats)[:, 0])
+    ref = O.deepfm_v2_forward(feats, model.weights, dtype=np.float64, fields=fields, order=order)[:, 0]
+    assert np.abs(outs[0] - ref).max() <= TIGHT
+    assert np.abs(outs[1] - ref).max() <= TIGHT
 
 
 def test_deepfm_v2_unaligned_views_and_tails(torch, config2):
