@@ -15,6 +15,20 @@
 // to 4 (56 -> 32 MFMAs per 16 samples), the gather from 6+2 loads to 3+3+1.  Same fp32 arithmetic,
 // other association of the sums (the oracle comparison is tolerance based either way).
 //
+// HALF: the big fields' share of deep0 and of the FM sum runs on v_mfma_f32_16x16x32_f16 with SPLIT
+// operands instead of f32 MFMA.  On gfx950 the f32-input MFMA issues at the f32 vector rate and shares the
+// SIMD's vector ALU with every VALU instruction (measured, profiles/r01/ubench_*); the f16 MFMA runs 16x
+// faster per FLOP and overlaps VALU work.  A value x (scaled by a power of two so that max|x| lands near
+// 2^15) is stored as two halfs hi = f16(x), lo = f16(x - hi): hi + lo carries 22 significand bits.  The
+// folded row of a big field holds, per 16-byte piece q, [hi(P[4q..4q+3]) | lo(P[4q..4q+3])] -- the same
+// 64 bytes per row as the 16 floats it replaces, gathered by the same load -- and IS the B operand of the
+// K = 32 instruction (8 halfs per lane).  Against A = [Whi | Whi] it yields Whi.(hi + lo), against
+// A = [Wlo | Wlo] the correction Wlo.(hi + lo): two MFMAs per (field, 16 outputs) for the full fp32-class
+// product (every partial product is exact in the f32 accumulator), one more against a 0/1 selection
+// matrix adds hi + lo into the FM sum.  16 samples: 15 f16 MFMAs (16 cycles each, VALU keeps issuing)
+// instead of 24 f32 MFMAs (32 cycles each, VALU blocked) + 12 VALU adds.  Error of the split: <= 2^-21
+// relative per operand, i.e. fp32 class (tests hold the same tolerances as the f32 path).
+//
 // Lane mapping, task pipeline and the "pure MFMA stream" scoring stage are those of k_deepfm_v2_chain
 // (see k_chain_v2.h): lane (r = lane&15, q = lane>>4) is sample r's q-th 16-byte column slot.
 
@@ -33,7 +47,58 @@ struct V2JRun {
     const float* jtab;                    // joint rows {sum P | b0 + sum W0 P | sum row scalars | 0..}, [KP + H0 + 16] floats each
     float h0w, fo_bias, head_bias;
     int flags;                            // 1 = ids/dense not 16-byte aligned: stage element-wise
+    // HALF: tab0 rows hold split halfs of P * p_scale; the deep0 weights of the big fields are split after
+    // multiplying by w_scale (powers of two chosen at finalize from the tables' / kernel's max |.|)
+    float w_scale, unscale_h, unscale_s;  // 2^sW, 2^-(sP+sW), 2^-sP
 };
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+// x*scale -> (hi, lo) halfs with hi + lo == x*scale to 22 bits
+__device__ __forceinline__ void split_half4(f32x4 w, float scale, f16x4& hi, f16x4& lo) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float x = w[j] * scale;
+        const _Float16 h = (_Float16)x;
+        hi[j] = h;
+        lo[j] = (_Float16)(x - (float)h);
+    }
+}
+
+// One-time (finalize) kernels for HALF.
+// max |x| over the first `ncols` floats of each row -> *out (bits of a non-negative float, atomicMax as uint)
+__global__ __launch_bounds__(256) void k_v2_absmax(const float* __restrict__ rows, long long nrows, int row_floats,
+                                                   int ncols, unsigned* __restrict__ out) {
+    float m = 0.f;
+    const long long total = nrows * ncols;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long v = i / ncols;
+        const int c = (int)(i - v * ncols);
+        const float a = fabsf(rows[v * row_floats + c]);
+        m = (a > m || a != a) ? a : m;                            // NaN propagates (the host then refuses HALF)
+    }
+    for (int d = 32; d >= 1; d >>= 1) { const float o = __shfl_xor(m, d); m = (o > m || o != o) ? o : m; }
+    if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));
+}
+// folded fp32 rows {P[16] | scalar | 0..} -> split rows {[hi4|lo4] x 4 | scalar | 0..} of P * scale
+__global__ __launch_bounds__(256) void k_v2_split_rows(const float* __restrict__ src, float* __restrict__ dst,
+                                                       long long nrows, float scale) {
+    const long long total = nrows * 8;                           // 8 sixteen-byte pieces per 128-byte row
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long v = i >> 3;
+        const int pc = (int)(i & 7);
+        const f32x4 in = ld4(src + v * 32 + 4 * pc);
+        if (pc < 4) {
+            f16x4 hi, lo;
+            split_half4(in, scale, hi, lo);
+            f16x8 o = {hi[0], hi[1], hi[2], hi[3], lo[0], lo[1], lo[2], lo[3]};
+            *reinterpret_cast<f16x8*>(dst + v * 32 + 4 * pc) = o;
+        } else {
+            st4(dst + v * 32 + 4 * pc, in);
+        }
+    }
+}
 
 // One-time (finalize) kernel: joint rows from the per-field folded rows (k_v2_fold output).
 // One wave per joint row; lane n < KP sums P, lane KP <= n < KP + H0 does deep0's share of output n - KP.
@@ -75,7 +140,7 @@ __global__ __launch_bounds__(256) void k_v2_fold_joint(const float* __restrict__
     }
 }
 
-template <int G_BIG, int NJF, int KPC, int H0C, int H1C, int WAVES>
+template <int G_BIG, int NJF, int KPC, int H0C, int H1C, int WAVES, bool HALF>
 __global__ __launch_bounds__(WAVES * 64, 2) void k_deepfm_v2_joint(const V2JRun A, const int* __restrict__ ids,
                                                                    const float* __restrict__ dense,
                                                                    float* __restrict__ out, int B,
@@ -86,7 +151,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_deepfm_v2_joint(const V2JRun 
     constexpr int KP = LD::KP, H0 = H0C * 16;
     constexpr unsigned RB = (KP + 16) * 4;                    // bytes per folded row
     constexpr unsigned JB = (KP + H0 + 16) * 4;               // bytes per joint row
-    constexpr int NKR = (G_BIG + 1) * KPC;                    // deep0 K chunks still computed per sample: numerics, then the big fields
+    constexpr int NKR = HALF ? 1 : (G_BIG + 1) * KPC;         // deep0 K chunks on f32 MFMA: numerics (+ the big fields unless HALF)
     static_assert(KPC == 1, "row layout: one 16-float chunk of projections per field");
     static_assert(G_BIG >= 1 && G_BIG <= 3 && NJF >= 1 && NJF <= V2J_MAX_JF, "field split");
     const int tid = threadIdx.x;
@@ -183,13 +248,29 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_deepfm_v2_joint(const V2JRun 
     f32x4 rW0[H0C][NKR], rW1[H1C][H0C];
     f32x4 rwn[KPC], rbpn[KPC], rb1[H1C], rhfm[KPC], rhd[H1C];
     f32x4 rfn = zero;
+    f16x8 hWa[HALF ? G_BIG : 1][H0C], hWb[HALF ? G_BIG : 1][H0C];   // HALF: [Whi|Whi], [Wlo|Wlo] fragments of the big fields
+    f16x8 hSel = {0, 0, 0, 0, 0, 0, 0, 0};                         // HALF: 0/1 selection A operand: D[n] = hi[n] + lo[n]
     auto load_weights = [&]() {
         const float* w0r = wq + LD::off_w0 + r * LD::S0;
 #pragma unroll
         for (int n0 = 0; n0 < H0C; ++n0) {
             rW0[n0][0] = ld4(w0r + n0 * 16 * LD::S0 + 16 * G_EMB);                     // numeric chunk
 #pragma unroll
-            for (int b = 0; b < G_BIG; ++b) rW0[n0][1 + b] = ld4(w0r + n0 * 16 * LD::S0 + 16 * A.big_grp[b]);
+            for (int b = 0; b < G_BIG; ++b) {
+                const f32x4 w = ld4(w0r + n0 * 16 * LD::S0 + 16 * A.big_grp[b]);
+                if constexpr (HALF) {
+                    f16x4 hi, lo;
+                    split_half4(w, A.w_scale, hi, lo);
+                    hWa[b][n0] = f16x8{hi[0], hi[1], hi[2], hi[3], hi[0], hi[1], hi[2], hi[3]};
+                    hWb[b][n0] = f16x8{lo[0], lo[1], lo[2], lo[3], lo[0], lo[1], lo[2], lo[3]};
+                } else {
+                    rW0[n0][(HALF ? 0 : 1 + b)] = w;
+                }
+            }
+        }
+        if constexpr (HALF) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) hSel[e] = (4 * q + (e & 3) == r) ? (_Float16)1.0f : (_Float16)0.0f;
         }
 #pragma unroll
         for (int n1 = 0; n1 < H1C; ++n1) {
@@ -225,25 +306,56 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_deepfm_v2_joint(const V2JRun 
 #pragma unroll
         for (int n0 = 0; n0 < H0C; ++n0) { hA[n0] = pq[n0]; hB[n0] = zero; }
         f32x4 s = ps + pn;                                        // FM sum: small fields (joint row) + numerics ...
+        if constexpr (HALF) {
+            // big fields on the f16 matrix pipe: per field [Whi|Whi].x, [Wlo|Wlo].x for both n-blocks and the
+            // selection matrix for the FM sum; three accumulator chains, same-accumulator distance >= 2
+            f32x4 aFa[H0C], aFb[H0C], aS = zero;                  // 2*H0C + 1 independent accumulator chains
 #pragma unroll
-        for (int b = 0; b < G_BIG; ++b) s += P[b];                // ... + big fields
-        __builtin_amdgcn_sched_barrier(0);
+            for (int n0 = 0; n0 < H0C; ++n0) { aFa[n0] = zero; aFb[n0] = zero; }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int c = 0; c < NKR; c += 2) {
-            const bool hb = c + 1 < NKR;
-            const f32x4 pa = c == 0 ? pn : P[c - 1];
-            const f32x4 pb = !hb ? zero : P[hb ? c : 0];
+            for (int b = 0; b < G_BIG; ++b) {
+                const f16x8 xb = __builtin_bit_cast(f16x8, P[b]);
 #pragma unroll
-            for (int st = 0; st < 4; ++st) {
+                for (int n0 = 0; n0 < H0C; ++n0) aFa[n0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(hWa[b][n0], xb, aFa[n0], 0, 0, 0);
+                aS = __builtin_amdgcn_mfma_f32_16x16x32_f16(hSel, xb, aS, 0, 0, 0);
+#pragma unroll
+                for (int n0 = 0; n0 < H0C; ++n0) aFb[n0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(hWb[b][n0], xb, aFb[n0], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);                // keep the round-robin order: the next use of a chain is 5 MFMAs away
+            }
+            f32x4 aF[H0C];
+#pragma unroll
+            for (int n0 = 0; n0 < H0C; ++n0) aF[n0] = aFa[n0] + aFb[n0];
+            // numerics' chunk on f32 MFMA (its operand is computed per sample); one chain per n-block
+#pragma unroll
+            for (int st = 0; st < 4; ++st)
 #pragma unroll
                 for (int n0 = 0; n0 < H0C; ++n0)
-                    hA[n0] = __builtin_amdgcn_mfma_f32_16x16x4f32(rW0[n0][c][st], pa[st], hA[n0], 0, 0, 0);
-                if (hb) {
+                    hA[n0] = __builtin_amdgcn_mfma_f32_16x16x4f32(rW0[n0][0][st], pn[st], hA[n0], 0, 0, 0);
+            s += aS * A.unscale_s;
+#pragma unroll
+            for (int n0 = 0; n0 < H0C; ++n0) hB[n0] = aF[n0] * A.unscale_h;
+        } else {
+#pragma unroll
+            for (int b = 0; b < G_BIG; ++b) s += P[b];            // ... + big fields
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int c = 0; c < NKR; c += 2) {
+                const bool hb = c + 1 < NKR;
+                const f32x4 pa = c == 0 ? pn : P[c > 0 ? c - 1 : 0];
+                const f32x4 pb = !hb ? zero : P[hb ? c : 0];
+#pragma unroll
+                for (int st = 0; st < 4; ++st) {
 #pragma unroll
                     for (int n0 = 0; n0 < H0C; ++n0)
-                        hB[n0] = __builtin_amdgcn_mfma_f32_16x16x4f32(rW0[n0][hb ? c + 1 : c][st], pb[st], hB[n0], 0, 0, 0);
+                        hA[n0] = __builtin_amdgcn_mfma_f32_16x16x4f32(rW0[n0][c][st], pa[st], hA[n0], 0, 0, 0);
+                    if (hb) {
+#pragma unroll
+                        for (int n0 = 0; n0 < H0C; ++n0)
+                            hB[n0] = __builtin_amdgcn_mfma_f32_16x16x4f32(rW0[n0][hb ? c + 1 : c][st], pb[st], hB[n0], 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-                __builtin_amdgcn_sched_barrier(0);
             }
         }
         f32x4 h0[H0C];

@@ -556,6 +556,7 @@ struct sprk_engine {
     int v2j_variant = -1;
     V2JRun v2j_run;
     float* v2j_tab = nullptr;      // joint rows (device)
+    float* v2j_big = nullptr;      // HALF: split-half rows of the big fields (device)
 };
 
 namespace {
@@ -719,23 +720,25 @@ const V2Variant kV2Variants[] = {
 
 // ---- dispatch table for k_deepfm_v2_joint<G_BIG, NJF, KPC, H0C, H1C, WAVES> ----
 typedef void (*V2JLaunchFn)(const V2JRun&, const int*, const float*, float*, int, int*, const float*, int, size_t, hipStream_t);
-template <int G_BIG, int NJF>
+template <int G_BIG, int NJF, bool HALF>
 void v2j_launch(const V2JRun& a, const int* ids, const float* dense, float* out, int B, int* err, const float* image,
                 int grid, size_t lds, hipStream_t st) {
-    hipLaunchKernelGGL((k_deepfm_v2_joint<G_BIG, NJF, 1, 2, 1, V2_WAVES>), dim3(grid), dim3(V2_WAVES * 64), lds, st,
+    hipLaunchKernelGGL((k_deepfm_v2_joint<G_BIG, NJF, 1, 2, 1, V2_WAVES, HALF>), dim3(grid), dim3(V2_WAVES * 64), lds, st,
                        a, ids, dense, out, B, err, image);
 }
 struct V2JVariant {
     int g_big, njf;
+    bool half;                            // big fields on split-f16 MFMA
     const void* fn;
     V2JLaunchFn launch;
 };
-#define V2J_VARIANT(G_BIG, NJF) \
-    {G_BIG, NJF, reinterpret_cast<const void*>(&k_deepfm_v2_joint<G_BIG, NJF, 1, 2, 1, V2_WAVES>), &v2j_launch<G_BIG, NJF>}
+#define V2J_VARIANT(G_BIG, NJF, HALF) \
+    {G_BIG, NJF, HALF, reinterpret_cast<const void*>(&k_deepfm_v2_joint<G_BIG, NJF, 1, 2, 1, V2_WAVES, HALF>), &v2j_launch<G_BIG, NJF, HALF>}
+#define V2J_BOTH(G_BIG, NJF) V2J_VARIANT(G_BIG, NJF, true), V2J_VARIANT(G_BIG, NJF, false)
 const V2JVariant kV2JVariants[] = {
-    V2J_VARIANT(3, 3),    // BASELINE config 2: movieId, userId, userRatedMovie1 + a joint table of the three genre fields
-    V2J_VARIANT(2, 2),    // the reference's own four fields (movieId, userId + two genres), config-4 shape
-    V2J_VARIANT(3, 2), V2J_VARIANT(3, 1), V2J_VARIANT(2, 3), V2J_VARIANT(2, 1), V2J_VARIANT(1, 3), V2J_VARIANT(1, 2), V2J_VARIANT(1, 1),
+    V2J_BOTH(3, 3),    // BASELINE config 2: movieId, userId, userRatedMovie1 + a joint table of the three genre fields
+    V2J_BOTH(2, 2),    // the reference's own four fields (movieId, userId + two genres), config-4 shape
+    V2J_BOTH(3, 2), V2J_BOTH(3, 1), V2J_BOTH(2, 3), V2J_BOTH(2, 1), V2J_BOTH(1, 3), V2J_BOTH(1, 2), V2J_BOTH(1, 1),
 };
 
 // Recognise the plan models.DeepFMv2 emits (DeepFM_v2.py graph) and fill the fused kernel's arguments.
@@ -874,9 +877,40 @@ int setup_v2_joint(sprk_engine* h) {
         else big[nbig++] = g;
     }
     if (njf < 1 || nbig < 1 || nbig > 3) return SPRK_OK;
+    // HALF: scales from max|P| over the big fields' folded rows and max|W0|; refused for non-finite weights
+    const char* hm = getenv("SPRK_V2_HALF");                  // A/B switch: "0" = big fields on f32 MFMA
+    bool half = !(hm && hm[0] == '0');
+    float p_scale = 1.f, w_scale = 1.f;
+    if (half) {
+        unsigned* d_max = nullptr;
+        HIP_TRY(hipMalloc((void**)&d_max, 2 * sizeof(unsigned)));
+        HIP_TRY(hipMemset(d_max, 0, 2 * sizeof(unsigned)));
+        for (int b = 0; b < nbig; ++b) {
+            const long long rows = (long long)h->v2run.vocab[big[b]] + 1;
+            long long blocks = (rows * KP + 255) / 256;
+            if (blocks > 8192) blocks = 8192;
+            hipLaunchKernelGGL(k_v2_absmax, dim3((unsigned)blocks), dim3(256), 0, 0,
+                               h->v2_folded + (size_t)h->v2run.rowbase[big[b]] * (KP + 16), rows, KP + 16, KP, d_max);
+        }
+        hipLaunchKernelGGL(k_v2_absmax, dim3(8), dim3(256), 0, 0, h->v2.W0, (long long)H0, (G + 1) * KP, (G + 1) * KP, d_max + 1);
+        HIP_TRY(hipGetLastError());
+        unsigned bits[2];
+        HIP_TRY(hipMemcpy(bits, d_max, sizeof(bits), hipMemcpyDeviceToHost));
+        (void)hipFree(d_max);
+        float mx[2];
+        memcpy(mx, bits, sizeof(mx));
+        for (int i = 0; i < 2; ++i) {
+            if (!(mx[i] < 3.0e38f)) { half = false; break; }     // NaN / Inf in the weights: keep the f32 path
+            int e = 0;
+            if (mx[i] > 0.f) { (void)frexpf(mx[i], &e); e = 15 - e; }   // mx * 2^e in [2^14, 2^15)
+            if (e > 60) e = 60;
+            if (e < -60) e = -60;
+            (i == 0 ? p_scale : w_scale) = ldexpf(1.f, e);
+        }
+    }
     int variant = -1;
     for (size_t v = 0; v < sizeof(kV2JVariants) / sizeof(kV2JVariants[0]); ++v)
-        if (kV2JVariants[v].g_big == nbig && kV2JVariants[v].njf == njf) variant = (int)v;
+        if (kV2JVariants[v].g_big == nbig && kV2JVariants[v].njf == njf && kV2JVariants[v].half == half) variant = (int)v;
     if (variant < 0) return SPRK_OK;
     V2JRun& r = h->v2j_run;
     memset(&r, 0, sizeof(r));
@@ -909,6 +943,26 @@ int setup_v2_joint(sprk_engine* h) {
     (void)hipFree(d_rb); (void)hipFree(d_v1); (void)hipFree(d_grp);
     r.tab0 = h->v2_folded;
     r.jtab = h->v2j_tab;
+    r.w_scale = w_scale; r.unscale_h = 1.f / (p_scale * w_scale); r.unscale_s = 1.f / p_scale;
+    if (half) {
+        size_t big_rows = 0;
+        for (int b = 0; b < nbig; ++b) big_rows += (size_t)r.big_vocab[b] + 1;
+        if (big_rows * (KP + 16) * sizeof(float) >= ((size_t)1 << 32)) return fail(SPRK_EINVAL, "split rows exceed 32-bit offsets");
+        HIP_TRY(hipMalloc((void**)&h->v2j_big, big_rows * (KP + 16) * sizeof(float)));
+        size_t base = 0;
+        for (int b = 0; b < nbig; ++b) {
+            const long long rows = (long long)r.big_vocab[b] + 1;
+            long long nb = (rows * 8 + 255) / 256;
+            if (nb > 65536) nb = 65536;
+            hipLaunchKernelGGL(k_v2_split_rows, dim3((unsigned)nb), dim3(256), 0, 0,
+                               h->v2_folded + (size_t)r.big_rowbase[b] * (KP + 16), h->v2j_big + base * (KP + 16), rows, p_scale);
+            r.big_rowbase[b] = (unsigned)base;
+            base += (size_t)rows;
+        }
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipDeviceSynchronize());
+        r.tab0 = h->v2j_big;
+    }
     HIP_TRY(hipFuncSetAttribute(kV2JVariants[variant].fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)vv.lds_bytes));
     h->v2j_variant = variant;
     return SPRK_OK;
@@ -1313,6 +1367,7 @@ void sprk_destroy(sprk_handle h) {
     if (h->v2_fo_all) (void)hipFree(h->v2_fo_all);
     if (h->v2_folded) (void)hipFree(h->v2_folded);
     if (h->v2j_tab) (void)hipFree(h->v2j_tab);
+    if (h->v2j_big) (void)hipFree(h->v2j_big);
     if (h->din_w12) (void)hipFree(h->din_w12);
     if (h->din_w4) (void)hipFree(h->din_w4);
     if (h->din_vc) (void)hipFree(h->din_vc);

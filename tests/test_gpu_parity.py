@@ -334,10 +334,10 @@ def test_concurrent_streams_share_a_handle(torch, config2):
 # --------------------------------------------------------------------------------------------
 # the four execution paths of the DeepFM_v2 graph must agree with the oracle and with each other
 # --------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("env", [{}, {"SPRK_V2_JOINT": "0"}, {"SPRK_V2_FOLD": "0"}, {"SPRK_FORCE_INTERPRETER": "1"}],
-                         ids=["joint-small-fields", "chain-folded-regs", "chain-unfolded-lds", "interpreter"])
+@pytest.mark.parametrize("env", [{}, {"SPRK_V2_HALF": "0"}, {"SPRK_V2_JOINT": "0"}, {"SPRK_V2_FOLD": "0"}, {"SPRK_FORCE_INTERPRETER": "1"}],
+                         ids=["joint-split-f16", "joint-f32", "chain-folded-regs", "chain-unfolded-lds", "interpreter"])
 def test_deepfm_v2_execution_paths(torch, env, monkeypatch):
-    for k in ("SPRK_V2_FOLD", "SPRK_V2_REG", "SPRK_V2_JOINT", "SPRK_FORCE_INTERPRETER"):
+    for k in ("SPRK_V2_FOLD", "SPRK_V2_REG", "SPRK_V2_JOINT", "SPRK_V2_HALF", "SPRK_FORCE_INTERPRETER"):
         monkeypatch.delenv(k, raising=False)
     for k, v in env.items():
         monkeypatch.setenv(k, v)
@@ -387,13 +387,42 @@ def test_deepfm_v2_joint_field_splits(torch, monkeypatch, fields):
     feats = SY.synth_fields(B, fields, seed=55)
     order = [k for k, _, _ in fields]
     outs = []
-    for joint in ("1", "0"):
+    for joint, half in (("1", "1"), ("1", "0"), ("0", "0")):
         monkeypatch.setenv("SPRK_V2_JOINT", joint)
+        monkeypatch.setenv("SPRK_V2_HALF", half)
         model = M.DeepFMv2(seed=44, emb_dim=16, fields=fields, proj_dim=16)
         outs.append(model.predict(feats)[:, 0])
     ref = O.deepfm_v2_forward(feats, model.weights, dtype=np.float64, fields=fields, order=order)[:, 0]
-    assert np.abs(outs[0] - ref).max() <= TIGHT
-    assert np.abs(outs[1] - ref).max() <= TIGHT
+    for o in outs:
+        assert np.abs(o - ref).max() <= TIGHT
+
+
+def test_deepfm_v2_split_f16_is_fp32_class(torch, monkeypatch):
+    """The split-f16 MFMA path (hi + lo halfs, f32 accumulate) must be as close to the fp64 oracle as the
+    f32 MFMA path is -- on the pre-sigmoid scale too, with O(1) numerics so that the score is not saturated
+    -- and must stay so for tables whose magnitudes are far from 1 (power-of-two operand scaling)."""
+    B = 16384
+    fields = SY.CONFIG2_FIELDS
+    order = [k for k, _, _ in fields]
+    feats = SY.synth_fields(B, fields, seed=61)
+    for k in ("movieRatingCount", "userRatingCount", "releaseYear"):     # keep the logit in sigmoid's live range
+        feats[k] = (np.asarray(feats[k], np.float64) % 7).astype(np.asarray(feats[k]).dtype)
+    for table_scale in (1.0, 1.0 / 4096.0, 37.0):
+        base = M.DeepFMv2(seed=45, emb_dim=16, fields=fields, proj_dim=16)
+        w = dict(base.weights)
+        for k, _, _ in fields:
+            w["emb/" + k] = (w["emb/" + k] * table_scale).astype(np.float32)
+        ref = O.deepfm_v2_forward(feats, w, dtype=np.float64, fields=fields, order=order)[:, 0]
+        err = {}
+        for half in ("1", "0"):
+            monkeypatch.setenv("SPRK_V2_HALF", half)
+            p = M.DeepFMv2(weights=w, emb_dim=16, fields=fields, proj_dim=16).predict(feats)[:, 0]
+            err[half] = float(np.abs(p - ref).max())
+        print("split-f16 vs f32 MFMA, table scale %g: max|err| vs fp64 oracle %.3g (split) %.3g (f32), score std %.3f"
+              % (table_scale, err["1"], err["0"], ref.std()))
+        assert 0.02 < ref.std()
+        assert err["1"] <= TOL and err["0"] <= TOL, (table_scale, err)
+        assert err["1"] <= 2 * err["0"] + 2e-6, (table_scale, err)
 
 
 def test_deepfm_v2_unaligned_views_and_tails(torch, config2):
