@@ -140,6 +140,23 @@ __global__ __launch_bounds__(256) void k_v2_fold_joint(const float* __restrict__
     }
 }
 
+// everything one 16-sample task needs from memory, in the (r,q) lane layout
+template <int G_BIG, int H0C>
+struct V2JSet {
+    f32x4 x[G_BIG];       // big fields' row pieces: 4 floats of P, or [hi4 | lo4] halfs (HALF)
+    f32x4 xs;             // joint row: sum of the small fields' P, this lane's piece
+    f32x4 xq[H0C];        // joint row: b0 + sum W0 P of the small fields, C/D layout
+    f32x4 xn;             // numerics
+    float w1a;            // per-id logit terms fetched by this lane
+};
+
+// Task pipeline: TWO gather sets per wave (A, B), each the direct operand of its scoring stage.  A wave's
+// first two tasks are gathered back to back at kernel entry, so at B = 65 536 (4 096 tasks on 2 048
+// resident waves: exactly two per wave) every row of the batch is requested as soon as its ids have
+// landed and the memory system streams without a bubble; afterwards the loop alternates
+// score(A), gather(A'), score(B), gather(B') with ids fetched two tasks ahead, i.e. one gather is
+// always in flight under a scoring stage.  Loads are unconditional (task indices are clamped, the tail
+// re-gathers a valid task and drops the result) so that the in-order vmcnt waits stay exact.
 template <int G_BIG, int NJF, int KPC, int H0C, int H1C, int WAVES, bool HALF>
 __global__ __launch_bounds__(WAVES * 64, 2) void k_deepfm_v2_joint(const V2JRun A, const int* __restrict__ ids,
                                                                    const float* __restrict__ dense,
@@ -148,6 +165,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_deepfm_v2_joint(const V2JRun 
                                                                    const float* __restrict__ image) {
     constexpr int G_EMB = G_BIG + NJF;
     using LD = V2Lds<G_EMB, 4, KPC, H0C, H1C, true>;          // the weight image is the FOLD image of the whole model
+    using Set = V2JSet<G_BIG, H0C>;
     constexpr int KP = LD::KP, H0 = H0C * 16;
     constexpr unsigned RB = (KP + 16) * 4;                    // bytes per folded row
     constexpr unsigned JB = (KP + H0 + 16) * 4;               // bytes per joint row
@@ -164,14 +182,14 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_deepfm_v2_joint(const V2JRun 
     const int wave_global = blockIdx.x * WAVES + wave;
     float* stage = smem + LD::total_pad + wave * LD::stage_floats;
     const float* wq = smem + 4 * q;
-
-    // ---- gather stage (consumed one loop trip after it was issued) ----
-    f32x4 raw = zero;
-    f32x4 x[G_BIG], xs = zero, xq[H0C], xn = zero;
-    float w1a = 0.f;
     bool bad = false;
     const bool aligned = !(A.flags & 1);
-    auto ld_raw = [&](int tk) {
+    auto clampt = [&](int tk) { return tk < ntasks ? tk : ntasks - 1; };
+
+    // ---- gather stage ----
+    //   ld_raw : the task's contiguous ids / numerics blocks, one 16-B load per lane
+    //   gather : VGPR -> wave-private LDS slot -> the (r,q) lanes that need them, then the row gathers
+    auto ld_raw = [&](int tk, f32x4& raw) {
         if (aligned && tk * 16 + 16 <= B) {                       // wave-uniform
             const bool isid = lane < 32;
             const int j = isid ? lane : lane - 32;
@@ -181,7 +199,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_deepfm_v2_joint(const V2JRun 
             raw = ld4(src + 4 * (j < n4 ? j : 0));
         }
     };
-    auto gather = [&](int tk) {
+    auto gather = [&](int tk, const f32x4& raw, Set& S) {
         if (aligned && tk * 16 + 16 <= B) {
             const bool isid = lane < 32;
             const int j = isid ? lane : lane - 32;
@@ -210,19 +228,19 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_deepfm_v2_joint(const V2JRun 
             const float* nrow = stage + 128 + r * A.ND;
             const int c0 = 4 * q, last = A.n_num - 1;
             // lane slots beyond n_num hold a duplicate finite value that only ever meets zero weights
-            xn.x = nrow[min(c0 + 0, last)];
-            xn.y = nrow[min(c0 + 1, last)];
-            xn.z = nrow[min(c0 + 2, last)];
-            xn.w = nrow[min(c0 + 3, last)];
+            S.xn.x = nrow[min(c0 + 0, last)];
+            S.xn.y = nrow[min(c0 + 1, last)];
+            S.xn.z = nrow[min(c0 + 2, last)];
+            S.xn.w = nrow[min(c0 + 3, last)];
         }
         const char* tb = reinterpret_cast<const char*>(A.tab0);
         const char* jb = reinterpret_cast<const char*>(A.jtab);
 #pragma unroll
-        for (int b = 0; b < G_BIG; ++b) x[b] = *reinterpret_cast<const f32x4*>(tb + (sid[b] * RB + 16u * q));
+        for (int b = 0; b < G_BIG; ++b) S.x[b] = *reinterpret_cast<const f32x4*>(tb + (sid[b] * RB + 16u * q));
         const unsigned jo = jidx * JB;
-        xs = *reinterpret_cast<const f32x4*>(jb + (jo + 16u * q));
+        S.xs = *reinterpret_cast<const f32x4*>(jb + (jo + 16u * q));
 #pragma unroll
-        for (int n0 = 0; n0 < H0C; ++n0) xq[n0] = *reinterpret_cast<const f32x4*>(jb + (jo + 4u * KP + 64u * n0 + 16u * q));
+        for (int n0 = 0; n0 < H0C; ++n0) S.xq[n0] = *reinterpret_cast<const f32x4*>(jb + (jo + 4u * KP + 64u * n0 + 16u * q));
         // per-id logit terms: lane (r,q) fetches big field q's row scalar, the lanes past the big fields the joint one
         {
             // (the offsets pass through an empty asm: left visible, the select chain over q is turned into a
@@ -236,13 +254,9 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_deepfm_v2_joint(const V2JRun 
             const bool isj = q == G_BIG;                          // G_BIG <= 3, so one q row is left for the joint scalar
             const char* base = isj ? jb : tb;
             so = isj ? jo + 4u * (KP + H0) : so;
-            w1a = *reinterpret_cast<const float*>(base + so);
+            S.w1a = *reinterpret_cast<const float*>(base + so);
         }
     };
-
-    // ---- operands of the task being scored ----
-    f32x4 P[G_BIG], ps = zero, pq[H0C], pnum = zero;
-    float z1 = 0.f;
 
     // ---- register-resident weights (filled once, after the image barrier) ----
     f32x4 rW0[H0C][NKR], rW1[H1C][H0C];
@@ -287,7 +301,10 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_deepfm_v2_joint(const V2JRun 
         }
         rfn = ld4(smem + LD::off_fn + 4 * (q & 1));
     };
-    auto compute = [&]() -> float {
+
+    // ---- scoring stage ----
+    auto compute = [&](const Set& S) -> float {
+        const f32x4 pnum = S.xn;
         // numeric group's Dense projection (DeepFM_v2.py:118-120): two chains (even / odd K step)
         f32x4 pn;
         {
@@ -299,23 +316,22 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_deepfm_v2_joint(const V2JRun 
             pn = e + o;
         }
         // this lane's share of the per-id logit terms + numeric first-order partial (rfn = h0w * fo_num weights)
-        float zz = z1 + ((q < 2) ? dot4(rfn, pnum) : 0.f);
-        // deep0 (DeepFM_v2.py:124-125): accumulators start at the joint row's b0 + sum W0 P of the small fields;
-        // chunk order: numerics, big fields; even positions -> hA, odd -> hB (2*H0C independent chains)
+        float zz = ((q <= G_BIG) ? S.w1a : 0.f) + ((q < 2) ? dot4(rfn, pnum) : 0.f);
+        // deep0 (DeepFM_v2.py:124-125): accumulators start at the joint row's b0 + sum W0 P of the small fields
         f32x4 hA[H0C], hB[H0C];
 #pragma unroll
-        for (int n0 = 0; n0 < H0C; ++n0) { hA[n0] = pq[n0]; hB[n0] = zero; }
-        f32x4 s = ps + pn;                                        // FM sum: small fields (joint row) + numerics ...
+        for (int n0 = 0; n0 < H0C; ++n0) { hA[n0] = S.xq[n0]; hB[n0] = zero; }
+        f32x4 s = S.xs + pn;                                      // FM sum: small fields (joint row) + numerics ...
         if constexpr (HALF) {
-            // big fields on the f16 matrix pipe: per field [Whi|Whi].x, [Wlo|Wlo].x for both n-blocks and the
-            // selection matrix for the FM sum; three accumulator chains, same-accumulator distance >= 2
+            // big fields on the f16 matrix pipe: per field [Whi|Whi].x and [Wlo|Wlo].x for both n-blocks and the
+            // selection matrix for the FM sum
             f32x4 aFa[H0C], aFb[H0C], aS = zero;                  // 2*H0C + 1 independent accumulator chains
 #pragma unroll
             for (int n0 = 0; n0 < H0C; ++n0) { aFa[n0] = zero; aFb[n0] = zero; }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int b = 0; b < G_BIG; ++b) {
-                const f16x8 xb = __builtin_bit_cast(f16x8, P[b]);
+                const f16x8 xb = __builtin_bit_cast(f16x8, S.x[b]);
 #pragma unroll
                 for (int n0 = 0; n0 < H0C; ++n0) aFa[n0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(hWa[b][n0], xb, aFa[n0], 0, 0, 0);
                 aS = __builtin_amdgcn_mfma_f32_16x16x32_f16(hSel, xb, aS, 0, 0, 0);
@@ -323,9 +339,6 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_deepfm_v2_joint(const V2JRun 
                 for (int n0 = 0; n0 < H0C; ++n0) aFb[n0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(hWb[b][n0], xb, aFb[n0], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);                // keep the round-robin order: the next use of a chain is 5 MFMAs away
             }
-            f32x4 aF[H0C];
-#pragma unroll
-            for (int n0 = 0; n0 < H0C; ++n0) aF[n0] = aFa[n0] + aFb[n0];
             // numerics' chunk on f32 MFMA (its operand is computed per sample); one chain per n-block
 #pragma unroll
             for (int st = 0; st < 4; ++st)
@@ -334,16 +347,16 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_deepfm_v2_joint(const V2JRun 
                     hA[n0] = __builtin_amdgcn_mfma_f32_16x16x4f32(rW0[n0][0][st], pn[st], hA[n0], 0, 0, 0);
             s += aS * A.unscale_s;
 #pragma unroll
-            for (int n0 = 0; n0 < H0C; ++n0) hB[n0] = aF[n0] * A.unscale_h;
+            for (int n0 = 0; n0 < H0C; ++n0) hB[n0] = (aFa[n0] + aFb[n0]) * A.unscale_h;
         } else {
 #pragma unroll
-            for (int b = 0; b < G_BIG; ++b) s += P[b];            // ... + big fields
+            for (int b = 0; b < G_BIG; ++b) s += S.x[b];          // ... + big fields
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int c = 0; c < NKR; c += 2) {
                 const bool hb = c + 1 < NKR;
-                const f32x4 pa = c == 0 ? pn : P[c > 0 ? c - 1 : 0];
-                const f32x4 pb = !hb ? zero : P[hb ? c : 0];
+                const f32x4 pa = c == 0 ? pn : S.x[c > 0 ? c - 1 : 0];
+                const f32x4 pb = !hb ? zero : S.x[hb ? c : 0];
 #pragma unroll
                 for (int st = 0; st < 4; ++st) {
 #pragma unroll
@@ -383,50 +396,58 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_deepfm_v2_joint(const V2JRun 
         z += __shfl_xor(z, 32);
         return sigmoidf_fast(z + A.h0w * A.fo_bias + A.head_bias);
     };
+    auto store = [&](int tk, float score) {
+        const int m = tk * 16 + r;
+        if (q == 0 && m < B) out[m] = score;
+    };
 
-    // ---- prologue + software-pipelined task loop (trip i gathers task i, then scores task i-1) ----
-    int cur = wave_global, prev = -1;
-    if (cur < ntasks) ld_raw(cur);
-    bool first = true;
-    for (;;) {
-        const bool have_cur = cur < ntasks;                   // wave-uniform
-        if (have_cur) {
-            gather(cur);                                      // its ids arrived during the previous compute
-            if (cur + task_stride < ntasks) ld_raw(cur + task_stride);
-        }
-        if (first) {                                          // every wave of the workgroup passes here once
-            // weight image -> LDS by LDS-DMA: 1-KB pieces, wave w takes w, w+WAVES, ...
+    // ---- prologue: ids of the first two tasks and the weight image are requested together (the image
+    //      is L2-hot and lands inside the ids' memory latency), one barrier, weights -> registers, then
+    //      both gather sets back to back.  Straight-line code up to the loop: every s_waitcnt vmcnt the
+    //      compiler places is exact, so score(A) starts when A's rows are in, B's still streaming. ----
+    Set SA, SB;
+    f32x4 rawA = zero, rawB = zero;
+    int tA = wave_global, tB = wave_global + task_stride;
+    if (ntasks > 0) {
+        ld_raw(clampt(tA), rawA);
+        ld_raw(clampt(tB), rawB);
+    }
+    // weight image -> LDS by LDS-DMA (no VGPRs, no ds_write pass): 1-KB pieces, wave w takes w, w+WAVES, ...
 #pragma unroll 1
-            for (int c = wave; c < LD::total_pad / 256; c += WAVES)
-                __builtin_amdgcn_global_load_lds(
-                    (const __attribute__((address_space(1))) void*)(image + c * 256 + lane * 4),
-                    (__attribute__((address_space(3))) void*)(smem + c * 256), 16, 0, 0);
-            __syncthreads();                                  // (drains this wave's DMA and gathers first)
-            load_weights();
-            first = false;
+    for (int c = wave; c < LD::total_pad / 256; c += WAVES)
+        __builtin_amdgcn_global_load_lds(
+            (const __attribute__((address_space(1))) void*)(image + c * 256 + lane * 4),
+            (__attribute__((address_space(3))) void*)(smem + c * 256), 16, 0, 0);
+    __syncthreads();                                          // (drains this wave's ids loads and DMA)
+    load_weights();
+    if (tA >= ntasks) {
+        // a wave without work leaves after the barrier
+    } else if (ntasks <= 2 * task_stride) {
+        // At most two tasks per wave (B <= 65 536 on a full chip): no loop, hence no loop-carried loads --
+        // the compiler counts every outstanding load exactly and score(A) waits for A's rows only,
+        // running while B's rows are still streaming in.  (At a loop header hipcc falls back to waiting
+        // for ALL outstanding loads before the first use of a loop-carried one.)
+        gather(tA, rawA, SA);
+        gather(clampt(tB), rawB, SB);
+        store(tA, compute(SA));
+        if (tB < ntasks) store(tB, compute(SB));
+    } else {
+        gather(tA, rawA, SA);
+        ld_raw(clampt(tA + 2 * task_stride), rawA);
+        gather(clampt(tB), rawB, SB);
+        ld_raw(clampt(tB + 2 * task_stride), rawB);
+        for (;;) {
+            store(tA, compute(SA));
+            tA += 2 * task_stride;
+            gather(clampt(tA), rawA, SA);                     // (past the end: re-gathers the last task, never scored)
+            ld_raw(clampt(tA + 2 * task_stride), rawA);
+            if (tB >= ntasks) break;
+            store(tB, compute(SB));
+            tB += 2 * task_stride;
+            gather(clampt(tB), rawB, SB);
+            ld_raw(clampt(tB + 2 * task_stride), rawB);
+            if (tA >= ntasks) break;
         }
-        // the score is stored one stage late (see k_deepfm_v2_chain)
-        float score = 0.f;
-        if (prev >= 0) score = compute();
-        if (!have_cur) {
-            const int m = prev * 16 + r;
-            if (prev >= 0 && q == 0 && m < B) out[m] = score;
-            break;
-        }
-        // hand the gathered rows to the compute stage
-#pragma unroll
-        for (int b = 0; b < G_BIG; ++b) P[b] = x[b];
-        ps = xs;
-#pragma unroll
-        for (int n0 = 0; n0 < H0C; ++n0) pq[n0] = xq[n0];
-        {
-            const int m = prev * 16 + r;
-            if (prev >= 0 && q == 0 && m < B) out[m] = score;
-        }
-        pnum = xn;
-        z1 = (q <= G_BIG) ? w1a : 0.f;
-        prev = cur;
-        cur += task_stride;
     }
     if (__ballot(bad) != 0 && lane == 0) atomicOr(err, 1);
 }
