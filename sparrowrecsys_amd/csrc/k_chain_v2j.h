@@ -418,16 +418,27 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_deepfm_v2_joint(const V2JRun 
         __builtin_amdgcn_global_load_lds(
             (const __attribute__((address_space(1))) void*)(image + c * 256 + lane * 4),
             (__attribute__((address_space(3))) void*)(smem + c * 256), 16, 0, 0);
-    __syncthreads();                                          // (drains this wave's ids loads and DMA)
+    // At most two tasks per wave (B <= 65 536 on a full chip): no loop, hence no loop-carried loads -- the
+    // compiler counts every outstanding load exactly and score(A) waits for A's rows only, running while
+    // B's rows are still streaming in.  (At a loop header hipcc falls back to waiting for ALL outstanding
+    // loads before the first use of a loop-carried one.)  Gather A is issued BEFORE the image barrier: it
+    // needs the ids only, and vmcnt retires in order, so "at most NG loads outstanding" means this wave's
+    // DMA pieces (older) have landed while its NG row loads (younger) may still fly.  (Gather B follows the
+    // weight fragments: both sets live across load_weights() would spill.)
+    const bool two = tA < ntasks && ntasks <= 2 * task_stride;        // workgroup-uniform except for idle waves
+    constexpr int NG = G_BIG + 1 + H0C + 1;                           // VMEM loads per gather
+    static_assert(NG < 16, "s_waitcnt immediate below encodes vmcnt < 16");
+    if (two) {
+        gather(tA, rawA, SA);
+        __builtin_amdgcn_s_waitcnt(0x0F70 | NG);                      // s_waitcnt vmcnt(NG)
+    } else {
+        __builtin_amdgcn_s_waitcnt(0x0F70);                           // s_waitcnt vmcnt(0): ids and DMA
+    }
+    __builtin_amdgcn_s_barrier();                             // every wave's pieces of the image are in LDS
     load_weights();
     if (tA >= ntasks) {
         // a wave without work leaves after the barrier
-    } else if (ntasks <= 2 * task_stride) {
-        // At most two tasks per wave (B <= 65 536 on a full chip): no loop, hence no loop-carried loads --
-        // the compiler counts every outstanding load exactly and score(A) waits for A's rows only,
-        // running while B's rows are still streaming in.  (At a loop header hipcc falls back to waiting
-        // for ALL outstanding loads before the first use of a loop-carried one.)
-        gather(tA, rawA, SA);
+    } else if (two) {
         gather(clampt(tB), rawB, SB);
         store(tA, compute(SA));
         if (tB < ntasks) store(tB, compute(SB));
