@@ -243,11 +243,16 @@ def main():
                   "hbm_frac": roof["bytes_per_sample"] * B / din_s / HBM_PEAK,
                   "avg_launch_us": din_s * 1e6, "step_us_all_kernels": fwd_s * 1e6,
                   "timed_with": "HIP events, %s-only loop after the timed region" % roof["kernel"]}
+        # memory-side bytes per launch from the committed PMC passes (rocprofv3 --pmc runs are separate from the
+        # timed run by design); only quoted for the batch size and kernel they were collected on
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get(args.workload)
+                t = json.load(open(tpath)).get(args.workload)
+                if t and t.get("batch") == B and t.get("kernel") == rl["kernel"]:
+                    traffic = t["bytes_per_launch"]
+                    rl["traffic_source"] = "profiles/traffic.json (PMC FETCH_SIZE x2 + WRITE_SIZE, round %s)" % t.get("round")
             except Exception:
                 traffic = None
         rl["traffic"] = traffic

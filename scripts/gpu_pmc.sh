@@ -1,32 +1,48 @@
 #!/bin/bash
-# PMC counter passes (separate from kernel-trace stats runs), per MI355X_MICROARCH.md guidance.
+# PMC counter passes (separate from the kernel-trace --stats runs, per MI355X_MICROARCH.md): memory-side traffic of
+# the dominant kernels + a calibration of FETCH_SIZE / WRITE_SIZE on a known-byte-count gather, then SQ-side counters.
+# Writes gpurun_out/pmc_summary.json (copy to profiles/rNN/) .
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-WL=${1:-deepfm_v2_c2}
-EXTRA=${2:-}
 mkdir -p $R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 -L 2>/dev/null | grep -o -E "\b(FETCH_SIZE|WRITE_SIZE|TCC_HIT_sum|TCC_MISS_sum|TCC_EA0_RDREQ_sum|TCC_EA0_RDREQ_32B_sum|TCC_REQ_sum|SQ_WAVE_CYCLES|SQ_BUSY_CYCLES|SQ_WAIT_ANY|SQ_WAIT_INST_ANY|SQ_ACTIVE_INST_ANY|SQ_VALU_MFMA_BUSY_CYCLES|SQ_INSTS_VALU_MFMA_MOPS_F32|SQ_INSTS_MFMA|SQ_INSTS_VALU|SQ_ACTIVE_INST_VALU|SQ_ACTIVE_INST_LDS|SQ_LDS_BANK_CONFLICT|SQ_LDS_IDX_ACTIVE|SQ_INST_CYCLES_VMEM|SQ_WAIT_INST_LDS|GRBM_GUI_ACTIVE|TCP_TCC_READ_REQ_sum|TCP_TOTAL_CACHE_ACCESSES_sum|TCC_BUSY_sum)\b" | sort -u | tr '\n' ' ' > $R/gpurun_out/pmc_available.txt
-cat $R/gpurun_out/pmc_available.txt; echo
-run() { # name counters...
-  name=$1; shift
-  timeout 300 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $R/gpurun_out/pmc_${WL}_$name -o p -- python $R/bench.py --steps 20 --warmup 5 --cpu-seconds 0 --no-check --workload $WL $EXTRA > $R/gpurun_out/pmc_${WL}_$name.log 2>&1
+pass() { # tag name counters -- command...
+  tag=$1; name=$2; shift 2; ctr=(); while [ "$1" != "--" ]; do ctr+=("$1"); shift; done; shift
+  timeout 300 rocprofv3 --pmc "${ctr[@]}" --kernel-trace --output-format csv -d $R/gpurun_out/pmc_${tag}_$name -o p -- "$@" > $R/gpurun_out/pmc_${tag}_$name.log 2>&1
 }
-run fetch FETCH_SIZE
-run tcc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum
-run write WRITE_SIZE TCC_REQ_sum
-run sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE
-run sq2 SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM
+C2="python $R/bench.py --steps 20 --warmup 5 --cpu-seconds 0 --no-check"
+C3="python $R/bench.py --steps 20 --warmup 5 --cpu-seconds 0 --no-check --workload din_c3"
+CAL="python $R/scripts/pmc_calib.py"
+for t in c2 c3 cal; do
+  case $t in c2) CMD=$C2;; c3) CMD=$C3;; cal) CMD=$CAL;; esac
+  pass $t fetch FETCH_SIZE -- $CMD
+  pass $t write WRITE_SIZE TCC_REQ_sum -- $CMD
+  pass $t tcc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum -- $CMD
+done
+for t in c2 c3; do
+  case $t in c2) CMD=$C2;; c3) CMD=$C3;; esac
+  pass $t sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -- $CMD
+  pass $t sq2 SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_MFMA SQ_WAVES SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT -- $CMD
+done
 cd $R
 python - <<'PY'
-import csv, glob, collections, os, sys
+import csv, glob, collections, os, json
+summary = {}
 for d in sorted(glob.glob('gpurun_out/pmc_*/')):
+    tag = os.path.basename(d.rstrip('/'))
     for f in glob.glob(d + '/**/*counter_collection.csv', recursive=True):
         agg = collections.defaultdict(lambda: collections.defaultdict(list))
         for row in csv.DictReader(open(f)):
-            k = row['Kernel_Name'][:60]
-            agg[k][row['Counter_Name']].append(float(row['Counter_Value']))
+            agg[row['Kernel_Name']][row['Counter_Name']].append(float(row['Counter_Value']))
         for k, cs in agg.items():
-            if 'rocclr' in k: continue
-            print(os.path.basename(d.rstrip('/')), k[:50], {c: round(sum(v)/len(v), 1) for c, v in cs.items()}, 'n=%d' % len(next(iter(cs.values()))))
+            if 'rocclr' in k or 'at::' in k or 'prep' in k or 'fold' in k or 'absmax' in k or 'split' in k or 'pack' in k:
+                continue
+            short = k.split('(')[0].split('::')[-1][:40]
+            summary.setdefault(tag, {})[short] = {c: round(sum(v) / len(v), 1) for c, v in cs.items()}
+            summary[tag][short]['launches'] = len(next(iter(cs.values())))
+json.dump(summary, open('gpurun_out/pmc_summary.json', 'w'), indent=1, sort_keys=True)
+for tag, ks in summary.items():
+    for k, v in ks.items():
+        print(tag, k, v)
 PY
+grep -h "calib D" gpurun_out/pmc_cal_fetch.log

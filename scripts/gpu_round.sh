@@ -1,5 +1,5 @@
 #!/bin/bash
-# Runs on the GPU box (via gpurun) from the repo root: parity tests, smoke, bench, rocprof kernel trace.
+# Runs on the GPU box (via gpurun) from the repo root: parity tests, smoke, bench A/B lines, rocprof kernel trace.
 set -u
 mkdir -p gpurun_out
 R=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -9,13 +9,17 @@ timeout 1200 python -m pytest tests -m gpu -q 2>&1 | tail -5 | tee gpurun_out/py
 echo "=== smoke"
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3 | tee gpurun_out/smoke.log
 echo "=== bench"
-timeout 600 python bench.py 2>&1 | tail -1 | tee gpurun_out/bench_c2.json
-SPRK_V2_FOLD=0 timeout 600 python bench.py --cpu-seconds 0 2>&1 | tail -1 | tee gpurun_out/bench_c2_unfolded.json
-SPRK_FORCE_INTERPRETER=1 timeout 600 python bench.py --cpu-seconds 0 2>&1 | tail -1 | tee gpurun_out/bench_c2_interp.json
-timeout 600 python bench.py --cpu-seconds 0 --dist zipf 2>&1 | tail -1 | tee gpurun_out/bench_c2_zipf.json
-timeout 600 python bench.py --cpu-seconds 0 --batch 1048576 --steps 400 --warmup 40 2>&1 | tail -1 | tee gpurun_out/bench_c2_b1m.json
-timeout 600 python bench.py --workload deepfm_c2 --cpu-seconds 0 2>&1 | tail -1 | tee gpurun_out/bench_c2_pairs.json
-timeout 600 python bench.py --steps 300 --warmup 30 --workload din_c3 --cpu-seconds 6 2>&1 | tail -1 | tee gpurun_out/bench_c3.json
+b() { out=$1; shift; timeout 600 env "$@" 2>&1 | tail -1 | tee gpurun_out/$out.json | cut -c1-200; }
+b bench_c2 python bench.py
+b bench_c2_joint_f32 SPRK_V2_HALF=0 python bench.py --cpu-seconds 0
+b bench_c2_perfield SPRK_V2_JOINT=0 python bench.py --cpu-seconds 0
+b bench_c2_unfolded SPRK_V2_FOLD=0 python bench.py --cpu-seconds 0
+b bench_c2_interp SPRK_FORCE_INTERPRETER=1 python bench.py --cpu-seconds 0
+b bench_c2_zipf python bench.py --cpu-seconds 0 --dist zipf
+b bench_c2_b1m python bench.py --cpu-seconds 0 --batch 1048576 --steps 400 --warmup 40
+b bench_c2_pairs python bench.py --workload deepfm_c2 --cpu-seconds 0
+b bench_c3 python bench.py --steps 300 --warmup 30 --workload din_c3 --cpu-seconds 6
+b bench_c3_legacy SPRK_DIN_LEGACY=1 python bench.py --steps 100 --warmup 10 --workload din_c3 --cpu-seconds 0
 echo "=== rocprofv3 kernel trace"
 cd /tmp && export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_c2 -o c2 -- python $R/bench.py --steps 400 --warmup 40 --cpu-seconds 0 --no-check > $R/gpurun_out/prof_c2.log 2>&1

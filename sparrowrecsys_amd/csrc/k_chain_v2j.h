@@ -1,19 +1,22 @@
 // k_chain_v2j.h -- k_deepfm_v2_joint: the register-chained DeepFM_v2 forward (k_chain_v2.h, FOLD + REG)
-// with the SMALL-vocabulary fields folded one step further.  Included inside sparrow_hip.hip's
-// anonymous namespace, after k_chain_v2.h.
+// with the SMALL-vocabulary fields folded one step further and kept in LDS.  Included inside
+// sparrow_hip.hip's anonymous namespace, after k_chain_v2.h.
 //
 // Everything field g contributes to a score is a function of its id alone (DeepFM_v2.py:106-126,147-155):
 //     P_g[id]                       its projected embedding  -> FM sum S = sum_g P_g and deep0's input
 //     W0_g^T P_g[id]                its share of deep0's pre-activation (deep0 is linear in the concat)
 //     h0w*w1_g[id] - hfm.P_g[id]^2  its first-order weight and its share of the FM sum of squares
-// For a field with a handful of rows (the 19-entry genre vocabularies) all of that is a tiny table, and
-// for a GROUP of such fields the sums over the group are again a table, indexed by the tuple of ids
-// (20^3 = 8 000 rows at BASELINE config 2).  k_v2_fold_joint builds it once at sprk_finalize:
-//     joint row = [ sum P (KP floats) | b0 + sum W0_g^T P_g (H0 floats) | sum of row scalars | 0.. ]  (256 B)
-// so per sample the NJF small fields cost ONE 256-byte gather (L2 resident) instead of NJF row gathers +
-// NJF row-scalar gathers + NJF*8 f32 MFMAs + NJF*4 VALU adds: at config 2 deep0 shrinks from 7 K-chunks
-// to 4 (56 -> 32 MFMAs per 16 samples), the gather from 6+2 loads to 3+3+1.  Same fp32 arithmetic,
-// other association of the sums (the oracle comparison is tolerance based either way).
+// For a field with a handful of rows (the 19-entry genre vocabularies) all of that is a tiny table:
+// k_v2_fold_small builds, once at sprk_finalize, rows {P (KP) | W0_g^T P (H0) | row scalar} for every id of
+// every small field (3 x 20 rows x 208 B = 12.5 KB at BASELINE config 2; deep0's bias rides in the first
+// field's rows), the kernel stages them in LDS next to the weight image, and a sample's small fields cost
+// three ds_read_b128 per field at scoring time -- no HBM/L2 gather, no MFMA: deep0 shrinks from 7 K-chunks
+// to 4, the per-sample gather from 6 rows + 2 row scalars to 3 rows + 1.
+// (A first version kept ONE joint table over the tuple of small ids in global memory -- 20^3 rows x 256 B =
+// 2 MB, a single gather per sample.  PMC showed what that costs: every XCD's 4 MB L2 streams 3 MB of
+// big-table lines per launch and keeps evicting the joint table, +77 k line fetches = +10 MB of fabric
+// traffic per 65 536-sample launch, 26 % above the algorithmic bytes.  In LDS the small fields cost no
+// memory traffic beyond a 12.5 KB broadcast read per workgroup.)
 //
 // HALF: the big fields' share of deep0 and of the FM sum runs on v_mfma_f32_16x16x32_f16 with SPLIT
 // operands instead of f32 MFMA.  On gfx950 the f32-input MFMA issues at the f32 vector rate and shares the
@@ -34,6 +37,7 @@
 
 #define V2J_MAX_BIG 4
 #define V2J_MAX_JF 3
+#define V2J_SS 52                         // floats per small-field row: 16 + 32 + 1, padded so that (SS/4) is odd (LDS banks)
 
 struct V2JRun {
     int F, ND, n_num;
@@ -41,10 +45,12 @@ struct V2JRun {
     int big_vocab[V2J_MAX_BIG];
     unsigned big_rowbase[V2J_MAX_BIG];    // first row of field b inside tab0 ([KP+16]-float rows, vocab+1 rows per field)
     int big_grp[V2J_MAX_BIG];             // its group index in the model's field order (selects the W0 K-chunk)
-    int j_col[V2J_MAX_JF];                // ids columns of the joint group's fields
+    int j_col[V2J_MAX_JF];                // ids columns of the small (LDS-resident) fields
     int j_vocab[V2J_MAX_JF];
+    int s_off[V2J_MAX_JF];                // float offset of small field f's rows inside the small-table block
+    int small_floats;                     // size of the small-table block (multiple of 256 floats = one LDS-DMA piece per wave)
     const float* tab0;                    // folded rows of the big fields {P | row scalar | 0..}
-    const float* jtab;                    // joint rows {sum P | b0 + sum W0 P | sum row scalars | 0..}, [KP + H0 + 16] floats each
+    const float* small;                   // small fields' rows {P | W0^T P (+ b0 in field 0) | row scalar | 0 0 0}, V2J_SS floats each
     float h0w, fo_bias, head_bias;
     int flags;                            // 1 = ids/dense not 16-byte aligned: stage element-wise
     // HALF: tab0 rows hold split halfs of P * p_scale; the deep0 weights of the big fields are split after
@@ -100,52 +106,36 @@ __global__ __launch_bounds__(256) void k_v2_split_rows(const float* __restrict__
     }
 }
 
-// One-time (finalize) kernel: joint rows from the per-field folded rows (k_v2_fold output).
-// One wave per joint row; lane n < KP sums P, lane KP <= n < KP + H0 does deep0's share of output n - KP.
-__global__ __launch_bounds__(256) void k_v2_fold_joint(const float* __restrict__ folded, int KP, int H0, int njf,
-                                                       const unsigned* __restrict__ rowbase,   // [njf] first folded row of each joint field
-                                                       const int* __restrict__ vocab1,         // [njf] rows per field (vocab + 1)
-                                                       const int* __restrict__ grp,            // [njf] group index (W0 K-chunk)
-                                                       const float* __restrict__ W0, int ldw0, // deep0 W^T [H0][ldw0]
-                                                       const float* __restrict__ b0, float* __restrict__ out,
-                                                       long long rows) {
-    const int FS = KP + 16, OS = KP + H0 + 16;
-    for (long long v = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); v < rows; v += (long long)gridDim.x * 4) {
-        const int n = threadIdx.x & 63;
-        // tuple of ids, last field fastest
-        long long rem = v;
-        const float* prow[V2J_MAX_JF];
-        for (int f = njf - 1; f >= 0; --f) {
-            const int id = (int)(rem % vocab1[f]);
-            rem /= vocab1[f];
-            prow[f] = folded + ((size_t)rowbase[f] + id) * FS;
+// One-time (finalize) kernel: LDS rows of ONE small field from its folded rows (k_v2_fold output):
+// out[v] = { P[v] (KP) | (add_b0 ? b0 : 0) + W0_g^T P[v] (H0) | row scalar | 0.. }, one wave per row.
+__global__ __launch_bounds__(256) void k_v2_fold_small(const float* __restrict__ folded, int KP, int H0, int grp,
+                                                       const float* __restrict__ W0, int ldw0,   // deep0 W^T [H0][ldw0]
+                                                       const float* __restrict__ b0, int add_b0,
+                                                       float* __restrict__ out, int rows) {
+    const int FS = KP + 16;
+    for (int v = blockIdx.x * 4 + (threadIdx.x >> 6); v < rows; v += gridDim.x * 4) {
+        const int col = threadIdx.x & 63;
+        const float* prow = folded + (size_t)v * FS;
+        float acc = 0.f;
+        if (col < KP) {
+            acc = prow[col];
+        } else if (col < KP + H0) {
+            const int m = col - KP;
+            acc = add_b0 ? b0[m] : 0.f;
+            const float* w = W0 + (size_t)m * ldw0 + grp * KP;
+            for (int k = 0; k < KP; ++k) acc = fmaf(w[k], prow[k], acc);
+        } else if (col == KP + H0) {
+            acc = prow[KP];
         }
-        float* o = out + v * OS;
-        for (int col = n; col < OS; col += 64) {
-            float acc = 0.f;
-            if (col < KP) {
-                for (int f = 0; f < njf; ++f) acc += prow[f][col];
-            } else if (col < KP + H0) {
-                const int m = col - KP;
-                acc = b0[m];
-                for (int f = 0; f < njf; ++f) {
-                    const float* w = W0 + (size_t)m * ldw0 + grp[f] * KP;
-                    for (int k = 0; k < KP; ++k) acc = fmaf(w[k], prow[f][k], acc);
-                }
-            } else if (col == KP + H0) {
-                for (int f = 0; f < njf; ++f) acc += prow[f][KP];
-            }
-            o[col] = acc;
-        }
+        if (col < V2J_SS) out[(size_t)v * V2J_SS + col] = acc;
     }
 }
 
 // everything one 16-sample task needs from memory, in the (r,q) lane layout
-template <int G_BIG, int H0C>
+template <int G_BIG, int NJF>
 struct V2JSet {
     f32x4 x[G_BIG];       // big fields' row pieces: 4 floats of P, or [hi4 | lo4] halfs (HALF)
-    f32x4 xs;             // joint row: sum of the small fields' P, this lane's piece
-    f32x4 xq[H0C];        // joint row: b0 + sum W0 P of the small fields, C/D layout
+    int so[NJF];          // small fields: LDS float offset of this sample's row
     f32x4 xn;             // numerics
     float w1a;            // per-id logit terms fetched by this lane
 };
@@ -165,10 +155,10 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_deepfm_v2_joint(const V2JRun 
                                                                    const float* __restrict__ image) {
     constexpr int G_EMB = G_BIG + NJF;
     using LD = V2Lds<G_EMB, 4, KPC, H0C, H1C, true>;          // the weight image is the FOLD image of the whole model
-    using Set = V2JSet<G_BIG, H0C>;
+    using Set = V2JSet<G_BIG, NJF>;
     constexpr int KP = LD::KP, H0 = H0C * 16;
     constexpr unsigned RB = (KP + 16) * 4;                    // bytes per folded row
-    constexpr unsigned JB = (KP + H0 + 16) * 4;               // bytes per joint row
+    static_assert(KP + H0 + 1 <= V2J_SS, "small-field row layout");
     constexpr int NKR = HALF ? 1 : (G_BIG + 1) * KPC;         // deep0 K chunks on f32 MFMA: numerics (+ the big fields unless HALF)
     static_assert(KPC == 1, "row layout: one 16-float chunk of projections per field");
     static_assert(G_BIG >= 1 && G_BIG <= 3 && NJF >= 1 && NJF <= V2J_MAX_JF, "field split");
@@ -181,6 +171,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_deepfm_v2_joint(const V2JRun 
     const int task_stride = gridDim.x * WAVES;
     const int wave_global = blockIdx.x * WAVES + wave;
     float* stage = smem + LD::total_pad + wave * LD::stage_floats;
+    const float* small_s = smem + LD::total_pad + WAVES * LD::stage_floats;   // small fields' rows
     const float* wq = smem + 4 * q;
     bool bad = false;
     const bool aligned = !(A.flags & 1);
@@ -217,12 +208,11 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_deepfm_v2_joint(const V2JRun 
             bad |= (unsigned)(id + 1) > (unsigned)A.big_vocab[b];             // neither a table row nor the "missing" marker -1
             sid[b] = min((unsigned)id, (unsigned)A.big_vocab[b]) + A.big_rowbase[b];   // -1 / out of range -> the zero row at index vocab
         }
-        unsigned jidx = 0;                                        // tuple index, last field fastest
 #pragma unroll
         for (int f = 0; f < NJF; ++f) {
             const int id = sid_row[A.j_col[f]];
             bad |= (unsigned)(id + 1) > (unsigned)A.j_vocab[f];
-            jidx = jidx * (unsigned)(A.j_vocab[f] + 1) + min((unsigned)id, (unsigned)A.j_vocab[f]);
+            S.so[f] = A.s_off[f] + (int)min((unsigned)id, (unsigned)A.j_vocab[f]) * V2J_SS;    // -1 -> the "missing" row at index vocab
         }
         {
             const float* nrow = stage + 128 + r * A.ND;
@@ -234,14 +224,9 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_deepfm_v2_joint(const V2JRun 
             S.xn.w = nrow[min(c0 + 3, last)];
         }
         const char* tb = reinterpret_cast<const char*>(A.tab0);
-        const char* jb = reinterpret_cast<const char*>(A.jtab);
 #pragma unroll
         for (int b = 0; b < G_BIG; ++b) S.x[b] = *reinterpret_cast<const f32x4*>(tb + (sid[b] * RB + 16u * q));
-        const unsigned jo = jidx * JB;
-        S.xs = *reinterpret_cast<const f32x4*>(jb + (jo + 16u * q));
-#pragma unroll
-        for (int n0 = 0; n0 < H0C; ++n0) S.xq[n0] = *reinterpret_cast<const f32x4*>(jb + (jo + 4u * KP + 64u * n0 + 16u * q));
-        // per-id logit terms: lane (r,q) fetches big field q's row scalar, the lanes past the big fields the joint one
+        // per-id logit terms of the big fields: lane (r,q) fetches big field q's row scalar
         {
             // (the offsets pass through an empty asm: left visible, the select chain over q is turned into a
             // dynamically indexed private array -- scratch memory traffic in the gather)
@@ -250,11 +235,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_deepfm_v2_joint(const V2JRun 
             unsigned so = s0;
             if (G_BIG > 1) so = q == 1 ? s1 : so;
             if (G_BIG > 2) so = q == 2 ? s2 : so;
-            so += 4u * KP;
-            const bool isj = q == G_BIG;                          // G_BIG <= 3, so one q row is left for the joint scalar
-            const char* base = isj ? jb : tb;
-            so = isj ? jo + 4u * (KP + H0) : so;
-            S.w1a = *reinterpret_cast<const float*>(base + so);
+            S.w1a = *reinterpret_cast<const float*>(tb + (so + 4u * KP));
         }
     };
 
@@ -316,12 +297,25 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_deepfm_v2_joint(const V2JRun 
             pn = e + o;
         }
         // this lane's share of the per-id logit terms + numeric first-order partial (rfn = h0w * fo_num weights)
-        float zz = ((q <= G_BIG) ? S.w1a : 0.f) + ((q < 2) ? dot4(rfn, pnum) : 0.f);
-        // deep0 (DeepFM_v2.py:124-125): accumulators start at the joint row's b0 + sum W0 P of the small fields
+        float zz = ((q < G_BIG) ? S.w1a : 0.f) + ((q < 2) ? dot4(rfn, pnum) : 0.f);
+        // small fields, from their LDS rows: P -> FM sum, W0^T P (+ b0) -> deep0's accumulators, row scalars (one q row adds them)
+        f32x4 sp = ld4(small_s + S.so[0] + 4 * q), sq[H0C];
+#pragma unroll
+        for (int n0 = 0; n0 < H0C; ++n0) sq[n0] = ld4(small_s + S.so[0] + KP + 16 * n0 + 4 * q);
+        float ssc = small_s[S.so[0] + KP + H0];
+#pragma unroll
+        for (int f = 1; f < NJF; ++f) {
+            sp += ld4(small_s + S.so[f] + 4 * q);
+#pragma unroll
+            for (int n0 = 0; n0 < H0C; ++n0) sq[n0] += ld4(small_s + S.so[f] + KP + 16 * n0 + 4 * q);
+            ssc += small_s[S.so[f] + KP + H0];
+        }
+        zz += (q == 3) ? ssc : 0.f;
+        // deep0 (DeepFM_v2.py:124-125): accumulators start at b0 + sum W0 P of the small fields
         f32x4 hA[H0C], hB[H0C];
 #pragma unroll
-        for (int n0 = 0; n0 < H0C; ++n0) { hA[n0] = S.xq[n0]; hB[n0] = zero; }
-        f32x4 s = S.xs + pn;                                      // FM sum: small fields (joint row) + numerics ...
+        for (int n0 = 0; n0 < H0C; ++n0) { hA[n0] = sq[n0]; hB[n0] = zero; }
+        f32x4 s = sp + pn;                                        // FM sum: small fields + numerics ...
         if constexpr (HALF) {
             // big fields on the f16 matrix pipe: per field [Whi|Whi].x and [Wlo|Wlo].x for both n-blocks and the
             // selection matrix for the FM sum
@@ -418,15 +412,20 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_deepfm_v2_joint(const V2JRun 
         __builtin_amdgcn_global_load_lds(
             (const __attribute__((address_space(1))) void*)(image + c * 256 + lane * 4),
             (__attribute__((address_space(3))) void*)(smem + c * 256), 16, 0, 0);
+#pragma unroll 1
+    for (int c = wave; c < A.small_floats / 256; c += WAVES)          // ... and the small fields' rows
+        __builtin_amdgcn_global_load_lds(
+            (const __attribute__((address_space(1))) void*)(A.small + c * 256 + lane * 4),
+            (__attribute__((address_space(3))) void*)(smem + LD::total_pad + WAVES * LD::stage_floats + c * 256), 16, 0, 0);
     // At most two tasks per wave (B <= 65 536 on a full chip): no loop, hence no loop-carried loads -- the
     // compiler counts every outstanding load exactly and score(A) waits for A's rows only, running while
     // B's rows are still streaming in.  (At a loop header hipcc falls back to waiting for ALL outstanding
     // loads before the first use of a loop-carried one.)  Gather A is issued BEFORE the image barrier: it
     // needs the ids only, and vmcnt retires in order, so "at most NG loads outstanding" means this wave's
-    // DMA pieces (older) have landed while its NG row loads (younger) may still fly.  (Gather B follows the
-    // weight fragments: both sets live across load_weights() would spill.)
+    // DMA pieces (older) have landed while its NG row loads (younger) may still fly; gather B follows the
+    // barrier (issuing it before as well measured the same, 9.2 us, at 12 more live registers).
     const bool two = tA < ntasks && ntasks <= 2 * task_stride;        // workgroup-uniform except for idle waves
-    constexpr int NG = G_BIG + 1 + H0C + 1;                           // VMEM loads per gather
+    constexpr int NG = G_BIG + 1;                                     // VMEM loads per gather: rows + row scalar
     static_assert(NG < 16, "s_waitcnt immediate below encodes vmcnt < 16");
     if (two) {
         gather(tA, rawA, SA);

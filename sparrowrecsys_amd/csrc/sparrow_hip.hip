@@ -555,7 +555,8 @@ struct sprk_engine {
     // ... with the small-vocabulary fields folded into one joint table (k_deepfm_v2_joint); -1 = not used
     int v2j_variant = -1;
     V2JRun v2j_run;
-    float* v2j_tab = nullptr;      // joint rows (device)
+    float* v2j_tab = nullptr;      // small fields' LDS rows (device image)
+    size_t v2j_lds_bytes = 0;
     float* v2j_big = nullptr;      // HALF: split-half rows of the big fields (device)
 };
 
@@ -870,10 +871,9 @@ int setup_v2_joint(sprk_engine* h) {
     if (!vv.fold || !vv.reg || vv.kpc != 1 || vv.h0c != 2 || vv.h1c != 1 || (jm && jm[0] == '0')) return SPRK_OK;
     const int KP = 16, H0 = 32, G = vv.g_emb;
     int big[V2_MAX_FIELDS], nbig = 0, jf[V2_MAX_FIELDS], njf = 0;
-    long long jrows = 1;
     for (int g = 0; g < G; ++g) {
         const long long v1 = (long long)h->v2run.vocab[g] + 1;
-        if (v1 <= 32 && njf < V2J_MAX_JF && jrows * v1 <= 32768) { jf[njf++] = g; jrows *= v1; }
+        if (v1 <= 32 && njf < V2J_MAX_JF) jf[njf++] = g;      // small enough to live in LDS
         else big[nbig++] = g;
     }
     if (njf < 1 || nbig < 1 || nbig > 3) return SPRK_OK;
@@ -920,29 +920,26 @@ int setup_v2_joint(sprk_engine* h) {
         r.big_col[b] = h->v2run.col[big[b]]; r.big_vocab[b] = h->v2run.vocab[big[b]];
         r.big_rowbase[b] = h->v2run.rowbase[big[b]]; r.big_grp[b] = big[b];
     }
-    unsigned rb[V2J_MAX_JF]; int v1[V2J_MAX_JF], grp[V2J_MAX_JF];
+    size_t small_floats = 0;
     for (int f = 0; f < njf; ++f) {
         r.j_col[f] = h->v2run.col[jf[f]]; r.j_vocab[f] = h->v2run.vocab[jf[f]];
-        rb[f] = h->v2run.rowbase[jf[f]]; v1[f] = h->v2run.vocab[jf[f]] + 1; grp[f] = jf[f];
+        r.s_off[f] = (int)small_floats;
+        small_floats += ((size_t)r.j_vocab[f] + 1) * V2J_SS;
     }
-    const size_t OS = KP + H0 + 16;
-    HIP_TRY(hipMalloc((void**)&h->v2j_tab, (size_t)jrows * OS * sizeof(float)));
-    unsigned* d_rb = nullptr; int* d_v1 = nullptr; int* d_grp = nullptr;
-    HIP_TRY(hipMalloc((void**)&d_rb, sizeof(rb)));
-    HIP_TRY(hipMalloc((void**)&d_v1, sizeof(v1)));
-    HIP_TRY(hipMalloc((void**)&d_grp, sizeof(grp)));
-    HIP_TRY(hipMemcpy(d_rb, rb, sizeof(rb), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(d_v1, v1, sizeof(v1), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(d_grp, grp, sizeof(grp), hipMemcpyHostToDevice));
-    long long blocks = (jrows + 3) / 4;
-    if (blocks > 65536) blocks = 65536;
-    hipLaunchKernelGGL(k_v2_fold_joint, dim3((unsigned)blocks), dim3(256), 0, 0, h->v2_folded, KP, H0, njf, d_rb, d_v1, d_grp,
-                       h->v2.W0, (G + 1) * KP, h->v2.b0, h->v2j_tab, jrows);
+    small_floats = (small_floats + 255) & ~(size_t)255;          // whole 1-KB LDS-DMA pieces
+    HIP_TRY(hipMalloc((void**)&h->v2j_tab, small_floats * sizeof(float)));
+    HIP_TRY(hipMemset(h->v2j_tab, 0, small_floats * sizeof(float)));
+    for (int f = 0; f < njf; ++f) {
+        const int rows = r.j_vocab[f] + 1;
+        hipLaunchKernelGGL(k_v2_fold_small, dim3((rows + 3) / 4), dim3(256), 0, 0,
+                           h->v2_folded + (size_t)h->v2run.rowbase[jf[f]] * (KP + 16), KP, H0, jf[f], h->v2.W0, (G + 1) * KP,
+                           h->v2.b0, f == 0 ? 1 : 0, h->v2j_tab + r.s_off[f], rows);
+    }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
-    (void)hipFree(d_rb); (void)hipFree(d_v1); (void)hipFree(d_grp);
+    r.small_floats = (int)small_floats;
     r.tab0 = h->v2_folded;
-    r.jtab = h->v2j_tab;
+    r.small = h->v2j_tab;
     r.w_scale = w_scale; r.unscale_h = 1.f / (p_scale * w_scale); r.unscale_s = 1.f / p_scale;
     if (half) {
         size_t big_rows = 0;
@@ -963,7 +960,8 @@ int setup_v2_joint(sprk_engine* h) {
         HIP_TRY(hipDeviceSynchronize());
         r.tab0 = h->v2j_big;
     }
-    HIP_TRY(hipFuncSetAttribute(kV2JVariants[variant].fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)vv.lds_bytes));
+    h->v2j_lds_bytes = vv.lds_bytes + small_floats * sizeof(float);
+    HIP_TRY(hipFuncSetAttribute(kV2JVariants[variant].fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->v2j_lds_bytes));
     h->v2j_variant = variant;
     return SPRK_OK;
 }
@@ -1292,7 +1290,7 @@ int sprk_forward(sprk_handle h, const int32_t* ids, const float* dense, float* o
         if (h->v2j_variant >= 0 && !run.trace && !(run.flags & ~1)) {
             V2JRun jr = h->v2j_run;
             jr.flags = run.flags;
-            kV2JVariants[h->v2j_variant].launch(jr, ids, dense, out, B, h->dev_err, h->v2_image, grid, h->v2_lds_bytes, st);
+            kV2JVariants[h->v2j_variant].launch(jr, ids, dense, out, B, h->dev_err, h->v2_image, grid, h->v2j_lds_bytes, st);
             HIP_TRY(hipGetLastError());
             return SPRK_OK;
         }
