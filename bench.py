@@ -4,8 +4,9 @@
     python bench.py --gpus N --steps K --warmup W [--workload NAME]
 
 One "step" = one pass of the hot path over one batch (ids + dense already resident in HBM ->
-scores in HBM); at N>1 every rank scores its own B-row shard (weak scaling: global batch N*B) and
-the step ends with the RCCL all-gather of the score vector.  Rank 0 prints ONE JSON line.
+scores in HBM); at N>1 every rank scores its own B-row shard (weak scaling: global batch N*B) and its
+score slices are all-gathered over RCCL, --gather-group steps per collective on a second stream (every
+step's scores have been exchanged on every rank when the timed region ends).  Rank 0 prints ONE JSON line.
 
 Workloads (BASELINE.json configs):
   deepfm_v2_c2 (default) configs[1]: DeepFM (sum-of-squares FM cross, DeepFM_v2 graph), 6 sparse
@@ -115,6 +116,10 @@ def main():
     ap.add_argument("--dist", default="uniform", choices=["uniform", "zipf", "hot"], help="id distribution")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget (0 = skip)")
     ap.add_argument("--no-check", action="store_true", help="skip the oracle spot check of the outputs")
+    ap.add_argument("--gather-group", type=int, default=16,
+                    help="N>1: batches whose score slices share one RCCL all-gather (overlapped with the next group)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend (gloo: functional test of the N>1 path with ranks sharing one GPU)")
     args = ap.parse_args()
 
     import torch
@@ -130,10 +135,14 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
-    torch.cuda.set_device(local_rank)
+    local_dev = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(local_dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_dev))
+        else:
+            dist.init_process_group("gloo")
 
     B = args.batch or (32768 if args.workload == "din_c3" else 65536)
     model, feats, desc, roof = build_workload(args.workload, B, args.dist, seed_offset=rank)
@@ -145,27 +154,34 @@ def main():
     NB = len(batches)
     outs = [torch.empty(B, dtype=torch.float32, device="cuda") for _ in range(NB)]
     ws = torch.empty(max(eng.workspace_bytes(B) // 4, 1), dtype=torch.float32, device="cuda")
-    gathered = torch.empty(B * world, dtype=torch.float32, device="cuda") if world > 1 else None
-
-    def step(i):
-        ids_t, dense_t = batches[i % NB]
-        out = outs[i % NB]
-        eng.forward(ids_t, dense_t, out, ws)
-        if world > 1:
-            dist.all_gather_into_tensor(gathered, out)
+    gs = None
+    if world > 1:
+        from sparrowrecsys_amd.dist import GroupedScoreGather
+        gs = GroupedScoreGather(B, max(1, args.gather_group), torch.device("cuda", local_dev))
 
     def run_steps(first, count):
-        """`count` steps starting at step index `first`.  N=1: one sprk_forward_many call enqueues them all
-        (the same `count` kernel launches, without a Python/ctypes round trip per launch, which at ~7 us
-        would out-last the kernel); N>1: per-step Python loop, each step ends with the RCCL all-gather."""
-        if world > 1:
-            for i in range(first, first + count):
-                step(i)
+        """`count` steps starting at step index `first`.  One sprk_forward_many call enqueues a run of
+        forwards (the same kernel launches, without a Python/ctypes round trip per launch, which at ~7 us
+        would out-last the kernel).  N>1: every step's score slice lands in a GroupedScoreGather ring slot;
+        each full group of --gather-group steps is exchanged by ONE RCCL all-gather on a second stream
+        while the next group is scored (a per-step all-gather of 256 KiB costs more launch latency than
+        the forward it follows)."""
+        if world == 1:
+            idx = [i % NB for i in range(first, first + count)]
+            eng.forward_many([batches[j][0] for j in idx], [batches[j][1] for j in idx], [outs[j] for j in idx], ws)
             return
-        idx = [i % NB for i in range(first, first + count)]
-        eng.forward_many([batches[j][0] for j in idx], [batches[j][1] for j in idx], [outs[j] for j in idx], ws)
+        i = first
+        while i < first + count:
+            n = min(gs.G - gs.fill, first + count - i)
+            idx = [j % NB for j in range(i, i + n)]
+            eng.forward_many([batches[j][0] for j in idx], [batches[j][1] for j in idx], [gs.out() for _ in idx], ws)
+            i += n
+            if gs.full():
+                gs.commit()
 
     def fence():
+        if gs is not None:
+            gs.flush()                     # exchange a partial group, wait for every collective
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -207,6 +223,9 @@ def main():
     # output spot check against the oracle (outside the timed region)
     check = None
     if rank == 0 and not args.no_check:
+        if world > 1:
+            eng.forward(batches[0][0], batches[0][1], outs[0], ws)
+            torch.cuda.synchronize()
         n = 4096
         got = outs[0][:n].cpu().numpy()
         ref = oracle_forward(args.workload, model, {k: v[:n] for k, v in feats[0].items()})[:, 0]
@@ -262,7 +281,9 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s: %s" % (args.workload, desc), "batch_per_gpu": B, "global_batch": B * world,
                        "id_distribution": args.dist, "input_batches_cycled": NB,
-                       "parallelism": "rows sharded over %d GPU(s), tables replicated, all-gather of scores" % world,
+                       "parallelism": ("rows sharded over %d GPU(s), tables replicated, all-gather of scores" % world)
+                                      + ("" if world == 1 else " (one collective per %d steps, overlapped; %d collectives in the timed region)"
+                                         % (gs.G, (args.steps + gs.G - 1) // gs.G)),
                        "oracle_check_max_abs_err": check},
             "roofline": rl,
         }

@@ -2,6 +2,15 @@
 replicated, ONE collective on the data path -- an all-gather of the per-rank score slice
 (the reference has no distributed path at all).  ``torch.distributed`` with
 backend "nccl" is RCCL over xGMI on ROCm; the same code runs on "gloo" for the CPU tests.
+
+Two shapes of the same exchange:
+  * ``RowShardedPredictor``  one global batch -> shard -> forward -> all-gather (latency path, what a
+    single ``/getrecforyou`` request needs);
+  * ``GroupedScoreGather``   the ``model.predict(dataset)`` loop: a forward of one 65 536-row shard takes
+    ~9 us, an RCCL all-gather of its 256 KiB score slice costs more than that in launch latency alone, so
+    scores of ``group`` consecutive batches are written into one ring slot and exchanged by ONE larger
+    collective on a second stream while the next group is being scored (xGMI is point-to-point: fewer,
+    larger messages per link).
 """
 from __future__ import annotations
 
@@ -60,3 +69,92 @@ def all_gather_scores(local, gathered=None, group=None):
         gathered = torch.empty(local.numel() * world, dtype=local.dtype, device=local.device)
     dist.all_gather_into_tensor(gathered, local, group=group)
     return gathered
+
+
+class GroupedScoreGather:
+    """Double-buffered ring of score slots for a predict-over-batches loop.
+
+    ``out(i)`` is the [B] tensor the forward of this rank's i-th batch must write.  After every
+    ``group`` batches call ``commit()``: the [group*B] slot is all-gathered into ``gathered[slot]``
+    ([world, group*B]) on a side stream (CUDA) while the compute stream goes on with the other slot;
+    ``flush()`` exchanges a partial last group and waits for everything.  Completed groups are
+    handed to ``sink(group_index, gathered_view, n_batches)`` if given (views are only valid until the
+    slot is reused two groups later)."""
+
+    def __init__(self, batch_rows: int, group: int, device, dtype=None, pg=None, sink: Optional[Callable] = None):
+        import torch
+        import torch.distributed as dist
+        if group < 1:
+            raise ValueError("group must be >= 1")
+        self.B, self.G, self.pg, self.sink = int(batch_rows), int(group), pg, sink
+        self.world = dist.get_world_size(pg) if dist.is_initialized() else 1
+        dtype = dtype or torch.float32
+        self.local = torch.zeros((2, self.G, self.B), dtype=dtype, device=device)
+        self.gathered = torch.zeros((2, self.world, self.G * self.B), dtype=dtype, device=device)
+        self.cuda = torch.device(device).type == "cuda"
+        self.comm_stream = torch.cuda.Stream(device=device) if (self.cuda and self.world > 1) else None
+        self.done = [None, None]              # CUDA event per slot: its collective has finished
+        self.slot, self.fill, self.groups_done, self.collectives = 0, 0, 0, 0
+        self._pending = [None, None]          # (group_index, n_batches) waiting for the sink
+
+    def out(self):
+        """Tensor for the NEXT batch's scores (call once per batch, before its forward is enqueued)."""
+        import torch
+        if self.fill == 0 and self.done[self.slot] is not None:
+            # this slot's previous collective must have read it before it is overwritten
+            torch.cuda.current_stream().wait_event(self.done[self.slot])
+            self._drain(self.slot)
+        t = self.local[self.slot, self.fill]
+        self.fill += 1
+        return t
+
+    def full(self) -> bool:
+        return self.fill == self.G
+
+    def _drain(self, slot):
+        if self._pending[slot] is not None and self.sink is not None:
+            gi, nb = self._pending[slot]
+            if self.cuda and self.done[slot] is not None:
+                self.done[slot].synchronize()
+            self.sink(gi, self.gathered[slot].view(self.world, self.G, self.B)[:, :nb], nb)
+        self._pending[slot] = None
+
+    def commit(self):
+        """Exchange the current slot (``fill`` batches of it) and switch to the other one."""
+        import torch
+        import torch.distributed as dist
+        if self.fill == 0:
+            return
+        slot, nb = self.slot, self.fill
+        src = self.local[slot].view(-1)
+        dst = self.gathered[slot].view(-1)
+        if self.world == 1:
+            dst.copy_(src)
+        elif self.comm_stream is not None:
+            ready = torch.cuda.Event()
+            ready.record(torch.cuda.current_stream())
+            self.comm_stream.wait_event(ready)
+            with torch.cuda.stream(self.comm_stream):
+                dist.all_gather_into_tensor(dst, src, group=self.pg)
+                ev = torch.cuda.Event()
+                ev.record(self.comm_stream)
+            self.done[slot] = ev
+        else:
+            dist.all_gather_into_tensor(dst, src, group=self.pg)
+        self.collectives += 1
+        self._pending[slot] = (self.groups_done, nb)
+        self.groups_done += 1
+        self.slot, self.fill = 1 - slot, 0
+        if not self.cuda:
+            self._drain(slot)
+
+    def flush(self):
+        """Exchange a partial group, wait for every outstanding collective, deliver to the sink."""
+        import torch
+        self.commit()
+        for slot in (self.slot, 1 - self.slot):       # older slot first
+            if self.cuda and self.done[slot] is not None:
+                torch.cuda.current_stream().wait_event(self.done[slot])
+            self._drain(slot)
+        if self.cuda:
+            torch.cuda.current_stream().synchronize()

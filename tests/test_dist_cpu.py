@@ -86,3 +86,49 @@ def test_two_rank_row_sharding_matches_single_process(n_rows):
         lo, hi = shard_bounds(n_rows, rank, world)
         assert calls == [hi - lo]                                    # ... having scored only its own shard
         np.testing.assert_array_equal(eq, [0, 0, 0, 0, 1, 1, 1, 1])
+
+
+def _group_worker(rank, world, port, q):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from sparrowrecsys_amd.dist import GroupedScoreGather
+        B, G, steps = 8, 3, 8                        # 8 batches in groups of 3: 3 + 3 + partial 2
+        got = []
+        gs = GroupedScoreGather(B, G, "cpu", sink=lambda gi, view, nb: got.append((gi, nb, view.clone())))
+        for i in range(steps):
+            out = gs.out()
+            out.copy_(torch.arange(B, dtype=torch.float32) + 1000 * rank + 100 * i)     # "forward" of batch i
+            if gs.full():
+                gs.commit()
+        gs.flush()
+        q.put((rank, gs.collectives, [(gi, nb, v.numpy()) for gi, nb, v in got]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_grouped_score_gather_two_ranks():
+    """GroupedScoreGather: G batches per collective, partial last group, every rank sees every rank's
+    scores of every batch in (group, rank, batch) order."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_group_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, collectives, got in results:
+        assert collectives == 3
+        assert [(gi, nb) for gi, nb, _ in got] == [(0, 3), (1, 3), (2, 2)]
+        for gi, nb, v in got:
+            assert v.shape == (world, nb, 8)
+            for r in range(world):
+                for j in range(nb):
+                    np.testing.assert_array_equal(v[r, j], np.arange(8, dtype=np.float32) + 1000 * r + 100 * (3 * gi + j))
