@@ -14,6 +14,14 @@
 // and the [B,T,4D] activation-unit input never exists.  (fp32 throughout; only the association of the
 // sums differs from the reference's einsum, i.e. rounding-level differences.)
 //
+// HALF: the K = D contraction runs on the f16 matrix pipe with split operands (see k_chain_v2j.h): both
+// A_b and the history rows are bounded by quantities known at sprk_finalize (max|E|, max|W12|, max|W4|),
+// so each is scaled by a power of two into f16 range and stored as hi + lo halfs (22 significand bits);
+// Ahi.Bhi + Ahi.Blo + Alo.Bhi accumulate in f32 (every partial product is exact there).  Per 16 rows that
+// is 6 v_mfma_f32_16x16x32_f16 (16 cycles each, VALU keeps issuing) + 16 conversion VALU instead of
+// 16 v_mfma_f32_16x16x4_f32 (32 cycles each on the SIMD's vector ALU).  PReLU is positively homogeneous,
+// so the power-of-two unscale is applied once, to the attention logit.
+//
 // Mapping: a wave owns one sample at a time.  Its T history rows are gathered ONCE from the table
 // (16-B pieces, whole 128-B rows per 8 lanes) into a wave-private LDS tile; the attention logits run on
 // v_mfma_f32_16x16x4_f32 with A = A_b (built in registers from the resident W12 / W4 fragments and the
@@ -34,11 +42,13 @@ struct DinRun {
     const float* vc;      // [vocab][HC*16]  (W3-W1)^T E[id] + bias
     const float* alpha;   // [T][HC*16]
     const float* w2;      // [HC*16]
+    // HALF: w12 / w4 are pre-multiplied by a_scale; history rows are multiplied by h_scale when they are split
+    float h_scale, acc_scale, unscale;    // 2^sH, 2^(sA+sH), 2^-(sA+sH)
 };
 
 // One-time (finalize) kernels.
 __global__ __launch_bounds__(256) void k_din_prep_w(const float* __restrict__ W, int hidden, int Dp, int KP,
-                                                    float* __restrict__ w12, float* __restrict__ w4) {
+                                                    float scale, float* __restrict__ w12, float* __restrict__ w4) {
     // W: [hidden][4*Dp] in [h-c | h | c | h*c] blocks (sprk_din.w_slot)
     const int total = hidden * KP;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
@@ -49,8 +59,8 @@ __global__ __launch_bounds__(256) void k_din_prep_w(const float* __restrict__ W,
             a = w[k] + w[Dp + k];
             b = w[3 * Dp + k];
         }
-        w12[i] = a;
-        w4[i] = b;
+        w12[i] = a * scale;
+        w4[i] = b * scale;
     }
 }
 __global__ __launch_bounds__(256) void k_din_prep_vc(const float* __restrict__ W, const float* __restrict__ bias,
@@ -93,6 +103,12 @@ __device__ __forceinline__ float rows4_sum(float v) {
     return a + b;
 }
 
+// f16 MFMA over a lane's EL = 4 or 8 operand halfs (K = 16 or 32)
+typedef _Float16 din_f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 din_f16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ f32x4 mfma_f16(din_f16x4 a, din_f16x4 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x16f16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f32x4 mfma_f16(din_f16x8 a, din_f16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+
 template <int KC, int HC>
 struct DinLds {
     static constexpr int KP = KC * 16, HP = HC * 16;
@@ -104,7 +120,7 @@ struct DinLds {
     static constexpr size_t bytes = sizeof(float) * (alpha_floats + 4 * wave_floats);
 };
 
-template <int KC, int HC, int NP>
+template <int KC, int HC, int NP, bool HALF>
 __global__ __launch_bounds__(256, 2) void k_din_attn(const DinRun A, const int* __restrict__ ids,
                                                      float* __restrict__ pooled, float* __restrict__ att, int B,
                                                      int* __restrict__ err) {
@@ -123,6 +139,11 @@ __global__ __launch_bounds__(256, 2) void k_din_attn(const DinRun A, const int* 
     const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
     float* alpha_s = smem;
     float* Hs = smem + LD::alpha_floats + wave * LD::wave_floats;
+    // first row element of this lane's c-th 4-float operand piece: the f32 MFMA steps through k = 16c + 4q + s,
+    // the f16 MFMA takes EL = 4*KC consecutive elements k = EL*q .. EL*q + EL-1 per lane
+    constexpr int EL = 4 * KC;
+    auto kof = [&](int c) { return HALF ? EL * q + 4 * c : 16 * c + 4 * q; };
+    typedef _Float16 f16xe __attribute__((ext_vector_type(EL)));
 
     // ---- one-time: zero the wave tile (padding columns / rows stay zero for ever), stage alpha ----
     for (int i = lane; i < LD::wave_floats; i += 64) Hs[i] = 0.f;
@@ -136,8 +157,8 @@ __global__ __launch_bounds__(256, 2) void k_din_attn(const DinRun A, const int* 
     for (int nb = 0; nb < HC; ++nb) {
 #pragma unroll
         for (int c = 0; c < KC; ++c) {
-            w12f[nb][c] = ld4(A.w12 + (size_t)(nb * 16 + r) * KP + 16 * c + 4 * q);
-            w4f[nb][c] = ld4(A.w4 + (size_t)(nb * 16 + r) * KP + 16 * c + 4 * q);
+            w12f[nb][c] = ld4(A.w12 + (size_t)(nb * 16 + r) * KP + kof(c));
+            w4f[nb][c] = ld4(A.w4 + (size_t)(nb * 16 + r) * KP + kof(c));
         }
         w2f[nb] = ld4(A.w2 + nb * 16 + 4 * q);
     }
@@ -176,7 +197,7 @@ __global__ __launch_bounds__(256, 2) void k_din_attn(const DinRun A, const int* 
         const unsigned csafe = (unsigned)cid < (unsigned)A.vocab ? (unsigned)cid : 0u;
         const float* crow = A.table + csafe * (unsigned)Dp;
 #pragma unroll
-        for (int c = 0; c < KC; ++c) cvn[c] = (16 * c + 4 * q < Dp) ? ld4(crow + 16 * c + 4 * q) : zero;
+        for (int c = 0; c < KC; ++c) cvn[c] = (kof(c) < Dp) ? ld4(crow + kof(c)) : zero;
         const float* vrow = A.vc + csafe * (unsigned)HP;
 #pragma unroll
         for (int nb = 0; nb < HC; ++nb) vcn[nb] = ld4(vrow + nb * 16 + 4 * q);
@@ -212,9 +233,25 @@ __global__ __launch_bounds__(256, 2) void k_din_attn(const DinRun A, const int* 
         for (int nb = 0; nb < HC; ++nb)
 #pragma unroll
             for (int c = 0; c < KC; ++c) Ab[nb][c] = w4f[nb][c] * cv[c] + w12f[nb][c];
+        f16xe Ahi[HC], Alo[HC];                                  // HALF: A_b * a_scale as hi + lo halfs
+        if constexpr (HALF) {
+#pragma unroll
+            for (int nb = 0; nb < HC; ++nb) {
+#pragma unroll
+                for (int c = 0; c < KC; ++c)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float x = Ab[nb][c][j];            // (w12 / w4 were pre-multiplied by a_scale)
+                        const _Float16 hh = (_Float16)x;
+                        Ahi[nb][4 * c + j] = hh;
+                        Alo[nb][4 * c + j] = (_Float16)(x - (float)hh);
+                    }
+                acc_init[nb] = acc_init[nb] * A.acc_scale;       // C operand in the accumulator's scale
+            }
+        }
 
         // ---- attention logits, two 16-row groups (= 2*HC accumulator chains) at a time ----
-        f32x4 pacc[KC];                                          // this lane's share of sum_t w[t] h[t][16c + 4q .. +3]
+        f32x4 pacc[KC];                                          // this lane's share of sum_t w[t] h[t][kof(c) .. +3]
 #pragma unroll
         for (int c = 0; c < KC; ++c) pacc[c] = zero;
         auto score_groups = [&](int g, auto two_tag) {
@@ -222,8 +259,8 @@ __global__ __launch_bounds__(256, 2) void k_din_attn(const DinRun A, const int* 
             f32x4 b0[KC], b1[KC], a0[HC], a1[HC];
 #pragma unroll
             for (int c = 0; c < KC; ++c) {
-                b0[c] = ld4(Hs + (16 * g + r) * hs + 16 * c + 4 * q);
-                b1[c] = TWO ? ld4(Hs + (16 * g + 16 + r) * hs + 16 * c + 4 * q) : zero;
+                b0[c] = ld4(Hs + (16 * g + r) * hs + kof(c));
+                b1[c] = TWO ? ld4(Hs + (16 * g + 16 + r) * hs + kof(c)) : zero;
             }
             f32x4 al0[HC], al1[HC];                              // PReLU alpha[t][n] of the rows being scored
 #pragma unroll
@@ -233,6 +270,32 @@ __global__ __launch_bounds__(256, 2) void k_din_attn(const DinRun A, const int* 
                 a0[nb] = acc_init[nb];
                 a1[nb] = acc_init[nb];
             }
+            if constexpr (HALF) {
+                // history rows * h_scale -> hi + lo halfs (one v_fma_mixlo/mixhi each), then three products per
+                // (group, n-block): 2*HC (4*HC with TWO) accumulator chains issued round robin
+                f16xe bh0, bl0, bh1, bl1;
+#pragma unroll
+                for (int c = 0; c < KC; ++c)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float x0 = b0[c][j] * A.h_scale;
+                        const _Float16 h0 = (_Float16)x0;
+                        bh0[4 * c + j] = h0;
+                        bl0[4 * c + j] = (_Float16)(x0 - (float)h0);
+                        const float x1 = b1[c][j] * A.h_scale;
+                        const _Float16 h1 = (_Float16)x1;
+                        bh1[4 * c + j] = h1;
+                        bl1[4 * c + j] = (_Float16)(x1 - (float)h1);
+                    }
+#pragma unroll
+                for (int pr = 0; pr < 3; ++pr) {
+#pragma unroll
+                    for (int nb = 0; nb < HC; ++nb) {
+                        a0[nb] = mfma_f16(pr == 2 ? Alo[nb] : Ahi[nb], pr == 1 ? bl0 : bh0, a0[nb]);
+                        if (TWO) a1[nb] = mfma_f16(pr == 2 ? Alo[nb] : Ahi[nb], pr == 1 ? bl1 : bh1, a1[nb]);
+                    }
+                }
+            } else {
 #pragma unroll
             for (int c = 0; c < KC; ++c)
 #pragma unroll
@@ -246,6 +309,7 @@ __global__ __launch_bounds__(256, 2) void k_din_attn(const DinRun A, const int* 
                             a1[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(Ab[nb][c][st], b1[c][st], a1[nb], 0, 0, 0);
                     }
                 }
+            }
             // epilogue: PReLU(alpha[t][n]) -> Dense(1) -> sigmoid (DIN.py:150-151); lane (r,q) holds
             // u[n = nb*16 + 4q + j] of row t = 16g + r
 #pragma unroll
@@ -263,7 +327,7 @@ __global__ __launch_bounds__(256, 2) void k_din_attn(const DinRun A, const int* 
                         sum = fmaf(w2f[nb][j], fmaf(al[j], neg, pos), sum);
                     }
                 }
-                const float wgt = sigmoidf_fast(rows4_sum(sum) + A.b2);
+                const float wgt = sigmoidf_fast(rows4_sum(sum) * (HALF ? A.unscale : 1.0f) + A.b2);   // PReLU is positively homogeneous
                 if (q == 0 && att && t < T) att[(size_t)s * T + t] = wgt;
                 // weighted sum pooling (DIN.py:152-158): rows past T are all-zero in the tile, so they add nothing
 #pragma unroll
@@ -284,7 +348,7 @@ __global__ __launch_bounds__(256, 2) void k_din_attn(const DinRun A, const int* 
         if (r == 0) {
 #pragma unroll
             for (int c = 0; c < KC; ++c)
-                if (16 * c + 4 * q < Dp) st4(pooled + (size_t)s * Dp + 16 * c + 4 * q, pacc[c]);
+                if (kof(c) < Dp) st4(pooled + (size_t)s * Dp + kof(c), pacc[c]);
         }
     }
     if (__ballot(bad) != 0 && lane == 0) atomicOr(err, 1);

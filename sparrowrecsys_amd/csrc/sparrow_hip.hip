@@ -968,17 +968,19 @@ int setup_v2_joint(sprk_engine* h) {
 
 // ---- dispatch table for k_din_attn<KC, HC> ----
 typedef void (*DinLaunchFn)(const DinRun&, const int*, float*, float*, int, int*, int, size_t, hipStream_t);
-template <int KC, int HC, int NP>
+template <int KC, int HC, int NP, bool HALF>
 void din_launch(const DinRun& a, const int* ids, float* pooled, float* att, int B, int* err, int grid, size_t lds, hipStream_t st) {
-    hipLaunchKernelGGL((k_din_attn<KC, HC, NP>), dim3(grid), dim3(256), lds, st, a, ids, pooled, att, B, err);
+    hipLaunchKernelGGL((k_din_attn<KC, HC, NP, HALF>), dim3(grid), dim3(256), lds, st, a, ids, pooled, att, B, err);
 }
 struct DinVariant {
     int kc, hc, np;                   // np: gather passes compiled in (each covers 64 / (row_stride/4) history slots)
+    bool half;                        // K = D contraction on split-f16 MFMA
     const void* fn;
     size_t lds_bytes;
     DinLaunchFn launch;
 };
-#define DIN_VARIANT(KC, HC, NP) {KC, HC, NP, reinterpret_cast<const void*>(&k_din_attn<KC, HC, NP>), DinLds<KC, HC>::bytes, &din_launch<KC, HC, NP>}
+#define DIN_VARIANT1(KC, HC, NP, HALF) {KC, HC, NP, HALF, reinterpret_cast<const void*>(&k_din_attn<KC, HC, NP, HALF>), DinLds<KC, HC>::bytes, &din_launch<KC, HC, NP, HALF>}
+#define DIN_VARIANT(KC, HC, NP) DIN_VARIANT1(KC, HC, NP, true), DIN_VARIANT1(KC, HC, NP, false)
 const DinVariant kDinVariants[] = {     // first match wins: smallest sufficient pass count first
     DIN_VARIANT(2, 2, 2), DIN_VARIANT(2, 2, 4),
     DIN_VARIANT(2, 2, 7),               // BASELINE config 3: emb_dim 32, 50 history slots, attention hidden 32
@@ -1145,15 +1147,45 @@ int sprk_finalize(sprk_handle h) {
         const size_t vc_bytes = (size_t)s.vocab * s.hidden * sizeof(float);
         if (!(legacy && legacy[0] == '1') && s.T <= 64 && vc_bytes < ((size_t)4 << 30) &&
             (size_t)s.vocab * s.row_stride * sizeof(float) < ((size_t)4 << 30)) {   // 32-bit element offsets
+            const char* hm = getenv("SPRK_DIN_HALF");            // A/B switch: "0" = f32 MFMA
+            bool want_half = !(hm && hm[0] == '0');
             for (size_t v = 0; v < sizeof(kDinVariants) / sizeof(kDinVariants[0]); ++v) {
                 const DinVariant& dv = kDinVariants[v];
                 if (dv.kc != kc || dv.hc != hc || dv.np * (64 / (s.row_stride / 4)) < s.T) continue;
+                if (dv.half != want_half) continue;
                 const int KP = kc * 16;
-                HIP_TRY(hipMalloc((void**)&h->din_w12, (size_t)s.hidden * KP * sizeof(float)));
-                HIP_TRY(hipMalloc((void**)&h->din_w4, (size_t)s.hidden * KP * sizeof(float)));
-                HIP_TRY(hipMalloc((void**)&h->din_vc, vc_bytes));
-                hipLaunchKernelGGL(k_din_prep_w, dim3(8), dim3(256), 0, 0, d.W, s.hidden, s.row_stride, KP, h->din_w12, h->din_w4);
+                if (!h->din_w12) {
+                    HIP_TRY(hipMalloc((void**)&h->din_w12, (size_t)s.hidden * KP * sizeof(float)));
+                    HIP_TRY(hipMalloc((void**)&h->din_w4, (size_t)s.hidden * KP * sizeof(float)));
+                    HIP_TRY(hipMalloc((void**)&h->din_vc, vc_bytes));
+                }
+                hipLaunchKernelGGL(k_din_prep_w, dim3(8), dim3(256), 0, 0, d.W, s.hidden, s.row_stride, KP, 1.0f, h->din_w12, h->din_w4);
                 HIP_TRY(hipGetLastError());
+                float h_scale = 1.f, a_scale = 1.f;
+                if (dv.half) {
+                    // power-of-two scales from max|E|, max|W12|, max|W4|: |A_b| <= max|W12| + max|W4| max|E|
+                    unsigned* d_max = nullptr;
+                    HIP_TRY(hipMalloc((void**)&d_max, 3 * sizeof(unsigned)));
+                    HIP_TRY(hipMemset(d_max, 0, 3 * sizeof(unsigned)));
+                    long long nb_ = ((long long)s.vocab * s.row_stride + 255) / 256;
+                    if (nb_ > 8192) nb_ = 8192;
+                    hipLaunchKernelGGL(k_v2_absmax, dim3((unsigned)nb_), dim3(256), 0, 0, d.table, (long long)s.vocab, s.row_stride, s.row_stride, d_max);
+                    hipLaunchKernelGGL(k_v2_absmax, dim3(4), dim3(256), 0, 0, h->din_w12, (long long)s.hidden, KP, KP, d_max + 1);
+                    hipLaunchKernelGGL(k_v2_absmax, dim3(4), dim3(256), 0, 0, h->din_w4, (long long)s.hidden, KP, KP, d_max + 2);
+                    HIP_TRY(hipGetLastError());
+                    unsigned bits[3];
+                    HIP_TRY(hipMemcpy(bits, d_max, sizeof(bits), hipMemcpyDeviceToHost));
+                    (void)hipFree(d_max);
+                    float mx[3];
+                    memcpy(mx, bits, sizeof(mx));
+                    if (!(mx[0] < 3.0e38f) || !(mx[1] < 3.0e38f) || !(mx[2] < 3.0e38f)) { want_half = false; v = (size_t)-1; continue; }   // NaN / Inf weights: rescan for the f32 kernel
+                    const float bound_a = mx[1] + mx[2] * mx[0];
+                    int e = 0;
+                    if (mx[0] > 0.f) { (void)frexpf(mx[0], &e); e = 15 - e; if (e > 60) e = 60; if (e < -60) e = -60; h_scale = ldexpf(1.f, e); }
+                    if (bound_a > 0.f) { (void)frexpf(bound_a, &e); e = 15 - e; if (e > 60) e = 60; if (e < -60) e = -60; a_scale = ldexpf(1.f, e); }
+                    hipLaunchKernelGGL(k_din_prep_w, dim3(8), dim3(256), 0, 0, d.W, s.hidden, s.row_stride, KP, a_scale, h->din_w12, h->din_w4);
+                    HIP_TRY(hipGetLastError());
+                }
                 long long blocks = ((long long)s.vocab * s.hidden + 255) / 256;
                 if (blocks > 65536) blocks = 65536;
                 hipLaunchKernelGGL(k_din_prep_vc, dim3((unsigned)blocks), dim3(256), 0, 0, d.W, d.bias, d.table, s.hidden,
@@ -1162,6 +1194,7 @@ int sprk_finalize(sprk_handle h) {
                 HIP_TRY(hipDeviceSynchronize());
                 DinRun& r = h->din_run;
                 r.T = s.T; r.F = p.n_id_cols; r.hist_col = s.hist_col; r.cand_col = s.cand_col; r.Dp = s.row_stride; r.vocab = s.vocab;
+                r.h_scale = h_scale; r.acc_scale = a_scale * h_scale; r.unscale = 1.0f / (a_scale * h_scale);
                 r.b2 = s.b2; r.table = d.table; r.w12 = h->din_w12; r.w4 = h->din_w4; r.vc = h->din_vc; r.alpha = d.alpha; r.w2 = d.w2;
                 HIP_TRY(hipFuncSetAttribute(dv.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dv.lds_bytes));
                 int wgs = (int)(160 * 1024 / dv.lds_bytes);
