@@ -115,7 +115,7 @@ struct DinLds {
     static constexpr int hs = KP + 4;           // history-row stride (floats): 16-B aligned, (hs/4) odd
     static constexpr int as = HP + 4;           // alpha-row stride
     static constexpr int rows = 64;             // T <= 64, padded to whole 16-row groups
-    static constexpr int alpha_floats = rows * as;
+    static constexpr int alpha_floats = 2 * rows * as;      // two coefficient tables (see the epilogue)
     static constexpr int wave_floats = rows * hs;            // Hs tile
     static constexpr size_t bytes = sizeof(float) * (alpha_floats + 4 * wave_floats);
 };
@@ -147,12 +147,20 @@ __global__ __launch_bounds__(256, 2) void k_din_attn(const DinRun A, const int* 
 
     // ---- one-time: zero the wave tile (padding columns / rows stay zero for ever), stage alpha ----
     for (int i = lane; i < LD::wave_floats; i += 64) Hs[i] = 0.f;
-    for (int i = tid; i < LD::alpha_floats; i += 256) {
+    // PReLU(alpha) followed by the Dense(1) weight w2, as two coefficients per (slot t, unit n):
+    //   w2 (max(u,0) + alpha min(u,0)) = ca u + cb |u|,  ca = w2 (1 + alpha) / 2,  cb = w2 (1 - alpha) / 2
+    // (max(u,0) = (u + |u|)/2, min(u,0) = (u - |u|)/2): two FMAs per element, |u| is a free source modifier
+    float* cb_s = alpha_s + LD::rows * as;
+    for (int i = tid; i < LD::rows * as; i += 256) {
         const int t = i / as, n = i - t * as;
-        alpha_s[i] = (t < T && n < HP) ? A.alpha[(size_t)t * HP + n] : 0.f;
+        const bool ok = t < T && n < HP;
+        const float al = ok ? A.alpha[(size_t)t * HP + n] : 0.f;
+        const float w2 = ok ? A.w2[n] : 0.f;
+        alpha_s[i] = 0.5f * w2 * (1.0f + al);
+        cb_s[i] = 0.5f * w2 * (1.0f - al);
     }
     // resident weight fragments: lane (r,q) holds W[n = nb*16 + r][k = 16c + 4q .. +3]
-    f32x4 w12f[HC][KC], w4f[HC][KC], w2f[HC];
+    f32x4 w12f[HC][KC], w4f[HC][KC];
 #pragma unroll
     for (int nb = 0; nb < HC; ++nb) {
 #pragma unroll
@@ -160,7 +168,6 @@ __global__ __launch_bounds__(256, 2) void k_din_attn(const DinRun A, const int* 
             w12f[nb][c] = ld4(A.w12 + (size_t)(nb * 16 + r) * KP + kof(c));
             w4f[nb][c] = ld4(A.w4 + (size_t)(nb * 16 + r) * KP + kof(c));
         }
-        w2f[nb] = ld4(A.w2 + nb * 16 + 4 * q);
     }
     __syncthreads();
     // the one-time loads above have landed before the pipelined loop starts: otherwise the compiler,
@@ -262,11 +269,13 @@ __global__ __launch_bounds__(256, 2) void k_din_attn(const DinRun A, const int* 
                 b0[c] = ld4(Hs + (16 * g + r) * hs + kof(c));
                 b1[c] = TWO ? ld4(Hs + (16 * g + 16 + r) * hs + kof(c)) : zero;
             }
-            f32x4 al0[HC], al1[HC];                              // PReLU alpha[t][n] of the rows being scored
+            f32x4 al0[HC], al1[HC], be0[HC], be1[HC];            // ca[t][n], cb[t][n] of the rows being scored
 #pragma unroll
             for (int nb = 0; nb < HC; ++nb) {
                 al0[nb] = ld4(alpha_s + (16 * g + r) * as + nb * 16 + 4 * q);
                 al1[nb] = TWO ? ld4(alpha_s + (16 * g + 16 + r) * as + nb * 16 + 4 * q) : zero;
+                be0[nb] = ld4(cb_s + (16 * g + r) * as + nb * 16 + 4 * q);
+                be1[nb] = TWO ? ld4(cb_s + (16 * g + 16 + r) * as + nb * 16 + 4 * q) : zero;
                 a0[nb] = acc_init[nb];
                 a1[nb] = acc_init[nb];
             }
@@ -310,7 +319,7 @@ __global__ __launch_bounds__(256, 2) void k_din_attn(const DinRun A, const int* 
                     }
                 }
             }
-            // epilogue: PReLU(alpha[t][n]) -> Dense(1) -> sigmoid (DIN.py:150-151); lane (r,q) holds
+            // epilogue: PReLU(alpha[t][n]) -> Dense(1) (both in ca / cb) -> sigmoid (DIN.py:150-151); lane (r,q) holds
             // u[n = nb*16 + 4q + j] of row t = 16g + r
 #pragma unroll
             for (int h = 0; h < (TWO ? 2 : 1); ++h) {
@@ -318,14 +327,11 @@ __global__ __launch_bounds__(256, 2) void k_din_attn(const DinRun A, const int* 
                 float sum = 0.f;
 #pragma unroll
                 for (int nb = 0; nb < HC; ++nb) {
-                    const f32x4 al = h ? al1[nb] : al0[nb];
+                    const f32x4 ca = h ? al1[nb] : al0[nb];
+                    const f32x4 cb = h ? be1[nb] : be0[nb];
                     const f32x4 u = h ? a1[nb] : a0[nb];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const float pos = __builtin_amdgcn_fmed3f(u[j], 0.f, __builtin_inff());
-                        const float neg = __builtin_amdgcn_fmed3f(u[j], -__builtin_inff(), 0.f);   // min(u, 0), one instruction
-                        sum = fmaf(w2f[nb][j], fmaf(al[j], neg, pos), sum);
-                    }
+                    for (int j = 0; j < 4; ++j) sum = fmaf(cb[j], __builtin_fabsf(u[j]), fmaf(ca[j], u[j], sum));
                 }
                 const float wgt = sigmoidf_fast(rows4_sum(sum) * (HALF ? A.unscale : 1.0f) + A.b2);   // PReLU is positively homogeneous
                 if (q == 0 && att && t < T) att[(size_t)s * T + t] = wgt;
