@@ -56,12 +56,13 @@ int fail(int code, const char* fmt, ...) {
 // ---------------------------------------------------------------------------------------------
 // device-side plan (slots resolved to pointers); lives in device memory, read through scalar loads
 // ---------------------------------------------------------------------------------------------
+#define SEG_ROWS_ACC 100   // internal (created by the first-Dense fold at finalize): += folded row into buffer `buf`
 struct DevSeg {
-    int kind, field, field2, row_stride, count, dst, vocab, pad_;
+    int kind, field, field2, row_stride, count, dst, vocab, buf;   // buf: destination buffer (ROWS_ACC only; others: 0)
     const float* table;
 };
 struct DevOp {
-    int kind, src_buf, src_off, K, dst_buf, dst_off, N, ldw, act, groups, group_stride, pad_;
+    int kind, src_buf, src_off, K, dst_buf, dst_off, N, ldw, act, groups, group_stride, acc_init;   // acc_init: Dense accumulates onto dst
     const float* W;
     const float* bias;
     const float* alpha;
@@ -85,7 +86,10 @@ struct DevPlan {
     int F, ND, NA, n_segs, n_ops, n_taps, n_pairs, n_bufs;
     int buf_stride[SPRK_MAX_BUFS];
     int buf_base[SPRK_MAX_BUFS];   // float offset of each buffer inside dynamic LDS
-    int pad_[2];
+    int ids_base;                  // float offset of the tile's ids block [64][n_idc] inside dynamic LDS
+    int n_idc;                     // ids columns the segments read, staged compactly (segs[].field / field2 index THIS list)
+    int idc[SPRK_MAX_SEGS];
+    int n_acc;                     // ROWS_ACC segments (first-Dense fold); they are the LAST n_acc entries of segs[]
     float head_bias;
     float pad2_;
     int pair_a[SPRK_MAX_PAIRS];
@@ -147,8 +151,13 @@ __device__ __forceinline__ void dense_unit(const DevOp& op, const float* __restr
     const float* wrow = op.W + (size_t)(nb * 16 + r) * op.ldw + 4 * q;
     const float* xrow = src + (mi0 * 16 + r) * sstride + op.src_off + 4 * q;
     f32x4 acc[MI];
+    const int n = nb * 16 + 4 * q;
 #pragma unroll
-    for (int i = 0; i < MI; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < MI; ++i) {
+        acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // folded first layer: the gather phase left sum_g (W_g^T E_g[id]) of the folded embedding columns here
+        if (op.acc_init) acc[i] = ld4(dst + ((mi0 + i) * 16 + r) * dstride + op.dst_off + n);
+    }
     const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
     f32x4 a = (4 * q < K) ? ld4(wrow) : zero;
     for (int k = 0; k < K; k += 16) {
@@ -162,7 +171,6 @@ __device__ __forceinline__ void dense_unit(const DevOp& op, const float* __restr
         }
         a = an;
     }
-    const int n = nb * 16 + 4 * q;
     f32x4 bias = ld4(op.bias + n);
     f32x4 alpha = zero;
     if (op.act == SPRK_ACT_PRELU) alpha = ld4(op.alpha + n);
@@ -216,42 +224,117 @@ __global__ __launch_bounds__(256) void k_tile_forward(const DevPlan* __restrict_
         const int m0 = tile * SPRK_TILE_M;
         const int mvalid = min(SPRK_TILE_M, B - m0);
 
-        // ---------------- phase 1: gather the tile into LDS buffer 0 ----------------
-        const int n_segs = P->n_segs;
+        // ---------------- phase 1: gather the tile into LDS ----------------
+        // The tile's ids block first (one coalesced pass, every later id read is an LDS read), then the row
+        // gathers with several independent loads in flight per thread: at one tile per workgroup the kernel's
+        // duration is this phase's chain of memory latencies, so what counts is how few round trips it takes.
+        int* ids_s = reinterpret_cast<int*>(smem + P->ids_base);
+        const int FC = P->n_idc;                                 // only the columns some segment reads (DIN's history ids stay out)
+        {
+            const int total = mvalid * FC;
+            const int* src = ids + (size_t)m0 * F;
+#pragma unroll 4
+            for (int i = tid; i < total; i += 256) {
+                const int m = i / FC, j = i - m * FC;
+                ids_s[i] = src[m * F + P->idc[j]];
+            }
+        }
+        __syncthreads();
+        const int n_acc = P->n_acc;
+        const int n_segs = P->n_segs - n_acc;
+        if (n_acc > 0) {
+            // folded embedding columns (first-Dense fold): dst[m][:] = sum over the folded columns g of F_g[id_g][:],
+            // one thread per (sample, 16-byte piece), fixed summation order, all of a piece's loads in flight together
+            const DevSeg* ag = &P->segs[n_segs];
+            const int nvec = ag[0].count;
+            const int total = SPRK_TILE_M * nvec;
+            float* bufd = smem + P->buf_base[ag[0].buf];
+            const int strided = P->buf_stride[ag[0].buf];
+            for (int base = tid; base < total; base += 1024) {        // 4 pieces per thread per trip
+                f32x4 acc[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int g0 = 0; g0 < n_acc; g0 += 4) {               // up to 4 pieces x 4 columns = 16 loads in flight
+                    f32x4 v[4][4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int idx = base + u * 256;
+                        const int m = idx / nvec;
+                        const int c = idx - m * nvec;
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            v[u][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+                            if (g0 + g < n_acc && idx < total && m < mvalid) {
+                                const DevSeg& a = ag[g0 + g];
+                                const int id = ids_s[m * FC + a.field];
+                                if ((unsigned)id < (unsigned)a.vocab) v[u][g] = ld4(a.table + (size_t)id * a.row_stride + 4 * c);
+                                else if (id != -1) atomicOr(err, 1);
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) acc[u] += v[u][g];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int idx = base + u * 256;
+                    if (idx < total) {
+                        const int m = idx / nvec;
+                        const int c = idx - m * nvec;
+                        st4(bufd + m * strided + ag[0].dst + 4 * c, acc[u]);
+                    }
+                }
+            }
+        }
         for (int s = 0; s < n_segs; ++s) {
             const DevSeg& sg = P->segs[s];
             const int kind = sg.kind;
             if (kind == SPRK_SEG_ROWS || kind == SPRK_SEG_CROSS_ROWS) {
                 const int nvec = sg.count;
                 const int total = SPRK_TILE_M * nvec;
-                for (int idx = tid; idx < total; idx += 256) {
-                    const int m = idx / nvec;
-                    const int c = idx - m * nvec;
-                    f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-                    if (m < mvalid) {
-                        const int* idrow = ids + (size_t)(m0 + m) * F;
-                        long long row;
-                        if (kind == SPRK_SEG_ROWS) {
-                            const int id = idrow[sg.field];
-                            row = id;
-                            if ((unsigned)id >= (unsigned)sg.vocab) {
-                                row = -1;
-                                if (id != -1) atomicOr(err, 1);
+                for (int base = tid; base < total; base += 1024) {
+                    f32x4 v[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int idx = base + u * 256;
+                        const int m = idx / nvec;
+                        const int c = idx - m * nvec;
+                        v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        if (idx < total && m < mvalid) {
+                            const int* idrow = ids_s + m * FC;
+                            long long row;
+                            if (kind == SPRK_SEG_ROWS) {
+                                const int id = idrow[sg.field];
+                                row = id;
+                                if ((unsigned)id >= (unsigned)sg.vocab) {
+                                    row = -1;
+                                    if (id != -1) atomicOr(err, 1);
+                                }
+                            } else {
+                                const int a = idrow[sg.field], b = idrow[sg.field2];
+                                row = (long long)cross_bucket(a, b, (uint64_t)sg.vocab);
                             }
-                        } else {
-                            const int a = idrow[sg.field], b = idrow[sg.field2];
-                            row = (long long)cross_bucket(a, b, (uint64_t)sg.vocab);
+                            if (row >= 0) v[u] = ld4(sg.table + (size_t)row * sg.row_stride + 4 * c);
                         }
-                        if (row >= 0) v = ld4(sg.table + (size_t)row * sg.row_stride + 4 * c);
                     }
-                    st4(buf0 + m * stride0 + sg.dst + 4 * c, v);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int idx = base + u * 256;
+                        if (idx < total) {
+                            const int m = idx / nvec;
+                            const int c = idx - m * nvec;
+                            st4(buf0 + m * stride0 + sg.dst + 4 * c, v[u]);
+                        }
+                    }
                 }
             } else if (kind == SPRK_SEG_SCALAR || kind == SPRK_SEG_CROSS_SCALAR) {
                 if (tid < SPRK_TILE_M) {
                     const int m = tid;
                     float v = 0.f;
                     if (m < mvalid) {
-                        const int* idrow = ids + (size_t)(m0 + m) * F;
+                        const int* idrow = ids_s + m * FC;
                         if (kind == SPRK_SEG_SCALAR) {
                             const int id = idrow[sg.field];
                             if ((unsigned)id < (unsigned)sg.vocab) v = sg.table[id];
@@ -268,12 +351,26 @@ __global__ __launch_bounds__(256) void k_tile_forward(const DevPlan* __restrict_
                 const int total = SPRK_TILE_M * cnt;
                 const float* base = (kind == SPRK_SEG_DENSE) ? dense : aux;
                 const int rw = (kind == SPRK_SEG_DENSE) ? ND : NA;
-                for (int idx = tid; idx < total; idx += 256) {
-                    const int m = idx / cnt;
-                    const int j = idx - m * cnt;
-                    float v = 0.f;
-                    if (m < mvalid) v = base[(size_t)(m0 + m) * rw + sg.field + j];
-                    buf0[m * stride0 + sg.dst + j] = v;
+                // (eight independent loads in flight per thread: this copy is pure latency otherwise)
+                for (int b8 = tid; b8 < total; b8 += 2048) {
+                    float v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int idx = b8 + u * 256;
+                        const int m = idx / cnt;
+                        const int j = idx - m * cnt;
+                        v[u] = 0.f;
+                        if (idx < total && m < mvalid) v[u] = base[(size_t)(m0 + m) * rw + sg.field + j];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int idx = b8 + u * 256;
+                        if (idx < total) {
+                            const int m = idx / cnt;
+                            const int j = idx - m * cnt;
+                            buf0[m * stride0 + sg.dst + j] = v[u];
+                        }
+                    }
                 }
             } else {  // SPRK_SEG_ZERO
                 const int cnt = sg.count;
@@ -485,6 +582,28 @@ __global__ __launch_bounds__(256) void k_din_pool(const DevPlan* __restrict__ P,
     }
 }
 
+// One-time (finalize) kernel of the first-Dense fold: F[v][n] = sum_j Wt[n][col0 + j] * table[v][j]
+// (Wt = the layer's W^T [N][ldw], col0 = the embedding column's offset inside the layer's input slice).
+__global__ __launch_bounds__(256) void k_fold_dense_rows(const float* __restrict__ table, long long vocab, int row_stride,
+                                                         int width, const float* __restrict__ Wt, int ldw, int col0,
+                                                         int N, float* __restrict__ F) {
+    const long long total = vocab * N;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long v = i / N;
+        const int n = (int)(i - v * N);
+        const float* e = table + v * row_stride;
+        const float* w = Wt + (size_t)n * ldw + col0;
+        float acc = 0.f;
+        for (int j = 0; j < width; ++j) acc = fmaf(w[j], e[j], acc);
+        F[i] = acc;
+    }
+}
+// copy of a W^T with the columns [c0, c1) zeroed (folded columns that stay inside the layer's K range)
+__global__ __launch_bounds__(256) void k_zero_columns(float* __restrict__ Wt, int N, int ldw, int c0, int c1) {
+    const int w = c1 - c0;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < N * w; i += gridDim.x * 256) Wt[(size_t)(i / w) * ldw + c0 + i % w] = 0.f;
+}
+
 #include "k_chain_v2.h"
 #include "k_chain_v2j.h"
 #include "k_din_attn.h"
@@ -529,7 +648,10 @@ struct sprk_engine {
     int buf_stride[SPRK_MAX_BUFS] = {0, 0, 0};
     int buf_base[SPRK_MAX_BUFS] = {0, 0, 0};
     size_t tile_lds_bytes = 0;
+    int ids_base = 0;              // float offset of the tile's ids block inside the tile kernel's LDS
+    std::vector<int> idc;          // ids columns read by the gather segments (compact staging order)
     int tile_grid_cap = 0;
+    std::vector<void*> fold_bufs;  // first-Dense fold: folded tables + the W^T copy (device)
     // DIN launch geometry
     int din_ms = 0;
     size_t din_lds_bytes = 0;
@@ -989,6 +1111,114 @@ const DinVariant kDinVariants[] = {     // first match wins: smallest sufficient
     DIN_VARIANT(1, 2, 4),
 };
 
+// First-Dense fold for plans the tile interpreter runs.  A Dense layer is linear in its input, so the share of
+// an embedding column is a table of its own: F_g[id] = W_g^T E_g[id] (N floats per id).  When a ROWS segment feeds
+// nothing but the plan's first Dense op, the fold replaces "gather E_g[id] into the input slice, multiply by W_g
+// on the matrix pipe" by "gather F_g[id] and add it to the layer's accumulator": the layer's K shrinks to the
+// columns that really are per-sample data (numerics, the DIN pooled vector, crossed columns), at the price of
+// N instead of D floats per gathered row.  DIN tail (DIN.py:161-166): K 168 -> 40; EmbeddingMLP: 108 -> 8.
+// Same fp32 arithmetic, other association.  SPRK_TILE_FOLD=0 switches it off (A/B, tests).
+int fold_first_dense(sprk_engine* h, DevPlan* dp) {
+    const char* fm = getenv("SPRK_TILE_FOLD");
+    if (fm && fm[0] == '0') return SPRK_OK;
+    if (dp->n_ops < 1) return SPRK_OK;
+    DevOp& op = dp->ops[0];
+    if (op.kind != SPRK_OP_DENSE || op.src_buf != 0 || op.dst_buf == 0 || op.N > 512) return SPRK_OK;
+    const int lo0 = op.src_off, hi0 = op.src_off + op.K;
+    auto used_elsewhere = [&](int a, int b) {                 // is the GATHERED content of buffer 0's [a,b) read by anything but ops[0]?
+        std::vector<char> live(b - a, 1);                     // columns still holding gathered data (later ops may overwrite buffer 0)
+        auto reads = [&](int s0, int s1) {
+            for (int c = (s0 > a ? s0 : a); c < (s1 < b ? s1 : b); ++c) if (live[c - a]) return true;
+            return false;
+        };
+        auto writes = [&](int s0, int s1) { for (int c = (s0 > a ? s0 : a); c < (s1 < b ? s1 : b); ++c) live[c - a] = 0; };
+        for (int i = 1; i < dp->n_ops; ++i) {
+            const DevOp& o = dp->ops[i];
+            if (o.src_buf == 0) {
+                if (o.kind == SPRK_OP_PAIR_DOT) {
+                    for (int p = 0; p < dp->n_pairs; ++p)
+                        if (reads(dp->pair_a[p], dp->pair_a[p] + o.K) || reads(dp->pair_b[p], dp->pair_b[p] + o.K)) return true;
+                } else if (o.kind == SPRK_OP_FM_SUMSQ) {
+                    if (reads(o.src_off, o.src_off + (o.groups - 1) * o.group_stride + o.K)) return true;
+                } else if (reads(o.src_off, o.src_off + o.K)) {
+                    return true;
+                }
+            }
+            if (o.dst_buf == 0) {
+                const int w = o.kind == SPRK_OP_DENSE ? o.N : o.kind == SPRK_OP_PAIR_DOT ? dp->n_pairs : o.K;
+                writes(o.dst_off, o.dst_off + w);
+            }
+        }
+        for (int t = 0; t < dp->n_taps; ++t)
+            if (dp->taps[t].buf == 0 && reads(dp->taps[t].off, dp->taps[t].off + dp->taps[t].len)) return true;
+        return false;
+    };
+    std::vector<int> fold;
+    size_t bytes = 0;
+    for (int i = 0; i < dp->n_segs; ++i) {
+        const DevSeg& sg = dp->segs[i];
+        if (sg.kind != SPRK_SEG_ROWS) continue;
+        const int a = sg.dst, b = sg.dst + 4 * sg.count;
+        if (a < lo0 || b > hi0 || used_elsewhere(a, b)) continue;
+        const size_t need = (size_t)sg.vocab * op.N * sizeof(float);
+        if (need > ((size_t)2 << 30) || bytes + need > ((size_t)8 << 30)) continue;   // keep huge tables as plain row gathers
+        if (fold.size() == 8) break;                          // the gather keeps at most 8 folded columns in flight per piece
+        bytes += need;
+        fold.push_back(i);
+    }
+    if (fold.empty()) return SPRK_OK;
+    // new K range: hull of the columns that stay (everything in [lo0,hi0) not covered by a folded segment)
+    std::vector<char> keep(hi0 - lo0, 1);
+    for (int i : fold)
+        for (int c = dp->segs[i].dst; c < dp->segs[i].dst + 4 * dp->segs[i].count; ++c) keep[c - lo0] = 0;
+    int lo = hi0, hi = lo0;
+    for (int c = lo0; c < hi0; ++c)
+        if (keep[c - lo0]) { if (c < lo) lo = c; if (c + 1 > hi) hi = c + 1; }
+    if (lo >= hi) { lo = lo0; hi = lo0; }
+    lo &= ~3;
+    hi = (hi + 3) & ~3;
+    if (hi > hi0) hi = hi0;
+    // W^T copy with the folded columns inside the hull zeroed; F tables
+    const size_t wbytes = (size_t)op.N * op.ldw * sizeof(float);
+    float* wcopy = nullptr;
+    HIP_TRY(hipMalloc((void**)&wcopy, wbytes + 16));
+    h->fold_bufs.push_back(wcopy);
+    HIP_TRY(hipMemcpy(wcopy, op.W, wbytes, hipMemcpyDeviceToDevice));
+    bool first = true;
+    for (int i : fold) {
+        DevSeg& sg = dp->segs[i];
+        float* F = nullptr;
+        HIP_TRY(hipMalloc((void**)&F, (size_t)sg.vocab * op.N * sizeof(float) + 16));
+        h->fold_bufs.push_back(F);
+        long long blocks = ((long long)sg.vocab * op.N + 255) / 256;
+        if (blocks > 65536) blocks = 65536;
+        hipLaunchKernelGGL(k_fold_dense_rows, dim3((unsigned)blocks), dim3(256), 0, 0, sg.table, (long long)sg.vocab, sg.row_stride,
+                           4 * sg.count, op.W, op.ldw, sg.dst - lo0, op.N, F);
+        HIP_TRY(hipGetLastError());
+        const int c0 = sg.dst - lo0, c1 = c0 + 4 * sg.count;
+        hipLaunchKernelGGL(k_zero_columns, dim3(16), dim3(256), 0, 0, wcopy, op.N, op.ldw, c0, c1);
+        HIP_TRY(hipGetLastError());
+        sg.kind = SEG_ROWS_ACC; sg.table = F; sg.row_stride = op.N; sg.count = op.N / 4; sg.dst = op.dst_off;
+        sg.buf = op.dst_buf; sg.field2 = first ? 0 : 1;
+        first = false;
+    }
+    HIP_TRY(hipDeviceSynchronize());
+    // folded columns go to the end of the segment list (the kernel handles them as one group)
+    {
+        std::vector<DevSeg> plain, acc;
+        for (int i = 0; i < dp->n_segs; ++i) (dp->segs[i].kind == SEG_ROWS_ACC ? acc : plain).push_back(dp->segs[i]);
+        int k = 0;
+        for (const DevSeg& g : plain) dp->segs[k++] = g;
+        for (const DevSeg& g : acc) dp->segs[k++] = g;
+        dp->n_acc = (int)acc.size();
+    }
+    op.W = wcopy + (lo - lo0);
+    op.src_off = lo;
+    op.K = hi - lo;
+    op.acc_init = 1;
+    return SPRK_OK;
+}
+
 int need_bytes(const sprk_engine* h, int slot, size_t bytes, const char* what) {
     if (!h->slot_ptr[slot]) return fail(SPRK_ESTATE, "%s: slot %d was never uploaded", what, slot);
     if (h->slot_bytes[slot] < bytes) return fail(SPRK_EINVAL, "%s: slot %d holds %zu bytes, needs %zu", what, slot, h->slot_bytes[slot], bytes);
@@ -1035,6 +1265,18 @@ int sprk_create(const sprk_plan* plan, sprk_handle* out) {
         h->buf_base[b] = off;
         off += SPRK_TILE_M * h->buf_stride[b];
     }
+    // the tile's ids block [64][columns some gather segment reads]
+    auto use_col = [&](int c) {
+        for (int x : h->idc) if (x == c) return;
+        h->idc.push_back(c);
+    };
+    for (int i = 0; i < plan->n_segs; ++i) {
+        const sprk_seg& sg = plan->segs[i];
+        if (sg.kind == SPRK_SEG_ROWS || sg.kind == SPRK_SEG_SCALAR || sg.kind == SPRK_SEG_CROSS_ROWS || sg.kind == SPRK_SEG_CROSS_SCALAR) use_col(sg.field);
+        if (sg.kind == SPRK_SEG_CROSS_ROWS || sg.kind == SPRK_SEG_CROSS_SCALAR) use_col(sg.field2);
+    }
+    h->ids_base = off;
+    off += (SPRK_TILE_M * (int)h->idc.size() + 3) & ~3;
     h->tile_lds_bytes = (size_t)off * sizeof(float);
     if (h->tile_lds_bytes > 160 * 1024) {
         size_t need = h->tile_lds_bytes;
@@ -1070,12 +1312,18 @@ int sprk_finalize(sprk_handle h) {
     dp->n_segs = p.n_segs; dp->n_ops = p.n_ops; dp->n_taps = p.n_taps; dp->n_pairs = p.n_pairs; dp->n_bufs = p.n_bufs;
     dp->head_bias = p.head_bias;
     for (int b = 0; b < SPRK_MAX_BUFS; ++b) { dp->buf_stride[b] = h->buf_stride[b]; dp->buf_base[b] = h->buf_base[b]; }
+    dp->ids_base = h->ids_base;
+    dp->n_idc = (int)h->idc.size();
+    for (size_t i = 0; i < h->idc.size(); ++i) dp->idc[i] = h->idc[i];
+    auto compact = [&](int c) { for (size_t i = 0; i < h->idc.size(); ++i) if (h->idc[i] == c) return (int)i; return 0; };
     for (int i = 0; i < p.n_pairs; ++i) { dp->pair_a[i] = p.pair_a[i]; dp->pair_b[i] = p.pair_b[i]; }
     int rc;
     for (int i = 0; i < p.n_segs; ++i) {
         const sprk_seg& s = p.segs[i];
         DevSeg& d = dp->segs[i];
         d.kind = s.kind; d.field = s.field; d.field2 = s.field2; d.row_stride = s.row_stride; d.count = s.count; d.dst = s.dst; d.vocab = s.vocab;
+        if (s.kind == SPRK_SEG_ROWS || s.kind == SPRK_SEG_SCALAR || s.kind == SPRK_SEG_CROSS_ROWS || s.kind == SPRK_SEG_CROSS_SCALAR) d.field = compact(s.field);
+        if (s.kind == SPRK_SEG_CROSS_ROWS || s.kind == SPRK_SEG_CROSS_SCALAR) d.field2 = compact(s.field2);
         d.table = nullptr;
         if (s.kind == SPRK_SEG_ROWS || s.kind == SPRK_SEG_CROSS_ROWS) {
             if ((rc = need_bytes(h, s.slot, (size_t)s.vocab * s.row_stride * 4, "embedding table"))) return rc;
@@ -1258,6 +1506,7 @@ int sprk_finalize(sprk_handle h) {
             HIP_TRY(hipDeviceSynchronize());
         }
     }
+    if (h->v2_variant < 0 && (rc = fold_first_dense(h, dp))) return rc;
     HIP_TRY(hipMalloc((void**)&h->dev_plan, sizeof(DevPlan)));
     HIP_TRY(hipMemcpy(h->dev_plan, dp, sizeof(DevPlan), hipMemcpyHostToDevice));
     HIP_TRY(hipMalloc((void**)&h->dev_err, sizeof(int)));
@@ -1398,6 +1647,7 @@ void sprk_destroy(sprk_handle h) {
     if (h->v2_fo_all) (void)hipFree(h->v2_fo_all);
     if (h->v2_folded) (void)hipFree(h->v2_folded);
     if (h->v2j_tab) (void)hipFree(h->v2j_tab);
+    for (void* p : h->fold_bufs) if (p) (void)hipFree(p);
     if (h->v2j_big) (void)hipFree(h->v2j_big);
     if (h->din_w12) (void)hipFree(h->din_w12);
     if (h->din_w4) (void)hipFree(h->din_w4);

@@ -756,13 +756,16 @@ class DIN(CTRModel):
         # ---- tail (k_tile_forward) ----
         rows, fan = self._fc_rows()
         x_of = {}
+        # LDS layout of the tail's input: the four embedding columns first, then the per-sample data (pooled
+        # history + numerics) side by side -- the engine folds embedding columns that feed only the first Dense
+        # into per-id tables (fold_first_dense), and fc0's K range then is just this last stretch
         x_of["userGenre1_embedding"] = pb.seg_rows("userGenre1", pad_table(w["emb/userGenre1"]), N_GENRES, D)
         x_of["userId_embedding"] = pb.seg_rows("userId", pad_table(w["emb/userId"]), self.user_buckets, D)
+        x_of["__cand__"] = pb.seg_rows("movieId", movie_tab, self.movie_buckets, D)
+        x_of["movieGenre1_embedding"] = pb.seg_rows("movieGenre1", pad_table(w["emb/movieGenre1"]), N_GENRES, D)
         poff = pb.x_alloc(Dp)
         pb.seg_aux(0, Dp, poff)
         x_of["__pooled__"] = poff
-        x_of["__cand__"] = pb.seg_rows("movieId", movie_tab, self.movie_buckets, D)
-        x_of["movieGenre1_embedding"] = pb.seg_rows("movieGenre1", pad_table(w["emb/movieGenre1"]), N_GENRES, D)
         num_off = pb.seg_numerics(len(self.numeric_keys))
         for j, k in enumerate(self.numeric_keys):
             x_of[k] = num_off + j

@@ -450,3 +450,39 @@ def test_forward_many_equals_forward(torch, config2):
     ref = model.predict_device(ids, dense)
     for i, o in enumerate(outs):
         assert torch.equal(o, ref[i * B:(i + 1) * B])
+
+
+# --------------------------------------------------------------------------------------------
+# first-Dense fold of the tile interpreter (embedding columns -> per-id tables of the layer's outputs)
+# --------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["embedding_mlp", "wide_n_deep", "neural_cf", "neural_cf2", "deepfm", "din"])
+def test_first_dense_fold_matches_unfolded(torch, samples, monkeypatch, name):
+    g = np.load(os.path.join(GOLDEN, "oracle_%s.npz" % name))
+    out = {}
+    for fold in ("1", "0"):
+        monkeypatch.setenv("SPRK_TILE_FOLD", fold)
+        out[fold] = make_model(name).predict(samples)[:, 0]
+        assert np.abs(out[fold] - g["pred64"]).max() <= TIGHT
+    assert np.abs(out["1"] - out["0"]).max() <= TIGHT
+    # missing / out-of-vocabulary ids still are zero rows when the column is folded
+    monkeypatch.setenv("SPRK_TILE_FOLD", "1")
+    if name in ("embedding_mlp", "wide_n_deep"):
+        s2 = dict(samples)
+        s2["userGenre2"] = np.array([""] * 256, dtype=object)
+        p_missing = make_model(name).predict(s2)[:, 0]
+        monkeypatch.setenv("SPRK_TILE_FOLD", "0")
+        np.testing.assert_allclose(make_model(name).predict(s2)[:, 0], p_missing, atol=TIGHT)
+
+
+def test_din_tail_fold_config3(torch, monkeypatch):
+    B, T, D = 4099, 50, 32
+    feats = SY.synth_din(B, T, SY.ML20M_MOVIE_IDS, SY.ML20M_USER_IDS, seed=21)
+    out = {}
+    for fold in ("1", "0"):
+        monkeypatch.setenv("SPRK_TILE_FOLD", fold)
+        model = M.DIN(seed=35, emb_dim=D, hist_len=T, movie_buckets=SY.ML20M_MOVIE_IDS, user_buckets=SY.ML20M_USER_IDS)
+        out[fold] = model.predict(feats)[:, 0]
+    ref = O.din_forward(feats, model.weights, dtype=np.float64, hist_len=T, movie_buckets=SY.ML20M_MOVIE_IDS,
+                        user_buckets=SY.ML20M_USER_IDS)[:, 0]
+    assert np.abs(out["1"] - ref).max() <= TOL and np.abs(out["0"] - ref).max() <= TOL
+    assert np.abs(out["1"] - out["0"]).max() <= TIGHT
