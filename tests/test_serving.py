@@ -1,0 +1,127 @@
+"""TF-Serving-compatible REST shim (sparrowrecsys_amd/serving.py): the wire contract of
+RecForYouProcess.java:113-138 against a stub model on CPU, and end to end over the HIP path with the
+reference-trained NeuralCF weights on a GPU."""
+import json
+import os
+import threading
+import urllib.error
+import urllib.request
+
+import numpy as np
+import pytest
+
+from sparrowrecsys_amd.serving import PredictServer
+from tests.conftest import GOLDEN
+
+
+class _StubModel:
+    """score = sigmoid-free closed form of (userId, movieId); ids >= 1000 are 'out of vocabulary'."""
+
+    def __init__(self):
+        self.calls = []
+
+    def predict(self, feats):
+        u = np.asarray(feats["userId"], dtype=np.int64)
+        m = np.asarray(feats["movieId"], dtype=np.int64)
+        self.calls.append(len(u))
+        if (m >= 1000).any() or (m < 0).any():
+            raise ValueError("an id was outside its table")
+        return ((u % 7) * 0.1 + (m % 5) * 0.01).astype(np.float32).reshape(-1, 1)
+
+
+def _post(port, body, path="/v1/models/recmodel:predict"):
+    req = urllib.request.Request("http://127.0.0.1:%d%s" % (port, path), data=json.dumps(body).encode(),
+                                 headers={"Content-Type": "application/json"})
+    try:
+        with urllib.request.urlopen(req, timeout=30) as r:
+            return r.status, json.loads(r.read())
+    except urllib.error.HTTPError as e:
+        return e.code, json.loads(e.read())
+
+
+@pytest.fixture()
+def stub_server():
+    model = _StubModel()
+    srv = PredictServer(model, port=0).start()
+    yield srv, model
+    srv.close()
+
+
+def test_row_format_matches_jetty_client(stub_server):
+    srv, model = stub_server
+    inst = [{"userId": 10 + i, "movieId": (3 * i) % 1000} for i in range(800)]   # RecForYouProcess.java:118-127
+    code, resp = _post(srv.port, {"instances": inst})
+    assert code == 200 and list(resp) == ["predictions"]
+    p = resp["predictions"]
+    assert len(p) == 800 and all(isinstance(x, list) and len(x) == 1 for x in p)    # getJSONArray(i).getDouble(0)
+    want = [((10 + i) % 7) * 0.1 + (((3 * i) % 1000) % 5) * 0.01 for i in range(800)]
+    np.testing.assert_allclose([x[0] for x in p], want, atol=1e-6)
+
+
+def test_columnar_format_status_and_errors(stub_server):
+    srv, _ = stub_server
+    code, resp = _post(srv.port, {"inputs": {"userId": [1, 2, 3], "movieId": [4, 5, 6]}})
+    assert code == 200 and len(resp["outputs"]) == 3
+    code, resp = _post(srv.port, {"instances": [{"userId": 1, "movieId": 5000}]})       # out-of-range id -> 400 + error
+    assert code == 400 and "error" in resp
+    code, resp = _post(srv.port, {"foo": 1})
+    assert code == 400 and "error" in resp
+    code, resp = _post(srv.port, {"instances": []})
+    assert code == 200 and resp == {"predictions": []}
+    code, resp = _post(srv.port, {"instances": [{"userId": 1, "movieId": 2}]}, path="/v1/models/other:predict")
+    assert code == 404
+    with urllib.request.urlopen("http://127.0.0.1:%d/v1/models/recmodel" % srv.port, timeout=30) as r:
+        assert json.loads(r.read())["model_version_status"][0]["state"] == "AVAILABLE"
+
+
+def test_concurrent_requests_are_batched_and_isolated(stub_server):
+    srv, model = stub_server
+    srv.batcher.max_wait_s = 0.05                       # give the 16 client threads time to pile up
+    results = {}
+
+    def client(i):
+        bad = i == 5
+        inst = [{"userId": 100 * i + j, "movieId": (5000 if bad else j)} for j in range(50)]
+        results[i] = _post(srv.port, {"instances": inst})
+
+    ts = [threading.Thread(target=client, args=(i,)) for i in range(16)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    for i in range(16):
+        code, resp = results[i]
+        if i == 5:
+            assert code == 400                          # its neighbours in the merged batch are not affected
+        else:
+            assert code == 200
+            want = [((100 * i + j) % 7) * 0.1 + (j % 5) * 0.01 for j in range(50)]
+            np.testing.assert_allclose([x[0] for x in resp["predictions"]], want, atol=1e-6)
+    assert srv.batcher.batches < srv.batcher.requests   # at least one merged forward
+
+
+@pytest.mark.gpu
+def test_neuralcf_served_end_to_end_with_reference_trained_weights():
+    """The reference's own trained NeuralCF (modeldata/neuralcf/001) behind the shim: the scores the Jetty
+    ranker would receive equal the oracle's on the same (userId, movieId) pairs."""
+    from oracle import ctr_oracle as O
+    from sparrowrecsys_amd import models as M
+    g = np.load(os.path.join(GOLDEN, "neuralcf_ckpt.npz"))
+    w = {k[4:]: g[k] for k in g.files if k.startswith("001/")}
+    table = np.zeros((30001, 10), np.float32)
+    table[g["users"]] = g["user_rows_001"]
+    w["emb/userId"] = table
+    model = M.NeuralCF(weights=w)
+    srv = PredictServer(model, port=0).start()
+    try:
+        n = 800
+        inst = [{"userId": int(u), "movieId": int(m)} for u, m in zip(g["userId"][:n], g["movieId"][:n])]
+        code, resp = _post(srv.port, {"instances": inst})
+        assert code == 200
+        got = np.array([x[0] for x in resp["predictions"]], dtype=np.float32)
+        ref = O.neural_cf_forward({"userId": g["userId"][:n], "movieId": g["movieId"][:n]}, w, dtype=np.float64)[:, 0]
+        assert np.abs(got - ref).max() <= 1e-4
+        code, resp = _post(srv.port, {"instances": [{"userId": 1, "movieId": 1001}]})     # movie table has 1001 rows
+        assert code == 400 and "error" in resp
+    finally:
+        srv.close()
