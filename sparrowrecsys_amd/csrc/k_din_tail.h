@@ -1,0 +1,211 @@
+// k_din_tail.h -- register-chained DIN tail (reference DIN.py:161-167): concat([user profile, pooled history,
+// candidate, context]) -> Dense(128) PReLU -> Dense(64) PReLU -> Dense(1, sigmoid), one WAVE per 16 samples.
+// Included inside sparrow_hip.hip's anonymous namespace, after k_din_attn.h.
+//
+// The first Dense is linear in the concat, so every embedding column's share is a table of its own,
+// F_g[id] = W_g^T E_g[id] (fold_first_dense builds them at sprk_finalize): per sample the layer is
+//     z0 = b0 + F_user[userId] + F_cand[movieId] + F_ug[userGenre1] + F_mg[movieGenre1]     four row gathers
+//          + Wp^T pooled + Wn^T numerics                                                     K = D + 8 on the matrix pipe
+// Lane (r = lane&15, q = lane>>4) holds z0[n = 16 nb + 4q + j] of sample r for every 16-wide block nb: the
+// C/D layout of v_mfma_f32_16x16x4_f32, which is also the B-operand layout of the next layer, so the folded
+// rows are gathered straight into the accumulators (16-byte pieces), fc0's remaining contraction, PReLU,
+// fc1 (K = 128: its B operand IS h1's registers), PReLU, the output dot and the sigmoid all stay in
+// registers.  Weights sit in LDS (pre-packed image, LDS-DMA), read as A fragments right before use.
+// f32 MFMA throughout: the operands here (raw numerics, hidden activations) have data-dependent range, the
+// static power-of-two scaling of the split-f16 path (k_chain_v2j.h) does not apply.
+// The interpreter ran this tail as a chain of memory round trips at one tile per workgroup (28 us at
+// B = 32 768); here every load of a task is in flight at once.
+
+#define DT_MAX_COLS 4
+
+struct DinTailRun {
+    int F, ND, NA;                        // ids / dense / aux (pooled) row widths
+    int n_cols;                           // folded embedding columns (<= DT_MAX_COLS)
+    int col[DT_MAX_COLS];                 // ids column
+    int vocab[DT_MAX_COLS];
+    const float* Ftab[DT_MAX_COLS];       // [vocab][N0] folded rows
+    int n_num;                            // numerics used (<= 8)
+    float head_bias;
+};
+
+template <int N0C, int N1C, int KPC>
+struct DinTailLds {
+    static constexpr int N0 = N0C * 16, N1 = N1C * 16;
+    static constexpr int K0 = KPC * 16 + 16;          // fc0's per-sample K: pooled chunks + one numeric chunk (8 used)
+    static constexpr int S0 = K0 + 4;                 // W0^T row stride
+    static constexpr int S1 = N0 + 4;                 // W1^T row stride
+    static constexpr int off_w0 = 0;                  // [N0][S0]
+    static constexpr int off_w1 = off_w0 + N0 * S0;   // [N1][S1]
+    static constexpr int off_b0 = off_w1 + N1 * S1;   // [N0]
+    static constexpr int off_a0 = off_b0 + N0;        // [N0]
+    static constexpr int off_b1 = off_a0 + N0;        // [N1]
+    static constexpr int off_a1 = off_b1 + N1;        // [N1]
+    static constexpr int off_hw = off_a1 + N1;        // [N1]
+    static constexpr int total = off_hw + N1;
+    static constexpr int total_pad = (total + 255) & ~255;
+    static constexpr size_t bytes = sizeof(float) * total_pad;
+};
+
+// One-time (finalize) kernel: the LDS image.  W0: the first Dense's W^T [N0][ldw0] (folded columns zeroed),
+// pooled columns at p_off, numerics at n_off; W1: second Dense's W^T [N1][ldw1].
+template <int N0C, int N1C, int KPC>
+__global__ __launch_bounds__(256) void k_din_tail_pack(const float* __restrict__ W0, int ldw0, int p_off, int Dp, int n_off,
+                                                       int n_num, const float* __restrict__ b0, const float* __restrict__ a0,
+                                                       const float* __restrict__ W1, int ldw1, const float* __restrict__ b1,
+                                                       const float* __restrict__ a1, const float* __restrict__ hw, int n_hw,
+                                                       float* __restrict__ img) {
+    using LD = DinTailLds<N0C, N1C, KPC>;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < LD::N0 * LD::S0; i += 256) {
+        const int n = i / LD::S0, k = i - n * LD::S0;
+        float v = 0.f;
+        if (k < KPC * 16) { if (k < Dp) v = W0[(size_t)n * ldw0 + p_off + k]; }
+        else if (k - KPC * 16 < n_num) v = W0[(size_t)n * ldw0 + n_off + (k - KPC * 16)];
+        img[LD::off_w0 + i] = v;
+    }
+    for (int i = tid; i < LD::N1 * LD::S1; i += 256) {
+        const int n = i / LD::S1, k = i - n * LD::S1;
+        img[LD::off_w1 + i] = k < LD::N0 ? W1[(size_t)n * ldw1 + k] : 0.f;
+    }
+    for (int i = tid; i < LD::N0; i += 256) { img[LD::off_b0 + i] = b0[i]; img[LD::off_a0 + i] = a0[i]; }
+    for (int i = tid; i < LD::N1; i += 256) {
+        img[LD::off_b1 + i] = b1[i];
+        img[LD::off_a1 + i] = a1[i];
+        img[LD::off_hw + i] = i < n_hw ? hw[i] : 0.f;
+    }
+    for (int i = LD::total + tid; i < LD::total_pad; i += 256) img[i] = 0.f;
+}
+
+template <int N0C, int N1C, int KPC, int WAVES>
+__global__ __launch_bounds__(WAVES * 64, 2) void k_din_tail(const DinTailRun A, const int* __restrict__ ids,
+                                                            const float* __restrict__ dense, const float* __restrict__ aux,
+                                                            float* __restrict__ out, int B, int* __restrict__ err,
+                                                            const float* __restrict__ image) {
+    using LD = DinTailLds<N0C, N1C, KPC>;
+    constexpr int N0 = LD::N0;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 15, q = lane >> 4;
+    const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int ntasks = (B + 15) >> 4;
+    const int task_stride = gridDim.x * WAVES;
+    bool bad = false;
+
+    // weight image -> LDS (1-KB LDS-DMA pieces), while the first task's ids are on their way
+    int tk = blockIdx.x * WAVES + wave;
+    int idv[DT_MAX_COLS];
+    auto ld_ids = [&](int t) {
+        const int m = min(t * 16 + r, B - 1);                    // rows past the end re-read the last sample, never stored
+        const int* row = ids + (size_t)m * A.F;
+#pragma unroll
+        for (int g = 0; g < DT_MAX_COLS; ++g) idv[g] = g < A.n_cols ? row[A.col[g]] : -1;
+    };
+    if (tk < ntasks) ld_ids(tk);
+#pragma unroll 1
+    for (int c = wave; c < LD::total_pad / 256; c += WAVES)
+        __builtin_amdgcn_global_load_lds(
+            (const __attribute__((address_space(1))) void*)(image + c * 256 + lane * 4),
+            (__attribute__((address_space(3))) void*)(smem + c * 256), 16, 0, 0);
+    __syncthreads();
+
+    for (; tk < ntasks; tk += task_stride) {
+        const int m = min(tk * 16 + r, B - 1);
+        // ---- per-sample operands: pooled history (aux) and numerics, in B-operand layout ----
+        f32x4 xp[KPC], xn;
+#pragma unroll
+        for (int c = 0; c < KPC; ++c) xp[c] = (16 * c + 4 * q < A.NA) ? ld4(aux + (size_t)m * A.NA + 16 * c + 4 * q) : zero;
+        {
+            const float* nrow = dense + (size_t)m * A.ND;
+            const int last = A.n_num - 1;
+            // slots beyond n_num hold a duplicate finite value that only ever meets zero weights
+            xn.x = nrow[min(4 * q + 0, last)];
+            xn.y = nrow[min(4 * q + 1, last)];
+            xn.z = nrow[min(4 * q + 2, last)];
+            xn.w = nrow[min(4 * q + 3, last)];
+        }
+        // ---- folded embedding columns gathered straight into fc0's accumulators ----
+        f32x4 z0[N0C];
+#pragma unroll
+        for (int nb = 0; nb < N0C; ++nb) z0[nb] = ld4(smem + LD::off_b0 + nb * 16 + 4 * q);
+#pragma unroll
+        for (int g0 = 0; g0 < DT_MAX_COLS; g0 += 2) {             // two columns = 2*N0C loads in flight at a time
+            f32x4 f[2][N0C];
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const int id = idv[g0 + g];
+                const bool ok = g0 + g < A.n_cols && (unsigned)id < (unsigned)A.vocab[g0 + g];
+                bad |= g0 + g < A.n_cols && !ok && id != -1;
+                const float* frow = A.Ftab[g0 + g] + (size_t)(ok ? id : 0) * N0 + 4 * q;
+#pragma unroll
+                for (int nb = 0; nb < N0C; ++nb) f[g][nb] = ok ? ld4(frow + nb * 16) : zero;
+            }
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+#pragma unroll
+                for (int nb = 0; nb < N0C; ++nb) z0[nb] += f[g][nb];
+        }
+        if (tk + task_stride < ntasks) ld_ids(tk + task_stride);   // next task's ids fly under this task's MFMAs
+
+        // ---- fc0's per-sample part: pooled chunks, then the numeric chunk (N0C independent chains) ----
+        const float* w0r = smem + LD::off_w0 + r * LD::S0 + 4 * q;
+#pragma unroll
+        for (int c = 0; c <= KPC; ++c) {
+            const f32x4 b = c < KPC ? xp[c < KPC ? c : 0] : xn;
+            f32x4 a[N0C];
+#pragma unroll
+            for (int nb = 0; nb < N0C; ++nb) {
+                a[nb] = ld4(w0r + nb * 16 * LD::S0 + 16 * c);
+                if (c == KPC && q >= 2) a[nb] = zero;             // the numeric chunk is 8 wide: k = 4q + s < 8
+            }
+#pragma unroll
+            for (int st = 0; st < 4; ++st)
+#pragma unroll
+                for (int nb = 0; nb < N0C; ++nb)
+                    z0[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[nb][st], b[st], z0[nb], 0, 0, 0);
+        }
+        // PReLU(alpha0) (DIN.py:164)
+#pragma unroll
+        for (int nb = 0; nb < N0C; ++nb) {
+            const f32x4 al = ld4(smem + LD::off_a0 + nb * 16 + 4 * q);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float u = z0[nb][j];
+                z0[nb][j] = __builtin_amdgcn_fmed3f(u, 0.f, __builtin_inff()) + al[j] * __builtin_amdgcn_fmed3f(u, -__builtin_inff(), 0.f);
+            }
+        }
+        // ---- fc1: K = N0, its B operand is h1 as it sits in the registers (N1C chains) ----
+        f32x4 z1[N1C];
+#pragma unroll
+        for (int n1 = 0; n1 < N1C; ++n1) z1[n1] = ld4(smem + LD::off_b1 + n1 * 16 + 4 * q);
+        const float* w1r = smem + LD::off_w1 + r * LD::S1 + 4 * q;
+#pragma unroll
+        for (int c = 0; c < N0C; ++c) {
+            f32x4 a[N1C];
+#pragma unroll
+            for (int n1 = 0; n1 < N1C; ++n1) a[n1] = ld4(w1r + n1 * 16 * LD::S1 + 16 * c);
+#pragma unroll
+            for (int st = 0; st < 4; ++st)
+#pragma unroll
+                for (int n1 = 0; n1 < N1C; ++n1)
+                    z1[n1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[n1][st], z0[c][st], z1[n1], 0, 0, 0);
+        }
+        // PReLU(alpha1) (DIN.py:166) -> Dense(1) -> sigmoid (DIN.py:167)
+        float z = 0.f;
+#pragma unroll
+        for (int n1 = 0; n1 < N1C; ++n1) {
+            const f32x4 al = ld4(smem + LD::off_a1 + n1 * 16 + 4 * q);
+            const f32x4 hw = ld4(smem + LD::off_hw + n1 * 16 + 4 * q);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float u = z1[n1][j];
+                const float h2 = __builtin_amdgcn_fmed3f(u, 0.f, __builtin_inff()) + al[j] * __builtin_amdgcn_fmed3f(u, -__builtin_inff(), 0.f);
+                z = fmaf(hw[j], h2, z);
+            }
+        }
+        z = rows4_sum(z);
+        const int mm = tk * 16 + r;
+        if (q == 0 && mm < B) out[mm] = sigmoidf_acc(z + A.head_bias);
+    }
+    if (__ballot(bad) != 0 && lane == 0) atomicOr(err, 1);
+}

@@ -607,6 +607,7 @@ __global__ __launch_bounds__(256) void k_zero_columns(float* __restrict__ Wt, in
 #include "k_chain_v2.h"
 #include "k_chain_v2j.h"
 #include "k_din_attn.h"
+#include "k_din_tail.h"
 
 // ---------------------------------------------------------------------------------------------
 // stand-alone operators
@@ -652,6 +653,10 @@ struct sprk_engine {
     std::vector<int> idc;          // ids columns read by the gather segments (compact staging order)
     int tile_grid_cap = 0;
     std::vector<void*> fold_bufs;  // first-Dense fold: folded tables + the W^T copy (device)
+    // register-chained DIN tail (k_din_tail); -1 = the tile interpreter runs the tail
+    int din_tail_variant = -1;
+    DinTailRun din_tail_run;
+    float* din_tail_image = nullptr;
     // DIN launch geometry
     int din_ms = 0;
     size_t din_lds_bytes = 0;
@@ -1219,6 +1224,85 @@ int fold_first_dense(sprk_engine* h, DevPlan* dp) {
     return SPRK_OK;
 }
 
+// ---- dispatch table for k_din_tail<N0C, N1C, KPC, WAVES> ----
+constexpr int DT_WAVES = 8;
+typedef void (*DinTailLaunchFn)(const DinTailRun&, const int*, const float*, const float*, float*, int, int*, const float*, int, hipStream_t);
+typedef void (*DinTailPackFn)(const float*, int, int, int, int, int, const float*, const float*, const float*, int, const float*,
+                              const float*, const float*, int, float*);
+template <int N0C, int N1C, int KPC>
+void din_tail_launch(const DinTailRun& a, const int* ids, const float* dense, const float* aux, float* out, int B, int* err,
+                     const float* image, int grid, hipStream_t st) {
+    const size_t lds = DinTailLds<N0C, N1C, KPC>::bytes;
+    hipLaunchKernelGGL((k_din_tail<N0C, N1C, KPC, DT_WAVES>), dim3(grid), dim3(DT_WAVES * 64), lds, st,
+                       a, ids, dense, aux, out, B, err, image);
+}
+template <int N0C, int N1C, int KPC>
+void din_tail_pack(const float* W0, int ldw0, int p_off, int Dp, int n_off, int n_num, const float* b0, const float* a0,
+                   const float* W1, int ldw1, const float* b1, const float* a1, const float* hw, int n_hw, float* img) {
+    hipLaunchKernelGGL((k_din_tail_pack<N0C, N1C, KPC>), dim3(1), dim3(256), 0, 0, W0, ldw0, p_off, Dp, n_off, n_num, b0, a0, W1, ldw1,
+                       b1, a1, hw, n_hw, img);
+}
+struct DinTailVariant {
+    int n0c, n1c, kpc;
+    const void* fn;
+    size_t lds_bytes;
+    DinTailLaunchFn launch;
+    DinTailPackFn pack;
+};
+#define DIN_TAIL_VARIANT(N0C, N1C, KPC) {N0C, N1C, KPC, reinterpret_cast<const void*>(&k_din_tail<N0C, N1C, KPC, DT_WAVES>), \
+                                         DinTailLds<N0C, N1C, KPC>::bytes, &din_tail_launch<N0C, N1C, KPC>, &din_tail_pack<N0C, N1C, KPC>}
+const DinTailVariant kDinTailVariants[] = {
+    DIN_TAIL_VARIANT(8, 4, 2),        // DIN.py:161-167 widths 128 / 64, emb_dim 17..32 (BASELINE config 3)
+    DIN_TAIL_VARIANT(8, 4, 1),        // ... emb_dim <= 16 (the reference's own emb_dim 10)
+};
+
+// Recognise the DIN tail the first-Dense fold left behind (every embedding column folded, fc0 reading only the
+// pooled history + numerics, two PReLU Dense layers, one weighted tap) and set up k_din_tail for it.
+int setup_din_tail(sprk_engine* h, DevPlan* dp) {
+    const char* sw = getenv("SPRK_DIN_TAIL");                // A/B switch: "0" = tile interpreter
+    if (sw && sw[0] == '0') return SPRK_OK;
+    const sprk_plan& p = h->plan;
+    if (!p.din.enabled || p.model_kind != SPRK_MODEL_DIN || dp->n_ops != 2 || dp->n_taps != 1) return SPRK_OK;
+    if (dp->n_acc < 1 || dp->n_acc > DT_MAX_COLS) return SPRK_OK;
+    const DevOp &o0 = dp->ops[0], &o1 = dp->ops[1];
+    if (o0.kind != SPRK_OP_DENSE || o1.kind != SPRK_OP_DENSE || o0.act != SPRK_ACT_PRELU || o1.act != SPRK_ACT_PRELU) return SPRK_OK;
+    if (!o0.acc_init || o0.src_buf != 0 || o0.dst_off != 0 || o1.src_buf != o0.dst_buf || o1.src_off != 0 || o1.K != o0.N ||
+        o1.dst_off != 0) return SPRK_OK;
+    const DevTap& tp = dp->taps[0];
+    if (tp.buf != o1.dst_buf || tp.off != 0 || tp.len > o1.N || !tp.w || tp.scale != 1.0f || tp.bias != 0.0f) return SPRK_OK;
+    int aux_dst = -1, num_dst = -1, n_num = 0, Dp = 0;
+    const int n_plain = dp->n_segs - dp->n_acc;
+    for (int i = 0; i < n_plain; ++i) {
+        const DevSeg& sg = dp->segs[i];
+        if (sg.kind == SPRK_SEG_AUX && aux_dst < 0 && sg.field == 0) { aux_dst = sg.dst; Dp = sg.count; }
+        else if (sg.kind == SPRK_SEG_DENSE && num_dst < 0 && sg.field == 0) { num_dst = sg.dst; n_num = sg.count; }
+        else if (sg.kind != SPRK_SEG_ZERO) return SPRK_OK;     // an unfolded gather remains: leave it to the interpreter
+    }
+    if (aux_dst < 0 || num_dst < 0 || Dp != p.n_aux || n_num < 1 || n_num > 8) return SPRK_OK;
+    const int p_off = aux_dst - o0.src_off, n_off = num_dst - o0.src_off;
+    if (p_off < 0 || p_off + Dp > o0.K || n_off < 0 || n_off + n_num > o0.K) return SPRK_OK;
+    const int n0c = o0.N / 16, n1c = o1.N / 16, kpc = (Dp + 15) / 16;
+    int variant = -1;
+    for (size_t v = 0; v < sizeof(kDinTailVariants) / sizeof(kDinTailVariants[0]); ++v)
+        if (kDinTailVariants[v].n0c == n0c && kDinTailVariants[v].n1c == n1c && kDinTailVariants[v].kpc == kpc) variant = (int)v;
+    if (variant < 0) return SPRK_OK;
+    const DinTailVariant& tv = kDinTailVariants[variant];
+    DinTailRun& r = h->din_tail_run;
+    memset(&r, 0, sizeof(r));
+    r.F = p.n_id_cols; r.ND = p.n_dense; r.NA = p.n_aux; r.n_cols = dp->n_acc; r.n_num = n_num; r.head_bias = dp->head_bias;
+    for (int g = 0; g < dp->n_acc; ++g) {
+        const DevSeg& sg = dp->segs[n_plain + g];
+        r.col[g] = h->idc[sg.field]; r.vocab[g] = sg.vocab; r.Ftab[g] = sg.table;
+    }
+    HIP_TRY(hipMalloc((void**)&h->din_tail_image, tv.lds_bytes));
+    tv.pack(o0.W, o0.ldw, p_off, Dp, n_off, n_num, o0.bias, o0.alpha, o1.W, o1.ldw, o1.bias, o1.alpha, tp.w, tp.len, h->din_tail_image);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipFuncSetAttribute(tv.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tv.lds_bytes));
+    h->din_tail_variant = variant;
+    return SPRK_OK;
+}
+
 int need_bytes(const sprk_engine* h, int slot, size_t bytes, const char* what) {
     if (!h->slot_ptr[slot]) return fail(SPRK_ESTATE, "%s: slot %d was never uploaded", what, slot);
     if (h->slot_bytes[slot] < bytes) return fail(SPRK_EINVAL, "%s: slot %d holds %zu bytes, needs %zu", what, slot, h->slot_bytes[slot], bytes);
@@ -1507,6 +1591,7 @@ int sprk_finalize(sprk_handle h) {
         }
     }
     if (h->v2_variant < 0 && (rc = fold_first_dense(h, dp))) return rc;
+    if (h->v2_variant < 0 && (rc = setup_din_tail(h, dp))) return rc;
     HIP_TRY(hipMalloc((void**)&h->dev_plan, sizeof(DevPlan)));
     HIP_TRY(hipMemcpy(h->dev_plan, dp, sizeof(DevPlan), hipMemcpyHostToDevice));
     HIP_TRY(hipMalloc((void**)&h->dev_err, sizeof(int)));
@@ -1580,6 +1665,14 @@ int sprk_forward(sprk_handle h, const int32_t* ids, const float* dense, float* o
         HIP_TRY(hipGetLastError());
         return SPRK_OK;
     }
+    if (h->din_tail_variant >= 0) {
+        const int ntasks = (B + 15) / 16;
+        int grid = (ntasks + DT_WAVES - 1) / DT_WAVES;
+        if (grid > h->num_cus) grid = h->num_cus;                  // one 8-wave workgroup per CU (2 waves per SIMD)
+        kDinTailVariants[h->din_tail_variant].launch(h->din_tail_run, ids, dense, aux, out, B, h->dev_err, h->din_tail_image, grid, st);
+        HIP_TRY(hipGetLastError());
+        return SPRK_OK;
+    }
     const int ntiles = (B + SPRK_TILE_M - 1) / SPRK_TILE_M;
     const int grid = ntiles < h->tile_grid_cap ? ntiles : h->tile_grid_cap;
     hipLaunchKernelGGL(k_tile_forward, dim3(grid), dim3(256), h->tile_lds_bytes, st, h->dev_plan, ids, dense, aux, out, B, h->dev_err);
@@ -1648,6 +1741,7 @@ void sprk_destroy(sprk_handle h) {
     if (h->v2_folded) (void)hipFree(h->v2_folded);
     if (h->v2j_tab) (void)hipFree(h->v2j_tab);
     for (void* p : h->fold_bufs) if (p) (void)hipFree(p);
+    if (h->din_tail_image) (void)hipFree(h->din_tail_image);
     if (h->v2j_big) (void)hipFree(h->v2j_big);
     if (h->din_w12) (void)hipFree(h->din_w12);
     if (h->din_w4) (void)hipFree(h->din_w4);

@@ -474,15 +474,22 @@ def test_first_dense_fold_matches_unfolded(torch, samples, monkeypatch, name):
         np.testing.assert_allclose(make_model(name).predict(s2)[:, 0], p_missing, atol=TIGHT)
 
 
-def test_din_tail_fold_config3(torch, monkeypatch):
-    B, T, D = 4099, 50, 32
-    feats = SY.synth_din(B, T, SY.ML20M_MOVIE_IDS, SY.ML20M_USER_IDS, seed=21)
+@pytest.mark.parametrize("T,D,B", [(50, 32, 4099), (5, 10, 777), (20, 16, 1), (50, 24, 33)])
+def test_din_tail_paths(torch, monkeypatch, T, D, B):
+    """The three ways the DIN tail (DIN.py:161-167) runs -- k_din_tail (register chained, folded embedding
+    columns), the interpreter with the first-Dense fold, the plain interpreter -- against the fp64 oracle and
+    each other, missing genres (-1) included, ragged batch sizes."""
+    V, U = SY.ML20M_MOVIE_IDS if D == 32 else 4000, SY.ML20M_USER_IDS if D == 32 else 900
+    feats = SY.synth_din(B, T, V, U, seed=21)
     out = {}
-    for fold in ("1", "0"):
-        monkeypatch.setenv("SPRK_TILE_FOLD", fold)
-        model = M.DIN(seed=35, emb_dim=D, hist_len=T, movie_buckets=SY.ML20M_MOVIE_IDS, user_buckets=SY.ML20M_USER_IDS)
-        out[fold] = model.predict(feats)[:, 0]
-    ref = O.din_forward(feats, model.weights, dtype=np.float64, hist_len=T, movie_buckets=SY.ML20M_MOVIE_IDS,
-                        user_buckets=SY.ML20M_USER_IDS)[:, 0]
-    assert np.abs(out["1"] - ref).max() <= TOL and np.abs(out["0"] - ref).max() <= TOL
-    assert np.abs(out["1"] - out["0"]).max() <= TIGHT
+    for tag, env in (("chain", {"SPRK_TILE_FOLD": "1", "SPRK_DIN_TAIL": "1"}), ("fold", {"SPRK_TILE_FOLD": "1", "SPRK_DIN_TAIL": "0"}),
+                     ("plain", {"SPRK_TILE_FOLD": "0", "SPRK_DIN_TAIL": "0"})):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        model = M.DIN(seed=35, emb_dim=D, hist_len=T, movie_buckets=V, user_buckets=U)
+        out[tag] = model.predict(feats)[:, 0]
+    ref = O.din_forward(feats, model.weights, dtype=np.float64, hist_len=T, movie_buckets=V, user_buckets=U)[:, 0]
+    for tag in out:
+        assert np.abs(out[tag] - ref).max() <= TOL, tag
+    assert np.abs(out["chain"] - out["plain"]).max() <= TIGHT
+    assert np.abs(out["fold"] - out["plain"]).max() <= TIGHT
