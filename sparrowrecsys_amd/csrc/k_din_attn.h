@@ -44,7 +44,28 @@ struct DinRun {
     const float* w2;      // [HC*16]
     // HALF: w12 / w4 are pre-multiplied by a_scale; history rows are multiplied by h_scale when they are split
     float h_scale, acc_scale, unscale;    // 2^sH, 2^(sA+sH), 2^-(sA+sH)
+    const float* tsplit;  // HALF: the table pre-split, rows of KP*4 bytes: per q group [hi(EL halfs) | lo(EL halfs)] of E * h_scale
+    float inv_h_scale;    // 2^-sH
 };
+
+// One-time (finalize) kernel for HALF: E[v][d] * scale -> hi/lo halfs in the lane layout of the f16 MFMA's B operand:
+// q group g = d / EL holds [hi(EL) | lo(EL)], EL = KP / 4 elements per lane.
+__global__ __launch_bounds__(256) void k_din_split_table(const float* __restrict__ table, long long vocab, int Dp, int KP,
+                                                         float scale, _Float16* __restrict__ out) {
+    const int EL = KP / 4;
+    const long long total = vocab * KP;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long v = i / KP;
+        const int d = (int)(i - v * KP);
+        const float x = d < Dp ? table[v * Dp + d] * scale : 0.f;
+        const _Float16 hi = (_Float16)x;
+        const _Float16 lo = (_Float16)(x - (float)hi);
+        const int g = d / EL, e = d - g * EL;
+        _Float16* row = out + v * (2 * KP);
+        row[g * 2 * EL + e] = hi;
+        row[g * 2 * EL + EL + e] = lo;
+    }
+}
 
 // One-time (finalize) kernels.
 __global__ __launch_bounds__(256) void k_din_prep_w(const float* __restrict__ W, int hidden, int Dp, int KP,
@@ -109,6 +130,33 @@ typedef _Float16 din_f16x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ f32x4 mfma_f16(din_f16x4 a, din_f16x4 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x16f16(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ f32x4 mfma_f16(din_f16x8 a, din_f16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
 
+// d = a * f16(lo / hi half of the dword `packed`) + c in one VALU instruction (v_fma_mix_f32: per-source f32 / f16
+// selection; hipcc 7.2 emits v_cvt_f32_f16 + v_fma for fmaf(a, (float)half, c) here)
+__device__ __forceinline__ float fma_mix_lo(float a, float packed, float c) {
+    float d;
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[0,1,0]" : "=v"(d) : "v"(a), "v"(packed), "v"(c));
+    return d;
+}
+__device__ __forceinline__ float fma_mix_hi(float a, float packed, float c) {
+    float d;
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[0,1,0]" : "=v"(d) : "v"(a), "v"(packed), "v"(c));
+    return d;
+}
+
+// KC 16-byte pieces holding [hi(EL) | lo(EL)] halfs (EL = 4*KC) -> the two operand vectors
+template <int KC>
+__device__ __forceinline__ void unpack_halfs(const f32x4* x, _Float16 __attribute__((ext_vector_type(4 * KC)))& hi,
+                                             _Float16 __attribute__((ext_vector_type(4 * KC)))& lo) {
+    if constexpr (KC == 2) {
+        hi = __builtin_bit_cast(din_f16x8, x[0]);
+        lo = __builtin_bit_cast(din_f16x8, x[1]);
+    } else {
+        const din_f16x8 both = __builtin_bit_cast(din_f16x8, x[0]);
+        hi = din_f16x4{both[0], both[1], both[2], both[3]};
+        lo = din_f16x4{both[4], both[5], both[6], both[7]};
+    }
+}
+
 template <int KC, int HC>
 struct DinLds {
     static constexpr int KP = KC * 16, HP = HC * 16;
@@ -132,7 +180,7 @@ __global__ __launch_bounds__(256, 2) void k_din_attn(const DinRun A, const int* 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 15, q = lane >> 4;
     const int T = A.T, F = A.F, Dp = A.Dp;
-    const int NV = Dp >> 2;                              // 16-B pieces per table row
+    const int NV = HALF ? KP >> 2 : Dp >> 2;            // 16-B pieces per gathered row (HALF: the pre-split row is KP*4 bytes)
     const int RPP = 64 / NV;                             // rows per gather pass
     const int lrow = lane / NV, piece = lane < RPP * NV ? lane - lrow * NV : 0;
     const int G = (T + 15) >> 4;                         // 16-row groups
@@ -202,9 +250,16 @@ __global__ __launch_bounds__(256, 2) void k_din_attn(const DinRun A, const int* 
     auto issue_rows = [&]() {
         bad |= (unsigned)cid >= (unsigned)A.vocab;
         const unsigned csafe = (unsigned)cid < (unsigned)A.vocab ? (unsigned)cid : 0u;
-        const float* crow = A.table + csafe * (unsigned)Dp;
+        if constexpr (HALF) {
+            // this lane's [hi(EL) | lo(EL)] group of the candidate's pre-split row (KC 16-byte pieces), raw
+            const float* crow = A.tsplit + csafe * (unsigned)KP + EL * q;
 #pragma unroll
-        for (int c = 0; c < KC; ++c) cvn[c] = (kof(c) < Dp) ? ld4(crow + kof(c)) : zero;
+            for (int c = 0; c < KC; ++c) cvn[c] = ld4(crow + 4 * c);
+        } else {
+            const float* crow = A.table + csafe * (unsigned)Dp;
+#pragma unroll
+            for (int c = 0; c < KC; ++c) cvn[c] = (kof(c) < Dp) ? ld4(crow + kof(c)) : zero;
+        }
         const float* vrow = A.vc + csafe * (unsigned)HP;
 #pragma unroll
         for (int nb = 0; nb < HC; ++nb) vcn[nb] = ld4(vrow + nb * 16 + 4 * q);
@@ -212,7 +267,8 @@ __global__ __launch_bounds__(256, 2) void k_din_attn(const DinRun A, const int* 
         for (int p = 0; p < NP; ++p) {
             bad |= (unsigned)hid[p] >= (unsigned)A.vocab;
             const unsigned id = (unsigned)hid[p] < (unsigned)A.vocab ? (unsigned)hid[p] : 0u;
-            v[p] = ld4(A.table + (id * (unsigned)Dp + 4u * (unsigned)piece));   // 32-bit element offset (checked at finalize)
+            v[p] = HALF ? ld4(A.tsplit + (id * (unsigned)KP + 4u * (unsigned)piece))
+                        : ld4(A.table + (id * (unsigned)Dp + 4u * (unsigned)piece));   // 32-bit element offsets (checked at finalize)
         }
     };
     if (s < B) {
@@ -226,8 +282,18 @@ __global__ __launch_bounds__(256, 2) void k_din_attn(const DinRun A, const int* 
         for (int p = 0; p < NP; ++p)
             if (pok[p]) st4(Hs + prow[p] * hs + 4 * piece, v[p]);
         f32x4 cv[KC], acc_init[HC];
+        if constexpr (HALF) {
+            // candidate row back to f32 from its halfs: c[EL*q + e] = (hi + lo) * 2^-sH
+            f16xe chi, clo;
+            unpack_halfs<KC>(cvn, chi, clo);
 #pragma unroll
-        for (int c = 0; c < KC; ++c) cv[c] = cvn[c];
+            for (int c = 0; c < KC; ++c)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) cv[c][j] = ((float)chi[4 * c + j] + (float)clo[4 * c + j]) * A.inv_h_scale;
+        } else {
+#pragma unroll
+            for (int c = 0; c < KC; ++c) cv[c] = cvn[c];
+        }
 #pragma unroll
         for (int nb = 0; nb < HC; ++nb) acc_init[nb] = vcn[nb];
         if (s + stride < B) {                                    // next sample's rows fly under this sample's MFMAs
@@ -266,8 +332,9 @@ __global__ __launch_bounds__(256, 2) void k_din_attn(const DinRun A, const int* 
             f32x4 b0[KC], b1[KC], a0[HC], a1[HC];
 #pragma unroll
             for (int c = 0; c < KC; ++c) {
-                b0[c] = ld4(Hs + (16 * g + r) * hs + kof(c));
-                b1[c] = TWO ? ld4(Hs + (16 * g + 16 + r) * hs + kof(c)) : zero;
+                // (HALF: the tile holds pre-split rows; EL*q + 4c addresses this lane's [hi | lo] group, raw)
+                b0[c] = ld4(Hs + (16 * g + r) * hs + (HALF ? EL * q + 4 * c : kof(c)));
+                b1[c] = TWO ? ld4(Hs + (16 * g + 16 + r) * hs + (HALF ? EL * q + 4 * c : kof(c))) : zero;
             }
             f32x4 al0[HC], al1[HC], be0[HC], be1[HC];            // ca[t][n], cb[t][n] of the rows being scored
 #pragma unroll
@@ -280,22 +347,10 @@ __global__ __launch_bounds__(256, 2) void k_din_attn(const DinRun A, const int* 
                 a1[nb] = acc_init[nb];
             }
             if constexpr (HALF) {
-                // history rows * h_scale -> hi + lo halfs (one v_fma_mixlo/mixhi each), then three products per
-                // (group, n-block): 2*HC (4*HC with TWO) accumulator chains issued round robin
-                f16xe bh0, bl0, bh1, bl1;
-#pragma unroll
-                for (int c = 0; c < KC; ++c)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const float x0 = b0[c][j] * A.h_scale;
-                        const _Float16 h0 = (_Float16)x0;
-                        bh0[4 * c + j] = h0;
-                        bl0[4 * c + j] = (_Float16)(x0 - (float)h0);
-                        const float x1 = b1[c][j] * A.h_scale;
-                        const _Float16 h1 = (_Float16)x1;
-                        bh1[4 * c + j] = h1;
-                        bl1[4 * c + j] = (_Float16)(x1 - (float)h1);
-                    }
+                // three products per (group, n-block): 2*HC (4*HC with TWO) accumulator chains issued round robin
+                f16xe bh0, bl0, bh1, bl1;                          // the gathered bytes ARE the B operands
+                unpack_halfs<KC>(b0, bh0, bl0);
+                unpack_halfs<KC>(b1, bh1, bl1);
 #pragma unroll
                 for (int pr = 0; pr < 3; ++pr) {
 #pragma unroll
@@ -336,8 +391,24 @@ __global__ __launch_bounds__(256, 2) void k_din_attn(const DinRun A, const int* 
                 const float wgt = sigmoidf_fast(rows4_sum(sum) * (HALF ? A.unscale : 1.0f) + A.b2);   // PReLU is positively homogeneous
                 if (q == 0 && att && t < T) att[(size_t)s * T + t] = wgt;
                 // weighted sum pooling (DIN.py:152-158): rows past T are all-zero in the tile, so they add nothing
+                if constexpr (HALF) {
+                    // w[t] * (hi + lo): two mixed-precision FMAs per element straight from the packed halfs
+                    // (element e = 4c + j: KC == 2: hi in dword e/2 of piece 0, lo in dword e/2 of piece 1;
+                    //  KC == 1: hi in dword e/2, lo in dword 2 + e/2 of the one piece)
+                    const f32x4* bb = h ? b1 : b0;
 #pragma unroll
-                for (int c = 0; c < KC; ++c) pacc[c] += wgt * (h ? b1[c] : b0[c]);
+                    for (int e = 0; e < EL; ++e) {
+                        const float hw = KC == 2 ? bb[0][e >> 1] : bb[0][e >> 1];
+                        const float lw = KC == 2 ? bb[KC - 1][e >> 1] : bb[0][2 + (e >> 1)];
+                        float acc = pacc[e >> 2][e & 3];
+                        acc = (e & 1) ? fma_mix_hi(wgt, hw, acc) : fma_mix_lo(wgt, hw, acc);
+                        acc = (e & 1) ? fma_mix_hi(wgt, lw, acc) : fma_mix_lo(wgt, lw, acc);
+                        pacc[e >> 2][e & 3] = acc;
+                    }
+                } else {
+#pragma unroll
+                    for (int c = 0; c < KC; ++c) pacc[c] += wgt * (h ? b1[c] : b0[c]);
+                }
             }
         };
         {
@@ -354,7 +425,7 @@ __global__ __launch_bounds__(256, 2) void k_din_attn(const DinRun A, const int* 
         if (r == 0) {
 #pragma unroll
             for (int c = 0; c < KC; ++c)
-                if (kof(c) < Dp) st4(pooled + (size_t)s * Dp + kof(c), pacc[c]);
+                if (kof(c) < Dp) st4(pooled + (size_t)s * Dp + kof(c), HALF ? pacc[c] * A.inv_h_scale : pacc[c]);
         }
     }
     if (__ballot(bad) != 0 && lane == 0) atomicOr(err, 1);

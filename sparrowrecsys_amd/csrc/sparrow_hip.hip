@@ -667,6 +667,7 @@ struct sprk_engine {
     float* din_w12 = nullptr;      // (W1+W2)^T, W4^T fragments and the per-id c-term table (device)
     float* din_w4 = nullptr;
     float* din_vc = nullptr;
+    float* din_tsplit = nullptr;   // HALF: the movie table pre-split into f16 hi/lo pairs
     size_t din_attn_lds = 0;
     int din_attn_grid_cap = 0;
     // register-chained fast path (k_deepfm_v2_chain); -1 = use the tile interpreter
@@ -1483,8 +1484,8 @@ int sprk_finalize(sprk_handle h) {
             bool want_half = !(hm && hm[0] == '0');
             for (size_t v = 0; v < sizeof(kDinVariants) / sizeof(kDinVariants[0]); ++v) {
                 const DinVariant& dv = kDinVariants[v];
-                if (dv.kc != kc || dv.hc != hc || dv.np * (64 / (s.row_stride / 4)) < s.T) continue;
                 if (dv.half != want_half) continue;
+                if (dv.kc != kc || dv.hc != hc || dv.np * (64 / (dv.half ? kc * 4 : s.row_stride / 4)) < s.T) continue;
                 const int KP = kc * 16;
                 if (!h->din_w12) {
                     HIP_TRY(hipMalloc((void**)&h->din_w12, (size_t)s.hidden * KP * sizeof(float)));
@@ -1517,6 +1518,13 @@ int sprk_finalize(sprk_handle h) {
                     if (bound_a > 0.f) { (void)frexpf(bound_a, &e); e = 15 - e; if (e > 60) e = 60; if (e < -60) e = -60; a_scale = ldexpf(1.f, e); }
                     hipLaunchKernelGGL(k_din_prep_w, dim3(8), dim3(256), 0, 0, d.W, s.hidden, s.row_stride, KP, a_scale, h->din_w12, h->din_w4);
                     HIP_TRY(hipGetLastError());
+                    if ((size_t)s.vocab * KP * sizeof(float) >= ((size_t)4 << 30)) { want_half = false; v = (size_t)-1; continue; }
+                    if (!h->din_tsplit) HIP_TRY(hipMalloc((void**)&h->din_tsplit, (size_t)s.vocab * KP * sizeof(float) + 16));
+                    long long sb = ((long long)s.vocab * KP + 255) / 256;
+                    if (sb > 65536) sb = 65536;
+                    hipLaunchKernelGGL(k_din_split_table, dim3((unsigned)sb), dim3(256), 0, 0, d.table, (long long)s.vocab, s.row_stride, KP,
+                                       h_scale, reinterpret_cast<_Float16*>(h->din_tsplit));
+                    HIP_TRY(hipGetLastError());
                 }
                 long long blocks = ((long long)s.vocab * s.hidden + 255) / 256;
                 if (blocks > 65536) blocks = 65536;
@@ -1527,6 +1535,7 @@ int sprk_finalize(sprk_handle h) {
                 DinRun& r = h->din_run;
                 r.T = s.T; r.F = p.n_id_cols; r.hist_col = s.hist_col; r.cand_col = s.cand_col; r.Dp = s.row_stride; r.vocab = s.vocab;
                 r.h_scale = h_scale; r.acc_scale = a_scale * h_scale; r.unscale = 1.0f / (a_scale * h_scale);
+                r.tsplit = h->din_tsplit; r.inv_h_scale = 1.0f / h_scale;
                 r.b2 = s.b2; r.table = d.table; r.w12 = h->din_w12; r.w4 = h->din_w4; r.vc = h->din_vc; r.alpha = d.alpha; r.w2 = d.w2;
                 HIP_TRY(hipFuncSetAttribute(dv.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dv.lds_bytes));
                 int wgs = (int)(160 * 1024 / dv.lds_bytes);
@@ -1746,6 +1755,7 @@ void sprk_destroy(sprk_handle h) {
     if (h->din_w12) (void)hipFree(h->din_w12);
     if (h->din_w4) (void)hipFree(h->din_w4);
     if (h->din_vc) (void)hipFree(h->din_vc);
+    if (h->din_tsplit) (void)hipFree(h->din_tsplit);
     if (h->dev_err) (void)hipFree(h->dev_err);
     delete h;
 }
