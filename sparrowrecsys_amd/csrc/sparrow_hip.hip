@@ -608,6 +608,7 @@ __global__ __launch_bounds__(256) void k_zero_columns(float* __restrict__ Wt, in
 #include "k_chain_v2j.h"
 #include "k_din_attn.h"
 #include "k_din_tail.h"
+#include "k_chain_v1.h"
 
 // ---------------------------------------------------------------------------------------------
 // stand-alone operators
@@ -653,6 +654,10 @@ struct sprk_engine {
     std::vector<int> idc;          // ids columns read by the gather segments (compact staging order)
     int tile_grid_cap = 0;
     std::vector<void*> fold_bufs;  // first-Dense fold: folded tables + the W^T copy (device)
+    // register-chained pairwise-dot DeepFM (k_deepfm_pairs); -1 = the tile interpreter
+    int v1_variant = -1;
+    V1Run v1_run;
+    std::vector<void*> v1_bufs;
     // register-chained DIN tail (k_din_tail); -1 = the tile interpreter runs the tail
     int din_tail_variant = -1;
     DinTailRun din_tail_run;
@@ -1225,6 +1230,136 @@ int fold_first_dense(sprk_engine* h, DevPlan* dp) {
     return SPRK_OK;
 }
 
+// ---- dispatch table for k_deepfm_pairs<NF, NV, H0C, H1C, WAVES> ----
+constexpr int V1_WAVES = 8;
+typedef void (*V1LaunchFn)(const V1Run&, const int*, const float*, float*, int, int*, int, hipStream_t);
+template <int NF, int NV>
+void v1_launch(const V1Run& a, const int* ids, const float* dense, float* out, int B, int* err, int grid, hipStream_t st) {
+    hipLaunchKernelGGL((k_deepfm_pairs<NF, NV, 4, 4, V1_WAVES>), dim3(grid), dim3(V1_WAVES * 64), 0, st, a, ids, dense, out, B, err);
+}
+struct V1Variant { int nf, nv; V1LaunchFn launch; };
+const V1Variant kV1Variants[] = {
+    {6, 4, &v1_launch<6, 4>},         // BASELINE config 2: 6 fields, emb_dim 16, deep 64-64
+    {4, 3, &v1_launch<4, 3>},         // the reference's own DeepFM.py: 4 fields, emb_dim 10 (rows padded to 12)
+    {4, 4, &v1_launch<4, 4>},
+};
+
+// Recognise the plan models.DeepFM emits (DeepFM.py graph: pair dots + first order + 2-layer deep part) and set up
+// k_deepfm_pairs for it.  Leaves v1_variant = -1 (tile interpreter) for any other shape.
+int setup_deepfm_pairs(sprk_engine* h) {
+    const char* sw = getenv("SPRK_V1_CHAIN");                 // A/B switch: "0" = tile interpreter
+    if (sw && sw[0] == '0') return SPRK_OK;
+    const sprk_plan& p = h->plan;
+    if (p.model_kind != SPRK_MODEL_DEEPFM || p.din.enabled || p.n_ops != 3 || p.n_taps != 3 || p.n_pairs < 1) return SPRK_OK;
+    const sprk_op &od = p.ops[0], &o0 = p.ops[1], &o1 = p.ops[2];
+    if (od.kind != SPRK_OP_PAIR_DOT || od.src_buf != 0 || od.dst_buf != 0) return SPRK_OK;
+    if (o0.kind != SPRK_OP_DENSE || o0.act != SPRK_ACT_RELU || o0.src_buf != 0 || o0.dst_buf != 1 || o0.dst_off != 0 || o0.N != 64) return SPRK_OK;
+    if (o1.kind != SPRK_OP_DENSE || o1.act != SPRK_ACT_RELU || o1.src_buf != 1 || o1.src_off != 0 || o1.K != o0.N || o1.dst_off != 0 || o1.N != 64) return SPRK_OK;
+    V1Run r;
+    memset(&r, 0, sizeof(r));
+    int row_dst[V1_MAX_FIELDS], nf = 0, Dp = 0, num_dst = -1, scal_dst[V1_MAX_FIELDS], ns = 0, scal_col[V1_MAX_FIELDS], scal_vocab[V1_MAX_FIELDS];
+    const float* scal_tab[V1_MAX_FIELDS];
+    for (int i = 0; i < p.n_segs; ++i) {
+        const sprk_seg& sg = p.segs[i];
+        if (sg.kind == SPRK_SEG_ROWS) {
+            if (nf == V1_MAX_FIELDS) return SPRK_OK;
+            if (nf == 0) Dp = sg.row_stride;
+            if (sg.row_stride != Dp || sg.count * 4 != Dp || Dp > 16) return SPRK_OK;
+            if (h->slot_bytes[sg.slot] < ((size_t)sg.vocab + 1) * Dp * sizeof(float)) return SPRK_OK;   // needs the zero row at index vocab
+            r.col[nf] = sg.field; r.vocab[nf] = sg.vocab; r.table[nf] = (const float*)h->slot_ptr[sg.slot];
+            row_dst[nf++] = sg.dst;
+        } else if (sg.kind == SPRK_SEG_SCALAR) {
+            if (ns == V1_MAX_FIELDS) return SPRK_OK;
+            if (h->slot_bytes[sg.slot] < ((size_t)sg.vocab + 1) * sizeof(float)) return SPRK_OK;
+            scal_col[ns] = sg.field; scal_vocab[ns] = sg.vocab; scal_tab[ns] = (const float*)h->slot_ptr[sg.slot]; scal_dst[ns++] = sg.dst;
+        } else if (sg.kind == SPRK_SEG_DENSE) {
+            if (num_dst >= 0 || sg.field != 0 || sg.count > 8) return SPRK_OK;
+            num_dst = sg.dst; r.n_num = sg.count;
+        } else if (sg.kind != SPRK_SEG_ZERO) {
+            return SPRK_OK;
+        }
+    }
+    if (nf < 2 || ns != nf || num_dst < 0 || r.n_num < 1) return SPRK_OK;
+    for (int f = 0; f < nf; ++f) {                            // first-order table of the same ids column
+        int hit = -1;
+        for (int i = 0; i < ns; ++i) if (scal_col[i] == r.col[f] && scal_vocab[i] == r.vocab[f]) hit = i;
+        if (hit < 0) return SPRK_OK;
+        r.w1[f] = scal_tab[hit];
+    }
+    int smin = scal_dst[0];
+    for (int i = 1; i < ns; ++i) if (scal_dst[i] < smin) smin = scal_dst[i];
+    // taps: first order (all ones), pair dots (weights), deep output (weights)
+    const sprk_tap *tf = nullptr, *tpair = nullptr, *tdeep = nullptr;
+    for (int t = 0; t < 3; ++t) {
+        const sprk_tap& tp = p.taps[t];
+        if (tp.scale != 1.0f || tp.bias != 0.0f) return SPRK_OK;
+        if (tp.buf == 0 && tp.off == smin && tp.len == ns && tp.w_slot < 0) tf = &tp;
+        else if (tp.buf == 0 && tp.off == od.dst_off && tp.len == p.n_pairs && tp.w_slot >= 0) tpair = &tp;
+        else if (tp.buf == o1.dst_buf && tp.off == 0 && tp.len <= o1.N && tp.w_slot >= 0) tdeep = &tp;
+    }
+    if (!tf || !tpair || !tdeep) return SPRK_OK;
+    for (int i = 0; i < ns; ++i) if (scal_dst[i] < smin || scal_dst[i] >= smin + ns) return SPRK_OK;
+    // pairs -> (field a, field b) x head weight
+    std::vector<float> pwh(p.n_pairs);
+    HIP_TRY(hipMemcpy(pwh.data(), h->slot_ptr[tpair->w_slot], p.n_pairs * sizeof(float), hipMemcpyDeviceToHost));
+    for (int i = 0; i < p.n_pairs; ++i) {
+        int a = -1, b = -1;
+        for (int f = 0; f < nf; ++f) { if (row_dst[f] == p.pair_a[i]) a = f; if (row_dst[f] == p.pair_b[i]) b = f; }
+        if (a < 0 || b < 0 || a == b || od.K != Dp) return SPRK_OK;
+        if (a > b) { const int t = a; a = b; b = t; }
+        r.pw[a * V1_MAX_FIELDS + b] += pwh[i];
+    }
+    // deep part: embedding columns inside deep0's input slice are folded, the numerics go through the matrix pipe
+    const int s0 = o0.src_off, s1 = o0.src_off + o0.K;
+    if (num_dst < s0 || num_dst + r.n_num > s1) return SPRK_OK;
+    for (int f = 0; f < nf; ++f) {
+        if (row_dst[f] >= s0 && row_dst[f] + Dp <= s1) {
+            if (r.n_deep == V1_MAX_DEEP) return SPRK_OK;
+            r.deep_field[r.n_deep++] = f;
+        } else if (row_dst[f] < s1 && row_dst[f] + Dp > s0) {
+            return SPRK_OK;
+        }
+    }
+    int variant = -1;
+    for (size_t v = 0; v < sizeof(kV1Variants) / sizeof(kV1Variants[0]); ++v)
+        if (kV1Variants[v].nf == nf && kV1Variants[v].nv == Dp / 4) variant = (int)v;
+    if (variant < 0) return SPRK_OK;
+    const int H0 = o0.N, H1 = o1.N;
+    const float* W0 = (const float*)h->slot_ptr[o0.w_slot];
+    for (int g = 0; g < r.n_deep; ++g) {
+        const int f = r.deep_field[g];
+        float* Fd = nullptr;
+        const long long rows = (long long)r.vocab[f] + 1;
+        HIP_TRY(hipMalloc((void**)&Fd, (size_t)rows * H0 * sizeof(float) + 16));
+        h->v1_bufs.push_back(Fd);
+        long long blocks = (rows * H0 + 255) / 256;
+        if (blocks > 65536) blocks = 65536;
+        hipLaunchKernelGGL(k_fold_dense_rows, dim3((unsigned)blocks), dim3(256), 0, 0, r.table[f], rows, Dp, Dp, W0, o0.ldw,
+                           row_dst[f] - s0, H0, Fd);
+        HIP_TRY(hipGetLastError());
+        r.Fdeep[g] = Fd;
+    }
+    for (int g = r.n_deep; g < V1_MAX_DEEP; ++g) { r.deep_field[g] = 0; r.Fdeep[g] = r.Fdeep[0]; }
+    float* wn = nullptr;
+    HIP_TRY(hipMalloc((void**)&wn, (size_t)H0 * 8 * sizeof(float) + 16));
+    h->v1_bufs.push_back(wn);
+    hipLaunchKernelGGL(k_v1_pack_wn, dim3(1), dim3(256), 0, 0, W0, o0.ldw, num_dst - s0, r.n_num, H0, wn);
+    HIP_TRY(hipGetLastError());
+    float* hd = nullptr;
+    HIP_TRY(hipMalloc((void**)&hd, (size_t)H1 * sizeof(float) + 16));
+    h->v1_bufs.push_back(hd);
+    HIP_TRY(hipMemset(hd, 0, (size_t)H1 * sizeof(float)));
+    HIP_TRY(hipMemcpy(hd, h->slot_ptr[tdeep->w_slot], (size_t)tdeep->len * sizeof(float), hipMemcpyDeviceToDevice));
+    HIP_TRY(hipDeviceSynchronize());
+    r.F = p.n_id_cols; r.ND = p.n_dense; r.nf = nf; r.row_floats = Dp;
+    r.wn = wn; r.b0 = (const float*)h->slot_ptr[o0.b_slot];
+    r.W1 = (const float*)h->slot_ptr[o1.w_slot]; r.ld1 = o1.ldw; r.b1 = (const float*)h->slot_ptr[o1.b_slot];
+    r.hdeep = hd; r.head_bias = p.head_bias;
+    h->v1_run = r;
+    h->v1_variant = variant;
+    return SPRK_OK;
+}
+
 // ---- dispatch table for k_din_tail<N0C, N1C, KPC, WAVES> ----
 constexpr int DT_WAVES = 8;
 typedef void (*DinTailLaunchFn)(const DinTailRun&, const int*, const float*, const float*, float*, int, int*, const float*, int, hipStream_t);
@@ -1599,7 +1734,8 @@ int sprk_finalize(sprk_handle h) {
             HIP_TRY(hipDeviceSynchronize());
         }
     }
-    if (h->v2_variant < 0 && (rc = fold_first_dense(h, dp))) return rc;
+    if (h->v2_variant < 0 && (rc = setup_deepfm_pairs(h))) return rc;
+    if (h->v2_variant < 0 && h->v1_variant < 0 && (rc = fold_first_dense(h, dp))) return rc;
     if (h->v2_variant < 0 && (rc = setup_din_tail(h, dp))) return rc;
     HIP_TRY(hipMalloc((void**)&h->dev_plan, sizeof(DevPlan)));
     HIP_TRY(hipMemcpy(h->dev_plan, dp, sizeof(DevPlan), hipMemcpyHostToDevice));
@@ -1671,6 +1807,14 @@ int sprk_forward(sprk_handle h, const int32_t* ids, const float* dense, float* o
             return SPRK_OK;
         }
         (run.trace ? vv.launch_trace : vv.launch)(run, ids, dense, out, B, h->dev_err, h->v2_image, grid, h->v2_lds_bytes, st);
+        HIP_TRY(hipGetLastError());
+        return SPRK_OK;
+    }
+    if (h->v1_variant >= 0) {
+        const int ntasks = (B + 15) / 16;
+        int grid = (ntasks + V1_WAVES - 1) / V1_WAVES;
+        if (grid > h->num_cus) grid = h->num_cus;                  // one 8-wave workgroup per CU (2 waves per SIMD)
+        kV1Variants[h->v1_variant].launch(h->v1_run, ids, dense, out, B, h->dev_err, grid, st);
         HIP_TRY(hipGetLastError());
         return SPRK_OK;
     }
@@ -1751,6 +1895,7 @@ void sprk_destroy(sprk_handle h) {
     if (h->v2j_tab) (void)hipFree(h->v2j_tab);
     for (void* p : h->fold_bufs) if (p) (void)hipFree(p);
     if (h->din_tail_image) (void)hipFree(h->din_tail_image);
+    for (void* p : h->v1_bufs) if (p) (void)hipFree(p);
     if (h->v2j_big) (void)hipFree(h->v2j_big);
     if (h->din_w12) (void)hipFree(h->din_w12);
     if (h->din_w4) (void)hipFree(h->din_w4);

@@ -493,3 +493,59 @@ def test_din_tail_paths(torch, monkeypatch, T, D, B):
         assert np.abs(out[tag] - ref).max() <= TOL, tag
     assert np.abs(out["chain"] - out["plain"]).max() <= TIGHT
     assert np.abs(out["fold"] - out["plain"]).max() <= TIGHT
+
+
+# --------------------------------------------------------------------------------------------
+# k_deepfm_pairs: the pairwise-dot DeepFM graph (DeepFM.py) as a register-chained kernel
+# --------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("shape", ["reference", "config2", "config2-zipf-ragged"])
+def test_deepfm_pairs_kernel_vs_interpreter_and_oracle(torch, monkeypatch, shape):
+    if shape == "reference":
+        fields, pairs, D, B, dist = None, None, 10, 2049, "uniform"       # DeepFM.py literals: 4 fields, 4 pairs, emb_dim 10
+        feats = SY.synth_fields(B, M._default_fields(), seed=71)
+    else:
+        fields, pairs, D = SY.CONFIG2_FIELDS, SY.CONFIG2_PAIRS, 16
+        B, dist = (16384, "uniform") if shape == "config2" else (10007, "zipf")
+        feats = SY.synth_fields(B, fields, seed=72, dist=dist)
+    out = {}
+    for chain in ("1", "0"):
+        monkeypatch.setenv("SPRK_V1_CHAIN", chain)
+        model = M.DeepFM(seed=46, emb_dim=D, fields=fields, pairs=pairs)
+        out[chain] = model.predict(feats)[:, 0]
+    kw = {} if fields is None else {"fields": fields, "pairs": pairs}
+    ref = O.deepfm_forward(feats, model.weights, dtype=np.float64, **kw)[:, 0]
+    assert np.abs(out["1"] - ref).max() <= TIGHT
+    assert np.abs(out["0"] - ref).max() <= TIGHT
+    assert 0.02 < ref.std()
+
+
+def test_deepfm_pairs_kernel_properties(torch):
+    """Determinism, slice invariance (ragged tails), missing ids = zero rows, out-of-range ids raise."""
+    B = 5000
+    feats = SY.synth_fields(B, SY.CONFIG2_FIELDS, seed=73)
+    model = M.DeepFM(seed=47, emb_dim=16, fields=SY.CONFIG2_FIELDS, pairs=SY.CONFIG2_PAIRS)
+    ids, dense = model.pack(feats)
+    ti, td = _cuda(torch, ids), _cuda(torch, dense)
+    p = model.predict_device(ti, td)
+    assert torch.equal(p, model.predict_device(ti, td))
+    for lo, hi in ((0, 1), (3, 20), (100, 1133), (4990, 5000)):
+        assert torch.equal(model.predict_device(ti[lo:hi].contiguous(), td[lo:hi].contiguous()), p[lo:hi])
+    # a missing genre (-1) must equal a zero embedding row and zero first-order weight
+    col = [k for k, _, _ in SY.CONFIG2_FIELDS].index("userGenre1")
+    ids2 = ids.copy()
+    ids2[:, col] = -1
+    w = dict(model.weights)
+    w["emb/userGenre1"] = np.zeros_like(w["emb/userGenre1"])
+    fo = M.first_order_offsets(SY.CONFIG2_FIELDS)
+    hk = w["head/kernel"].copy()
+    hk[fo["userGenre1"]:fo["userGenre1"] + 19] = 0
+    w["head/kernel"] = hk
+    zeroed = M.DeepFM(weights=w, emb_dim=16, fields=SY.CONFIG2_FIELDS, pairs=SY.CONFIG2_PAIRS)
+    got = model.predict_device(_cuda(torch, ids2), td).cpu().numpy()
+    want = zeroed.predict_device(ti, td).cpu().numpy()
+    assert np.abs(got - want).max() <= 1e-6
+    bad = ids.copy()
+    bad[17, 0] = SY.ML20M_MOVIE_IDS + 3
+    model.predict_device(_cuda(torch, bad), td)
+    with pytest.raises(ValueError):
+        model.engine.check_ids()
