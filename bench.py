@@ -47,7 +47,8 @@ def build_workload(name, B, dist_name, seed_offset=0):
         v2_kernel = "k_deepfm_v2_chain" if (os.environ.get("SPRK_V2_JOINT") == "0" or os.environ.get("SPRK_V2_FOLD") == "0") else "k_deepfm_v2_joint"
         if os.environ.get("SPRK_FORCE_INTERPRETER") == "1":
             v2_kernel = "k_tile_forward"
-        roof = {"bound": "hbm", "kernel": v2_kernel if name == "deepfm_v2_c2" else "k_tile_forward",
+        v1_kernel = "k_tile_forward" if os.environ.get("SPRK_V1_CHAIN") == "0" else "k_deepfm_pairs"
+        roof = {"bound": "hbm", "kernel": v2_kernel if name == "deepfm_v2_c2" else v1_kernel,
                 "bytes_per_sample": bytes_per_sample}
     elif name == "din_c3":
         T, D = 50, 32

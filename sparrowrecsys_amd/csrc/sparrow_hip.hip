@@ -1235,7 +1235,8 @@ constexpr int V1_WAVES = 8;
 typedef void (*V1LaunchFn)(const V1Run&, const int*, const float*, float*, int, int*, int, hipStream_t);
 template <int NF, int NV>
 void v1_launch(const V1Run& a, const int* ids, const float* dense, float* out, int B, int* err, int grid, hipStream_t st) {
-    hipLaunchKernelGGL((k_deepfm_pairs<NF, NV, 4, 4, V1_WAVES>), dim3(grid), dim3(V1_WAVES * 64), 0, st, a, ids, dense, out, B, err);
+    const size_t lds = V1Lds<4, 4>::bytes;
+    hipLaunchKernelGGL((k_deepfm_pairs<NF, NV, 4, 4, V1_WAVES>), dim3(grid), dim3(V1_WAVES * 64), lds, st, a, ids, dense, out, B, err);
 }
 struct V1Variant { int nf, nv; V1LaunchFn launch; };
 const V1Variant kV1Variants[] = {
@@ -1309,16 +1310,42 @@ int setup_deepfm_pairs(sprk_engine* h) {
         if (a > b) { const int t = a; a = b; b = t; }
         r.pw[a * V1_MAX_FIELDS + b] += pwh[i];
     }
-    // deep part: embedding columns inside deep0's input slice are folded, the numerics go through the matrix pipe
+    // deep part: the embedding columns inside deep0's input slice (at most V1_MAX_DEEP) become fields 0.. of the kernel
     const int s0 = o0.src_off, s1 = o0.src_off + o0.K;
     if (num_dst < s0 || num_dst + r.n_num > s1) return SPRK_OK;
+    int order[V1_MAX_FIELDS], no = 0, deep_off[V1_MAX_DEEP] = {0, 0};
     for (int f = 0; f < nf; ++f) {
         if (row_dst[f] >= s0 && row_dst[f] + Dp <= s1) {
             if (r.n_deep == V1_MAX_DEEP) return SPRK_OK;
-            r.deep_field[r.n_deep++] = f;
+            deep_off[r.n_deep++] = row_dst[f] - s0;
+            order[no++] = f;
         } else if (row_dst[f] < s1 && row_dst[f] + Dp > s0) {
             return SPRK_OK;
         }
+    }
+    for (int f = 0; f < nf; ++f) {
+        bool deep = false;
+        for (int i = 0; i < r.n_deep; ++i) deep |= order[i] == f;
+        if (!deep) order[no++] = f;
+    }
+    {
+        V1Run t = r;
+        int inv[V1_MAX_FIELDS];
+        for (int i = 0; i < nf; ++i) {
+            const int f = order[i];
+            inv[f] = i;
+            t.col[i] = r.col[f]; t.vocab[i] = r.vocab[f]; t.table[i] = r.table[f]; t.w1[i] = r.w1[f];
+        }
+        memset(t.pw, 0, sizeof(t.pw));
+        for (int a = 0; a < nf; ++a)
+            for (int b = a + 1; b < nf; ++b) {
+                const float w = r.pw[a * V1_MAX_FIELDS + b];
+                if (w == 0.f) continue;
+                int x = inv[a], y = inv[b];
+                if (x > y) { const int tt = x; x = y; y = tt; }
+                t.pw[x * V1_MAX_FIELDS + y] += w;
+            }
+        r = t;
     }
     int variant = -1;
     for (size_t v = 0; v < sizeof(kV1Variants) / sizeof(kV1Variants[0]); ++v)
@@ -1326,24 +1353,11 @@ int setup_deepfm_pairs(sprk_engine* h) {
     if (variant < 0) return SPRK_OK;
     const int H0 = o0.N, H1 = o1.N;
     const float* W0 = (const float*)h->slot_ptr[o0.w_slot];
-    for (int g = 0; g < r.n_deep; ++g) {
-        const int f = r.deep_field[g];
-        float* Fd = nullptr;
-        const long long rows = (long long)r.vocab[f] + 1;
-        HIP_TRY(hipMalloc((void**)&Fd, (size_t)rows * H0 * sizeof(float) + 16));
-        h->v1_bufs.push_back(Fd);
-        long long blocks = (rows * H0 + 255) / 256;
-        if (blocks > 65536) blocks = 65536;
-        hipLaunchKernelGGL(k_fold_dense_rows, dim3((unsigned)blocks), dim3(256), 0, 0, r.table[f], rows, Dp, Dp, W0, o0.ldw,
-                           row_dst[f] - s0, H0, Fd);
-        HIP_TRY(hipGetLastError());
-        r.Fdeep[g] = Fd;
-    }
-    for (int g = r.n_deep; g < V1_MAX_DEEP; ++g) { r.deep_field[g] = 0; r.Fdeep[g] = r.Fdeep[0]; }
-    float* wn = nullptr;
-    HIP_TRY(hipMalloc((void**)&wn, (size_t)H0 * 8 * sizeof(float) + 16));
-    h->v1_bufs.push_back(wn);
-    hipLaunchKernelGGL(k_v1_pack_wn, dim3(1), dim3(256), 0, 0, W0, o0.ldw, num_dst - s0, r.n_num, H0, wn);
+    float* w0p = nullptr;
+    HIP_TRY(hipMalloc((void**)&w0p, (size_t)H0 * 16 * (V1_MAX_DEEP + 1) * sizeof(float) + 16));
+    h->v1_bufs.push_back(w0p);
+    hipLaunchKernelGGL(k_v1_pack_w0, dim3(1), dim3(256), 0, 0, W0, o0.ldw, r.n_deep, deep_off[0], deep_off[1], Dp, num_dst - s0, r.n_num,
+                       H0, w0p);
     HIP_TRY(hipGetLastError());
     float* hd = nullptr;
     HIP_TRY(hipMalloc((void**)&hd, (size_t)H1 * sizeof(float) + 16));
@@ -1352,7 +1366,7 @@ int setup_deepfm_pairs(sprk_engine* h) {
     HIP_TRY(hipMemcpy(hd, h->slot_ptr[tdeep->w_slot], (size_t)tdeep->len * sizeof(float), hipMemcpyDeviceToDevice));
     HIP_TRY(hipDeviceSynchronize());
     r.F = p.n_id_cols; r.ND = p.n_dense; r.nf = nf; r.row_floats = Dp;
-    r.wn = wn; r.b0 = (const float*)h->slot_ptr[o0.b_slot];
+    r.w0 = w0p; r.b0 = (const float*)h->slot_ptr[o0.b_slot];
     r.W1 = (const float*)h->slot_ptr[o1.w_slot]; r.ld1 = o1.ldw; r.b1 = (const float*)h->slot_ptr[o1.b_slot];
     r.hdeep = hd; r.head_bias = p.head_bias;
     h->v1_run = r;
@@ -1813,7 +1827,7 @@ int sprk_forward(sprk_handle h, const int32_t* ids, const float* dense, float* o
     if (h->v1_variant >= 0) {
         const int ntasks = (B + 15) / 16;
         int grid = (ntasks + V1_WAVES - 1) / V1_WAVES;
-        if (grid > h->num_cus) grid = h->num_cus;                  // one 8-wave workgroup per CU (2 waves per SIMD)
+        if (grid > h->num_cus) grid = h->num_cus;                  // one 8-wave workgroup per CU (2 waves per SIMD; 3 per SIMD measured slower at B = 65 536)
         kV1Variants[h->v1_variant].launch(h->v1_run, ids, dense, out, B, h->dev_err, grid, st);
         HIP_TRY(hipGetLastError());
         return SPRK_OK;
