@@ -654,6 +654,11 @@ struct sprk_engine {
     std::vector<int> idc;          // ids columns read by the gather segments (compact staging order)
     int tile_grid_cap = 0;
     std::vector<void*> fold_bufs;  // first-Dense fold: folded tables + the W^T copy (device)
+    // sprk_forward_many fan-out: independent batches alternate over helper streams (hardware queues), so that one
+    // kernel's dispatch / drain (3.3 us even for an empty kernel in a dependent launch chain) overlaps its neighbours
+    int many_streams = 0;
+    hipStream_t many_stream[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t many_fork = nullptr, many_join[4] = {nullptr, nullptr, nullptr, nullptr};
     // register-chained pairwise-dot DeepFM (k_deepfm_pairs); -1 = the tile interpreter
     int v1_variant = -1;
     V1Run v1_run;
@@ -1755,6 +1760,19 @@ int sprk_finalize(sprk_handle h) {
     HIP_TRY(hipMemcpy(h->dev_plan, dp, sizeof(DevPlan), hipMemcpyHostToDevice));
     HIP_TRY(hipMalloc((void**)&h->dev_err, sizeof(int)));
     HIP_TRY(hipMemset(h->dev_err, 0, sizeof(int)));
+    {
+        const char* ms = getenv("SPRK_MANY_STREAMS");          // 0 / 1 = strict stream order (default), 2..4 = fan out
+        int n = ms ? atoi(ms) : 0;
+        if (n > 4) n = 4;
+        if (n >= 2 && !p.din.enabled) {                        // a DIN forward is two dependent kernels sharing the workspace
+            HIP_TRY(hipEventCreateWithFlags(&h->many_fork, hipEventDisableTiming));
+            for (int i = 0; i < n; ++i) {
+                HIP_TRY(hipStreamCreateWithFlags(&h->many_stream[i], hipStreamNonBlocking));
+                HIP_TRY(hipEventCreateWithFlags(&h->many_join[i], hipEventDisableTiming));
+            }
+            h->many_streams = n;
+        }
+    }
     h->finalized = true;
     return SPRK_OK;
 }
@@ -1852,10 +1870,21 @@ int sprk_forward_many(sprk_handle h, int32_t n_batches, const int32_t* const* id
     if (!h) return fail(SPRK_EINVAL, "handle is NULL");
     if (n_batches < 0) return fail(SPRK_EINVAL, "negative batch count");
     if (n_batches > 0 && !out) return fail(SPRK_EINVAL, "out is NULL");
+    const int S = (h->finalized && n_batches > 1) ? h->many_streams : 0;
+    if (S >= 2) {
+        HIP_TRY(hipEventRecord(h->many_fork, (hipStream_t)stream));
+        for (int s = 0; s < S; ++s) HIP_TRY(hipStreamWaitEvent(h->many_stream[s], h->many_fork, 0));
+    }
     for (int32_t i = 0; i < n_batches; ++i) {
         const int rc = sprk_forward(h, ids ? ids[i] : nullptr, dense ? dense[i] : nullptr, out[i], B, workspace,
-                                    workspace_bytes, stream);
+                                    workspace_bytes, S >= 2 ? (void*)h->many_stream[i % S] : stream);
         if (rc) return rc;
+    }
+    if (S >= 2) {
+        for (int s = 0; s < S; ++s) {
+            HIP_TRY(hipEventRecord(h->many_join[s], h->many_stream[s]));
+            HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, h->many_join[s], 0));
+        }
     }
     return SPRK_OK;
 }
@@ -1908,6 +1937,8 @@ void sprk_destroy(sprk_handle h) {
     if (h->v2_folded) (void)hipFree(h->v2_folded);
     if (h->v2j_tab) (void)hipFree(h->v2j_tab);
     for (void* p : h->fold_bufs) if (p) (void)hipFree(p);
+    for (int i = 0; i < 4; ++i) { if (h->many_stream[i]) (void)hipStreamDestroy(h->many_stream[i]); if (h->many_join[i]) (void)hipEventDestroy(h->many_join[i]); }
+    if (h->many_fork) (void)hipEventDestroy(h->many_fork);
     if (h->din_tail_image) (void)hipFree(h->din_tail_image);
     for (void* p : h->v1_bufs) if (p) (void)hipFree(p);
     if (h->v2j_big) (void)hipFree(h->v2j_big);

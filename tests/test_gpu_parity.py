@@ -549,3 +549,24 @@ def test_deepfm_pairs_kernel_properties(torch):
     model.predict_device(_cuda(torch, bad), td)
     with pytest.raises(ValueError):
         model.engine.check_ids()
+
+
+def test_forward_many_fan_out_over_streams(torch, monkeypatch):
+    """SPRK_MANY_STREAMS=2: sprk_forward_many alternates independent batches over two helper streams (forked from and
+    joined back into the caller's stream); results equal the strictly ordered run bit for bit."""
+    B, n = 4099, 7
+    feats = [SY.synth_fields(B, SY.CONFIG2_FIELDS, seed=80 + i) for i in range(n)]
+    res = {}
+    for streams in ("0", "2"):
+        monkeypatch.setenv("SPRK_MANY_STREAMS", streams)
+        model = M.DeepFMv2(seed=48, emb_dim=16, fields=SY.CONFIG2_FIELDS, proj_dim=16)
+        packed = [model.pack(f) for f in feats]
+        ids = [_cuda(torch, p[0]) for p in packed]
+        dense = [_cuda(torch, p[1]) for p in packed]
+        outs = [torch.full((B,), -1.0, dtype=torch.float32, device="cuda") for _ in range(n)]
+        model.engine.forward_many(ids, dense, outs)
+        torch.cuda.current_stream().synchronize()            # the join makes the caller's stream wait for every helper stream
+        model.engine.check_ids()
+        res[streams] = [o.cpu().numpy() for o in outs]
+    for a, b in zip(res["0"], res["2"]):
+        np.testing.assert_array_equal(a, b)
