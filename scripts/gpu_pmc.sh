@@ -37,7 +37,7 @@ for d in sorted(glob.glob('gpurun_out/pmc_*/')):
         for k, cs in agg.items():
             if 'rocclr' in k or 'at::' in k or 'prep' in k or 'fold' in k or 'absmax' in k or 'split' in k or 'pack' in k:
                 continue
-            short = k.split('(')[0].split('::')[-1][:40]
+            short = k.split('(anonymous namespace)::')[1].split('(')[0].split('<')[0] if '(anonymous namespace)::' in k else k[:40]
             summary.setdefault(tag, {})[short] = {c: round(sum(v) / len(v), 1) for c, v in cs.items()}
             summary[tag][short]['launches'] = len(next(iter(cs.values())))
 json.dump(summary, open('gpurun_out/pmc_summary.json', 'w'), indent=1, sort_keys=True)
