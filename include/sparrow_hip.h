@@ -232,6 +232,23 @@ int sprk_embedding_gather(const float* table, int32_t V, int32_t D, int32_t row_
 int sprk_cross_hash(const int32_t* a, const int32_t* b, int32_t B, int64_t num_buckets,
                     int64_t* out, void* stream);
 
+/* ---- host ingest (no GPU involved): the step before the path ----
+ * Replaces `tf.data.experimental.make_csv_dataset(..., na_value="0", ignore_errors=True)` of the reference's
+ * get_dataset (DeepFM.py:14-22) plus the feature-column id resolution (DeepFM.py:54-76) for a CSV text held in
+ * memory: header line + rows -> the two packed arrays sprk_forward reads.  Identity columns: empty -> 0, values
+ * outside [0, vocab) -> SPRK_ERANGE (TF: assert_less_than_num_buckets); genre columns: position in the 19-entry
+ * vocabulary of DeepFM.py:64-66, anything else (empty, unknown) -> -1; dense columns: empty -> 0.0.  Rows whose
+ * field count differs from the header's are skipped (ignore_errors).  `ids_out` is [max_rows, n_id] int32,
+ * `dense_out` [max_rows, n_dense] float32 (HOST memory); *rows_out receives the number of rows packed. */
+typedef struct sprk_csv_col {
+    const char* name;    /* CSV header name (reference schema key)                  */
+    int32_t kind;        /* 0 = categorical_column_with_identity, 1 = genre vocabulary */
+    int32_t vocab;       /* buckets / vocabulary size                                */
+} sprk_csv_col;
+int sprk_pack_csv(const char* text, size_t len, const sprk_csv_col* id_cols, int32_t n_id,
+                  const char* const* dense_names, int32_t n_dense, int32_t max_rows,
+                  int32_t* ids_out, float* dense_out, int32_t* rows_out);
+
 const char* sprk_last_error(void);
 
 #ifdef __cplusplus

@@ -1964,6 +1964,118 @@ int sprk_embedding_gather(const float* table, int32_t V, int32_t D, int32_t row_
     return SPRK_OK;
 }
 
+// ---- host ingest: CSV text -> packed ids / dense (schema.py's read_samples_csv + pack_ids + pack_dense in one pass) ----
+namespace {
+const char* const kGenreVocab[19] = {"Film-Noir", "Action", "Adventure", "Horror", "Romance", "War", "Comedy", "Western",
+                                     "Documentary", "Sci-Fi", "Drama", "Thriller", "Crime", "Fantasy", "Animation", "IMAX",
+                                     "Mystery", "Children", "Musical"};   // DeepFM.py:64-66
+struct CsvField { const char* p; size_t n; };
+// splits one line (no trailing newline) into fields; supports "quoted, fields" with "" escapes (unescaped into `scratch`)
+void split_csv_line(const char* p, const char* end, std::vector<CsvField>& out, std::string& scratch) {
+    out.clear();
+    scratch.clear();
+    scratch.reserve((size_t)(end - p) + 1);                     // pointers into scratch stay valid
+    while (true) {
+        if (p < end && *p == '"') {
+            const size_t start = scratch.size();
+            ++p;
+            while (p < end) {
+                if (*p == '"') {
+                    if (p + 1 < end && p[1] == '"') { scratch.push_back('"'); p += 2; continue; }
+                    ++p;
+                    break;
+                }
+                scratch.push_back(*p++);
+            }
+            out.push_back(CsvField{scratch.data() + start, scratch.size() - start});
+            while (p < end && *p != ',') ++p;
+        } else {
+            const char* q = p;
+            while (q < end && *q != ',') ++q;
+            out.push_back(CsvField{p, (size_t)(q - p)});
+            p = q;
+        }
+        if (p >= end) break;
+        ++p;                                                    // the comma
+        if (p == end) { out.push_back(CsvField{p, 0}); break; }
+    }
+}
+bool parse_number(const CsvField& f, double* v) {
+    char buf[64];
+    if (f.n == 0 || f.n >= sizeof(buf)) return false;
+    memcpy(buf, f.p, f.n);
+    buf[f.n] = 0;
+    char* e = nullptr;
+    *v = strtod(buf, &e);
+    return e != buf && *e == 0;
+}
+}  // namespace
+
+int sprk_pack_csv(const char* text, size_t len, const sprk_csv_col* id_cols, int32_t n_id, const char* const* dense_names,
+                  int32_t n_dense, int32_t max_rows, int32_t* ids_out, float* dense_out, int32_t* rows_out) {
+    if (!text || !rows_out || n_id < 0 || n_dense < 0 || max_rows < 0) return fail(SPRK_EINVAL, "bad pack_csv arguments");
+    if ((n_id > 0 && (!id_cols || !ids_out)) || (n_dense > 0 && (!dense_names || !dense_out))) return fail(SPRK_EINVAL, "NULL column list / output");
+    *rows_out = 0;
+    const char* p = text;
+    const char* const end = text + len;
+    auto line_end = [&](const char* s) { while (s < end && *s != '\n') ++s; return s; };
+    std::vector<CsvField> fields;
+    std::string scratch;
+    // header
+    const char* le = line_end(p);
+    const char* he = (le > p && le[-1] == '\r') ? le - 1 : le;
+    split_csv_line(p, he, fields, scratch);
+    const size_t n_cols = fields.size();
+    std::vector<int> id_pos(n_id, -1), dense_pos(n_dense, -1);
+    auto find = [&](const char* name) {
+        const size_t L = strlen(name);
+        for (size_t c = 0; c < n_cols; ++c) if (fields[c].n == L && memcmp(fields[c].p, name, L) == 0) return (int)c;
+        return -1;
+    };
+    for (int j = 0; j < n_id; ++j) if ((id_pos[j] = find(id_cols[j].name)) < 0) return fail(SPRK_EINVAL, "CSV has no column %s", id_cols[j].name);
+    for (int j = 0; j < n_dense; ++j) if ((dense_pos[j] = find(dense_names[j])) < 0) return fail(SPRK_EINVAL, "CSV has no column %s", dense_names[j]);
+    p = le < end ? le + 1 : end;
+    int32_t rows = 0;
+    while (p < end && rows < max_rows) {
+        le = line_end(p);
+        const char* re = (le > p && le[-1] == '\r') ? le - 1 : le;
+        if (re > p) {
+            split_csv_line(p, re, fields, scratch);
+            if (fields.size() == n_cols) {                      // ignore_errors=True: other rows are dropped
+                for (int j = 0; j < n_id; ++j) {
+                    const CsvField& f = fields[id_pos[j]];
+                    int32_t v;
+                    if (id_cols[j].kind == 1) {
+                        v = -1;
+                        for (int g = 0; g < 19; ++g)
+                            if (f.n == strlen(kGenreVocab[g]) && memcmp(f.p, kGenreVocab[g], f.n) == 0) { v = g; break; }
+                        if (v >= id_cols[j].vocab) v = -1;
+                    } else {
+                        double d = 0.0;
+                        if (f.n != 0 && !parse_number(f, &d)) return fail(SPRK_EINVAL, "row %d: %s is not a number", rows, id_cols[j].name);
+                        const long long iv = (long long)d;      // int(float(v)) of the Python packer
+                        if (iv < 0 || iv >= id_cols[j].vocab)
+                            return fail(SPRK_ERANGE, "%s id %lld outside [0, %d) (reference: assert_less_than_num_buckets)",
+                                        id_cols[j].name, iv, id_cols[j].vocab);
+                        v = (int32_t)iv;
+                    }
+                    ids_out[(size_t)rows * n_id + j] = v;
+                }
+                for (int j = 0; j < n_dense; ++j) {
+                    const CsvField& f = fields[dense_pos[j]];
+                    double d = 0.0;
+                    if (f.n != 0 && !parse_number(f, &d)) return fail(SPRK_EINVAL, "row %d: %s is not a number", rows, dense_names[j]);
+                    dense_out[(size_t)rows * n_dense + j] = (float)d;
+                }
+                ++rows;
+            }
+        }
+        p = le < end ? le + 1 : end;
+    }
+    *rows_out = rows;
+    return SPRK_OK;
+}
+
 int sprk_cross_hash(const int32_t* a, const int32_t* b, int32_t B, int64_t num_buckets, int64_t* out, void* stream) {
     if (!a || !b || !out) return fail(SPRK_EINVAL, "NULL argument");
     if (num_buckets <= 0) return fail(SPRK_EINVAL, "num_buckets must be positive");
