@@ -302,7 +302,11 @@ def main():
                                       + ("" if world == 1 else " (one collective per %d steps, overlapped; %d collectives in the timed region)"
                                          % (gs.G, (args.steps + gs.G - 1) // gs.G)),
                        "oracle_check_max_abs_err": check,
-                       "launch_overlap_streams": int(os.environ.get("SPRK_MANY_STREAMS", "0") or 0)},
+                       "launch_overlap_streams": int(os.environ.get("SPRK_MANY_STREAMS", "0") or 0),
+                       "arithmetic": "fp32 semantics; contractions whose operands are bounded at finalize (table rows x weights) run on "
+                                     "v_mfma_f32_16x16x32_f16 with split operands hi + lo (22 significand bits) and f32 accumulation -- "
+                                     "fp32-class error, tests/test_gpu_parity.py::test_deepfm_v2_split_f16_is_fp32_class; everything else "
+                                     "on f32 MFMA / VALU (SPRK_V2_HALF=0 / SPRK_DIN_HALF=0 force f32 MFMA throughout)"},
             "roofline": rl,
         }
         if world == 1 and args.cpu_seconds > 0:
