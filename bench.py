@@ -13,6 +13,7 @@ Workloads (BASELINE.json configs):
                fields, emb_dim 16, projection width 16, B = 65 536 per GPU
   deepfm_c2    the pairwise-dot DeepFM graph on the same fields
   din_c3       configs[2]: DIN, hist_len 50, emb_dim 32, B = 32 768 per GPU
+  widedeep_c5  configs[4], one GPU's share: Wide&Deep with the 10 M-bucket x 32 hashed cross table, B = 131 072
 """
 import argparse
 import json
@@ -63,6 +64,18 @@ def build_workload(name, B, dist_name, seed_offset=0):
         roof = {"bound": "mfma", "kernel": "k_din_pool" if legacy else "k_din_attn", "flops_per_sample": flops,
                 "executed_flops_per_sample": flops if legacy else executed,
                 "bytes_per_sample": (T + 1) * 4 + (T + 1) * D * 4 + D * 4}
+    elif name == "widedeep_c5":
+        # BASELINE configs[4], one GPU's share: Wide&Deep, hashed cross (movieId x userRatedMovie1) computed on device into a
+        # 10 M-bucket x 32 embedding table (1.28 GB), emb_dim 32, deep 128-128
+        D, CB = 32, 10_000_000
+        model = M.WideNDeep(seed=105, emb_dim=D, movie_buckets=SY.ML20M_MOVIE_IDS, user_buckets=SY.ML20M_USER_IDS,
+                            cross_buckets=CB, cross_dim=D)
+        desc = "Wide&Deep, 10 embedding columns emb_dim=32 + hashed cross 10M buckets x 32 (on-device FingerprintCat64), deep 128-128"
+        feats = [SY.synth_embedding_mlp(B, SY.ML20M_MOVIE_IDS, SY.ML20M_USER_IDS, seed=SY.SEED + 1000 * seed_offset + i, dist=dist_name,
+                                        rated_vocab=SY.ML20M_MOVIE_IDS) for i in range(NB)]
+        # 8 B ids + 128 B cross row per sample for the wide part; + the deep part's 11 ids, 10 rows, numerics, score
+        roof = {"bound": "hbm", "kernel": "k_tile_forward" if os.environ.get("SPRK_MLP_CHAIN") == "0" else "k_mlp_chain",
+                "bytes_per_sample": 8 + D * 4 + 9 * 4 + 10 * D * 4 + 7 * 4 + 4}
     else:
         raise SystemExit("unknown workload %r" % name)
     return model, feats, desc, roof
@@ -76,6 +89,10 @@ def oracle_forward(name, model, feats):
                                    order=[k for k, _, _ in SY.CONFIG2_FIELDS])
     if name == "deepfm_c2":
         return O.deepfm_forward(feats, model.weights, dtype=np.float32, fields=SY.CONFIG2_FIELDS, pairs=SY.CONFIG2_PAIRS)
+    if name == "widedeep_c5":
+        return O.wide_n_deep_forward(feats, model.weights, dtype=np.float32, movie_buckets=model.movie_buckets,
+                                     user_buckets=model.user_buckets, cross_buckets=model.cross_buckets,
+                                     rated_buckets=model.rated_buckets)
     return O.din_forward(feats, model.weights, dtype=np.float32, hist_len=model.hist_len,
                          movie_buckets=model.movie_buckets, user_buckets=model.user_buckets)
 
@@ -148,7 +165,7 @@ def main():
         else:
             dist.init_process_group("gloo")
 
-    B = args.batch or (32768 if args.workload == "din_c3" else 65536)
+    B = args.batch or {"din_c3": 32768, "widedeep_c5": 131072}.get(args.workload, 65536)
     if args.overlap_streams >= 2:
         os.environ["SPRK_MANY_STREAMS"] = str(args.overlap_streams)     # read by sprk_finalize
     model, feats, desc, roof = build_workload(args.workload, B, args.dist, seed_offset=rank)

@@ -570,3 +570,30 @@ def test_forward_many_fan_out_over_streams(torch, monkeypatch):
         res[streams] = [o.cpu().numpy() for o in outs]
     for a, b in zip(res["0"], res["2"]):
         np.testing.assert_array_equal(a, b)
+
+
+# --------------------------------------------------------------------------------------------
+# k_mlp_chain: EmbeddingMLP / Wide&Deep graphs as a register-chained kernel
+# --------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("kind", ["embedding_mlp", "wide_indicator", "wide_cross_rows"])
+def test_mlp_chain_vs_interpreter_and_oracle(torch, monkeypatch, kind):
+    B = 6007                                                   # ragged
+    V, U = 20000, 30000
+    feats = SY.synth_embedding_mlp(B, V, U, seed=91, rated_vocab=V if kind != "embedding_mlp" else None)
+    out = {}
+    for chain in ("1", "0"):
+        monkeypatch.setenv("SPRK_MLP_CHAIN", chain)
+        if kind == "embedding_mlp":
+            model = M.EmbeddingMLP(seed=51, emb_dim=32, movie_buckets=V, user_buckets=U)
+        else:
+            model = M.WideNDeep(seed=52, emb_dim=32, movie_buckets=V, user_buckets=U,
+                                **(dict(cross_buckets=10000, cross_dim=0) if kind == "wide_indicator" else dict(cross_buckets=200000, cross_dim=32)))
+        out[chain] = model.predict(feats)[:, 0]
+    if kind == "embedding_mlp":
+        ref = O.embedding_mlp_forward(feats, model.weights, dtype=np.float64, movie_buckets=V, user_buckets=U)[:, 0]
+    else:
+        ref = O.wide_n_deep_forward(feats, model.weights, dtype=np.float64, movie_buckets=V, user_buckets=U,
+                                    cross_buckets=model.cross_buckets, rated_buckets=V)[:, 0]
+    assert np.abs(out["1"] - ref).max() <= TIGHT
+    assert np.abs(out["0"] - ref).max() <= TIGHT
+    assert 0.02 < ref.std()
