@@ -31,11 +31,24 @@ HBM_PEAK = 8.0e12          # B/s, MI355X spec (MI355X_MICROARCH.md)
 MFMA_F32_PEAK = 157.3e12   # FLOP/s, fp32-input MFMA
 
 
-def build_workload(name, B, dist_name, seed_offset=0):
+def build_workload(name, B, dist_name, seed_offset=0, big_vocab=0):
     from sparrowrecsys_amd import models as M, synthetic as SY
     NB = 8   # distinct input batches cycled through, so steps do not re-read identical ids
     if name in ("deepfm_v2_c2", "deepfm_c2"):
         F, D = 6, 16
+        fields = SY.CONFIG2_FIELDS
+        if big_vocab:
+            # same graph, the three identity fields' tables blown up past the 256 MB Infinity Cache: every row gather is a
+            # real HBM access (config 4's "true HBM-resident gather" at config 2's widths)
+            fields = [(k, kind, big_vocab if kind == "id" else v) for k, kind, v in fields]
+        if name == "deepfm_v2_c2" and big_vocab:
+            model = M.DeepFMv2(seed=101, emb_dim=D, fields=fields, proj_dim=16)
+            desc = "DeepFM sum-of-squares FM (DeepFM_v2 graph), F=6, emb_dim=16, proj=16, deep 32-16, identity tables of %d rows each" % big_vocab
+            feats = [SY.synth_fields(B, fields, seed=SY.SEED + 1000 * seed_offset + i, dist=dist_name) for i in range(NB)]
+            bytes_per_sample = F * 4 + F * D * 4 + F * 4 + 7 * 4 + 4
+            roof = {"bound": "hbm", "kernel": "k_deepfm_v2_joint", "bytes_per_sample": bytes_per_sample}
+            model._bench_fields = fields
+            return model, feats, desc, roof
         if name == "deepfm_v2_c2":
             model = M.DeepFMv2(seed=101, emb_dim=D, fields=SY.CONFIG2_FIELDS, proj_dim=16)
             desc = "DeepFM sum-of-squares FM (DeepFM_v2 graph), F=6 sparse fields, emb_dim=16, proj=16, deep 32-16"
@@ -85,8 +98,8 @@ def oracle_forward(name, model, feats):
     from oracle import ctr_oracle as O
     from sparrowrecsys_amd import synthetic as SY
     if name == "deepfm_v2_c2":
-        return O.deepfm_v2_forward(feats, model.weights, dtype=np.float32, fields=SY.CONFIG2_FIELDS,
-                                   order=[k for k, _, _ in SY.CONFIG2_FIELDS])
+        fields = getattr(model, "_bench_fields", SY.CONFIG2_FIELDS)
+        return O.deepfm_v2_forward(feats, model.weights, dtype=np.float32, fields=fields, order=[k for k, _, _ in fields])
     if name == "deepfm_c2":
         return O.deepfm_forward(feats, model.weights, dtype=np.float32, fields=SY.CONFIG2_FIELDS, pairs=SY.CONFIG2_PAIRS)
     if name == "widedeep_c5":
@@ -139,6 +152,9 @@ def main():
     ap.add_argument("--overlap-streams", type=int, default=0,
                     help="fan sprk_forward_many's independent batches over S helper streams (2..4) so that consecutive "
                          "launches overlap; default 0 = strict stream order, the mode the roofline numbers are quoted in")
+    ap.add_argument("--big-vocab", type=int, default=0,
+                    help="deepfm_v2_c2 only: rows of each identity table (e.g. 8388608 = 1 GiB of folded rows per table, "
+                         "far beyond the Infinity Cache); default 0 = the MovieLens-20M-shaped vocabularies of the config")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend (gloo: functional test of the N>1 path with ranks sharing one GPU)")
     args = ap.parse_args()
@@ -168,7 +184,7 @@ def main():
     B = args.batch or {"din_c3": 32768, "widedeep_c5": 131072}.get(args.workload, 65536)
     if args.overlap_streams >= 2:
         os.environ["SPRK_MANY_STREAMS"] = str(args.overlap_streams)     # read by sprk_finalize
-    model, feats, desc, roof = build_workload(args.workload, B, args.dist, seed_offset=rank)
+    model, feats, desc, roof = build_workload(args.workload, B, args.dist, seed_offset=rank, big_vocab=args.big_vocab)
     eng = model.engine
     batches = []
     for f in feats:
