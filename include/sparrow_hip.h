@@ -190,6 +190,13 @@ int sprk_forward(sprk_handle h, const int32_t* ids, const float* dense, float* o
 int sprk_forward_many(sprk_handle h, int32_t n_batches, const int32_t* const* ids, const float* const* dense,
                       float* const* out, int32_t B, void* workspace, size_t workspace_bytes, void* stream);
 
+/* How sprk_forward_many enqueues its batches.  n = 0 (default): all on `stream`, strictly one after the other -- on this
+ * stack even an empty kernel costs ~3.3 us per launch in such a dependent chain.  n = 2..4: independent batches alternate
+ * over n library-owned helper streams forked from `stream` and joined back into it, so that one kernel's dispatch / drain
+ * overlaps its neighbours' execution (config 2: 8.9 -> 6.8 us per 65 536-row batch).  Results are identical; completion is
+ * still ordered on `stream`.  SPRK_EKIND for models whose forward is a chain of dependent kernels (DIN). */
+int sprk_set_many_streams(sprk_handle h, int32_t n);
+
 /* Per-model entry points: identical to sprk_forward but fail with
  * SPRK_EKIND unless the handle was created from that model's plan. */
 int sprk_forward_embedding_mlp(sprk_handle h, const int32_t* ids, const float* dense, float* out, int32_t B, void* ws, size_t ws_bytes, void* stream);

@@ -17,13 +17,15 @@ b bench_c2_unfolded SPRK_V2_FOLD=0 python bench.py --cpu-seconds 0
 b bench_c2_interp SPRK_FORCE_INTERPRETER=1 python bench.py --cpu-seconds 0
 b bench_c2_zipf python bench.py --cpu-seconds 0 --dist zipf
 b bench_c2_b1m python bench.py --cpu-seconds 0 --batch 1048576 --steps 400 --warmup 40
-b bench_c2_overlap2 python bench.py --cpu-seconds 0 --overlap-streams 2
+b bench_c2_strict python bench.py --cpu-seconds 0 --overlap-streams 0
 b bench_c2_pairs python bench.py --workload deepfm_c2 --cpu-seconds 0
 b bench_c2_pairs_interp SPRK_V1_CHAIN=0 python bench.py --workload deepfm_c2 --cpu-seconds 0
 b bench_c3 python bench.py --steps 300 --warmup 30 --workload din_c3 --cpu-seconds 6
 b bench_c3_f32 SPRK_DIN_HALF=0 python bench.py --steps 300 --warmup 30 --workload din_c3 --cpu-seconds 0
 b bench_c3_interp_tail SPRK_DIN_TAIL=0 python bench.py --steps 300 --warmup 30 --workload din_c3 --cpu-seconds 0
 b bench_c3_legacy SPRK_DIN_LEGACY=1 SPRK_DIN_TAIL=0 SPRK_TILE_FOLD=0 python bench.py --steps 100 --warmup 10 --workload din_c3 --cpu-seconds 0
+b bench_c5 python bench.py --workload widedeep_c5 --steps 200 --warmup 20 --cpu-seconds 0
+b bench_c5_interp SPRK_MLP_CHAIN=0 python bench.py --workload widedeep_c5 --steps 200 --warmup 20 --cpu-seconds 0
 echo "=== rocprofv3 kernel trace"
 cd /tmp && export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_c2 -o c2 -- python $R/bench.py --steps 400 --warmup 40 --cpu-seconds 0 --no-check > $R/gpurun_out/prof_c2.log 2>&1

@@ -1863,16 +1863,16 @@ int sprk_finalize(sprk_handle h) {
     HIP_TRY(hipMalloc((void**)&h->dev_err, sizeof(int)));
     HIP_TRY(hipMemset(h->dev_err, 0, sizeof(int)));
     {
-        const char* ms = getenv("SPRK_MANY_STREAMS");          // 0 / 1 = strict stream order (default), 2..4 = fan out
-        int n = ms ? atoi(ms) : 0;
-        if (n > 4) n = 4;
-        if (n >= 2 && !p.din.enabled) {                        // a DIN forward is two dependent kernels sharing the workspace
+        // helper streams for sprk_forward_many's fan-out (sprk_set_many_streams; SPRK_MANY_STREAMS presets it)
+        if (!p.din.enabled) {                                  // a DIN forward is two dependent kernels sharing the workspace
             HIP_TRY(hipEventCreateWithFlags(&h->many_fork, hipEventDisableTiming));
-            for (int i = 0; i < n; ++i) {
+            for (int i = 0; i < 4; ++i) {
                 HIP_TRY(hipStreamCreateWithFlags(&h->many_stream[i], hipStreamNonBlocking));
                 HIP_TRY(hipEventCreateWithFlags(&h->many_join[i], hipEventDisableTiming));
             }
-            h->many_streams = n;
+            const char* ms = getenv("SPRK_MANY_STREAMS");      // 0 / 1 = strict stream order (default), 2..4 = fan out
+            int n = ms ? atoi(ms) : 0;
+            h->many_streams = n < 2 ? 0 : (n > 4 ? 4 : n);
         }
     }
     h->finalized = true;
@@ -2014,6 +2014,15 @@ SPRK_FORWARD_KIND(sprk_forward_neuralcf, SPRK_MODEL_NEURALCF)
 SPRK_FORWARD_KIND(sprk_forward_deepfm, SPRK_MODEL_DEEPFM)
 SPRK_FORWARD_KIND(sprk_forward_deepfm_v2, SPRK_MODEL_DEEPFM_V2)
 SPRK_FORWARD_KIND(sprk_forward_din, SPRK_MODEL_DIN)
+
+int sprk_set_many_streams(sprk_handle h, int32_t n) {
+    if (!h) return fail(SPRK_EINVAL, "handle is NULL");
+    if (!h->finalized) return fail(SPRK_ESTATE, "set_many_streams before finalize");
+    if (n < 0 || n > 4) return fail(SPRK_EINVAL, "stream count %d outside [0,4]", n);
+    if (n >= 2 && !h->many_fork) return fail(SPRK_EKIND, "this model's forward is a chain of dependent kernels: no fan-out");
+    h->many_streams = n < 2 ? 0 : n;
+    return SPRK_OK;
+}
 
 int sprk_check_ids(sprk_handle h, void* stream) {
     if (!h) return fail(SPRK_EINVAL, "handle is NULL");

@@ -118,6 +118,15 @@ class Engine:
         L.check(self.lib.sprk_forward_many(self.handle, n, ids_a, dense_a, out_a, B, C.c_void_p(ws_ptr), ws_bytes,
                                            C.c_void_p(stream)))
 
+    def set_many_streams(self, n: int) -> bool:
+        """Fan forward_many's independent batches over ``n`` helper streams (0 = strict order).  Returns False for
+        models whose forward is a chain of dependent kernels (DIN), which always run in strict order."""
+        rc = self.lib.sprk_set_many_streams(self.handle, int(n))
+        if rc == L.EKIND:
+            return False
+        L.check(rc)
+        return True
+
     def din_pool(self, ids, pooled, att=None, stream: Optional[int] = None):
         import torch
         if stream is None:

@@ -552,14 +552,14 @@ def test_deepfm_pairs_kernel_properties(torch):
 
 
 def test_forward_many_fan_out_over_streams(torch, monkeypatch):
-    """SPRK_MANY_STREAMS=2: sprk_forward_many alternates independent batches over two helper streams (forked from and
+    """sprk_set_many_streams(2): sprk_forward_many alternates independent batches over two helper streams (forked from and
     joined back into the caller's stream); results equal the strictly ordered run bit for bit."""
     B, n = 4099, 7
     feats = [SY.synth_fields(B, SY.CONFIG2_FIELDS, seed=80 + i) for i in range(n)]
     res = {}
     for streams in ("0", "2"):
-        monkeypatch.setenv("SPRK_MANY_STREAMS", streams)
         model = M.DeepFMv2(seed=48, emb_dim=16, fields=SY.CONFIG2_FIELDS, proj_dim=16)
+        assert model.engine.set_many_streams(int(streams))
         packed = [model.pack(f) for f in feats]
         ids = [_cuda(torch, p[0]) for p in packed]
         dense = [_cuda(torch, p[1]) for p in packed]
@@ -570,6 +570,8 @@ def test_forward_many_fan_out_over_streams(torch, monkeypatch):
         res[streams] = [o.cpu().numpy() for o in outs]
     for a, b in zip(res["0"], res["2"]):
         np.testing.assert_array_equal(a, b)
+    din = M.DIN(seed=49)
+    assert din.engine.set_many_streams(2) is False            # two dependent kernels sharing the workspace: strict order only
 
 
 # --------------------------------------------------------------------------------------------
