@@ -193,7 +193,7 @@ def main():
         batches.append((torch.from_numpy(ids).cuda(), torch.from_numpy(dense).cuda()))
     NB = len(batches)
     outs = [torch.empty(B, dtype=torch.float32, device="cuda") for _ in range(NB)]
-    ws = torch.empty(max(eng.workspace_bytes(B) // 4, 1), dtype=torch.float32, device="cuda")
+    ws = torch.empty(max(eng.many_workspace_bytes(B, max(fan, 1)) // 4, 1), dtype=torch.float32, device="cuda")
     gs = None
     if world > 1:
         from sparrowrecsys_amd.dist import GroupedScoreGather

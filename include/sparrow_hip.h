@@ -194,7 +194,8 @@ int sprk_forward_many(sprk_handle h, int32_t n_batches, const int32_t* const* id
  * stack even an empty kernel costs ~3.3 us per launch in such a dependent chain.  n = 2..4: independent batches alternate
  * over n library-owned helper streams forked from `stream` and joined back into it, so that one kernel's dispatch / drain
  * overlaps its neighbours' execution (config 2: 8.9 -> 6.8 us per 65 536-row batch).  Results are identical; completion is
- * still ordered on `stream`.  SPRK_EKIND for models whose forward is a chain of dependent kernels (DIN). */
+ * still ordered on `stream`.  Models with a workspace (DIN) fan out only when `workspace_bytes` holds one 256-byte-aligned
+ * slice of sprk_workspace_bytes(B) per stream. */
 int sprk_set_many_streams(sprk_handle h, int32_t n);
 
 /* Per-model entry points: identical to sprk_forward but fail with

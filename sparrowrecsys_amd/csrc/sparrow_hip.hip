@@ -1864,7 +1864,7 @@ int sprk_finalize(sprk_handle h) {
     HIP_TRY(hipMemset(h->dev_err, 0, sizeof(int)));
     {
         // helper streams for sprk_forward_many's fan-out (sprk_set_many_streams; SPRK_MANY_STREAMS presets it)
-        if (!p.din.enabled) {                                  // a DIN forward is two dependent kernels sharing the workspace
+        {
             HIP_TRY(hipEventCreateWithFlags(&h->many_fork, hipEventDisableTiming));
             for (int i = 0; i < 4; ++i) {
                 HIP_TRY(hipStreamCreateWithFlags(&h->many_stream[i], hipStreamNonBlocking));
@@ -1982,14 +1982,22 @@ int sprk_forward_many(sprk_handle h, int32_t n_batches, const int32_t* const* id
     if (!h) return fail(SPRK_EINVAL, "handle is NULL");
     if (n_batches < 0) return fail(SPRK_EINVAL, "negative batch count");
     if (n_batches > 0 && !out) return fail(SPRK_EINVAL, "out is NULL");
-    const int S = (h->finalized && n_batches > 1) ? h->many_streams : 0;
+    int S = (h->finalized && n_batches > 1) ? h->many_streams : 0;
+    // a model with a workspace (DIN: attention kernel -> pooled vectors -> tail kernel) needs one workspace slice per
+    // stream; with a single slice its forwards stay in strict order
+    const size_t ws_need = (sprk_workspace_bytes(h, B) + 255) & ~(size_t)255;
+    if (S >= 2 && ws_need > 0) {
+        while (S >= 2 && (!workspace || workspace_bytes < (size_t)S * ws_need)) --S;
+        if (S < 2) S = 0;
+    }
     if (S >= 2) {
         HIP_TRY(hipEventRecord(h->many_fork, (hipStream_t)stream));
         for (int s = 0; s < S; ++s) HIP_TRY(hipStreamWaitEvent(h->many_stream[s], h->many_fork, 0));
     }
     for (int32_t i = 0; i < n_batches; ++i) {
-        const int rc = sprk_forward(h, ids ? ids[i] : nullptr, dense ? dense[i] : nullptr, out[i], B, workspace,
-                                    workspace_bytes, S >= 2 ? (void*)h->many_stream[i % S] : stream);
+        void* wsi = (S >= 2 && ws_need > 0) ? (void*)((char*)workspace + (size_t)(i % S) * ws_need) : workspace;
+        const int rc = sprk_forward(h, ids ? ids[i] : nullptr, dense ? dense[i] : nullptr, out[i], B, wsi,
+                                    (S >= 2 && ws_need > 0) ? ws_need : workspace_bytes, S >= 2 ? (void*)h->many_stream[i % S] : stream);
         if (rc) return rc;
     }
     if (S >= 2) {
@@ -2019,7 +2027,6 @@ int sprk_set_many_streams(sprk_handle h, int32_t n) {
     if (!h) return fail(SPRK_EINVAL, "handle is NULL");
     if (!h->finalized) return fail(SPRK_ESTATE, "set_many_streams before finalize");
     if (n < 0 || n > 4) return fail(SPRK_EINVAL, "stream count %d outside [0,4]", n);
-    if (n >= 2 && !h->many_fork) return fail(SPRK_EKIND, "this model's forward is a chain of dependent kernels: no fan-out");
     h->many_streams = n < 2 ? 0 : n;
     return SPRK_OK;
 }

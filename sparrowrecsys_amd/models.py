@@ -119,13 +119,15 @@ class Engine:
                                            C.c_void_p(stream)))
 
     def set_many_streams(self, n: int) -> bool:
-        """Fan forward_many's independent batches over ``n`` helper streams (0 = strict order).  Returns False for
-        models whose forward is a chain of dependent kernels (DIN), which always run in strict order."""
-        rc = self.lib.sprk_set_many_streams(self.handle, int(n))
-        if rc == L.EKIND:
-            return False
-        L.check(rc)
+        """Fan forward_many's independent batches over ``n`` helper streams (0 = strict order).  Models with a workspace
+        (DIN) additionally need ``n`` workspace slices (see ``many_workspace_bytes``)."""
+        L.check(self.lib.sprk_set_many_streams(self.handle, int(n)))
         return True
+
+    def many_workspace_bytes(self, B: int, n: int) -> int:
+        """Workspace size that lets forward_many fan a workspace model over ``n`` streams."""
+        need = (self.workspace_bytes(B) + 255) & ~255
+        return max(1, n) * need
 
     def din_pool(self, ids, pooled, att=None, stream: Optional[int] = None):
         import torch

@@ -570,8 +570,25 @@ def test_forward_many_fan_out_over_streams(torch, monkeypatch):
         res[streams] = [o.cpu().numpy() for o in outs]
     for a, b in zip(res["0"], res["2"]):
         np.testing.assert_array_equal(a, b)
-    din = M.DIN(seed=49)
-    assert din.engine.set_many_streams(2) is False            # two dependent kernels sharing the workspace: strict order only
+    # DIN (attention kernel -> pooled vectors in the workspace -> tail kernel): one workspace slice per stream
+    Bd, T = 2049, 50
+    din = M.DIN(seed=49, emb_dim=32, hist_len=T, movie_buckets=5000, user_buckets=7000)
+    eng = din.engine
+    fd = [SY.synth_din(Bd, T, 5000, 7000, seed=90 + i) for i in range(5)]
+    packed = [din.pack(f) for f in fd]
+    ids = [_cuda(torch, p[0]) for p in packed]
+    dense = [_cuda(torch, p[1]) for p in packed]
+    res = {}
+    for streams in (0, 2):
+        eng.set_many_streams(streams)
+        ws = torch.empty(eng.many_workspace_bytes(Bd, max(streams, 1)) // 4, dtype=torch.float32, device="cuda")
+        outs = [torch.full((Bd,), -1.0, dtype=torch.float32, device="cuda") for _ in range(5)]
+        eng.forward_many(ids, dense, outs, ws)
+        torch.cuda.current_stream().synchronize()
+        eng.check_ids()
+        res[streams] = [o.cpu().numpy() for o in outs]
+    for a, b in zip(res[0], res[2]):
+        np.testing.assert_array_equal(a, b)
 
 
 # --------------------------------------------------------------------------------------------
