@@ -240,6 +240,22 @@ int sprk_embedding_gather(const float* table, int32_t V, int32_t D, int32_t row_
 int sprk_cross_hash(const int32_t* a, const int32_t* b, int32_t B, int64_t num_buckets,
                     int64_t* out, void* stream);
 
+/* The reference's "emb" ranker: RecForYouProcess.java:69-92 (ranker, case "emb") with
+ * calculateEmbSimilarScore :100-105, SimilarMovieProcess.java:121-136,167-172, Embedding.calculateSimilarity
+ * (Embedding.java:33-47).  For query u (a user's embedding, or a movie's) and its C candidate movies
+ *   scores[u][c] = dot / (sqrt(n1) * sqrt(n2)), float products summed into doubles in index order exactly as the Java
+ *                  loop does (bit-exact doubles; an all-zero vector gives NaN as in Java);
+ *                  -1.0 if the query has no embedding (query_has[u] == 0), cand[u][c] is outside [0, n_items) (a Movie
+ *                  unknown to the table) or that item has none (item_has[id] == 0) -- Embedding.java:34-37.
+ *   order[u][0..C) (optional, C <= 4096): candidate POSITIONS in the order of
+ *                  `sorted(Map.Entry.comparingByValue(Comparator.reverseOrder()))`: descending in Double.compareTo
+ *                  order (NaN first, 0.0 before -0.0); equal scores stay in candidate order (Java: unspecified).
+ * All pointers are device memory; item_emb [n_items][item_stride], query_emb [n_queries][query_stride] floats (first D
+ * used), cand [n_queries][C]; item_has / query_has may be NULL (= all present). */
+int sprk_emb_rank(const float* item_emb, const uint8_t* item_has, int32_t n_items, int32_t D, int32_t item_stride,
+                  const float* query_emb, const uint8_t* query_has, int32_t n_queries, int32_t query_stride,
+                  const int32_t* cand, int32_t C, double* scores, int32_t* order, void* stream);
+
 /* ---- host ingest (no GPU involved): the step before the path ----
  * Replaces `tf.data.experimental.make_csv_dataset(..., na_value="0", ignore_errors=True)` of the reference's
  * get_dataset (DeepFM.py:14-22) plus the feature-column id resolution (DeepFM.py:54-76) for a CSV text held in

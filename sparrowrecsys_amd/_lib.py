@@ -33,7 +33,7 @@ EXPORTED_SYMBOLS = [
     "sprk_forward", "sprk_forward_many", "sprk_forward_embedding_mlp", "sprk_forward_widedeep", "sprk_forward_neuralcf",
     "sprk_forward_deepfm", "sprk_forward_deepfm_v2", "sprk_forward_din", "sprk_din_pool",
     "sprk_check_ids", "sprk_debug_set_trace", "sprk_destroy", "sprk_embedding_gather", "sprk_cross_hash", "sprk_last_error",
-    "sprk_pack_csv", "sprk_set_many_streams",
+    "sprk_pack_csv", "sprk_set_many_streams", "sprk_emb_rank",
 ]
 
 

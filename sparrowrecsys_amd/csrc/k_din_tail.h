@@ -11,8 +11,8 @@
 // rows are gathered straight into the accumulators (16-byte pieces), fc0's remaining contraction, PReLU,
 // fc1 (K = 128: its B operand IS h1's registers), PReLU, the output dot and the sigmoid all stay in
 // registers.  Weights sit in LDS (pre-packed image, LDS-DMA), read as A fragments right before use.
-// f32 MFMA throughout: the operands here (raw numerics, hidden activations) have data-dependent range, the
-// static power-of-two scaling of the split-f16 path (k_chain_v2j.h) does not apply.
+// fc0's per-sample part (raw numerics, pooled history) runs on f32 MFMA; fc1 runs on the f16 matrix pipe with a
+// per-sample DYNAMIC power-of-two scale of its input (dyn_split.h), since hidden activations have data-dependent range.
 // The interpreter ran this tail as a chain of memory round trips at one tile per workgroup (28 us at
 // B = 32 768); here every load of a task is in flight at once.
 
@@ -26,17 +26,21 @@ struct DinTailRun {
     const float* Ftab[DT_MAX_COLS];       // [vocab][N0] folded rows
     int n_num;                            // numerics used (<= 8)
     float head_bias;
+    float inv_w1_scale;                   // DYN: 1 / (static power-of-two scale of fc1's split weights)
 };
 
+// DYN: fc1 on the f16 matrix pipe with per-sample dynamic scaling (dyn_split.h); its W1 region then holds the packed
+// hi / lo A fragments ((N1/16) x (N0/32) blocks of 2 KB) instead of the f32 W^T rows.
 template <int N0C, int N1C, int KPC>
 struct DinTailLds {
     static constexpr int N0 = N0C * 16, N1 = N1C * 16;
+    static constexpr int w1h_floats = N1C * (N0C / 2) * 512;       // DYN fragments, in floats
     static constexpr int K0 = KPC * 16 + 16;          // fc0's per-sample K: pooled chunks + one numeric chunk (8 used)
     static constexpr int S0 = K0 + 4;                 // W0^T row stride
     static constexpr int S1 = N0 + 4;                 // W1^T row stride
     static constexpr int off_w0 = 0;                  // [N0][S0]
     static constexpr int off_w1 = off_w0 + N0 * S0;   // [N1][S1]
-    static constexpr int off_b0 = off_w1 + N1 * S1;   // [N0]
+    static constexpr int off_b0 = off_w1 + (N1 * S1 > w1h_floats ? N1 * S1 : w1h_floats);   // [N0]
     static constexpr int off_a0 = off_b0 + N0;        // [N0]
     static constexpr int off_b1 = off_a0 + N0;        // [N1]
     static constexpr int off_a1 = off_b1 + N1;        // [N1]
@@ -53,7 +57,7 @@ __global__ __launch_bounds__(256) void k_din_tail_pack(const float* __restrict__
                                                        int n_num, const float* __restrict__ b0, const float* __restrict__ a0,
                                                        const float* __restrict__ W1, int ldw1, const float* __restrict__ b1,
                                                        const float* __restrict__ a1, const float* __restrict__ hw, int n_hw,
-                                                       float* __restrict__ img) {
+                                                       const float* __restrict__ w1frag, float* __restrict__ img) {
     using LD = DinTailLds<N0C, N1C, KPC>;
     const int tid = threadIdx.x;
     for (int i = tid; i < LD::N0 * LD::S0; i += 256) {
@@ -63,9 +67,13 @@ __global__ __launch_bounds__(256) void k_din_tail_pack(const float* __restrict__
         else if (k - KPC * 16 < n_num) v = W0[(size_t)n * ldw0 + n_off + (k - KPC * 16)];
         img[LD::off_w0 + i] = v;
     }
-    for (int i = tid; i < LD::N1 * LD::S1; i += 256) {
-        const int n = i / LD::S1, k = i - n * LD::S1;
-        img[LD::off_w1 + i] = k < LD::N0 ? W1[(size_t)n * ldw1 + k] : 0.f;
+    if (w1frag) {
+        for (int i = tid; i < LD::w1h_floats; i += 256) img[LD::off_w1 + i] = w1frag[i];     // DYN: packed f16 fragments
+    } else {
+        for (int i = tid; i < LD::N1 * LD::S1; i += 256) {
+            const int n = i / LD::S1, k = i - n * LD::S1;
+            img[LD::off_w1 + i] = k < LD::N0 ? W1[(size_t)n * ldw1 + k] : 0.f;
+        }
     }
     for (int i = tid; i < LD::N0; i += 256) { img[LD::off_b0 + i] = b0[i]; img[LD::off_a0 + i] = a0[i]; }
     for (int i = tid; i < LD::N1; i += 256) {
@@ -76,7 +84,7 @@ __global__ __launch_bounds__(256) void k_din_tail_pack(const float* __restrict__
     for (int i = LD::total + tid; i < LD::total_pad; i += 256) img[i] = 0.f;
 }
 
-template <int N0C, int N1C, int KPC, int WAVES>
+template <int N0C, int N1C, int KPC, int WAVES, bool DYN>
 __global__ __launch_bounds__(WAVES * 64, 2) void k_din_tail(const DinTailRun A, const int* __restrict__ ids,
                                                             const float* __restrict__ dense, const float* __restrict__ aux,
                                                             float* __restrict__ out, int B, int* __restrict__ err,
@@ -176,6 +184,37 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_din_tail(const DinTailRun A, 
         }
         // ---- fc1: K = N0, its B operand is h1 as it sits in the registers (N1C chains) ----
         f32x4 z1[N1C];
+        if constexpr (DYN) {
+            static_assert(N0C % 2 == 0, "K blocks of 32");
+            // per-sample scale from max |h1| (this lane's 4*N0C values, then the sample's other three q rows)
+            float mx = 0.f;
+#pragma unroll
+            for (int nb = 0; nb < N0C; ++nb)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) mx = fmaxf(mx, __builtin_fabsf(z0[nb][j]));
+            mx = rows4_max(mx);
+            float scale, inv;
+            dyn_scale(mx, A.inv_w1_scale, scale, inv);
+            f32x4 acc[N1C];
+#pragma unroll
+            for (int n1 = 0; n1 < N1C; ++n1) acc[n1] = zero;
+            const float* wf = smem + LD::off_w1 + (r * 4 + q) * 4;       // this lane's 16 bytes inside a 1-KB fragment
+#pragma unroll
+            for (int b = 0; b < N0C / 2; ++b) {
+                din_f16x8 bh, bl;
+                dyn_split8(z0[2 * b], z0[2 * b + 1], scale, bh, bl);
+#pragma unroll
+                for (int n1 = 0; n1 < N1C; ++n1) {
+                    const din_f16x8 ah = __builtin_bit_cast(din_f16x8, ld4(wf + ((n1 * (N0C / 2) + b) * 2 + 0) * 256));
+                    const din_f16x8 al = __builtin_bit_cast(din_f16x8, ld4(wf + ((n1 * (N0C / 2) + b) * 2 + 1) * 256));
+                    acc[n1] = mfma_f16(ah, bh, acc[n1]);
+                    acc[n1] = mfma_f16(ah, bl, acc[n1]);
+                    acc[n1] = mfma_f16(al, bh, acc[n1]);
+                }
+            }
+#pragma unroll
+            for (int n1 = 0; n1 < N1C; ++n1) z1[n1] = acc[n1] * inv + ld4(smem + LD::off_b1 + n1 * 16 + 4 * q);
+        } else {
 #pragma unroll
         for (int n1 = 0; n1 < N1C; ++n1) z1[n1] = ld4(smem + LD::off_b1 + n1 * 16 + 4 * q);
         const float* w1r = smem + LD::off_w1 + r * LD::S1 + 4 * q;
@@ -189,6 +228,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_din_tail(const DinTailRun A, 
 #pragma unroll
                 for (int n1 = 0; n1 < N1C; ++n1)
                     z1[n1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[n1][st], z0[c][st], z1[n1], 0, 0, 0);
+        }
         }
         // PReLU(alpha1) (DIN.py:166) -> Dense(1) -> sigmoid (DIN.py:167)
         float z = 0.f;

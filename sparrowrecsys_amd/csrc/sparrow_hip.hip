@@ -607,9 +607,11 @@ __global__ __launch_bounds__(256) void k_zero_columns(float* __restrict__ Wt, in
 #include "k_chain_v2.h"
 #include "k_chain_v2j.h"
 #include "k_din_attn.h"
+#include "dyn_split.h"
 #include "k_din_tail.h"
 #include "k_chain_v1.h"
 #include "k_mlp_chain.h"
+#include "k_emb_rank.h"
 
 // ---------------------------------------------------------------------------------------------
 // stand-alone operators
@@ -1484,28 +1486,35 @@ int setup_mlp_chain(sprk_engine* h, DevPlan* dp) {
 constexpr int DT_WAVES = 8;
 typedef void (*DinTailLaunchFn)(const DinTailRun&, const int*, const float*, const float*, float*, int, int*, const float*, int, hipStream_t);
 typedef void (*DinTailPackFn)(const float*, int, int, int, int, int, const float*, const float*, const float*, int, const float*,
-                              const float*, const float*, int, float*);
+                              const float*, const float*, int, const float*, float*);
 template <int N0C, int N1C, int KPC>
 void din_tail_launch(const DinTailRun& a, const int* ids, const float* dense, const float* aux, float* out, int B, int* err,
                      const float* image, int grid, hipStream_t st) {
     const size_t lds = DinTailLds<N0C, N1C, KPC>::bytes;
-    hipLaunchKernelGGL((k_din_tail<N0C, N1C, KPC, DT_WAVES>), dim3(grid), dim3(DT_WAVES * 64), lds, st,
-                       a, ids, dense, aux, out, B, err, image);
+    if (a.inv_w1_scale != 0.f)
+        hipLaunchKernelGGL((k_din_tail<N0C, N1C, KPC, DT_WAVES, true>), dim3(grid), dim3(DT_WAVES * 64), lds, st,
+                           a, ids, dense, aux, out, B, err, image);
+    else
+        hipLaunchKernelGGL((k_din_tail<N0C, N1C, KPC, DT_WAVES, false>), dim3(grid), dim3(DT_WAVES * 64), lds, st,
+                           a, ids, dense, aux, out, B, err, image);
 }
 template <int N0C, int N1C, int KPC>
 void din_tail_pack(const float* W0, int ldw0, int p_off, int Dp, int n_off, int n_num, const float* b0, const float* a0,
-                   const float* W1, int ldw1, const float* b1, const float* a1, const float* hw, int n_hw, float* img) {
+                   const float* W1, int ldw1, const float* b1, const float* a1, const float* hw, int n_hw, const float* w1frag,
+                   float* img) {
     hipLaunchKernelGGL((k_din_tail_pack<N0C, N1C, KPC>), dim3(1), dim3(256), 0, 0, W0, ldw0, p_off, Dp, n_off, n_num, b0, a0, W1, ldw1,
-                       b1, a1, hw, n_hw, img);
+                       b1, a1, hw, n_hw, w1frag, img);
 }
 struct DinTailVariant {
     int n0c, n1c, kpc;
     const void* fn;
+    const void* fn_dyn;
     size_t lds_bytes;
     DinTailLaunchFn launch;
     DinTailPackFn pack;
 };
-#define DIN_TAIL_VARIANT(N0C, N1C, KPC) {N0C, N1C, KPC, reinterpret_cast<const void*>(&k_din_tail<N0C, N1C, KPC, DT_WAVES>), \
+#define DIN_TAIL_VARIANT(N0C, N1C, KPC) {N0C, N1C, KPC, reinterpret_cast<const void*>(&k_din_tail<N0C, N1C, KPC, DT_WAVES, false>), \
+                                         reinterpret_cast<const void*>(&k_din_tail<N0C, N1C, KPC, DT_WAVES, true>),                \
                                          DinTailLds<N0C, N1C, KPC>::bytes, &din_tail_launch<N0C, N1C, KPC>, &din_tail_pack<N0C, N1C, KPC>}
 const DinTailVariant kDinTailVariants[] = {
     DIN_TAIL_VARIANT(8, 4, 2),        // DIN.py:161-167 widths 128 / 64, emb_dim 17..32 (BASELINE config 3)
@@ -1551,10 +1560,36 @@ int setup_din_tail(sprk_engine* h, DevPlan* dp) {
         r.col[g] = h->idc[sg.field]; r.vocab[g] = sg.vocab; r.Ftab[g] = sg.table;
     }
     HIP_TRY(hipMalloc((void**)&h->din_tail_image, tv.lds_bytes));
-    tv.pack(o0.W, o0.ldw, p_off, Dp, n_off, n_num, o0.bias, o0.alpha, o1.W, o1.ldw, o1.bias, o1.alpha, tp.w, tp.len, h->din_tail_image);
+    // DYN: fc1's weights split into f16 hi / lo fragments with a static power-of-two scale (max |W1| -> ~2^14)
+    float* w1frag = nullptr;
+    const char* dsw = getenv("SPRK_DYN_F16");                // A/B switch: "0" = fc1 on f32 MFMA
+    if (!(dsw && dsw[0] == '0')) {
+        unsigned* d_max = nullptr;
+        HIP_TRY(hipMalloc((void**)&d_max, sizeof(unsigned)));
+        HIP_TRY(hipMemset(d_max, 0, sizeof(unsigned)));
+        hipLaunchKernelGGL(k_v2_absmax, dim3(8), dim3(256), 0, 0, o1.W, (long long)o1.N, o1.ldw, o1.K, d_max);
+        unsigned bits = 0;
+        HIP_TRY(hipMemcpy(&bits, d_max, sizeof(bits), hipMemcpyDeviceToHost));
+        (void)hipFree(d_max);
+        float mx;
+        memcpy(&mx, &bits, sizeof(mx));
+        if (mx < 3.0e38f) {
+            int e = 0;
+            float w_scale = 1.f;
+            if (mx > 0.f) { (void)frexpf(mx, &e); e = 15 - e; if (e > 60) e = 60; if (e < -60) e = -60; w_scale = ldexpf(1.f, e); }
+            const size_t frag_floats = (size_t)(o1.N / 16) * (o1.K / 32) * 512;
+            HIP_TRY(hipMalloc((void**)&w1frag, frag_floats * sizeof(float)));
+            h->fold_bufs.push_back(w1frag);
+            hipLaunchKernelGGL(k_dyn_pack_w, dim3(32), dim3(256), 0, 0, o1.W, o1.ldw, o1.N, o1.K, w_scale, reinterpret_cast<_Float16*>(w1frag));
+            HIP_TRY(hipGetLastError());
+            r.inv_w1_scale = 1.0f / w_scale;
+        }
+    }
+    tv.pack(o0.W, o0.ldw, p_off, Dp, n_off, n_num, o0.bias, o0.alpha, o1.W, o1.ldw, o1.bias, o1.alpha, tp.w, tp.len, w1frag, h->din_tail_image);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipFuncSetAttribute(tv.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tv.lds_bytes));
+    HIP_TRY(hipFuncSetAttribute(tv.fn_dyn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tv.lds_bytes));
     h->din_tail_variant = variant;
     return SPRK_OK;
 }
@@ -2139,6 +2174,23 @@ bool parse_number(const CsvField& f, double* v) {
     return e != buf && *e == 0;
 }
 }  // namespace
+
+int sprk_emb_rank(const float* item_emb, const uint8_t* item_has, int32_t n_items, int32_t D, int32_t item_stride,
+                  const float* query_emb, const uint8_t* query_has, int32_t n_queries, int32_t query_stride,
+                  const int32_t* cand, int32_t C, double* scores, int32_t* order, void* stream) {
+    if (!item_emb || !query_emb || !cand || !scores) return fail(SPRK_EINVAL, "emb_rank: NULL table / queries / candidates / scores");
+    if (n_items < 0 || n_queries < 0 || C < 0 || D < 1 || D > 1024 || item_stride < D || query_stride < D)
+        return fail(SPRK_EINVAL, "emb_rank: bad sizes (need 1 <= D <= 1024, strides >= D)");
+    if (order && C > ER_MAX_SORT) return fail(SPRK_EINVAL, "emb_rank: ranking supports at most 4096 candidates per query");
+    if (n_queries == 0 || C == 0) return SPRK_OK;
+    int P = 0;
+    if (order) { P = 2; while (P < C) P <<= 1; }
+    const size_t lds = (size_t)P * 12 + (size_t)D * 4 + 16;
+    hipLaunchKernelGGL(k_emb_rank, dim3(n_queries), dim3(ER_THREADS), lds, (hipStream_t)stream, item_emb, item_has, n_items, D,
+                       item_stride, query_emb, query_has, query_stride, cand, C, P, scores, order);
+    HIP_TRY(hipGetLastError());
+    return SPRK_OK;
+}
 
 int sprk_pack_csv(const char* text, size_t len, const sprk_csv_col* id_cols, int32_t n_id, const char* const* dense_names,
                   int32_t n_dense, int32_t max_rows, int32_t* ids_out, float* dense_out, int32_t* rows_out) {

@@ -482,7 +482,9 @@ def test_din_tail_paths(torch, monkeypatch, T, D, B):
     V, U = SY.ML20M_MOVIE_IDS if D == 32 else 4000, SY.ML20M_USER_IDS if D == 32 else 900
     feats = SY.synth_din(B, T, V, U, seed=21)
     out = {}
-    for tag, env in (("chain", {"SPRK_TILE_FOLD": "1", "SPRK_DIN_TAIL": "1"}), ("fold", {"SPRK_TILE_FOLD": "1", "SPRK_DIN_TAIL": "0"}),
+    for tag, env in (("chain", {"SPRK_TILE_FOLD": "1", "SPRK_DIN_TAIL": "1", "SPRK_DYN_F16": "1"}),
+                     ("chain_f32", {"SPRK_TILE_FOLD": "1", "SPRK_DIN_TAIL": "1", "SPRK_DYN_F16": "0"}),
+                     ("fold", {"SPRK_TILE_FOLD": "1", "SPRK_DIN_TAIL": "0"}),
                      ("plain", {"SPRK_TILE_FOLD": "0", "SPRK_DIN_TAIL": "0"})):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -492,7 +494,41 @@ def test_din_tail_paths(torch, monkeypatch, T, D, B):
     for tag in out:
         assert np.abs(out[tag] - ref).max() <= TOL, tag
     assert np.abs(out["chain"] - out["plain"]).max() <= TIGHT
+    assert np.abs(out["chain_f32"] - out["plain"]).max() <= TIGHT
     assert np.abs(out["fold"] - out["plain"]).max() <= TIGHT
+
+
+@pytest.mark.parametrize("scale", [1e-4, 1.0, 300.0])
+def test_din_tail_dynamic_f16_wide_activation_range(torch, monkeypatch, scale):
+    """fc1 of k_din_tail runs on the f16 matrix pipe with a PER-SAMPLE power-of-two scale taken from the sample's
+    largest hidden activation (dyn_split.h).  Stress it where a static scale would overflow or flush: embedding
+    tables and numerics blown up / shrunk by `scale`, so the hidden activations span many binades across samples;
+    the logit before the sigmoid is the quantity compared (a saturated sigmoid would hide errors)."""
+    T, D, B = 20, 16, 2051
+    V, U = 4000, 900
+    feats = SY.synth_din(B, T, V, U, seed=23)
+    rng = np.random.default_rng(5)
+    # per-sample spread on top of the global scale: numerics over 6 decades
+    feats = dict(feats)
+    spread = (10.0 ** rng.uniform(-3, 3, size=B)).astype(np.float32)
+    for k in list(feats):
+        if np.asarray(feats[k]).dtype.kind == "f":
+            feats[k] = (np.asarray(feats[k], dtype=np.float32) * spread).astype(np.float32)
+    out = {}
+    for tag in ("1", "0"):
+        monkeypatch.setenv("SPRK_DYN_F16", tag)
+        w0 = M.DIN(seed=36, emb_dim=D, hist_len=T, movie_buckets=V, user_buckets=U).weights
+        w0 = {k: (np.asarray(w) * np.float32(scale) if k.startswith("emb/") else np.asarray(w)) for k, w in w0.items()}
+        model = M.DIN(weights=w0, emb_dim=D, hist_len=T, movie_buckets=V, user_buckets=U)
+        out[tag] = model.predict(feats)[:, 0]
+    ref = O.din_forward(feats, model.weights, dtype=np.float64, hist_len=T, movie_buckets=V, user_buckets=U)[:, 0]
+    assert np.isfinite(out["1"]).all()
+    e1, e0 = np.abs(out["1"] - ref).max(), np.abs(out["0"] - ref).max()
+    print("scale %g: dyn-f16 err %.3e, f32-MFMA err %.3e" % (scale, e1, e0))
+    if scale <= 1.0:                       # at 300x the logits reach 1e5: fp32 itself cannot hold 1e-4 on the sigmoid
+        assert e1 <= TOL and e0 <= TOL
+    # the f16-split path is no worse than twice the f32-MFMA path (+ fp32 rounding of the sigmoid)
+    assert e1 <= 2 * e0 + 2e-6
 
 
 # --------------------------------------------------------------------------------------------
