@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SPRK_ABI_VERSION 1
+#define SPRK_ABI_VERSION 2
 
 #define SPRK_OK 0
 #define SPRK_EINVAL (-1)    /* bad argument / malformed plan            */
@@ -52,7 +52,8 @@ enum sprk_model_kind {
     SPRK_MODEL_NEURALCF = 3,      /* NeuralCF.py:45-70      */
     SPRK_MODEL_DEEPFM = 4,        /* DeepFM.py:91-115       */
     SPRK_MODEL_DEEPFM_V2 = 5,     /* DeepFM_v2.py:98-157    */
-    SPRK_MODEL_DIN = 6            /* DIN.py:125-169         */
+    SPRK_MODEL_DIN = 6,           /* DIN.py:125-169         */
+    SPRK_MODEL_DIEN = 7           /* DIEN.py:114-259 (y_pred) */
 };
 
 /* Gather segments: how one sample's row of activation buffer 0 is assembled.  Together they
@@ -127,6 +128,16 @@ typedef struct sprk_din {
     int32_t alpha_slot;  /* PReLU alpha [T][hidden]                                        */
     int32_t w2_slot;     /* att1 kernel [hidden]                                           */
     float b2;            /* att1 bias                                                      */
+    /* enabled == 2: DIEN's interest-evolution stage instead (DIEN.py:163-250: Embedding mask -> GRU -> attention gate ->
+     * AUGRU; its final state [B, row_stride] is what SPRK_SEG_AUX reads).  Uses T, hist_col, cand_col, table_slot,
+     * row_stride, vocab, hidden (= 32) and the two fields below; w_slot .. b2 are ignored. */
+    int32_t emb_dim;     /* D: Embedding / GRU / AUGRU width (10 or 16)                    */
+    int32_t seq_slot;    /* packed weights, strides padded to 4 floats (Dq = pad4(D), N3 = pad4(3D)):
+                          *   GRU kernel [D][N3] | recurrent kernel [D][N3] | bias [2][N3]  (z | r | h columns, reset_after)
+                          *   | attention Dense(32) kernel [D][32] | bias [32] | Dense(1) kernel [32] | bias [4]
+                          *   | for gate in (R_t, Z_t, H_t_next): input_w kernel [D][Dq] | bias [Dq] | hidden_w kernel [D][Dq]
+                          *     | Dense_sigmoid / Dense_tanh kernel [D][Dq] | bias [Dq]
+                          *   | AUGRU initial state h0 [Dq]; the whole image zero-padded to a multiple of 64 floats */
 } sprk_din;
 
 typedef struct sprk_plan {
@@ -206,9 +217,10 @@ int sprk_forward_neuralcf(sprk_handle h, const int32_t* ids, const float* dense,
 int sprk_forward_deepfm(sprk_handle h, const int32_t* ids, const float* dense, float* out, int32_t B, void* ws, size_t ws_bytes, void* stream);
 int sprk_forward_deepfm_v2(sprk_handle h, const int32_t* ids, const float* dense, float* out, int32_t B, void* ws, size_t ws_bytes, void* stream);
 int sprk_forward_din(sprk_handle h, const int32_t* ids, const float* dense, float* out, int32_t B, void* ws, size_t ws_bytes, void* stream);
+int sprk_forward_dien(sprk_handle h, const int32_t* ids, const float* dense, float* out, int32_t B, void* ws, size_t ws_bytes, void* stream);
 
 /* DIN stage alone (DIN.py:132-158): pooled [B, row_stride] and, if att != NULL, the attention
- * weights att [B, T]. */
+ * weights att [B, T].  For a DIEN handle: the final AUGRU state [B, row_stride]; att must be NULL. */
 int sprk_din_pool(sprk_handle h, const int32_t* ids, float* pooled, float* att, int32_t B, void* stream);
 
 /* Replaces TF's assert_greater_or_equal_0 / assert_less_than_num_buckets

@@ -484,6 +484,101 @@ def din_forward(features: Dict, w: Dict[str, np.ndarray], dtype=np.float32,
     return out
 
 
+def dien_forward(features: Dict, w: Dict[str, np.ndarray], dtype=np.float32,
+                 hist_len: int = 5, movie_buckets=MOVIE_BUCKETS, user_buckets=USER_BUCKETS,
+                 return_parts: bool = False):
+    """DIEN.py:114-250, the y_pred output (the second model output, the auxiliary loss of DIEN.py:253-292, needs labels
+    and sampled negatives and is training-only).  PARITY UNPINNED: no trained DIEN checkpoint, no golden vector.
+
+    * ids as numeric columns with default 0 -> shared Embedding(1001, D, mask_zero=True) (DIEN.py:111-121,163-169).
+    * tf.keras.layers.GRU(D, return_sequences=True) (DIEN.py:173) -- TF2 defaults: reset_after=True, tanh / sigmoid,
+      kernel [D, 3D] and recurrent_kernel [D, 3D] in z | r | h order, bias [2, 3D] (input row, recurrent row):
+          z = sig(x Wz + bz + h Uz + cz)   r = sig(x Wr + br + h Ur + cr)   hh = tanh(x Wh + bh + r * (h Uh + ch))
+          h' = z * h + (1 - z) * hh
+      and, unlike DIN, the Embedding's mask IS consumed here ([TF-MEM]: the GRU is the first mask-aware layer down
+      stream of mask_zero=True; Keras' masked RNN step keeps the previous state and REPEATS the previous output --
+      zeros before the first unmasked step -- at every slot whose id is 0).  The custom layers after it do not
+      support masking, so the mask stops there.
+    * attention (DIEN.py:175-206): a_t = sigmoid(Dense(1)(sigmoid(Dense(32)(g_t * c)))) -- a plain per-slot gate in
+      (0, 1), no softmax; repeated over the D lanes.
+    * AUGRU (DIEN.py:210-250), every gate a GRU_gate_parameter: pre = input_w(g_t) + hidden_w(h) (hidden_w without
+      bias), r = sigmoid(Dense_r(pre_r)), z likewise, h~ = tanh(Dense_h(input_w_h(g_t) + hidden_w_h(h * z)));
+      u = a_t * r;  h <- (1 - u) * h + u * h~.  Note the attention scales the gate named R_t and the candidate
+      state uses Z_t -- restated as written, not as in the DIEN paper.
+      The initial state is `GlorotUniform()(shape=(1, D))` evaluated INSIDE call() (DIEN.py:239-240): the reference
+      draws a fresh random h_0 per forward pass, so its predictions are not reproducible; here h_0 is the explicit
+      weight ``augru/h0`` [1, D].
+    * tail (DIEN.py:252-259): concat [augru, candidate, user profile, context] -> Dense(128) PReLU Dense(64) PReLU
+      Dense(1, sigmoid)."""
+    if "userRatedMovies" in features:
+        hist = np.asarray(features["userRatedMovies"]).astype(np.int64)
+    else:
+        names = sorted("userRatedMovie%d" % (i + 1) for i in range(hist_len))
+        hist = np.stack([int_feature(features, n) for n in names], axis=1)
+    cand = int_feature(features, "movieId")
+    table = w["emb/movie"].astype(dtype)
+    if hist.size and (hist.min() < 0 or hist.max() >= table.shape[0]):
+        raise ValueError("history id outside [0, %d)" % table.shape[0])
+    if cand.size and (cand.min() < 0 or cand.max() >= table.shape[0]):
+        raise ValueError("movieId outside [0, %d)" % table.shape[0])
+    B, T = hist.shape
+    D = table.shape[1]
+    x = table[hist]                                                         # [B,T,D] DIEN.py:167
+    c = table[cand]                                                         # [B,D]   DIEN.py:168-171
+    mask = hist != 0                                                        # Embedding.compute_mask
+    # ---- GRU (DIEN.py:173) ----
+    Wk, Uk, bk = w["gru/kernel"].astype(dtype), w["gru_rec/kernel"].astype(dtype), w["gru/bias"].astype(dtype)
+    h = np.zeros((B, D), dtype=dtype)
+    prev_out = np.zeros((B, D), dtype=dtype)
+    g = np.zeros((B, T, D), dtype=dtype)
+    for t in range(T):
+        mx = x[:, t, :] @ Wk + bk[0]
+        mh = h @ Uk + bk[1]
+        z = sigmoid(mx[:, :D] + mh[:, :D])
+        r = sigmoid(mx[:, D:2 * D] + mh[:, D:2 * D])
+        hh = np.tanh(mx[:, 2 * D:] + r * mh[:, 2 * D:])
+        hn = z * h + (1 - z) * hh
+        m = mask[:, t][:, None]
+        h = np.where(m, hn, h)
+        prev_out = np.where(m, hn, prev_out)
+        g[:, t, :] = prev_out
+    # ---- attention gate (DIEN.py:193-203) ----
+    a = sigmoid(dense(sigmoid(dense(g * c[:, None, :], w["att0/kernel"], w["att0/bias"], dtype)),
+                      w["att1/kernel"], w["att1/bias"], dtype))[..., 0]      # [B,T]
+    # ---- AUGRU (DIEN.py:238-248) ----
+    def gate(name, gt, hid, act):
+        pre = dense(gt, w["augru_%s_in/kernel" % name], w["augru_%s_in/bias" % name], dtype) \
+            + hid @ w["augru_%s_hid/kernel" % name].astype(dtype)
+        return act(dense(pre, w["augru_%s_out/kernel" % name], w["augru_%s_out/bias" % name], dtype))
+    hs = np.repeat(w["augru/h0"].astype(dtype).reshape(1, D), B, axis=0)
+    for t in range(T):
+        gt = g[:, t, :]
+        r_t = gate("r", gt, hs, sigmoid)
+        z_t = gate("z", gt, hs, sigmoid)
+        h_next = gate("h", gt, hs * z_t, np.tanh)
+        u = a[:, t][:, None] * r_t
+        hs = (1 - u) * hs + u * h_next
+    # ---- profile / context / tail (DIEN.py:131-150,252-259) ----
+    prof_blocks = {k: numeric(features, k, dtype) for k in ["userRatingCount", "userAvgRating", "userRatingStddev"]}
+    prof_blocks["userId_embedding"] = embedding_lookup(
+        w["emb/userId"].astype(dtype), identity_ids(int_feature(features, "userId"), user_buckets, "userId"))
+    prof_blocks["userGenre1_embedding"] = embedding_lookup(w["emb/userGenre1"].astype(dtype),
+                                                           vocab_ids(features["userGenre1"]))
+    profile, _ = dense_features(prof_blocks)
+    ctx_blocks = {k: numeric(features, k, dtype) for k in
+                  ["releaseYear", "movieRatingCount", "movieAvgRating", "movieRatingStddev"]}
+    ctx_blocks["movieGenre1_embedding"] = embedding_lookup(w["emb/movieGenre1"].astype(dtype),
+                                                           vocab_ids(features["movieGenre1"]))
+    context, _ = dense_features(ctx_blocks)
+    y = np.concatenate([hs, c, profile, context], axis=1)                   # DIEN.py:252
+    y = prelu(dense(y, w["fc0/kernel"], w["fc0/bias"], dtype), w["fc0_prelu/alpha"])
+    y = prelu(dense(y, w["fc1/kernel"], w["fc1/bias"], dtype), w["fc1_prelu/alpha"])
+    out = sigmoid(dense(y, w["head/kernel"], w["head/bias"], dtype)).astype(np.float32)
+    if return_parts:
+        return out, {"augru": hs, "att": a, "gru": g}
+    return out
+
+
 FORWARDS = {
     "embedding_mlp": embedding_mlp_forward,
     "wide_n_deep": wide_n_deep_forward,
@@ -492,4 +587,5 @@ FORWARDS = {
     "deepfm": deepfm_forward,
     "deepfm_v2": deepfm_v2_forward,
     "din": din_forward,
+    "dien": dien_forward,
 }

@@ -16,13 +16,13 @@ LIB_PATH = os.path.join(_HERE, "libsparrow_hip.so")
 SRC_PATH = os.path.join(_HERE, "csrc", "sparrow_hip.hip")
 INCLUDE_DIR = os.path.join(REPO_ROOT, "include")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 TILE_M = 64
 MAX_SEGS, MAX_OPS, MAX_TAPS, MAX_PAIRS, MAX_BUFS = 40, 24, 8, 32, 3
 
 OK, EINVAL, EHIP, ESTATE, ERANGE, EKIND = 0, -1, -2, -3, -4, -5
 
-MODEL_GENERIC, MODEL_EMBEDDING_MLP, MODEL_WIDE_DEEP, MODEL_NEURALCF, MODEL_DEEPFM, MODEL_DEEPFM_V2, MODEL_DIN = range(7)
+MODEL_GENERIC, MODEL_EMBEDDING_MLP, MODEL_WIDE_DEEP, MODEL_NEURALCF, MODEL_DEEPFM, MODEL_DEEPFM_V2, MODEL_DIN, MODEL_DIEN = range(8)
 SEG_ROWS, SEG_SCALAR, SEG_DENSE, SEG_ZERO, SEG_CROSS_SCALAR, SEG_CROSS_ROWS, SEG_AUX = range(7)
 OP_DENSE, OP_FM_SUMSQ, OP_PAIR_DOT = range(3)
 ACT_NONE, ACT_RELU, ACT_PRELU = range(3)
@@ -31,7 +31,7 @@ ACT_NONE, ACT_RELU, ACT_PRELU = range(3)
 EXPORTED_SYMBOLS = [
     "sprk_runtime_info", "sprk_create", "sprk_upload", "sprk_finalize", "sprk_workspace_bytes",
     "sprk_forward", "sprk_forward_many", "sprk_forward_embedding_mlp", "sprk_forward_widedeep", "sprk_forward_neuralcf",
-    "sprk_forward_deepfm", "sprk_forward_deepfm_v2", "sprk_forward_din", "sprk_din_pool",
+    "sprk_forward_deepfm", "sprk_forward_deepfm_v2", "sprk_forward_din", "sprk_forward_dien", "sprk_din_pool",
     "sprk_check_ids", "sprk_debug_set_trace", "sprk_destroy", "sprk_embedding_gather", "sprk_cross_hash", "sprk_last_error",
     "sprk_pack_csv", "sprk_set_many_streams", "sprk_emb_rank",
 ]
@@ -62,7 +62,8 @@ class Din(C.Structure):
     _fields_ = [("enabled", C.c_int32), ("T", C.c_int32), ("hist_col", C.c_int32), ("cand_col", C.c_int32),
                 ("table_slot", C.c_int32), ("row_stride", C.c_int32), ("vocab", C.c_int32),
                 ("hidden", C.c_int32), ("w_slot", C.c_int32), ("b_slot", C.c_int32),
-                ("alpha_slot", C.c_int32), ("w2_slot", C.c_int32), ("b2", C.c_float)]
+                ("alpha_slot", C.c_int32), ("w2_slot", C.c_int32), ("b2", C.c_float),
+                ("emb_dim", C.c_int32), ("seq_slot", C.c_int32)]
 
 
 class Plan(C.Structure):

@@ -612,6 +612,7 @@ __global__ __launch_bounds__(256) void k_zero_columns(float* __restrict__ Wt, in
 #include "k_chain_v1.h"
 #include "k_mlp_chain.h"
 #include "k_emb_rank.h"
+#include "k_dien_seq.h"
 
 // ---------------------------------------------------------------------------------------------
 // stand-alone operators
@@ -680,6 +681,7 @@ struct sprk_engine {
     int din_grid_cap = 0;
     // wave-per-sample attention kernel (k_din_attn); -1 = the generic k_din_pool
     int din_variant = -1;
+    DienRun dien_run{};
     DinRun din_run;
     float* din_w12 = nullptr;      // (W1+W2)^T, W4^T fragments and the per-id c-term table (device)
     float* din_w4 = nullptr;
@@ -803,8 +805,18 @@ int validate_plan(const sprk_plan& p) {
         if (t.buf < 0 || t.buf >= p.n_bufs || t.off < 0 || t.len <= 0 || t.off + t.len > p.buf_width[t.buf]) return fail(SPRK_EINVAL, "tap %d outside its buffer", i);
         if (check_slot(p, t.w_slot, true, "tap weights")) return SPRK_EINVAL;
     }
-    if (p.din.enabled) {
+    if (p.din.enabled == 2) {
         const sprk_din& d = p.din;
+        if (d.T <= 0 || d.T > 256) return fail(SPRK_EINVAL, "DIEN history length %d outside [1,256]", d.T);
+        if (d.hist_col < 0 || d.hist_col + d.T > p.n_id_cols || d.cand_col < 0 || d.cand_col >= p.n_id_cols) return fail(SPRK_EINVAL, "DIEN ids columns out of range");
+        if (d.row_stride <= 0 || (d.row_stride & 3) || d.vocab <= 0) return fail(SPRK_EINVAL, "DIEN bad table geometry");
+        if ((d.emb_dim != 10 && d.emb_dim != 16) || d.emb_dim > d.row_stride) return fail(SPRK_EINVAL, "DIEN emb_dim %d: instantiated for 10 and 16", d.emb_dim);
+        if (d.hidden != 32) return fail(SPRK_EINVAL, "DIEN attention width must be 32 (DIEN.py:184)");
+        if (p.n_aux != d.row_stride) return fail(SPRK_EINVAL, "DIEN: n_aux (%d) must equal row_stride (%d)", p.n_aux, d.row_stride);
+        if (check_slot(p, d.table_slot, false, "DIEN table") || check_slot(p, d.seq_slot, false, "DIEN sequence weights")) return SPRK_EINVAL;
+    } else if (p.din.enabled) {
+        const sprk_din& d = p.din;
+        if (p.din.enabled != 1) return fail(SPRK_EINVAL, "din.enabled must be 0, 1 (DIN) or 2 (DIEN)");
         if (d.T <= 0 || d.T > 256) return fail(SPRK_EINVAL, "DIN history length %d outside [1,256]", d.T);
         if (d.hist_col < 0 || d.hist_col + d.T > p.n_id_cols || d.cand_col < 0 || d.cand_col >= p.n_id_cols) return fail(SPRK_EINVAL, "DIN ids columns out of range");
         if (d.row_stride <= 0 || (d.row_stride & 3) || d.vocab <= 0) return fail(SPRK_EINVAL, "DIN bad table geometry");
@@ -1527,7 +1539,7 @@ int setup_din_tail(sprk_engine* h, DevPlan* dp) {
     const char* sw = getenv("SPRK_DIN_TAIL");                // A/B switch: "0" = tile interpreter
     if (sw && sw[0] == '0') return SPRK_OK;
     const sprk_plan& p = h->plan;
-    if (!p.din.enabled || p.model_kind != SPRK_MODEL_DIN || dp->n_ops != 2 || dp->n_taps != 1) return SPRK_OK;
+    if (!p.din.enabled || (p.model_kind != SPRK_MODEL_DIN && p.model_kind != SPRK_MODEL_DIEN) || dp->n_ops != 2 || dp->n_taps != 1) return SPRK_OK;
     if (dp->n_acc < 1 || dp->n_acc > DT_MAX_COLS) return SPRK_OK;
     const DevOp &o0 = dp->ops[0], &o1 = dp->ops[1];
     if (o0.kind != SPRK_OP_DENSE || o1.kind != SPRK_OP_DENSE || o0.act != SPRK_ACT_PRELU || o1.act != SPRK_ACT_PRELU) return SPRK_OK;
@@ -1737,7 +1749,19 @@ int sprk_finalize(sprk_handle h) {
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, h->device));
     h->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    if (p.din.enabled) {
+    if (p.din.enabled == 2) {
+        const sprk_din& s = p.din;
+        DevDin& d = dp->din;
+        d.enabled = 1; d.T = s.T; d.hist_col = s.hist_col; d.cand_col = s.cand_col; d.row_stride = s.row_stride; d.vocab = s.vocab; d.hidden = s.hidden;
+        const size_t img = s.emb_dim == 10 ? DienLayout<10, 32>::total_pad : DienLayout<16, 32>::total_pad;
+        if ((rc = need_bytes(h, s.table_slot, (size_t)s.vocab * s.row_stride * 4, "DIEN table"))) return rc;
+        if ((rc = need_bytes(h, s.seq_slot, img * 4, "DIEN sequence weights"))) return rc;
+        d.table = (const float*)h->slot_ptr[s.table_slot];
+        h->dien_run.T = s.T; h->dien_run.F = p.n_id_cols; h->dien_run.hist_col = s.hist_col; h->dien_run.cand_col = s.cand_col;
+        h->dien_run.Dp = s.row_stride; h->dien_run.vocab = s.vocab; h->dien_run.NA = p.n_aux;
+        h->dien_run.table = d.table;
+        h->dien_run.image = (const float*)h->slot_ptr[s.seq_slot];
+    } else if (p.din.enabled) {
         const sprk_din& s = p.din;
         DevDin& d = dp->din;
         d.enabled = 1; d.T = s.T; d.hist_col = s.hist_col; d.cand_col = s.cand_col; d.row_stride = s.row_stride; d.vocab = s.vocab; d.hidden = s.hidden; d.b2 = s.b2;
@@ -1920,6 +1944,17 @@ size_t sprk_workspace_bytes(sprk_handle h, int32_t B) {
 }
 
 static int launch_din(sprk_handle h, const int32_t* ids, float* pooled, float* att, int32_t B, hipStream_t st) {
+    if (h->plan.din.enabled == 2) {                               // DIEN: GRU -> attention gate -> AUGRU, one lane per sample
+        if (att) return fail(SPRK_EINVAL, "DIEN stage has no attention output");
+        int grid = (B + 63) / 64;
+        if (grid > h->num_cus * 8) grid = h->num_cus * 8;
+        if (h->plan.din.emb_dim == 10)
+            hipLaunchKernelGGL((k_dien_seq<10, 32>), dim3(grid), dim3(64), 0, st, h->dien_run, ids, pooled, B, h->dev_err);
+        else
+            hipLaunchKernelGGL((k_dien_seq<16, 32>), dim3(grid), dim3(64), 0, st, h->dien_run, ids, pooled, B, h->dev_err);
+        HIP_TRY(hipGetLastError());
+        return SPRK_OK;
+    }
     if (h->din_variant >= 0) {
         int grid = (B + 3) / 4;
         if (grid > h->din_attn_grid_cap) grid = h->din_attn_grid_cap;
@@ -2057,6 +2092,7 @@ SPRK_FORWARD_KIND(sprk_forward_neuralcf, SPRK_MODEL_NEURALCF)
 SPRK_FORWARD_KIND(sprk_forward_deepfm, SPRK_MODEL_DEEPFM)
 SPRK_FORWARD_KIND(sprk_forward_deepfm_v2, SPRK_MODEL_DEEPFM_V2)
 SPRK_FORWARD_KIND(sprk_forward_din, SPRK_MODEL_DIN)
+SPRK_FORWARD_KIND(sprk_forward_dien, SPRK_MODEL_DIEN)
 
 int sprk_set_many_streams(sprk_handle h, int32_t n) {
     if (!h) return fail(SPRK_EINVAL, "handle is NULL");

@@ -206,6 +206,8 @@ class CTRModel:
             elif name.endswith("/alpha"):
                 out[name] = rng.uniform(0.0, 0.5, size=shape).astype(np.float32) if trained_like \
                     else np.zeros(shape, np.float32)
+            elif name.endswith("/h0"):
+                out[name] = _glorot(rng, shape)                    # GlorotUniform()(shape=(1, D)), DIEN.py:239-240
             else:
                 raise ValueError("unknown weight kind %r" % name)
         if trained_like:
@@ -763,8 +765,12 @@ class DIN(CTRModel):
         pb.n_aux = Dp
         pb.din = L.Din(1, T, pb.col(self._hist_keys()[0]), pb.col("movieId"), pb.slot(movie_tab), Dp,
                        self.movie_buckets, Hp, pb.slot(a0), pb.slot(b0), pb.slot(al), pb.slot(w2),
-                       float(w["att1/bias"][0]))
-        # ---- tail (k_tile_forward) ----
+                       float(w["att1/bias"][0]), 0, 0)
+        self._compile_tail(pb, w, movie_tab)
+
+    def _compile_tail(self, pb, w, movie_tab):
+        """concat -> Dense PReLU Dense PReLU Dense(1, sigmoid) (DIN.py:161-167, DIEN.py:252-259)."""
+        D, Dp = self.emb_dim, pad4(self.emb_dim)
         rows, fan = self._fc_rows()
         x_of = {}
         # LDS layout of the tail's input: the four embedding columns first, then the per-sample data (pooled
@@ -790,3 +796,93 @@ class DIN(CTRModel):
         buf, n = _mlp_stack(pb, w, names, 0, 0, K0, xmap, [L.ACT_PRELU] * len(names), alphas)
         pb.tap(buf, 0, n, w["head/kernel"][:n, 0])
         pb.head_bias = float(w["head/bias"][0])
+
+
+class DIEN(DIN):
+    """DIEN.py:114-259, the y_pred output: shared movie Embedding (mask_zero consumed by the GRU) -> GRU ->
+    per-slot attention gate -> AUGRU -> concat [augru, candidate, user profile, context] -> Dense(128) PReLU
+    Dense(64) PReLU Dense(1, sigmoid).  The auxiliary-loss output (DIEN.py:253-292) is training-only and not built.
+
+    The reference draws the AUGRU's initial state from GlorotUniform INSIDE call() (DIEN.py:239-240), i.e. a new
+    random vector per forward pass; here it is the explicit weight ``augru/h0`` [1, D] so predictions are
+    reproducible.  Instantiated for emb_dim 10 (the reference) and 16."""
+    MODEL_KIND = L.MODEL_DIEN
+    FORWARD_SYMBOL = "sprk_forward_dien"
+    GATES = ("r", "z", "h")                                       # R_t, Z_t, H_t_next (DIEN.py:233-236)
+
+    def __init__(self, weights=None, seed=None, emb_dim=10, hist_len=5, att_hidden=32, hidden=(128, 64),
+                 movie_buckets=MOVIE_BUCKETS, user_buckets=USER_BUCKETS):
+        if emb_dim not in (10, 16) or att_hidden != 32:
+            raise ValueError("DIEN: emb_dim 10 or 16, attention width 32")
+        super().__init__(weights, seed, emb_dim, hist_len, att_hidden, hidden, movie_buckets, user_buckets)
+
+    def _fc_rows(self):
+        """Input-row index of every block of the tail's concat (DIEN.py:252): augru, candidate, profile, context."""
+        D = self.emb_dim
+        rows, r = {"__pooled__": (0, D), "__cand__": (D, D)}, 2 * D
+        prof = {k: 1 for k in self._PROFILE_NUM}
+        prof.update({"userId_embedding": D, "userGenre1_embedding": D})
+        for n in sorted(prof):
+            rows[n] = (r, prof[n])
+            r += prof[n]
+        ctx = {k: 1 for k in self._CONTEXT_NUM}
+        ctx["movieGenre1_embedding"] = D
+        for n in sorted(ctx):
+            rows[n] = (r, ctx[n])
+            r += ctx[n]
+        return rows, r
+
+    def weight_shapes(self):
+        D, H = self.emb_dim, self.att_hidden
+        s = {"emb/movie": (self.movie_buckets, D), "emb/userId": (self.user_buckets, D),
+             "emb/userGenre1": (N_GENRES, D), "emb/movieGenre1": (N_GENRES, D),
+             "gru/kernel": (D, 3 * D), "gru_rec/kernel": (D, 3 * D), "gru/bias": (2, 3 * D),
+             "att0/kernel": (D, H), "att0/bias": (H,), "att1/kernel": (H, 1), "att1/bias": (1,)}
+        for g in self.GATES:
+            s["augru_%s_in/kernel" % g] = (D, D)
+            s["augru_%s_in/bias" % g] = (D,)
+            s["augru_%s_hid/kernel" % g] = (D, D)
+            s["augru_%s_out/kernel" % g] = (D, D)
+            s["augru_%s_out/bias" % g] = (D,)
+        s["augru/h0"] = (1, D)
+        _, fan = self._fc_rows()
+        for i, h in enumerate(self.hidden):
+            s["fc%d/kernel" % i] = (fan, h)
+            s["fc%d/bias" % i] = (h,)
+            s["fc%d_prelu/alpha" % i] = (h,)
+            fan = h
+        s["head/kernel"] = (fan, 1)
+        s["head/bias"] = (1,)
+        return s
+
+    def _seq_image(self, w):
+        """The packed sequence-stage weights, layout of include/sparrow_hip.h sprk_din.seq_slot (k_dien_seq.h)."""
+        D, H = self.emb_dim, self.att_hidden
+        Dq, N3 = pad4(D), pad4(3 * D)
+
+        def mat(a, stride):
+            out = np.zeros((a.shape[0], stride), np.float32)
+            out[:, :a.shape[1]] = a
+            return out.ravel()
+
+        def vec(a, n):
+            out = np.zeros(n, np.float32)
+            out[:a.size] = np.asarray(a, np.float32).ravel()
+            return out
+        parts = [mat(w["gru/kernel"], N3), mat(w["gru_rec/kernel"], N3), mat(w["gru/bias"], N3),
+                 mat(w["att0/kernel"], H), vec(w["att0/bias"], H), vec(w["att1/kernel"], H), vec(w["att1/bias"], 4)]
+        for g in self.GATES:
+            parts += [mat(w["augru_%s_in/kernel" % g], Dq), vec(w["augru_%s_in/bias" % g], Dq),
+                      mat(w["augru_%s_hid/kernel" % g], Dq), mat(w["augru_%s_out/kernel" % g], Dq),
+                      vec(w["augru_%s_out/bias" % g], Dq)]
+        parts.append(vec(w["augru/h0"], Dq))
+        img = np.concatenate(parts)
+        return np.concatenate([img, np.zeros((-img.size) % 64, np.float32)])
+
+    def _compile(self, pb, w):
+        D, Dp, T = self.emb_dim, pad4(self.emb_dim), self.hist_len
+        movie_tab = pad_table(w["emb/movie"])
+        pb.n_aux = Dp
+        pb.din = L.Din(2, T, pb.col(self._hist_keys()[0]), pb.col("movieId"), pb.slot(movie_tab), Dp,
+                       self.movie_buckets, self.att_hidden, 0, 0, 0, 0, 0.0, D, pb.slot(self._seq_image(w)))
+        self._compile_tail(pb, w, movie_tab)

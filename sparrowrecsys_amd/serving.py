@@ -235,14 +235,14 @@ class PredictServer:
 def _main():
     from . import models as M
     ap = argparse.ArgumentParser(description=__doc__.split("\n\n")[0])
-    ap.add_argument("--model", default="neuralcf", choices=["neuralcf", "embedding_mlp", "wide_n_deep", "deepfm", "deepfm_v2", "din"])
+    ap.add_argument("--model", default="neuralcf", choices=["neuralcf", "embedding_mlp", "wide_n_deep", "deepfm", "deepfm_v2", "din", "dien"])
     ap.add_argument("--weights", help=".npz of reference-layout weights (keys as CTRModel.weight_shapes()); default: seeded random")
     ap.add_argument("--name", default="recmodel")
     ap.add_argument("--host", default="127.0.0.1")
     ap.add_argument("--port", type=int, default=8501)
     args = ap.parse_args()
     cls = {"neuralcf": M.NeuralCF, "embedding_mlp": M.EmbeddingMLP, "wide_n_deep": M.WideNDeep, "deepfm": M.DeepFM,
-           "deepfm_v2": M.DeepFMv2, "din": M.DIN}[args.model]
+           "deepfm_v2": M.DeepFMv2, "din": M.DIN, "dien": M.DIEN}[args.model]
     weights = dict(np.load(args.weights)) if args.weights else None
     model = cls(weights=weights, seed=None if weights else 0)
     model.engine                                           # fail loudly now if the HIP library / device is missing

@@ -58,11 +58,66 @@ def din_pool(plan, slots, ids, dtype=np.float64):
     return pooled, att
 
 
+def _sig(x):
+    return 1.0 / (1.0 + np.exp(-x))
+
+
+def dien_seq(plan, slots, ids, dtype=np.float64):
+    """DIEN stage (din.enabled == 2) from the PACKED weight image, layout as documented in include/sparrow_hip.h
+    (sprk_din.seq_slot) -- parsed here independently of models.DIEN._seq_image."""
+    d = plan.din
+    T, Dp, D, H = d.T, d.row_stride, d.emb_dim, d.hidden
+    Dq, N3 = (D + 3) // 4 * 4, (3 * D + 3) // 4 * 4
+    img = _slot(slots, d.seq_slot).astype(dtype)
+    pos = [0]
+
+    def take(rows, stride, cols):
+        a = img[pos[0]:pos[0] + rows * stride].reshape(rows, stride)[:, :cols]
+        pos[0] += rows * stride
+        return a
+    Wk, Uk, bk = take(D, N3, 3 * D), take(D, N3, 3 * D), take(2, N3, 3 * D)
+    A0, a0b, a1, a1b = take(D, H, H), take(1, H, H)[0], take(1, H, H)[0], take(1, 4, 1)[0, 0]
+    gates = []
+    for _ in range(3):
+        gates.append((take(D, Dq, D), take(1, Dq, D)[0], take(D, Dq, D), take(D, Dq, D), take(1, Dq, D)[0]))
+    h0 = take(1, Dq, D)[0]
+    assert (-pos[0]) % 64 + pos[0] == img.size
+    table = _slot(slots, d.table_slot).reshape(-1, Dp).astype(dtype)[:, :D]
+    hist = ids[:, d.hist_col:d.hist_col + T]
+    c = table[ids[:, d.cand_col]]
+    B = ids.shape[0]
+    h = np.zeros((B, D), dtype)
+    g = np.zeros((B, D), dtype)
+    hs = np.repeat(h0[None, :], B, axis=0)
+
+    def gate(k, gt, hid, act):
+        ik, ib, hk, ok, ob = gates[k]
+        return act((gt @ ik + ib + hid @ hk) @ ok + ob)
+    for t in range(T):
+        x = table[hist[:, t]]
+        mx, mh = x @ Wk + bk[0], h @ Uk + bk[1]
+        z, r = _sig(mx[:, :D] + mh[:, :D]), _sig(mx[:, D:2 * D] + mh[:, D:2 * D])
+        hn = z * h + (1 - z) * np.tanh(mx[:, 2 * D:] + r * mh[:, 2 * D:])
+        live = (hist[:, t] != 0)[:, None]
+        h = np.where(live, hn, h)
+        g = np.where(live, hn, g)
+        a = _sig(_sig((g * c) @ A0 + a0b) @ a1 + a1b)[:, None]
+        r_t, z_t = gate(0, g, hs, _sig), gate(1, g, hs, _sig)
+        hnext = gate(2, g, hs * z_t, np.tanh)
+        u = a * r_t
+        hs = (1 - u) * hs + u * hnext
+    out = np.zeros((B, Dp), dtype)
+    out[:, :D] = hs
+    return out
+
+
 def run_plan(plan, slots, ids, dense, dtype=np.float64):
     """-> scores [B] (float64/32).  ids [B,F] int, dense [B,N] float."""
     B = ids.shape[0] if plan.n_id_cols else dense.shape[0]
     aux = None
-    if plan.din.enabled:
+    if plan.din.enabled == 2:
+        aux = dien_seq(plan, slots, ids, dtype)
+    elif plan.din.enabled:
         aux, _ = din_pool(plan, slots, ids, dtype)
     bufs = [np.full((B, plan.buf_width[i]), np.nan, dtype=dtype) for i in range(plan.n_bufs)]
     for i in range(plan.n_segs):

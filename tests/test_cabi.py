@@ -30,8 +30,8 @@ def test_header_constants_match_ctypes_mirror():
             int(consts["SPRK_MAX_PAIRS"]), int(consts["SPRK_MAX_BUFS"])) == (L.MAX_SEGS, L.MAX_OPS, L.MAX_TAPS, L.MAX_PAIRS, L.MAX_BUFS)
     assert (int(consts["SPRK_EINVAL"]), int(consts["SPRK_ERANGE"]), int(consts["SPRK_EKIND"])) == (L.EINVAL, L.ERANGE, L.EKIND)
     # struct sizes: all-int32/float members, so size = 4 * member count
-    assert C.sizeof(L.Seg) == 32 and C.sizeof(L.Op) == 56 and C.sizeof(L.Tap) == 24 and C.sizeof(L.Din) == 52
-    assert C.sizeof(L.Plan) == 4 * (7 + 3 + 1 + 1 + 1 + 2 * L.MAX_PAIRS + 1 + 1) + 32 * L.MAX_SEGS + 56 * L.MAX_OPS + 24 * L.MAX_TAPS + 52
+    assert C.sizeof(L.Seg) == 32 and C.sizeof(L.Op) == 56 and C.sizeof(L.Tap) == 24 and C.sizeof(L.Din) == 60
+    assert C.sizeof(L.Plan) == 4 * (7 + 3 + 1 + 1 + 1 + 2 * L.MAX_PAIRS + 1 + 1) + 32 * L.MAX_SEGS + 56 * L.MAX_OPS + 24 * L.MAX_TAPS + 60
 
 
 def test_runtime_info_without_compute(lib):
@@ -48,7 +48,7 @@ def _create(lib, plan):
     return rc
 
 
-@pytest.mark.parametrize("model", [M.EmbeddingMLP, M.WideNDeep, M.NeuralCF, M.DeepFM, M.DeepFMv2, M.DIN])
+@pytest.mark.parametrize("model", [M.EmbeddingMLP, M.WideNDeep, M.NeuralCF, M.DeepFM, M.DeepFMv2, M.DIN, M.DIEN])
 def test_valid_plans_pass_validation(lib, model):
     plan, _ = model(seed=1).build_plan()
     assert _create(lib, plan) == 0, lib.sprk_last_error()

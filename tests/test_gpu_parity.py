@@ -652,3 +652,54 @@ def test_mlp_chain_vs_interpreter_and_oracle(torch, monkeypatch, kind):
     assert np.abs(out["1"] - ref).max() <= TIGHT
     assert np.abs(out["0"] - ref).max() <= TIGHT
     assert 0.02 < ref.std()
+
+
+# --------------------------------------------------------------------------------------------
+# DIEN (DIEN.py:163-259): k_dien_seq (GRU with the Embedding mask -> attention gate -> AUGRU) + the DIN tail kernels
+# --------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("D,T,B,holes", [(10, 5, 4099, "tail"), (16, 20, 1000, "anywhere"), (10, 50, 777, "anywhere"),
+                                         (10, 1, 65, "tail"), (16, 5, 1, "tail")])
+def test_dien_vs_oracle(torch, monkeypatch, D, T, B, holes):
+    V, U = 3000, 900
+    feats = SY.synth_din(B, T, V, U, seed=300 + T)
+    h = feats["userRatedMovies"]
+    if holes == "anywhere":
+        h[np.random.default_rng(T).random(h.shape) < 0.3] = 0
+    h[0] = 0                                                         # no history at all
+    if B > 2:
+        h[2, :T // 2] = 0                                            # leading holes
+    out = {}
+    for tail in ("1", "0"):
+        monkeypatch.setenv("SPRK_DIN_TAIL", tail)
+        model = M.DIEN(seed=61, emb_dim=D, hist_len=T, movie_buckets=V, user_buckets=U)
+        ids, dense = model.pack(feats)
+        eng = model.engine
+        aux = torch.full((B, eng.n_aux), float("nan"), dtype=torch.float32, device="cuda")
+        eng.din_pool(_cuda(torch, ids), aux, None)
+        eng.check_ids()
+        out[tail] = (aux.cpu().numpy(), model.predict(feats)[:, 0])
+    ref, parts = O.dien_forward(feats, model.weights, dtype=np.float64, hist_len=T, movie_buckets=V, user_buckets=U,
+                                return_parts=True)
+    for tail in out:
+        a, sc = out[tail]
+        assert np.abs(a[:, :D] - parts["augru"]).max() <= TIGHT
+        assert not a[:, D:].any()
+        assert np.abs(sc - ref[:, 0]).max() <= TOL
+    assert np.abs(out["1"][1] - out["0"][1]).max() <= TIGHT
+
+
+def test_dien_reference_schema_and_bad_ids(torch, samples):
+    model = M.DIEN(seed=6)
+    got = model.predict(samples)[:, 0]
+    ref = O.dien_forward(samples, model.weights, dtype=np.float64)[:, 0]
+    assert np.abs(got - ref).max() <= TOL
+    ids, dense = model.pack(samples)
+    bad = ids.copy()
+    bad[100, 3] = 1001                                               # a history id outside Embedding(1001, ...)
+    eng = model.engine
+    aux = torch.empty((256, eng.n_aux), dtype=torch.float32, device="cuda")
+    eng.din_pool(_cuda(torch, bad), aux, None)
+    with pytest.raises(ValueError):
+        eng.check_ids()
+    with pytest.raises(L.SparrowHipError):                           # DIEN has no attention-weights output
+        eng.din_pool(_cuda(torch, ids), aux, torch.empty((256, 5), dtype=torch.float32, device="cuda"))
