@@ -2219,6 +2219,19 @@ int sprk_emb_rank(const float* item_emb, const uint8_t* item_has, int32_t n_item
         return fail(SPRK_EINVAL, "emb_rank: bad sizes (need 1 <= D <= 1024, strides >= D)");
     if (order && C > ER_MAX_SORT) return fail(SPRK_EINVAL, "emb_rank: ranking supports at most 4096 candidates per query");
     if (n_queries == 0 || C == 0) return SPRK_OK;
+    if (order && C <= 1024 && !getenv("SPRK_EMB_RANK_GENERIC")) {   // one wave per query, bitonic network in registers
+        const int grid = (n_queries + ERW_WAVES - 1) / ERW_WAVES;
+        const int E = C <= 256 ? 4 : 16;
+        const size_t lds_w = (size_t)ERW_WAVES * 64 * E * 8 + (size_t)ERW_WAVES * D * 4;
+        if (E == 4)
+            hipLaunchKernelGGL(k_emb_rank_wave<4>, dim3(grid), dim3(ERW_WAVES * 64), lds_w, (hipStream_t)stream, item_emb, item_has,
+                               n_items, D, item_stride, query_emb, query_has, n_queries, query_stride, cand, C, scores, order);
+        else
+            hipLaunchKernelGGL(k_emb_rank_wave<16>, dim3(grid), dim3(ERW_WAVES * 64), lds_w, (hipStream_t)stream, item_emb, item_has,
+                               n_items, D, item_stride, query_emb, query_has, n_queries, query_stride, cand, C, scores, order);
+        HIP_TRY(hipGetLastError());
+        return SPRK_OK;
+    }
     int P = 0;
     if (order) { P = 2; while (P < C) P <<= 1; }
     const size_t lds = (size_t)P * 12 + (size_t)D * 4 + 16;

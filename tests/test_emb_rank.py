@@ -70,7 +70,7 @@ def _case(Q, C, N, D, seed):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("Q,C,N,D", [(1, 800, 881, 10), (37, 800, 881, 10), (5, 1, 3, 10), (3, 4096, 20000, 32), (16, 1000, 1001, 7)])
+@pytest.mark.parametrize("Q,C,N,D", [(1, 800, 881, 10), (37, 800, 881, 10), (5, 1, 3, 10), (3, 4096, 20000, 32), (16, 1000, 1001, 7), (9, 256, 300, 10), (6, 257, 300, 16), (3, 1024, 5000, 10), (2, 1025, 5000, 10)])
 def test_emb_rank_bit_exact(Q, C, N, D):
     import torch
     from sparrowrecsys_amd.ranker import EmbRanker
@@ -84,9 +84,43 @@ def test_emb_rank_bit_exact(Q, C, N, D):
     assert np.array_equal(np.isnan(got), nan)
     assert np.array_equal(got[~nan].view(np.uint64), want[~nan].view(np.uint64))      # bit-exact doubles
     assert np.array_equal(order.cpu().numpy(), EO.rank(want))
+    os.environ["SPRK_EMB_RANK_GENERIC"] = "1"                           # the one-workgroup-per-query LDS kernel
+    try:
+        s3, o3 = r.score_many(q, cand, qh)
+    finally:
+        os.environ.pop("SPRK_EMB_RANK_GENERIC", None)
+    assert np.array_equal(s3.cpu().numpy().view(np.uint64), got.view(np.uint64)) and np.array_equal(o3.cpu().numpy(), order.cpu().numpy())
     # scores only (no ranking) takes the same path
     s2, o2 = r.score_many(q, cand, qh, want_order=False)
     assert o2 is None and np.array_equal(s2.cpu().numpy().view(np.uint64), got.view(np.uint64))
+
+
+@pytest.mark.gpu
+def test_emb_rank_near_ties_take_the_exact_path():
+    """Scores that agree in the upper 52 bits of their keys but differ below (cos of (1, k 1e-7) against (1, 0):
+    1 - 5e-15 k^2): the one-word register sort would order them by position; the kernel must detect it and rank exactly.
+    Also the generic LDS kernel (SPRK_EMB_RANK_GENERIC) must agree."""
+    import torch
+    from sparrowrecsys_amd.ranker import EmbRanker
+    N = 300
+    items = np.zeros((N, 2), dtype=np.float32)
+    items[:, 0] = 1.0
+    items[:, 1] = (1e-7 * np.arange(N, 0, -1)).astype(np.float32)      # candidate order = ASCENDING score
+    q = np.array([[1.0, 0.0], [0.5, 0.0]], dtype=np.float32)
+    cand = np.tile(np.arange(N, dtype=np.int32), (2, 1))
+    want = EO.scores(items, None, q, None, cand)
+    assert len(np.unique(want[0])) > N // 2 and np.ptp(want[0]) < 1e-9
+    r = EmbRanker({i: items[i] for i in range(N)})
+    for generic in (False, True):
+        if generic:
+            os.environ["SPRK_EMB_RANK_GENERIC"] = "1"
+        try:
+            scores, order = r.score_many(q, cand)
+        finally:
+            os.environ.pop("SPRK_EMB_RANK_GENERIC", None)
+        assert np.array_equal(scores.cpu().numpy().view(np.uint64), want.view(np.uint64))
+        assert np.array_equal(order.cpu().numpy(), EO.rank(want))
+    assert EO.rank(want)[0, 0] != 0                                      # the order really is not the position order
 
 
 @pytest.mark.gpu
