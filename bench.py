@@ -147,7 +147,7 @@ def main():
     ap.add_argument("--dist", default="uniform", choices=["uniform", "zipf", "hot"], help="id distribution")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget (0 = skip)")
     ap.add_argument("--no-check", action="store_true", help="skip the oracle spot check of the outputs")
-    ap.add_argument("--gather-group", type=int, default=16,
+    ap.add_argument("--gather-group", type=int, default=64,
                     help="N>1: batches whose score slices share one RCCL all-gather (overlapped with the next group)")
     ap.add_argument("--overlap-streams", type=int, default=2,
                     help="fan sprk_forward_many's independent batches over S helper HIP streams (2..4; 0 = strict stream order) in "
@@ -176,8 +176,14 @@ def main():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
     local_dev = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_dev)
-    if world > 1:
+    # SPRK_BENCH_FORCE_DIST=1: run the N>1 code path (process group, grouped all-gather on the side stream) with
+    # WORLD_SIZE 1 -- a functional check of the RCCL calls on a one-GPU box
+    dist_on = world > 1 or os.environ.get("SPRK_BENCH_FORCE_DIST") == "1"
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_dev))
         else:
@@ -195,9 +201,11 @@ def main():
     outs = [torch.empty(B, dtype=torch.float32, device="cuda") for _ in range(NB)]
     ws = torch.empty(max(eng.many_workspace_bytes(B, max(fan, 1)) // 4, 1), dtype=torch.float32, device="cuda")
     gs = None
-    if world > 1:
+    if dist_on:
         from sparrowrecsys_amd.dist import GroupedScoreGather
         gs = GroupedScoreGather(B, max(1, args.gather_group), torch.device("cuda", local_dev))
+
+    group_run = [None, None]
 
     def run_steps(first, count):
         """`count` steps starting at step index `first`.  One sprk_forward_many call enqueues a run of
@@ -206,12 +214,23 @@ def main():
         each full group of --gather-group steps is exchanged by ONE RCCL all-gather on a second stream
         while the next group is scored (a per-step all-gather of 256 KiB costs more launch latency than
         the forward it follows)."""
-        if world == 1:
+        if gs is None:
             idx = [i % NB for i in range(first, first + count)]
             eng.forward_many([batches[j][0] for j in idx], [batches[j][1] for j in idx], [outs[j] for j in idx], ws)
             return
         i = first
         while i < first + count:
+            if gs.fill == 0 and first + count - i >= gs.G:
+                # a whole group: prepared pointer arrays (one per ring slot), one foreign call, one collective
+                slot = gs.slot
+                outs_g = gs.group_outs()
+                if group_run[slot] is None:
+                    idx = [j % NB for j in range(gs.G)]
+                    group_run[slot] = eng.prepare_many([batches[j][0] for j in idx], [batches[j][1] for j in idx], outs_g, ws)
+                group_run[slot](stream=torch.cuda.current_stream().cuda_stream)
+                gs.commit()
+                i += gs.G
+                continue
             n = min(gs.G - gs.fill, first + count - i)
             idx = [j % NB for j in range(i, i + n)]
             eng.forward_many([batches[j][0] for j in idx], [batches[j][1] for j in idx], [gs.out() for _ in idx], ws)
@@ -223,7 +242,7 @@ def main():
         if gs is not None:
             gs.flush()                     # exchange a partial group, wait for every collective
         torch.cuda.synchronize()
-        if world > 1:
+        if dist_on:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -240,7 +259,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     ev_ms = ev0.elapsed_time(ev1)
-    if world > 1:
+    if dist_on:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -249,7 +268,7 @@ def main():
     # time, what rocprofv3's per-kernel duration measures), re-timed right after the timed region whenever that region
     # overlapped launches (fan-out) or held the all-gathers (N>1)
     region = "timed region"
-    if world > 1 or fan:
+    if dist_on or fan:
         region = "strict-order forward loop after the timed region"
         if fan:
             eng.set_many_streams(0)
@@ -267,7 +286,7 @@ def main():
     # output spot check against the oracle (outside the timed region)
     check = None
     if rank == 0 and not args.no_check:
-        if world > 1:
+        if dist_on:
             eng.forward(batches[0][0], batches[0][1], outs[0], ws)
             torch.cuda.synchronize()
         n = 4096
@@ -349,8 +368,16 @@ def main():
         }
         if world == 1 and args.cpu_seconds > 0:
             line["cpu_baseline"] = cpu_baseline(args.workload, model, feats, args.cpu_seconds)
+        # RCCL prints a version banner through C stdio, which (stdout being a pipe) would otherwise be flushed at exit,
+        # AFTER this line: flush it first so the JSON is the last line of output
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if dist_on:
         dist.barrier()
         dist.destroy_process_group()
 

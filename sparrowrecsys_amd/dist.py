@@ -14,6 +14,7 @@ Two shapes of the same exchange:
 """
 from __future__ import annotations
 
+import os
 from typing import Callable, Optional, Tuple
 
 
@@ -92,10 +93,13 @@ class GroupedScoreGather:
         self.local = torch.zeros((2, self.G, self.B), dtype=dtype, device=device)
         self.gathered = torch.zeros((2, self.world, self.G * self.B), dtype=dtype, device=device)
         self.cuda = torch.device(device).type == "cuda"
-        self.comm_stream = torch.cuda.Stream(device=device) if (self.cuda and self.world > 1) else None
+        # SPRK_FORCE_COLLECTIVE=1: issue the collective even in a world of one (functional check of the RCCL path)
+        self.force = dist.is_initialized() and os.environ.get("SPRK_FORCE_COLLECTIVE") == "1"
+        self.comm_stream = torch.cuda.Stream(device=device) if (self.cuda and (self.world > 1 or self.force)) else None
         self.done = [None, None]              # CUDA event per slot: its collective has finished
         self.slot, self.fill, self.groups_done, self.collectives = 0, 0, 0, 0
         self._pending = [None, None]          # (group_index, n_batches) waiting for the sink
+        self._views = [None, None]            # cached per-slot output views (group_outs)
 
     def out(self):
         """Tensor for the NEXT batch's scores (call once per batch, before its forward is enqueued)."""
@@ -110,6 +114,21 @@ class GroupedScoreGather:
 
     def full(self) -> bool:
         return self.fill == self.G
+
+    def group_outs(self):
+        """All G output tensors of the CURRENT (empty) slot at once -- the whole-group form of G calls of ``out()``,
+        for loops that enqueue a group with one foreign call; the views are created once per slot and reused (a tensor
+        view costs microseconds of host time, the forward it belongs to ~7 us of GPU time).  Follow with ``commit()``."""
+        import torch
+        if self.fill != 0:
+            raise RuntimeError("group_outs() needs an empty slot (fill = %d)" % self.fill)
+        if self.done[self.slot] is not None:
+            torch.cuda.current_stream().wait_event(self.done[self.slot])
+            self._drain(self.slot)
+        if self._views[self.slot] is None:
+            self._views[self.slot] = [self.local[self.slot, i] for i in range(self.G)]
+        self.fill = self.G
+        return self._views[self.slot]
 
     def _drain(self, slot):
         if self._pending[slot] is not None and self.sink is not None:
@@ -128,7 +147,7 @@ class GroupedScoreGather:
         slot, nb = self.slot, self.fill
         src = self.local[slot].view(-1)
         dst = self.gathered[slot].view(-1)
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             dst.copy_(src)
         elif self.comm_stream is not None:
             ready = torch.cuda.Event()

@@ -118,6 +118,35 @@ class Engine:
         L.check(self.lib.sprk_forward_many(self.handle, n, ids_a, dense_a, out_a, B, C.c_void_p(ws_ptr), ws_bytes,
                                            C.c_void_p(stream)))
 
+    def prepare_many(self, ids_list, dense_list, out_list, workspace=None):
+        """The argument marshalling of ``forward_many`` done once: returns ``run(stream=None)`` that enqueues the same
+        sequence of batches again (the tensors must stay alive and in place).  For loops that replay a fixed set of
+        device buffers -- e.g. one gather group of a multi-GPU predict loop -- the per-call host cost drops to one
+        foreign call."""
+        import torch
+        n = len(out_list)
+        B = int(out_list[0].shape[0])
+        if any(int(o.shape[0]) != B for o in out_list):
+            raise ValueError("prepare_many: every batch must have the same number of rows")
+        ws_ptr, ws_bytes = None, 0
+        if self.has_din:
+            need = self.workspace_bytes(B)
+            if workspace is None or workspace.numel() * workspace.element_size() < need:
+                raise ValueError("DIN forward needs a %d-byte workspace tensor" % need)
+            ws_ptr, ws_bytes = workspace.data_ptr(), workspace.numel() * workspace.element_size()
+        arr = C.c_void_p * n
+        ids_a = arr(*[t.data_ptr() for t in ids_list]) if ids_list is not None else None
+        dense_a = arr(*[t.data_ptr() for t in dense_list]) if dense_list is not None else None
+        out_a = arr(*[t.data_ptr() for t in out_list])
+        keep = (list(ids_list or ()), list(dense_list or ()), list(out_list), workspace)
+        fn, handle, ws_p = self.lib.sprk_forward_many, self.handle, C.c_void_p(ws_ptr)
+
+        def run(stream: Optional[int] = None, _keep=keep):
+            if stream is None:
+                stream = torch.cuda.current_stream().cuda_stream
+            L.check(fn(handle, n, ids_a, dense_a, out_a, B, ws_p, ws_bytes, C.c_void_p(stream)))
+        return run
+
     def set_many_streams(self, n: int) -> bool:
         """Fan forward_many's independent batches over ``n`` helper streams (0 = strict order).  Models with a workspace
         (DIN) additionally need ``n`` workspace slices (see ``many_workspace_bytes``)."""

@@ -99,9 +99,18 @@ def _group_worker(rank, world, port, q):
         B, G, steps = 8, 3, 8                        # 8 batches in groups of 3: 3 + 3 + partial 2
         got = []
         gs = GroupedScoreGather(B, G, "cpu", sink=lambda gi, view, nb: got.append((gi, nb, view.clone())))
-        for i in range(steps):
+        i = 0
+        while i < steps:
+            if i == 3:                               # second group through the whole-group form (cached views)
+                for j, out in enumerate(gs.group_outs()):
+                    out.copy_(torch.arange(B, dtype=torch.float32) + 1000 * rank + 100 * (i + j))
+                assert gs.full()
+                gs.commit()
+                i += G
+                continue
             out = gs.out()
             out.copy_(torch.arange(B, dtype=torch.float32) + 1000 * rank + 100 * i)     # "forward" of batch i
+            i += 1
             if gs.full():
                 gs.commit()
         gs.flush()
