@@ -16,7 +16,8 @@
 //    and lost: 2 x 256 B more per sample made the kernel memory bound at 5.9 TB/s of actual traffic)
 //  * deep1 (K = 64) takes relu(deep0) from the registers it sits in (C/D layout = B layout); weights of both
 //    layers are read from LDS as A fragments; first-order weights: lane (r,q) fetches field q's and field q+4's.
-// fp32 throughout (f32 MFMA: deep1's input has data-dependent range); nothing but ids, rows and the score
+// deep0 on f32 MFMA; deep1 (data-dependent input range) on the f16 matrix pipe with a per-sample dynamic power-of-two
+// scale and hi + lo split operands (dyn_split.h; SPRK_DYN_F16=0: f32 MFMA); nothing but ids, rows and the score
 // touches memory.  The plan interpreter ran this graph in 40 us per 65 536 samples.
 
 #define V1_MAX_FIELDS 8
@@ -39,6 +40,8 @@ struct V1Run {
     const float* b1;                      // [H1]
     const float* hdeep;                   // head weights on deep1's output [H1] (zero padded)
     float head_bias;
+    const float* w1frag;                  // DYN: deep1's W^T as split-f16 A fragments (dyn_split.h: k_dyn_pack_w), or NULL
+    float inv_w1_scale;                   // DYN: 1 / their static power-of-two scale (0 = deep1 on f32 MFMA)
 };
 
 // One-time (finalize) kernel: deep0's W^T columns -> [H0][16*(V1_MAX_DEEP+1)]: chunk g < n_deep = the Dp columns of deep
@@ -74,7 +77,7 @@ struct V1Lds {
 // its ids were fetched one task earlier still.  Everything the scoring stage reads besides its operands comes from
 // LDS (deep1's weights, biases): a global load there would sit behind the prefetched gather in the in-order vmcnt
 // queue and drain it.
-template <int NF, int NV, int H0C, int H1C, int WAVES>
+template <int NF, int NV, int H0C, int H1C, int WAVES, bool DYN>
 __global__ __launch_bounds__(WAVES * 64, 2) void k_deepfm_pairs(const V1Run A, const int* __restrict__ ids,
                                                                 const float* __restrict__ dense, float* __restrict__ out,
                                                                 int B, int* __restrict__ err) {
@@ -91,9 +94,14 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_deepfm_pairs(const V1Run A, c
     bool bad = false;
 
     // ---- one-time: both layers' W^T, biases, head weights -> LDS ----
-    for (int i = tid; i < LD::H1 * LD::S1; i += WAVES * 64) {
-        const int n = i / LD::S1, k = i - n * LD::S1;
-        smem[LD::off_w1 + i] = k < H0 ? A.W1[(size_t)n * A.ld1 + k] : 0.f;
+    if constexpr (DYN) {
+        static_assert(H1C * (H0C / 2) * 512 <= LD::H1 * LD::S1 && H0C % 2 == 0, "fragments fit W1's region");
+        for (int i = tid; i < H1C * (H0C / 2) * 512; i += WAVES * 64) smem[LD::off_w1 + i] = A.w1frag[i];
+    } else {
+        for (int i = tid; i < LD::H1 * LD::S1; i += WAVES * 64) {
+            const int n = i / LD::S1, k = i - n * LD::S1;
+            smem[LD::off_w1 + i] = k < H0 ? A.W1[(size_t)n * A.ld1 + k] : 0.f;
+        }
     }
     for (int i = tid; i < H0 * LD::S0; i += WAVES * 64) {
         const int n = i / LD::S0, k = i - n * LD::S0;
@@ -202,6 +210,37 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_deepfm_pairs(const V1Run A, c
         for (int nb = 0; nb < H0C; ++nb) h0[nb] = relu4_fast(h0[nb]);
         // ---- deep1 (H1C independent chains; A fragments from LDS), ReLU, head weights ----
         f32x4 h1[H1C];
+        if constexpr (DYN) {
+            // f16 matrix pipe with a per-sample power-of-two scale of relu(deep0) (dyn_split.h; see k_din_tail's fc1)
+            float mx = 0.f;
+#pragma unroll
+            for (int nb = 0; nb < H0C; ++nb)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) mx = fmaxf(mx, __builtin_fabsf(h0[nb][j]));
+            mx = rows4_max(mx);
+            float scale, inv;
+            dyn_scale(mx, A.inv_w1_scale, scale, inv);
+            f32x4 acc[H1C];
+#pragma unroll
+            for (int n1 = 0; n1 < H1C; ++n1) acc[n1] = zero;
+            int wfo = LD::off_w1 + (r * 4 + q) * 4;               // this lane's 16 bytes inside a 1-KB fragment
+            asm volatile("" : "+v"(wfo));                         // (keeps the loop-invariant LDS reads inside the task loop)
+#pragma unroll
+            for (int b = 0; b < H0C / 2; ++b) {
+                din_f16x8 bh, bl;
+                dyn_split8(h0[2 * b], h0[2 * b + 1], scale, bh, bl);
+#pragma unroll
+                for (int n1 = 0; n1 < H1C; ++n1) {
+                    const din_f16x8 ah = __builtin_bit_cast(din_f16x8, ld4(smem + wfo + ((n1 * (H0C / 2) + b) * 2 + 0) * 256));
+                    const din_f16x8 al = __builtin_bit_cast(din_f16x8, ld4(smem + wfo + ((n1 * (H0C / 2) + b) * 2 + 1) * 256));
+                    acc[n1] = mfma_f16(ah, bh, acc[n1]);
+                    acc[n1] = mfma_f16(ah, bl, acc[n1]);
+                    acc[n1] = mfma_f16(al, bh, acc[n1]);
+                }
+            }
+#pragma unroll
+            for (int n1 = 0; n1 < H1C; ++n1) h1[n1] = acc[n1] * inv + ld4(smem + LD::off_b1 + n1 * 16 + 4 * q);
+        } else {
 #pragma unroll
         for (int n1 = 0; n1 < H1C; ++n1) h1[n1] = ld4(smem + LD::off_b1 + n1 * 16 + 4 * q);
         // (the offset passes through a volatile asm so that the loop-invariant LDS reads are not hoisted into 64 registers)
@@ -217,6 +256,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_deepfm_pairs(const V1Run A, c
 #pragma unroll
                 for (int n1 = 0; n1 < H1C; ++n1)
                     h1[n1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[n1][st], h0[c][st], h1[n1], 0, 0, 0);
+        }
         }
 #pragma unroll
         for (int n1 = 0; n1 < H1C; ++n1) z += dot4(ld4(smem + LD::off_hd + n1 * 16 + 4 * q), relu4_fast(h1[n1]));

@@ -1254,13 +1254,47 @@ int fold_first_dense(sprk_engine* h, DevPlan* dp) {
     return SPRK_OK;
 }
 
+// A Dense layer's W^T [N][ld] (K columns) as split-f16 A fragments for the per-sample dynamic-scale path (dyn_split.h):
+// static power-of-two scale putting max |W| in [2^14, 2^15).  *frag stays NULL when switched off (SPRK_DYN_F16=0), when
+// the shape does not tile (N % 16, K % 32) or the weights are not finite.
+int make_dyn_fragments(sprk_engine* h, const float* W, int ld, int N, int K, float** frag, float* w_scale_out) {
+    *frag = nullptr;
+    const char* dsw = getenv("SPRK_DYN_F16");                // A/B switch: "0" = f32 MFMA
+    if ((dsw && dsw[0] == '0') || (N & 15) || (K & 31)) return SPRK_OK;
+    unsigned* d_max = nullptr;
+    HIP_TRY(hipMalloc((void**)&d_max, sizeof(unsigned)));
+    HIP_TRY(hipMemset(d_max, 0, sizeof(unsigned)));
+    hipLaunchKernelGGL(k_v2_absmax, dim3(8), dim3(256), 0, 0, W, (long long)N, ld, K, d_max);
+    unsigned bits = 0;
+    HIP_TRY(hipMemcpy(&bits, d_max, sizeof(bits), hipMemcpyDeviceToHost));
+    (void)hipFree(d_max);
+    float mx;
+    memcpy(&mx, &bits, sizeof(mx));
+    if (!(mx < 3.0e38f)) return SPRK_OK;
+    int e = 0;
+    float w_scale = 1.f;
+    if (mx > 0.f) { (void)frexpf(mx, &e); e = 15 - e; if (e > 60) e = 60; if (e < -60) e = -60; w_scale = ldexpf(1.f, e); }
+    const size_t frag_floats = (size_t)(N / 16) * (K / 32) * 512;
+    float* f = nullptr;
+    HIP_TRY(hipMalloc((void**)&f, frag_floats * sizeof(float)));
+    h->fold_bufs.push_back(f);
+    hipLaunchKernelGGL(k_dyn_pack_w, dim3(32), dim3(256), 0, 0, W, ld, N, K, w_scale, reinterpret_cast<_Float16*>(f));
+    HIP_TRY(hipGetLastError());
+    *frag = f;
+    *w_scale_out = w_scale;
+    return SPRK_OK;
+}
+
 // ---- dispatch table for k_deepfm_pairs<NF, NV, H0C, H1C, WAVES> ----
 constexpr int V1_WAVES = 8;
 typedef void (*V1LaunchFn)(const V1Run&, const int*, const float*, float*, int, int*, int, hipStream_t);
 template <int NF, int NV>
 void v1_launch(const V1Run& a, const int* ids, const float* dense, float* out, int B, int* err, int grid, hipStream_t st) {
     const size_t lds = V1Lds<4, 4>::bytes;
-    hipLaunchKernelGGL((k_deepfm_pairs<NF, NV, 4, 4, V1_WAVES>), dim3(grid), dim3(V1_WAVES * 64), lds, st, a, ids, dense, out, B, err);
+    if (a.inv_w1_scale != 0.f)
+        hipLaunchKernelGGL((k_deepfm_pairs<NF, NV, 4, 4, V1_WAVES, true>), dim3(grid), dim3(V1_WAVES * 64), lds, st, a, ids, dense, out, B, err);
+    else
+        hipLaunchKernelGGL((k_deepfm_pairs<NF, NV, 4, 4, V1_WAVES, false>), dim3(grid), dim3(V1_WAVES * 64), lds, st, a, ids, dense, out, B, err);
 }
 struct V1Variant { int nf, nv; V1LaunchFn launch; };
 const V1Variant kV1Variants[] = {
@@ -1393,6 +1427,14 @@ int setup_deepfm_pairs(sprk_engine* h) {
     r.w0 = w0p; r.b0 = (const float*)h->slot_ptr[o0.b_slot];
     r.W1 = (const float*)h->slot_ptr[o1.w_slot]; r.ld1 = o1.ldw; r.b1 = (const float*)h->slot_ptr[o1.b_slot];
     r.hdeep = hd; r.head_bias = p.head_bias;
+    r.w1frag = nullptr; r.inv_w1_scale = 0.f;
+    {
+        float w_scale = 0.f;
+        float* frag = nullptr;
+        const int rc2 = make_dyn_fragments(h, r.W1, r.ld1, H1, H0, &frag, &w_scale);
+        if (rc2) return rc2;
+        if (frag) { r.w1frag = frag; r.inv_w1_scale = 1.0f / w_scale; }
+    }
     h->v1_run = r;
     h->v1_variant = variant;
     return SPRK_OK;
@@ -1572,30 +1614,13 @@ int setup_din_tail(sprk_engine* h, DevPlan* dp) {
         r.col[g] = h->idc[sg.field]; r.vocab[g] = sg.vocab; r.Ftab[g] = sg.table;
     }
     HIP_TRY(hipMalloc((void**)&h->din_tail_image, tv.lds_bytes));
-    // DYN: fc1's weights split into f16 hi / lo fragments with a static power-of-two scale (max |W1| -> ~2^14)
+    // DYN: fc1's weights split into f16 hi / lo fragments with a static power-of-two scale
     float* w1frag = nullptr;
-    const char* dsw = getenv("SPRK_DYN_F16");                // A/B switch: "0" = fc1 on f32 MFMA
-    if (!(dsw && dsw[0] == '0')) {
-        unsigned* d_max = nullptr;
-        HIP_TRY(hipMalloc((void**)&d_max, sizeof(unsigned)));
-        HIP_TRY(hipMemset(d_max, 0, sizeof(unsigned)));
-        hipLaunchKernelGGL(k_v2_absmax, dim3(8), dim3(256), 0, 0, o1.W, (long long)o1.N, o1.ldw, o1.K, d_max);
-        unsigned bits = 0;
-        HIP_TRY(hipMemcpy(&bits, d_max, sizeof(bits), hipMemcpyDeviceToHost));
-        (void)hipFree(d_max);
-        float mx;
-        memcpy(&mx, &bits, sizeof(mx));
-        if (mx < 3.0e38f) {
-            int e = 0;
-            float w_scale = 1.f;
-            if (mx > 0.f) { (void)frexpf(mx, &e); e = 15 - e; if (e > 60) e = 60; if (e < -60) e = -60; w_scale = ldexpf(1.f, e); }
-            const size_t frag_floats = (size_t)(o1.N / 16) * (o1.K / 32) * 512;
-            HIP_TRY(hipMalloc((void**)&w1frag, frag_floats * sizeof(float)));
-            h->fold_bufs.push_back(w1frag);
-            hipLaunchKernelGGL(k_dyn_pack_w, dim3(32), dim3(256), 0, 0, o1.W, o1.ldw, o1.N, o1.K, w_scale, reinterpret_cast<_Float16*>(w1frag));
-            HIP_TRY(hipGetLastError());
-            r.inv_w1_scale = 1.0f / w_scale;
-        }
+    {
+        float w_scale = 0.f;
+        const int rc2 = make_dyn_fragments(h, o1.W, o1.ldw, o1.N, o1.K, &w1frag, &w_scale);
+        if (rc2) return rc2;
+        if (w1frag) r.inv_w1_scale = 1.0f / w_scale;
     }
     tv.pack(o0.W, o0.ldw, p_off, Dp, n_off, n_num, o0.bias, o0.alpha, o1.W, o1.ldw, o1.bias, o1.alpha, tp.w, tp.len, w1frag, h->din_tail_image);
     HIP_TRY(hipGetLastError());

@@ -544,13 +544,16 @@ def test_deepfm_pairs_kernel_vs_interpreter_and_oracle(torch, monkeypatch, shape
         B, dist = (16384, "uniform") if shape == "config2" else (10007, "zipf")
         feats = SY.synth_fields(B, fields, seed=72, dist=dist)
     out = {}
-    for chain in ("1", "0"):
-        monkeypatch.setenv("SPRK_V1_CHAIN", chain)
+    for chain, dyn in (("1", "1"), ("1f32", "0"), ("0", "1")):          # chain kernel with deep1 on split-f16 / on f32 MFMA, interpreter
+        monkeypatch.setenv("SPRK_V1_CHAIN", chain[0])
+        monkeypatch.setenv("SPRK_DYN_F16", dyn)
         model = M.DeepFM(seed=46, emb_dim=D, fields=fields, pairs=pairs)
         out[chain] = model.predict(feats)[:, 0]
     kw = {} if fields is None else {"fields": fields, "pairs": pairs}
     ref = O.deepfm_forward(feats, model.weights, dtype=np.float64, **kw)[:, 0]
     assert np.abs(out["1"] - ref).max() <= TIGHT
+    assert np.abs(out["1f32"] - ref).max() <= TIGHT
+    assert np.abs(out["1"] - ref).max() <= 2 * np.abs(out["1f32"] - ref).max() + 2e-6
     assert np.abs(out["0"] - ref).max() <= TIGHT
     assert 0.02 < ref.std()
 
