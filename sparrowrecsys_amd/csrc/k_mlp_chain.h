@@ -36,6 +36,7 @@ struct MlpChainRun {
     const float* wide_tab;
     const float* wide_w;                  // [wide_dim] head weights (kind 1)
     float head_bias;
+    float inv_w1_scale;                   // DYN: 1 / static scale of the second layer's split-f16 fragments (0 = f32 MFMA)
 };
 
 template <int N0C, int N1C>
@@ -63,8 +64,9 @@ __global__ __launch_bounds__(256) void k_mlp_chain_pack(const float* __restrict_
                                                         const float* __restrict__ b0, const float* __restrict__ a0,
                                                         const float* __restrict__ W1, int ldw1, const float* __restrict__ b1,
                                                         const float* __restrict__ a1, const float* __restrict__ hw, int n_hw,
-                                                        float* __restrict__ img) {
+                                                        const float* __restrict__ w1frag, float* __restrict__ img) {
     using LD = MlpChainLds<N0C, N1C>;
+    static_assert(N1C * (N0C / 2) * 512 <= LD::N1 * LD::S1 && N0C % 2 == 0, "DYN fragments fit the second layer's region");
     const int tid = threadIdx.x;
     for (int i = tid; i < LD::N0 * LD::S0; i += 256) {
         const int n = i / LD::S0, k = i - n * LD::S0, c = k >> 4, j = k & 15;
@@ -72,9 +74,13 @@ __global__ __launch_bounds__(256) void k_mlp_chain_pack(const float* __restrict_
         if (k < LD::K0 && c < n_chunks && j < col_w[c]) v = W0[(size_t)n * ldw0 + col_off[c] + j];
         img[LD::off_w0 + i] = v;
     }
-    for (int i = tid; i < LD::N1 * LD::S1; i += 256) {
-        const int n = i / LD::S1, k = i - n * LD::S1;
-        img[LD::off_w1 + i] = k < LD::N0 ? W1[(size_t)n * ldw1 + k] : 0.f;
+    if (w1frag) {                                     // DYN: split-f16 A fragments (dyn_split.h) instead of the f32 W^T rows
+        for (int i = tid; i < LD::N1 * LD::S1; i += 256) img[LD::off_w1 + i] = i < N1C * (N0C / 2) * 512 ? w1frag[i] : 0.f;
+    } else {
+        for (int i = tid; i < LD::N1 * LD::S1; i += 256) {
+            const int n = i / LD::S1, k = i - n * LD::S1;
+            img[LD::off_w1 + i] = k < LD::N0 ? W1[(size_t)n * ldw1 + k] : 0.f;
+        }
     }
     for (int i = tid; i < LD::N0; i += 256) { img[LD::off_b0 + i] = b0[i]; img[LD::off_a0 + i] = a0 ? a0[i] : 0.f; }
     for (int i = tid; i < LD::N1; i += 256) {
@@ -85,7 +91,7 @@ __global__ __launch_bounds__(256) void k_mlp_chain_pack(const float* __restrict_
     for (int i = LD::total + tid; i < LD::total_pad; i += 256) img[i] = 0.f;
 }
 
-template <int N0C, int N1C, int WAVES>
+template <int N0C, int N1C, int WAVES, bool DYN>
 __global__ __launch_bounds__(WAVES * 64, 2) void k_mlp_chain(const MlpChainRun A, const int* __restrict__ ids,
                                                              const float* __restrict__ dense, float* __restrict__ out,
                                                              int B, int* __restrict__ err, const float* __restrict__ image) {
@@ -197,6 +203,35 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_mlp_chain(const MlpChainRun A
         }
         // ---- second layer: K = N0, B operand = h1 as it sits in the registers (N1C chains) ----
         f32x4 z1[N1C];
+        if constexpr (DYN) {
+            // f16 matrix pipe with a per-sample power-of-two scale of the hidden activations (dyn_split.h; k_din_tail's fc1)
+            float mx = 0.f;
+#pragma unroll
+            for (int nb = 0; nb < N0C; ++nb)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) mx = fmaxf(mx, __builtin_fabsf(z0[nb][j]));
+            mx = rows4_max(mx);
+            float scale, inv;
+            dyn_scale(mx, A.inv_w1_scale, scale, inv);
+#pragma unroll
+            for (int n1 = 0; n1 < N1C; ++n1) z1[n1] = zero;
+            const float* wf = smem + LD::off_w1 + (r * 4 + q) * 4;       // this lane's 16 bytes inside a 1-KB fragment
+#pragma unroll
+            for (int b = 0; b < N0C / 2; ++b) {
+                din_f16x8 bh, bl;
+                dyn_split8(z0[2 * b], z0[2 * b + 1], scale, bh, bl);
+#pragma unroll
+                for (int n1 = 0; n1 < N1C; ++n1) {
+                    const din_f16x8 ah = __builtin_bit_cast(din_f16x8, ld4(wf + ((n1 * (N0C / 2) + b) * 2 + 0) * 256));
+                    const din_f16x8 al = __builtin_bit_cast(din_f16x8, ld4(wf + ((n1 * (N0C / 2) + b) * 2 + 1) * 256));
+                    z1[n1] = mfma_f16(ah, bh, z1[n1]);
+                    z1[n1] = mfma_f16(ah, bl, z1[n1]);
+                    z1[n1] = mfma_f16(al, bh, z1[n1]);
+                }
+            }
+#pragma unroll
+            for (int n1 = 0; n1 < N1C; ++n1) z1[n1] = z1[n1] * inv + ld4(smem + LD::off_b1 + n1 * 16 + 4 * q);
+        } else {
 #pragma unroll
         for (int n1 = 0; n1 < N1C; ++n1) z1[n1] = ld4(smem + LD::off_b1 + n1 * 16 + 4 * q);
         const float* w1r = smem + LD::off_w1 + r * LD::S1 + 4 * q;
@@ -210,6 +245,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_mlp_chain(const MlpChainRun A
 #pragma unroll
                 for (int n1 = 0; n1 < N1C; ++n1)
                     z1[n1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[n1][st], z0[c][st], z1[n1], 0, 0, 0);
+        }
         }
         float z = zw;
 #pragma unroll

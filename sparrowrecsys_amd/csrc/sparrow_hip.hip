@@ -1524,13 +1524,21 @@ int setup_mlp_chain(sprk_engine* h, DevPlan* dp) {
     HIP_TRY(hipMalloc((void**)&d_w, sizeof(col_w)));
     HIP_TRY(hipMemcpy(d_off, col_off, sizeof(col_off), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(d_w, col_w, sizeof(col_w), hipMemcpyHostToDevice));
+    float* w1frag = nullptr;
+    {
+        float w_scale = 0.f;
+        const int rc2 = make_dyn_fragments(h, o1.W, o1.ldw, o1.N, o1.K, &w1frag, &w_scale);
+        if (rc2) return rc2;
+        r.inv_w1_scale = w1frag ? 1.0f / w_scale : 0.f;
+    }
     hipLaunchKernelGGL((k_mlp_chain_pack<8, 8>), dim3(1), dim3(256), 0, 0, o0.W, o0.ldw, r.n_chunks, d_off, d_w, o0.bias,
                        o0.act == SPRK_ACT_PRELU ? o0.alpha : nullptr, o1.W, o1.ldw, o1.bias, o1.act == SPRK_ACT_PRELU ? o1.alpha : nullptr,
-                       tdeep->w, tdeep->len, h->mlp_image);
+                       tdeep->w, tdeep->len, w1frag, h->mlp_image);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
     (void)hipFree(d_off); (void)hipFree(d_w);
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mlp_chain<8, 8, MC_WAVES>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LD::bytes));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mlp_chain<8, 8, MC_WAVES, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LD::bytes));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mlp_chain<8, 8, MC_WAVES, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LD::bytes));
     h->mlp_run = r;
     h->mlp_variant = 0;
     return SPRK_OK;
@@ -2052,8 +2060,12 @@ int sprk_forward(sprk_handle h, const int32_t* ids, const float* dense, float* o
         int grid = (ntasks + MC_WAVES - 1) / MC_WAVES;
         if (grid > h->num_cus) grid = h->num_cus;                  // one 8-wave workgroup per CU (120 KB of LDS weights)
         const size_t lds = MlpChainLds<8, 8>::bytes;
-        hipLaunchKernelGGL((k_mlp_chain<8, 8, MC_WAVES>), dim3(grid), dim3(MC_WAVES * 64), lds, st, h->mlp_run, ids, dense, out, B,
-                           h->dev_err, h->mlp_image);
+        if (h->mlp_run.inv_w1_scale != 0.f)
+            hipLaunchKernelGGL((k_mlp_chain<8, 8, MC_WAVES, true>), dim3(grid), dim3(MC_WAVES * 64), lds, st, h->mlp_run, ids, dense, out, B,
+                               h->dev_err, h->mlp_image);
+        else
+            hipLaunchKernelGGL((k_mlp_chain<8, 8, MC_WAVES, false>), dim3(grid), dim3(MC_WAVES * 64), lds, st, h->mlp_run, ids, dense, out, B,
+                               h->dev_err, h->mlp_image);
         HIP_TRY(hipGetLastError());
         return SPRK_OK;
     }

@@ -639,8 +639,9 @@ def test_mlp_chain_vs_interpreter_and_oracle(torch, monkeypatch, kind):
     V, U = 20000, 30000
     feats = SY.synth_embedding_mlp(B, V, U, seed=91, rated_vocab=V if kind != "embedding_mlp" else None)
     out = {}
-    for chain in ("1", "0"):
-        monkeypatch.setenv("SPRK_MLP_CHAIN", chain)
+    for chain, dyn in (("1", "1"), ("1f32", "0"), ("0", "1")):   # chain kernel with layer 2 on split-f16 / f32 MFMA; interpreter
+        monkeypatch.setenv("SPRK_MLP_CHAIN", chain[0])
+        monkeypatch.setenv("SPRK_DYN_F16", dyn)
         if kind == "embedding_mlp":
             model = M.EmbeddingMLP(seed=51, emb_dim=32, movie_buckets=V, user_buckets=U)
         else:
@@ -653,6 +654,8 @@ def test_mlp_chain_vs_interpreter_and_oracle(torch, monkeypatch, kind):
         ref = O.wide_n_deep_forward(feats, model.weights, dtype=np.float64, movie_buckets=V, user_buckets=U,
                                     cross_buckets=model.cross_buckets, rated_buckets=V)[:, 0]
     assert np.abs(out["1"] - ref).max() <= TIGHT
+    assert np.abs(out["1f32"] - ref).max() <= TIGHT
+    assert np.abs(out["1"] - ref).max() <= 2 * np.abs(out["1f32"] - ref).max() + 2e-6
     assert np.abs(out["0"] - ref).max() <= TIGHT
     assert 0.02 < ref.std()
 
