@@ -26,6 +26,32 @@ b bench_c3_interp_tail SPRK_DIN_TAIL=0 python bench.py --steps 300 --warmup 30 -
 b bench_c3_legacy SPRK_DIN_LEGACY=1 SPRK_DIN_TAIL=0 SPRK_TILE_FOLD=0 python bench.py --steps 100 --warmup 10 --workload din_c3 --cpu-seconds 0
 b bench_c5 python bench.py --workload widedeep_c5 --steps 200 --warmup 20 --cpu-seconds 0
 b bench_c5_interp SPRK_MLP_CHAIN=0 python bench.py --workload widedeep_c5 --steps 200 --warmup 20 --cpu-seconds 0
+b bench_c2_f32_hidden SPRK_DYN_F16=0 python bench.py --workload deepfm_c2 --cpu-seconds 0
+b bench_c3_f32_hidden SPRK_DYN_F16=0 python bench.py --steps 300 --warmup 30 --workload din_c3 --cpu-seconds 0
+b bench_c2_forced_collective SPRK_BENCH_FORCE_DIST=1 SPRK_FORCE_COLLECTIVE=1 python bench.py --cpu-seconds 0
+b bench_emb_rank python scripts/bench_emb_rank.py
+b bench_emb_rank_scores_only python scripts/bench_emb_rank.py --no-rank --cpu-seconds 1
+echo "=== DIEN timing"
+timeout 300 python - <<'PY' 2>&1 | grep DIEN | tee gpurun_out/dien_time.log
+import torch
+from sparrowrecsys_amd import models as M, synthetic as SY
+for T in (5, 50):
+    B = 32768
+    f = SY.synth_din(B, T, 1001, 30001, seed=1)
+    m = M.DIEN(seed=2, emb_dim=10, hist_len=T)
+    ids, dense = m.pack(f)
+    ids, dense = torch.from_numpy(ids).cuda(), torch.from_numpy(dense).cuda()
+    eng = m.engine
+    aux = torch.empty((B, eng.n_aux), device="cuda")
+    for name, fn in (("stage", lambda: eng.din_pool(ids, aux, None)), ("forward", lambda: m.predict_device(ids, dense))):
+        for _ in range(5): fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(50): fn()
+        e1.record(); torch.cuda.synchronize()
+        print("DIEN T=%d B=%d %s: %.1f us" % (T, B, name, e0.elapsed_time(e1) * 20))
+PY
 echo "=== rocprofv3 kernel trace"
 cd /tmp && export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_c2 -o c2 -- python $R/bench.py --steps 400 --warmup 40 --cpu-seconds 0 --no-check > $R/gpurun_out/prof_c2.log 2>&1
