@@ -56,5 +56,9 @@ echo "=== rocprofv3 kernel trace"
 cd /tmp && export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_c2 -o c2 -- python $R/bench.py --steps 400 --warmup 40 --cpu-seconds 0 --no-check > $R/gpurun_out/prof_c2.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_c3 -o c3 -- python $R/bench.py --steps 50 --warmup 5 --workload din_c3 --cpu-seconds 0 --no-check > $R/gpurun_out/prof_c3.log 2>&1
+# the same commands with launches in strict stream order: per-kernel durations comparable with bench.py's roofline block
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_c2s -o c2_strict -- python $R/bench.py --steps 400 --warmup 40 --cpu-seconds 0 --no-check --overlap-streams 0 > $R/gpurun_out/prof_c2s.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_c3s -o c3_strict -- python $R/bench.py --steps 50 --warmup 5 --workload din_c3 --cpu-seconds 0 --no-check --overlap-streams 0 > $R/gpurun_out/prof_c3s.log 2>&1
 cd $R
-for f in $(find gpurun_out/prof_c2 gpurun_out/prof_c3 -name "*kernel_stats.csv"); do echo "--- $f"; head -6 $f | cut -c1-200; done
+tail -1 gpurun_out/prof_c2s.log | cut -c1-200; tail -1 gpurun_out/prof_c3s.log | cut -c1-200
+for f in $(find gpurun_out/prof_c2 gpurun_out/prof_c3 gpurun_out/prof_c2s gpurun_out/prof_c3s -name "*kernel_stats.csv"); do echo "--- $f"; head -6 $f | cut -c1-200; done
