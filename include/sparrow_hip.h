@@ -284,6 +284,11 @@ typedef struct sprk_csv_col {
 int sprk_pack_csv(const char* text, size_t len, const sprk_csv_col* id_cols, int32_t n_id,
                   const char* const* dense_names, int32_t n_dense, int32_t max_rows,
                   int32_t* ids_out, float* dense_out, int32_t* rows_out);
+/* The same on n_threads host threads (clamped to [1, 256]; the body is cut at line boundaries, chunks are parsed
+ * concurrently and stitched in file order): identical outputs, identical first error, for any thread count. */
+int sprk_pack_csv_mt(const char* text, size_t len, const sprk_csv_col* id_cols, int32_t n_id,
+                     const char* const* dense_names, int32_t n_dense, int32_t max_rows, int32_t n_threads,
+                     int32_t* ids_out, float* dense_out, int32_t* rows_out);
 
 const char* sprk_last_error(void);
 

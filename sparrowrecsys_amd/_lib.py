@@ -33,7 +33,7 @@ EXPORTED_SYMBOLS = [
     "sprk_forward", "sprk_forward_many", "sprk_forward_embedding_mlp", "sprk_forward_widedeep", "sprk_forward_neuralcf",
     "sprk_forward_deepfm", "sprk_forward_deepfm_v2", "sprk_forward_din", "sprk_forward_dien", "sprk_din_pool",
     "sprk_check_ids", "sprk_debug_set_trace", "sprk_destroy", "sprk_embedding_gather", "sprk_cross_hash", "sprk_last_error",
-    "sprk_pack_csv", "sprk_set_many_streams", "sprk_emb_rank",
+    "sprk_pack_csv", "sprk_pack_csv_mt", "sprk_set_many_streams", "sprk_emb_rank",
 ]
 
 
@@ -91,7 +91,7 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     if not os.path.exists(hipcc):
         hipcc = "hipcc"
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-pthread",
            "-I", INCLUDE_DIR, "-I", os.path.dirname(SRC_PATH), SRC_PATH, "-o", LIB_PATH + ".tmp"]
     if verbose:
         print(" ".join(cmd))

@@ -27,6 +27,7 @@
 #include <new>
 #include <string>
 #include <type_traits>
+#include <thread>
 #include <vector>
 
 #include "sparrow_hip.h"
@@ -2278,39 +2279,38 @@ int sprk_emb_rank(const float* item_emb, const uint8_t* item_has, int32_t n_item
     return SPRK_OK;
 }
 
-int sprk_pack_csv(const char* text, size_t len, const sprk_csv_col* id_cols, int32_t n_id, const char* const* dense_names,
-                  int32_t n_dense, int32_t max_rows, int32_t* ids_out, float* dense_out, int32_t* rows_out) {
-    if (!text || !rows_out || n_id < 0 || n_dense < 0 || max_rows < 0) return fail(SPRK_EINVAL, "bad pack_csv arguments");
-    if ((n_id > 0 && (!id_cols || !ids_out)) || (n_dense > 0 && (!dense_names || !dense_out))) return fail(SPRK_EINVAL, "NULL column list / output");
-    *rows_out = 0;
-    const char* p = text;
-    const char* const end = text + len;
-    auto line_end = [&](const char* s) { while (s < end && *s != '\n') ++s; return s; };
+}  // extern "C" (helpers below are C++)
+
+namespace {
+struct CsvLayout {
+    size_t n_cols;
+    std::vector<int> id_pos, dense_pos;
+};
+struct CsvChunkResult {
+    std::vector<int32_t> ids;
+    std::vector<float> dense;
+    int32_t rows = 0;
+    int rc = SPRK_OK;                 // first error of the chunk, raised after `rows` good rows
+    std::string msg;
+};
+// Rows of [p, end) appended to `out` (at most max_rows); stops at the first bad value (out.rc / out.msg).
+void pack_csv_rows(const char* p, const char* end, const CsvLayout& L, const sprk_csv_col* id_cols, int n_id, const char* const* dense_names,
+                   int n_dense, int32_t max_rows, CsvChunkResult& out) {
     std::vector<CsvField> fields;
     std::string scratch;
-    // header
-    const char* le = line_end(p);
-    const char* he = (le > p && le[-1] == '\r') ? le - 1 : le;
-    split_csv_line(p, he, fields, scratch);
-    const size_t n_cols = fields.size();
-    std::vector<int> id_pos(n_id, -1), dense_pos(n_dense, -1);
-    auto find = [&](const char* name) {
-        const size_t L = strlen(name);
-        for (size_t c = 0; c < n_cols; ++c) if (fields[c].n == L && memcmp(fields[c].p, name, L) == 0) return (int)c;
-        return -1;
-    };
-    for (int j = 0; j < n_id; ++j) if ((id_pos[j] = find(id_cols[j].name)) < 0) return fail(SPRK_EINVAL, "CSV has no column %s", id_cols[j].name);
-    for (int j = 0; j < n_dense; ++j) if ((dense_pos[j] = find(dense_names[j])) < 0) return fail(SPRK_EINVAL, "CSV has no column %s", dense_names[j]);
-    p = le < end ? le + 1 : end;
-    int32_t rows = 0;
-    while (p < end && rows < max_rows) {
-        le = line_end(p);
+    char buf[256];
+    auto line_end = [&](const char* s) { const void* q = memchr(s, '\n', (size_t)(end - s)); return q ? (const char*)q : end; };
+    while (p < end && out.rows < max_rows) {
+        const char* le = line_end(p);
         const char* re = (le > p && le[-1] == '\r') ? le - 1 : le;
         if (re > p) {
             split_csv_line(p, re, fields, scratch);
-            if (fields.size() == n_cols) {                      // ignore_errors=True: other rows are dropped
+            if (fields.size() == L.n_cols) {                    // ignore_errors=True: other rows are dropped
+                const size_t i0 = out.ids.size(), d0 = out.dense.size();
+                out.ids.resize(i0 + n_id);
+                out.dense.resize(d0 + n_dense);
                 for (int j = 0; j < n_id; ++j) {
-                    const CsvField& f = fields[id_pos[j]];
+                    const CsvField& f = fields[L.id_pos[j]];
                     int32_t v;
                     if (id_cols[j].kind == 1) {
                         v = -1;
@@ -2319,28 +2319,110 @@ int sprk_pack_csv(const char* text, size_t len, const sprk_csv_col* id_cols, int
                         if (v >= id_cols[j].vocab) v = -1;
                     } else {
                         double d = 0.0;
-                        if (f.n != 0 && !parse_number(f, &d)) return fail(SPRK_EINVAL, "row %d: %s is not a number", rows, id_cols[j].name);
+                        if (f.n != 0 && !parse_number(f, &d)) {
+                            snprintf(buf, sizeof(buf), "%s is not a number", id_cols[j].name);
+                            out.rc = SPRK_EINVAL; out.msg = buf; out.ids.resize(i0); out.dense.resize(d0);
+                            return;
+                        }
                         const long long iv = (long long)d;      // int(float(v)) of the Python packer
-                        if (iv < 0 || iv >= id_cols[j].vocab)
-                            return fail(SPRK_ERANGE, "%s id %lld outside [0, %d) (reference: assert_less_than_num_buckets)",
-                                        id_cols[j].name, iv, id_cols[j].vocab);
+                        if (iv < 0 || iv >= id_cols[j].vocab) {
+                            snprintf(buf, sizeof(buf), "%s id %lld outside [0, %d) (reference: assert_less_than_num_buckets)", id_cols[j].name, iv,
+                                     id_cols[j].vocab);
+                            out.rc = SPRK_ERANGE; out.msg = buf; out.ids.resize(i0); out.dense.resize(d0);
+                            return;
+                        }
                         v = (int32_t)iv;
                     }
-                    ids_out[(size_t)rows * n_id + j] = v;
+                    out.ids[i0 + j] = v;
                 }
                 for (int j = 0; j < n_dense; ++j) {
-                    const CsvField& f = fields[dense_pos[j]];
+                    const CsvField& f = fields[L.dense_pos[j]];
                     double d = 0.0;
-                    if (f.n != 0 && !parse_number(f, &d)) return fail(SPRK_EINVAL, "row %d: %s is not a number", rows, dense_names[j]);
-                    dense_out[(size_t)rows * n_dense + j] = (float)d;
+                    if (f.n != 0 && !parse_number(f, &d)) {
+                        snprintf(buf, sizeof(buf), "%s is not a number", dense_names[j]);
+                        out.rc = SPRK_EINVAL; out.msg = buf; out.ids.resize(i0); out.dense.resize(d0);
+                        return;
+                    }
+                    out.dense[d0 + j] = (float)d;
                 }
-                ++rows;
+                ++out.rows;
             }
         }
         p = le < end ? le + 1 : end;
     }
+}
+}  // namespace
+
+extern "C" {
+
+int sprk_pack_csv_mt(const char* text, size_t len, const sprk_csv_col* id_cols, int32_t n_id, const char* const* dense_names,
+                     int32_t n_dense, int32_t max_rows, int32_t n_threads, int32_t* ids_out, float* dense_out, int32_t* rows_out) {
+    if (!text || !rows_out || n_id < 0 || n_dense < 0 || max_rows < 0) return fail(SPRK_EINVAL, "bad pack_csv arguments");
+    if ((n_id > 0 && (!id_cols || !ids_out)) || (n_dense > 0 && (!dense_names || !dense_out))) return fail(SPRK_EINVAL, "NULL column list / output");
+    *rows_out = 0;
+    const char* p = text;
+    const char* const end = text + len;
+    // header
+    CsvLayout L;
+    {
+        const void* q = memchr(p, '\n', len);
+        const char* le = q ? (const char*)q : end;
+        const char* he = (le > p && le[-1] == '\r') ? le - 1 : le;
+        std::vector<CsvField> fields;
+        std::string scratch;
+        split_csv_line(p, he, fields, scratch);
+        L.n_cols = fields.size();
+        L.id_pos.assign(n_id, -1);
+        L.dense_pos.assign(n_dense, -1);
+        auto find = [&](const char* name) {
+            const size_t n = strlen(name);
+            for (size_t c = 0; c < L.n_cols; ++c) if (fields[c].n == n && memcmp(fields[c].p, name, n) == 0) return (int)c;
+            return -1;
+        };
+        for (int j = 0; j < n_id; ++j) if ((L.id_pos[j] = find(id_cols[j].name)) < 0) return fail(SPRK_EINVAL, "CSV has no column %s", id_cols[j].name);
+        for (int j = 0; j < n_dense; ++j) if ((L.dense_pos[j] = find(dense_names[j])) < 0) return fail(SPRK_EINVAL, "CSV has no column %s", dense_names[j]);
+        p = le < end ? le + 1 : end;
+    }
+    // chunks of whole lines, one per thread (a text below 1 MiB is not worth a thread start)
+    int T = n_threads < 1 ? 1 : (n_threads > 256 ? 256 : n_threads);
+    const size_t body = (size_t)(end - p);
+    if (body < ((size_t)1 << 20)) T = 1;
+    std::vector<const char*> cut(T + 1, end);
+    cut[0] = p;
+    for (int t = 1; t < T; ++t) {
+        const char* c = p + body / T * t;
+        if (c < cut[t - 1]) c = cut[t - 1];
+        const void* q = c < end ? memchr(c, '\n', (size_t)(end - c)) : nullptr;
+        cut[t] = q ? (const char*)q + 1 : end;
+    }
+    std::vector<CsvChunkResult> res(T);
+    if (T == 1) {
+        pack_csv_rows(cut[0], cut[1], L, id_cols, n_id, dense_names, n_dense, max_rows, res[0]);
+    } else {
+        std::vector<std::thread> th;
+        for (int t = 0; t < T; ++t)
+            th.emplace_back([&, t]() { pack_csv_rows(cut[t], cut[t + 1], L, id_cols, n_id, dense_names, n_dense, max_rows, res[t]); });
+        for (auto& x : th) x.join();
+    }
+    // stitch in file order: exactly what one pass would have produced (rows beyond max_rows are never looked at)
+    int32_t rows = 0;
+    for (int t = 0; t < T && rows < max_rows; ++t) {
+        const CsvChunkResult& r = res[t];
+        const int32_t take = r.rows < max_rows - rows ? r.rows : max_rows - rows;
+        if (take > 0) {
+            if (n_id) memcpy(ids_out + (size_t)rows * n_id, r.ids.data(), (size_t)take * n_id * sizeof(int32_t));
+            if (n_dense) memcpy(dense_out + (size_t)rows * n_dense, r.dense.data(), (size_t)take * n_dense * sizeof(float));
+        }
+        rows += take;
+        if (r.rc != SPRK_OK && rows < max_rows) return fail(r.rc, "row %d: %s", rows, r.msg.c_str());
+    }
     *rows_out = rows;
     return SPRK_OK;
+}
+
+int sprk_pack_csv(const char* text, size_t len, const sprk_csv_col* id_cols, int32_t n_id, const char* const* dense_names,
+                  int32_t n_dense, int32_t max_rows, int32_t* ids_out, float* dense_out, int32_t* rows_out) {
+    return sprk_pack_csv_mt(text, len, id_cols, n_id, dense_names, n_dense, max_rows, 1, ids_out, dense_out, rows_out);
 }
 
 int sprk_cross_hash(const int32_t* a, const int32_t* b, int32_t B, int64_t num_buckets, int64_t* out, void* stream) {

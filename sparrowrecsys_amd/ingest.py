@@ -20,8 +20,10 @@ from .schema import IdColumn, NUMERIC_KEYS
 
 
 def pack_csv(text, id_columns: Sequence[IdColumn], numeric_keys: Sequence[str] = NUMERIC_KEYS,
-             max_rows: int = None) -> Tuple[np.ndarray, np.ndarray]:
-    """``text``: the CSV file's content (bytes or str, header line first) -> ``(ids, dense)``."""
+             max_rows: int = None, threads: int = 1) -> Tuple[np.ndarray, np.ndarray]:
+    """``text``: the CSV file's content (bytes or str, header line first) -> ``(ids, dense)``.
+    ``threads`` > 1: the body is cut at line boundaries and parsed on that many host threads (``sprk_pack_csv_mt``);
+    outputs and the first error are identical for any thread count."""
     if isinstance(text, str):
         text = text.encode("utf-8")
     lib = L.load_library()
@@ -35,12 +37,12 @@ def pack_csv(text, id_columns: Sequence[IdColumn], numeric_keys: Sequence[str] =
     ids = np.empty((max_rows, n_id), dtype=np.int32)
     dense = np.empty((max_rows, n_dense), dtype=np.float32)
     rows = C.c_int32(0)
-    L.check(lib.sprk_pack_csv(text, len(text), cols, n_id, names, n_dense, max_rows, C.c_void_p(ids.ctypes.data),
-                              C.c_void_p(dense.ctypes.data), C.byref(rows)))
+    L.check(lib.sprk_pack_csv_mt(text, C.c_size_t(len(text)), cols, n_id, names, n_dense, max_rows, int(max(1, threads)),
+                                 C.c_void_p(ids.ctypes.data), C.c_void_p(dense.ctypes.data), C.byref(rows)))
     return ids[:rows.value], dense[:rows.value]
 
 
 def pack_csv_file(path: str, id_columns: Sequence[IdColumn], numeric_keys: Sequence[str] = NUMERIC_KEYS,
-                  max_rows: int = None) -> Tuple[np.ndarray, np.ndarray]:
+                  max_rows: int = None, threads: int = 1) -> Tuple[np.ndarray, np.ndarray]:
     with open(path, "rb") as f:
-        return pack_csv(f.read(), id_columns, numeric_keys, max_rows)
+        return pack_csv(f.read(), id_columns, numeric_keys, max_rows, threads)

@@ -77,3 +77,69 @@ def test_reference_test_samples_bit_identical_and_faster():
         print("%s: %d rows, native %.0f k rows/s, python %.0f k rows/s" % (type(model).__name__, ids.shape[0],
               ids.shape[0] / t_native / 1e3, ids.shape[0] / t_python / 1e3))
         assert t_native < t_python
+
+
+def _synthetic_csv(n_rows, seed=0, bad_at=None, ragged_every=0):
+    """A MovieLens-schema CSV body of n_rows lines (> 1 MiB so the packer really splits it)."""
+    rng = np.random.default_rng(seed)
+    genres = ["Drama", "Comedy", "Action", "", "Sci-Fi", "NotAGenre"]
+    lines = ["movieId,userId,userGenre1,movieGenre1,releaseYear,movieAvgRating"]
+    mid = rng.integers(0, 1001, n_rows)
+    uid = rng.integers(0, 30001, n_rows)
+    g1 = rng.integers(0, len(genres), n_rows)
+    g2 = rng.integers(0, len(genres), n_rows)
+    yr = rng.integers(1900, 2020, n_rows)
+    rt = rng.random(n_rows) * 5
+    for i in range(n_rows):
+        m = "" if i % 97 == 0 else str(mid[i])                          # NA -> 0
+        if bad_at is not None and i == bad_at:
+            m = "1001"                                                  # outside movieId's buckets
+        row = '%s,%d,%s,"%s",%d,%.2f' % (m, uid[i], genres[g1[i]], genres[g2[i]], yr[i], rt[i])
+        if ragged_every and i % ragged_every == 5:
+            row += ",extra"                                             # wrong width: dropped (ignore_errors)
+        lines.append(row)
+    return ("\n".join(lines) + "\n").encode()
+
+
+COLS4 = [S.IdColumn("movieId", "id", 1001), S.IdColumn("userId", "id", 30001), S.IdColumn("userGenre1", "genre", 19),
+         S.IdColumn("movieGenre1", "genre", 19)]
+
+
+@pytest.mark.parametrize("threads", [2, 3, 8, 64])
+def test_multithreaded_pack_is_identical(threads):
+    text = _synthetic_csv(60000, seed=1, ragged_every=1000)
+    assert len(text) > (1 << 20)
+    ids1, dense1 = pack_csv(text, COLS4, ["releaseYear", "movieAvgRating"])
+    idsN, denseN = pack_csv(text, COLS4, ["releaseYear", "movieAvgRating"], threads=threads)
+    assert ids1.shape[0] == 60000 - 60
+    np.testing.assert_array_equal(ids1, idsN)
+    np.testing.assert_array_equal(dense1, denseN)
+    # max_rows cuts the same prefix
+    idsC, denseC = pack_csv(text, COLS4, ["releaseYear", "movieAvgRating"], max_rows=12345, threads=threads)
+    np.testing.assert_array_equal(idsC, ids1[:12345])
+    np.testing.assert_array_equal(denseC, dense1[:12345])
+
+
+def test_multithreaded_pack_reports_the_first_error_like_one_thread():
+    text = _synthetic_csv(60000, seed=2, bad_at=41000)
+    msgs = []
+    for threads in (1, 4, 16):
+        with pytest.raises(ValueError) as e:
+            pack_csv(text, COLS4, ["releaseYear"], threads=threads)
+        msgs.append(str(e.value))
+    assert len(set(msgs)) == 1 and "row 41000" in msgs[0] and "movieId id 1001" in msgs[0]
+    # the bad row lies beyond max_rows: never looked at, with any thread count
+    for threads in (1, 4, 16):
+        ids, _ = pack_csv(text, COLS4, ["releaseYear"], max_rows=40000, threads=threads)
+        assert ids.shape[0] == 40000
+
+
+def test_multithreaded_pack_throughput_note():
+    text = _synthetic_csv(200000, seed=3)
+    t = {}
+    for threads in (1, 8):
+        t0 = time.perf_counter()
+        ids, _ = pack_csv(text, COLS4, ["releaseYear", "movieAvgRating"], threads=threads)
+        t[threads] = time.perf_counter() - t0
+    print("pack_csv: 1 thread %.2f M rows/s, 8 threads %.2f M rows/s" % (0.2 / t[1], 0.2 / t[8]))
+    assert ids.shape[0] == 200000
