@@ -86,20 +86,32 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     (hipcc cross-compiles without a GPU)."""
     csrc = os.path.dirname(SRC_PATH)
     deps = [os.path.join(csrc, f) for f in os.listdir(csrc)] + [os.path.join(INCLUDE_DIR, "sparrow_hip.h")]
-    if not force and os.path.exists(LIB_PATH) and os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(d) for d in deps):
+    def fresh():
+        return os.path.exists(LIB_PATH) and os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(d) for d in deps)
+    if not force and fresh():
         return LIB_PATH
-    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    if not os.path.exists(hipcc):
-        hipcc = "hipcc"
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-pthread",
-           "-I", INCLUDE_DIR, "-I", os.path.dirname(SRC_PATH), SRC_PATH, "-o", LIB_PATH + ".tmp"]
-    if verbose:
-        print(" ".join(cmd))
-    res = subprocess.run(cmd, capture_output=True, text=True)
-    if res.returncode != 0:
-        raise RuntimeError("hipcc failed:\n%s\n%s" % (res.stdout, res.stderr))
-    os.replace(LIB_PATH + ".tmp", LIB_PATH)
-    return LIB_PATH
+    # several processes (one rank per GPU, pytest-xdist workers) may get here at once: one builds, the others wait
+    import fcntl
+    with open(LIB_PATH + ".lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and fresh():
+                return LIB_PATH
+            hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+            if not os.path.exists(hipcc):
+                hipcc = "hipcc"
+            tmp = "%s.tmp.%d" % (LIB_PATH, os.getpid())
+            cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-pthread",
+                   "-I", INCLUDE_DIR, "-I", os.path.dirname(SRC_PATH), SRC_PATH, "-o", tmp]
+            if verbose:
+                print(" ".join(cmd))
+            res = subprocess.run(cmd, capture_output=True, text=True)
+            if res.returncode != 0:
+                raise RuntimeError("hipcc failed:\n%s\n%s" % (res.stdout, res.stderr))
+            os.replace(tmp, LIB_PATH)
+            return LIB_PATH
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
 
 
 def load_library():
@@ -123,7 +135,7 @@ def load_library():
         lib.sprk_workspace_bytes.restype = sz
         fwd = [vp, vp, vp, vp, i32, vp, sz, vp]
         for name in ("sprk_forward", "sprk_forward_embedding_mlp", "sprk_forward_widedeep", "sprk_forward_neuralcf",
-                     "sprk_forward_deepfm", "sprk_forward_deepfm_v2", "sprk_forward_din"):
+                     "sprk_forward_deepfm", "sprk_forward_deepfm_v2", "sprk_forward_din", "sprk_forward_dien"):
             getattr(lib, name).argtypes = fwd
         lib.sprk_forward_many.argtypes = [vp, i32, vp, vp, vp, i32, vp, sz, vp]
         lib.sprk_din_pool.argtypes = [vp, vp, vp, vp, i32, vp]
@@ -136,6 +148,9 @@ def load_library():
         lib.sprk_set_many_streams.argtypes = [vp, i32]
         lib.sprk_pack_csv.argtypes = [C.c_char_p, sz, C.POINTER(CsvCol), i32, C.POINTER(C.c_char_p), i32, i32, vp, vp,
                                       C.POINTER(i32)]
+        lib.sprk_pack_csv_mt.argtypes = [C.c_char_p, sz, C.POINTER(CsvCol), i32, C.POINTER(C.c_char_p), i32, i32, i32, vp, vp,
+                                         C.POINTER(i32)]
+        lib.sprk_emb_rank.argtypes = [vp, vp, i32, i32, i32, vp, vp, i32, i32, vp, i32, vp, vp, vp]
         for name in EXPORTED_SYMBOLS:
             if name not in ("sprk_last_error", "sprk_destroy", "sprk_workspace_bytes"):
                 getattr(lib, name).restype = C.c_int
