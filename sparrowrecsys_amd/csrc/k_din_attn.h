@@ -110,6 +110,37 @@ __device__ __forceinline__ float row16_sum(float v) {
     return v;
 }
 
+// Reduce-scatter over the 16 lanes of a DPP row: every lane comes in with EL partial sums v[0..EL), lane r < EL goes out
+// with the row's total of ONE element, e_out(r) -- a halving butterfly (xor 1, 2 by DPP quad permutes, xor 4, 8 by
+// ds_bpermute): 2 EL + 6 instructions instead of the 8 EL of EL full row sums.
+template <int EL>
+__device__ __forceinline__ float row16_reduce_scatter(const float (&v)[EL], int r, int& e_out) {
+    static_assert(EL == 4 || EL == 8, "4 or 8 partials per lane");
+    const bool b0 = r & 1, b1 = r & 2, b2 = r & 4;
+    float a[EL / 2];
+#pragma unroll
+    for (int i = 0; i < EL / 2; ++i) {                           // xor 1: odd lanes keep the upper half
+        const float send = b0 ? v[i] : v[i + EL / 2], keep = b0 ? v[i + EL / 2] : v[i];
+        a[i] = keep + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, send), 0xB1, 0xF, 0xF, true));
+    }
+    float b[EL / 4];
+#pragma unroll
+    for (int i = 0; i < EL / 4; ++i) {                           // xor 2
+        const float send = b1 ? a[i] : a[i + EL / 4], keep = b1 ? a[i + EL / 4] : a[i];
+        b[i] = keep + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, send), 0x4E, 0xF, 0xF, true));
+    }
+    float t;
+    if constexpr (EL == 8) {                                     // xor 4
+        const float send = b2 ? b[0] : b[1], keep = b2 ? b[1] : b[0];
+        t = keep + __shfl_xor(send, 4);
+        e_out = (b0 ? 4 : 0) | (b1 ? 2 : 0) | (b2 ? 1 : 0);
+    } else {
+        t = b[0] + __shfl_xor(b[0], 4);
+        e_out = (b0 ? 2 : 0) | (b1 ? 1 : 0);
+    }
+    return t + __shfl_xor(t, 8);
+}
+
 // sum over the four 16-lane rows (q = 0..3) of a wave, result in every lane: v_permlane16_swap /
 // v_permlane32_swap (gfx950) exchange rows inside the VALU, no LDS round trip as ds_bpermute would take
 __device__ __forceinline__ float rows4_sum(float v) {
@@ -417,15 +448,15 @@ __global__ __launch_bounds__(256, 2) void k_din_attn(const DinRun A, const int* 
             if (g < G) score_groups(g, std::false_type{});
         }
 
-        // ---- reduce the pooled partials over the 16 r-lanes of each q row (DPP adds, no LDS) ----
+        // ---- reduce the pooled partials over the 16 r-lanes of each q row: lane r < EL ends up with element e(r) ----
+        {
+            float pv[EL];
 #pragma unroll
-        for (int c = 0; c < KC; ++c)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) pacc[c][j] = row16_sum(pacc[c][j]);
-        if (r == 0) {
-#pragma unroll
-            for (int c = 0; c < KC; ++c)
-                if (kof(c) < Dp) st4(pooled + (size_t)s * Dp + kof(c), HALF ? pacc[c] * A.inv_h_scale : pacc[c]);
+            for (int e = 0; e < EL; ++e) pv[e] = pacc[e >> 2][e & 3];
+            int e_mine;
+            const float tot = row16_reduce_scatter<EL>(pv, r, e_mine);
+            const int k = kof(e_mine >> 2) + (e_mine & 3);
+            if (r < EL && k < Dp) pooled[(size_t)s * Dp + k] = HALF ? tot * A.inv_h_scale : tot;
         }
     }
     if (__ballot(bad) != 0 && lane == 0) atomicOr(err, 1);
