@@ -154,6 +154,12 @@ def main():
                          "the TIMED region: a dependent launch chain costs ~3.3 us per launch even for an empty kernel, so the "
                          "predict-over-batches loop is launch bound without it.  The roofline block is always measured in strict "
                          "order (one kernel at a time), in its own loop after the timed region.")
+    ap.add_argument("--launch-batches", type=int, default=16,
+                    help="batches ONE kernel launch scores in the timed region (sprk_set_many_batches, up to 64; 1 = a launch per "
+                         "batch; deepfm_v2_c2 only).  Each batch keeps its own buffers of --batch rows; the ~3.3 us launch floor is "
+                         "spent once per N batches.  With N > 1 the launches of the timed region run in strict order (no stream "
+                         "fan-out).  The `roofline` block stays ONE batch per launch; `roofline_timed_region` describes the "
+                         "N-batch launches.")
     ap.add_argument("--big-vocab", type=int, default=0,
                     help="deepfm_v2_c2 only: rows of each identity table (e.g. 8388608 = 1 GiB of folded rows per table, "
                          "far beyond the Infinity Cache); default 0 = the MovieLens-20M-shaped vocabularies of the config")
@@ -192,6 +198,12 @@ def main():
     B = args.batch or {"din_c3": 32768, "widedeep_c5": 131072}.get(args.workload, 65536)
     model, feats, desc, roof = build_workload(args.workload, B, args.dist, seed_offset=rank, big_vocab=args.big_vocab)
     eng = model.engine
+    lb = args.launch_batches if (args.launch_batches > 1 and args.workload == "deepfm_v2_c2"
+                                 and os.environ.get("SPRK_V2_JOINT") != "0" and os.environ.get("SPRK_V2_FOLD") != "0"
+                                 and os.environ.get("SPRK_FORCE_INTERPRETER") != "1") else 1
+    if lb > 1:
+        eng.set_many_batches(lb)
+        args.overlap_streams = 0           # several batches per launch: strict order measured faster than the fan-out
     fan = args.overlap_streams if (args.overlap_streams >= 2 and eng.set_many_streams(args.overlap_streams)) else 0
     batches = []
     for f in feats:
@@ -259,6 +271,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     ev_ms = ev0.elapsed_time(ev1)
+    ev_ms_timed = ev_ms
     if dist_on:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -268,10 +281,12 @@ def main():
     # time, what rocprofv3's per-kernel duration measures), re-timed right after the timed region whenever that region
     # overlapped launches (fan-out) or held the all-gathers (N>1)
     region = "timed region"
-    if dist_on or fan:
+    if dist_on or fan or lb > 1:
         region = "strict-order forward loop after the timed region"
         if fan:
             eng.set_many_streams(0)
+        if lb > 1:
+            eng.set_many_batches(1)
         torch.cuda.synchronize()
         ev0.record()
         idx = [i % NB for i in range(args.steps)]
@@ -281,6 +296,8 @@ def main():
         ev_ms = ev0.elapsed_time(ev1)
         if fan:
             eng.set_many_streams(fan)
+        if lb > 1:
+            eng.set_many_batches(lb)
     fwd_s = ev_ms * 1e-3 / args.steps          # avg forward duration (all kernels of one step)
 
     # output spot check against the oracle (outside the timed region)
@@ -307,6 +324,9 @@ def main():
                   "avg_launch_us": fwd_s * 1e6, "timed_with": "HIP events, " + region}
             if fan:
                 rl["timed_with"] += " (the timed region itself fans independent batches over %d streams: ms_per_step %.5f)" % (fan, elapsed * 1e3 / args.steps)
+            if lb > 1:
+                rl["kernel"] += " (one batch of %d rows per launch)" % B
+                rl["timed_with"] += "; ONE batch per launch -- the north-star's 'at batch 65 536' figure.  The timed region scores %d batches per launch, see roofline_timed_region" % lb
         else:
             # DIN step = k_din_pool + k_tile_forward; time the attention kernel alone for its MFMA fraction
             pooled = torch.empty((B, eng.n_aux), dtype=torch.float32, device="cuda")
@@ -359,13 +379,22 @@ def main():
                                       + ("" if world == 1 else " (one collective per %d steps, overlapped; %d collectives in the timed region)"
                                          % (gs.G, (args.steps + gs.G - 1) // gs.G)),
                        "oracle_check_max_abs_err": check,
-                       "launch_overlap_streams": fan,
+                       "launch_overlap_streams": fan, "batches_per_launch": lb,
                        "arithmetic": "fp32 semantics; contractions whose operands are bounded at finalize (table rows x weights) run on "
                                      "v_mfma_f32_16x16x32_f16 with split operands hi + lo (22 significand bits) and f32 accumulation -- "
                                      "fp32-class error, tests/test_gpu_parity.py::test_deepfm_v2_split_f16_is_fp32_class; everything else "
                                      "on f32 MFMA / VALU (SPRK_V2_HALF=0 / SPRK_DIN_HALF=0 force f32 MFMA throughout)"},
             "roofline": rl,
         }
+        if lb > 1 and not dist_on and roof["bound"] == "hbm":
+            # the timed region's own launches: lb batches (own buffers, B rows each) per launch, strict stream order, so the
+            # HIP events around the region bracket exactly ceil(K / lb) back-to-back launches of the multi-batch instantiation
+            n_launch = (args.steps + lb - 1) // lb
+            ach = roof["bytes_per_sample"] * B * args.steps / (ev_ms_timed * 1e-3) / 1e9
+            line["roofline_timed_region"] = {
+                "bound": "hbm", "kernel": roof["kernel"] + " (multi-batch instantiation, %d batches of %d rows per launch)" % (lb, B),
+                "achieved": ach, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": ach * 1e9 / HBM_PEAK,
+                "launches": n_launch, "avg_launch_us": ev_ms_timed * 1e3 / n_launch, "timed_with": "HIP events around the timed region"}
         if world == 1 and args.cpu_seconds > 0:
             line["cpu_baseline"] = cpu_baseline(args.workload, model, feats, args.cpu_seconds)
         # RCCL prints a version banner through C stdio, which (stdout being a pipe) would otherwise be flushed at exit,

@@ -209,6 +209,12 @@ int sprk_forward_many(sprk_handle h, int32_t n_batches, const int32_t* const* id
  * slice of sprk_workspace_bytes(B) per stream. */
 int sprk_set_many_streams(sprk_handle h, int32_t n);
 
+/* How many of sprk_forward_many's batches ONE kernel launch scores (1 = a launch per batch, the default; up to 64).  Each
+ * batch keeps its own ids / dense / out buffers of B rows; the launch walks the tasks of all of them, so the fixed cost of
+ * a launch is spent once per n batches.  Bit-identical results.  Honoured by the fused DeepFM_v2 kernel with 16-byte
+ * aligned buffers; every other case silently goes batch by batch (and takes sprk_set_many_streams into account). */
+int sprk_set_many_batches(sprk_handle h, int32_t n);
+
 /* Per-model entry points: identical to sprk_forward but fail with
  * SPRK_EKIND unless the handle was created from that model's plan. */
 int sprk_forward_embedding_mlp(sprk_handle h, const int32_t* ids, const float* dense, float* out, int32_t B, void* ws, size_t ws_bytes, void* stream);

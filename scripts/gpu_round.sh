@@ -11,13 +11,17 @@ timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3 | 
 echo "=== bench"
 b() { out=$1; shift; timeout 600 env "$@" 2>&1 | tail -1 | tee gpurun_out/$out.json | cut -c1-200; }
 b bench_c2 python bench.py
-b bench_c2_joint_f32 SPRK_V2_HALF=0 python bench.py --cpu-seconds 0
+b bench_c2_lb32 python bench.py --cpu-seconds 0 --launch-batches 32
+b bench_c2_lb64 python bench.py --cpu-seconds 0 --launch-batches 64
+b bench_c2_lb1 python bench.py --cpu-seconds 0 --launch-batches 1
+b bench_c2_joint_f32 SPRK_V2_HALF=0 python bench.py --cpu-seconds 0 --launch-batches 1
 b bench_c2_perfield SPRK_V2_JOINT=0 python bench.py --cpu-seconds 0
 b bench_c2_unfolded SPRK_V2_FOLD=0 python bench.py --cpu-seconds 0
 b bench_c2_interp SPRK_FORCE_INTERPRETER=1 python bench.py --cpu-seconds 0
-b bench_c2_zipf python bench.py --cpu-seconds 0 --dist zipf
-b bench_c2_b1m python bench.py --cpu-seconds 0 --batch 1048576 --steps 400 --warmup 40
-b bench_c2_strict python bench.py --cpu-seconds 0 --overlap-streams 0
+b bench_c2_zipf python bench.py --cpu-seconds 0 --dist zipf --launch-batches 1
+b bench_c2_zipf_lb16 python bench.py --cpu-seconds 0 --dist zipf
+b bench_c2_b1m python bench.py --cpu-seconds 0 --batch 1048576 --steps 400 --warmup 40 --launch-batches 1
+b bench_c2_strict python bench.py --cpu-seconds 0 --overlap-streams 0 --launch-batches 1
 b bench_c2_pairs python bench.py --workload deepfm_c2 --cpu-seconds 0
 b bench_c2_pairs_interp SPRK_V1_CHAIN=0 python bench.py --workload deepfm_c2 --cpu-seconds 0
 b bench_c3 python bench.py --steps 300 --warmup 30 --workload din_c3 --cpu-seconds 6
@@ -57,7 +61,7 @@ cd /tmp && export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_c2 -o c2 -- python $R/bench.py --steps 400 --warmup 40 --cpu-seconds 0 --no-check > $R/gpurun_out/prof_c2.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_c3 -o c3 -- python $R/bench.py --steps 50 --warmup 5 --workload din_c3 --cpu-seconds 0 --no-check > $R/gpurun_out/prof_c3.log 2>&1
 # the same commands with launches in strict stream order: per-kernel durations comparable with bench.py's roofline block
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_c2s -o c2_strict -- python $R/bench.py --steps 400 --warmup 40 --cpu-seconds 0 --no-check --overlap-streams 0 > $R/gpurun_out/prof_c2s.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_c2s -o c2_strict -- python $R/bench.py --steps 400 --warmup 40 --cpu-seconds 0 --no-check --overlap-streams 0 --launch-batches 1 > $R/gpurun_out/prof_c2s.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_c3s -o c3_strict -- python $R/bench.py --steps 50 --warmup 5 --workload din_c3 --cpu-seconds 0 --no-check --overlap-streams 0 > $R/gpurun_out/prof_c3s.log 2>&1
 cd $R
 tail -1 gpurun_out/prof_c2s.log | cut -c1-200; tail -1 gpurun_out/prof_c3s.log | cut -c1-200

@@ -58,6 +58,19 @@ struct V2JRun {
     float w_scale, unscale_h, unscale_s;  // 2^sW, 2^-(sP+sW), 2^-sP
 };
 
+// Multi-batch launch (sprk_forward_many with sprk_set_many_batches > 1): one launch scores up to V2J_MB batches of B rows,
+// each with its own ids / dense / out buffers; task t of the launch is task t % ntpb of batch t / ntpb.  A dependent launch
+// chain costs ~3.3 us per launch on this stack, more than a third of a 65 536-row forward; one launch per 16 (up to 64)
+// batches spends it once.  Results are bit-identical to per-batch launches (samples are independent).
+#define V2J_MB 64
+struct V2JMany {
+    const int* ids[V2J_MB];
+    const float* dense[V2J_MB];
+    float* out[V2J_MB];
+    int n;                                // batches in this launch
+    int ntpb;                             // tasks per batch = ceil(B / 16)
+};
+
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
@@ -147,12 +160,12 @@ struct V2JSet {
 // score(A), gather(A'), score(B), gather(B') with ids fetched two tasks ahead, i.e. one gather is
 // always in flight under a scoring stage.  Loads are unconditional (task indices are clamped, the tail
 // re-gathers a valid task and drops the result) so that the in-order vmcnt waits stay exact.
-template <int G_BIG, int NJF, int KPC, int H0C, int H1C, int WAVES, bool HALF>
+template <int G_BIG, int NJF, int KPC, int H0C, int H1C, int WAVES, bool HALF, bool MB = false>
 __global__ __launch_bounds__(WAVES * 64, 2) void k_deepfm_v2_joint(const V2JRun A, const int* __restrict__ ids,
                                                                    const float* __restrict__ dense,
                                                                    float* __restrict__ out, int B,
                                                                    int* __restrict__ err,
-                                                                   const float* __restrict__ image) {
+                                                                   const float* __restrict__ image, const V2JMany M) {
     constexpr int G_EMB = G_BIG + NJF;
     using LD = V2Lds<G_EMB, 4, KPC, H0C, H1C, true>;          // the weight image is the FOLD image of the whole model
     using Set = V2JSet<G_BIG, NJF>;
@@ -167,30 +180,51 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_deepfm_v2_joint(const V2JRun 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 15, q = lane >> 4;
     const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int ntasks = (B + 15) >> 4;
+    const int ntasks = MB ? M.n * M.ntpb : (B + 15) >> 4;
     const int task_stride = gridDim.x * WAVES;
     const int wave_global = blockIdx.x * WAVES + wave;
+    // MB: (batch, task inside the batch) of launch task tk (wave-uniform), and that batch's buffers
+    auto batch_of = [&](int tk, int& tl) {
+        if constexpr (MB) {
+            const int b = __builtin_amdgcn_readfirstlane(tk / M.ntpb);
+            tl = tk - b * M.ntpb;
+            return b;
+        } else {
+            tl = tk;
+            return 0;
+        }
+    };
     float* stage = smem + LD::total_pad + wave * LD::stage_floats;
     const float* small_s = smem + LD::total_pad + WAVES * LD::stage_floats;   // small fields' rows
     const float* wq = smem + 4 * q;
     bool bad = false;
     const bool aligned = !(A.flags & 1);
     auto clampt = [&](int tk) { return tk < ntasks ? tk : ntasks - 1; };
+    const int* const ids0 = ids;
+    const float* const dense0 = dense;
 
     // ---- gather stage ----
     //   ld_raw : the task's contiguous ids / numerics blocks, one 16-B load per lane
     //   gather : VGPR -> wave-private LDS slot -> the (r,q) lanes that need them, then the row gathers
-    auto ld_raw = [&](int tk, f32x4& raw) {
+    auto ld_raw = [&](int tkg, f32x4& raw) {
+        int tk;
+        const int bi = batch_of(tkg, tk);
+        const int* ids_b = MB ? M.ids[bi] : ids;
+        const float* dense_b = MB ? M.dense[bi] : dense;
         if (aligned && tk * 16 + 16 <= B) {                       // wave-uniform
             const bool isid = lane < 32;
             const int j = isid ? lane : lane - 32;
             const int n4 = 4 * (isid ? A.F : A.ND);
-            const float* src = isid ? reinterpret_cast<const float*>(ids) + (size_t)tk * 16 * A.F
-                                    : dense + (size_t)tk * 16 * A.ND;
+            const float* src = isid ? reinterpret_cast<const float*>(ids_b) + (size_t)tk * 16 * A.F
+                                    : dense_b + (size_t)tk * 16 * A.ND;
             raw = ld4(src + 4 * (j < n4 ? j : 0));
         }
     };
-    auto gather = [&](int tk, const f32x4& raw, Set& S) {
+    auto gather = [&](int tkg, const f32x4& raw, Set& S) {
+        int tk;
+        const int bi = batch_of(tkg, tk);
+        const int* ids = MB ? M.ids[bi] : ids0;
+        const float* dense = MB ? M.dense[bi] : dense0;
         if (aligned && tk * 16 + 16 <= B) {
             const bool isid = lane < 32;
             const int j = isid ? lane : lane - 32;
@@ -390,9 +424,12 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_deepfm_v2_joint(const V2JRun 
         z += __shfl_xor(z, 32);
         return sigmoidf_fast(z + A.h0w * A.fo_bias + A.head_bias);
     };
-    auto store = [&](int tk, float score) {
+    auto store = [&](int tkg, float score) {
+        int tk;
+        const int bi = batch_of(tkg, tk);
+        float* out_b = MB ? M.out[bi] : out;
         const int m = tk * 16 + r;
-        if (q == 0 && m < B) out[m] = score;
+        if (q == 0 && m < B) out_b[m] = score;
     };
 
     // ---- prologue: ids of the first two tasks and the weight image are requested together (the image

@@ -702,6 +702,7 @@ struct sprk_engine {
     size_t v2_fo_floats = 0;
     // ... with the small-vocabulary fields folded into one joint table (k_deepfm_v2_joint); -1 = not used
     int v2j_variant = -1;
+    int many_batches = 1;                 // sprk_forward_many: batches scored per launch (sprk_set_many_batches)
     V2JRun v2j_run;
     float* v2j_tab = nullptr;      // small fields' LDS rows (device image)
     size_t v2j_lds_bytes = 0;
@@ -879,20 +880,31 @@ const V2Variant kV2Variants[] = {
 
 // ---- dispatch table for k_deepfm_v2_joint<G_BIG, NJF, KPC, H0C, H1C, WAVES> ----
 typedef void (*V2JLaunchFn)(const V2JRun&, const int*, const float*, float*, int, int*, const float*, int, size_t, hipStream_t);
+typedef void (*V2JLaunchManyFn)(const V2JRun&, const V2JMany&, int, int*, const float*, int, size_t, hipStream_t);
 template <int G_BIG, int NJF, bool HALF>
 void v2j_launch(const V2JRun& a, const int* ids, const float* dense, float* out, int B, int* err, const float* image,
                 int grid, size_t lds, hipStream_t st) {
-    hipLaunchKernelGGL((k_deepfm_v2_joint<G_BIG, NJF, 1, 2, 1, V2_WAVES, HALF>), dim3(grid), dim3(V2_WAVES * 64), lds, st,
-                       a, ids, dense, out, B, err, image);
+    static const V2JMany none{};
+    hipLaunchKernelGGL((k_deepfm_v2_joint<G_BIG, NJF, 1, 2, 1, V2_WAVES, HALF, false>), dim3(grid), dim3(V2_WAVES * 64), lds, st,
+                       a, ids, dense, out, B, err, image, none);
+}
+template <int G_BIG, int NJF, bool HALF>
+void v2j_launch_many(const V2JRun& a, const V2JMany& m, int B, int* err, const float* image, int grid, size_t lds, hipStream_t st) {
+    hipLaunchKernelGGL((k_deepfm_v2_joint<G_BIG, NJF, 1, 2, 1, V2_WAVES, HALF, true>), dim3(grid), dim3(V2_WAVES * 64), lds, st,
+                       a, (const int*)nullptr, (const float*)nullptr, (float*)nullptr, B, err, image, m);
 }
 struct V2JVariant {
     int g_big, njf;
     bool half;                            // big fields on split-f16 MFMA
     const void* fn;
+    const void* fn_many;
     V2JLaunchFn launch;
+    V2JLaunchManyFn launch_many;
 };
 #define V2J_VARIANT(G_BIG, NJF, HALF) \
-    {G_BIG, NJF, HALF, reinterpret_cast<const void*>(&k_deepfm_v2_joint<G_BIG, NJF, 1, 2, 1, V2_WAVES, HALF>), &v2j_launch<G_BIG, NJF, HALF>}
+    {G_BIG, NJF, HALF, reinterpret_cast<const void*>(&k_deepfm_v2_joint<G_BIG, NJF, 1, 2, 1, V2_WAVES, HALF, false>), \
+     reinterpret_cast<const void*>(&k_deepfm_v2_joint<G_BIG, NJF, 1, 2, 1, V2_WAVES, HALF, true>), &v2j_launch<G_BIG, NJF, HALF>, \
+     &v2j_launch_many<G_BIG, NJF, HALF>}
 #define V2J_BOTH(G_BIG, NJF) V2J_VARIANT(G_BIG, NJF, true), V2J_VARIANT(G_BIG, NJF, false)
 const V2JVariant kV2JVariants[] = {
     V2J_BOTH(3, 3),    // BASELINE config 2: movieId, userId, userRatedMovie1 + a joint table of the three genre fields
@@ -1120,6 +1132,7 @@ int setup_v2_joint(sprk_engine* h) {
     }
     h->v2j_lds_bytes = vv.lds_bytes + small_floats * sizeof(float);
     HIP_TRY(hipFuncSetAttribute(kV2JVariants[variant].fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->v2j_lds_bytes));
+    HIP_TRY(hipFuncSetAttribute(kV2JVariants[variant].fn_many, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->v2j_lds_bytes));
     h->v2j_variant = variant;
     return SPRK_OK;
 }
@@ -2098,6 +2111,33 @@ int sprk_forward_many(sprk_handle h, int32_t n_batches, const int32_t* const* id
         while (S >= 2 && (!workspace || workspace_bytes < (size_t)S * ws_need)) --S;
         if (S < 2) S = 0;
     }
+    // several batches per launch (sprk_set_many_batches): the fused DeepFM_v2 kernel takes up to V2J_MB batches' buffers
+    // and walks their tasks as one grid; everything else (other models, unaligned buffers, tracing) goes batch by batch
+    if (h->finalized && h->many_batches > 1 && n_batches > 1 && h->v2_variant >= 0 && h->v2j_variant >= 0 && !h->v2run.trace &&
+        !getenv("SPRK_V2_XFLAGS") && B > 0 && ids && dense) {
+        bool ok = true;
+        for (int32_t i = 0; i < n_batches && ok; ++i)
+            ok = ids[i] && dense[i] && out[i] && !(((uintptr_t)ids[i] | (uintptr_t)dense[i]) & 15);
+        if (ok) {
+            const int ntpb = (B + 15) / 16;
+            const V2JVariant& jv = kV2JVariants[h->v2j_variant];
+            V2JRun jr = h->v2j_run;
+            jr.flags = 0;
+            for (int32_t i0 = 0; i0 < n_batches; i0 += h->many_batches) {
+                V2JMany m;
+                memset(&m, 0, sizeof(m));
+                m.n = n_batches - i0 < h->many_batches ? n_batches - i0 : h->many_batches;
+                m.ntpb = ntpb;
+                for (int j = 0; j < m.n; ++j) { m.ids[j] = ids[i0 + j]; m.dense[j] = dense[i0 + j]; m.out[j] = out[i0 + j]; }
+                const long long ntasks = (long long)m.n * ntpb;
+                long long grid = (ntasks + V2_WAVES - 1) / V2_WAVES;
+                if (grid > h->v2_grid_cap) grid = h->v2_grid_cap;
+                jv.launch_many(jr, m, B, h->dev_err, h->v2_image, (int)grid, h->v2j_lds_bytes, (hipStream_t)stream);
+                HIP_TRY(hipGetLastError());
+            }
+            return SPRK_OK;
+        }
+    }
     if (S >= 2) {
         HIP_TRY(hipEventRecord(h->many_fork, (hipStream_t)stream));
         for (int s = 0; s < S; ++s) HIP_TRY(hipStreamWaitEvent(h->many_stream[s], h->many_fork, 0));
@@ -2137,6 +2177,14 @@ int sprk_set_many_streams(sprk_handle h, int32_t n) {
     if (!h->finalized) return fail(SPRK_ESTATE, "set_many_streams before finalize");
     if (n < 0 || n > 4) return fail(SPRK_EINVAL, "stream count %d outside [0,4]", n);
     h->many_streams = n < 2 ? 0 : n;
+    return SPRK_OK;
+}
+
+int sprk_set_many_batches(sprk_handle h, int32_t n) {
+    if (!h) return fail(SPRK_EINVAL, "handle is NULL");
+    if (!h->finalized) return fail(SPRK_ESTATE, "set_many_batches before finalize");
+    if (n < 1 || n > V2J_MB) return fail(SPRK_EINVAL, "batches per launch %d outside [1,%d]", n, V2J_MB);
+    h->many_batches = n;
     return SPRK_OK;
 }
 

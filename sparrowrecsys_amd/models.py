@@ -153,6 +153,11 @@ class Engine:
         L.check(self.lib.sprk_set_many_streams(self.handle, int(n)))
         return True
 
+    def set_many_batches(self, n: int) -> bool:
+        """Let one kernel launch score up to ``n`` of forward_many's batches (1 = a launch per batch)."""
+        L.check(self.lib.sprk_set_many_batches(self.handle, int(n)))
+        return True
+
     def many_workspace_bytes(self, B: int, n: int) -> int:
         """Workspace size that lets forward_many fan a workspace model over ``n`` streams."""
         need = (self.workspace_bytes(B) + 255) & ~255

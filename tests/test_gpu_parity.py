@@ -630,6 +630,49 @@ def test_forward_many_fan_out_over_streams(torch, monkeypatch):
         np.testing.assert_array_equal(a, b)
 
 
+@pytest.mark.parametrize("B,n,k", [(4099, 7, 4), (65536, 5, 16), (1000, 17, 16), (16, 3, 2), (33, 70, 64), (2048, 2, 16)])
+def test_forward_many_several_batches_per_launch(torch, B, n, k):
+    """sprk_set_many_batches(k): one launch of the fused DeepFM_v2 kernel scores up to k batches (own buffers each); scores
+    equal the launch-per-batch run bit for bit, ragged B and a ragged last launch included; unaligned buffers and other
+    models fall back to launch-per-batch."""
+    feats = [SY.synth_fields(B, SY.CONFIG2_FIELDS, seed=180 + i, dist="zipf" if i % 2 else "uniform") for i in range(n)]
+    model = M.DeepFMv2(seed=58, emb_dim=16, fields=SY.CONFIG2_FIELDS, proj_dim=16)
+    eng = model.engine
+    packed = [model.pack(f) for f in feats]
+    ids = [_cuda(torch, p[0]) for p in packed]
+    dense = [_cuda(torch, p[1]) for p in packed]
+    res = {}
+    for kk in (1, k):
+        assert eng.set_many_batches(kk)
+        outs = [torch.full((B,), -1.0, dtype=torch.float32, device="cuda") for _ in range(n)]
+        eng.forward_many(ids, dense, outs)
+        torch.cuda.synchronize()
+        eng.check_ids()
+        res[kk] = [o.cpu().numpy() for o in outs]
+    for a, b in zip(res[1], res[k]):
+        np.testing.assert_array_equal(a, b)
+    ref = O.deepfm_v2_forward(feats[-1], model.weights, dtype=np.float64, fields=SY.CONFIG2_FIELDS,
+                              order=[f for f, _, _ in SY.CONFIG2_FIELDS])[:, 0]
+    assert np.abs(res[k][-1] - ref).max() <= TIGHT
+    # an out-of-range id in a later batch of a launch is still flagged
+    bad = packed[-1][0].copy()
+    bad[B // 2, 0] = 10 ** 6
+    eng.forward_many(ids[:-1] + [_cuda(torch, bad)], dense, [torch.empty(B, dtype=torch.float32, device="cuda") for _ in range(n)])
+    with pytest.raises(ValueError):
+        eng.check_ids()
+    # unaligned buffers: served launch by launch, same scores
+    if B >= 33:
+        big_i = torch.empty(B * 6 + 3, dtype=torch.int32, device="cuda")
+        off_ids = [big_i[1:1 + B * 6].view(B, 6).copy_(i) for i in ids[:1]] + ids[1:]
+        outs = [torch.full((B,), -1.0, dtype=torch.float32, device="cuda") for _ in range(n)]
+        eng.forward_many(off_ids, dense, outs)
+        torch.cuda.synchronize()
+        for a, o in zip(res[1], outs):
+            np.testing.assert_array_equal(a, o.cpu().numpy())
+    with pytest.raises(L.SparrowHipError):
+        eng.set_many_batches(65)
+
+
 # --------------------------------------------------------------------------------------------
 # k_mlp_chain: EmbeddingMLP / Wide&Deep graphs as a register-chained kernel
 # --------------------------------------------------------------------------------------------
