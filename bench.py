@@ -363,7 +363,7 @@ def main():
         if os.path.exists(tpath):
             try:
                 t = json.load(open(tpath)).get(args.workload)
-                if t and t.get("batch") == B and t.get("kernel") == rl["kernel"]:
+                if t and t.get("batch") == B and t.get("kernel") == roof["kernel"]:
                     traffic = t["bytes_per_launch"]
                     rl["traffic_source"] = "profiles/traffic.json (PMC FETCH_SIZE x2 + WRITE_SIZE, round %s)" % t.get("round")
             except Exception:
