@@ -198,12 +198,15 @@ def main():
     B = args.batch or {"din_c3": 32768, "widedeep_c5": 131072}.get(args.workload, 65536)
     model, feats, desc, roof = build_workload(args.workload, B, args.dist, seed_offset=rank, big_vocab=args.big_vocab)
     eng = model.engine
-    lb = args.launch_batches if (args.launch_batches > 1 and args.workload == "deepfm_v2_c2"
-                                 and os.environ.get("SPRK_V2_JOINT") != "0" and os.environ.get("SPRK_V2_FOLD") != "0"
-                                 and os.environ.get("SPRK_FORCE_INTERPRETER") != "1") else 1
+    lb = 1
+    if args.launch_batches > 1 and os.environ.get("SPRK_FORCE_INTERPRETER") != "1":
+        if args.workload == "deepfm_v2_c2" and os.environ.get("SPRK_V2_JOINT") != "0" and os.environ.get("SPRK_V2_FOLD") != "0":
+            lb = args.launch_batches
+            args.overlap_streams = 0       # several batches per launch: strict order measured faster than the fan-out
+        elif args.workload == "din_c3" and os.environ.get("SPRK_DIN_LEGACY") != "1" and os.environ.get("SPRK_DIN_TAIL") != "0":
+            lb = min(args.launch_batches, 16)   # groups of batches: one attention + one tail launch each, alternating streams
     if lb > 1:
         eng.set_many_batches(lb)
-        args.overlap_streams = 0           # several batches per launch: strict order measured faster than the fan-out
     fan = args.overlap_streams if (args.overlap_streams >= 2 and eng.set_many_streams(args.overlap_streams)) else 0
     batches = []
     for f in feats:
@@ -211,7 +214,7 @@ def main():
         batches.append((torch.from_numpy(ids).cuda(), torch.from_numpy(dense).cuda()))
     NB = len(batches)
     outs = [torch.empty(B, dtype=torch.float32, device="cuda") for _ in range(NB)]
-    ws = torch.empty(max(eng.many_workspace_bytes(B, max(fan, 1)) // 4, 1), dtype=torch.float32, device="cuda")
+    ws = torch.empty(max(eng.many_workspace_bytes(B, max(fan, 1) * lb) // 4, 1), dtype=torch.float32, device="cuda")
     gs = None
     if dist_on:
         from sparrowrecsys_amd.dist import GroupedScoreGather

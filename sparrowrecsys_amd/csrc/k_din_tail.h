@@ -29,6 +29,17 @@ struct DinTailRun {
     float inv_w1_scale;                   // DYN: 1 / (static power-of-two scale of fc1's split weights)
 };
 
+// Multi-batch launch (sprk_set_many_batches): launch task t is task t % ntpb of batch t / ntpb, every batch with its own
+// buffers -- one LDS image load and one dispatch for up to DIN_MB batches, and waves that run more than one task.
+#define DIN_MB 16
+struct DinTailMany {
+    const int* ids[DIN_MB];
+    const float* dense[DIN_MB];
+    const float* aux[DIN_MB];
+    float* out[DIN_MB];
+    int n, ntpb;
+};
+
 // DYN: fc1 on the f16 matrix pipe with per-sample dynamic scaling (dyn_split.h); its W1 region then holds the packed
 // hi / lo A fragments ((N1/16) x (N0/32) blocks of 2 KB) instead of the f32 W^T rows.
 template <int N0C, int N1C, int KPC>
@@ -84,11 +95,11 @@ __global__ __launch_bounds__(256) void k_din_tail_pack(const float* __restrict__
     for (int i = LD::total + tid; i < LD::total_pad; i += 256) img[i] = 0.f;
 }
 
-template <int N0C, int N1C, int KPC, int WAVES, bool DYN>
-__global__ __launch_bounds__(WAVES * 64, 2) void k_din_tail(const DinTailRun A, const int* __restrict__ ids,
-                                                            const float* __restrict__ dense, const float* __restrict__ aux,
-                                                            float* __restrict__ out, int B, int* __restrict__ err,
-                                                            const float* __restrict__ image) {
+template <int N0C, int N1C, int KPC, int WAVES, bool DYN, bool MB = false>
+__global__ __launch_bounds__(WAVES * 64, 2) void k_din_tail(const DinTailRun A, const int* __restrict__ ids0,
+                                                            const float* __restrict__ dense0, const float* __restrict__ aux0,
+                                                            float* __restrict__ out0, int B, int* __restrict__ err,
+                                                            const float* __restrict__ image, const DinTailMany M) {
     using LD = DinTailLds<N0C, N1C, KPC>;
     constexpr int N0 = LD::N0;
     const int tid = threadIdx.x;
@@ -96,14 +107,28 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_din_tail(const DinTailRun A, 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 15, q = lane >> 4;
     const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int ntasks = (B + 15) >> 4;
+    const int ntasks = MB ? M.n * M.ntpb : (B + 15) >> 4;
     const int task_stride = gridDim.x * WAVES;
     bool bad = false;
+    // MB: (batch, task inside the batch) of launch task t (wave-uniform)
+    auto batch_of = [&](int t, int& tl) {
+        if constexpr (MB) {
+            const int b = __builtin_amdgcn_readfirstlane(t / M.ntpb);
+            tl = t - b * M.ntpb;
+            return b;
+        } else {
+            tl = t;
+            return 0;
+        }
+    };
 
     // weight image -> LDS (1-KB LDS-DMA pieces), while the first task's ids are on their way
     int tk = blockIdx.x * WAVES + wave;
     int idv[DT_MAX_COLS];
-    auto ld_ids = [&](int t) {
+    auto ld_ids = [&](int tg) {
+        int t;
+        const int bi = batch_of(tg, t);
+        const int* ids = MB ? M.ids[bi] : ids0;
         const int m = min(t * 16 + r, B - 1);                    // rows past the end re-read the last sample, never stored
         const int* row = ids + (size_t)m * A.F;
 #pragma unroll
@@ -118,7 +143,12 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_din_tail(const DinTailRun A, 
     __syncthreads();
 
     for (; tk < ntasks; tk += task_stride) {
-        const int m = min(tk * 16 + r, B - 1);
+        int tl;
+        const int bi = batch_of(tk, tl);
+        const float* dense = MB ? M.dense[bi] : dense0;
+        const float* aux = MB ? M.aux[bi] : aux0;
+        float* out = MB ? M.out[bi] : out0;
+        const int m = min(tl * 16 + r, B - 1);
         // ---- per-sample operands: pooled history (aux) and numerics, in B-operand layout ----
         f32x4 xp[KPC], xn;
 #pragma unroll
@@ -244,7 +274,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_din_tail(const DinTailRun A, 
             }
         }
         z = rows4_sum(z);
-        const int mm = tk * 16 + r;
+        const int mm = tl * 16 + r;
         if (q == 0 && mm < B) out[mm] = sigmoidf_acc(z + A.head_bias);
     }
     if (__ballot(bad) != 0 && lane == 0) atomicOr(err, 1);

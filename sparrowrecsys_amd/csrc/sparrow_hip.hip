@@ -1561,18 +1561,30 @@ int setup_mlp_chain(sprk_engine* h, DevPlan* dp) {
 // ---- dispatch table for k_din_tail<N0C, N1C, KPC, WAVES> ----
 constexpr int DT_WAVES = 8;
 typedef void (*DinTailLaunchFn)(const DinTailRun&, const int*, const float*, const float*, float*, int, int*, const float*, int, hipStream_t);
+typedef void (*DinTailLaunchManyFn)(const DinTailRun&, const DinTailMany&, int, int*, const float*, int, hipStream_t);
 typedef void (*DinTailPackFn)(const float*, int, int, int, int, int, const float*, const float*, const float*, int, const float*,
                               const float*, const float*, int, const float*, float*);
 template <int N0C, int N1C, int KPC>
 void din_tail_launch(const DinTailRun& a, const int* ids, const float* dense, const float* aux, float* out, int B, int* err,
                      const float* image, int grid, hipStream_t st) {
     const size_t lds = DinTailLds<N0C, N1C, KPC>::bytes;
+    static const DinTailMany none{};
     if (a.inv_w1_scale != 0.f)
-        hipLaunchKernelGGL((k_din_tail<N0C, N1C, KPC, DT_WAVES, true>), dim3(grid), dim3(DT_WAVES * 64), lds, st,
-                           a, ids, dense, aux, out, B, err, image);
+        hipLaunchKernelGGL((k_din_tail<N0C, N1C, KPC, DT_WAVES, true, false>), dim3(grid), dim3(DT_WAVES * 64), lds, st,
+                           a, ids, dense, aux, out, B, err, image, none);
     else
-        hipLaunchKernelGGL((k_din_tail<N0C, N1C, KPC, DT_WAVES, false>), dim3(grid), dim3(DT_WAVES * 64), lds, st,
-                           a, ids, dense, aux, out, B, err, image);
+        hipLaunchKernelGGL((k_din_tail<N0C, N1C, KPC, DT_WAVES, false, false>), dim3(grid), dim3(DT_WAVES * 64), lds, st,
+                           a, ids, dense, aux, out, B, err, image, none);
+}
+template <int N0C, int N1C, int KPC>
+void din_tail_launch_many(const DinTailRun& a, const DinTailMany& m, int B, int* err, const float* image, int grid, hipStream_t st) {
+    const size_t lds = DinTailLds<N0C, N1C, KPC>::bytes;
+    if (a.inv_w1_scale != 0.f)
+        hipLaunchKernelGGL((k_din_tail<N0C, N1C, KPC, DT_WAVES, true, true>), dim3(grid), dim3(DT_WAVES * 64), lds, st,
+                           a, (const int*)nullptr, (const float*)nullptr, (const float*)nullptr, (float*)nullptr, B, err, image, m);
+    else
+        hipLaunchKernelGGL((k_din_tail<N0C, N1C, KPC, DT_WAVES, false, true>), dim3(grid), dim3(DT_WAVES * 64), lds, st,
+                           a, (const int*)nullptr, (const float*)nullptr, (const float*)nullptr, (float*)nullptr, B, err, image, m);
 }
 template <int N0C, int N1C, int KPC>
 void din_tail_pack(const float* W0, int ldw0, int p_off, int Dp, int n_off, int n_num, const float* b0, const float* a0,
@@ -1583,15 +1595,18 @@ void din_tail_pack(const float* W0, int ldw0, int p_off, int Dp, int n_off, int 
 }
 struct DinTailVariant {
     int n0c, n1c, kpc;
-    const void* fn;
-    const void* fn_dyn;
+    const void* fn[4];                // [DYN][MB] instantiations
     size_t lds_bytes;
     DinTailLaunchFn launch;
+    DinTailLaunchManyFn launch_many;
     DinTailPackFn pack;
 };
-#define DIN_TAIL_VARIANT(N0C, N1C, KPC) {N0C, N1C, KPC, reinterpret_cast<const void*>(&k_din_tail<N0C, N1C, KPC, DT_WAVES, false>), \
-                                         reinterpret_cast<const void*>(&k_din_tail<N0C, N1C, KPC, DT_WAVES, true>),                \
-                                         DinTailLds<N0C, N1C, KPC>::bytes, &din_tail_launch<N0C, N1C, KPC>, &din_tail_pack<N0C, N1C, KPC>}
+#define DIN_TAIL_VARIANT(N0C, N1C, KPC) {N0C, N1C, KPC, {reinterpret_cast<const void*>(&k_din_tail<N0C, N1C, KPC, DT_WAVES, false, false>), \
+                                         reinterpret_cast<const void*>(&k_din_tail<N0C, N1C, KPC, DT_WAVES, false, true>),               \
+                                         reinterpret_cast<const void*>(&k_din_tail<N0C, N1C, KPC, DT_WAVES, true, false>),               \
+                                         reinterpret_cast<const void*>(&k_din_tail<N0C, N1C, KPC, DT_WAVES, true, true>)},               \
+                                         DinTailLds<N0C, N1C, KPC>::bytes, &din_tail_launch<N0C, N1C, KPC>, &din_tail_launch_many<N0C, N1C, KPC>, \
+                                         &din_tail_pack<N0C, N1C, KPC>}
 const DinTailVariant kDinTailVariants[] = {
     DIN_TAIL_VARIANT(8, 4, 2),        // DIN.py:161-167 widths 128 / 64, emb_dim 17..32 (BASELINE config 3)
     DIN_TAIL_VARIANT(8, 4, 1),        // ... emb_dim <= 16 (the reference's own emb_dim 10)
@@ -1647,8 +1662,7 @@ int setup_din_tail(sprk_engine* h, DevPlan* dp) {
     tv.pack(o0.W, o0.ldw, p_off, Dp, n_off, n_num, o0.bias, o0.alpha, o1.W, o1.ldw, o1.bias, o1.alpha, tp.w, tp.len, w1frag, h->din_tail_image);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipFuncSetAttribute(tv.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tv.lds_bytes));
-    HIP_TRY(hipFuncSetAttribute(tv.fn_dyn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tv.lds_bytes));
+    for (int i = 0; i < 4; ++i) HIP_TRY(hipFuncSetAttribute(tv.fn[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)tv.lds_bytes));
     h->din_tail_variant = variant;
     return SPRK_OK;
 }
@@ -2138,6 +2152,56 @@ int sprk_forward_many(sprk_handle h, int32_t n_batches, const int32_t* const* id
             return SPRK_OK;
         }
     }
+    // DIN (k_din_attn -> pooled vectors -> k_din_tail): the attention launches of a group of batches, then ONE tail launch for
+    // the group; a workspace slice per batch of the group.  Groups alternate over the helper streams when there are slices for that.
+    if (h->finalized && h->many_batches > 1 && n_batches > 1 && h->plan.din.enabled == 1 && h->din_variant >= 0 &&
+        h->din_tail_variant >= 0 && B > 0 && ids && dense && workspace && ws_need > 0) {
+        int per = h->many_batches < DIN_MB ? h->many_batches : DIN_MB;
+        if ((size_t)per * ws_need > workspace_bytes) per = (int)(workspace_bytes / ws_need);
+        bool ok = per >= 2;
+        for (int32_t i = 0; i < n_batches && ok; ++i) ok = ids[i] && dense[i] && out[i];
+        if (ok) {
+            int SG = S >= 2 ? S : 1;                                   // streams the groups alternate over
+            while (SG > 1 && (size_t)SG * per * ws_need > workspace_bytes) --SG;
+            if (SG >= 2) {
+                HIP_TRY(hipEventRecord(h->many_fork, (hipStream_t)stream));
+                for (int s = 0; s < SG; ++s) HIP_TRY(hipStreamWaitEvent(h->many_stream[s], h->many_fork, 0));
+            }
+            const DinVariant& av = kDinVariants[h->din_variant];
+            const DinTailVariant& tv = kDinTailVariants[h->din_tail_variant];
+            const int ntpb = (B + 15) / 16;
+            int g = 0;
+            for (int32_t i0 = 0; i0 < n_batches; i0 += per, ++g) {
+                const int n = n_batches - i0 < per ? n_batches - i0 : per;
+                hipStream_t st = SG >= 2 ? h->many_stream[g % SG] : (hipStream_t)stream;
+                char* wbase = (char*)workspace + (size_t)(g % SG) * per * ws_need;
+                DinTailMany tm;
+                memset(&tm, 0, sizeof(tm));
+                tm.n = n; tm.ntpb = ntpb;
+                for (int j = 0; j < n; ++j) {
+                    float* pooled = (float*)(wbase + (size_t)j * ws_need);
+                    tm.ids[j] = ids[i0 + j]; tm.dense[j] = dense[i0 + j]; tm.aux[j] = pooled; tm.out[j] = out[i0 + j];
+                }
+                // the attention kernel stays one launch per batch (50 us each: its launch floor is small change); the tail,
+                // a 16-us kernel whose waves otherwise run ONE task, is where a launch per group pays
+                int ag = (B + 3) / 4;
+                if (ag > h->din_attn_grid_cap) ag = h->din_attn_grid_cap;
+                for (int j = 0; j < n; ++j)
+                    av.launch(h->din_run, tm.ids[j], const_cast<float*>(tm.aux[j]), nullptr, B, h->dev_err, ag, h->din_attn_lds, st);
+                long long tg = ((long long)n * ntpb + DT_WAVES - 1) / DT_WAVES;
+                if (tg > h->num_cus) tg = h->num_cus;
+                tv.launch_many(h->din_tail_run, tm, B, h->dev_err, h->din_tail_image, (int)tg, st);
+                HIP_TRY(hipGetLastError());
+            }
+            if (SG >= 2) {
+                for (int s = 0; s < SG; ++s) {
+                    HIP_TRY(hipEventRecord(h->many_join[s], h->many_stream[s]));
+                    HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, h->many_join[s], 0));
+                }
+            }
+            return SPRK_OK;
+        }
+    }
     if (S >= 2) {
         HIP_TRY(hipEventRecord(h->many_fork, (hipStream_t)stream));
         for (int s = 0; s < S; ++s) HIP_TRY(hipStreamWaitEvent(h->many_stream[s], h->many_fork, 0));
@@ -2183,7 +2247,7 @@ int sprk_set_many_streams(sprk_handle h, int32_t n) {
 int sprk_set_many_batches(sprk_handle h, int32_t n) {
     if (!h) return fail(SPRK_EINVAL, "handle is NULL");
     if (!h->finalized) return fail(SPRK_ESTATE, "set_many_batches before finalize");
-    if (n < 1 || n > V2J_MB) return fail(SPRK_EINVAL, "batches per launch %d outside [1,%d]", n, V2J_MB);
+    if (n < 1 || n > V2J_MB) return fail(SPRK_EINVAL, "batches per launch %d outside [1,%d]", n, V2J_MB);   // (DIN caps at DIN_MB)
     h->many_batches = n;
     return SPRK_OK;
 }

@@ -673,6 +673,42 @@ def test_forward_many_several_batches_per_launch(torch, B, n, k):
         eng.set_many_batches(65)
 
 
+@pytest.mark.parametrize("Bd,n,k,streams", [(2049, 5, 4, 0), (4096, 9, 16, 0), (1000, 7, 3, 2), (16, 4, 2, 2)])
+def test_forward_many_several_batches_per_launch_din(torch, Bd, n, k, streams):
+    """DIN with sprk_set_many_batches(k): the group's k_din_attn launches, then ONE k_din_tail launch for the k batches (a workspace
+    slice per batch of the group; groups alternate over the helper streams when slices allow): bit-identical scores."""
+    T = 50
+    din = M.DIN(seed=59, emb_dim=32, hist_len=T, movie_buckets=5000, user_buckets=7000)
+    eng = din.engine
+    fd = [SY.synth_din(Bd, T, 5000, 7000, seed=190 + i) for i in range(n)]
+    packed = [din.pack(f) for f in fd]
+    ids = [_cuda(torch, p[0]) for p in packed]
+    dense = [_cuda(torch, p[1]) for p in packed]
+    res = {}
+    for kk in (1, k):
+        eng.set_many_batches(kk)
+        eng.set_many_streams(streams)
+        ws = torch.empty(eng.many_workspace_bytes(Bd, max(streams, 1) * kk) // 4, dtype=torch.float32, device="cuda")
+        outs = [torch.full((Bd,), -1.0, dtype=torch.float32, device="cuda") for _ in range(n)]
+        eng.forward_many(ids, dense, outs, ws)
+        torch.cuda.synchronize()
+        eng.check_ids()
+        res[kk] = [o.cpu().numpy() for o in outs]
+    for a, b in zip(res[1], res[k]):
+        np.testing.assert_array_equal(a, b)
+    ref = O.din_forward(fd[-1], din.weights, dtype=np.float64, hist_len=T, movie_buckets=5000, user_buckets=7000)[:, 0]
+    assert np.abs(res[k][-1] - ref).max() <= TOL
+    # a workspace with room for one slice only: served batch by batch, same scores
+    eng.set_many_batches(k)
+    eng.set_many_streams(0)
+    ws1 = torch.empty(eng.many_workspace_bytes(Bd, 1) // 4, dtype=torch.float32, device="cuda")
+    outs = [torch.full((Bd,), -1.0, dtype=torch.float32, device="cuda") for _ in range(n)]
+    eng.forward_many(ids, dense, outs, ws1)
+    torch.cuda.synchronize()
+    for a, o in zip(res[1], outs):
+        np.testing.assert_array_equal(a, o.cpu().numpy())
+
+
 # --------------------------------------------------------------------------------------------
 # k_mlp_chain: EmbeddingMLP / Wide&Deep graphs as a register-chained kernel
 # --------------------------------------------------------------------------------------------
