@@ -31,9 +31,9 @@ HBM_PEAK = 8.0e12          # B/s, MI355X spec (MI355X_MICROARCH.md)
 MFMA_F32_PEAK = 157.3e12   # FLOP/s, fp32-input MFMA
 
 
-def build_workload(name, B, dist_name, seed_offset=0, big_vocab=0):
+def build_workload(name, B, dist_name, seed_offset=0, big_vocab=0, NB=8):
+    """NB: distinct input batches (own ids / dense / score buffers each) the steps cycle through."""
     from sparrowrecsys_amd import models as M, synthetic as SY
-    NB = 8   # distinct input batches cycled through, so steps do not re-read identical ids
     if name in ("deepfm_v2_c2", "deepfm_c2"):
         F, D = 6, 16
         fields = SY.CONFIG2_FIELDS
@@ -160,6 +160,9 @@ def main():
                          "spent once per N batches.  With N > 1 the launches of the timed region run in strict order (no stream "
                          "fan-out).  The `roofline` block stays ONE batch per launch; `roofline_timed_region` describes the "
                          "N-batch launches.")
+    ap.add_argument("--input-batches", type=int, default=0,
+                    help="distinct synthetic input batches the steps cycle through (default: 32 for the headline workload -- no "
+                         "two batches of one 16-batch launch share buffers -- 16 for din_c3, 8 otherwise)")
     ap.add_argument("--big-vocab", type=int, default=0,
                     help="deepfm_v2_c2 only: rows of each identity table (e.g. 8388608 = 1 GiB of folded rows per table, "
                          "far beyond the Infinity Cache); default 0 = the MovieLens-20M-shaped vocabularies of the config")
@@ -196,7 +199,10 @@ def main():
             dist.init_process_group("gloo")
 
     B = args.batch or {"din_c3": 32768, "widedeep_c5": 131072}.get(args.workload, 65536)
-    model, feats, desc, roof = build_workload(args.workload, B, args.dist, seed_offset=rank, big_vocab=args.big_vocab)
+    nb_in = args.input_batches or {"deepfm_v2_c2": 32, "din_c3": 16}.get(args.workload, 8)
+    if args.batch and args.batch > 262144:
+        nb_in = min(nb_in, 8)
+    model, feats, desc, roof = build_workload(args.workload, B, args.dist, seed_offset=rank, big_vocab=args.big_vocab, NB=nb_in)
     eng = model.engine
     lb = 1
     if args.launch_batches > 1 and os.environ.get("SPRK_FORCE_INTERPRETER") != "1":
