@@ -199,7 +199,7 @@ def main():
             dist.init_process_group("gloo")
 
     B = args.batch or {"din_c3": 32768, "widedeep_c5": 131072}.get(args.workload, 65536)
-    nb_in = args.input_batches or {"deepfm_v2_c2": 32, "din_c3": 16}.get(args.workload, 8)
+    nb_in = args.input_batches or {"deepfm_v2_c2": 32, "deepfm_c2": 16, "din_c3": 16}.get(args.workload, 8)
     if args.batch and args.batch > 262144:
         nb_in = min(nb_in, 8)
     model, feats, desc, roof = build_workload(args.workload, B, args.dist, seed_offset=rank, big_vocab=args.big_vocab, NB=nb_in)
@@ -209,6 +209,9 @@ def main():
         if args.workload == "deepfm_v2_c2" and os.environ.get("SPRK_V2_JOINT") != "0" and os.environ.get("SPRK_V2_FOLD") != "0":
             lb = args.launch_batches
             args.overlap_streams = 0       # several batches per launch: strict order measured faster than the fan-out
+        elif args.workload == "deepfm_c2" and os.environ.get("SPRK_V1_CHAIN") != "0":
+            lb = min(args.launch_batches, 16)
+            args.overlap_streams = 0
         elif args.workload == "din_c3" and os.environ.get("SPRK_DIN_LEGACY") != "1" and os.environ.get("SPRK_DIN_TAIL") != "0":
             lb = min(args.launch_batches, 16)   # groups of batches: one attention + one tail launch each, alternating streams
     if lb > 1:

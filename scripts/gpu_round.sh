@@ -23,6 +23,7 @@ b bench_c2_zipf_lb16 python bench.py --cpu-seconds 0 --dist zipf
 b bench_c2_b1m python bench.py --cpu-seconds 0 --batch 1048576 --steps 400 --warmup 40 --launch-batches 1
 b bench_c2_strict python bench.py --cpu-seconds 0 --overlap-streams 0 --launch-batches 1
 b bench_c2_pairs python bench.py --workload deepfm_c2 --cpu-seconds 0
+b bench_c2_pairs_lb1 python bench.py --workload deepfm_c2 --cpu-seconds 0 --launch-batches 1
 b bench_c2_pairs_interp SPRK_V1_CHAIN=0 python bench.py --workload deepfm_c2 --cpu-seconds 0
 b bench_c3 python bench.py --steps 320 --warmup 32 --workload din_c3 --cpu-seconds 6
 b bench_c3_lb1 python bench.py --steps 320 --warmup 32 --workload din_c3 --cpu-seconds 0 --launch-batches 1

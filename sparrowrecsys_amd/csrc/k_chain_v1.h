@@ -58,6 +58,15 @@ __global__ __launch_bounds__(256) void k_v1_pack_w0(const float* __restrict__ W0
     }
 }
 
+// Multi-batch launch (sprk_set_many_batches): launch task t is task t % ntpb of batch t / ntpb, every batch with its own buffers.
+#define V1_MB 16
+struct V1Many {
+    const int* ids[V1_MB];
+    const float* dense[V1_MB];
+    float* out[V1_MB];
+    int n, ntpb;
+};
+
 template <int H0C, int H1C>
 struct V1Lds {
     static constexpr int H0 = H0C * 16, H1 = H1C * 16;
@@ -77,10 +86,10 @@ struct V1Lds {
 // its ids were fetched one task earlier still.  Everything the scoring stage reads besides its operands comes from
 // LDS (deep1's weights, biases): a global load there would sit behind the prefetched gather in the in-order vmcnt
 // queue and drain it.
-template <int NF, int NV, int H0C, int H1C, int WAVES, bool DYN>
-__global__ __launch_bounds__(WAVES * 64, 2) void k_deepfm_pairs(const V1Run A, const int* __restrict__ ids,
-                                                                const float* __restrict__ dense, float* __restrict__ out,
-                                                                int B, int* __restrict__ err) {
+template <int NF, int NV, int H0C, int H1C, int WAVES, bool DYN, bool MB = false>
+__global__ __launch_bounds__(WAVES * 64, 2) void k_deepfm_pairs(const V1Run A, const int* __restrict__ ids0,
+                                                                const float* __restrict__ dense0, float* __restrict__ out0,
+                                                                int B, int* __restrict__ err, const V1Many M) {
     using LD = V1Lds<H0C, H1C>;
     constexpr int H0 = H0C * 16;
     static_assert(NF >= 2 && NF <= V1_MAX_FIELDS && NV >= 1 && NV <= 4, "shape");
@@ -89,9 +98,20 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_deepfm_pairs(const V1Run A, c
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 15, q = lane >> 4;
     const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int ntasks = (B + 15) >> 4;
+    const int ntasks = MB ? M.n * M.ntpb : (B + 15) >> 4;
     const int task_stride = gridDim.x * WAVES;
     bool bad = false;
+    // MB: (batch, task inside the batch) of launch task t (wave-uniform)
+    auto batch_of = [&](int t, int& tl) {
+        if constexpr (MB) {
+            const int b = __builtin_amdgcn_readfirstlane(t / M.ntpb);
+            tl = t - b * M.ntpb;
+            return b;
+        } else {
+            tl = t;
+            return 0;
+        }
+    };
 
     // ---- one-time: both layers' W^T, biases, head weights -> LDS ----
     if constexpr (DYN) {
@@ -116,13 +136,19 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_deepfm_pairs(const V1Run A, c
     int idv[NF];
     f32x4 gx[NF], gxn = zero;
     float gw1a = 0.f, gw1b = 0.f;
-    auto ld_ids = [&](int t) {
+    auto ld_ids = [&](int tg) {
+        int t;
+        const int bi = batch_of(tg, t);
+        const int* ids = MB ? M.ids[bi] : ids0;
         const int m = min(t * 16 + r, B - 1);                    // rows past the end re-read the last sample, never stored
         const int* row = ids + (size_t)m * A.F;
 #pragma unroll
         for (int f = 0; f < NF; ++f) idv[f] = row[A.col[f]];
     };
-    auto issue_gather = [&](int t) {
+    auto issue_gather = [&](int tg) {
+        int t;
+        const int bi = batch_of(tg, t);
+        const float* dense = MB ? M.dense[bi] : dense0;
         const int m = min(t * 16 + r, B - 1);
         {
             const float* nrow = dense + (size_t)m * A.ND;
@@ -261,7 +287,10 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_deepfm_pairs(const V1Run A, c
 #pragma unroll
         for (int n1 = 0; n1 < H1C; ++n1) z += dot4(ld4(smem + LD::off_hd + n1 * 16 + 4 * q), relu4_fast(h1[n1]));
         z = rows4_sum(z);
-        const int mm = tk * 16 + r;
+        int tl;
+        const int bo = batch_of(tk, tl);
+        float* out = MB ? M.out[bo] : out0;
+        const int mm = tl * 16 + r;
         if (q == 0 && mm < B) out[mm] = sigmoidf_acc(z + A.head_bias);
     }
     if (__ballot(bad) != 0 && lane == 0) atomicOr(err, 1);

@@ -1302,19 +1302,31 @@ int make_dyn_fragments(sprk_engine* h, const float* W, int ld, int N, int K, flo
 // ---- dispatch table for k_deepfm_pairs<NF, NV, H0C, H1C, WAVES> ----
 constexpr int V1_WAVES = 8;
 typedef void (*V1LaunchFn)(const V1Run&, const int*, const float*, float*, int, int*, int, hipStream_t);
+typedef void (*V1LaunchManyFn)(const V1Run&, const V1Many&, int, int*, int, hipStream_t);
 template <int NF, int NV>
 void v1_launch(const V1Run& a, const int* ids, const float* dense, float* out, int B, int* err, int grid, hipStream_t st) {
     const size_t lds = V1Lds<4, 4>::bytes;
+    static const V1Many none{};
     if (a.inv_w1_scale != 0.f)
-        hipLaunchKernelGGL((k_deepfm_pairs<NF, NV, 4, 4, V1_WAVES, true>), dim3(grid), dim3(V1_WAVES * 64), lds, st, a, ids, dense, out, B, err);
+        hipLaunchKernelGGL((k_deepfm_pairs<NF, NV, 4, 4, V1_WAVES, true, false>), dim3(grid), dim3(V1_WAVES * 64), lds, st, a, ids, dense, out, B, err, none);
     else
-        hipLaunchKernelGGL((k_deepfm_pairs<NF, NV, 4, 4, V1_WAVES, false>), dim3(grid), dim3(V1_WAVES * 64), lds, st, a, ids, dense, out, B, err);
+        hipLaunchKernelGGL((k_deepfm_pairs<NF, NV, 4, 4, V1_WAVES, false, false>), dim3(grid), dim3(V1_WAVES * 64), lds, st, a, ids, dense, out, B, err, none);
 }
-struct V1Variant { int nf, nv; V1LaunchFn launch; };
+template <int NF, int NV>
+void v1_launch_many(const V1Run& a, const V1Many& m, int B, int* err, int grid, hipStream_t st) {
+    const size_t lds = V1Lds<4, 4>::bytes;
+    if (a.inv_w1_scale != 0.f)
+        hipLaunchKernelGGL((k_deepfm_pairs<NF, NV, 4, 4, V1_WAVES, true, true>), dim3(grid), dim3(V1_WAVES * 64), lds, st, a,
+                           (const int*)nullptr, (const float*)nullptr, (float*)nullptr, B, err, m);
+    else
+        hipLaunchKernelGGL((k_deepfm_pairs<NF, NV, 4, 4, V1_WAVES, false, true>), dim3(grid), dim3(V1_WAVES * 64), lds, st, a,
+                           (const int*)nullptr, (const float*)nullptr, (float*)nullptr, B, err, m);
+}
+struct V1Variant { int nf, nv; V1LaunchFn launch; V1LaunchManyFn launch_many; };
 const V1Variant kV1Variants[] = {
-    {6, 4, &v1_launch<6, 4>},         // BASELINE config 2: 6 fields, emb_dim 16, deep 64-64
-    {4, 3, &v1_launch<4, 3>},         // the reference's own DeepFM.py: 4 fields, emb_dim 10 (rows padded to 12)
-    {4, 4, &v1_launch<4, 4>},
+    {6, 4, &v1_launch<6, 4>, &v1_launch_many<6, 4>},   // BASELINE config 2: 6 fields, emb_dim 16, deep 64-64
+    {4, 3, &v1_launch<4, 3>, &v1_launch_many<4, 3>},   // the reference's own DeepFM.py: 4 fields, emb_dim 10 (rows padded to 12)
+    {4, 4, &v1_launch<4, 4>, &v1_launch_many<4, 4>},
 };
 
 // Recognise the plan models.DeepFM emits (DeepFM.py graph: pair dots + first order + 2-layer deep part) and set up
@@ -2147,6 +2159,27 @@ int sprk_forward_many(sprk_handle h, int32_t n_batches, const int32_t* const* id
                 long long grid = (ntasks + V2_WAVES - 1) / V2_WAVES;
                 if (grid > h->v2_grid_cap) grid = h->v2_grid_cap;
                 jv.launch_many(jr, m, B, h->dev_err, h->v2_image, (int)grid, h->v2j_lds_bytes, (hipStream_t)stream);
+                HIP_TRY(hipGetLastError());
+            }
+            return SPRK_OK;
+        }
+    }
+    // the pairwise-dot DeepFM kernel: up to V1_MB batches per launch
+    if (h->finalized && h->many_batches > 1 && n_batches > 1 && h->v2_variant < 0 && h->v1_variant >= 0 && B > 0 && ids && dense) {
+        bool ok = true;
+        for (int32_t i = 0; i < n_batches && ok; ++i) ok = ids[i] && dense[i] && out[i];
+        if (ok) {
+            const int per = h->many_batches < V1_MB ? h->many_batches : V1_MB;
+            const int ntpb = (B + 15) / 16;
+            for (int32_t i0 = 0; i0 < n_batches; i0 += per) {
+                V1Many m;
+                memset(&m, 0, sizeof(m));
+                m.n = n_batches - i0 < per ? n_batches - i0 : per;
+                m.ntpb = ntpb;
+                for (int j = 0; j < m.n; ++j) { m.ids[j] = ids[i0 + j]; m.dense[j] = dense[i0 + j]; m.out[j] = out[i0 + j]; }
+                long long grid = ((long long)m.n * ntpb + V1_WAVES - 1) / V1_WAVES;
+                if (grid > h->num_cus) grid = h->num_cus;
+                kV1Variants[h->v1_variant].launch_many(h->v1_run, m, B, h->dev_err, (int)grid, (hipStream_t)stream);
                 HIP_TRY(hipGetLastError());
             }
             return SPRK_OK;

@@ -673,6 +673,35 @@ def test_forward_many_several_batches_per_launch(torch, B, n, k):
         eng.set_many_batches(65)
 
 
+@pytest.mark.parametrize("shape,B,n,k", [("config2", 4099, 7, 4), ("reference", 1000, 19, 16), ("config2", 16, 3, 2)])
+def test_forward_many_several_batches_per_launch_pairs(torch, shape, B, n, k):
+    """k_deepfm_pairs under sprk_set_many_batches(k): bit-identical to a launch per batch."""
+    if shape == "reference":
+        fields, pairs, D = None, None, 10
+        feats = [SY.synth_fields(B, M._default_fields(), seed=270 + i) for i in range(n)]
+    else:
+        fields, pairs, D = SY.CONFIG2_FIELDS, SY.CONFIG2_PAIRS, 16
+        feats = [SY.synth_fields(B, fields, seed=270 + i, dist="zipf" if i % 2 else "uniform") for i in range(n)]
+    model = M.DeepFM(seed=47, emb_dim=D, fields=fields, pairs=pairs)
+    eng = model.engine
+    packed = [model.pack(f) for f in feats]
+    ids = [_cuda(torch, p[0]) for p in packed]
+    dense = [_cuda(torch, p[1]) for p in packed]
+    res = {}
+    for kk in (1, k):
+        eng.set_many_batches(kk)
+        outs = [torch.full((B,), -1.0, dtype=torch.float32, device="cuda") for _ in range(n)]
+        eng.forward_many(ids, dense, outs)
+        torch.cuda.synchronize()
+        eng.check_ids()
+        res[kk] = [o.cpu().numpy() for o in outs]
+    for a, b in zip(res[1], res[k]):
+        np.testing.assert_array_equal(a, b)
+    kw = {} if fields is None else {"fields": fields, "pairs": pairs}
+    ref = O.deepfm_forward(feats[-1], model.weights, dtype=np.float64, **kw)[:, 0]
+    assert np.abs(res[k][-1] - ref).max() <= TIGHT
+
+
 @pytest.mark.parametrize("Bd,n,k,streams", [(2049, 5, 4, 0), (4096, 9, 16, 0), (1000, 7, 3, 2), (16, 4, 2, 2)])
 def test_forward_many_several_batches_per_launch_din(torch, Bd, n, k, streams):
     """DIN with sprk_set_many_batches(k): the group's k_din_attn launches, then ONE k_din_tail launch for the k batches (a workspace
