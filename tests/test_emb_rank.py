@@ -149,3 +149,26 @@ def test_emb_rank_reference_embeddings_fixture():
     scores, order = r.score_many(z["user_emb"], cand)
     assert np.array_equal(scores.cpu().numpy().view(np.uint64), z["scores"].view(np.uint64))
     assert np.array_equal(order.cpu().numpy(), z["order"])
+
+
+# ---------------------------------------------------------------- CPU: two independent restatements agree bit for bit
+def test_c_restatement_equals_numpy_oracle():
+    """oracle/emb_rank_c.c (plain C, float products / double sums written as the Java loop) against the numpy oracle:
+    identical doubles, NaN and -1 cases included."""
+    import ctypes as C
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    so = os.path.join(root, "oracle", "_build", "libemb_rank_c.so")
+    if not os.path.exists(so):
+        subprocess.run(["make", "-C", os.path.join(root, "oracle")], check=True, capture_output=True)
+    lib = C.CDLL(so)
+    for (Q, Cn, N, D, seed) in [(7, 300, 500, 10, 1), (3, 64, 40, 32, 2), (2, 5, 3, 1, 3)]:
+        items, has, q, qh, cand = _case(Q, Cn, N, D, seed)
+        out = np.empty((Q, Cn), dtype=np.float64)
+        lib.emb_rank_scores(items.ctypes.data_as(C.c_void_p), has.ctypes.data_as(C.c_void_p), C.c_int32(N), C.c_int32(D),
+                            q.ctypes.data_as(C.c_void_p), qh.ctypes.data_as(C.c_void_p), C.c_int32(Q),
+                            np.ascontiguousarray(cand).ctypes.data_as(C.c_void_p), C.c_int32(Cn), out.ctypes.data_as(C.c_void_p))
+        want = EO.scores(items, has, q, qh, cand)
+        nan = np.isnan(want)
+        assert np.array_equal(np.isnan(out), nan)
+        assert np.array_equal(out[~nan].view(np.uint64), want[~nan].view(np.uint64))
