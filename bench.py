@@ -110,9 +110,58 @@ def oracle_forward(name, model, feats):
                          movie_buckets=model.movie_buckets, user_buckets=model.user_buckets)
 
 
+def cpu_baseline_c(name, model, feats, budget_s):
+    """deepfm_v2_c2 only: the plain-C restatement of the forward (oracle/ctr_c.c, OpenMP over samples, built with
+    -march=native on THIS host) on the packed ids / dense of the same synthetic batch -- a fairer stand-in for the
+    reference's TF2 CPU forward than the numpy oracle, whose time goes into Python feature handling.  Checked against
+    the numpy oracle before it is timed.  Returns None when it cannot be used (other workloads, no compiler)."""
+    if name != "deepfm_v2_c2":
+        return None
+    try:
+        from oracle import ctr_c
+        from sparrowrecsys_amd import synthetic as SY
+        fields = getattr(model, "_bench_fields", SY.CONFIG2_FIELDS)
+        ctr_c.load(native=True)
+        cm = ctr_c.DeepFMv2C(model.weights, fields)
+        ids, dense = model.pack(feats[0])
+        n = ids.shape[0]
+        threads = max(1, min(os.cpu_count() or 1, 128))
+        got = cm.forward(ids[:2048], dense[:2048], threads=1)
+        ref = oracle_forward(name, model, {k: v[:2048] for k, v in feats[0].items()})[:, 0]
+        if not (np.abs(got - ref).max() <= 5e-5):
+            return None
+        out = np.empty(n, dtype=np.float32)
+        cm.forward(ids, dense, threads=threads, out=out)     # warm-up (threads, page faults)
+        t0 = time.perf_counter()
+        done = 0
+        while True:
+            cm.forward(ids, dense, threads=threads, out=out)
+            done += n
+            el = time.perf_counter() - t0
+            if el >= budget_s or done >= 4096 * n:
+                break
+        return {"value": done / el, "unit": "samples/s", "cores": threads, "kind": "port",
+                "sample": "plain-C restatement of the DeepFM_v2 forward (oracle/ctr_c.c, OpenMP, -march=native; TensorFlow unavailable), "
+                          "%d passes over one packed batch of %d rows, %.1f s" % (done // n, n, el),
+                "host_cpus": os.cpu_count()}
+    except Exception:
+        return None
+
+
 def cpu_baseline(name, model, feats, budget_s):
-    """The numpy oracle ("port": TensorFlow is not installable) timed on this host's cores over a
-    bounded sample of the same workload."""
+    """The CPU restatement ("port": TensorFlow is not installable) timed on this host's cores over a bounded sample of
+    the same workload: the C restatement where there is one (DeepFM_v2), with the numpy oracle's rate reported next to
+    it; the numpy oracle otherwise."""
+    c = cpu_baseline_c(name, model, feats, 0.5 * budget_s)
+    if c is not None:
+        npy = cpu_baseline_numpy(name, model, feats, 0.5 * budget_s)
+        c["numpy_oracle_samples_per_sec"] = npy["value"]
+        c["numpy_oracle_threads"] = npy["cores"]
+        return c
+    return cpu_baseline_numpy(name, model, feats, budget_s)
+
+
+def cpu_baseline_numpy(name, model, feats, budget_s):
     try:
         from threadpoolctl import threadpool_info
         cores = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
