@@ -111,18 +111,22 @@ def oracle_forward(name, model, feats):
 
 
 def cpu_baseline_c(name, model, feats, budget_s):
-    """deepfm_v2_c2 only: the plain-C restatement of the forward (oracle/ctr_c.c, OpenMP over samples, built with
+    """deepfm_v2_c2 / din_c3: the plain-C restatement of the forward (oracle/ctr_c.c, OpenMP over samples, built with
     -march=native on THIS host) on the packed ids / dense of the same synthetic batch -- a fairer stand-in for the
     reference's TF2 CPU forward than the numpy oracle, whose time goes into Python feature handling.  Checked against
     the numpy oracle before it is timed.  Returns None when it cannot be used (other workloads, no compiler)."""
-    if name != "deepfm_v2_c2":
+    if name not in ("deepfm_v2_c2", "din_c3"):
         return None
     try:
         from oracle import ctr_c
         from sparrowrecsys_amd import synthetic as SY
-        fields = getattr(model, "_bench_fields", SY.CONFIG2_FIELDS)
         ctr_c.load(native=True)
-        cm = ctr_c.DeepFMv2C(model.weights, fields)
+        if name == "deepfm_v2_c2":
+            cm = ctr_c.DeepFMv2C(model.weights, getattr(model, "_bench_fields", SY.CONFIG2_FIELDS))
+            what = "DeepFM_v2"
+        else:
+            cm = ctr_c.DinC(model)
+            what = "DIN"
         ids, dense = model.pack(feats[0])
         n = ids.shape[0]
         threads = max(1, min(os.cpu_count() or 1, 128))
@@ -141,8 +145,8 @@ def cpu_baseline_c(name, model, feats, budget_s):
             if el >= budget_s or done >= 4096 * n:
                 break
         return {"value": done / el, "unit": "samples/s", "cores": threads, "kind": "port",
-                "sample": "plain-C restatement of the DeepFM_v2 forward (oracle/ctr_c.c, OpenMP, -march=native; TensorFlow unavailable), "
-                          "%d passes over one packed batch of %d rows, %.1f s" % (done // n, n, el),
+                "sample": "plain-C restatement of the %s forward (oracle/ctr_c.c, OpenMP, -march=native; TensorFlow unavailable), "
+                          "%d passes over one packed batch of %d rows, %.1f s" % (what, done // n, n, el),
                 "host_cpus": os.cpu_count()}
     except Exception:
         return None

@@ -86,3 +86,84 @@ void deepfm_v2_forward_c(int32_t B, int32_t F, int32_t D, int32_t K, int32_t NN,
         out[m] = z >= 0.f ? 1.0f / (1.0f + expf(-z)) : expf(z) / (1.0f + expf(z));
     }
 }
+
+/* ---------------------------------------------------------------------------------------------------------------------
+ * DIN forward (reference DIN.py:95-167), same role as above: cross-check of the numpy oracle's din_forward and the
+ * cpu_baseline leg of `bench.py --workload din_c3`.
+ *   h_t = E[hist_t], c = E[cand] (one shared Embedding; id 0 is an ordinary row: the mask has no numeric effect)
+ *   a_t = sigmoid(Dense(1)(PReLU_t(Dense(H)([h_t - c, h_t, c, h_t * c]))))            DIN.py:139-151
+ *   pooled = sum_t a_t h_t                                                             DIN.py:152-158
+ *   x = concat(segments) -> Dense(N0) PReLU -> Dense(N1) PReLU -> Dense(1, sigmoid)    DIN.py:161-167
+ * The concat is described by `seg`: n_seg x {dst, len, kind, a, b}: kind 0 = numeric column a of `dense`;
+ * kind 1 = row ids[b] of extra table a (zero row when the id is < 0); kind 2 = pooled; kind 3 = candidate row. */
+#define DIN_MAXD 64
+#define DIN_MAXH 64
+#define DIN_MAXX 512
+
+void din_forward_c(int32_t B, int32_t F, int32_t ND, int32_t T, int32_t D, int32_t H, int32_t hist_col, int32_t cand_col,
+                   const int32_t* ids, const float* dense, const float* table /*[V][D]*/,
+                   const float* Wa /*[4D][H]*/, const float* ba /*[H]*/, const float* alpha /*[T][H]*/, const float* w2 /*[H]*/,
+                   float b2, int32_t n_seg, const int32_t* seg, const float* const* extra /* tables [V_i][D] */,
+                   int32_t X, int32_t N0, int32_t N1, const float* W0, const float* b0, const float* a0, const float* W1,
+                   const float* b1, const float* a1, const float* hw, float hb, float* out, int32_t threads) {
+    if (D > DIN_MAXD || H > DIN_MAXH || X > DIN_MAXX || N0 > DIN_MAXX || N1 > DIN_MAXX) return;
+#pragma omp parallel for num_threads(threads) schedule(static)
+    for (int32_t m = 0; m < B; ++m) {
+        const int32_t* idr = ids + (size_t)m * F;
+        const float* c = table + (size_t)idr[cand_col] * D;
+        float pooled[DIN_MAXD], cw[DIN_MAXH], u[DIN_MAXH], x[DIN_MAXX], y0[DIN_MAXX], y1[DIN_MAXX];
+        for (int d = 0; d < D; ++d) pooled[d] = 0.f;
+        /* the c-only part of the activation unit's first layer is the same for every slot */
+        for (int n = 0; n < H; ++n) cw[n] = ba[n];
+        for (int d = 0; d < D; ++d) {
+            const float x1 = -c[d], x3 = c[d];
+            const float* r0 = Wa + (size_t)d * H;
+            const float* r2 = Wa + (size_t)(2 * D + d) * H;
+            for (int n = 0; n < H; ++n) cw[n] += x1 * r0[n] + x3 * r2[n];
+        }
+        for (int t = 0; t < T; ++t) {
+            const float* h = table + (size_t)idr[hist_col + t] * D;
+            for (int n = 0; n < H; ++n) u[n] = cw[n];
+            for (int d = 0; d < D; ++d) {
+                const float hd = h[d], hc = h[d] * c[d];
+                const float* r0 = Wa + (size_t)d * H;
+                const float* r1 = Wa + (size_t)(D + d) * H;
+                const float* r3 = Wa + (size_t)(3 * D + d) * H;
+                for (int n = 0; n < H; ++n) u[n] += hd * (r0[n] + r1[n]) + hc * r3[n];
+            }
+            float s = b2;
+            const float* al = alpha + (size_t)t * H;
+            for (int n = 0; n < H; ++n) s += w2[n] * (u[n] > 0.f ? u[n] : al[n] * u[n]);
+            const float a = s >= 0.f ? 1.0f / (1.0f + expf(-s)) : expf(s) / (1.0f + expf(s));
+            for (int d = 0; d < D; ++d) pooled[d] += a * h[d];
+        }
+        for (int i = 0; i < n_seg; ++i) {
+            const int32_t* sg = seg + 5 * i;
+            float* dst = x + sg[0];
+            if (sg[2] == 0) dst[0] = dense[(size_t)m * ND + sg[3]];
+            else if (sg[2] == 1) {
+                const int32_t id = idr[sg[4]];
+                for (int d = 0; d < sg[1]; ++d) dst[d] = id >= 0 ? extra[sg[3]][(size_t)id * D + d] : 0.f;
+            } else {
+                const float* src = sg[2] == 2 ? pooled : c;
+                for (int d = 0; d < sg[1]; ++d) dst[d] = src[d];
+            }
+        }
+        for (int n = 0; n < N0; ++n) y0[n] = b0[n];
+        for (int i = 0; i < X; ++i) {
+            const float xi = x[i];
+            const float* w = W0 + (size_t)i * N0;
+            for (int n = 0; n < N0; ++n) y0[n] += xi * w[n];
+        }
+        for (int n = 0; n < N0; ++n) y0[n] = y0[n] > 0.f ? y0[n] : a0[n] * y0[n];
+        for (int n = 0; n < N1; ++n) y1[n] = b1[n];
+        for (int i = 0; i < N0; ++i) {
+            const float xi = y0[i];
+            const float* w = W1 + (size_t)i * N1;
+            for (int n = 0; n < N1; ++n) y1[n] += xi * w[n];
+        }
+        float z = hb;
+        for (int n = 0; n < N1; ++n) z += hw[n] * (y1[n] > 0.f ? y1[n] : a1[n] * y1[n]);
+        out[m] = z >= 0.f ? 1.0f / (1.0f + expf(-z)) : expf(z) / (1.0f + expf(z));
+    }
+}

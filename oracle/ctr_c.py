@@ -80,3 +80,56 @@ class DeepFMv2C:
             vp(self.b0.ctypes.data), vp(self.W1.ctypes.data), vp(self.b1.ctypes.data), vp(self.head_w.ctypes.data),
             C.c_float(self.head_b), vp(out.ctypes.data), C.c_int32(int(threads)))
         return out
+
+
+class DinC:
+    """Weights of a models.DIN laid out once for the C forward (din_forward_c); ``model`` supplies the concat order of the
+    tail (its ``_fc_rows``), the ids column order of ``pack`` and the numeric key order."""
+
+    def __init__(self, model):
+        w = model.weights
+        c = lambda a: np.ascontiguousarray(a, dtype=np.float32)
+        self.T, self.D, self.H = model.hist_len, model.emb_dim, model.att_hidden
+        cols = [col.key for col in model.id_columns]
+        self.F, self.ND = len(cols), len(model.numeric_keys)
+        self.hist_col, self.cand_col = cols.index(model._hist_keys()[0]), cols.index("movieId")
+        self.table = c(w["emb/movie"])
+        self.Wa, self.ba, self.alpha = c(w["att0/kernel"]), c(w["att0/bias"]), c(w["att_prelu/alpha"])
+        self.w2, self.b2 = c(w["att1/kernel"])[:, 0].copy(), float(w["att1/bias"][0])
+        extra_names = ["userId", "userGenre1", "movieGenre1"]
+        self.extra = [c(w["emb/" + k]) for k in extra_names]
+        rows, fan = model._fc_rows()
+        seg = []
+        for name, (r0, width) in rows.items():
+            if name == "__pooled__":
+                seg.append((r0, width, 2, 0, 0))
+            elif name == "__cand__":
+                seg.append((r0, width, 3, 0, 0))
+            elif name.endswith("_embedding"):
+                k = name[:-len("_embedding")]
+                seg.append((r0, width, 1, extra_names.index(k), cols.index(k)))
+            else:
+                seg.append((r0, 1, 0, list(model.numeric_keys).index(name), 0))
+        self.seg = np.ascontiguousarray(np.array(seg, dtype=np.int32))
+        self.X = fan
+        self.W0, self.b0, self.a0 = c(w["fc0/kernel"]), c(w["fc0/bias"]), c(w["fc0_prelu/alpha"])
+        self.W1, self.b1, self.a1 = c(w["fc1/kernel"]), c(w["fc1/bias"]), c(w["fc1_prelu/alpha"])
+        self.N0, self.N1 = self.W0.shape[1], self.W1.shape[1]
+        self.hw, self.hb = c(w["head/kernel"])[:, 0].copy(), float(w["head/bias"][0])
+        self._extra_p = _ptr_array(self.extra)
+
+    def forward(self, ids, dense, threads=1, out=None):
+        ids = np.ascontiguousarray(ids, dtype=np.int32)
+        dense = np.ascontiguousarray(dense, dtype=np.float32)
+        B = ids.shape[0]
+        assert ids.shape[1] == self.F and dense.shape == (B, self.ND)
+        if out is None:
+            out = np.empty(B, dtype=np.float32)
+        vp, i32 = C.c_void_p, C.c_int32
+        p = lambda a: vp(a.ctypes.data)
+        load().din_forward_c(
+            i32(B), i32(self.F), i32(self.ND), i32(self.T), i32(self.D), i32(self.H), i32(self.hist_col), i32(self.cand_col),
+            p(ids), p(dense), p(self.table), p(self.Wa), p(self.ba), p(self.alpha), p(self.w2), C.c_float(self.b2),
+            i32(len(self.seg)), p(self.seg), self._extra_p, i32(self.X), i32(self.N0), i32(self.N1), p(self.W0), p(self.b0),
+            p(self.a0), p(self.W1), p(self.b1), p(self.a1), p(self.hw), C.c_float(self.hb), p(out), i32(int(threads)))
+        return out

@@ -31,6 +31,19 @@ def test_c_forward_matches_numpy_oracle(fields, D, K):
     assert ref.std() > 0.02
 
 
+@pytest.mark.parametrize("T,D,B", [(50, 32, 1500), (5, 10, 777), (20, 16, 1)])
+def test_c_din_forward_matches_numpy_oracle(T, D, B):
+    V, U = 5000, 7000
+    model = M.DIN(seed=9, emb_dim=D, hist_len=T, movie_buckets=V, user_buckets=U)
+    feats = SY.synth_din(B, T, V, U, seed=13)
+    ids, dense = model.pack(feats)
+    cm = ctr_c.DinC(model)
+    got = cm.forward(ids, dense, threads=1)
+    assert np.array_equal(got, cm.forward(ids, dense, threads=3))
+    ref = O.din_forward(feats, model.weights, dtype=np.float64, hist_len=T, movie_buckets=V, user_buckets=U)[:, 0]
+    assert np.abs(got - ref).max() <= 2e-5
+
+
 def test_bench_cpu_baseline_legs_run_without_a_gpu():
     sys.path.insert(0, ROOT)
     import bench
@@ -42,4 +55,8 @@ def test_bench_cpu_baseline_legs_run_without_a_gpu():
     assert "oracle/ctr_c.c" in r["sample"] and r["numpy_oracle_samples_per_sec"] > 0
     r2 = bench.cpu_baseline_numpy("deepfm_v2_c2", model, feats, 0.2)
     assert r2["kind"] == "port" and "numpy oracle" in r2["sample"]
-    assert bench.cpu_baseline_c("din_c3", model, feats, 0.1) is None   # no C restatement for DIN: numpy leg is used
+    assert bench.cpu_baseline_c("widedeep_c5", model, feats, 0.1) is None   # no C restatement: the numpy leg is used
+    din = M.DIN(seed=103, emb_dim=32, hist_len=50, movie_buckets=SY.ML20M_MOVIE_IDS, user_buckets=SY.ML20M_USER_IDS)
+    fd = [SY.synth_din(1024, 50, SY.ML20M_MOVIE_IDS, SY.ML20M_USER_IDS, seed=4)]
+    r3 = bench.cpu_baseline("din_c3", din, fd, 0.4)
+    assert r3["kind"] == "port" and "DIN forward (oracle/ctr_c.c" in r3["sample"] and r3["value"] > 0
