@@ -3,21 +3,37 @@
 
     python bench.py --gpus N --steps K --warmup W [--workload NAME]
 
-One "step" = one pass of the hot path over one batch (ids + dense already resident in HBM ->
-scores in HBM); at N>1 every rank scores its own B-row shard (weak scaling: global batch N*B) and its
-score slices are all-gathered over RCCL, --gather-group steps per collective on a second stream (every
-step's scores have been exchanged on every rank when the timed region ends).  Rank 0 prints ONE JSON line.
+One "step" = one pass of the hot path over one batch (ids + dense already resident in HBM -> scores in HBM); at N>1
+every rank scores its own B-row shard (weak scaling: global batch N*B) and its score slices are all-gathered over RCCL,
+--gather-group steps per collective on a second stream (every step's scores have been exchanged on every rank when a
+timed region ends).  Rank 0 prints ONE JSON line.
+
+How the K steps are timed.  A 65 536-row forward takes single-digit microseconds, so K = 20 steps are ~100 us of GPU work
+-- less than one host synchronisation.  The timed REGION is therefore R back-to-back repetitions of the K-step block,
+R chosen (after the warm-up) so that a region lasts >= --min-region-ms (50 ms); a region is bracketed by barrier +
+torch.cuda.synchronize() on both sides and timed with the host clock (max over ranks); --regions (5) regions are timed
+and `ms_per_step` = median region / (R*K).  `config.repeats` = R.  The warm-up runs W steps AND at least --settle-ms of
+work, so clocks have settled whatever W is.
+
+--gpus N without a launcher (no RANK in the environment) starts the N ranks itself, one process per GPU.
 
 Workloads (BASELINE.json configs):
-  deepfm_v2_c2 (default) configs[1]: DeepFM (sum-of-squares FM cross, DeepFM_v2 graph), 6 sparse
-               fields, emb_dim 16, projection width 16, B = 65 536 per GPU
-  deepfm_c2    the pairwise-dot DeepFM graph on the same fields
+  deepfm_v2_c2 (default) configs[1]: DeepFM (sum-of-squares FM cross, DeepFM_v2 graph), 6 sparse fields, emb_dim 16,
+               projection width 16, B = 65 536 per GPU
+  deepfm_c2    the pairwise-dot DeepFM graph (DeepFM.py) on the same fields
   din_c3       configs[2]: DIN, hist_len 50, emb_dim 32, B = 32 768 per GPU
+  deepfm_v2_c4 configs[3], one GPU's replica: DeepFM_v2 graph, emb_dim 64, tables of 138 493 users x 27 M rows (6.9 GB), B = 65 536
+  deepfm_c4    configs[3] for the pairwise-dot graph: real 256-byte row gathers out of the 6.9 GB table
   widedeep_c5  configs[4], one GPU's share: Wide&Deep with the 10 M-bucket x 32 hashed cross table, B = 131 072
+  deepfm_v2_ref / neuralcf_ref   the reference's own literal shapes (DeepFM_v2.py: 4 fields, emb_dim 10, Dense(64)
+               projections; NeuralCF.py: 2 fields, emb_dim 10, 20->10->10->1) on MovieLens-20M-sized vocabularies
 """
 import argparse
 import json
+import math
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -28,12 +44,32 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK = 8.0e12          # B/s, MI355X spec (MI355X_MICROARCH.md)
-MFMA_F32_PEAK = 157.3e12   # FLOP/s, fp32-input MFMA
+MFMA_F32_PEAK = 157.3e12   # FLOP/s, fp32-input MFMA (= the fp32 vector rate on gfx950)
+MFMA_F16_PEAK = 2.5e15     # FLOP/s, dense f16/bf16 MFMA
+CONFIG4_ROWS = 27_000_000  # BASELINE configs[3]: "138 k-movie x 27 M-row synthetic table"
+
+
+def _device_table(V, D, seed, std):
+    """[V, D] float32 table drawn ON the device (a 27 M x 64 table is 6.9 GB: numpy would need minutes and as much host
+    memory).  Truncated at 2 sigma like tf's truncated_normal initialiser."""
+    import torch
+    g = torch.Generator(device="cuda")
+    g.manual_seed(seed)
+    t = torch.empty((V, D), dtype=torch.float32, device="cuda")
+    t.normal_(0.0, 1.0, generator=g).clamp_(-2.0, 2.0).mul_(std)
+    return t
 
 
 def build_workload(name, B, dist_name, seed_offset=0, big_vocab=0, NB=8):
-    """NB: distinct input batches (own ids / dense / score buffers each) the steps cycle through."""
+    """NB: distinct input batches (own ids / dense / score buffers each) the steps cycle through.
+    Returns (model, feats, desc, roof): roof = the dominant kernel, its bound, its algorithmic bytes / flops per sample."""
     from sparrowrecsys_amd import models as M, synthetic as SY
+    from sparrowrecsys_amd.schema import N_GENRES
+    env = os.environ.get
+
+    def synth(fields):
+        return [SY.synth_fields(B, fields, seed=SY.SEED + 1000 * seed_offset + i, dist=dist_name) for i in range(NB)]
+
     if name in ("deepfm_v2_c2", "deepfm_c2"):
         F, D = 6, 16
         fields = SY.CONFIG2_FIELDS
@@ -41,43 +77,91 @@ def build_workload(name, B, dist_name, seed_offset=0, big_vocab=0, NB=8):
             # same graph, the three identity fields' tables blown up past the 256 MB Infinity Cache: every row gather is a
             # real HBM access (config 4's "true HBM-resident gather" at config 2's widths)
             fields = [(k, kind, big_vocab if kind == "id" else v) for k, kind, v in fields]
-        if name == "deepfm_v2_c2" and big_vocab:
-            model = M.DeepFMv2(seed=101, emb_dim=D, fields=fields, proj_dim=16)
-            desc = "DeepFM sum-of-squares FM (DeepFM_v2 graph), F=6, emb_dim=16, proj=16, deep 32-16, identity tables of %d rows each" % big_vocab
-            feats = [SY.synth_fields(B, fields, seed=SY.SEED + 1000 * seed_offset + i, dist=dist_name) for i in range(NB)]
-            bytes_per_sample = F * 4 + F * D * 4 + F * 4 + 7 * 4 + 4
-            roof = {"bound": "hbm", "kernel": "k_deepfm_v2_joint", "bytes_per_sample": bytes_per_sample}
-            model._bench_fields = fields
-            return model, feats, desc, roof
-        if name == "deepfm_v2_c2":
-            model = M.DeepFMv2(seed=101, emb_dim=D, fields=SY.CONFIG2_FIELDS, proj_dim=16)
-            desc = "DeepFM sum-of-squares FM (DeepFM_v2 graph), F=6 sparse fields, emb_dim=16, proj=16, deep 32-16"
-        else:
-            model = M.DeepFM(seed=101, emb_dim=D, fields=SY.CONFIG2_FIELDS, pairs=SY.CONFIG2_PAIRS)
-            desc = "DeepFM pairwise-dot FM (DeepFM graph), F=6 sparse fields, emb_dim=16, 8 pairs, deep 64-64"
-        feats = [SY.synth_fields(B, SY.CONFIG2_FIELDS, seed=SY.SEED + 1000 * seed_offset + i, dist=dist_name) for i in range(NB)]
-        # fused kernel: ids + embedding rows + first-order weights + numerics in, one score out
         bytes_per_sample = F * 4 + F * D * 4 + F * 4 + 7 * 4 + 4
-        v2_kernel = "k_deepfm_v2_chain" if (os.environ.get("SPRK_V2_JOINT") == "0" or os.environ.get("SPRK_V2_FOLD") == "0") else "k_deepfm_v2_joint"
-        if os.environ.get("SPRK_FORCE_INTERPRETER") == "1":
-            v2_kernel = "k_tile_forward"
-        v1_kernel = "k_tile_forward" if os.environ.get("SPRK_V1_CHAIN") == "0" else "k_deepfm_pairs"
-        roof = {"bound": "hbm", "kernel": v2_kernel if name == "deepfm_v2_c2" else v1_kernel,
-                "bytes_per_sample": bytes_per_sample}
-    elif name == "din_c3":
+        if name == "deepfm_v2_c2":
+            model = M.DeepFMv2(seed=101, emb_dim=D, fields=fields, proj_dim=16)
+            desc = "DeepFM sum-of-squares FM (DeepFM_v2 graph), F=6 sparse fields, emb_dim=16, proj=16, deep 32-16"
+            if big_vocab:
+                desc += ", identity tables of %d rows each" % big_vocab
+            kernel = "k_deepfm_v2_chain" if (env("SPRK_V2_JOINT") == "0" or env("SPRK_V2_FOLD") == "0") else "k_deepfm_v2_joint"
+        else:
+            model = M.DeepFM(seed=101, emb_dim=D, fields=fields, pairs=SY.CONFIG2_PAIRS)
+            desc = "DeepFM pairwise-dot FM (DeepFM graph), F=6 sparse fields, emb_dim=16, 8 pairs, deep 64-64"
+            kernel = "k_tile_forward" if env("SPRK_V1_CHAIN") == "0" else "k_deepfm_pairs"
+        if env("SPRK_FORCE_INTERPRETER") == "1":
+            kernel = "k_tile_forward"
+        model._bench_fields = fields
+        # fused kernel: ids + embedding rows + first-order weights + numerics in, one score out
+        roof = {"bound": "hbm", "kernel": kernel, "bytes_per_sample": bytes_per_sample}
+        if name == "deepfm_c2":
+            # MFMA work of the tail as issued: deep0 (K = 2*16 + 8 numerics -> 48 f32 MFMAs of 16x16x4 per 16 samples = 3 K-chunks
+            # x 4 steps x 4 n-blocks) on f32, deep1 (64 x 64) as 3 split-f16 products of 16x16x32 x 2 K-chunks x 4 n-blocks
+            roof["mfma"] = {"f32_flops_per_sample": 48 * 2 * 16 * 16 * 4 / 16, "f16_flops_per_sample": 24 * 2 * 16 * 16 * 32 / 16,
+                            "reference_flops_per_sample": 2 * (39 * 64 + 64 * 64 + 64)}
+        return model, synth(fields), desc, roof
+    if name in ("deepfm_v2_c4", "deepfm_c4"):
+        # BASELINE configs[3]: emb_dim 64, userId (138 493 users) and a 27 M-row item table (6.9 GB, HBM-resident), plus the two
+        # genre fields of the reference's DeepFM.py; tables drawn on the device
+        D = 64
+        fields = [("movieId", "id", CONFIG4_ROWS), ("userId", "id", SY.ML20M_USER_IDS),
+                  ("userGenre1", "genre", N_GENRES), ("movieGenre1", "genre", N_GENRES)]
+        cls = M.DeepFMv2 if name == "deepfm_v2_c4" else M.DeepFM
+        kw = dict(proj_dim=16) if name == "deepfm_v2_c4" else dict(pairs=None)
+        small = cls(seed=107, emb_dim=D, fields=[(k, kind, min(v, 1024)) for k, kind, v in fields], **kw)
+        w = dict(small.weights)
+        for i, (k, kind, v) in enumerate(fields):
+            if kind == "id":
+                w["emb/" + k] = _device_table(v, D, 1000 + i, 1.0 / math.sqrt(D))
+        rng = np.random.default_rng(7)
+        fo_key = "fo_cat/kernel" if name == "deepfm_v2_c4" else "head/kernel"
+        model = cls(weights=_resize_first_order(small, w, fields, fo_key, rng), emb_dim=D, fields=fields, **kw)
+        model._bench_fields = fields
+        F = 4
+        if name == "deepfm_v2_c4":
+            desc = "DeepFM_v2 graph, emb_dim=64, 4 fields: movieId 27 M rows (6.9 GB table), userId 138 494, two genre fields; proj=16, deep 32-16"
+            # folded rows: what the kernel gathers per big field is the 64-B projected row + its scalar, not the 256-B embedding row
+            roof = {"bound": "hbm", "kernel": "k_deepfm_v2_joint", "bytes_per_sample": F * 4 + 2 * (64 + 4) + 2 * 4 + 7 * 4 + 4,
+                    "reference_bytes_per_sample": F * (4 + D * 4 + 4) + D * 4}
+        else:
+            desc = "DeepFM pairwise-dot graph, emb_dim=64, 4 fields: movieId 27 M rows (6.9 GB table), userId 138 494, two genre fields; 4 pairs, deep 64-64"
+            roof = {"bound": "hbm", "kernel": "k_deepfm_pairs", "bytes_per_sample": F * (4 + D * 4 + 4) + 7 * 4 + 4}
+        return model, synth(fields), desc, roof
+    if name == "deepfm_v2_ref":
+        # DeepFM_v2.py as written: 4 fields, emb_dim 10, Dense(64) projections, deep 32-16 -- on ML-20M-sized vocabularies
+        fields = [("movieId", "id", SY.ML20M_MOVIE_IDS), ("userId", "id", SY.ML20M_USER_IDS),
+                  ("userGenre1", "genre", N_GENRES), ("movieGenre1", "genre", N_GENRES)]
+        model = M.DeepFMv2(seed=109, emb_dim=10, fields=fields, order=["movieGenre1", "movieId", "userGenre1", "userId"], proj_dim=64)
+        model._bench_fields = fields
+        desc = "DeepFM_v2.py literal: 4 fields, emb_dim=10, Dense(64) projections, deep 32-16"
+        roof = {"bound": "hbm", "kernel": "?", "bytes_per_sample": 4 * 4 + 2 * (64 * 4 + 4) + 2 * 4 + 7 * 4 + 4,
+                "reference_bytes_per_sample": 4 * (4 + 40 + 4) + 7 * 4 + 4}
+        return model, synth(fields), desc, roof
+    if name == "neuralcf_ref":
+        model = M.NeuralCF(seed=111, emb_dim=10, movie_buckets=SY.ML20M_MOVIE_IDS, user_buckets=SY.ML20M_USER_IDS)
+        desc = "NeuralCF.py literal: movieId/userId emb_dim=10, 20->10->10->1"
+        fields = [("movieId", "id", SY.ML20M_MOVIE_IDS), ("userId", "id", SY.ML20M_USER_IDS)]
+        model._bench_fields = fields
+        roof = {"bound": "hbm", "kernel": "?", "bytes_per_sample": 2 * 4 + 2 * 40 + 4}
+        return model, synth(fields), desc, roof
+    if name == "din_c3":
         T, D = 50, 32
         model = M.DIN(seed=103, emb_dim=D, hist_len=T, movie_buckets=SY.ML20M_MOVIE_IDS, user_buckets=SY.ML20M_USER_IDS)
         desc = "DIN, hist_len=50, emb_dim=32, attention 128->32->1, tail 167->128->64->1"
         feats = [SY.synth_din(B, T, SY.ML20M_MOVIE_IDS, SY.ML20M_USER_IDS, seed=SY.SEED + 1000 * seed_offset + i, dist=dist_name) for i in range(NB)]
         flops = T * (2 * 4 * D * 32 + 2 * 32 + 3 * 32)            # the reference's count: K = 4D per (b,t)
         # what k_din_attn issues on the matrix pipe: K = D per (b,t) after folding the c-only and h-only
-        # blocks (A_b = W12 + W4 diag(c)), over whole 16-row groups (T=50 -> 64 columns)
+        # blocks (A_b = W12 + W4 diag(c)), over whole 16-row groups (T=50 -> 64 columns), 3 split-f16 products
         executed = ((T + 15) // 16) * 16 * 2 * D * 32
-        legacy = os.environ.get("SPRK_DIN_LEGACY") == "1"
+        legacy = env("SPRK_DIN_LEGACY") == "1"
         roof = {"bound": "mfma", "kernel": "k_din_pool" if legacy else "k_din_attn", "flops_per_sample": flops,
                 "executed_flops_per_sample": flops if legacy else executed,
-                "bytes_per_sample": (T + 1) * 4 + (T + 1) * D * 4 + D * 4}
-    elif name == "widedeep_c5":
+                "bytes_per_sample": (T + 1) * 4 + (T + 1) * D * 4 + D * 4,
+                # k_din_tail per 16 samples: fc0's per-sample part (K = 32 pooled + 8 numerics -> 96 f32 MFMAs 16x16x4 ... counted
+                # as issued: 8 n-blocks x (8 + 2) K-steps + ...), fc1 128 x 64 as 48 split-f16 MFMAs 16x16x32
+                "tail_mfma": {"f32_flops_per_sample": 96 * 2 * 16 * 16 * 4 / 16, "f16_flops_per_sample": 48 * 2 * 16 * 16 * 32 / 16,
+                              "reference_flops_per_sample": 2 * (167 * 128 + 128 * 64 + 64)}}
+        return model, feats, desc, roof
+    if name == "widedeep_c5":
         # BASELINE configs[4], one GPU's share: Wide&Deep, hashed cross (movieId x userRatedMovie1) computed on device into a
         # 10 M-bucket x 32 embedding table (1.28 GB), emb_dim 32, deep 128-128
         D, CB = 32, 10_000_000
@@ -87,35 +171,93 @@ def build_workload(name, B, dist_name, seed_offset=0, big_vocab=0, NB=8):
         feats = [SY.synth_embedding_mlp(B, SY.ML20M_MOVIE_IDS, SY.ML20M_USER_IDS, seed=SY.SEED + 1000 * seed_offset + i, dist=dist_name,
                                         rated_vocab=SY.ML20M_MOVIE_IDS) for i in range(NB)]
         # 8 B ids + 128 B cross row per sample for the wide part; + the deep part's 11 ids, 10 rows, numerics, score
-        roof = {"bound": "hbm", "kernel": "k_tile_forward" if os.environ.get("SPRK_MLP_CHAIN") == "0" else "k_mlp_chain",
-                "bytes_per_sample": 8 + D * 4 + 9 * 4 + 10 * D * 4 + 7 * 4 + 4}
-    else:
-        raise SystemExit("unknown workload %r" % name)
-    return model, feats, desc, roof
+        roof = {"bound": "hbm", "kernel": "k_tile_forward" if env("SPRK_MLP_CHAIN") == "0" else "k_mlp_chain",
+                "bytes_per_sample": 8 + D * 4 + 9 * 4 + 10 * D * 4 + 7 * 4 + 4,
+                # per 16 samples: dense0's unfolded part (movieId + userId rows 2 x 32 + 8 numerics = K 72 -> 5 K-chunks of 16 = 20 steps x
+                # 8 n-blocks = 160 ... as issued 192 f32) and dense1 128 x 128 as 96 split-f16 MFMAs
+                "mfma": {"f32_flops_per_sample": 192 * 2 * 16 * 16 * 4 / 16, "f16_flops_per_sample": 96 * 2 * 16 * 16 * 32 / 16,
+                         "reference_flops_per_sample": 2 * (327 * 128 + 128 * 128 + 128)}}
+        return model, feats, desc, roof
+    raise SystemExit("unknown workload %r" % name)
+
+
+def _resize_first_order(small, w, fields, fo_key, rng):
+    """Weights of the config-4 models: everything from a small-vocabulary twin except the first-order block (one weight
+    per id of every field, 27 M of them) and the big tables (already in `w`, on the device)."""
+    from sparrowrecsys_amd.models import first_order_offsets
+    fo_small = first_order_offsets(small.fields)
+    fo_big = first_order_offsets(fields)
+    old = np.asarray(small.weights[fo_key])
+    n_small, n_big = fo_small["__total__"], fo_big["__total__"]
+    blk = rng.uniform(-0.05, 0.05, size=(n_big, 1)).astype(np.float32)
+    w[fo_key] = np.concatenate([blk, old[n_small:]], axis=0) if fo_key == "head/kernel" else blk
+    return w
 
 
 def oracle_forward(name, model, feats):
+    """The numpy oracle on `feats` (a few thousand rows).  Models holding device tables (config 4) are compacted first:
+    only the table rows the sample references are pulled to the host and the ids are renumbered, so the oracle never sees
+    the 6.9 GB table."""
     from oracle import ctr_oracle as O
     from sparrowrecsys_amd import synthetic as SY
-    if name == "deepfm_v2_c2":
-        fields = getattr(model, "_bench_fields", SY.CONFIG2_FIELDS)
-        return O.deepfm_v2_forward(feats, model.weights, dtype=np.float32, fields=fields, order=[k for k, _, _ in fields])
-    if name == "deepfm_c2":
-        return O.deepfm_forward(feats, model.weights, dtype=np.float32, fields=SY.CONFIG2_FIELDS, pairs=SY.CONFIG2_PAIRS)
+    fields = getattr(model, "_bench_fields", SY.CONFIG2_FIELDS)
+    weights = model.weights
+    if any(hasattr(v, "data_ptr") for v in weights.values()):
+        feats, weights, fields = compact_for_oracle(model, feats, fields)
+    if name in ("deepfm_v2_c2", "deepfm_v2_c4", "deepfm_v2_ref"):
+        return O.deepfm_v2_forward(feats, weights, dtype=np.float32, fields=fields, order=model.order)
+    if name in ("deepfm_c2", "deepfm_c4"):
+        return O.deepfm_forward(feats, weights, dtype=np.float32, fields=fields, pairs=model.pairs)
+    if name == "neuralcf_ref":
+        return O.neural_cf_forward(feats, weights, dtype=np.float32, movie_buckets=model.movie_buckets, user_buckets=model.user_buckets)
     if name == "widedeep_c5":
-        return O.wide_n_deep_forward(feats, model.weights, dtype=np.float32, movie_buckets=model.movie_buckets,
+        return O.wide_n_deep_forward(feats, weights, dtype=np.float32, movie_buckets=model.movie_buckets,
                                      user_buckets=model.user_buckets, cross_buckets=model.cross_buckets,
                                      rated_buckets=model.rated_buckets)
-    return O.din_forward(feats, model.weights, dtype=np.float32, hist_len=model.hist_len,
+    return O.din_forward(feats, weights, dtype=np.float32, hist_len=model.hist_len,
                          movie_buckets=model.movie_buckets, user_buckets=model.user_buckets)
 
 
-def cpu_baseline_c(name, model, feats, budget_s):
+def compact_for_oracle(model, feats, fields):
+    """DeepFM / DeepFM_v2 with device-resident identity tables: renumber each identity field's ids to 0..n_unique-1 and
+    keep only those rows of its table and of the first-order block (name-sorted one-hot offsets, models.first_order_offsets)."""
+    import torch
+    from sparrowrecsys_amd.models import first_order_offsets
+    fo_key = "fo_cat/kernel" if "fo_cat/kernel" in model.weights else "head/kernel"
+    fo = first_order_offsets(fields)
+    fo_w = np.asarray(model.weights[fo_key])
+    new_fields, new_feats, uniq = [], dict(feats), {}
+    for k, kind, v in fields:
+        if kind == "id":
+            u, inv = np.unique(np.asarray(feats[k]).astype(np.int64), return_inverse=True)
+            uniq[k] = u
+            new_feats[k] = inv.astype(np.int64)
+            new_fields.append((k, kind, len(u)))
+        else:
+            new_fields.append((k, kind, v))
+    w = {}
+    for name, a in model.weights.items():
+        if name.startswith("emb/") and name[4:] in uniq:
+            a = a[torch.from_numpy(uniq[name[4:]]).to(a.device)].cpu().numpy() if hasattr(a, "data_ptr") else np.asarray(a)[uniq[name[4:]]]
+        elif hasattr(a, "data_ptr"):
+            a = a.cpu().numpy()
+        w[name] = a
+    fo_new = first_order_offsets(new_fields)
+    blk = np.zeros((fo_new["__total__"], 1), np.float32)
+    for k, kind, v in fields:
+        rows = uniq[k] if kind == "id" else np.arange(v)
+        blk[fo_new[k]:fo_new[k] + len(rows), 0] = fo_w[fo[k] + rows, 0]
+    w[fo_key] = np.concatenate([blk, fo_w[fo["__total__"]:]], axis=0) if fo_key == "head/kernel" else blk
+    return new_feats, w, new_fields
+
+
+def cpu_baseline_c(name, model, feats, budget_s, note):
     """deepfm_v2_c2 / din_c3: the plain-C restatement of the forward (oracle/ctr_c.c, OpenMP over samples, built with
     -march=native on THIS host) on the packed ids / dense of the same synthetic batch -- a fairer stand-in for the
     reference's TF2 CPU forward than the numpy oracle, whose time goes into Python feature handling.  Checked against
-    the numpy oracle before it is timed.  Returns None when it cannot be used (other workloads, no compiler)."""
+    the numpy oracle before it is timed.  Returns None (and says why in `note`) when it cannot be used."""
     if name not in ("deepfm_v2_c2", "din_c3"):
+        note.append("no C restatement for this workload")
         return None
     try:
         from oracle import ctr_c
@@ -133,6 +275,7 @@ def cpu_baseline_c(name, model, feats, budget_s):
         got = cm.forward(ids[:2048], dense[:2048], threads=1)
         ref = oracle_forward(name, model, {k: v[:2048] for k, v in feats[0].items()})[:, 0]
         if not (np.abs(got - ref).max() <= 5e-5):
+            note.append("C restatement disagreed with the numpy oracle (max |diff| %g): not used" % np.abs(got - ref).max())
             return None
         out = np.empty(n, dtype=np.float32)
         cm.forward(ids, dense, threads=threads, out=out)     # warm-up (threads, page faults)
@@ -144,25 +287,30 @@ def cpu_baseline_c(name, model, feats, budget_s):
             el = time.perf_counter() - t0
             if el >= budget_s or done >= 4096 * n:
                 break
-        return {"value": done / el, "unit": "samples/s", "cores": threads, "kind": "port",
+        return {"value": done / el, "unit": "samples/s", "cores": threads, "kind": "port", "ran": "oracle/ctr_c.c",
                 "sample": "plain-C restatement of the %s forward (oracle/ctr_c.c, OpenMP, -march=native; TensorFlow unavailable), "
                           "%d passes over one packed batch of %d rows, %.1f s" % (what, done // n, n, el),
                 "host_cpus": os.cpu_count()}
-    except Exception:
+    except Exception as e:                                    # no compiler on this host, ...: say so, fall back to numpy
+        note.append("C restatement unavailable (%s: %s)" % (type(e).__name__, e))
         return None
 
 
 def cpu_baseline(name, model, feats, budget_s):
     """The CPU restatement ("port": TensorFlow is not installable) timed on this host's cores over a bounded sample of
-    the same workload: the C restatement where there is one (DeepFM_v2), with the numpy oracle's rate reported next to
-    it; the numpy oracle otherwise."""
-    c = cpu_baseline_c(name, model, feats, 0.5 * budget_s)
+    the same workload: the C restatement where there is one (DeepFM_v2, DIN), with the numpy oracle's rate reported next
+    to it; the numpy oracle otherwise.  `ran` names the one that produced `value`."""
+    note = []
+    c = cpu_baseline_c(name, model, feats, 0.5 * budget_s, note)
     if c is not None:
         npy = cpu_baseline_numpy(name, model, feats, 0.5 * budget_s)
         c["numpy_oracle_samples_per_sec"] = npy["value"]
         c["numpy_oracle_threads"] = npy["cores"]
         return c
-    return cpu_baseline_numpy(name, model, feats, budget_s)
+    r = cpu_baseline_numpy(name, model, feats, budget_s)
+    r["ran"] = "oracle/ctr_oracle.py (numpy)"
+    r["why_not_c"] = "; ".join(note)
+    return r
 
 
 def cpu_baseline_numpy(name, model, feats, budget_s):
@@ -190,6 +338,83 @@ def cpu_baseline_numpy(name, model, feats, budget_s):
             "host_cpus": os.cpu_count()}
 
 
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves (what
+    `python -m torch.distributed.run --nproc-per-node N` would do), rank r on GPU r, rendezvous on 127.0.0.1."""
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
+    rcs = [p.wait() for p in procs]
+    sys.exit(max(abs(rc) for rc in rcs))
+
+
+class Timer:
+    """Regions of R*K back-to-back steps, bracketed by fence() (barrier + synchronize) on both sides, host clock,
+    max over ranks; HIP events around the same region ride along."""
+
+    def __init__(self, run_steps, fence, dist_on, device_events):
+        self.run_steps, self.fence, self.dist_on, self.device_events = run_steps, fence, dist_on, device_events
+        self.step = 0
+
+    def region(self, n_steps):
+        import torch
+        self.fence()
+        ev = None
+        if self.device_events:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        t0 = time.perf_counter()
+        if ev:
+            ev[0].record()
+        self.run_steps(self.step, n_steps)
+        if ev:
+            ev[1].record()
+        self.fence()
+        wall = time.perf_counter() - t0
+        self.step += n_steps
+        if self.dist_on:
+            import torch.distributed as dist
+            t = torch.tensor([wall], dtype=torch.float64, device="cuda" if self.device_events else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            wall = float(t.item())
+        return wall, (ev[0].elapsed_time(ev[1]) * 1e-3 if ev else wall)
+
+
+def strict_loop(eng, batches, outs, ws, n_steps, lb_restore, fan_restore):
+    """n_steps forwards, ONE batch per launch, strict stream order, HIP events on the launch stream: the per-launch
+    duration rocprofv3's kernel trace reports for the same command.  Returns seconds per launch (median of 3 loops)."""
+    import torch
+    NB = len(batches)
+    eng.set_many_streams(0)
+    eng.set_many_batches(1)
+    idx = [i % NB for i in range(n_steps)]
+    run = eng.prepare_many([batches[j][0] for j in idx], [batches[j][1] for j in idx], [outs[j] for j in idx], ws)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    times = []
+    for _ in range(3):
+        torch.cuda.synchronize()
+        ev0.record()
+        run()
+        ev1.record()
+        torch.cuda.synchronize()
+        times.append(ev0.elapsed_time(ev1) * 1e-3 / n_steps)
+    if fan_restore:
+        eng.set_many_streams(fan_restore)
+    if lb_restore > 1:
+        eng.set_many_batches(lb_restore)
+    return float(np.median(times))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -200,28 +425,39 @@ def main():
     ap.add_argument("--dist", default="uniform", choices=["uniform", "zipf", "hot"], help="id distribution")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget (0 = skip)")
     ap.add_argument("--no-check", action="store_true", help="skip the oracle spot check of the outputs")
+    ap.add_argument("--min-region-ms", type=float, default=50.0,
+                    help="a timed region = R back-to-back repetitions of the K-step block, R chosen so that it lasts at least this long")
+    ap.add_argument("--regions", type=int, default=5, help="timed regions; ms_per_step is the median region / (R*K)")
+    ap.add_argument("--settle-ms", type=float, default=40.0, help="the warm-up lasts at least this long, whatever --warmup says")
     ap.add_argument("--gather-group", type=int, default=64,
                     help="N>1: batches whose score slices share one RCCL all-gather (overlapped with the next group)")
     ap.add_argument("--overlap-streams", type=int, default=2,
-                    help="fan sprk_forward_many's independent batches over S helper HIP streams (2..4; 0 = strict stream order) in "
-                         "the TIMED region: a dependent launch chain costs ~3.3 us per launch even for an empty kernel, so the "
-                         "predict-over-batches loop is launch bound without it.  The roofline block is always measured in strict "
-                         "order (one kernel at a time), in its own loop after the timed region.")
+                    help="with --launch-batches 1: fan sprk_forward_many's independent batches over S helper HIP streams (2..4; "
+                         "0 = strict stream order) in the TIMED region.  The roofline block is always measured in strict order "
+                         "(one kernel at a time), in its own loop after the timed regions.")
     ap.add_argument("--launch-batches", type=int, default=16,
                     help="batches ONE kernel launch scores in the timed region (sprk_set_many_batches, up to 64; 1 = a launch per "
-                         "batch; deepfm_v2_c2 only).  Each batch keeps its own buffers of --batch rows; the ~3.3 us launch floor is "
-                         "spent once per N batches.  With N > 1 the launches of the timed region run in strict order (no stream "
-                         "fan-out).  The `roofline` block stays ONE batch per launch; `roofline_timed_region` describes the "
-                         "N-batch launches.")
+                         "batch).  Each batch keeps its own buffers of --batch rows.  With N > 1 the launches of the timed region run "
+                         "in strict order (no stream fan-out).  `roofline` and `value_one_batch_per_launch` stay ONE batch per "
+                         "launch; `roofline_timed_region` describes the N-batch launches.")
     ap.add_argument("--input-batches", type=int, default=0,
                     help="distinct synthetic input batches the steps cycle through (default: 32 for the headline workload -- no "
                          "two batches of one 16-batch launch share buffers -- 16 for din_c3, 8 otherwise)")
     ap.add_argument("--big-vocab", type=int, default=0,
-                    help="deepfm_v2_c2 only: rows of each identity table (e.g. 8388608 = 1 GiB of folded rows per table, "
+                    help="deepfm_v2_c2 / deepfm_c2: rows of each identity table (e.g. 8388608 = 1 GiB of folded rows per table, "
                          "far beyond the Infinity Cache); default 0 = the MovieLens-20M-shaped vocabularies of the config")
+    ap.add_argument("--hbm-resident", type=int, default=-1,
+                    help="deepfm_v2_c2 at N=1: also measure the same graph with identity tables of this many rows (HBM-resident "
+                         "gather, block `roofline_hbm_resident`); default 8388608, 0 = skip")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend (gloo: functional test of the N>1 path with ranks sharing one GPU)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="no GPU, no kernels: the launcher / process-group / grouped all-gather / timing plumbing with a stand-in "
+                         "forward on CPU tensors (gloo).  For the CPU test of `--gpus N` self-spawning; the line says dry_run")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "RANK" not in os.environ:
+        spawn_ranks(args.gpus, sys.argv[1:])
 
     import torch
     import torch.distributed as dist
@@ -230,10 +466,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs one process per GPU: launch with python -m torch.distributed.run "
-                             "--nproc-per-node %d ..." % (args.gpus, args.gpus))
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if args.dry_run:
+        return dry_run(args, rank, world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
     local_dev = local_rank % torch.cuda.device_count()
@@ -257,18 +492,21 @@ def main():
         nb_in = min(nb_in, 8)
     model, feats, desc, roof = build_workload(args.workload, B, args.dist, seed_offset=rank, big_vocab=args.big_vocab, NB=nb_in)
     eng = model.engine
+    if roof["kernel"] == "?":
+        roof["kernel"] = eng.kernel_name()
+    env = os.environ.get
     lb = 1
-    if args.launch_batches > 1 and os.environ.get("SPRK_FORCE_INTERPRETER") != "1":
-        if args.workload == "deepfm_v2_c2" and os.environ.get("SPRK_V2_JOINT") != "0" and os.environ.get("SPRK_V2_FOLD") != "0":
+    if args.launch_batches > 1 and env("SPRK_FORCE_INTERPRETER") != "1":
+        if roof["kernel"] == "k_deepfm_v2_joint":
             lb = args.launch_batches
-            args.overlap_streams = 0       # several batches per launch: strict order measured faster than the fan-out
-        elif args.workload == "deepfm_c2" and os.environ.get("SPRK_V1_CHAIN") != "0":
+        elif roof["kernel"] == "k_deepfm_pairs":
             lb = min(args.launch_batches, 16)
-            args.overlap_streams = 0
-        elif args.workload == "din_c3" and os.environ.get("SPRK_DIN_LEGACY") != "1" and os.environ.get("SPRK_DIN_TAIL") != "0":
+        elif args.workload == "din_c3" and env("SPRK_DIN_LEGACY") != "1" and env("SPRK_DIN_TAIL") != "0":
             lb = min(args.launch_batches, 16)   # groups of batches: one attention + one tail launch each, alternating streams
     if lb > 1:
         eng.set_many_batches(lb)
+        if args.workload != "din_c3":
+            args.overlap_streams = 0           # several batches per launch: strict order measured faster than the fan-out
     fan = args.overlap_streams if (args.overlap_streams >= 2 and eng.set_many_streams(args.overlap_streams)) else 0
     batches = []
     for f in feats:
@@ -283,6 +521,7 @@ def main():
         gs = GroupedScoreGather(B, max(1, args.gather_group), torch.device("cuda", local_dev))
 
     group_run = [None, None]
+    prepared = {}
 
     def run_steps(first, count):
         """`count` steps starting at step index `first`.  One sprk_forward_many call enqueues a run of
@@ -291,9 +530,16 @@ def main():
         each full group of --gather-group steps is exchanged by ONE RCCL all-gather on a second stream
         while the next group is scored (a per-step all-gather of 256 KiB costs more launch latency than
         the forward it follows)."""
+        if count <= 0:
+            return
         if gs is None:
-            idx = [i % NB for i in range(first, first + count)]
-            eng.forward_many([batches[j][0] for j in idx], [batches[j][1] for j in idx], [outs[j] for j in idx], ws)
+            key = (first % NB, count)
+            if key not in prepared:                # the marshalled pointer arrays of a (phase, length) pair are reused
+                idx = [i % NB for i in range(first, first + count)]
+                if len(prepared) > 8:
+                    prepared.clear()
+                prepared[key] = eng.prepare_many([batches[j][0] for j in idx], [batches[j][1] for j in idx], [outs[j] for j in idx], ws)
+            prepared[key]()
             return
         i = first
         while i < first + count:
@@ -323,54 +569,69 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    K = args.steps
+    timer = Timer(run_steps, fence, dist_on, True)
+    # ---- warm-up: W steps as asked, then K-step blocks until --settle-ms have passed (clocks, caches, RCCL channels) ----
+    t_w = time.perf_counter()
+    fence()
     run_steps(0, args.warmup)
     fence()
+    timer.step = args.warmup
+    settle = torch.tensor([0.0], dtype=torch.float64, device="cuda")
+    while True:
+        el = time.perf_counter() - t_w
+        if dist_on:                        # every rank must take the same number of blocks
+            settle[0] = el
+            dist.all_reduce(settle, op=dist.ReduceOp.MIN)
+            el = float(settle.item())
+        if el * 1e3 >= args.settle_ms:
+            break
+        timer.region(K)
     eng.check_ids()
-
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    fence()
-    t0 = time.perf_counter()
-    ev0.record()
-    run_steps(args.warmup, args.steps)
-    ev1.record()
-    fence()
-    elapsed = time.perf_counter() - t0
-    ev_ms = ev0.elapsed_time(ev1)
-    ev_ms_timed = ev_ms
+    # ---- calibration: one K-step block -> R ----
+    _, blk = timer.region(K)
     if dist_on:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([blk], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        blk = float(t.item())
+    R = int(max(1, min(math.ceil(args.min_region_ms * 1e-3 / max(blk, 1e-9)), max(1, 2_000_000 // max(K, 1)))))
+    # ---- timed regions ----
+    walls, evs = [], []
+    for _ in range(max(1, args.regions)):
+        w, e = timer.region(R * K)
+        walls.append(w)
+        evs.append(e)
+    elapsed = float(np.median(walls))          # seconds per region of R*K steps (max over ranks, median over regions)
+    ev_region = float(np.median(evs))
+    n_region = R * K
 
-    # kernel time for the roofline: HIP events on the launch stream around K forwards in STRICT order (one kernel at a
-    # time, what rocprofv3's per-kernel duration measures), re-timed right after the timed region whenever that region
-    # overlapped launches (fan-out) or held the all-gathers (N>1)
-    region = "timed region"
-    if dist_on or fan or lb > 1:
-        region = "strict-order forward loop after the timed region"
-        if fan:
-            eng.set_many_streams(0)
-        if lb > 1:
-            eng.set_many_batches(1)
-        torch.cuda.synchronize()
-        ev0.record()
-        idx = [i % NB for i in range(args.steps)]
-        eng.forward_many([batches[j][0] for j in idx], [batches[j][1] for j in idx], [outs[j] for j in idx], ws)
-        ev1.record()
-        torch.cuda.synchronize()
-        ev_ms = ev0.elapsed_time(ev1)
-        if fan:
-            eng.set_many_streams(fan)
-        if lb > 1:
-            eng.set_many_batches(lb)
-    fwd_s = ev_ms * 1e-3 / args.steps          # avg forward duration (all kernels of one step)
+    # kernel time for the roofline: HIP events on the launch stream around forwards in STRICT order, ONE batch per
+    # launch (what rocprofv3's per-kernel duration measures), in its own loop after the timed regions
+    n_strict = int(max(K, min(20000, math.ceil(0.02 / max(blk / K, 1e-9)))))
+    fwd_s = strict_loop(eng, batches, outs, ws, n_strict, lb, fan)
+    fan2_s = None
+    if not dist_on and lb > 1 and args.workload != "din_c3":
+        # one batch per launch, independent batches alternating over two helper streams (still a launch per batch)
+        eng.set_many_batches(1)
+        eng.set_many_streams(2)
+        idx = [i % NB for i in range(n_strict)]
+        run2 = eng.prepare_many([batches[j][0] for j in idx], [batches[j][1] for j in idx], [outs[j] for j in idx], ws)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        tt = []
+        for _ in range(3):
+            torch.cuda.synchronize()
+            ev0.record(); run2(); ev1.record()
+            torch.cuda.synchronize()
+            tt.append(ev0.elapsed_time(ev1) * 1e-3 / n_strict)
+        fan2_s = float(np.median(tt))
+        eng.set_many_streams(fan)
+        eng.set_many_batches(lb)
 
     # output spot check against the oracle (outside the timed region)
     check = None
     if rank == 0 and not args.no_check:
-        if dist_on:
-            eng.forward(batches[0][0], batches[0][1], outs[0], ws)
-            torch.cuda.synchronize()
+        eng.forward(batches[0][0], batches[0][1], outs[0], ws)
+        torch.cuda.synchronize()
         n = 4096
         got = outs[0][:n].cpu().numpy()
         ref = oracle_forward(args.workload, model, {k: v[:n] for k, v in feats[0].items()})[:, 0]
@@ -379,29 +640,35 @@ def main():
             raise SystemExit("bench outputs differ from the oracle: max|err| = %g" % check)
 
     if rank == 0:
-        value = B * world * args.steps / elapsed
-        din_s = None
-        legacy_din = os.environ.get("SPRK_DIN_LEGACY") == "1"
+        value = B * world * n_region / elapsed
+        region = "strict-order one-batch-per-launch loop after the timed regions (%d launches, median of 3 loops)" % n_strict
+        legacy_din = env("SPRK_DIN_LEGACY") == "1"
+        extra = {}
         if roof["bound"] == "hbm":
             achieved = roof["bytes_per_sample"] * B / fwd_s / 1e9
-            rl = {"bound": "hbm", "kernel": roof["kernel"], "achieved": achieved, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                  "frac": achieved * 1e9 / HBM_PEAK, "algorithmic_bytes_per_sample": roof["bytes_per_sample"],
-                  "avg_launch_us": fwd_s * 1e6, "timed_with": "HIP events, " + region}
-            if fan:
-                rl["timed_with"] += " (the timed region itself fans independent batches over %d streams: ms_per_step %.5f)" % (fan, elapsed * 1e3 / args.steps)
-            if lb > 1:
-                rl["kernel"] += " (one batch of %d rows per launch)" % B
-                rl["timed_with"] += "; ONE batch per launch -- the north-star's 'at batch 65 536' figure.  The timed region scores %d batches per launch, see roofline_timed_region" % lb
+            rl = {"bound": "hbm", "kernel": roof["kernel"] + " (one batch of %d rows per launch)" % B, "achieved": achieved,
+                  "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved * 1e9 / HBM_PEAK,
+                  "algorithmic_bytes_per_sample": roof["bytes_per_sample"], "avg_launch_us": fwd_s * 1e6,
+                  "timed_with": "HIP events, " + region}
+            if "reference_bytes_per_sample" in roof:
+                rl["reference_bytes_per_sample"] = roof["reference_bytes_per_sample"]
+            if "mfma" in roof:
+                extra["roofline_mfma"] = mfma_block(roof["kernel"], roof["mfma"], B, fwd_s)
         else:
-            # DIN step = k_din_pool + k_tile_forward; time the attention kernel alone for its MFMA fraction
+            # DIN step = k_din_attn + k_din_tail; time the attention kernel alone
             pooled = torch.empty((B, eng.n_aux), dtype=torch.float32, device="cuda")
-            torch.cuda.synchronize()
-            ev0.record()
-            for i in range(args.steps):
-                eng.din_pool(batches[i % NB][0], pooled)
-            ev1.record()
-            torch.cuda.synchronize()
-            din_s = ev0.elapsed_time(ev1) * 1e-3 / args.steps
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            n_att = max(K, 200)
+            tt = []
+            for _ in range(3):
+                torch.cuda.synchronize()
+                ev0.record()
+                for i in range(n_att):
+                    eng.din_pool(batches[i % NB][0], pooled)
+                ev1.record()
+                torch.cuda.synchronize()
+                tt.append(ev0.elapsed_time(ev1) * 1e-3 / n_att)
+            din_s = float(np.median(tt))
             if legacy_din:
                 # k_din_pool: the reference's K = 4D contraction on f32 MFMA
                 achieved = roof["flops_per_sample"] * B / din_s / 1e12
@@ -411,21 +678,26 @@ def main():
             else:
                 # k_din_attn: after the K = 4D -> D fold and the move to split-f16 MFMA the matrix pipe is a small
                 # share of the kernel; what bounds it is the history gather (+ the VALU work per gathered row),
-                # so it is priced against HBM bandwidth on SURVEY 8(d)'s algorithmic bytes
+                # so it is priced against HBM bandwidth on SURVEY 8(d)'s algorithmic bytes -- and, next to it,
+                # against the f16 MFMA peak on what it issues (roofline_mfma)
                 achieved = roof["bytes_per_sample"] * B / din_s / 1e9
                 rl = {"bound": "hbm", "kernel": roof["kernel"], "achieved": achieved, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                       "frac": achieved * 1e9 / HBM_PEAK,
-                      "matrix_flops_per_sample_issued": roof["executed_flops_per_sample"],
                       "reference_flops_per_sample": roof["flops_per_sample"],
                       "reference_equivalent_TFLOPs": roof["flops_per_sample"] * B / din_s / 1e12}
+                extra["roofline_mfma"] = mfma_block("k_din_attn", {"f32_flops_per_sample": 0.0,
+                                                                   "f16_flops_per_sample": 3 * roof["executed_flops_per_sample"],
+                                                                   "reference_flops_per_sample": roof["flops_per_sample"]}, B, din_s)
+                if env("SPRK_DIN_TAIL") != "0":
+                    extra["roofline_mfma_tail"] = mfma_block("k_din_tail", roof["tail_mfma"], B, max(fwd_s - din_s, 1e-9))
             rl.update({"algorithmic_bytes_per_sample": roof["bytes_per_sample"],
                        "avg_launch_us": din_s * 1e6, "step_us_all_kernels": fwd_s * 1e6,
-                       "timed_with": "HIP events, %s-only loop after the timed region" % roof["kernel"]})
+                       "timed_with": "HIP events, %s-only loop after the timed regions" % roof["kernel"]})
         # memory-side bytes per launch from the committed PMC passes (rocprofv3 --pmc runs are separate from the
         # timed run by design); only quoted for the batch size and kernel they were collected on
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
+        if os.path.exists(tpath) and not args.big_vocab:
             try:
                 t = json.load(open(tpath)).get(args.workload)
                 if t and t.get("batch") == B and t.get("kernel") == roof["kernel"]:
@@ -434,32 +706,51 @@ def main():
             except Exception:
                 traffic = None
         rl["traffic"] = traffic
+        table_mb = getattr(eng, "table_bytes", lambda: 0)() / 1e6
         line = {
             "metric": "ctr_samples_per_sec", "value": value, "unit": "samples/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed * 1e3 / args.steps,
+            "steps": K, "warmup": args.warmup, "ms_per_step": elapsed * 1e3 / n_region,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "value_one_batch_per_launch": B * world / fwd_s,
             "config": {"workload": "%s: %s" % (args.workload, desc), "batch_per_gpu": B, "global_batch": B * world,
                        "id_distribution": args.dist, "input_batches_cycled": NB,
+                       "repeats": R, "regions": len(walls), "region_ms": [round(w * 1e3, 3) for w in walls],
+                       "timed": "each region = %d back-to-back repetitions of the %d-step block (>= %.0f ms), barrier + synchronize on both "
+                                "sides, host clock, max over ranks; ms_per_step = median region / %d; value = the same region" % (R, K, args.min_region_ms, n_region),
+                       "ms_per_step_hip_events": ev_region * 1e3 / n_region,
                        "parallelism": ("rows sharded over %d GPU(s), tables replicated, all-gather of scores" % world)
-                                      + ("" if world == 1 else " (one collective per %d steps, overlapped; %d collectives in the timed region)"
-                                         % (gs.G, (args.steps + gs.G - 1) // gs.G)),
+                                      + ("" if world == 1 else " (one collective per %d steps, overlapped; %d collectives per region)"
+                                         % (gs.G, (n_region + gs.G - 1) // gs.G)),
                        "oracle_check_max_abs_err": check,
                        "launch_overlap_streams": fan, "batches_per_launch": lb,
+                       "tables": "%.0f MB of device tables: %s" % (table_mb, "beyond the 256 MB Infinity Cache (HBM-resident gather)" if table_mb > 512
+                                                                      else "resident in the 256 MB Infinity Cache -- `roofline` is a fabric/cache-side rate for this "
+                                                                           "config; see roofline_hbm_resident") if table_mb else None,
+                       "kernel": eng.kernel_name(),
                        "arithmetic": "fp32 semantics; contractions whose operands are bounded at finalize (table rows x weights) run on "
                                      "v_mfma_f32_16x16x32_f16 with split operands hi + lo (22 significand bits) and f32 accumulation -- "
                                      "fp32-class error, tests/test_gpu_parity.py::test_deepfm_v2_split_f16_is_fp32_class; everything else "
                                      "on f32 MFMA / VALU (SPRK_V2_HALF=0 / SPRK_DIN_HALF=0 force f32 MFMA throughout)"},
             "roofline": rl,
         }
-        if lb > 1 and not dist_on and roof["bound"] == "hbm":
+        line["value_one_batch_per_launch_note"] = ("B x n_gpus / the strict-order per-launch time of `roofline` (%.2f us): the north star's "
+                                                   "'at batch %d' figure; `value` scores %d batch(es) per launch" % (fwd_s * 1e6, B, lb))
+        if fan2_s is not None:
+            line["value_one_batch_per_launch_two_streams"] = B * world / fan2_s
+        if lb > 1 and roof["bound"] == "hbm":
             # the timed region's own launches: lb batches (own buffers, B rows each) per launch, strict stream order, so the
-            # HIP events around the region bracket exactly ceil(K / lb) back-to-back launches of the multi-batch instantiation
-            n_launch = (args.steps + lb - 1) // lb
-            ach = roof["bytes_per_sample"] * B * args.steps / (ev_ms_timed * 1e-3) / 1e9
+            # HIP events around the region bracket exactly ceil(R*K / lb) back-to-back launches of the multi-batch instantiation
+            n_launch = (n_region + lb - 1) // lb
+            ach = roof["bytes_per_sample"] * B * n_region / ev_region / 1e9
             line["roofline_timed_region"] = {
                 "bound": "hbm", "kernel": roof["kernel"] + " (multi-batch instantiation, %d batches of %d rows per launch)" % (lb, B),
                 "achieved": ach, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": ach * 1e9 / HBM_PEAK,
-                "launches": n_launch, "avg_launch_us": ev_ms_timed * 1e3 / n_launch, "timed_with": "HIP events around the timed region"}
+                "launches": n_launch, "avg_launch_us": ev_region * 1e6 / n_launch, "timed_with": "HIP events around the median timed region"
+                + (" (includes the grouped all-gathers' share)" if dist_on else "")}
+        line.update(extra)
+        hbm_rows = args.hbm_resident if args.hbm_resident >= 0 else 8388608
+        if world == 1 and not dist_on and args.workload == "deepfm_v2_c2" and not args.big_vocab and hbm_rows > 0 and roof["kernel"] == "k_deepfm_v2_joint":
+            line["roofline_hbm_resident"] = hbm_resident_block(args, B, hbm_rows, K)
         if world == 1 and args.cpu_seconds > 0:
             line["cpu_baseline"] = cpu_baseline(args.workload, model, feats, args.cpu_seconds)
         # RCCL prints a version banner through C stdio, which (stdout being a pipe) would otherwise be flushed at exit,
@@ -471,6 +762,107 @@ def main():
             pass
         sys.stdout.flush()
         print(json.dumps(line), flush=True)
+    if dist_on:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def mfma_block(kernel, m, B, seconds):
+    """north_star's "MFMA utilisation on the MLP against gfx950 peak": the MFMA FLOPs the kernel ISSUES (by operand type,
+    whole 16-sample tiles) / its duration / the matching dense peak; `frac` = share of the kernel's duration the matrix
+    pipe is busy if it ran at peak = f32 time + f16 time.  The PMC view (SQ_VALU_MFMA_BUSY_CYCLES) is in profiles/."""
+    f32, f16 = m.get("f32_flops_per_sample", 0.0) * B, m.get("f16_flops_per_sample", 0.0) * B
+    t_peak = f32 / MFMA_F32_PEAK + f16 / MFMA_F16_PEAK
+    return {"bound": "mfma", "kernel": kernel, "issued_f32_TFLOPs": f32 / seconds / 1e12, "peak_f32_TFLOPs": MFMA_F32_PEAK / 1e12,
+            "issued_f16_TFLOPs": f16 / seconds / 1e12, "peak_f16_TFLOPs": MFMA_F16_PEAK / 1e12,
+            "frac": t_peak / seconds, "kernel_us": seconds * 1e6,
+            "reference_flops_per_sample": m.get("reference_flops_per_sample"),
+            "reference_equivalent_TFLOPs": (m.get("reference_flops_per_sample") or 0.0) * B / seconds / 1e12,
+            "note": "frac = (issued f32 FLOPs / 157.3 TF + issued f16 FLOPs / 2.5 PF) / kernel time: the share of the kernel the matrix pipe "
+                    "would be busy at peak issue rate; the kernels are gather-latency bound, not MFMA bound"}
+
+
+def hbm_resident_block(args, B, rows, K):
+    """The headline graph with identity tables far beyond the 256 MB Infinity Cache (3 x `rows` x 128 B of folded rows):
+    every row gather is a real HBM access.  Strict order, one batch per launch, non-recycled ids (8 distinct batches)."""
+    import torch
+    model, feats, desc, roof = build_workload("deepfm_v2_c2", B, args.dist, seed_offset=7, big_vocab=rows, NB=8)
+    eng = model.engine
+    batches = []
+    for f in feats:
+        ids, dense = model.pack(f)
+        batches.append((torch.from_numpy(ids).cuda(), torch.from_numpy(dense).cuda()))
+    outs = [torch.empty(B, dtype=torch.float32, device="cuda") for _ in batches]
+    n = int(max(K, 1000))
+    strict_loop(eng, batches, outs, None, n, 1, 0)           # warm-up
+    s = strict_loop(eng, batches, outs, None, n, 1, 0)
+    ach = roof["bytes_per_sample"] * B / s / 1e9
+    eng.set_many_batches(16)
+    idx = [i % len(batches) for i in range(n)]
+    run = eng.prepare_many([batches[j][0] for j in idx], [batches[j][1] for j in idx], [outs[j] for j in idx], None)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    run()
+    torch.cuda.synchronize()
+    ev0.record(); run(); ev1.record()
+    torch.cuda.synchronize()
+    s16 = ev0.elapsed_time(ev1) * 1e-3 / n
+    check = None
+    if not args.no_check:
+        nchk = 2048
+        ref = oracle_forward("deepfm_v2_c2", model, {k: v[:nchk] for k, v in feats[0].items()})[:, 0]
+        eng.set_many_batches(1)
+        eng.forward(batches[0][0], batches[0][1], outs[0])
+        torch.cuda.synchronize()
+        check = float(np.abs(outs[0][:nchk].cpu().numpy() - ref).max())
+    table_mb = eng.table_bytes() / 1e6
+    eng.close()
+    return {"bound": "hbm", "kernel": "k_deepfm_v2_joint (one batch of %d rows per launch)" % B, "achieved": ach, "peak": HBM_PEAK / 1e9,
+            "unit": "GB/s", "frac": ach * 1e9 / HBM_PEAK, "algorithmic_bytes_per_sample": roof["bytes_per_sample"], "avg_launch_us": s * 1e6,
+            "frac_16_batches_per_launch": roof["bytes_per_sample"] * B / s16 / HBM_PEAK, "us_per_step_16_batches_per_launch": s16 * 1e6,
+            "identity_table_rows": rows, "device_table_mb": table_mb, "oracle_check_max_abs_err": check,
+            "timed_with": "HIP events, strict order, %d launches" % n}
+
+
+def dry_run(args, rank, world):
+    """Everything around the kernels -- rank start-up, process group (gloo), GroupedScoreGather's grouped all-gather, the
+    region timing with max-over-ranks -- with a stand-in forward on CPU tensors.  No throughput claim: the line says so."""
+    import torch
+    import torch.distributed as dist
+    from sparrowrecsys_amd.dist import GroupedScoreGather
+    dist_on = world > 1
+    if dist_on:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+    B, K = args.batch or 1024, args.steps
+    got = []
+    gs = GroupedScoreGather(B, max(1, args.gather_group), "cpu", sink=lambda gi, view, nb: got.append(float(view.sum()))) if dist_on else None
+    scratch = torch.empty(B)
+
+    def run_steps(first, count):
+        for i in range(first, first + count):
+            out = gs.out() if gs is not None else scratch
+            out.fill_(float(rank * 1000 + i % 7))
+            if gs is not None and gs.full():
+                gs.commit()
+
+    def fence():
+        if gs is not None:
+            gs.flush()
+        if dist_on:
+            dist.barrier()
+
+    timer = Timer(run_steps, fence, dist_on, False)
+    run_steps(0, args.warmup)
+    fence()
+    walls = [timer.region(K)[0] for _ in range(max(1, args.regions))]
+    elapsed = float(np.median(walls))
+    if rank == 0:
+        print(json.dumps({"metric": "ctr_samples_per_sec", "value": B * world * K / elapsed, "unit": "samples/s", "n_gpus": world,
+                          "steps": K, "warmup": args.warmup, "ms_per_step": elapsed * 1e3 / K, "higher_is_better": True,
+                          "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic", "dry_run": True,
+                          "config": {"workload": "DRY RUN (no GPU, stand-in forward): launcher / collective / timing plumbing only",
+                                     "batch_per_gpu": B, "global_batch": B * world, "collectives": gs.collectives if gs else 0,
+                                     "groups_seen_by_sink": len(got)}}), flush=True)
     if dist_on:
         dist.barrier()
         dist.destroy_process_group()

@@ -234,6 +234,15 @@ int sprk_din_pool(sprk_handle h, const int32_t* ids, float* pooled, float* att, 
  * SPRK_ERANGE if any forward since the last call saw an id >= its table size or < -1. */
 int sprk_check_ids(sprk_handle h, void* stream);
 
+/* Which kernels a finalized handle dispatches to (no reference counterpart; Keras would answer `model.summary()`).  Writes a
+ * NUL-terminated "key=value;..." line into buf: kernel = the fused kernel instantiation that scores a batch, or k_tile_forward
+ * when no fused kernel matched the plan and the generic plan interpreter runs it (fused=0: several times slower -- a shape that
+ * silently fell off the fast path is visible here); stage = the history stage of DIN / DIEN handles (k_din_attn, k_din_pool,
+ * k_dien_seq) or empty; uploaded_bytes / derived_bytes = device memory of the uploaded slots and of the tables derived from them
+ * at finalize (folded rows, split halfs, per-id terms); first_dense_fold = embedding columns folded into the first Dense layer.
+ * SPRK_EINVAL when the buffer is too small (256 bytes always suffice). */
+int sprk_describe(sprk_handle h, char* buf, size_t buf_bytes);
+
 /* Diagnostics (no reference counterpart): when `dev_buf` is non-NULL the fused DeepFM_v2 kernel
  * writes 16 uint64 per wave -- shader-clock (s_memtime) stamps [0] entry, [1] ids/numerics block
  * landed, [2] rows issued, [3] weight image copied, [4] workgroup barrier passed, [5] first rows

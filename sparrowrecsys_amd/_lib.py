@@ -34,6 +34,7 @@ EXPORTED_SYMBOLS = [
     "sprk_forward_deepfm", "sprk_forward_deepfm_v2", "sprk_forward_din", "sprk_forward_dien", "sprk_din_pool",
     "sprk_check_ids", "sprk_debug_set_trace", "sprk_destroy", "sprk_embedding_gather", "sprk_cross_hash", "sprk_last_error",
     "sprk_pack_csv", "sprk_pack_csv_mt", "sprk_set_many_streams", "sprk_set_many_batches", "sprk_emb_rank",
+    "sprk_describe",
 ]
 
 
@@ -145,6 +146,7 @@ def load_library():
         lib.sprk_destroy.restype = None
         lib.sprk_embedding_gather.argtypes = [vp, i32, i32, i32, vp, i32, vp, vp]
         lib.sprk_cross_hash.argtypes = [vp, vp, i32, C.c_int64, vp, vp]
+        lib.sprk_describe.argtypes = [vp, C.c_char_p, sz]
         lib.sprk_set_many_streams.argtypes = [vp, i32]
         lib.sprk_set_many_batches.argtypes = [vp, i32]
         lib.sprk_pack_csv.argtypes = [C.c_char_p, sz, C.POINTER(CsvCol), i32, C.POINTER(C.c_char_p), i32, i32, vp, vp,

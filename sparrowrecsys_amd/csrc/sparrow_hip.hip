@@ -703,6 +703,11 @@ struct sprk_engine {
     // ... with the small-vocabulary fields folded into one joint table (k_deepfm_v2_joint); -1 = not used
     int v2j_variant = -1;
     int many_batches = 1;                 // sprk_forward_many: batches scored per launch (sprk_set_many_batches)
+    int ncf_variant = -1;                 // register-chained NeuralCF (k_neuralcf_chain); -1 = the tile interpreter
+    int n_acc_folded = 0;                 // embedding columns folded into the first Dense layer (fold_first_dense)
+    size_t derived_bytes = 0;             // device memory of tables DERIVED at finalize (folded rows, split halfs, per-id terms)
+    int v2_xflags = 0;                    // SPRK_V2_XFLAGS experiment switches, read ONCE at finalize (never on the launch path)
+    bool v2_xflags_set = false;
     V2JRun v2j_run;
     float* v2j_tab = nullptr;      // small fields' LDS rows (device image)
     size_t v2j_lds_bytes = 0;
@@ -894,7 +899,7 @@ void v2j_launch_many(const V2JRun& a, const V2JMany& m, int B, int* err, const f
                        a, (const int*)nullptr, (const float*)nullptr, (float*)nullptr, B, err, image, m);
 }
 struct V2JVariant {
-    int g_big, njf;
+    int g_big, njf, kpc;
     bool half;                            // big fields on split-f16 MFMA
     const void* fn;
     const void* fn_many;
@@ -902,7 +907,7 @@ struct V2JVariant {
     V2JLaunchManyFn launch_many;
 };
 #define V2J_VARIANT(G_BIG, NJF, HALF) \
-    {G_BIG, NJF, HALF, reinterpret_cast<const void*>(&k_deepfm_v2_joint<G_BIG, NJF, 1, 2, 1, V2_WAVES, HALF, false>), \
+    {G_BIG, NJF, 1, HALF, reinterpret_cast<const void*>(&k_deepfm_v2_joint<G_BIG, NJF, 1, 2, 1, V2_WAVES, HALF, false>), \
      reinterpret_cast<const void*>(&k_deepfm_v2_joint<G_BIG, NJF, 1, 2, 1, V2_WAVES, HALF, true>), &v2j_launch<G_BIG, NJF, HALF>, \
      &v2j_launch_many<G_BIG, NJF, HALF>}
 #define V2J_BOTH(G_BIG, NJF) V2J_VARIANT(G_BIG, NJF, true), V2J_VARIANT(G_BIG, NJF, false)
@@ -1116,6 +1121,7 @@ int setup_v2_joint(sprk_engine* h) {
         for (int b = 0; b < nbig; ++b) big_rows += (size_t)r.big_vocab[b] + 1;
         if (big_rows * (KP + 16) * sizeof(float) >= ((size_t)1 << 32)) return fail(SPRK_EINVAL, "split rows exceed 32-bit offsets");
         HIP_TRY(hipMalloc((void**)&h->v2j_big, big_rows * (KP + 16) * sizeof(float)));
+        h->derived_bytes += big_rows * (KP + 16) * sizeof(float);
         size_t base = 0;
         for (int b = 0; b < nbig; ++b) {
             const long long rows = (long long)r.big_vocab[b] + 1;
@@ -1238,6 +1244,7 @@ int fold_first_dense(sprk_engine* h, DevPlan* dp) {
         DevSeg& sg = dp->segs[i];
         float* F = nullptr;
         HIP_TRY(hipMalloc((void**)&F, (size_t)sg.vocab * op.N * sizeof(float) + 16));
+        h->derived_bytes += (size_t)sg.vocab * op.N * sizeof(float);
         h->fold_bufs.push_back(F);
         long long blocks = ((long long)sg.vocab * op.N + 255) / 256;
         if (blocks > 65536) blocks = 65536;
@@ -1260,6 +1267,7 @@ int fold_first_dense(sprk_engine* h, DevPlan* dp) {
         for (const DevSeg& g : plain) dp->segs[k++] = g;
         for (const DevSeg& g : acc) dp->segs[k++] = g;
         dp->n_acc = (int)acc.size();
+        h->n_acc_folded = dp->n_acc;
     }
     op.W = wcopy + (lo - lo0);
     op.src_off = lo;
@@ -1878,6 +1886,7 @@ int sprk_finalize(sprk_handle h) {
                     HIP_TRY(hipMalloc((void**)&h->din_w12, (size_t)s.hidden * KP * sizeof(float)));
                     HIP_TRY(hipMalloc((void**)&h->din_w4, (size_t)s.hidden * KP * sizeof(float)));
                     HIP_TRY(hipMalloc((void**)&h->din_vc, vc_bytes));
+                    h->derived_bytes += vc_bytes;
                 }
                 hipLaunchKernelGGL(k_din_prep_w, dim3(8), dim3(256), 0, 0, d.W, s.hidden, s.row_stride, KP, 1.0f, h->din_w12, h->din_w4);
                 HIP_TRY(hipGetLastError());
@@ -1906,7 +1915,7 @@ int sprk_finalize(sprk_handle h) {
                     hipLaunchKernelGGL(k_din_prep_w, dim3(8), dim3(256), 0, 0, d.W, s.hidden, s.row_stride, KP, a_scale, h->din_w12, h->din_w4);
                     HIP_TRY(hipGetLastError());
                     if ((size_t)s.vocab * KP * sizeof(float) >= ((size_t)4 << 30)) { want_half = false; v = (size_t)-1; continue; }
-                    if (!h->din_tsplit) HIP_TRY(hipMalloc((void**)&h->din_tsplit, (size_t)s.vocab * KP * sizeof(float) + 16));
+                    if (!h->din_tsplit) { HIP_TRY(hipMalloc((void**)&h->din_tsplit, (size_t)s.vocab * KP * sizeof(float) + 16)); h->derived_bytes += (size_t)s.vocab * KP * sizeof(float); }
                     long long sb = ((long long)s.vocab * KP + 255) / 256;
                     if (sb > 65536) sb = 65536;
                     hipLaunchKernelGGL(k_din_split_table, dim3((unsigned)sb), dim3(256), 0, 0, d.table, (long long)s.vocab, s.row_stride, KP,
@@ -1966,6 +1975,7 @@ int sprk_finalize(sprk_handle h) {
                 size_t rows_total = 0;
                 for (int g = 0; g < vv.g_emb; ++g) { h->v2run.rowbase[g] = (unsigned)rows_total; rows_total += (size_t)h->v2run.vocab[g] + 1; }
                 HIP_TRY(hipMalloc((void**)&h->v2_folded, rows_total * (KP + 16) * sizeof(float)));
+                h->derived_bytes += rows_total * (KP + 16) * sizeof(float);
                 for (int g = 0; g < vv.g_emb; ++g) {
                     const long long rows = (long long)h->v2run.vocab[g] + 1;
                     long long blocks = (rows + 3) / 4;
@@ -2007,6 +2017,7 @@ int sprk_finalize(sprk_handle h) {
             h->many_streams = n < 2 ? 0 : (n > 4 ? 4 : n);
         }
     }
+    { const char* xf = getenv("SPRK_V2_XFLAGS"); if (xf) { h->v2_xflags = atoi(xf); h->v2_xflags_set = true; } }
     h->finalized = true;
     return SPRK_OK;
 }
@@ -2074,7 +2085,7 @@ int sprk_forward(sprk_handle h, const int32_t* ids, const float* dense, float* o
         if (grid > h->v2_grid_cap) grid = h->v2_grid_cap;
         V2Run run = h->v2run;
         run.flags = (((uintptr_t)ids | (uintptr_t)dense) & 15) ? 1 : 0;    // unaligned inputs: element-wise staging
-        { const char* xf = getenv("SPRK_V2_XFLAGS"); if (xf) run.flags |= atoi(xf); }   // experiment switches
+        run.flags |= h->v2_xflags;                                          // experiment switches (cached at finalize)
         const V2Variant& vv = kV2Variants[h->v2_variant];
         if (h->v2j_variant >= 0 && !run.trace && !(run.flags & ~1)) {
             V2JRun jr = h->v2j_run;
@@ -2140,7 +2151,7 @@ int sprk_forward_many(sprk_handle h, int32_t n_batches, const int32_t* const* id
     // several batches per launch (sprk_set_many_batches): the fused DeepFM_v2 kernel takes up to V2J_MB batches' buffers
     // and walks their tasks as one grid; everything else (other models, unaligned buffers, tracing) goes batch by batch
     if (h->finalized && h->many_batches > 1 && n_batches > 1 && h->v2_variant >= 0 && h->v2j_variant >= 0 && !h->v2run.trace &&
-        !getenv("SPRK_V2_XFLAGS") && B > 0 && ids && dense) {
+        !h->v2_xflags_set && B > 0 && ids && dense) {
         bool ok = true;
         for (int32_t i = 0; i < n_batches && ok; ++i)
             ok = ids[i] && dense[i] && out[i] && !(((uintptr_t)ids[i] | (uintptr_t)dense[i]) & 15);
@@ -2282,6 +2293,39 @@ int sprk_set_many_batches(sprk_handle h, int32_t n) {
     if (!h->finalized) return fail(SPRK_ESTATE, "set_many_batches before finalize");
     if (n < 1 || n > V2J_MB) return fail(SPRK_EINVAL, "batches per launch %d outside [1,%d]", n, V2J_MB);   // (DIN caps at DIN_MB)
     h->many_batches = n;
+    return SPRK_OK;
+}
+
+int sprk_describe(sprk_handle h, char* buf, size_t buf_bytes) {
+    if (!h || !buf || buf_bytes == 0) return fail(SPRK_EINVAL, "describe: NULL argument");
+    if (!h->finalized) return fail(SPRK_ESTATE, "describe before finalize");
+    char kern[160];
+    if (h->v2_variant >= 0 && h->v2j_variant >= 0) {
+        const V2JVariant& jv = kV2JVariants[h->v2j_variant];
+        snprintf(kern, sizeof(kern), "k_deepfm_v2_joint<G_BIG=%d,NJF=%d,KPC=%d,%s>", jv.g_big, jv.njf, jv.kpc, jv.half ? "split-f16" : "f32");
+    } else if (h->v2_variant >= 0) {
+        const V2Variant& vv = kV2Variants[h->v2_variant];
+        snprintf(kern, sizeof(kern), "k_deepfm_v2_chain<G=%d,KPC=%d,%s>", vv.g_emb, vv.kpc, vv.fold ? "folded" : "unfolded");
+    } else if (h->v1_variant >= 0) {
+        snprintf(kern, sizeof(kern), "k_deepfm_pairs<NF=%d,NV=%d>", kV1Variants[h->v1_variant].nf, kV1Variants[h->v1_variant].nv);
+    } else if (h->ncf_variant >= 0) {
+        snprintf(kern, sizeof(kern), "k_neuralcf_chain");
+    } else if (h->mlp_variant >= 0) {
+        snprintf(kern, sizeof(kern), "k_mlp_chain<8,8>");
+    } else if (h->din_tail_variant >= 0) {
+        const DinTailVariant& tv = kDinTailVariants[h->din_tail_variant];
+        snprintf(kern, sizeof(kern), "k_din_tail<%d,%d,%d>", tv.n0c, tv.n1c, tv.kpc);
+    } else {
+        snprintf(kern, sizeof(kern), "k_tile_forward");
+    }
+    const char* stage = "";
+    if (h->plan.din.enabled == 2) stage = "k_dien_seq";
+    else if (h->plan.din.enabled == 1) stage = h->din_variant >= 0 ? "k_din_attn" : "k_din_pool";
+    size_t uploaded = 0;
+    for (size_t b : h->slot_bytes) uploaded += b;
+    const int n = snprintf(buf, buf_bytes, "kernel=%s;stage=%s;fused=%d;uploaded_bytes=%zu;derived_bytes=%zu;first_dense_fold=%d", kern, stage,
+                           strcmp(kern, "k_tile_forward") != 0 ? 1 : 0, uploaded, h->derived_bytes, h->n_acc_folded);
+    if (n < 0 || (size_t)n >= buf_bytes) return fail(SPRK_EINVAL, "describe: buffer of %zu bytes is too small", buf_bytes);
     return SPRK_OK;
 }
 

@@ -149,6 +149,12 @@ class GroupedScoreGather:
         dst = self.gathered[slot].view(-1)
         if self.world == 1 and not self.force:
             dst.copy_(src)
+            if self.cuda:
+                # the slot is reused two groups later: without an event here out()/group_outs() would never drain it
+                # and the sink would only ever see the last two groups
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream())
+                self.done[slot] = ev
         elif self.comm_stream is not None:
             ready = torch.cuda.Event()
             ready.record(torch.cuda.current_stream())

@@ -74,24 +74,104 @@ class Engine:
         self.has_din = bool(plan.din.enabled)
         self.din_T = plan.din.T
 
+    def describe(self) -> Dict[str, str]:
+        """``sprk_describe``: which kernel instantiation scores a batch (``kernel``; ``k_tile_forward`` = the generic plan
+        interpreter, i.e. no fused kernel matched the plan), the history stage, device bytes of tables."""
+        buf = C.create_string_buffer(512)
+        L.check(self.lib.sprk_describe(self.handle, buf, len(buf)))
+        return dict(kv.split("=", 1) for kv in buf.value.decode().split(";") if "=" in kv)
+
+    def kernel_name(self) -> str:
+        """Name (without template arguments) of the kernel that scores a batch."""
+        return self.describe()["kernel"].split("<")[0]
+
+    def table_bytes(self) -> int:
+        d = self.describe()
+        return int(d["uploaded_bytes"]) + int(d["derived_bytes"])
+
     def workspace_bytes(self, B: int) -> int:
         return int(self.lib.sprk_workspace_bytes(self.handle, B))
+
+    # ---- argument validation: the C ABI takes raw device pointers, so everything it cannot see is checked here ----
+    def _check_tensor(self, t, what, dtype, shape_tail, B=None):
+        import torch
+        if not isinstance(t, torch.Tensor):
+            raise ValueError("%s must be a torch tensor, got %s" % (what, type(t).__name__))
+        if not t.is_cuda:
+            raise ValueError("%s must live on a HIP device (got %s)" % (what, t.device))
+        if t.dtype != dtype:
+            raise ValueError("%s must be %s, got %s" % (what, dtype, t.dtype))
+        if not t.is_contiguous():
+            raise ValueError("%s must be contiguous (row-major); call .contiguous()" % what)
+        if t.dim() != 1 + len(shape_tail) or tuple(t.shape[1:]) != tuple(shape_tail):
+            raise ValueError("%s must have shape [B%s], got %s" % (what, "".join(", %d" % d for d in shape_tail), tuple(t.shape)))
+        if B is not None and int(t.shape[0]) != B:
+            raise ValueError("%s has %d rows, expected %d (rows of `out`)" % (what, int(t.shape[0]), B))
+
+    def _check_batch(self, ids, dense, out, what=""):
+        """dtype / device / contiguity / shape of one batch's tensors; returns B.  A torch.long ids tensor, a column
+        slice or a short ids tensor would otherwise be read as garbage (or out of bounds) by the kernels."""
+        import torch
+        self._check_tensor(out, what + "out", torch.float32, ())
+        B = int(out.shape[0])
+        if self.n_id_cols > 0:
+            if ids is None:
+                raise ValueError(what + "ids is required (model has %d ids columns)" % self.n_id_cols)
+            self._check_tensor(ids, what + "ids", torch.int32, (self.n_id_cols,), B)
+            if ids.device != out.device:
+                raise ValueError(what + "ids and out live on different devices")
+        if self.n_dense > 0:
+            if dense is None:
+                raise ValueError(what + "dense is required (model has %d numeric columns)" % self.n_dense)
+            self._check_tensor(dense, what + "dense", torch.float32, (self.n_dense,), B)
+            if dense.device != out.device:
+                raise ValueError(what + "dense and out live on different devices")
+        return B
+
+    def _check_workspace(self, workspace, B, slices=1):
+        if not self.has_din:
+            return None, 0
+        import torch
+        need = self.workspace_bytes(B)
+        if workspace is None or not isinstance(workspace, torch.Tensor) or not workspace.is_cuda or not workspace.is_contiguous() \
+                or workspace.numel() * workspace.element_size() < need:
+            raise ValueError("DIN forward needs a contiguous %d-byte device workspace tensor" % need)
+        return workspace.data_ptr(), workspace.numel() * workspace.element_size()
+
+    def _check_many(self, ids_list, dense_list, out_list, what):
+        n = len(out_list)
+        if self.n_id_cols > 0 and (ids_list is None or len(ids_list) != n):
+            raise ValueError("%s: ids_list must hold one tensor per batch (%d)" % (what, n))
+        if self.n_dense > 0 and (dense_list is None or len(dense_list) != n):
+            raise ValueError("%s: dense_list must hold one tensor per batch (%d)" % (what, n))
+        B = None
+        for i in range(n):
+            b = self._check_batch(ids_list[i] if self.n_id_cols > 0 else None, dense_list[i] if self.n_dense > 0 else None,
+                                  out_list[i], "%s: batch %d: " % (what, i))
+            if B is None:
+                B = b
+            elif b != B:
+                raise ValueError("%s: every batch must have the same number of rows" % what)
+        return B
 
     def forward(self, ids, dense, out, workspace=None, stream: Optional[int] = None):
         """ids/dense/out/workspace: torch CUDA tensors (int32 [B,F], float32 [B,N], float32 [B])."""
         import torch
-        B = int(out.shape[0])
+        B = self._check_batch(ids, dense, out)
         if stream is None:
             stream = torch.cuda.current_stream().cuda_stream
-        ws_ptr, ws_bytes = None, 0
-        if self.has_din:
-            need = self.workspace_bytes(B)
-            if workspace is None or workspace.numel() * workspace.element_size() < need:
-                raise ValueError("DIN forward needs a %d-byte workspace tensor" % need)
-            ws_ptr, ws_bytes = workspace.data_ptr(), workspace.numel() * workspace.element_size()
+        ws_ptr, ws_bytes = self._check_workspace(workspace, B)
         L.check(self._forward(self.handle, C.c_void_p(ids.data_ptr() if ids is not None else None),
                               C.c_void_p(dense.data_ptr() if dense is not None else None),
                               C.c_void_p(out.data_ptr()), B, C.c_void_p(ws_ptr), ws_bytes, C.c_void_p(stream)))
+
+    def _many_arrays(self, ids_list, dense_list, out_list):
+        n = len(out_list)
+        arr = C.c_void_p * n
+        ids_a = arr(*[t.data_ptr() for t in ids_list]) if (ids_list is not None and self.n_id_cols > 0) else None
+        dense_a = arr(*[t.data_ptr() for t in dense_list]) if (dense_list is not None and self.n_dense > 0) else None
+        out_a = arr(*[t.data_ptr() for t in out_list])
+        return ids_a, dense_a, out_a
 
     def forward_many(self, ids_list, dense_list, out_list, workspace=None, stream: Optional[int] = None):
         """``predict`` over a sequence of device-resident batches with ONE foreign call
@@ -100,44 +180,26 @@ class Engine:
         n = len(out_list)
         if n == 0:
             return
-        B = int(out_list[0].shape[0])
-        if any(int(o.shape[0]) != B for o in out_list):
-            raise ValueError("forward_many: every batch must have the same number of rows")
+        B = self._check_many(ids_list, dense_list, out_list, "forward_many")
         if stream is None:
             stream = torch.cuda.current_stream().cuda_stream
-        ws_ptr, ws_bytes = None, 0
-        if self.has_din:
-            need = self.workspace_bytes(B)
-            if workspace is None or workspace.numel() * workspace.element_size() < need:
-                raise ValueError("DIN forward needs a %d-byte workspace tensor" % need)
-            ws_ptr, ws_bytes = workspace.data_ptr(), workspace.numel() * workspace.element_size()
-        arr = C.c_void_p * n
-        ids_a = arr(*[t.data_ptr() for t in ids_list]) if ids_list is not None else None
-        dense_a = arr(*[t.data_ptr() for t in dense_list]) if dense_list is not None else None
-        out_a = arr(*[t.data_ptr() for t in out_list])
+        ws_ptr, ws_bytes = self._check_workspace(workspace, B)
+        ids_a, dense_a, out_a = self._many_arrays(ids_list, dense_list, out_list)
         L.check(self.lib.sprk_forward_many(self.handle, n, ids_a, dense_a, out_a, B, C.c_void_p(ws_ptr), ws_bytes,
                                            C.c_void_p(stream)))
 
     def prepare_many(self, ids_list, dense_list, out_list, workspace=None):
-        """The argument marshalling of ``forward_many`` done once: returns ``run(stream=None)`` that enqueues the same
-        sequence of batches again (the tensors must stay alive and in place).  For loops that replay a fixed set of
-        device buffers -- e.g. one gather group of a multi-GPU predict loop -- the per-call host cost drops to one
-        foreign call."""
+        """The argument marshalling (and validation) of ``forward_many`` done once: returns ``run(stream=None)`` that
+        enqueues the same sequence of batches again (the tensors must stay alive and in place).  For loops that replay a
+        fixed set of device buffers -- e.g. one gather group of a multi-GPU predict loop -- the per-call host cost drops
+        to one foreign call."""
         import torch
         n = len(out_list)
-        B = int(out_list[0].shape[0])
-        if any(int(o.shape[0]) != B for o in out_list):
-            raise ValueError("prepare_many: every batch must have the same number of rows")
-        ws_ptr, ws_bytes = None, 0
-        if self.has_din:
-            need = self.workspace_bytes(B)
-            if workspace is None or workspace.numel() * workspace.element_size() < need:
-                raise ValueError("DIN forward needs a %d-byte workspace tensor" % need)
-            ws_ptr, ws_bytes = workspace.data_ptr(), workspace.numel() * workspace.element_size()
-        arr = C.c_void_p * n
-        ids_a = arr(*[t.data_ptr() for t in ids_list]) if ids_list is not None else None
-        dense_a = arr(*[t.data_ptr() for t in dense_list]) if dense_list is not None else None
-        out_a = arr(*[t.data_ptr() for t in out_list])
+        if n == 0:
+            raise ValueError("prepare_many: no batches")
+        B = self._check_many(ids_list, dense_list, out_list, "prepare_many")
+        ws_ptr, ws_bytes = self._check_workspace(workspace, B)
+        ids_a, dense_a, out_a = self._many_arrays(ids_list, dense_list, out_list)
         keep = (list(ids_list or ()), list(dense_list or ()), list(out_list), workspace)
         fn, handle, ws_p = self.lib.sprk_forward_many, self.handle, C.c_void_p(ws_ptr)
 
@@ -165,6 +227,13 @@ class Engine:
 
     def din_pool(self, ids, pooled, att=None, stream: Optional[int] = None):
         import torch
+        if not self.has_din:
+            raise ValueError("din_pool: the model has no DIN / DIEN stage")
+        B = int(ids.shape[0]) if hasattr(ids, "shape") and len(ids.shape) else -1
+        self._check_tensor(ids, "ids", torch.int32, (self.n_id_cols,))
+        self._check_tensor(pooled, "pooled", torch.float32, (self.n_aux,), B)
+        if att is not None:
+            self._check_tensor(att, "att", torch.float32, (self.din_T,), B)
         if stream is None:
             stream = torch.cuda.current_stream().cuda_stream
         L.check(self.lib.sprk_din_pool(self.handle, C.c_void_p(ids.data_ptr()), C.c_void_p(pooled.data_ptr()),
@@ -302,18 +371,20 @@ class CTRModel:
         import torch
         eng = self.engine
         outs = []
+        # batches are enqueued back to back (host packing of batch n+1 overlaps the forward of batch n); ONE id check
+        # (= one stream synchronisation) and ONE device -> host copy at the end instead of one per batch
         for feats in iter_feature_batches(x, batch_size):
             ids, dense = self.pack(feats)
             if ids.shape[0] == 0:
                 continue
-            ids_t = torch.from_numpy(ids).cuda()
-            dense_t = torch.from_numpy(dense).cuda()
-            out = self.predict_device(ids_t, dense_t)
-            eng.check_ids()
-            outs.append(out.cpu().numpy())
+            ids_t = torch.from_numpy(ids).cuda(non_blocking=True)
+            dense_t = torch.from_numpy(dense).cuda(non_blocking=True)
+            outs.append(self.predict_device(ids_t, dense_t))
         if not outs:
             return np.zeros((0, 1), dtype=np.float32)
-        return np.concatenate(outs).reshape(-1, 1)
+        eng.check_ids()
+        scores = outs[0] if len(outs) == 1 else torch.cat(outs)
+        return scores.cpu().numpy().reshape(-1, 1)
 
     __call__ = predict
 

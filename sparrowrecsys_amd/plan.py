@@ -30,10 +30,17 @@ def pad16(n: int) -> int:
     return (n + 15) & ~15
 
 
-def pad_table(table: np.ndarray) -> np.ndarray:
+def pad_table(table):
     """[V, D] -> device layout [V+1, Dp]: rows padded to whole 16-byte lanes, plus ONE all-zero row at
     index V.  The fused kernels point a missing / out-of-vocabulary id at that row, so "no id ->
-    zero vector" (safe_embedding_lookup_sparse) costs no select; valid rows are copied bit-exactly."""
+    zero vector" (safe_embedding_lookup_sparse) costs no select; valid rows are copied bit-exactly.
+    A torch CUDA tensor (tables too large to build on the host, e.g. BASELINE config 4's 27 M x 64) is padded on its device."""
+    if hasattr(table, "data_ptr"):
+        import torch
+        V, D = table.shape
+        out = torch.zeros((V + 1, pad4(D)), dtype=torch.float32, device=table.device)
+        out[:V, :D] = table
+        return out
     table = np.ascontiguousarray(table, dtype=np.float32)
     V, D = table.shape
     Dp = pad4(D)

@@ -1,0 +1,129 @@
+"""Host-side API of the HIP engine on a real device (``-m gpu``): argument validation in front of the raw-pointer C ABI
+(a torch.long ids tensor or a column slice used to be read as garbage), the dispatch report
+(``sprk_describe``: a plan that fell off the fused kernels must be visible), ``predict`` pipelining, and the single-rank
+grouped score ring."""
+import numpy as np
+import pytest
+
+from oracle import ctr_oracle as O
+from sparrowrecsys_amd import models as M
+from sparrowrecsys_amd import synthetic as SY
+from tests.golden.make_golden import make_model
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch():
+    import torch as t
+    assert t.cuda.is_available(), "gpu tests need a HIP device"
+    return t
+
+
+def test_forward_rejects_malformed_tensors(torch):
+    model = M.DeepFMv2(seed=3, emb_dim=16, fields=SY.CONFIG2_FIELDS, proj_dim=16)
+    eng = model.engine
+    B = 128
+    ids, dense = model.pack(SY.synth_fields(B, SY.CONFIG2_FIELDS, seed=5))
+    ids_t, dense_t = torch.from_numpy(ids).cuda(), torch.from_numpy(dense).cuda()
+    out = torch.empty(B, dtype=torch.float32, device="cuda")
+    eng.forward(ids_t, dense_t, out)                                     # the well-formed call
+    torch.cuda.synchronize()
+    good = out.clone()
+    bad_calls = {
+        "int32": (ids_t.long(), dense_t, out),                           # torch's default integer dtype
+        "float32": (ids_t, dense_t.double(), out),
+        "contiguous": (torch.cat([ids_t, ids_t], 1)[:, :ids_t.shape[1]], dense_t, out),   # a column slice: strided view
+        "rows": (ids_t[:B - 1], dense_t, out),                           # short ids
+        "shape": (ids_t[:, :3].contiguous(), dense_t, out),              # too few ids columns
+        "HIP device": (ids_t.cpu(), dense_t, out),
+        "must have shape": (ids_t, dense_t, out.view(B, 1)),
+    }
+    for what, (a, b, c) in bad_calls.items():
+        with pytest.raises(ValueError, match=what):
+            eng.forward(a, b, c)
+    with pytest.raises(ValueError, match="batch 1"):
+        eng.forward_many([ids_t, ids_t.long()], [dense_t, dense_t], [out, out.clone()])
+    with pytest.raises(ValueError, match="one tensor per batch"):
+        eng.forward_many([ids_t], [dense_t, dense_t], [out, out.clone()])
+    with pytest.raises(ValueError, match="same number of rows"):
+        eng.forward_many([ids_t, ids_t[:64].contiguous()], [dense_t, dense_t[:64].contiguous()], [out, out[:64].clone()])
+    eng.forward(ids_t, dense_t, out)
+    torch.cuda.synchronize()
+    assert torch.equal(out, good)                                        # nothing the rejected calls did changed the engine
+
+
+def test_din_workspace_is_validated(torch):
+    din = M.DIN(seed=4, emb_dim=32, hist_len=50, movie_buckets=5000, user_buckets=7000)
+    eng = din.engine
+    B = 64
+    ids, dense = din.pack(SY.synth_din(B, 50, 5000, 7000, seed=3))
+    ids_t, dense_t = torch.from_numpy(ids).cuda(), torch.from_numpy(dense).cuda()
+    out = torch.empty(B, dtype=torch.float32, device="cuda")
+    with pytest.raises(ValueError, match="workspace"):
+        eng.forward(ids_t, dense_t, out, None)
+    with pytest.raises(ValueError, match="workspace"):
+        eng.forward(ids_t, dense_t, out, torch.empty(8, device="cuda"))
+    pooled = torch.empty((B, eng.n_aux), dtype=torch.float32, device="cuda")
+    with pytest.raises(ValueError, match="pooled"):
+        eng.din_pool(ids_t, pooled[:, :4])
+    with pytest.raises(ValueError, match="int32"):
+        eng.din_pool(ids_t.long(), pooled)
+
+
+@pytest.mark.parametrize("name,kernel,stage", [
+    ("deepfm_v2_c2", "k_deepfm_v2_joint", ""), ("deepfm_c2", "k_deepfm_pairs", ""), ("din_c3", "k_din_tail", "k_din_attn"),
+    ("embedding_mlp", "k_mlp_chain", ""), ("dien", "k_din_tail", "k_dien_seq")])
+def test_describe_reports_the_dispatched_kernels(torch, name, kernel, stage):
+    if name == "deepfm_v2_c2":
+        model = M.DeepFMv2(seed=1, emb_dim=16, fields=SY.CONFIG2_FIELDS, proj_dim=16)
+    elif name == "deepfm_c2":
+        model = M.DeepFM(seed=1, emb_dim=16, fields=SY.CONFIG2_FIELDS, pairs=SY.CONFIG2_PAIRS)
+    elif name == "din_c3":
+        model = M.DIN(seed=1, emb_dim=32, hist_len=50, movie_buckets=5000, user_buckets=7000)
+    elif name == "dien":
+        model = M.DIEN(seed=1)
+    else:
+        model = make_model(name)
+    d = model.engine.describe()
+    assert d["kernel"].split("<")[0] == kernel and d["stage"] == stage and d["fused"] == "1"
+    assert int(d["uploaded_bytes"]) > 0
+    assert model.engine.kernel_name() == kernel
+
+
+def test_describe_shows_an_interpreter_fallback(torch, monkeypatch):
+    monkeypatch.setenv("SPRK_FORCE_INTERPRETER", "1")
+    model = M.DeepFMv2(seed=1, emb_dim=16, fields=SY.CONFIG2_FIELDS, proj_dim=16)
+    d = model.engine.describe()
+    assert d["kernel"] == "k_tile_forward" and d["fused"] == "0"
+
+
+def test_predict_over_many_batches_checks_ids_once_and_keeps_row_order(torch, samples):
+    model = make_model("deepfm_v2")
+    full = model.predict(samples)
+    np.testing.assert_array_equal(model.predict(samples, batch_size=7), full)
+    bad = dict(samples)
+    bad["movieId"] = samples["movieId"].copy()
+    bad["movieId"][200] = "1001"                                          # out of range in the 29th batch of 7
+    with pytest.raises(ValueError):
+        model.predict(bad, batch_size=7)
+    np.testing.assert_array_equal(model.predict(samples, batch_size=7), full)   # the error flag was cleared
+
+
+def test_grouped_score_ring_single_rank_delivers_every_group(torch):
+    """with world == 1 on CUDA the ring never recorded a completion event, so the sink only ever saw the last
+    two groups."""
+    from sparrowrecsys_amd.dist import GroupedScoreGather
+    B, G, steps = 32, 3, 11
+    got = []
+    gs = GroupedScoreGather(B, G, torch.device("cuda", 0), sink=lambda gi, view, nb: got.append((gi, nb, view.clone().cpu())))
+    for i in range(steps):
+        gs.out().fill_(float(i))
+        if gs.full():
+            gs.commit()
+    gs.flush()
+    assert [(gi, nb) for gi, nb, _ in got] == [(0, 3), (1, 3), (2, 3), (3, 2)]
+    for gi, nb, v in got:
+        assert v.shape == (1, nb, B)
+        for j in range(nb):
+            assert float(v[0, j, 0]) == float(3 * gi + j) and float(v[0, j, -1]) == float(3 * gi + j)
