@@ -533,13 +533,12 @@ def main():
         if count <= 0:
             return
         if gs is None:
-            key = (first % NB, count)
-            if key not in prepared:                # the marshalled pointer arrays of a (phase, length) pair are reused
-                idx = [i % NB for i in range(first, first + count)]
-                if len(prepared) > 8:
-                    prepared.clear()
-                prepared[key] = eng.prepare_many([batches[j][0] for j in idx], [batches[j][1] for j in idx], [outs[j] for j in idx], ws)
-            prepared[key]()
+            # the marshalled (and validated) pointer arrays of a `count`-step run are built once, OUTSIDE any timed region
+            # (prime() below), and replayed: a run always starts at input batch 0
+            if count not in prepared:
+                idx = [i % NB for i in range(count)]
+                prepared[count] = eng.prepare_many([batches[j][0] for j in idx], [batches[j][1] for j in idx], [outs[j] for j in idx], ws)
+            prepared[count]()
             return
         i = first
         while i < first + count:
@@ -588,13 +587,15 @@ def main():
             break
         timer.region(K)
     eng.check_ids()
-    # ---- calibration: one K-step block -> R ----
+    # ---- calibration: one K-step block -> R (second pass: the first builds the block's prepared launch list) ----
+    timer.region(K)
     _, blk = timer.region(K)
     if dist_on:
         t = torch.tensor([blk], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         blk = float(t.item())
     R = int(max(1, min(math.ceil(args.min_region_ms * 1e-3 / max(blk, 1e-9)), max(1, 2_000_000 // max(K, 1)))))
+    timer.region(R * K)                        # untimed: builds the region's prepared launch list, one more warm-up pass
     # ---- timed regions ----
     walls, evs = [], []
     for _ in range(max(1, args.regions)):

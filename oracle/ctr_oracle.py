@@ -13,15 +13,25 @@ TensorFlow is not installable here, so every ``tf.*`` call is restated from its
 published semantics (SURVEY.md §8(c) checklist).
 
 PARITY PIN STATUS: the reference has no tests and no golden vectors
-("parity unpinned" by the reference itself).  What pins this oracle instead
-(tests/test_oracle_pins.py): the trained checkpoints the reference ships under
+("parity unpinned" by the reference itself).  What pins this oracle instead:
+(1) tests/test_savedmodel_pins.py -- the seven SavedModels the reference EXPORTED
+(``webroot/modeldata/{neuralcf/001,002, MLPRec/001..005}/saved_model.pb``) are
+executed op by op by oracle/tf_graph_exec.py (a numpy interpreter of their
+GraphDefs) on rows of the reference's testSamples.csv, and this oracle must agree
+to 1e-6: that pins categorical_column_with_identity + embedding_column (the
+SparseFillEmptyRows / SparseSegmentMean chain), categorical_column_with_vocabulary_list
++ indicator_column (genre index = list position, OOV -> zero row), numeric_column,
+DenseFeatures' name-sorted concat, Dense, concatenate and Dot to the wiring
+TensorFlow itself generated for the reference; outputs are committed as
+tests/golden/savedmodel_exec.npz.  (2) tests/test_oracle_pins.py: the trained checkpoints the reference ships under
 ``webroot/modeldata`` evaluated on its ``testSamples.csv`` reproduce sane
 known answers (NeuralCF/001 ROC-AUC 0.7514, NeuralCF/002 0.7321, MLPRec/004
 0.7353 only with name-sorted DenseFeatures order, two-tower MLPRec/005 0.7320)
 -- these pin table/kernel layouts, concat orders and the DenseFeatures column
-sort.  DIN/DeepFM/Wide&Deep have no trained checkpoint in the reference; for
-them and for the FingerprintCat64 cross hash parity remains "unpinned" beyond
-the restated semantics.
+sort.  STILL UNPINNED (no exported graph, no checkpoint, no vector in the
+reference): DIN's attention unit / PReLU shapes / pooling, DeepFM(_v2)'s FM wiring,
+Wide&Deep's FingerprintCat64 cross hash, DIEN -- restated semantics only (their
+feature-column inputs are the pinned ones above).
 
 Every function cites the reference file:line it follows.  ``dtype`` selects the
 arithmetic type: float32 reproduces the reference's fp32 CPU forward, float64 is
@@ -219,6 +229,25 @@ def _numeric_blocks(features, dtype, keys=NUMERIC_KEYS):
     return {k: numeric(features, k, dtype) for k in keys}
 
 
+def indicator(ids: np.ndarray, depth: int, dtype) -> np.ndarray:
+    """indicator_column(categorical) (DeepFM.py:56,61,71,76): multi-hot float [B, depth] -- with one id per
+    row a one-hot; "no id" (-1: out-of-vocabulary / empty string) -> an all-zero row.  The op chain the
+    reference's exported graphs hold for it (modeldata/MLPRec/{001,003}/saved_model.pb, executed by
+    oracle/tf_graph_exec.py): SparseToDense(default -1) -> OneHot(depth, 1.0, 0.0) -> Sum(axis=-2)."""
+    out = np.zeros((ids.shape[0], depth), dtype=dtype)
+    ok = (ids >= 0) & (ids < depth)
+    out[np.nonzero(ok)[0], ids[ok]] = 1
+    return out
+
+
+def int_vocab_ids(values, vocab_size: int) -> np.ndarray:
+    """categorical_column_with_vocabulary_list(key, list(range(vocab_size))) over an INTEGER feature (the movieId /
+    userRatedMovieN columns of the exported MLPRec/{001,003} graphs): index = the value itself when it is in the
+    list, else -1 (default_value); the "missing" marker to_sparse_input drops for integers is -1."""
+    v = np.asarray(values).astype(np.int64)
+    return np.where((v < 0) | (v >= vocab_size), -1, v)
+
+
 # --------------------------------------------------------------------------------------
 # models
 # --------------------------------------------------------------------------------------
@@ -243,6 +272,28 @@ def _embedding_mlp_body(features, w, dtype, movie_buckets, user_buckets):
     x = relu(dense(x, w["dense0/kernel"], w["dense0/bias"], dtype))      # EmbeddingMLP.py:74
     x = relu(dense(x, w["dense1/kernel"], w["dense1/bias"], dtype))      # EmbeddingMLP.py:75
     return x
+
+
+def feature_column_mlp_forward(features: Dict, w: Dict[str, np.ndarray], dtype=np.float32,
+                               numeric_keys: Sequence[str] = (), genre_keys: Sequence[str] = (),
+                               int_vocab_keys: Sequence[str] = (), int_vocab_size: int = MOVIE_BUCKETS) -> np.ndarray:
+    """Sequential([DenseFeatures(numeric columns + INDICATOR columns), Dense(128, relu), Dense(128, relu),
+    Dense(1, sigmoid)]): EmbeddingMLP.py:72-77 with indicator_column(categorical_column_with_vocabulary_list(...))
+    where the script now has embedding columns -- the graph of the reference's exported modeldata/MLPRec/{001..004}
+    SavedModels (001: 8 genre + 6 integer-vocabulary indicator columns; 003: the same + 8 numeric columns; 002 / 004:
+    numeric columns only).  Exists so that the feature-column restatements above (vocab_ids, indicator, numeric,
+    dense_features) can be checked against those graphs executed op by op (tests/test_savedmodel_pins.py)."""
+    blocks = _numeric_blocks(features, dtype, numeric_keys)
+    for k in genre_keys:
+        blocks[k + "_indicator"] = indicator(vocab_ids(features[k]), len(GENRE_VOCAB), dtype)
+    for k in int_vocab_keys:
+        blocks[k + "_indicator"] = indicator(int_vocab_ids(int_feature(features, k), int_vocab_size), int_vocab_size, dtype)
+    x, _ = dense_features(blocks)
+    i = 0
+    while "dense%d/kernel" % i in w:
+        x = relu(dense(x, w["dense%d/kernel" % i], w["dense%d/bias" % i], dtype))
+        i += 1
+    return sigmoid(dense(x, w["head/kernel"], w["head/bias"], dtype)).astype(np.float32)
 
 
 def wide_n_deep_forward(features: Dict, w: Dict[str, np.ndarray], dtype=np.float32,

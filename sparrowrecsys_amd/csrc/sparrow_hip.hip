@@ -928,12 +928,14 @@ bool match_v2_chain(sprk_engine* h) {
     if (g_emb < 1 || g_emb > V2_MAX_FIELDS) return false;
     if (p.n_id_cols > 8 || p.n_dense > 8 || p.n_dense < 1) return false;   // one 16-B/lane load stages a task's ids+numerics
     const int Dp = p.segs[0].row_stride;
+    bool raw_over_4g = false;                 // a raw table beyond 32-bit byte offsets: fine when folded (the kernel never reads it)
     for (int g = 0; g < g_emb; ++g) {
         const sprk_seg& s = p.segs[g];
         if (s.row_stride != Dp || s.count * 4 != Dp || s.dst != g * Dp) return false;
-        // the fused kernel needs the all-zero row at index vocab and 32-bit element offsets
+        // the fused kernel needs the all-zero row at index vocab and (unfolded) 32-bit element offsets
         const size_t need = ((size_t)s.vocab + 1) * Dp * sizeof(float);
-        if (h->slot_bytes[s.slot] < need || need >= ((size_t)1 << 32)) return false;
+        if (h->slot_bytes[s.slot] < need) return false;
+        if (need >= ((size_t)1 << 32)) raw_over_4g = true;
         a.emb_col[g] = s.field; a.emb_vocab[g] = s.vocab; a.table[g] = (const float*)h->slot_ptr[s.slot];
     }
     int si = g_emb;
@@ -996,6 +998,7 @@ bool match_v2_chain(sprk_engine* h) {
     const bool want_fold = Kp <= Dp && Kp + 16 <= 64 && total_rows * (size_t)(Kp + 16) * 4 < ((size_t)1 << 32) &&
                            !(fmode && fmode[0] == '0');
     const bool want_reg = want_fold;                         // folded tables <=> register-resident scoring stage
+    if (raw_over_4g && !want_fold) return false;             // e.g. BASELINE config 4's 27 M x 64 table (6.9 GB): folded rows only
     // the fused kernel reads ONE id per field for both the embedding row and the first-order
     // weight: the two field lists must be the same set of ids columns
     if (n_fo != g_emb) return false;
