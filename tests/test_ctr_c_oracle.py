@@ -55,7 +55,9 @@ def test_bench_cpu_baseline_legs_run_without_a_gpu():
     assert "oracle/ctr_c.c" in r["sample"] and r["numpy_oracle_samples_per_sec"] > 0
     r2 = bench.cpu_baseline_numpy("deepfm_v2_c2", model, feats, 0.2)
     assert r2["kind"] == "port" and "numpy oracle" in r2["sample"]
-    assert bench.cpu_baseline_c("widedeep_c5", model, feats, 0.1) is None   # no C restatement: the numpy leg is used
+    note = []
+    assert bench.cpu_baseline_c("widedeep_c5", model, feats, 0.1, note) is None and note   # no C restatement: the numpy leg is used, and says why
+    assert r["ran"] == "oracle/ctr_c.c"
     din = M.DIN(seed=103, emb_dim=32, hist_len=50, movie_buckets=SY.ML20M_MOVIE_IDS, user_buckets=SY.ML20M_USER_IDS)
     fd = [SY.synth_din(1024, 50, SY.ML20M_MOVIE_IDS, SY.ML20M_USER_IDS, seed=4)]
     r3 = bench.cpu_baseline("din_c3", din, fd, 0.4)
