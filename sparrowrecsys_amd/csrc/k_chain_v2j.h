@@ -160,12 +160,10 @@ struct V2JSet {
 // score(A), gather(A'), score(B), gather(B') with ids fetched two tasks ahead, i.e. one gather is
 // always in flight under a scoring stage.  Loads are unconditional (task indices are clamped, the tail
 // re-gathers a valid task and drops the result) so that the in-order vmcnt waits stay exact.
-template <int G_BIG, int NJF, int KPC, int H0C, int H1C, int WAVES, bool HALF, bool MB = false>
-__global__ __launch_bounds__(WAVES * 64, 2) void k_deepfm_v2_joint(const V2JRun A, const int* __restrict__ ids,
-                                                                   const float* __restrict__ dense,
-                                                                   float* __restrict__ out, int B,
-                                                                   int* __restrict__ err,
-                                                                   const float* __restrict__ image, const V2JMany M) {
+template <int G_BIG, int NJF, int KPC, int H0C, int H1C, int WAVES, bool HALF, bool MB>
+__device__ __forceinline__ void v2j_body(const V2JRun& A, const int* __restrict__ ids, const float* __restrict__ dense,
+                                         float* __restrict__ out, int B, int* __restrict__ err,
+                                         const float* __restrict__ image, const V2JMany* __restrict__ Mp) {
     constexpr int G_EMB = G_BIG + NJF;
     using LD = V2Lds<G_EMB, 4, KPC, H0C, H1C, true>;          // the weight image is the FOLD image of the whole model
     using Set = V2JSet<G_BIG, NJF>;
@@ -180,14 +178,15 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_deepfm_v2_joint(const V2JRun 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 15, q = lane >> 4;
     const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int ntasks = MB ? M.n * M.ntpb : (B + 15) >> 4;
+    const int m_ntpb = MB ? Mp->ntpb : 0;
+    const int ntasks = MB ? Mp->n * m_ntpb : (B + 15) >> 4;
     const int task_stride = gridDim.x * WAVES;
     const int wave_global = blockIdx.x * WAVES + wave;
     // MB: (batch, task inside the batch) of launch task tk (wave-uniform), and that batch's buffers
     auto batch_of = [&](int tk, int& tl) {
         if constexpr (MB) {
-            const int b = __builtin_amdgcn_readfirstlane(tk / M.ntpb);
-            tl = tk - b * M.ntpb;
+            const int b = __builtin_amdgcn_readfirstlane(tk / m_ntpb);
+            tl = tk - b * m_ntpb;
             return b;
         } else {
             tl = tk;
@@ -209,8 +208,8 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_deepfm_v2_joint(const V2JRun 
     auto ld_raw = [&](int tkg, f32x4& raw) {
         int tk;
         const int bi = batch_of(tkg, tk);
-        const int* ids_b = MB ? M.ids[bi] : ids;
-        const float* dense_b = MB ? M.dense[bi] : dense;
+        const int* ids_b = MB ? Mp->ids[bi] : ids;
+        const float* dense_b = MB ? Mp->dense[bi] : dense;
         if (aligned && tk * 16 + 16 <= B) {                       // wave-uniform
             const bool isid = lane < 32;
             const int j = isid ? lane : lane - 32;
@@ -223,8 +222,8 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_deepfm_v2_joint(const V2JRun 
     auto gather = [&](int tkg, const f32x4& raw, Set& S) {
         int tk;
         const int bi = batch_of(tkg, tk);
-        const int* ids = MB ? M.ids[bi] : ids0;
-        const float* dense = MB ? M.dense[bi] : dense0;
+        const int* ids = MB ? Mp->ids[bi] : ids0;
+        const float* dense = MB ? Mp->dense[bi] : dense0;
         if (aligned && tk * 16 + 16 <= B) {
             const bool isid = lane < 32;
             const int j = isid ? lane : lane - 32;
@@ -427,7 +426,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_deepfm_v2_joint(const V2JRun 
     auto store = [&](int tkg, float score) {
         int tk;
         const int bi = batch_of(tkg, tk);
-        float* out_b = MB ? M.out[bi] : out;
+        float* out_b = MB ? Mp->out[bi] : out;
         const int m = tk * 16 + r;
         if (q == 0 && m < B) out_b[m] = score;
     };
@@ -497,4 +496,20 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_deepfm_v2_joint(const V2JRun 
         }
     }
     if (__ballot(bad) != 0 && lane == 0) atomicOr(err, 1);
+}
+
+// One batch per launch: no per-batch pointer table in the kernel arguments at all (round 1 passed an unused 1.5 KB V2JMany
+// by value on every launch).
+template <int G_BIG, int NJF, int KPC, int H0C, int H1C, int WAVES, bool HALF>
+__global__ __launch_bounds__(WAVES * 64, 2) void k_deepfm_v2_joint(const V2JRun A, const int* __restrict__ ids,
+                                                                   const float* __restrict__ dense, float* __restrict__ out, int B,
+                                                                   int* __restrict__ err, const float* __restrict__ image) {
+    v2j_body<G_BIG, NJF, KPC, H0C, H1C, WAVES, HALF, false>(A, ids, dense, out, B, err, image, nullptr);
+}
+// Several batches per launch (sprk_set_many_batches): the table travels in the kernarg segment (+0.05 us of host time per
+// launch, no device-side cost: scripts/ubench/launch_floor.hip).
+template <int G_BIG, int NJF, int KPC, int H0C, int H1C, int WAVES, bool HALF>
+__global__ __launch_bounds__(WAVES * 64, 2) void k_deepfm_v2_joint_many(const V2JRun A, const V2JMany M, int B, int* __restrict__ err,
+                                                                        const float* __restrict__ image) {
+    v2j_body<G_BIG, NJF, KPC, H0C, H1C, WAVES, HALF, true>(A, nullptr, nullptr, nullptr, B, err, image, &M);
 }
