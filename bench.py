@@ -194,7 +194,7 @@ def _resize_first_order(small, w, fields, fo_key, rng):
     return w
 
 
-def oracle_forward(name, model, feats):
+def oracle_forward(name, model, feats, dtype=np.float32):
     """The numpy oracle on `feats` (a few thousand rows).  Models holding device tables (config 4) are compacted first:
     only the table rows the sample references are pulled to the host and the ids are renumbered, so the oracle never sees
     the 6.9 GB table."""
@@ -205,16 +205,16 @@ def oracle_forward(name, model, feats):
     if any(hasattr(v, "data_ptr") for v in weights.values()):
         feats, weights, fields = compact_for_oracle(model, feats, fields)
     if name in ("deepfm_v2_c2", "deepfm_v2_c4", "deepfm_v2_ref"):
-        return O.deepfm_v2_forward(feats, weights, dtype=np.float32, fields=fields, order=model.order)
+        return O.deepfm_v2_forward(feats, weights, dtype=dtype, fields=fields, order=model.order)
     if name in ("deepfm_c2", "deepfm_c4"):
-        return O.deepfm_forward(feats, weights, dtype=np.float32, fields=fields, pairs=model.pairs)
+        return O.deepfm_forward(feats, weights, dtype=dtype, fields=fields, pairs=model.pairs)
     if name == "neuralcf_ref":
-        return O.neural_cf_forward(feats, weights, dtype=np.float32, movie_buckets=model.movie_buckets, user_buckets=model.user_buckets)
+        return O.neural_cf_forward(feats, weights, dtype=dtype, movie_buckets=model.movie_buckets, user_buckets=model.user_buckets)
     if name == "widedeep_c5":
-        return O.wide_n_deep_forward(feats, weights, dtype=np.float32, movie_buckets=model.movie_buckets,
+        return O.wide_n_deep_forward(feats, weights, dtype=dtype, movie_buckets=model.movie_buckets,
                                      user_buckets=model.user_buckets, cross_buckets=model.cross_buckets,
                                      rated_buckets=model.rated_buckets)
-    return O.din_forward(feats, weights, dtype=np.float32, hist_len=model.hist_len,
+    return O.din_forward(feats, weights, dtype=dtype, hist_len=model.hist_len,
                          movie_buckets=model.movie_buckets, user_buckets=model.user_buckets)
 
 
@@ -497,7 +497,7 @@ def main():
     env = os.environ.get
     lb = 1
     if args.launch_batches > 1 and env("SPRK_FORCE_INTERPRETER") != "1":
-        if roof["kernel"] == "k_deepfm_v2_joint":
+        if roof["kernel"] in ("k_deepfm_v2_joint", "k_rows_chain"):
             lb = args.launch_batches
         elif roof["kernel"] == "k_deepfm_pairs":
             lb = min(args.launch_batches, 16)

@@ -1,0 +1,309 @@
+// k_mlp_rows.h -- k_mlp_rows: the "DenseFeatures -> Dense(relu) -> Dense(relu) -> Dense(1, sigmoid)" graphs (reference
+// EmbeddingMLP.py:72-77, the deep part of WideNDeep.py:99-107 + its hashed-cross wide part; BASELINE config 5) with EVERY
+// embedding column folded through the first Dense layer, one WAVE per 16 samples.  Included inside sparrow_hip.hip's
+// anonymous namespace, after k_mlp_chain.h (the round-1 kernel it replaces for ReLU graphs; that one stays for PReLU / A/B).
+//
+// What round 1's k_mlp_chain did per 16 samples: the 8 genre columns folded to per-id tables F_g = W0_g^T E_g (512-byte rows,
+// 19 of them per column) and gathered from L2 -- 4 KB per SAMPLE of cache traffic -- while movieId / userId rows went through
+// the first layer on f32 MFMA: 160 instructions of 32 cycles, i.e. 5 120 matrix-pipe cycles per task before the second layer
+// even starts (the f32-input MFMA runs at 1/16 of the f16 rate on gfx950), gathers issued per task, not a task ahead.  101 us
+// per 131 072 samples, 24 % of the HBM roofline.  Here:
+//   * the genre tables live in LDS (8 x 19 x 512 B = 76 KB; a shared all-zero row serves "no id"): no cache traffic at all;
+//   * movieId / userId are folded as well: their F rows (512 B per id) are gathered from HBM / Infinity Cache straight into the
+//     first layer's accumulators (C/D layout: lane (r,q) holds outputs 16 nb + 4q .. +3 of sample r) -- 1 KB per sample instead
+//     of 2 x 128 B, bought back many times over by the 144 f32 MFMAs it removes; total gathered bytes stay BELOW the reference's
+//     algorithmic 1.6 KB per sample (10 embedding rows x 128 B + the cross row), because the genre rows never leave LDS;
+//   * the matrix pipe sees the numerics (K = 8: two 16x16x4 steps per 16 outputs) and the second layer (per-sample dynamic
+//     split-f16, dyn_split.h: 96 instructions of 16 cycles);
+//   * the gathers of task n+1 are issued before the second layer of task n runs (ONE register set: the rows are summed into
+//     the accumulators first thing in a trip, which frees the set for the next task's loads), ids / numerics one task further
+//     ahead, staged through a wave-private LDS slot.
+//   z0 = b0 + sum_{10 columns} F_g[id_g] + W0[:, numerics]^T x;  h1 = relu(z0);  h2 = relu(b1 + W1^T h1)
+//   score = sigmoid(hw . h2 + wide + bias),  wide = hc . X[FingerprintCat64(movieId, userRatedMovie1) mod buckets] or its indicator weight
+
+#define MR_MAX_BIG 3
+#define MR_MAX_SMALL 8
+#define MR_STAGE 320                      // floats per wave: ids [16][F <= 12] + numerics [16][<= 8]
+
+struct MlpRowsRun {
+    int F, ND, n_num;
+    int n_big, n_small;
+    int big_col[MR_MAX_BIG], big_vocab[MR_MAX_BIG];
+    const float* big_tab[MR_MAX_BIG];     // [vocab + 1][N0] folded rows, the last one all zero ("no id")
+    int s_col[MR_MAX_SMALL], s_vocab[MR_MAX_SMALL];
+    int s_off[MR_MAX_SMALL];              // float offset of small column f's rows inside the LDS small block
+    int zero_off;                         // float offset of the shared all-zero row inside the small block
+    int small_floats;                     // multiple of 256
+    const float* small;                   // device image of the small block
+    int wide_kind, wide_a, wide_b, wide_dim, wide_stride;   // 0 none, 1 cross rows x head weights, 2 cross scalar (indicator weight)
+    long long wide_buckets;
+    const float* wide_tab;
+    const float* wide_w;
+    float head_bias;
+    float inv_w1_scale;                   // DYN: 1 / static scale of the second layer's split-f16 fragments
+    int flags;                            // 1 = ids / dense not 16-byte aligned: stage element-wise
+};
+
+template <int N0C, int N1C>
+struct MlpRowsLds {
+    static constexpr int N0 = N0C * 16, N1 = N1C * 16;
+    static constexpr int S1 = N0 + 4;
+    static constexpr int off_w1 = 0;                  // DYN: split-f16 fragments N1C*(N0C/2)*512 floats; else W1^T [N1][S1]
+    static constexpr int w1_floats = N1 * S1;
+    static constexpr int off_w0n = off_w1 + w1_floats;   // W0[:, numerics]^T [N0][8]
+    static constexpr int off_b0 = off_w0n + N0 * 8;
+    static constexpr int off_b1 = off_b0 + N0;
+    static constexpr int off_hw = off_b1 + N1;
+    static constexpr int total = off_hw + N1;
+    static constexpr int total_pad = (total + 255) & ~255;
+};
+
+// One-time (finalize) kernel: the fixed part of the LDS image.
+template <int N0C, int N1C>
+__global__ __launch_bounds__(256) void k_mlp_rows_pack(const float* __restrict__ W0, int ldw0, int num_col0, int n_num,
+                                                       const float* __restrict__ b0, const float* __restrict__ W1, int ldw1,
+                                                       const float* __restrict__ b1, const float* __restrict__ hw, int n_hw,
+                                                       const float* __restrict__ w1frag, float* __restrict__ img) {
+    using LD = MlpRowsLds<N0C, N1C>;
+    static_assert(N1C * (N0C / 2) * 512 <= LD::w1_floats && N0C % 2 == 0, "DYN fragments fit the second layer's region");
+    const int tid = threadIdx.x;
+    if (w1frag) {
+        for (int i = tid; i < LD::w1_floats; i += 256) img[LD::off_w1 + i] = i < N1C * (N0C / 2) * 512 ? w1frag[i] : 0.f;
+    } else {
+        for (int i = tid; i < LD::w1_floats; i += 256) {
+            const int n = i / LD::S1, k = i - n * LD::S1;
+            img[LD::off_w1 + i] = k < LD::N0 ? W1[(size_t)n * ldw1 + k] : 0.f;
+        }
+    }
+    for (int i = tid; i < LD::N0 * 8; i += 256) {
+        const int n = i >> 3, k = i & 7;
+        img[LD::off_w0n + i] = k < n_num ? W0[(size_t)n * ldw0 + num_col0 + k] : 0.f;
+    }
+    for (int i = tid; i < LD::N0; i += 256) img[LD::off_b0 + i] = b0[i];
+    for (int i = tid; i < LD::N1; i += 256) {
+        img[LD::off_b1 + i] = b1[i];
+        img[LD::off_hw + i] = i < n_hw ? hw[i] : 0.f;
+    }
+    for (int i = LD::total + tid; i < LD::total_pad; i += 256) img[i] = 0.f;
+}
+
+template <int N0C, int N1C, int NBIG, int WAVES, bool DYN>
+__global__ __launch_bounds__(WAVES * 64, 2) void k_mlp_rows(const MlpRowsRun A, const int* __restrict__ ids,
+                                                            const float* __restrict__ dense, float* __restrict__ out,
+                                                            int B, int* __restrict__ err, const float* __restrict__ image) {
+    using LD = MlpRowsLds<N0C, N1C>;
+    constexpr int N0 = LD::N0;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 15, q = lane >> 4;
+    const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int ntasks = (B + 15) >> 4;
+    const int task_stride = gridDim.x * WAVES;
+    const float* small_s = smem + LD::total_pad;
+    float* stage = smem + LD::total_pad + A.small_floats + wave * MR_STAGE;
+    bool bad = false;
+    const bool aligned = !(A.flags & 1);
+    auto clampt = [&](int tk) { return tk < ntasks ? tk : ntasks - 1; };
+
+    // ---- ids / numerics of a task: two coalesced 16-byte loads per lane (ids block, numerics block) ----
+    auto ld_raw = [&](int tk, f32x4& ri, f32x4& rd) {
+        if (aligned && tk * 16 + 16 <= B) {                       // wave-uniform
+            const int ni = 4 * A.F, nd = 4 * A.ND;
+            ri = ld4(reinterpret_cast<const float*>(ids) + (size_t)tk * 16 * A.F + 4 * (lane < ni ? lane : 0));
+            rd = ld4(dense + (size_t)tk * 16 * A.ND + 4 * (lane < nd ? lane : 0));
+        }
+    };
+    // everything of a task that is in flight while the previous task's second layer runs
+    f32x4 g[NBIG][N0C];                   // big columns' folded rows (C/D layout pieces)
+    f32x4 gw[2];                          // cross row pieces (wide part)
+    int so[MR_MAX_SMALL];                 // small columns: LDS float offset of this sample's row
+    float xa = 0.f, xb = 0.f, gws = 0.f;  // numerics q / q + 4; cross indicator weight
+    auto gather = [&](int tk, const f32x4& ri, const f32x4& rd) {
+        if (aligned && tk * 16 + 16 <= B) {
+            if (lane < 4 * A.F) st4(stage + 4 * lane, ri);
+            if (lane < 4 * A.ND) st4(stage + 192 + 4 * lane, rd);
+        } else {
+            int* si = reinterpret_cast<int*>(stage);
+#pragma clang loop vectorize(disable) unroll(disable)
+            for (int e = lane; e < 16 * A.F; e += 64) {
+                const int mm = e / A.F, c = e - mm * A.F;
+                si[e] = ids[(size_t)min(tk * 16 + mm, B - 1) * A.F + c];
+            }
+#pragma clang loop vectorize(disable) unroll(disable)
+            for (int e = lane; e < 16 * A.ND; e += 64) {
+                const int mm = e / A.ND, c = e - mm * A.ND;
+                stage[192 + e] = dense[(size_t)min(tk * 16 + mm, B - 1) * A.ND + c];
+            }
+        }
+        // one wave: LDS operations complete in issue order, no barrier needed
+        const int* idrow = reinterpret_cast<const int*>(stage) + r * A.F;
+#pragma unroll
+        for (int b = 0; b < NBIG; ++b) {
+            const int id = idrow[A.big_col[b]];
+            bad |= (unsigned)(id + 1) > (unsigned)A.big_vocab[b];
+            const unsigned sid = min((unsigned)id, (unsigned)A.big_vocab[b]);      // -1 -> the zero row at index vocab
+            const float* row = A.big_tab[b] + (size_t)sid * N0 + 4 * q;
+#pragma unroll
+            for (int nb = 0; nb < N0C; ++nb) g[b][nb] = ld4(row + 16 * nb);
+        }
+#pragma unroll
+        for (int f = 0; f < MR_MAX_SMALL; ++f) {
+            if (f < A.n_small) {                                  // wave-uniform
+                const int id = idrow[A.s_col[f]];
+                bad |= (unsigned)(id + 1) > (unsigned)A.s_vocab[f];
+                so[f] = (unsigned)id < (unsigned)A.s_vocab[f] ? A.s_off[f] + id * N0 : A.zero_off;
+            }
+        }
+        {
+            const float* nrow = stage + 192 + r * A.ND;
+            const int last = A.n_num - 1;
+            // slots beyond n_num hold a duplicate finite value that only ever meets zero weights
+            xa = nrow[min(q, last)];
+            xb = nrow[min(q + 4, last)];
+        }
+        if (A.wide_kind) {                                        // wave-uniform
+            const unsigned long long bkt = cross_bucket(idrow[A.wide_a], idrow[A.wide_b], (uint64_t)A.wide_buckets);
+            if (A.wide_kind == 1) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int d = 16 * h + 4 * q;
+                    gw[h] = d < A.wide_dim ? ld4(A.wide_tab + (size_t)bkt * A.wide_stride + d) : zero;
+                }
+            } else {
+                gws = A.wide_tab[bkt];
+            }
+        }
+    };
+
+    // ---- prologue: first task's ids and the LDS image / small tables requested together ----
+    f32x4 ri = zero, rd = zero;
+    int tk = blockIdx.x * WAVES + wave;
+    if (ntasks > 0) ld_raw(clampt(tk), ri, rd);
+#pragma unroll 1
+    for (int c = wave; c < LD::total_pad / 256; c += WAVES)
+        __builtin_amdgcn_global_load_lds(
+            (const __attribute__((address_space(1))) void*)(image + c * 256 + lane * 4),
+            (__attribute__((address_space(3))) void*)(smem + c * 256), 16, 0, 0);
+#pragma unroll 1
+    for (int c = wave; c < A.small_floats / 256; c += WAVES)
+        __builtin_amdgcn_global_load_lds(
+            (const __attribute__((address_space(1))) void*)(A.small + c * 256 + lane * 4),
+            (__attribute__((address_space(3))) void*)(smem + LD::total_pad + c * 256), 16, 0, 0);
+    __builtin_amdgcn_s_waitcnt(0x0F70);                           // vmcnt(0): this wave's DMA pieces and ids have landed
+    __builtin_amdgcn_s_barrier();
+    // numerics' A operands: rows (nb*16 + r) of W0[:, numerics]^T, columns q and q + 4
+    float rwa[N0C], rwb[N0C];
+#pragma unroll
+    for (int nb = 0; nb < N0C; ++nb) {
+        rwa[nb] = smem[LD::off_w0n + (nb * 16 + r) * 8 + q];
+        rwb[nb] = smem[LD::off_w0n + (nb * 16 + r) * 8 + q + 4];
+    }
+    f32x4 wwide[2] = {zero, zero};
+    if (A.wide_kind == 1) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int d = 16 * h + 4 * q;
+            if (d < A.wide_dim) wwide[h] = ld4(A.wide_w + d);
+        }
+    }
+    if (tk < ntasks) {
+        gather(tk, ri, rd);
+        ld_raw(clampt(tk + task_stride), ri, rd);
+    }
+    for (; tk < ntasks; tk += task_stride) {
+        // ---- the task's gathered rows -> first-layer accumulators (frees the register set for the next task) ----
+        f32x4 z0[N0C];
+#pragma unroll
+        for (int nb = 0; nb < N0C; ++nb) {
+            z0[nb] = g[0][nb];
+#pragma unroll
+            for (int b = 1; b < NBIG; ++b) z0[nb] += g[b][nb];
+        }
+        float zw = 0.f;
+        if (A.wide_kind == 1) zw = dot4(gw[0], wwide[0]) + dot4(gw[1], wwide[1]);
+        else if (A.wide_kind == 2) zw = q == 0 ? gws : 0.f;
+        int so_c[MR_MAX_SMALL];
+#pragma unroll
+        for (int f = 0; f < MR_MAX_SMALL; ++f) so_c[f] = so[f];
+        const float xa_c = xa, xb_c = xb;
+        // ---- next task: gathers issued now, consumed after this task's second layer; ids one task further ahead ----
+        if (tk + task_stride < ntasks) {
+            gather(tk + task_stride, ri, rd);
+            ld_raw(clampt(tk + 2 * task_stride), ri, rd);
+        }
+        // ---- small columns from LDS, bias, numerics on the matrix pipe ----
+#pragma unroll
+        for (int nb = 0; nb < N0C; ++nb) z0[nb] += ld4(smem + LD::off_b0 + nb * 16 + 4 * q);
+#pragma unroll
+        for (int f = 0; f < MR_MAX_SMALL; ++f) {
+            if (f < A.n_small) {
+#pragma unroll
+                for (int nb = 0; nb < N0C; ++nb) z0[nb] += ld4(small_s + so_c[f] + 16 * nb + 4 * q);
+            }
+        }
+#pragma unroll
+        for (int nb = 0; nb < N0C; ++nb) z0[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(rwa[nb], xa_c, z0[nb], 0, 0, 0);
+#pragma unroll
+        for (int nb = 0; nb < N0C; ++nb) z0[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(rwb[nb], xb_c, z0[nb], 0, 0, 0);
+#pragma unroll
+        for (int nb = 0; nb < N0C; ++nb) z0[nb] = relu4_fast(z0[nb]);
+        // ---- second layer: K = N0, B operand = h1 as it sits in the registers ----
+        f32x4 z1[N1C];
+        if constexpr (DYN) {
+            float mx = 0.f;
+#pragma unroll
+            for (int nb = 0; nb < N0C; ++nb)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) mx = fmaxf(mx, z0[nb][j]);       // h1 >= 0
+            mx = rows4_max(mx);
+            float scale, inv;
+            dyn_scale(mx, A.inv_w1_scale, scale, inv);
+#pragma unroll
+            for (int n1 = 0; n1 < N1C; ++n1) z1[n1] = zero;
+            const float* wf = smem + LD::off_w1 + (r * 4 + q) * 4;       // this lane's 16 bytes inside a 1-KB fragment
+#pragma unroll
+            for (int b = 0; b < N0C / 2; ++b) {
+                din_f16x8 bh, bl;
+                dyn_split8(z0[2 * b], z0[2 * b + 1], scale, bh, bl);
+#pragma unroll
+                for (int n1 = 0; n1 < N1C; ++n1) {
+                    const din_f16x8 ah = __builtin_bit_cast(din_f16x8, ld4(wf + ((n1 * (N0C / 2) + b) * 2 + 0) * 256));
+                    const din_f16x8 al = __builtin_bit_cast(din_f16x8, ld4(wf + ((n1 * (N0C / 2) + b) * 2 + 1) * 256));
+                    z1[n1] = mfma_f16(ah, bh, z1[n1]);
+                    z1[n1] = mfma_f16(ah, bl, z1[n1]);
+                    z1[n1] = mfma_f16(al, bh, z1[n1]);
+                }
+            }
+#pragma unroll
+            for (int n1 = 0; n1 < N1C; ++n1) z1[n1] = z1[n1] * inv + ld4(smem + LD::off_b1 + n1 * 16 + 4 * q);
+        } else {
+#pragma unroll
+            for (int n1 = 0; n1 < N1C; ++n1) z1[n1] = ld4(smem + LD::off_b1 + n1 * 16 + 4 * q);
+            const float* w1r = smem + LD::off_w1 + r * LD::S1 + 4 * q;
+#pragma unroll
+            for (int c = 0; c < N0C; ++c) {
+                f32x4 a[N1C];
+#pragma unroll
+                for (int n1 = 0; n1 < N1C; ++n1) a[n1] = ld4(w1r + n1 * 16 * LD::S1 + 16 * c);
+#pragma unroll
+                for (int st = 0; st < 4; ++st)
+#pragma unroll
+                    for (int n1 = 0; n1 < N1C; ++n1)
+                        z1[n1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[n1][st], z0[c][st], z1[n1], 0, 0, 0);
+            }
+        }
+        float z = zw;
+#pragma unroll
+        for (int n1 = 0; n1 < N1C; ++n1) {
+            const f32x4 hw = ld4(smem + LD::off_hw + n1 * 16 + 4 * q);
+            const f32x4 h2 = relu4_fast(z1[n1]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) z = fmaf(hw[j], h2[j], z);
+        }
+        z = rows4_sum(z);
+        const int mm = tk * 16 + r;
+        if (q == 0 && mm < B) out[mm] = sigmoidf_acc(z + A.head_bias);
+    }
+    if (__ballot(bad) != 0 && lane == 0) atomicOr(err, 1);
+}

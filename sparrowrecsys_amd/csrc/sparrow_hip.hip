@@ -613,6 +613,7 @@ __global__ __launch_bounds__(256) void k_zero_columns(float* __restrict__ Wt, in
 #include "k_din_tail.h"
 #include "k_chain_v1.h"
 #include "k_mlp_chain.h"
+#include "k_mlp_rows.h"
 #include "k_emb_rank.h"
 #include "k_dien_seq.h"
 
@@ -673,6 +674,13 @@ struct sprk_engine {
     int mlp_variant = -1;
     MlpChainRun mlp_run;
     float* mlp_image = nullptr;
+    // ... with every embedding column folded through the first layer, genre tables in LDS (k_mlp_rows); -1 = not used
+    int mlp_rows_nbig = -1;
+    MlpRowsRun mlp_rows_run;
+    float* mlp_rows_image = nullptr;
+    float* mlp_rows_small = nullptr;
+    size_t mlp_rows_lds = 0;
+    std::vector<void*> mlp_rows_bufs;
     // register-chained DIN tail (k_din_tail); -1 = the tile interpreter runs the tail
     int din_tail_variant = -1;
     DinTailRun din_tail_run;
@@ -1839,6 +1847,141 @@ int setup_mlp_chain(sprk_engine* h, DevPlan* dp) {
     return SPRK_OK;
 }
 
+// ---- k_mlp_rows<8, 8, NBIG, WAVES, DYN> ----
+constexpr int MR_WAVES = 8;
+template <int NBIG>
+void mlp_rows_launch(const MlpRowsRun& a, const int* ids, const float* dense, float* out, int B, int* err, const float* image, int grid,
+                     size_t lds, hipStream_t st) {
+    if (a.inv_w1_scale != 0.f)
+        hipLaunchKernelGGL((k_mlp_rows<8, 8, NBIG, MR_WAVES, true>), dim3(grid), dim3(MR_WAVES * 64), lds, st, a, ids, dense, out, B, err, image);
+    else
+        hipLaunchKernelGGL((k_mlp_rows<8, 8, NBIG, MR_WAVES, false>), dim3(grid), dim3(MR_WAVES * 64), lds, st, a, ids, dense, out, B, err, image);
+}
+template <int NBIG>
+int mlp_rows_attr(size_t lds) {
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mlp_rows<8, 8, NBIG, MR_WAVES, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mlp_rows<8, 8, NBIG, MR_WAVES, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    return SPRK_OK;
+}
+// Recognise an EmbeddingMLP / Wide&Deep plan (EmbeddingMLP.py:72-77, WideNDeep.py:99-107) with ReLU layers of 128 and fold
+// EVERY embedding column through the first Dense layer (see k_mlp_rows.h).  Leaves mlp_rows_nbig = -1 for any other shape.
+int setup_mlp_rows(sprk_engine* h) {
+    const char* sw = getenv("SPRK_MLP_ROWS");                 // A/B switch: "0" = round-1 k_mlp_chain
+    if (sw && sw[0] == '0') return SPRK_OK;
+    sw = getenv("SPRK_MLP_CHAIN");                            // "0" = tile interpreter (switches both chain kernels off)
+    if (sw && sw[0] == '0') return SPRK_OK;
+    const sprk_plan& p = h->plan;
+    if (p.din.enabled || p.n_ops != 2 || p.n_taps < 1 || p.n_taps > 2) return SPRK_OK;
+    if (p.model_kind != SPRK_MODEL_EMBEDDING_MLP && p.model_kind != SPRK_MODEL_WIDE_DEEP) return SPRK_OK;
+    if (p.n_id_cols > 12 || p.n_dense > 8 || p.n_dense < 1) return SPRK_OK;
+    const sprk_op &o0 = p.ops[0], &o1 = p.ops[1];
+    if (o0.kind != SPRK_OP_DENSE || o1.kind != SPRK_OP_DENSE || o0.act != SPRK_ACT_RELU || o1.act != SPRK_ACT_RELU) return SPRK_OK;
+    if (o0.src_buf != 0 || o0.dst_buf == 0 || o0.dst_off != 0 || o1.src_buf != o0.dst_buf || o1.src_off != 0 || o1.K != o0.N ||
+        o1.dst_off != 0 || o0.N != 128 || o1.N != 128) return SPRK_OK;
+    typedef MlpRowsLds<8, 8> LD;
+    const int lo = o0.src_off, hi = o0.src_off + o0.K, N0 = 128;
+    MlpRowsRun r;
+    memset(&r, 0, sizeof(r));
+    const sprk_seg* big_seg[MR_MAX_BIG];
+    const sprk_seg* small_seg[MR_MAX_SMALL];
+    const sprk_seg* cross = nullptr;
+    int num_dst = -1;
+    for (int i = 0; i < p.n_segs; ++i) {
+        const sprk_seg& sg = p.segs[i];
+        if (sg.kind == SPRK_SEG_ROWS) {
+            if (sg.dst < lo || sg.dst + 4 * sg.count > hi) return SPRK_OK;
+            if ((long long)sg.vocab <= 31 && r.n_small < MR_MAX_SMALL) small_seg[r.n_small++] = &sg;
+            else if (r.n_big < MR_MAX_BIG) big_seg[r.n_big++] = &sg;
+            else return SPRK_OK;
+            if ((size_t)sg.vocab * N0 * sizeof(float) > ((size_t)8 << 30)) return SPRK_OK;
+        } else if (sg.kind == SPRK_SEG_DENSE) {
+            if (num_dst >= 0 || sg.field != 0 || sg.count > 8 || sg.dst < lo || sg.dst + sg.count > hi) return SPRK_OK;
+            num_dst = sg.dst; r.n_num = sg.count;
+        } else if (sg.kind == SPRK_SEG_CROSS_ROWS || sg.kind == SPRK_SEG_CROSS_SCALAR) {
+            if (cross || (sg.dst < hi && sg.dst + (sg.kind == SPRK_SEG_CROSS_ROWS ? 4 * sg.count : 1) > lo)) return SPRK_OK;
+            cross = &sg;
+        } else if (sg.kind != SPRK_SEG_ZERO) {
+            return SPRK_OK;
+        }
+    }
+    if (r.n_big < 1 || r.n_big > 2 || num_dst < 0 || r.n_num < 1) return SPRK_OK;   // (three big columns spill: 3 x 8 float4 in flight)
+    const sprk_tap *tdeep = nullptr, *twide = nullptr;
+    for (int t = 0; t < p.n_taps; ++t) {
+        const sprk_tap& tp = p.taps[t];
+        if (tp.scale != 1.0f || tp.bias != 0.0f) return SPRK_OK;
+        if (tp.buf == o1.dst_buf && tp.off == 0 && tp.len <= o1.N && tp.w_slot >= 0 && !tdeep) tdeep = &tp;
+        else if (cross && tp.buf == 0 && tp.off == cross->dst && !twide) twide = &tp;
+        else return SPRK_OK;
+    }
+    if (!tdeep || (cross != nullptr) != (twide != nullptr)) return SPRK_OK;
+    if (cross) {
+        if (cross->kind == SPRK_SEG_CROSS_ROWS) {
+            if (twide->len != 4 * cross->count || twide->w_slot < 0 || twide->len > 32) return SPRK_OK;
+            r.wide_kind = 1; r.wide_dim = twide->len; r.wide_stride = cross->row_stride; r.wide_w = (const float*)h->slot_ptr[twide->w_slot];
+        } else {
+            if (twide->len != 1 || twide->w_slot >= 0) return SPRK_OK;
+            r.wide_kind = 2;
+        }
+        r.wide_a = cross->field; r.wide_b = cross->field2; r.wide_buckets = cross->vocab; r.wide_tab = (const float*)h->slot_ptr[cross->slot];
+    }
+    // LDS: fixed image + small tables (+ one shared zero row) + a staging slot per wave
+    size_t small_floats = 0;
+    for (int f = 0; f < r.n_small; ++f) { r.s_off[f] = (int)small_floats; small_floats += (size_t)small_seg[f]->vocab * N0; }
+    r.zero_off = (int)small_floats;
+    small_floats += N0;
+    small_floats = (small_floats + 255) & ~(size_t)255;
+    const size_t lds = ((size_t)LD::total_pad + small_floats + (size_t)MR_WAVES * MR_STAGE) * sizeof(float);
+    if (lds > 160 * 1024) return SPRK_OK;
+    const float* W0 = (const float*)h->slot_ptr[o0.w_slot];
+    HIP_TRY(hipMalloc((void**)&h->mlp_rows_small, small_floats * sizeof(float)));
+    HIP_TRY(hipMemset(h->mlp_rows_small, 0, small_floats * sizeof(float)));
+    auto fold = [&](const sprk_seg& sg, float* F) {
+        long long blocks = ((long long)sg.vocab * N0 + 255) / 256;
+        if (blocks > 65536) blocks = 65536;
+        hipLaunchKernelGGL(k_fold_dense_rows, dim3((unsigned)blocks), dim3(256), 0, 0, (const float*)h->slot_ptr[sg.slot], (long long)sg.vocab,
+                           sg.row_stride, 4 * sg.count, W0, o0.ldw, sg.dst - lo, N0, F);
+    };
+    for (int f = 0; f < r.n_small; ++f) {
+        r.s_col[f] = small_seg[f]->field; r.s_vocab[f] = small_seg[f]->vocab;
+        fold(*small_seg[f], h->mlp_rows_small + r.s_off[f]);
+    }
+    for (int b = 0; b < r.n_big; ++b) {
+        const sprk_seg& sg = *big_seg[b];
+        float* F = nullptr;
+        const size_t bytes = ((size_t)sg.vocab + 1) * N0 * sizeof(float);
+        HIP_TRY(hipMalloc((void**)&F, bytes));
+        h->mlp_rows_bufs.push_back(F);
+        h->derived_bytes += bytes;
+        HIP_TRY(hipMemset(F + (size_t)sg.vocab * N0, 0, N0 * sizeof(float)));        // the "no id" row
+        fold(sg, F);
+        r.big_col[b] = sg.field; r.big_vocab[b] = sg.vocab; r.big_tab[b] = F;
+    }
+    HIP_TRY(hipGetLastError());
+    float* w1frag = nullptr;
+    {
+        float w_scale = 0.f;
+        const int rc2 = make_dyn_fragments(h, (const float*)h->slot_ptr[o1.w_slot], o1.ldw, o1.N, o1.K, &w1frag, &w_scale);
+        if (rc2) return rc2;
+        r.inv_w1_scale = w1frag ? 1.0f / w_scale : 0.f;
+    }
+    HIP_TRY(hipMalloc((void**)&h->mlp_rows_image, (size_t)LD::total_pad * sizeof(float)));
+    hipLaunchKernelGGL((k_mlp_rows_pack<8, 8>), dim3(1), dim3(256), 0, 0, W0, o0.ldw, num_dst - lo, r.n_num, (const float*)h->slot_ptr[o0.b_slot],
+                       (const float*)h->slot_ptr[o1.w_slot], o1.ldw, (const float*)h->slot_ptr[o1.b_slot],
+                       (const float*)h->slot_ptr[tdeep->w_slot], tdeep->len, w1frag, h->mlp_rows_image);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    r.F = p.n_id_cols; r.ND = p.n_dense; r.head_bias = p.head_bias;
+    r.small = h->mlp_rows_small; r.small_floats = (int)small_floats;
+    int rc;
+    if (r.n_big == 1) rc = mlp_rows_attr<1>(lds);
+    else rc = mlp_rows_attr<2>(lds);
+    if (rc) return rc;
+    h->mlp_rows_run = r;
+    h->mlp_rows_lds = lds;
+    h->mlp_rows_nbig = r.n_big;
+    return SPRK_OK;
+}
+
 // ---- dispatch table for k_din_tail<N0C, N1C, KPC, WAVES> ----
 constexpr int DT_WAVES = 8;
 typedef void (*DinTailLaunchFn)(const DinTailRun&, const int*, const float*, const float*, float*, int, int*, const float*, int, hipStream_t);
@@ -2266,9 +2409,14 @@ int sprk_finalize(sprk_handle h) {
     }
     const bool rows_on = h->rows_variant >= 0;
     if (!rows_on && h->v2_variant < 0 && (rc = setup_deepfm_pairs(h))) return rc;
-    if (!rows_on && h->v2_variant < 0 && h->v1_variant < 0 && (rc = fold_first_dense(h, dp))) return rc;
-    if (!rows_on && h->v2_variant < 0 && (rc = setup_din_tail(h, dp))) return rc;
-    if (!rows_on && h->v2_variant < 0 && h->v1_variant < 0 && h->din_tail_variant < 0 && (rc = setup_mlp_chain(h, dp))) return rc;
+    if (!rows_on && h->v2_variant < 0 && h->v1_variant < 0) {
+        const char* force = getenv("SPRK_FORCE_INTERPRETER");
+        if (!(force && force[0] == '1') && (rc = setup_mlp_rows(h))) return rc;
+    }
+    const bool mrows_on = h->mlp_rows_nbig >= 0;
+    if (!mrows_on && !rows_on && h->v2_variant < 0 && h->v1_variant < 0 && (rc = fold_first_dense(h, dp))) return rc;
+    if (!mrows_on && !rows_on && h->v2_variant < 0 && (rc = setup_din_tail(h, dp))) return rc;
+    if (!mrows_on && !rows_on && h->v2_variant < 0 && h->v1_variant < 0 && h->din_tail_variant < 0 && (rc = setup_mlp_chain(h, dp))) return rc;
     HIP_TRY(hipMalloc((void**)&h->dev_plan, sizeof(DevPlan)));
     HIP_TRY(hipMemcpy(h->dev_plan, dp, sizeof(DevPlan), hipMemcpyHostToDevice));
     HIP_TRY(hipMalloc((void**)&h->dev_err, sizeof(int)));
@@ -2382,6 +2530,17 @@ int sprk_forward(sprk_handle h, const int32_t* ids, const float* dense, float* o
         int grid = (ntasks + V1_WAVES - 1) / V1_WAVES;
         if (grid > h->num_cus) grid = h->num_cus;                  // one 8-wave workgroup per CU (2 waves per SIMD; 3 per SIMD measured slower at B = 65 536)
         kV1Variants[h->v1_variant].launch(h->v1_run, ids, dense, out, B, h->dev_err, grid, st);
+        HIP_TRY(hipGetLastError());
+        return SPRK_OK;
+    }
+    if (h->mlp_rows_nbig >= 0) {
+        const int ntasks = (B + 15) / 16;
+        int grid = (ntasks + MR_WAVES - 1) / MR_WAVES;
+        if (grid > h->num_cus) grid = h->num_cus;                  // one 8-wave workgroup per CU (the LDS holds weights + genre tables)
+        MlpRowsRun rr = h->mlp_rows_run;
+        rr.flags = (((uintptr_t)ids | (uintptr_t)dense) & 15) ? 1 : 0;
+        if (h->mlp_rows_nbig == 1) mlp_rows_launch<1>(rr, ids, dense, out, B, h->dev_err, h->mlp_rows_image, grid, h->mlp_rows_lds, st);
+        else mlp_rows_launch<2>(rr, ids, dense, out, B, h->dev_err, h->mlp_rows_image, grid, h->mlp_rows_lds, st);
         HIP_TRY(hipGetLastError());
         return SPRK_OK;
     }
@@ -2614,6 +2773,8 @@ int sprk_describe(sprk_handle h, char* buf, size_t buf_bytes) {
     } else if (h->rows_variant >= 0) {
         const RowsVariant& rv = kRowsVariants[h->rows_variant];
         snprintf(kern, sizeof(kern), "k_rows_chain<KPC=%d,H0C=%d,H1C=%d,G_BIG=%d,NJF=%d>", rv.kpc, rv.h0c, rv.h1c, rv.g_big, rv.njf);
+    } else if (h->mlp_rows_nbig >= 0) {
+        snprintf(kern, sizeof(kern), "k_mlp_rows<8,8,NBIG=%d,NSMALL=%d>", h->mlp_rows_nbig, h->mlp_rows_run.n_small);
     } else if (h->mlp_variant >= 0) {
         snprintf(kern, sizeof(kern), "k_mlp_chain<8,8>");
     } else if (h->din_tail_variant >= 0) {
@@ -2671,6 +2832,9 @@ void sprk_destroy(sprk_handle h) {
     if (h->many_fork) (void)hipEventDestroy(h->many_fork);
     if (h->din_tail_image) (void)hipFree(h->din_tail_image);
     if (h->mlp_image) (void)hipFree(h->mlp_image);
+    if (h->mlp_rows_image) (void)hipFree(h->mlp_rows_image);
+    if (h->mlp_rows_small) (void)hipFree(h->mlp_rows_small);
+    for (void* q : h->mlp_rows_bufs) if (q) (void)hipFree(q);
     for (void* p : h->v1_bufs) if (p) (void)hipFree(p);
     if (h->v2j_big) (void)hipFree(h->v2j_big);
     if (h->rows_tab) (void)hipFree(h->rows_tab);

@@ -558,6 +558,54 @@ def test_deepfm_pairs_kernel_vs_interpreter_and_oracle(torch, monkeypatch, shape
     assert 0.02 < ref.std()
 
 
+@pytest.mark.parametrize("kind,B", [("embedding_mlp_ref", 4099), ("embedding_mlp", 131072), ("wide_indicator", 6007), ("wide_cross_rows", 1), ("wide_cross_rows", 33)])
+def test_mlp_rows_kernel_vs_round1_chain_and_oracle(torch, monkeypatch, kind, B):
+    """k_mlp_rows (every embedding column folded through the first Dense, genre tables in LDS, gathers a task ahead)
+    against round 1's k_mlp_chain (SPRK_MLP_ROWS=0) and the fp64 oracle; missing genre / history ids, ragged sizes,
+    a batch large enough that every wave loops over several tasks, unaligned views."""
+    V, U = (1001, 30001) if kind == "embedding_mlp_ref" else (20000, 30000)
+    D = 10 if kind == "embedding_mlp_ref" else 32
+    feats = SY.synth_embedding_mlp(B, V, U, seed=93, rated_vocab=V if kind.startswith("wide") else None)
+
+    def make():
+        if kind.startswith("embedding_mlp"):
+            return M.EmbeddingMLP(seed=51, emb_dim=D, movie_buckets=V, user_buckets=U)
+        return M.WideNDeep(seed=52, emb_dim=D, movie_buckets=V, user_buckets=U,
+                           **(dict(cross_buckets=10000, cross_dim=0) if kind == "wide_indicator" else dict(cross_buckets=200000, cross_dim=32)))
+    model = make()
+    assert model.engine.describe()["kernel"].startswith("k_mlp_rows<8,8,NBIG=2,NSMALL=8>")
+    p = model.predict(feats)[:, 0]
+    monkeypatch.setenv("SPRK_MLP_ROWS", "0")
+    old = make()
+    assert old.engine.describe()["kernel"].startswith("k_mlp_chain")
+    q = old.predict(feats)[:, 0]
+    monkeypatch.delenv("SPRK_MLP_ROWS")
+    n = min(B, 8192)
+    sub = {k: v[:n] for k, v in feats.items()}
+    if kind.startswith("embedding_mlp"):
+        ref = O.embedding_mlp_forward(sub, model.weights, dtype=np.float64, movie_buckets=V, user_buckets=U)[:, 0]
+    else:
+        ref = O.wide_n_deep_forward(sub, model.weights, dtype=np.float64, movie_buckets=V, user_buckets=U,
+                                    cross_buckets=model.cross_buckets, rated_buckets=V)[:, 0]
+    assert np.abs(p[:n] - ref).max() <= TIGHT
+    assert np.abs(p - q).max() <= TIGHT
+    # slices / unaligned row views score the same as inside the batch
+    ids, dense = model.pack(feats)
+    ti, td = _cuda(torch, ids), _cuda(torch, dense)
+    full = model.predict_device(ti, td)
+    for lo, hi in ((1, min(B, 40)), (min(B - 1, 3), min(B, 3 + 1000)), (max(0, B - 517), B)):
+        if hi > lo:
+            assert torch.equal(model.predict_device(ti[lo:hi], td[lo:hi]), full[lo:hi]), (lo, hi)
+    # out-of-range id raises, then the engine works again
+    if B > 10:
+        bad = dict(feats)
+        bad["movieId"] = feats["movieId"].copy()
+        bad["movieId"][7] = V
+        with pytest.raises(ValueError):
+            model.predict(bad)
+        np.testing.assert_array_equal(model.predict(feats)[:, 0], p)
+
+
 def test_deepfm_pairs_kernel_properties(torch):
     """Determinism, slice invariance (ragged tails), missing ids = zero rows, out-of-range ids raise."""
     B = 5000
@@ -766,6 +814,54 @@ def test_mlp_chain_vs_interpreter_and_oracle(torch, monkeypatch, kind):
     assert np.abs(out["1"] - ref).max() <= 2 * np.abs(out["1f32"] - ref).max() + 2e-6
     assert np.abs(out["0"] - ref).max() <= TIGHT
     assert 0.02 < ref.std()
+
+
+@pytest.mark.parametrize("kind,B", [("embedding_mlp_ref", 4099), ("embedding_mlp", 131072), ("wide_indicator", 6007), ("wide_cross_rows", 1), ("wide_cross_rows", 33)])
+def test_mlp_rows_kernel_vs_round1_chain_and_oracle(torch, monkeypatch, kind, B):
+    """k_mlp_rows (every embedding column folded through the first Dense, genre tables in LDS, gathers a task ahead)
+    against round 1's k_mlp_chain (SPRK_MLP_ROWS=0) and the fp64 oracle; missing genre / history ids, ragged sizes,
+    a batch large enough that every wave loops over several tasks, unaligned views."""
+    V, U = (1001, 30001) if kind == "embedding_mlp_ref" else (20000, 30000)
+    D = 10 if kind == "embedding_mlp_ref" else 32
+    feats = SY.synth_embedding_mlp(B, V, U, seed=93, rated_vocab=V if kind.startswith("wide") else None)
+
+    def make():
+        if kind.startswith("embedding_mlp"):
+            return M.EmbeddingMLP(seed=51, emb_dim=D, movie_buckets=V, user_buckets=U)
+        return M.WideNDeep(seed=52, emb_dim=D, movie_buckets=V, user_buckets=U,
+                           **(dict(cross_buckets=10000, cross_dim=0) if kind == "wide_indicator" else dict(cross_buckets=200000, cross_dim=32)))
+    model = make()
+    assert model.engine.describe()["kernel"].startswith("k_mlp_rows<8,8,NBIG=2,NSMALL=8>")
+    p = model.predict(feats)[:, 0]
+    monkeypatch.setenv("SPRK_MLP_ROWS", "0")
+    old = make()
+    assert old.engine.describe()["kernel"].startswith("k_mlp_chain")
+    q = old.predict(feats)[:, 0]
+    monkeypatch.delenv("SPRK_MLP_ROWS")
+    n = min(B, 8192)
+    sub = {k: v[:n] for k, v in feats.items()}
+    if kind.startswith("embedding_mlp"):
+        ref = O.embedding_mlp_forward(sub, model.weights, dtype=np.float64, movie_buckets=V, user_buckets=U)[:, 0]
+    else:
+        ref = O.wide_n_deep_forward(sub, model.weights, dtype=np.float64, movie_buckets=V, user_buckets=U,
+                                    cross_buckets=model.cross_buckets, rated_buckets=V)[:, 0]
+    assert np.abs(p[:n] - ref).max() <= TIGHT
+    assert np.abs(p - q).max() <= TIGHT
+    # slices / unaligned row views score the same as inside the batch
+    ids, dense = model.pack(feats)
+    ti, td = _cuda(torch, ids), _cuda(torch, dense)
+    full = model.predict_device(ti, td)
+    for lo, hi in ((1, min(B, 40)), (min(B - 1, 3), min(B, 3 + 1000)), (max(0, B - 517), B)):
+        if hi > lo:
+            assert torch.equal(model.predict_device(ti[lo:hi], td[lo:hi]), full[lo:hi]), (lo, hi)
+    # out-of-range id raises, then the engine works again
+    if B > 10:
+        bad = dict(feats)
+        bad["movieId"] = feats["movieId"].copy()
+        bad["movieId"][7] = V
+        with pytest.raises(ValueError):
+            model.predict(bad)
+        np.testing.assert_array_equal(model.predict(feats)[:, 0], p)
 
 
 # --------------------------------------------------------------------------------------------

@@ -1,0 +1,95 @@
+"""BASELINE.json configs 3, 4 and 5 AT THEIR STATED SIZES (``-m gpu``):
+
+* config 3  DIN, hist_len 50, emb_dim 32, batch 32 768
+* config 4  DeepFM emb_dim 64 with a 27 M-row x 64 item table (6.9 GB, drawn on the device) next to the 138 k-user table,
+            batch 65 536 -- both the sum-of-squares graph (DeepFM_v2: folded rows) and the pair-dot graph (DeepFM.py:100-103:
+            the 256-byte embedding rows themselves are gathered)
+* config 5  Wide&Deep with the 10 M-bucket x 32 hashed cross table (1.28 GB, hash computed on the device), batch 131 072
+
+The models are the ones ``bench.py --workload ...`` runs (same builder).  The host stays cheap: a few thousand rows sampled
+ACROSS the batch are compared with the fp64 oracle (for the device-resident tables the oracle sees only the rows the sample
+references, ``bench.compact_for_oracle``); the whole batch goes through size-independent properties -- determinism, and a
+slice scored alone equals the slice of the full batch, bit for bit."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from tests.conftest import ROOT
+
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+SAMPLE = 4096
+
+
+@pytest.fixture(scope="module")
+def torch():
+    import torch as t
+    assert t.cuda.is_available()
+    return t
+
+
+def _check(torch, name, B, expect_kernel, sample=SAMPLE):
+    model, feats, desc, roof = bench.build_workload(name, B, "uniform", NB=1)
+    f = feats[0]
+    eng = model.engine
+    d = eng.describe()
+    assert d["kernel"].split("<")[0] == expect_kernel, d
+    ids, dense = model.pack(f)
+    assert ids.shape[0] == B
+    ti, td = torch.from_numpy(ids).cuda(), torch.from_numpy(dense).cuda()
+    p = model.predict_device(ti, td)
+    eng.check_ids()
+    assert torch.equal(p, model.predict_device(ti, td))                               # deterministic
+    for lo, hi in ((0, 1000), (B // 2 - 333, B // 2 + 4001), (B - 517, B)):          # slice invariance incl. a ragged tail
+        assert torch.equal(model.predict_device(ti[lo:hi].contiguous(), td[lo:hi].contiguous()), p[lo:hi])
+    idx = np.sort(np.random.default_rng(1).choice(B, size=sample, replace=False))
+    ref = bench.oracle_forward(name, model, {k: np.asarray(v)[idx] for k, v in f.items()}, dtype=np.float64)[:, 0]
+    got = p.cpu().numpy()[idx]
+    assert np.isfinite(got).all()
+    assert np.abs(got - ref).max() <= TOL
+    assert ref.std() > 0.03                                                            # scores are spread out: not a vacuous comparison
+    tables = eng.table_bytes()
+    eng.close()
+    return tables
+
+
+def test_config3_din_at_stated_size(torch):
+    _check(torch, "din_c3", 32768, "k_din_tail")
+
+
+def test_config4_deepfm_v2_27m_row_table(torch):
+    tables = _check(torch, "deepfm_v2_c4", 65536, "k_deepfm_v2_joint")
+    assert tables > 6.9e9                                                              # the 27 M x 64 table really lives on the device
+
+
+def test_config4_pair_dot_deepfm_27m_row_table(torch):
+    """DeepFM.py:100-103 at emb_dim 64: the fold does not apply, 256-byte rows are gathered out of the 6.9 GB table."""
+    tables = _check(torch, "deepfm_c4", 65536, "k_tile_forward")
+    assert tables > 6.9e9
+
+
+def test_config5_wide_and_deep_10m_bucket_cross(torch):
+    tables = _check(torch, "widedeep_c5", 131072, "k_mlp_rows")
+    assert tables > 1.28e9
+
+
+def test_config5_hashed_buckets_bit_exact_at_stated_size(torch):
+    """The cross hash alone, 131 072 pairs into 10 M buckets: device == oracle, bit for bit."""
+    import ctypes as C
+    from oracle import ctr_oracle as O
+    from sparrowrecsys_amd import _lib as L, synthetic as SY
+    B = 131072
+    rng = np.random.default_rng(2)
+    a = rng.integers(0, SY.ML20M_MOVIE_IDS, B).astype(np.int32)
+    b = rng.integers(0, SY.ML20M_MOVIE_IDS, B).astype(np.int32)
+    ta, tb = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
+    out = torch.empty(B, dtype=torch.int64, device="cuda")
+    lib = L.load_library()
+    L.check(lib.sprk_cross_hash(C.c_void_p(ta.data_ptr()), C.c_void_p(tb.data_ptr()), B, 10_000_000, C.c_void_p(out.data_ptr()), None))
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(out.cpu().numpy(), O.crossed_bucket_np([a.astype(np.int64), b.astype(np.int64)], 10_000_000))
