@@ -37,6 +37,14 @@ __device__ __forceinline__ void dyn_split8(f32x4 x, f32x4 y, float scale, din_f1
             asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "+v"(l[e >> 1]) : "v"(v), "v"(scale), "v"(h[e >> 1]));
         }
     }
+    // HAZARD GUARD.  The eight dwords above were written by VALU instructions INSIDE asm statements, which hipcc's hazard
+    // recognizer does not see: it pads nothing between such a write and an MFMA that reads the register as its B operand
+    // (a VALU write of a VGPR needs 2 wait states before an MFMA reads it; for a compiler-visible producer hipcc inserts
+    // them).  Whether the pad happened to be there depended on how the scheduler interleaved the surrounding code: round 2's
+    // k_deepfm_pairs_many scheduled an MFMA straight behind the last v_fma_mixhi and read a half-updated operand (scores
+    // off by 7e-6 in one instantiation, exact in its twin) -- the same class as round 1's unexplained k_din_attn multi-batch
+    // failure.  One statement that owns all eight dwords and carries the wait states closes it for every user.
+    asm volatile("s_nop 1" : "+v"(h[0]), "+v"(h[1]), "+v"(h[2]), "+v"(h[3]), "+v"(l[0]), "+v"(l[1]), "+v"(l[2]), "+v"(l[3]));
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     hi = __builtin_bit_cast(din_f16x8, u32x4{h[0], h[1], h[2], h[3]});
     lo = __builtin_bit_cast(din_f16x8, u32x4{l[0], l[1], l[2], l[3]});

@@ -16,9 +16,13 @@
 //    and lost: 2 x 256 B more per sample made the kernel memory bound at 5.9 TB/s of actual traffic)
 //  * deep1 (K = 64) takes relu(deep0) from the registers it sits in (C/D layout = B layout); weights of both
 //    layers are read from LDS as A fragments; first-order weights: lane (r,q) fetches field q's and field q+4's.
-// deep0 on f32 MFMA; deep1 (data-dependent input range) on the f16 matrix pipe with a per-sample dynamic power-of-two
-// scale and hi + lo split operands (dyn_split.h; SPRK_DYN_F16=0: f32 MFMA); nothing but ids, rows and the score
-// touches memory.  The plan interpreter ran this graph in 40 us per 65 536 samples.
+// deep0's embedding columns (K = 32: the two deep fields' rows) and deep1 (K = 64) run on the f16 matrix pipe with a per-sample
+// dynamic power-of-two scale and hi + lo split operands (dyn_split.h; SPRK_DYN_F16=0: f32 MFMA); the numerics (up to 67 000
+// next to values of order 1) stay on f32 MFMA, K = 8 as two steps (k = q + 4s); nothing but ids, rows and the score touches
+// memory.  Round 2: the prologue no longer serialises weight staging -> ids -> rows (ids of a wave's first two tasks are
+// requested first, the weight image arrives by LDS-DMA inside their latency, and at two tasks per wave -- B = 65 536 on a full
+// chip -- both gathers are issued before the first scoring stage).  The plan interpreter ran this graph in 40 us per 65 536
+// samples, round 1's version of this kernel in 15.8.
 
 #define V1_MAX_FIELDS 8
 #define V1_MAX_DEEP 2
@@ -42,6 +46,9 @@ struct V1Run {
     float head_bias;
     const float* w1frag;                  // DYN: deep1's W^T as split-f16 A fragments (dyn_split.h: k_dyn_pack_w), or NULL
     float inv_w1_scale;                   // DYN: 1 / their static power-of-two scale (0 = deep1 on f32 MFMA)
+    const float* w0frag;                  // DYN: deep0's embedding columns [H0][32] as split-f16 A fragments, or NULL
+    float inv_w0_scale;
+    const float* image;                   // the LDS image (k_v1_pack_image), staged by LDS-DMA
 };
 
 // One-time (finalize) kernel: deep0's W^T columns -> [H0][16*(V1_MAX_DEEP+1)]: chunk g < n_deep = the Dp columns of deep
@@ -70,94 +77,101 @@ struct V1Many {
 template <int H0C, int H1C>
 struct V1Lds {
     static constexpr int H0 = H0C * 16, H1 = H1C * 16;
-    static constexpr int S1 = H0 + 4;                 // deep1 W^T row stride
-    static constexpr int K0 = 16 * (V1_MAX_DEEP + 1); // deep0's packed K: deep field chunks + numerics chunk
-    static constexpr int S0 = K0 + 4;                 // deep0 W^T row stride
-    static constexpr int off_w1 = 0;                  // [H1][S1]
-    static constexpr int off_w0 = off_w1 + H1 * S1;   // [H0][S0]
-    static constexpr int off_b0 = off_w0 + H0 * S0;   // [H0]
+    static constexpr int S1 = H0 + 4;                 // deep1 W^T row stride (f32 path)
+    static constexpr int SE = 32 + 4;                 // deep0 embedding-part W^T row stride (f32 path)
+    static constexpr int off_w1 = 0;                  // DYN: H1C*(H0C/2)*512 fragment floats; else [H1][S1]
+    static constexpr int off_w0e = off_w1 + H1 * S1;  // DYN: H0C*512 fragment floats (one K = 32 block); else [H0][SE]
+    static constexpr int off_w0n = off_w0e + H0 * SE; // [H0][8] numerics columns
+    static constexpr int off_b0 = off_w0n + H0 * 8;   // [H0]
     static constexpr int off_b1 = off_b0 + H0;        // [H1]
     static constexpr int off_hd = off_b1 + H1;        // [H1]
     static constexpr int total = off_hd + H1;
-    static constexpr size_t bytes = sizeof(float) * total;
+    static constexpr int total_pad = (total + 255) & ~255;
+    static constexpr size_t bytes = sizeof(float) * total_pad;
+    static_assert(H1C * (H0C / 2) * 512 <= H1 * S1 && H0C * 512 <= H0 * SE && H0C % 2 == 0, "fragments fit their regions");
 };
 
-// Task pipeline: the rows of task n+1 are in flight (in the gather registers) while task n is scored from copies;
-// its ids were fetched one task earlier still.  Everything the scoring stage reads besides its operands comes from
-// LDS (deep1's weights, biases): a global load there would sit behind the prefetched gather in the in-order vmcnt
-// queue and drain it.
-template <int NF, int NV, int H0C, int H1C, int WAVES, bool DYN, bool MB = false>
-__global__ __launch_bounds__(WAVES * 64, 2) void k_deepfm_pairs(const V1Run A, const int* __restrict__ ids0,
-                                                                const float* __restrict__ dense0, float* __restrict__ out0,
-                                                                int B, int* __restrict__ err, const V1Many M) {
+// One-time (finalize) kernel: the LDS image.  w0 = k_v1_pack_w0's [H0][48] (deep field chunks, numerics chunk).
+template <int H0C, int H1C>
+__global__ __launch_bounds__(256) void k_v1_pack_image(const V1Run A, float* __restrict__ img) {
     using LD = V1Lds<H0C, H1C>;
-    constexpr int H0 = H0C * 16;
+    const int tid = threadIdx.x, KW = 16 * (V1_MAX_DEEP + 1);
+    for (int i = tid; i < LD::total_pad; i += 256) img[i] = 0.f;
+    __syncthreads();
+    if (A.w1frag) {
+        for (int i = tid; i < H1C * (H0C / 2) * 512; i += 256) img[LD::off_w1 + i] = A.w1frag[i];
+    } else {
+        for (int i = tid; i < LD::H1 * LD::S1; i += 256) {
+            const int n = i / LD::S1, k = i - n * LD::S1;
+            img[LD::off_w1 + i] = k < LD::H0 ? A.W1[(size_t)n * A.ld1 + k] : 0.f;
+        }
+    }
+    if (A.w0frag) {
+        for (int i = tid; i < H0C * 512; i += 256) img[LD::off_w0e + i] = A.w0frag[i];
+    } else {
+        for (int i = tid; i < LD::H0 * LD::SE; i += 256) {
+            const int n = i / LD::SE, k = i - n * LD::SE;
+            img[LD::off_w0e + i] = k < 32 ? A.w0[(size_t)n * KW + k] : 0.f;
+        }
+    }
+    for (int i = tid; i < LD::H0 * 8; i += 256) img[LD::off_w0n + i] = A.w0[(size_t)(i >> 3) * KW + 16 * V1_MAX_DEEP + (i & 7)];
+    for (int i = tid; i < LD::H0; i += 256) img[LD::off_b0 + i] = A.b0[i];
+    for (int i = tid; i < LD::H1; i += 256) { img[LD::off_b1 + i] = A.b1[i]; img[LD::off_hd + i] = A.hdeep[i]; }
+}
+
+template <int NF>
+struct V1Set {
+    f32x4 x[NF];                          // every field's row piece
+    float xa, xb;                         // numerics q and q + 4
+    float w1a, w1b;                       // first-order weights fetched by this lane
+};
+
+template <int NF, int NV, int H0C, int H1C, int WAVES, bool DYN, bool MB>
+__device__ __forceinline__ void v1_body(const V1Run& A, const int* __restrict__ ids0, const float* __restrict__ dense0,
+                                        float* __restrict__ out0, int B, int* __restrict__ err, const V1Many* __restrict__ Mp) {
+    using LD = V1Lds<H0C, H1C>;
+    using Set = V1Set<NF>;
     static_assert(NF >= 2 && NF <= V1_MAX_FIELDS && NV >= 1 && NV <= 4, "shape");
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 15, q = lane >> 4;
     const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int ntasks = MB ? M.n * M.ntpb : (B + 15) >> 4;
+    const int m_ntpb = MB ? Mp->ntpb : 0;
+    const int ntasks = MB ? Mp->n * m_ntpb : (B + 15) >> 4;
     const int task_stride = gridDim.x * WAVES;
     bool bad = false;
     // MB: (batch, task inside the batch) of launch task t (wave-uniform)
     auto batch_of = [&](int t, int& tl) {
         if constexpr (MB) {
-            const int b = __builtin_amdgcn_readfirstlane(t / M.ntpb);
-            tl = t - b * M.ntpb;
+            const int b = __builtin_amdgcn_readfirstlane(t / m_ntpb);
+            tl = t - b * m_ntpb;
             return b;
         } else {
             tl = t;
             return 0;
         }
     };
-
-    // ---- one-time: both layers' W^T, biases, head weights -> LDS ----
-    if constexpr (DYN) {
-        static_assert(H1C * (H0C / 2) * 512 <= LD::H1 * LD::S1 && H0C % 2 == 0, "fragments fit W1's region");
-        for (int i = tid; i < H1C * (H0C / 2) * 512; i += WAVES * 64) smem[LD::off_w1 + i] = A.w1frag[i];
-    } else {
-        for (int i = tid; i < LD::H1 * LD::S1; i += WAVES * 64) {
-            const int n = i / LD::S1, k = i - n * LD::S1;
-            smem[LD::off_w1 + i] = k < H0 ? A.W1[(size_t)n * A.ld1 + k] : 0.f;
-        }
-    }
-    for (int i = tid; i < H0 * LD::S0; i += WAVES * 64) {
-        const int n = i / LD::S0, k = i - n * LD::S0;
-        smem[LD::off_w0 + i] = k < LD::K0 ? A.w0[(size_t)n * LD::K0 + k] : 0.f;
-    }
-    for (int i = tid; i < H0; i += WAVES * 64) smem[LD::off_b0 + i] = A.b0[i];
-    for (int i = tid; i < LD::H1; i += WAVES * 64) { smem[LD::off_b1 + i] = A.b1[i]; smem[LD::off_hd + i] = A.hdeep[i]; }
-    __syncthreads();
-    __builtin_amdgcn_s_waitcnt(0x0F70);                      // one-time loads have landed before the pipelined loop
-
-    // ---- gather registers (task n+1) ----
-    int idv[NF];
-    f32x4 gx[NF], gxn = zero;
-    float gw1a = 0.f, gw1b = 0.f;
-    auto ld_ids = [&](int tg) {
+    auto ld_ids = [&](int tg, int (&idv)[NF]) {
         int t;
         const int bi = batch_of(tg, t);
-        const int* ids = MB ? M.ids[bi] : ids0;
+        const int* ids = MB ? Mp->ids[bi] : ids0;
         const int m = min(t * 16 + r, B - 1);                    // rows past the end re-read the last sample, never stored
         const int* row = ids + (size_t)m * A.F;
 #pragma unroll
         for (int f = 0; f < NF; ++f) idv[f] = row[A.col[f]];
     };
-    auto issue_gather = [&](int tg) {
+    auto issue_gather = [&](int tg, const int (&idv)[NF], Set& S) {
         int t;
         const int bi = batch_of(tg, t);
-        const float* dense = MB ? M.dense[bi] : dense0;
+        const float* dense = MB ? Mp->dense[bi] : dense0;
         const int m = min(t * 16 + r, B - 1);
         {
             const float* nrow = dense + (size_t)m * A.ND;
             const int last = A.n_num - 1;
             // slots beyond n_num hold a duplicate finite value that only ever meets zero weights
-            gxn.x = nrow[min(4 * q + 0, last)];
-            gxn.y = nrow[min(4 * q + 1, last)];
-            gxn.z = nrow[min(4 * q + 2, last)];
-            gxn.w = nrow[min(4 * q + 3, last)];
+            S.xa = nrow[min(q, last)];
+            S.xb = nrow[min(q + 4, last)];
         }
         unsigned sid[NF];
 #pragma unroll
@@ -166,71 +180,83 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_deepfm_pairs(const V1Run A, c
             sid[f] = min((unsigned)idv[f], (unsigned)A.vocab[f]);              // -1 / out of range -> the zero row at index vocab
         }
 #pragma unroll
-        for (int f = 0; f < NF; ++f) gx[f] = q < NV ? ld4(A.table[f] + (size_t)sid[f] * A.row_floats + 4 * q) : zero;
+        for (int f = 0; f < NF; ++f) S.x[f] = q < NV ? ld4(A.table[f] + (size_t)sid[f] * A.row_floats + 4 * q) : zero;
         {
             // first order: lane (r,q) fetches field q's weight, then field q+4's
             const float* pa = A.w1[0] + sid[0];
             if (NF > 1) pa = q == 1 ? A.w1[NF > 1 ? 1 : 0] + sid[NF > 1 ? 1 : 0] : pa;
             if (NF > 2) pa = q == 2 ? A.w1[NF > 2 ? 2 : 0] + sid[NF > 2 ? 2 : 0] : pa;
             if (NF > 3) pa = q == 3 ? A.w1[NF > 3 ? 3 : 0] + sid[NF > 3 ? 3 : 0] : pa;
-            gw1a = (q < NF) ? *pa : 0.f;
+            S.w1a = (q < NF) ? *pa : 0.f;
+            S.w1b = 0.f;
             if (NF > 4) {
                 const float* pb = A.w1[NF > 4 ? 4 : 0] + sid[NF > 4 ? 4 : 0];
                 if (NF > 5) pb = q == 1 ? A.w1[NF > 5 ? 5 : 0] + sid[NF > 5 ? 5 : 0] : pb;
                 if (NF > 6) pb = q == 2 ? A.w1[NF > 6 ? 6 : 0] + sid[NF > 6 ? 6 : 0] : pb;
                 if (NF > 7) pb = q == 3 ? A.w1[NF > 7 ? 7 : 0] + sid[NF > 7 ? 7 : 0] : pb;
-                gw1b = (q + 4 < NF) ? *pb : 0.f;
+                S.w1b = (q + 4 < NF) ? *pb : 0.f;
             }
         }
     };
-
-    int tk = blockIdx.x * WAVES + wave;
-    if (tk < ntasks) {
-        ld_ids(tk);
-        issue_gather(tk);
-        if (tk + task_stride < ntasks) ld_ids(tk + task_stride);
-    }
-    for (; tk < ntasks; tk += task_stride) {
-        // ---- hand-off: this task's operands out of the gather registers ----
-        f32x4 x[NF], h0[H0C];
-#pragma unroll
-        for (int f = 0; f < NF; ++f) x[f] = gx[f];
-#pragma unroll
-        for (int nb = 0; nb < H0C; ++nb) h0[nb] = ld4(smem + LD::off_b0 + nb * 16 + 4 * q);
-        const f32x4 xn = gxn;
-        float z = gw1a + gw1b;
-        if (tk + task_stride < ntasks) {                          // next task's rows fly under this task's arithmetic
-            issue_gather(tk + task_stride);
-            if (tk + 2 * task_stride < ntasks) ld_ids(tk + 2 * task_stride);
-        }
+    float rna[H0C], rnb[H0C];             // numerics' A operands: rows (nb*16 + r) of W0[:, numerics]^T, columns q and q + 4
+    auto compute = [&](const Set& S) -> float {
+#pragma clang fp contract(off)
+        float z = S.w1a + S.w1b;
         // ---- pair dots (per-lane partials; the sum over q is part of the final reduction) ----
 #pragma unroll
         for (int a = 0; a < NF; ++a)
 #pragma unroll
             for (int b = a + 1; b < NF; ++b) {
                 const float hw = A.pw[a * V1_MAX_FIELDS + b];       // wave-uniform (SGPR); zero when (a,b) is not a pair
-                const f32x4 p = x[a] * x[b];
+                const f32x4 p = S.x[a] * S.x[b];
                 z = fmaf(hw, (p.x + p.y) + (p.z + p.w), z);
             }
-        // ---- deep0 (DeepFM.py:106-107): the deep fields' row pieces and the numerics as B operands, A fragments from
-        //      LDS (the offset passes through a volatile asm so that the loop-invariant reads are not hoisted) ----
-        int w0o = LD::off_w0 + r * LD::S0 + 4 * q;
-        asm volatile("" : "+v"(w0o));
+        // ---- deep0 (DeepFM.py:106-107): bias + numerics on f32 MFMA, the deep fields' rows on split f16 ----
+        f32x4 h0[H0C];
 #pragma unroll
-        for (int c = 0; c <= V1_MAX_DEEP; ++c) {
-            if (c < V1_MAX_DEEP && c >= A.n_deep) continue;       // wave-uniform
-            const f32x4 bop = c < V1_MAX_DEEP ? x[c < NF ? c : 0] : xn;
-            f32x4 a[H0C];
+        for (int nb = 0; nb < H0C; ++nb) h0[nb] = ld4(smem + LD::off_b0 + nb * 16 + 4 * q);
+#pragma unroll
+        for (int nb = 0; nb < H0C; ++nb) h0[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(rna[nb], S.xa, h0[nb], 0, 0, 0);
+#pragma unroll
+        for (int nb = 0; nb < H0C; ++nb) h0[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(rnb[nb], S.xb, h0[nb], 0, 0, 0);
+        const f32x4 e0 = S.x[0], e1 = A.n_deep > 1 ? S.x[1] : zero;
+        if constexpr (DYN) {
+            float mx = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) mx = fmaxf(mx, fmaxf(__builtin_fabsf(e0[j]), __builtin_fabsf(e1[j])));
+            mx = rows4_max(mx);
+            float scale, inv;
+            dyn_scale(mx, A.inv_w0_scale, scale, inv);
+            din_f16x8 bh, bl;
+            dyn_split8(e0, e1, scale, bh, bl);
+            int wfo = LD::off_w0e + (r * 4 + q) * 4;              // this lane's 16 bytes inside a 1-KB fragment
+            asm volatile("" : "+v"(wfo));                         // (keeps the loop-invariant LDS reads inside the task loop)
+            f32x4 acc[H0C];
 #pragma unroll
             for (int nb = 0; nb < H0C; ++nb) {
-                a[nb] = ld4(smem + w0o + nb * 16 * LD::S0 + 16 * c);
-                if (c == V1_MAX_DEEP && q >= 2) a[nb] = zero;     // the numeric chunk is 8 wide: k = 4q + s < 8
+                const din_f16x8 ah = __builtin_bit_cast(din_f16x8, ld4(smem + wfo + (nb * 2 + 0) * 256));
+                const din_f16x8 al = __builtin_bit_cast(din_f16x8, ld4(smem + wfo + (nb * 2 + 1) * 256));
+                acc[nb] = mfma_f16(ah, bh, zero);
+                acc[nb] = mfma_f16(ah, bl, acc[nb]);
+                acc[nb] = mfma_f16(al, bh, acc[nb]);
             }
 #pragma unroll
-            for (int st = 0; st < 4; ++st)
+            for (int nb = 0; nb < H0C; ++nb) h0[nb] = acc[nb] * inv + h0[nb];
+        } else {
+            int w0o = LD::off_w0e + r * LD::SE + 4 * q;
+            asm volatile("" : "+v"(w0o));
 #pragma unroll
-                for (int nb = 0; nb < H0C; ++nb)
-                    h0[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[nb][st], bop[st], h0[nb], 0, 0, 0);
+            for (int c = 0; c < 2; ++c) {
+                const f32x4 bop = c == 0 ? e0 : e1;
+                f32x4 a[H0C];
+#pragma unroll
+                for (int nb = 0; nb < H0C; ++nb) a[nb] = ld4(smem + w0o + nb * 16 * LD::SE + 16 * c);
+#pragma unroll
+                for (int st = 0; st < 4; ++st)
+#pragma unroll
+                    for (int nb = 0; nb < H0C; ++nb)
+                        h0[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[nb][st], bop[st], h0[nb], 0, 0, 0);
+            }
         }
 #pragma unroll
         for (int nb = 0; nb < H0C; ++nb) h0[nb] = relu4_fast(h0[nb]);
@@ -242,15 +268,15 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_deepfm_pairs(const V1Run A, c
 #pragma unroll
             for (int nb = 0; nb < H0C; ++nb)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) mx = fmaxf(mx, __builtin_fabsf(h0[nb][j]));
+                for (int j = 0; j < 4; ++j) mx = fmaxf(mx, h0[nb][j]);
             mx = rows4_max(mx);
             float scale, inv;
             dyn_scale(mx, A.inv_w1_scale, scale, inv);
             f32x4 acc[H1C];
 #pragma unroll
             for (int n1 = 0; n1 < H1C; ++n1) acc[n1] = zero;
-            int wfo = LD::off_w1 + (r * 4 + q) * 4;               // this lane's 16 bytes inside a 1-KB fragment
-            asm volatile("" : "+v"(wfo));                         // (keeps the loop-invariant LDS reads inside the task loop)
+            int wfo = LD::off_w1 + (r * 4 + q) * 4;
+            asm volatile("" : "+v"(wfo));
 #pragma unroll
             for (int b = 0; b < H0C / 2; ++b) {
                 din_f16x8 bh, bl;
@@ -268,30 +294,87 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_deepfm_pairs(const V1Run A, c
             for (int n1 = 0; n1 < H1C; ++n1) h1[n1] = acc[n1] * inv + ld4(smem + LD::off_b1 + n1 * 16 + 4 * q);
         } else {
 #pragma unroll
-        for (int n1 = 0; n1 < H1C; ++n1) h1[n1] = ld4(smem + LD::off_b1 + n1 * 16 + 4 * q);
-        // (the offset passes through a volatile asm so that the loop-invariant LDS reads are not hoisted into 64 registers)
-        int w1o = LD::off_w1 + r * LD::S1 + 4 * q;
-        asm volatile("" : "+v"(w1o));
+            for (int n1 = 0; n1 < H1C; ++n1) h1[n1] = ld4(smem + LD::off_b1 + n1 * 16 + 4 * q);
+            // (the offset passes through a volatile asm so that the loop-invariant LDS reads are not hoisted into 64 registers)
+            int w1o = LD::off_w1 + r * LD::S1 + 4 * q;
+            asm volatile("" : "+v"(w1o));
 #pragma unroll
-        for (int c = 0; c < H0C; ++c) {
-            f32x4 a[H1C];
+            for (int c = 0; c < H0C; ++c) {
+                f32x4 a[H1C];
 #pragma unroll
-            for (int n1 = 0; n1 < H1C; ++n1) a[n1] = ld4(smem + w1o + n1 * 16 * LD::S1 + 16 * c);
+                for (int n1 = 0; n1 < H1C; ++n1) a[n1] = ld4(smem + w1o + n1 * 16 * LD::S1 + 16 * c);
 #pragma unroll
-            for (int st = 0; st < 4; ++st)
+                for (int st = 0; st < 4; ++st)
 #pragma unroll
-                for (int n1 = 0; n1 < H1C; ++n1)
-                    h1[n1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[n1][st], h0[c][st], h1[n1], 0, 0, 0);
+                    for (int n1 = 0; n1 < H1C; ++n1)
+                        h1[n1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[n1][st], h0[c][st], h1[n1], 0, 0, 0);
+            }
         }
-        }
 #pragma unroll
-        for (int n1 = 0; n1 < H1C; ++n1) z += dot4(ld4(smem + LD::off_hd + n1 * 16 + 4 * q), relu4_fast(h1[n1]));
+        for (int n1 = 0; n1 < H1C; ++n1) {
+            const f32x4 hd = ld4(smem + LD::off_hd + n1 * 16 + 4 * q), hr = relu4_fast(h1[n1]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) z = fmaf(hd[j], hr[j], z);
+        }
         z = rows4_sum(z);
+        return sigmoidf_acc(z + A.head_bias);
+    };
+    auto store = [&](int tg, float score) {
         int tl;
-        const int bo = batch_of(tk, tl);
-        float* out = MB ? M.out[bo] : out0;
+        const int bo = batch_of(tg, tl);
+        float* out = MB ? Mp->out[bo] : out0;
         const int mm = tl * 16 + r;
-        if (q == 0 && mm < B) out[mm] = sigmoidf_acc(z + A.head_bias);
+        if (q == 0 && mm < B) out[mm] = score;
+    };
+
+    // ---- prologue: ids of this wave's first two tasks, then the weight image by LDS-DMA inside their latency ----
+    int tA = blockIdx.x * WAVES + wave, tB = tA + task_stride;
+    int idA[NF], idB[NF];
+#pragma unroll
+    for (int f = 0; f < NF; ++f) { idA[f] = -1; idB[f] = -1; }
+    if (tA < ntasks) ld_ids(tA, idA);
+    if (tB < ntasks) ld_ids(tB, idB);
+#pragma unroll 1
+    for (int c = wave; c < LD::total_pad / 256; c += WAVES)
+        __builtin_amdgcn_global_load_lds(
+            (const __attribute__((address_space(1))) void*)(A.image + c * 256 + lane * 4),
+            (__attribute__((address_space(3))) void*)(smem + c * 256), 16, 0, 0);
+    __builtin_amdgcn_s_waitcnt(0x0F70);                          // vmcnt(0): ids and this wave's DMA pieces
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int nb = 0; nb < H0C; ++nb) {
+        rna[nb] = smem[LD::off_w0n + (nb * 16 + r) * 8 + q];
+        rnb[nb] = smem[LD::off_w0n + (nb * 16 + r) * 8 + q + 4];
+    }
+    Set SA, SB;
+    if (tA >= ntasks) {
+        // a wave without work leaves after the barrier
+    } else if (ntasks <= 2 * task_stride) {
+        // at most two tasks per wave (B <= 65 536 on a full chip): both gathers in flight before the first scoring stage
+        issue_gather(tA, idA, SA);
+        if (tB < ntasks) issue_gather(tB, idB, SB);
+        store(tA, compute(SA));
+        if (tB < ntasks) store(tB, compute(SB));
+    } else {
+        issue_gather(tA, idA, SA);
+        for (int tk = tA; tk < ntasks; tk += task_stride) {
+            const Set cur = SA;
+            if (tk + task_stride < ntasks) {                      // next task's rows fly under this task's arithmetic
+                issue_gather(tk + task_stride, idB, SA);
+                if (tk + 2 * task_stride < ntasks) ld_ids(tk + 2 * task_stride, idB);
+            }
+            store(tk, compute(cur));
+        }
     }
     if (__ballot(bad) != 0 && lane == 0) atomicOr(err, 1);
+}
+
+template <int NF, int NV, int H0C, int H1C, int WAVES, bool DYN>
+__global__ __launch_bounds__(WAVES * 64, 2) void k_deepfm_pairs(const V1Run A, const int* __restrict__ ids, const float* __restrict__ dense,
+                                                                float* __restrict__ out, int B, int* __restrict__ err) {
+    v1_body<NF, NV, H0C, H1C, WAVES, DYN, false>(A, ids, dense, out, B, err, nullptr);
+}
+template <int NF, int NV, int H0C, int H1C, int WAVES, bool DYN>
+__global__ __launch_bounds__(WAVES * 64, 2) void k_deepfm_pairs_many(const V1Run A, const V1Many M, int B, int* __restrict__ err) {
+    v1_body<NF, NV, H0C, H1C, WAVES, DYN, true>(A, nullptr, nullptr, nullptr, B, err, &M);
 }

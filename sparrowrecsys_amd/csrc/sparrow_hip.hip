@@ -1583,21 +1583,18 @@ typedef void (*V1LaunchManyFn)(const V1Run&, const V1Many&, int, int*, int, hipS
 template <int NF, int NV>
 void v1_launch(const V1Run& a, const int* ids, const float* dense, float* out, int B, int* err, int grid, hipStream_t st) {
     const size_t lds = V1Lds<4, 4>::bytes;
-    static const V1Many none{};
     if (a.inv_w1_scale != 0.f)
-        hipLaunchKernelGGL((k_deepfm_pairs<NF, NV, 4, 4, V1_WAVES, true, false>), dim3(grid), dim3(V1_WAVES * 64), lds, st, a, ids, dense, out, B, err, none);
+        hipLaunchKernelGGL((k_deepfm_pairs<NF, NV, 4, 4, V1_WAVES, true>), dim3(grid), dim3(V1_WAVES * 64), lds, st, a, ids, dense, out, B, err);
     else
-        hipLaunchKernelGGL((k_deepfm_pairs<NF, NV, 4, 4, V1_WAVES, false, false>), dim3(grid), dim3(V1_WAVES * 64), lds, st, a, ids, dense, out, B, err, none);
+        hipLaunchKernelGGL((k_deepfm_pairs<NF, NV, 4, 4, V1_WAVES, false>), dim3(grid), dim3(V1_WAVES * 64), lds, st, a, ids, dense, out, B, err);
 }
 template <int NF, int NV>
 void v1_launch_many(const V1Run& a, const V1Many& m, int B, int* err, int grid, hipStream_t st) {
     const size_t lds = V1Lds<4, 4>::bytes;
     if (a.inv_w1_scale != 0.f)
-        hipLaunchKernelGGL((k_deepfm_pairs<NF, NV, 4, 4, V1_WAVES, true, true>), dim3(grid), dim3(V1_WAVES * 64), lds, st, a,
-                           (const int*)nullptr, (const float*)nullptr, (float*)nullptr, B, err, m);
+        hipLaunchKernelGGL((k_deepfm_pairs_many<NF, NV, 4, 4, V1_WAVES, true>), dim3(grid), dim3(V1_WAVES * 64), lds, st, a, m, B, err);
     else
-        hipLaunchKernelGGL((k_deepfm_pairs<NF, NV, 4, 4, V1_WAVES, false, true>), dim3(grid), dim3(V1_WAVES * 64), lds, st, a,
-                           (const int*)nullptr, (const float*)nullptr, (float*)nullptr, B, err, m);
+        hipLaunchKernelGGL((k_deepfm_pairs_many<NF, NV, 4, 4, V1_WAVES, false>), dim3(grid), dim3(V1_WAVES * 64), lds, st, a, m, B, err);
 }
 struct V1Variant { int nf, nv; V1LaunchFn launch; V1LaunchManyFn launch_many; };
 const V1Variant kV1Variants[] = {
@@ -1730,13 +1727,24 @@ int setup_deepfm_pairs(sprk_engine* h) {
     r.w0 = w0p; r.b0 = (const float*)h->slot_ptr[o0.b_slot];
     r.W1 = (const float*)h->slot_ptr[o1.w_slot]; r.ld1 = o1.ldw; r.b1 = (const float*)h->slot_ptr[o1.b_slot];
     r.hdeep = hd; r.head_bias = p.head_bias;
-    r.w1frag = nullptr; r.inv_w1_scale = 0.f;
+    r.w1frag = nullptr; r.inv_w1_scale = 0.f; r.w0frag = nullptr; r.inv_w0_scale = 0.f;
     {
-        float w_scale = 0.f;
-        float* frag = nullptr;
-        const int rc2 = make_dyn_fragments(h, r.W1, r.ld1, H1, H0, &frag, &w_scale);
+        // DYN: deep1's kernel and the embedding columns of deep0's (the first 32 of the packed 48) as split-f16 fragments
+        float w_scale = 0.f, w0_scale = 0.f;
+        float *frag = nullptr, *frag0 = nullptr;
+        int rc2 = make_dyn_fragments(h, r.W1, r.ld1, H1, H0, &frag, &w_scale);
         if (rc2) return rc2;
-        if (frag) { r.w1frag = frag; r.inv_w1_scale = 1.0f / w_scale; }
+        if (frag && (rc2 = make_dyn_fragments(h, w0p, 16 * (V1_MAX_DEEP + 1), H0, 32, &frag0, &w0_scale))) return rc2;
+        if (frag && frag0) { r.w1frag = frag; r.inv_w1_scale = 1.0f / w_scale; r.w0frag = frag0; r.inv_w0_scale = 1.0f / w0_scale; }
+    }
+    {
+        float* img = nullptr;
+        HIP_TRY(hipMalloc((void**)&img, V1Lds<4, 4>::bytes));
+        h->v1_bufs.push_back(img);
+        hipLaunchKernelGGL((k_v1_pack_image<4, 4>), dim3(1), dim3(256), 0, 0, r, img);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipDeviceSynchronize());
+        r.image = img;
     }
     h->v1_run = r;
     h->v1_variant = variant;
