@@ -158,6 +158,8 @@ __device__ __forceinline__ float rows4_sum(float v) {
 // f16 MFMA over a lane's EL = 4 or 8 operand halfs (K = 16 or 32)
 typedef _Float16 din_f16x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 din_f16x8 __attribute__((ext_vector_type(8)));
+// (x0..x3 | y0..y3) * scale -> packed hi / lo halfs; defined in dyn_split.h (which follows this file and uses its typedefs)
+__device__ __forceinline__ void dyn_split8(f32x4 x, f32x4 y, float scale, din_f16x8& hi, din_f16x8& lo);
 __device__ __forceinline__ f32x4 mfma_f16(din_f16x4 a, din_f16x4 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x16f16(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ f32x4 mfma_f16(din_f16x8 a, din_f16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
 
@@ -188,22 +190,28 @@ __device__ __forceinline__ void unpack_halfs(const f32x4* x, _Float16 __attribut
     }
 }
 
-template <int KC, int HC>
+template <int KC, int HC, int WPB = 4>
 struct DinLds {
     static constexpr int KP = KC * 16, HP = HC * 16;
     static constexpr int hs = KP + 4;           // history-row stride (floats): 16-B aligned, (hs/4) odd
     static constexpr int as = HP + 4;           // alpha-row stride
     static constexpr int rows = 64;             // T <= 64, padded to whole 16-row groups
     static constexpr int alpha_floats = 2 * rows * as;      // two coefficient tables (see the epilogue)
+    static constexpr int w_floats = 2 * HC * KC * 256;       // W12 / W4 fragments in lane order: [w12 | w4][nb][c][lane] float4
     static constexpr int wave_floats = rows * hs;            // Hs tile
-    static constexpr size_t bytes = sizeof(float) * (alpha_floats + 4 * wave_floats);
+    static constexpr size_t bytes = sizeof(float) * (alpha_floats + w_floats + WPB * wave_floats);
 };
 
-template <int KC, int HC, int NP, bool HALF>
-__global__ __launch_bounds__(256, 2) void k_din_attn(const DinRun A, const int* __restrict__ ids,
+// WPB waves per workgroup: 4 (two workgroups per CU, 2 waves per SIMD: round 1) or 12 (ONE workgroup per CU, 3 waves per SIMD).
+// The kernel is bound by its per-sample dependency chains (LDS tile -> MFMA chain -> PReLU/Dense(1) sum -> cross-lane sum ->
+// sigmoid -> pooling), not by VALU issue (cutting 14 % of the VALU instructions changed nothing), MFMA (13 % busy) or memory
+// (2.8 TB/s at the fabric): the lever is more waves per SIMD, and what stood in the way was 220 VGPRs -- the resident W12 / W4
+// fragments now live in LDS (8 ds_read_b128 per sample) and the PReLU coefficient rows are read after the MFMAs, not before.
+template <int KC, int HC, int NP, bool HALF, int WPB = 4>
+__global__ __launch_bounds__(WPB * 64, WPB / 4 == 1 ? 2 : WPB / 4) void k_din_attn(const DinRun A, const int* __restrict__ ids,
                                                      float* __restrict__ pooled, float* __restrict__ att, int B,
                                                      int* __restrict__ err) {
-    using LD = DinLds<KC, HC>;
+    using LD = DinLds<KC, HC, WPB>;
     constexpr int KP = LD::KP, HP = LD::HP, hs = LD::hs, as = LD::as;
     static_assert(NP >= 1 && NP <= 8 && KC <= 2, "the 8-pass row gather covers 64 rows only for rows of <= 8 pieces");
     const int tid = threadIdx.x;
@@ -217,7 +225,8 @@ __global__ __launch_bounds__(256, 2) void k_din_attn(const DinRun A, const int* 
     const int G = (T + 15) >> 4;                         // 16-row groups
     const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
     float* alpha_s = smem;
-    float* Hs = smem + LD::alpha_floats + wave * LD::wave_floats;
+    float* wfrag_s = smem + LD::alpha_floats;
+    float* Hs = smem + LD::alpha_floats + LD::w_floats + wave * LD::wave_floats;
     // first row element of this lane's c-th 4-float operand piece: the f32 MFMA steps through k = 16c + 4q + s,
     // the f16 MFMA takes EL = 4*KC consecutive elements k = EL*q .. EL*q + EL-1 per lane
     constexpr int EL = 4 * KC;
@@ -230,7 +239,7 @@ __global__ __launch_bounds__(256, 2) void k_din_attn(const DinRun A, const int* 
     //   w2 (max(u,0) + alpha min(u,0)) = ca u + cb |u|,  ca = w2 (1 + alpha) / 2,  cb = w2 (1 - alpha) / 2
     // (max(u,0) = (u + |u|)/2, min(u,0) = (u - |u|)/2): two FMAs per element, |u| is a free source modifier
     float* cb_s = alpha_s + LD::rows * as;
-    for (int i = tid; i < LD::rows * as; i += 256) {
+    for (int i = tid; i < LD::rows * as; i += WPB * 64) {
         const int t = i / as, n = i - t * as;
         const bool ok = t < T && n < HP;
         const float al = ok ? A.alpha[(size_t)t * HP + n] : 0.f;
@@ -238,15 +247,18 @@ __global__ __launch_bounds__(256, 2) void k_din_attn(const DinRun A, const int* 
         alpha_s[i] = 0.5f * w2 * (1.0f + al);
         cb_s[i] = 0.5f * w2 * (1.0f - al);
     }
-    // resident weight fragments: lane (r,q) holds W[n = nb*16 + r][k = 16c + 4q .. +3]
-    f32x4 w12f[HC][KC], w4f[HC][KC];
+    // W12 / W4 fragments: lane (r,q) needs W[n = nb*16 + r][kof(c) .. +3]; wave 0 lays them out in LDS in lane order, every
+    // sample reads them back with conflict-free ds_read_b128 (they were 32 resident registers in round 1)
+    if (wave == 0) {
 #pragma unroll
-    for (int nb = 0; nb < HC; ++nb) {
+        for (int nb = 0; nb < HC; ++nb)
 #pragma unroll
-        for (int c = 0; c < KC; ++c) {
-            w12f[nb][c] = ld4(A.w12 + (size_t)(nb * 16 + r) * KP + kof(c));
-            w4f[nb][c] = ld4(A.w4 + (size_t)(nb * 16 + r) * KP + kof(c));
-        }
+            for (int c = 0; c < KC; ++c) {
+                f32x4 w4v = ld4(A.w4 + (size_t)(nb * 16 + r) * KP + kof(c));
+                if constexpr (HALF && KC == 2) w4v = w4v * A.inv_h_scale;           // meets the candidate's SCALED halfs (c * 2^sH)
+                st4(wfrag_s + ((nb * KC + c) * 64 + lane) * 4, ld4(A.w12 + (size_t)(nb * 16 + r) * KP + kof(c)));
+                st4(wfrag_s + ((HC * KC + nb * KC + c) * 64 + lane) * 4, w4v);
+            }
     }
     __syncthreads();
     // the one-time loads above have landed before the pipelined loop starts: otherwise the compiler,
@@ -254,28 +266,24 @@ __global__ __launch_bounds__(256, 2) void k_din_attn(const DinRun A, const int* 
     // first use of a weight fragment inside the loop
     __builtin_amdgcn_s_waitcnt(0x0F70);                      // s_waitcnt vmcnt(0)
 
-    const int stride = gridDim.x * 4;
-    int s = blockIdx.x * 4 + wave;
+    const int stride = gridDim.x * WPB;
+    int s = blockIdx.x * WPB + wave;
     bool bad = false;
     // Software pipeline over this wave's samples: the rows of sample n+1 are in flight (in registers)
     // while sample n is scored from the LDS tile; its ids were fetched one sample earlier still.
     // Gather pass p covers history slots p*RPP .. p*RPP+RPP-1, NV lanes (16-B pieces) per row.
     // NP passes (compile time, >= ceil(T / RPP)): no control flow inside the gather, so every load of a
     // sample is in flight together and the compiler can count them (s_waitcnt vmcnt is in-order).
-    int prow[NP];                         // this lane's history slot in pass p (clamped)
-    bool pok[NP];                         // ... and whether it stores what it loaded
-#pragma unroll
-    for (int p = 0; p < NP; ++p) {
-        const int row = p * RPP + lrow;
-        pok[p] = lrow < RPP && row < T;
-        prow[p] = row < T ? row : T - 1;
-    }
+    // this lane's history slot in pass p (clamped) and whether it stores what it loaded: recomputed where used (two VALU each)
+    // rather than held in 2 NP registers across the sample loop
+    auto prow = [&](int p) { const int row = p * RPP + lrow; return row < T ? row : T - 1; };
+    auto pok = [&](int p) { return lrow < RPP && p * RPP + lrow < T; };
     int hid[NP], cid = 0;                 // ids of the sample whose rows are issued next
     f32x4 v[NP], cvn[KC], vcn[HC];         // rows / candidate row / vc row of the sample scored next
     auto ld_ids = [&](int b) {
         const int* row = ids + (size_t)b * F;
 #pragma unroll
-        for (int p = 0; p < NP; ++p) hid[p] = row[A.hist_col + prow[p]];
+        for (int p = 0; p < NP; ++p) hid[p] = row[A.hist_col + prow(p)];
         cid = row[A.cand_col];
     };
     auto issue_rows = [&]() {
@@ -311,9 +319,9 @@ __global__ __launch_bounds__(256, 2) void k_din_attn(const DinRun A, const int* 
         // ---- hand-off: this sample's rows -> LDS tile, candidate-side operands -> registers ----
 #pragma unroll
         for (int p = 0; p < NP; ++p)
-            if (pok[p]) st4(Hs + prow[p] * hs + 4 * piece, v[p]);
+            if (pok(p)) st4(Hs + prow(p) * hs + 4 * piece, v[p]);
         f32x4 cv[KC], acc_init[HC];
-        if constexpr (HALF) {
+        if constexpr (HALF && KC != 2) {
             // candidate row back to f32 from its halfs: c[EL*q + e] = (hi + lo) * 2^-sH
             f16xe chi, clo;
             unpack_halfs<KC>(cvn, chi, clo);
@@ -321,6 +329,9 @@ __global__ __launch_bounds__(256, 2) void k_din_attn(const DinRun A, const int* 
             for (int c = 0; c < KC; ++c)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) cv[c][j] = ((float)chi[4 * c + j] + (float)clo[4 * c + j]) * A.inv_h_scale;
+        } else if constexpr (HALF) {
+#pragma unroll
+            for (int c = 0; c < KC; ++c) cv[c] = cvn[c];          // KC == 2: the packed halfs themselves (piece 0 = hi, piece 1 = lo), see below
         } else {
 #pragma unroll
             for (int c = 0; c < KC; ++c) cv[c] = cvn[c];
@@ -331,25 +342,58 @@ __global__ __launch_bounds__(256, 2) void k_din_attn(const DinRun A, const int* 
             issue_rows();
             if (s + 2 * stride < B) ld_ids(s + 2 * stride);
         }
-        // A_b = W12 + W4 diag(c)
+        // A_b = W12 + W4 diag(c); the weight fragments come from LDS (lane-ordered, conflict free)
+        f32x4 w12f[HC][KC], w4f[HC][KC];
+        {
+            int wo = lane * 4;
+            asm volatile("" : "+v"(wo));                          // keeps these loop-invariant reads inside the sample loop (registers)
+#pragma unroll
+            for (int nb = 0; nb < HC; ++nb)
+#pragma unroll
+                for (int c = 0; c < KC; ++c) {
+                    w12f[nb][c] = ld4(wfrag_s + (nb * KC + c) * 256 + wo);
+                    w4f[nb][c] = ld4(wfrag_s + (HC * KC + nb * KC + c) * 256 + wo);
+                }
+        }
         f32x4 Ab[HC][KC];
+        if constexpr (HALF && KC == 2) {
+            // straight from the candidate's packed halfs: w4s (c_hi + c_lo) + w12 as two mixed-precision FMAs per element
+            // (w4s = W4 * 2^-sH, folded once per wave): no unpack, no rescale -- 32 VALU instead of 48 per sample
 #pragma unroll
-        for (int nb = 0; nb < HC; ++nb)
+            for (int nb = 0; nb < HC; ++nb)
 #pragma unroll
-            for (int c = 0; c < KC; ++c) Ab[nb][c] = w4f[nb][c] * cv[c] + w12f[nb][c];
+                for (int e = 0; e < EL; ++e) {
+                    const float w4 = w4f[nb][e >> 2][e & 3];
+                    float x = w12f[nb][e >> 2][e & 3];   // (fragments re-read from LDS just above)
+                    x = (e & 1) ? fma_mix_hi(w4, cv[1][e >> 1], x) : fma_mix_lo(w4, cv[1][e >> 1], x);    // + w4s * c_lo
+                    x = (e & 1) ? fma_mix_hi(w4, cv[0][e >> 1], x) : fma_mix_lo(w4, cv[0][e >> 1], x);    // + w4s * c_hi
+                    Ab[nb][e >> 2][e & 3] = x;
+                }
+        } else {
+#pragma unroll
+            for (int nb = 0; nb < HC; ++nb)
+#pragma unroll
+                for (int c = 0; c < KC; ++c) Ab[nb][c] = w4f[nb][c] * cv[c] + w12f[nb][c];
+        }
         f16xe Ahi[HC], Alo[HC];                                  // HALF: A_b * a_scale as hi + lo halfs
         if constexpr (HALF) {
 #pragma unroll
             for (int nb = 0; nb < HC; ++nb) {
+                if constexpr (KC == 2) {
+                    // hi = f16(x), lo = f16(x - hi) with v_fma_mixlo/hi_f16 (2 VALU per element, halfs land packed; ends
+                    // with the hazard guard an asm-written MFMA operand needs -- dyn_split.h)
+                    dyn_split8(Ab[nb][0], Ab[nb][1], 1.0f, Ahi[nb], Alo[nb]);
+                } else {
 #pragma unroll
-                for (int c = 0; c < KC; ++c)
+                    for (int c = 0; c < KC; ++c)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const float x = Ab[nb][c][j];            // (w12 / w4 were pre-multiplied by a_scale)
-                        const _Float16 hh = (_Float16)x;
-                        Ahi[nb][4 * c + j] = hh;
-                        Alo[nb][4 * c + j] = (_Float16)(x - (float)hh);
-                    }
+                        for (int j = 0; j < 4; ++j) {
+                            const float x = Ab[nb][c][j];        // (w12 / w4 were pre-multiplied by a_scale)
+                            const _Float16 hh = (_Float16)x;
+                            Ahi[nb][4 * c + j] = hh;
+                            Alo[nb][4 * c + j] = (_Float16)(x - (float)hh);
+                        }
+                }
                 acc_init[nb] = acc_init[nb] * A.acc_scale;       // C operand in the accumulator's scale
             }
         }
@@ -367,13 +411,8 @@ __global__ __launch_bounds__(256, 2) void k_din_attn(const DinRun A, const int* 
                 b0[c] = ld4(Hs + (16 * g + r) * hs + (HALF ? EL * q + 4 * c : kof(c)));
                 b1[c] = TWO ? ld4(Hs + (16 * g + 16 + r) * hs + (HALF ? EL * q + 4 * c : kof(c))) : zero;
             }
-            f32x4 al0[HC], al1[HC], be0[HC], be1[HC];            // ca[t][n], cb[t][n] of the rows being scored
 #pragma unroll
             for (int nb = 0; nb < HC; ++nb) {
-                al0[nb] = ld4(alpha_s + (16 * g + r) * as + nb * 16 + 4 * q);
-                al1[nb] = TWO ? ld4(alpha_s + (16 * g + 16 + r) * as + nb * 16 + 4 * q) : zero;
-                be0[nb] = ld4(cb_s + (16 * g + r) * as + nb * 16 + 4 * q);
-                be1[nb] = TWO ? ld4(cb_s + (16 * g + 16 + r) * as + nb * 16 + 4 * q) : zero;
                 a0[nb] = acc_init[nb];
                 a1[nb] = acc_init[nb];
             }
@@ -410,15 +449,20 @@ __global__ __launch_bounds__(256, 2) void k_din_attn(const DinRun A, const int* 
 #pragma unroll
             for (int h = 0; h < (TWO ? 2 : 1); ++h) {
                 const int t = 16 * (g + h) + r;
-                float sum = 0.f;
+                // ca[t][n], cb[t][n] of this row, read here (after the MFMAs were issued) rather than held across them;
+                // four independent partial sums: the 16-term chain was on the per-sample critical path
+                float sum = 0.f, sum1 = 0.f;
 #pragma unroll
                 for (int nb = 0; nb < HC; ++nb) {
-                    const f32x4 ca = h ? al1[nb] : al0[nb];
-                    const f32x4 cb = h ? be1[nb] : be0[nb];
+                    const f32x4 ca = ld4(alpha_s + t * as + nb * 16 + 4 * q);
+                    const f32x4 cb = ld4(cb_s + t * as + nb * 16 + 4 * q);
                     const f32x4 u = h ? a1[nb] : a0[nb];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) sum = fmaf(cb[j], __builtin_fabsf(u[j]), fmaf(ca[j], u[j], sum));
+                    sum = fmaf(cb[0], __builtin_fabsf(u[0]), fmaf(ca[0], u[0], sum));
+                    sum1 = fmaf(cb[1], __builtin_fabsf(u[1]), fmaf(ca[1], u[1], sum1));
+                    sum = fmaf(cb[2], __builtin_fabsf(u[2]), fmaf(ca[2], u[2], sum));
+                    sum1 = fmaf(cb[3], __builtin_fabsf(u[3]), fmaf(ca[3], u[3], sum1));
                 }
+                sum += sum1;
                 const float wgt = sigmoidf_fast(rows4_sum(sum) * (HALF ? A.unscale : 1.0f) + A.b2);   // PReLU is positively homogeneous
                 if (q == 0 && att && t < T) att[(size_t)s * T + t] = wgt;
                 // weighted sum pooling (DIN.py:152-158): rows past T are all-zero in the tile, so they add nothing

@@ -699,6 +699,7 @@ struct sprk_engine {
     float* din_tsplit = nullptr;   // HALF: the movie table pre-split into f16 hi/lo pairs
     size_t din_attn_lds = 0;
     int din_attn_grid_cap = 0;
+    int din_wpb = 4;               // waves per k_din_attn workgroup
     // register-chained fast path (k_deepfm_v2_chain); -1 = use the tile interpreter
     int v2_variant = -1;
     V2Args v2;
@@ -1414,23 +1415,25 @@ int setup_rows_ncf(sprk_engine* h) {
 
 // ---- dispatch table for k_din_attn<KC, HC> ----
 typedef void (*DinLaunchFn)(const DinRun&, const int*, float*, float*, int, int*, int, size_t, hipStream_t);
-template <int KC, int HC, int NP, bool HALF>
+template <int KC, int HC, int NP, bool HALF, int WPB>
 void din_launch(const DinRun& a, const int* ids, float* pooled, float* att, int B, int* err, int grid, size_t lds, hipStream_t st) {
-    hipLaunchKernelGGL((k_din_attn<KC, HC, NP, HALF>), dim3(grid), dim3(256), lds, st, a, ids, pooled, att, B, err);
+    hipLaunchKernelGGL((k_din_attn<KC, HC, NP, HALF, WPB>), dim3(grid), dim3(WPB * 64), lds, st, a, ids, pooled, att, B, err);
 }
 struct DinVariant {
     int kc, hc, np;                   // np: gather passes compiled in (each covers 64 / (row_stride/4) history slots)
     bool half;                        // K = D contraction on split-f16 MFMA
+    int wpb;                          // waves per workgroup: 12 = one workgroup per CU at 3 waves per SIMD, 4 = two at 2 (round 1)
     const void* fn;
     size_t lds_bytes;
     DinLaunchFn launch;
 };
-#define DIN_VARIANT1(KC, HC, NP, HALF) {KC, HC, NP, HALF, reinterpret_cast<const void*>(&k_din_attn<KC, HC, NP, HALF>), DinLds<KC, HC>::bytes, &din_launch<KC, HC, NP, HALF>}
-#define DIN_VARIANT(KC, HC, NP) DIN_VARIANT1(KC, HC, NP, true), DIN_VARIANT1(KC, HC, NP, false)
-const DinVariant kDinVariants[] = {     // first match wins: smallest sufficient pass count first
-    DIN_VARIANT(2, 2, 2), DIN_VARIANT(2, 2, 4),
-    DIN_VARIANT(2, 2, 7),               // BASELINE config 3: emb_dim 32, 50 history slots, attention hidden 32
-    DIN_VARIANT(2, 2, 8),
+#define DIN_VARIANT1(KC, HC, NP, HALF, WPB) {KC, HC, NP, HALF, WPB, reinterpret_cast<const void*>(&k_din_attn<KC, HC, NP, HALF, WPB>), DinLds<KC, HC, WPB>::bytes, &din_launch<KC, HC, NP, HALF, WPB>}
+#define DIN_VARIANT(KC, HC, NP) DIN_VARIANT1(KC, HC, NP, true, 4), DIN_VARIANT1(KC, HC, NP, false, 4)
+const DinVariant kDinVariants[] = {     // first match wins: smallest sufficient pass count first; 12-wave forms before their 4-wave twins
+    DIN_VARIANT1(2, 2, 2, true, 12), DIN_VARIANT(2, 2, 2), DIN_VARIANT1(2, 2, 4, true, 12), DIN_VARIANT(2, 2, 4),
+    DIN_VARIANT1(2, 2, 7, true, 12),    // BASELINE config 3: emb_dim 32, 50 history slots, attention hidden 32
+    DIN_VARIANT(2, 2, 7),
+    DIN_VARIANT1(2, 2, 8, true, 12), DIN_VARIANT(2, 2, 8),
     DIN_VARIANT(1, 2, 1),               // the reference's own DIN.py: emb_dim 10 (rows padded to 12), 5 slots, hidden 32
     DIN_VARIANT(1, 2, 4),
 };
@@ -2289,9 +2292,12 @@ int sprk_finalize(sprk_handle h) {
             (size_t)s.vocab * s.row_stride * sizeof(float) < ((size_t)4 << 30)) {   // 32-bit element offsets
             const char* hm = getenv("SPRK_DIN_HALF");            // A/B switch: "0" = f32 MFMA
             bool want_half = !(hm && hm[0] == '0');
+            const char* wm = getenv("SPRK_DIN_WPB");             // A/B switch: "4" = round 1's four-wave workgroups
+            const bool allow12 = !(wm && wm[0] == '4');
             for (size_t v = 0; v < sizeof(kDinVariants) / sizeof(kDinVariants[0]); ++v) {
                 const DinVariant& dv = kDinVariants[v];
                 if (dv.half != want_half) continue;
+                if (dv.wpb == 12 && !allow12) continue;
                 if (dv.kc != kc || dv.hc != hc || dv.np * (64 / (dv.half ? kc * 4 : s.row_stride / 4)) < s.T) continue;
                 const int KP = kc * 16;
                 if (!h->din_w12) {
@@ -2348,8 +2354,10 @@ int sprk_finalize(sprk_handle h) {
                 HIP_TRY(hipFuncSetAttribute(dv.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dv.lds_bytes));
                 int wgs = (int)(160 * 1024 / dv.lds_bytes);
                 if (wgs > 2) wgs = 2;                                // launch bounds: 2 waves per SIMD
+                if (dv.wpb == 12) wgs = 1;                           // ... or one 12-wave workgroup: 3 waves per SIMD
                 if (wgs < 1) wgs = 1;
                 h->din_attn_grid_cap = h->num_cus * wgs;
+                h->din_wpb = dv.wpb;
                 h->din_attn_lds = dv.lds_bytes;
                 h->din_variant = (int)v;
                 break;
@@ -2465,7 +2473,7 @@ static int launch_din(sprk_handle h, const int32_t* ids, float* pooled, float* a
         return SPRK_OK;
     }
     if (h->din_variant >= 0) {
-        int grid = (B + 3) / 4;
+        int grid = (B + h->din_wpb - 1) / h->din_wpb;
         if (grid > h->din_attn_grid_cap) grid = h->din_attn_grid_cap;
         kDinVariants[h->din_variant].launch(h->din_run, ids, pooled, att, B, h->dev_err, grid, h->din_attn_lds, st);
         HIP_TRY(hipGetLastError());
@@ -2698,7 +2706,7 @@ int sprk_forward_many(sprk_handle h, int32_t n_batches, const int32_t* const* id
                 }
                 // the attention kernel stays one launch per batch (50 us each: its launch floor is small change); the tail,
                 // a 16-us kernel whose waves otherwise run ONE task, is where a launch per group pays
-                int ag = (B + 3) / 4;
+                int ag = (B + h->din_wpb - 1) / h->din_wpb;
                 if (ag > h->din_attn_grid_cap) ag = h->din_attn_grid_cap;
                 for (int j = 0; j < n; ++j)
                     av.launch(h->din_run, tm.ids[j], const_cast<float*>(tm.aux[j]), nullptr, B, h->dev_err, ag, h->din_attn_lds, st);
@@ -2796,8 +2804,8 @@ int sprk_describe(sprk_handle h, char* buf, size_t buf_bytes) {
     else if (h->plan.din.enabled == 1) stage = h->din_variant >= 0 ? "k_din_attn" : "k_din_pool";
     size_t uploaded = 0;
     for (size_t b : h->slot_bytes) uploaded += b;
-    const int n = snprintf(buf, buf_bytes, "kernel=%s;stage=%s;fused=%d;uploaded_bytes=%zu;derived_bytes=%zu;first_dense_fold=%d", kern, stage,
-                           strcmp(kern, "k_tile_forward") != 0 ? 1 : 0, uploaded, h->derived_bytes, h->n_acc_folded);
+    const int n = snprintf(buf, buf_bytes, "kernel=%s;stage=%s;stage_waves_per_workgroup=%d;fused=%d;uploaded_bytes=%zu;derived_bytes=%zu;first_dense_fold=%d", kern, stage,
+                           h->din_variant >= 0 ? h->din_wpb : 0, strcmp(kern, "k_tile_forward") != 0 ? 1 : 0, uploaded, h->derived_bytes, h->n_acc_folded);
     if (n < 0 || (size_t)n >= buf_bytes) return fail(SPRK_EINVAL, "describe: buffer of %zu bytes is too small", buf_bytes);
     return SPRK_OK;
 }
