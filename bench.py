@@ -94,10 +94,7 @@ def build_workload(name, B, dist_name, seed_offset=0, big_vocab=0, NB=8):
         # fused kernel: ids + embedding rows + first-order weights + numerics in, one score out
         roof = {"bound": "hbm", "kernel": kernel, "bytes_per_sample": bytes_per_sample}
         if name == "deepfm_c2":
-            # MFMA work of the tail as issued: deep0 (K = 2*16 + 8 numerics -> 48 f32 MFMAs of 16x16x4 per 16 samples = 3 K-chunks
-            # x 4 steps x 4 n-blocks) on f32, deep1 (64 x 64) as 3 split-f16 products of 16x16x32 x 2 K-chunks x 4 n-blocks
-            roof["mfma"] = {"f32_flops_per_sample": 48 * 2 * 16 * 16 * 4 / 16, "f16_flops_per_sample": 24 * 2 * 16 * 16 * 32 / 16,
-                            "reference_flops_per_sample": 2 * (39 * 64 + 64 * 64 + 64)}
+            roof["mfma_reference_flops"] = 2 * (39 * 64 + 64 * 64 + 64)
         return model, synth(fields), desc, roof
     if name in ("deepfm_v2_c4", "deepfm_c4"):
         # BASELINE configs[3]: emb_dim 64, userId (138 493 users) and a 27 M-row item table (6.9 GB, HBM-resident), plus the two
@@ -156,10 +153,7 @@ def build_workload(name, B, dist_name, seed_offset=0, big_vocab=0, NB=8):
         roof = {"bound": "mfma", "kernel": "k_din_pool" if legacy else "k_din_attn", "flops_per_sample": flops,
                 "executed_flops_per_sample": flops if legacy else executed,
                 "bytes_per_sample": (T + 1) * 4 + (T + 1) * D * 4 + D * 4,
-                # k_din_tail per 16 samples: fc0's per-sample part (K = 32 pooled + 8 numerics -> 96 f32 MFMAs 16x16x4 ... counted
-                # as issued: 8 n-blocks x (8 + 2) K-steps + ...), fc1 128 x 64 as 48 split-f16 MFMAs 16x16x32
-                "tail_mfma": {"f32_flops_per_sample": 96 * 2 * 16 * 16 * 4 / 16, "f16_flops_per_sample": 48 * 2 * 16 * 16 * 32 / 16,
-                              "reference_flops_per_sample": 2 * (167 * 128 + 128 * 64 + 64)}}
+                "tail_reference_flops": 2 * (167 * 128 + 128 * 64 + 64)}
         return model, feats, desc, roof
     if name == "widedeep_c5":
         # BASELINE configs[4], one GPU's share: Wide&Deep, hashed cross (movieId x userRatedMovie1) computed on device into a
@@ -173,10 +167,7 @@ def build_workload(name, B, dist_name, seed_offset=0, big_vocab=0, NB=8):
         # 8 B ids + 128 B cross row per sample for the wide part; + the deep part's 11 ids, 10 rows, numerics, score
         roof = {"bound": "hbm", "kernel": "k_tile_forward" if env("SPRK_MLP_CHAIN") == "0" else "k_mlp_chain",
                 "bytes_per_sample": 8 + D * 4 + 9 * 4 + 10 * D * 4 + 7 * 4 + 4,
-                # per 16 samples: dense0's unfolded part (movieId + userId rows 2 x 32 + 8 numerics = K 72 -> 5 K-chunks of 16 = 20 steps x
-                # 8 n-blocks = 160 ... as issued 192 f32) and dense1 128 x 128 as 96 split-f16 MFMAs
-                "mfma": {"f32_flops_per_sample": 192 * 2 * 16 * 16 * 4 / 16, "f16_flops_per_sample": 96 * 2 * 16 * 16 * 32 / 16,
-                         "reference_flops_per_sample": 2 * (327 * 128 + 128 * 128 + 128)}}
+                "mfma_reference_flops": 2 * (327 * 128 + 128 * 128 + 128)}
         return model, feats, desc, roof
     raise SystemExit("unknown workload %r" % name)
 
@@ -492,8 +483,7 @@ def main():
         nb_in = min(nb_in, 8)
     model, feats, desc, roof = build_workload(args.workload, B, args.dist, seed_offset=rank, big_vocab=args.big_vocab, NB=nb_in)
     eng = model.engine
-    if roof["kernel"] == "?":
-        roof["kernel"] = eng.kernel_name()
+    roof["kernel"] = eng.kernel_name() if args.workload != "din_c3" else roof["kernel"]   # what the handle really dispatches to
     env = os.environ.get
     lb = 1
     if args.launch_batches > 1 and env("SPRK_FORCE_INTERPRETER") != "1":
@@ -653,8 +643,9 @@ def main():
                   "timed_with": "HIP events, " + region}
             if "reference_bytes_per_sample" in roof:
                 rl["reference_bytes_per_sample"] = roof["reference_bytes_per_sample"]
-            if "mfma" in roof:
-                extra["roofline_mfma"] = mfma_block(roof["kernel"], roof["mfma"], B, fwd_s)
+            mi = mfma_issued(roof["kernel"], roof.get("mfma_reference_flops"))
+            if mi:
+                extra["roofline_mfma"] = mfma_block(roof["kernel"], mi, B, fwd_s)
         else:
             # DIN step = k_din_attn + k_din_tail; time the attention kernel alone
             pooled = torch.empty((B, eng.n_aux), dtype=torch.float32, device="cuda")
@@ -686,11 +677,10 @@ def main():
                       "frac": achieved * 1e9 / HBM_PEAK,
                       "reference_flops_per_sample": roof["flops_per_sample"],
                       "reference_equivalent_TFLOPs": roof["flops_per_sample"] * B / din_s / 1e12}
-                extra["roofline_mfma"] = mfma_block("k_din_attn", {"f32_flops_per_sample": 0.0,
-                                                                   "f16_flops_per_sample": 3 * roof["executed_flops_per_sample"],
-                                                                   "reference_flops_per_sample": roof["flops_per_sample"]}, B, din_s)
-                if env("SPRK_DIN_TAIL") != "0":
-                    extra["roofline_mfma_tail"] = mfma_block("k_din_tail", roof["tail_mfma"], B, max(fwd_s - din_s, 1e-9))
+                extra["roofline_mfma"] = mfma_block("k_din_attn", mfma_issued("k_din_attn", roof["flops_per_sample"]), B, din_s)
+                if eng.kernel_name() == "k_din_tail":
+                    extra["roofline_mfma_tail"] = mfma_block("k_din_tail", mfma_issued("k_din_tail", roof["tail_reference_flops"]), B,
+                                                             max(fwd_s - din_s, 1e-9))
             rl.update({"algorithmic_bytes_per_sample": roof["bytes_per_sample"],
                        "avg_launch_us": din_s * 1e6, "step_us_all_kernels": fwd_s * 1e6,
                        "timed_with": "HIP events, %s-only loop after the timed regions" % roof["kernel"]})
@@ -766,6 +756,30 @@ def main():
     if dist_on:
         dist.barrier()
         dist.destroy_process_group()
+
+
+# MFMA instructions each fused kernel ISSUES per 16-sample task (or per sample for the wave-per-sample attention kernel), by
+# operand type: v_mfma_f32_16x16x4_f32 (2 048 FLOP) / v_mfma_f32_16x16x32_f16 (16 384 FLOP).  Read off the kernels' source.
+MFMA_ISSUED = {
+    # numerics K = 8 as two steps x 4 n-blocks; deep0's embedding block 4 n-blocks x 3 split products; deep1 4 x 2 K-blocks x 3
+    "k_deepfm_pairs": {"per": 16, "f32": 8, "f16": 12 + 24},
+    # numerics two steps x 8 n-blocks; second layer 8 n-blocks x 4 K-blocks x 3 split products (every embedding column is folded)
+    "k_mlp_rows": {"per": 16, "f32": 16, "f16": 96},
+    # round 1: 5 K-chunks x 4 steps x 8 n-blocks on f32 + the same second layer
+    "k_mlp_chain": {"per": 16, "f32": 160, "f16": 96},
+    # fc0's per-sample part: pooled history (K = 32) + numerics chunk = 3 K-chunks x 4 steps x 8 n-blocks; fc1 4 n-blocks x 4 K-blocks x 3
+    "k_din_tail": {"per": 16, "f32": 96, "f16": 48},
+    # per SAMPLE: 4 sixteen-row groups x 2 n-blocks x 3 split products
+    "k_din_attn": {"per": 1, "f32": 0, "f16": 24},
+}
+
+
+def mfma_issued(kernel, reference_flops_per_sample):
+    m = MFMA_ISSUED.get(kernel)
+    if not m:
+        return None
+    return {"f32_flops_per_sample": m["f32"] * 2048.0 / m["per"], "f16_flops_per_sample": m["f16"] * 16384.0 / m["per"],
+            "reference_flops_per_sample": reference_flops_per_sample}
 
 
 def mfma_block(kernel, m, B, seconds):
