@@ -8,7 +8,11 @@
 // the first layer on f32 MFMA: 160 instructions of 32 cycles, i.e. 5 120 matrix-pipe cycles per task before the second layer
 // even starts (the f32-input MFMA runs at 1/16 of the f16 rate on gfx950), gathers issued per task, not a task ahead.  101 us
 // per 131 072 samples, 24 % of the HBM roofline.  Here:
-//   * the genre tables live in LDS (8 x 19 x 512 B = 76 KB; a shared all-zero row serves "no id"): no cache traffic at all;
+//   * the genre tables live in LDS (8 x 19 x 512 B = 76 KB; a shared all-zero row serves "no id"): no cache traffic at all.
+//     Rows are 512 B = two full bank rows, so sixteen lanes reading the same 16-byte piece of sixteen DIFFERENT rows would be a
+//     16-way bank conflict (first version: SQ_LDS_BANK_CONFLICT = 11 x SQ_INSTS_LDS, profiles/r02); the image is therefore
+//     XOR-swizzled: piece p of row i sits at slot p ^ (i & 15), and a lane reads slot (16 nb + 4 q) ^ 4 (i & 15) -- distinct
+//     ids land in distinct banks, equal ids broadcast;
 //   * movieId / userId are folded as well: their F rows (512 B per id) are gathered from HBM / Infinity Cache straight into the
 //     first layer's accumulators (C/D layout: lane (r,q) holds outputs 16 nb + 4q .. +3 of sample r) -- 1 KB per sample instead
 //     of 2 x 128 B, bought back many times over by the 144 f32 MFMAs it removes; total gathered bytes stay BELOW the reference's
@@ -57,6 +61,14 @@ struct MlpRowsLds {
     static constexpr int total = off_hw + N1;
     static constexpr int total_pad = (total + 255) & ~255;
 };
+
+// One-time (finalize) kernel: rows [rows][128] -> the XOR-swizzled LDS layout (piece p of row i at slot p ^ (i & 15)).
+__global__ __launch_bounds__(256) void k_mlp_rows_swizzle(const float* __restrict__ in, float* __restrict__ out, int rows) {
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < rows * 128; i += gridDim.x * 256) {
+        const int row = i >> 7, n = i & 127;
+        out[(row << 7) + ((((n >> 2) ^ (row & 15)) << 2) | (n & 3))] = in[i];
+    }
+}
 
 // One-time (finalize) kernel: the fixed part of the LDS image.
 template <int N0C, int N1C>
@@ -152,7 +164,8 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_mlp_rows(const MlpRowsRun A, 
             if (f < A.n_small) {                                  // wave-uniform
                 const int id = idrow[A.s_col[f]];
                 bad |= (unsigned)(id + 1) > (unsigned)A.s_vocab[f];
-                so[f] = (unsigned)id < (unsigned)A.s_vocab[f] ? A.s_off[f] + id * N0 : A.zero_off;
+                // float offset of this lane's piece 0 (q) inside the sample's swizzled row; piece 16 nb + 4 q = this ^ (16 nb)
+                so[f] = (unsigned)id < (unsigned)A.s_vocab[f] ? (A.s_off[f] + id * N0) ^ (4 * (id & 15)) ^ (4 * q) : A.zero_off ^ (4 * q);
             }
         }
         {
@@ -239,7 +252,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_mlp_rows(const MlpRowsRun A, 
         for (int f = 0; f < MR_MAX_SMALL; ++f) {
             if (f < A.n_small) {
 #pragma unroll
-                for (int nb = 0; nb < N0C; ++nb) z0[nb] += ld4(small_s + so_c[f] + 16 * nb + 4 * q);
+                for (int nb = 0; nb < N0C; ++nb) z0[nb] += ld4(small_s + (so_c[f] ^ (16 * nb)));
             }
         }
 #pragma unroll

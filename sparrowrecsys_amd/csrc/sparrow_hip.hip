@@ -1952,9 +1952,19 @@ int setup_mlp_rows(sprk_engine* h) {
         hipLaunchKernelGGL(k_fold_dense_rows, dim3((unsigned)blocks), dim3(256), 0, 0, (const float*)h->slot_ptr[sg.slot], (long long)sg.vocab,
                            sg.row_stride, 4 * sg.count, W0, o0.ldw, sg.dst - lo, N0, F);
     };
-    for (int f = 0; f < r.n_small; ++f) {
-        r.s_col[f] = small_seg[f]->field; r.s_vocab[f] = small_seg[f]->vocab;
-        fold(*small_seg[f], h->mlp_rows_small + r.s_off[f]);
+    {
+        // small columns: fold into a scratch buffer, then into the XOR-swizzled LDS layout (k_mlp_rows.h); s_off must keep the
+        // low 7 bits of a row's float offset free for the swizzle
+        float* tmp = nullptr;
+        HIP_TRY(hipMalloc((void**)&tmp, (size_t)32 * N0 * sizeof(float)));
+        for (int f = 0; f < r.n_small; ++f) {
+            r.s_col[f] = small_seg[f]->field; r.s_vocab[f] = small_seg[f]->vocab;
+            if (r.s_off[f] & 127) { (void)hipFree(tmp); return fail(SPRK_EINVAL, "small-table offset not a multiple of 128 floats"); }
+            fold(*small_seg[f], tmp);
+            hipLaunchKernelGGL(k_mlp_rows_swizzle, dim3(4), dim3(256), 0, 0, tmp, h->mlp_rows_small + r.s_off[f], small_seg[f]->vocab);
+        }
+        HIP_TRY(hipDeviceSynchronize());
+        (void)hipFree(tmp);
     }
     for (int b = 0; b < r.n_big; ++b) {
         const sprk_seg& sg = *big_seg[b];
