@@ -305,6 +305,19 @@ int sprk_pack_csv_mt(const char* text, size_t len, const sprk_csv_col* id_cols, 
                      const char* const* dense_names, int32_t n_dense, int32_t max_rows, int32_t n_threads,
                      int32_t* ids_out, float* dense_out, int32_t* rows_out);
 
+/* ---- multi-GPU: the path's one collective (the reference has no distributed path) ----
+ * Batch rows are sharded over one process per GPU, tables and weights replicated; every rank ends with all scores through ONE
+ * all-gather of the per-rank score slices over RCCL / xGMI, enqueued on the caller's HIP stream (no host synchronisation).
+ * RCCL is loaded at run time on first use.  Rank 0 calls sprk_comm_unique_id and hands the 128 bytes to the other ranks through
+ * any host channel (the Python host uses the process group's store); every rank then calls sprk_comm_create (collective).
+ * gathered = [world][count] floats, rank r's slice at offset r * count; in-place (local == gathered + rank * count) is allowed. */
+#define SPRK_COMM_ID_BYTES 128
+typedef struct sprk_comm_s* sprk_comm;
+int sprk_comm_unique_id(uint8_t id[SPRK_COMM_ID_BYTES]);
+int sprk_comm_create(const uint8_t id[SPRK_COMM_ID_BYTES], int32_t rank, int32_t world, sprk_comm* out);
+int sprk_comm_allgather_scores(sprk_comm c, const float* local, float* gathered, size_t count, void* stream);
+void sprk_comm_destroy(sprk_comm c);
+
 const char* sprk_last_error(void);
 
 #ifdef __cplusplus

@@ -34,7 +34,7 @@ EXPORTED_SYMBOLS = [
     "sprk_forward_deepfm", "sprk_forward_deepfm_v2", "sprk_forward_din", "sprk_forward_dien", "sprk_din_pool",
     "sprk_check_ids", "sprk_debug_set_trace", "sprk_destroy", "sprk_embedding_gather", "sprk_cross_hash", "sprk_last_error",
     "sprk_pack_csv", "sprk_pack_csv_mt", "sprk_set_many_streams", "sprk_set_many_batches", "sprk_emb_rank",
-    "sprk_describe",
+    "sprk_describe", "sprk_comm_unique_id", "sprk_comm_create", "sprk_comm_allgather_scores", "sprk_comm_destroy",
 ]
 
 
@@ -147,6 +147,11 @@ def load_library():
         lib.sprk_embedding_gather.argtypes = [vp, i32, i32, i32, vp, i32, vp, vp]
         lib.sprk_cross_hash.argtypes = [vp, vp, i32, C.c_int64, vp, vp]
         lib.sprk_describe.argtypes = [vp, C.c_char_p, sz]
+        lib.sprk_comm_unique_id.argtypes = [C.c_char_p]
+        lib.sprk_comm_create.argtypes = [C.c_char_p, i32, i32, C.POINTER(vp)]
+        lib.sprk_comm_allgather_scores.argtypes = [vp, vp, vp, sz, vp]
+        lib.sprk_comm_destroy.argtypes = [vp]
+        lib.sprk_comm_destroy.restype = None
         lib.sprk_set_many_streams.argtypes = [vp, i32]
         lib.sprk_set_many_batches.argtypes = [vp, i32]
         lib.sprk_pack_csv.argtypes = [C.c_char_p, sz, C.POINTER(CsvCol), i32, C.POINTER(C.c_char_p), i32, i32, vp, vp,
@@ -155,7 +160,7 @@ def load_library():
                                          C.POINTER(i32)]
         lib.sprk_emb_rank.argtypes = [vp, vp, i32, i32, i32, vp, vp, i32, i32, vp, i32, vp, vp, vp]
         for name in EXPORTED_SYMBOLS:
-            if name not in ("sprk_last_error", "sprk_destroy", "sprk_workspace_bytes"):
+            if name not in ("sprk_last_error", "sprk_destroy", "sprk_workspace_bytes", "sprk_comm_destroy"):
                 getattr(lib, name).restype = C.c_int
         _lib = lib
         return lib

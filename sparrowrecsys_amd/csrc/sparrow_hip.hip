@@ -18,6 +18,7 @@
 //
 // Reference constructs each piece replaces are cited in include/sparrow_hip.h.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <cstdarg>
 #include <cstdint>
@@ -3122,6 +3123,95 @@ int sprk_cross_hash(const int32_t* a, const int32_t* b, int32_t B, int64_t num_b
     hipLaunchKernelGGL(k_cross_hash, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, b, B, (unsigned long long)num_buckets, (long long*)out);
     HIP_TRY(hipGetLastError());
     return SPRK_OK;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------
+// Multi-GPU: the ONE collective of the path behind the C ABI -- an all-gather of the per-rank score
+// slices over RCCL (xGMI), enqueued on the caller's HIP stream.  RCCL is bound at run time (dlopen), so libsparrow_hip.so has
+// no link-time dependency on it and single-GPU users never load it.
+// ---------------------------------------------------------------------------------------------
+namespace {
+struct RcclUid { char b[SPRK_COMM_ID_BYTES]; };           // ncclUniqueId: 128 opaque bytes, passed by value
+struct RcclApi {
+    void* lib = nullptr;
+    int (*GetUniqueId)(RcclUid*) = nullptr;
+    int (*CommInitRank)(void**, int, RcclUid, int) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+};
+RcclApi g_rccl;
+int rccl_load() {
+    if (g_rccl.lib) return SPRK_OK;
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void* lib = nullptr;
+    for (const char* n : names) { lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (lib) break; }
+    if (!lib) return fail(SPRK_EHIP, "cannot load RCCL (librccl.so.1): %s", dlerror());
+    RcclApi a;
+    a.lib = lib;
+    a.GetUniqueId = (decltype(a.GetUniqueId))dlsym(lib, "ncclGetUniqueId");
+    a.CommInitRank = (decltype(a.CommInitRank))dlsym(lib, "ncclCommInitRank");
+    a.CommDestroy = (decltype(a.CommDestroy))dlsym(lib, "ncclCommDestroy");
+    a.AllGather = (decltype(a.AllGather))dlsym(lib, "ncclAllGather");
+    a.GetErrorString = (decltype(a.GetErrorString))dlsym(lib, "ncclGetErrorString");
+    if (!a.GetUniqueId || !a.CommInitRank || !a.CommDestroy || !a.AllGather) return fail(SPRK_EHIP, "librccl.so lacks the nccl entry points");
+    g_rccl = a;
+    return SPRK_OK;
+}
+int rccl_fail(const char* what, int rc) {
+    return fail(SPRK_EHIP, "%s failed: %s", what, g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "rccl error");
+}
+}  // namespace
+
+struct sprk_comm_s {
+    void* comm = nullptr;
+    int rank = 0, world = 1;
+};
+
+extern "C" {
+
+int sprk_comm_unique_id(uint8_t id[SPRK_COMM_ID_BYTES]) {
+    if (!id) return fail(SPRK_EINVAL, "id is NULL");
+    int rc = rccl_load();
+    if (rc) return rc;
+    RcclUid uid;
+    const int nrc = g_rccl.GetUniqueId(&uid);
+    if (nrc) return rccl_fail("ncclGetUniqueId", nrc);
+    memcpy(id, uid.b, SPRK_COMM_ID_BYTES);
+    return SPRK_OK;
+}
+
+int sprk_comm_create(const uint8_t id[SPRK_COMM_ID_BYTES], int32_t rank, int32_t world, sprk_comm* out) {
+    if (!id || !out) return fail(SPRK_EINVAL, "id/out is NULL");
+    *out = nullptr;
+    if (world < 1 || rank < 0 || rank >= world) return fail(SPRK_EINVAL, "bad rank/world %d/%d", rank, world);
+    int rc = rccl_load();
+    if (rc) return rc;
+    sprk_comm_s* c = new (std::nothrow) sprk_comm_s();
+    if (!c) return fail(SPRK_EHIP, "out of host memory");
+    c->rank = rank; c->world = world;
+    RcclUid uid;
+    memcpy(uid.b, id, SPRK_COMM_ID_BYTES);
+    const int nrc = g_rccl.CommInitRank(&c->comm, world, uid, rank);
+    if (nrc) { delete c; return rccl_fail("ncclCommInitRank", nrc); }
+    *out = c;
+    return SPRK_OK;
+}
+
+int sprk_comm_allgather_scores(sprk_comm c, const float* local, float* gathered, size_t count, void* stream) {
+    if (!c || !c->comm) return fail(SPRK_EINVAL, "communicator is NULL");
+    if (!local || !gathered) return fail(SPRK_EINVAL, "NULL buffer");
+    if (count == 0) return SPRK_OK;
+    const int nrc = g_rccl.AllGather(local, gathered, count, 7 /* ncclFloat32 */, c->comm, (hipStream_t)stream);
+    return nrc ? rccl_fail("ncclAllGather", nrc) : SPRK_OK;
+}
+
+void sprk_comm_destroy(sprk_comm c) {
+    if (!c) return;
+    if (c->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(c->comm);
+    delete c;
 }
 
 }  // extern "C"

@@ -18,6 +18,59 @@ import os
 from typing import Callable, Optional, Tuple
 
 
+class ScoreComm:
+    """The path's one collective behind the C ABI (``sprk_comm_*``, include/sparrow_hip.h): an RCCL all-gather of float32
+    score slices enqueued on a HIP stream, without torch on the data path.  The 128-byte RCCL id is created on rank 0 and
+    handed to the other ranks through the torch.distributed process group (host side, once)."""
+
+    def __init__(self, group=None):
+        import ctypes as C
+
+        import torch
+        import torch.distributed as dist
+
+        from . import _lib as L
+        self.lib = L.load_library()
+        self._L, self._C = L, C
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        buf = C.create_string_buffer(128)
+        if self.rank == 0:
+            L.check(self.lib.sprk_comm_unique_id(buf))
+        if self.world > 1:
+            box = [bytes(buf.raw)]
+            dist.broadcast_object_list(box, src=0, group=group)
+            buf = C.create_string_buffer(box[0], 128)
+        self.handle = C.c_void_p()
+        torch.cuda.synchronize()
+        L.check(self.lib.sprk_comm_create(buf, self.rank, self.world, C.byref(self.handle)))
+
+    def all_gather(self, local, gathered, stream=None):
+        """local [count] float32 -> gathered [world * count] float32 on every rank (async on ``stream``)."""
+        import torch
+        C = self._C
+        if local.dtype != torch.float32 or gathered.dtype != torch.float32 or not local.is_cuda or not gathered.is_cuda:
+            raise ValueError("ScoreComm.all_gather: float32 device tensors only")
+        if not local.is_contiguous() or not gathered.is_contiguous() or gathered.numel() != self.world * local.numel():
+            raise ValueError("ScoreComm.all_gather: gathered must be contiguous with world * local.numel() elements")
+        if stream is None:
+            stream = torch.cuda.current_stream().cuda_stream
+        self._L.check(self.lib.sprk_comm_allgather_scores(self.handle, C.c_void_p(local.data_ptr()), C.c_void_p(gathered.data_ptr()),
+                                                         local.numel(), C.c_void_p(stream)))
+        return gathered
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.sprk_comm_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def shard_bounds(n_rows: int, rank: int, world: int) -> Tuple[int, int]:
     """Rows [lo, hi) owned by ``rank``: contiguous, sizes differ by at most one, earlier ranks larger."""
     if world <= 0 or not 0 <= rank < world:
@@ -32,12 +85,14 @@ class RowShardedPredictor:
     its row shard only, then the score slices are all-gathered so every rank ends with all scores
     (what the Jetty ranker needs to sort the candidates, RecForYouProcess.java:89-91)."""
 
-    def __init__(self, forward: Callable, group=None):
+    def __init__(self, forward: Callable, group=None, comm: Optional["ScoreComm"] = None):
         import torch.distributed as dist
         self.forward = forward
         self.group = group
+        self.comm = comm                     # ScoreComm: the all-gather through the C ABI instead of torch.distributed
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
+        self._bufs = {}                      # (rows, dtype, device) -> (slot, gathered): no allocation per request
 
     def predict(self, ids, dense):
         import torch
@@ -48,10 +103,18 @@ class RowShardedPredictor:
         if self.world == 1:
             return local
         per = (n + self.world - 1) // self.world                 # slot size (largest shard)
-        slot = torch.zeros(per, dtype=local.dtype, device=local.device)
+        key = (n, local.dtype, local.device)
+        if key not in self._bufs:
+            if len(self._bufs) > 8:
+                self._bufs.clear()
+            self._bufs[key] = (torch.zeros(per, dtype=local.dtype, device=local.device),
+                               torch.empty(per * self.world, dtype=local.dtype, device=local.device))
+        slot, gathered = self._bufs[key]
         slot[:hi - lo] = local
-        gathered = torch.empty(per * self.world, dtype=local.dtype, device=local.device)
-        dist.all_gather_into_tensor(gathered, slot, group=self.group)
+        if self.comm is not None and local.is_cuda:
+            self.comm.all_gather(slot, gathered)
+        else:
+            dist.all_gather_into_tensor(gathered, slot, group=self.group)
         if n % self.world == 0:
             return gathered
         pieces = []
@@ -82,12 +145,14 @@ class GroupedScoreGather:
     handed to ``sink(group_index, gathered_view, n_batches)`` if given (views are only valid until the
     slot is reused two groups later)."""
 
-    def __init__(self, batch_rows: int, group: int, device, dtype=None, pg=None, sink: Optional[Callable] = None):
+    def __init__(self, batch_rows: int, group: int, device, dtype=None, pg=None, sink: Optional[Callable] = None,
+                 comm: Optional["ScoreComm"] = None):
         import torch
         import torch.distributed as dist
         if group < 1:
             raise ValueError("group must be >= 1")
         self.B, self.G, self.pg, self.sink = int(batch_rows), int(group), pg, sink
+        self.comm = comm                      # ScoreComm: collectives through sprk_comm_allgather_scores (RCCL behind the C ABI)
         self.world = dist.get_world_size(pg) if dist.is_initialized() else 1
         dtype = dtype or torch.float32
         self.local = torch.zeros((2, self.G, self.B), dtype=dtype, device=device)
@@ -160,7 +225,10 @@ class GroupedScoreGather:
             ready.record(torch.cuda.current_stream())
             self.comm_stream.wait_event(ready)
             with torch.cuda.stream(self.comm_stream):
-                dist.all_gather_into_tensor(dst, src, group=self.pg)
+                if self.comm is not None:
+                    self.comm.all_gather(src, dst, self.comm_stream.cuda_stream)
+                else:
+                    dist.all_gather_into_tensor(dst, src, group=self.pg)
                 ev = torch.cuda.Event()
                 ev.record(self.comm_stream)
             self.done[slot] = ev

@@ -127,3 +127,26 @@ def test_grouped_score_ring_single_rank_delivers_every_group(torch):
         assert v.shape == (1, nb, B)
         for j in range(nb):
             assert float(v[0, j, 0]) == float(3 * gi + j) and float(v[0, j, -1]) == float(3 * gi + j)
+
+
+def test_score_allgather_through_the_c_abi_single_rank(torch):
+    """sprk_comm_* (RCCL bound at run time inside libsparrow_hip.so): a world of one is what a 1-GPU box can run -- the id, the
+    communicator, the stream-ordered collective and the GroupedScoreGather path that uses it (SPRK_FORCE_COLLECTIVE issues the
+    collective even at world 1)."""
+    import os
+    from sparrowrecsys_amd.dist import GroupedScoreGather, ScoreComm
+    comm = ScoreComm()
+    assert comm.world == 1 and comm.rank == 0
+    local = torch.arange(4096, dtype=torch.float32, device="cuda")
+    gathered = torch.full((4096,), -1.0, device="cuda")
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        comm.all_gather(local, gathered, side.cuda_stream)
+    side.synchronize()
+    assert torch.equal(gathered, local)
+    with pytest.raises(ValueError):
+        comm.all_gather(local.double(), gathered)
+    with pytest.raises(ValueError):
+        comm.all_gather(local, gathered[:100])
+    comm.close()
