@@ -51,16 +51,21 @@ struct V1Run {
     const float* image;                   // the LDS image (k_v1_pack_image), staged by LDS-DMA
 };
 
-// One-time (finalize) kernel: deep0's W^T columns -> [H0][16*(V1_MAX_DEEP+1)]: chunk g < n_deep = the Dp columns of deep
-// field g (at col_off[g] of the layer's input slice), chunk V1_MAX_DEEP = the numerics; everything else zero.
+// One-time (finalize) kernel: deep0's W^T columns -> [H0][KW], KW = 16 * (V1_MAX_DEEP * PC + 1), PC = 16-float chunks per embedding
+// row: chunk c < V1_MAX_DEEP * PC = columns [16 (c % PC), +16) of deep field c / PC (at col_off of the layer's input slice), the
+// last chunk = the numerics; everything else zero.
 __global__ __launch_bounds__(256) void k_v1_pack_w0(const float* __restrict__ W0, int ldw0, int n_deep, int off0, int off1,
-                                                    int Dp, int n_off, int n_num, int H0, float* __restrict__ w0) {
-    const int KW = 16 * (V1_MAX_DEEP + 1);
+                                                    int Dp, int n_off, int n_num, int H0, int PC, float* __restrict__ w0) {
+    const int KW = 16 * (V1_MAX_DEEP * PC + 1);
     for (int i = threadIdx.x; i < H0 * KW; i += 256) {
         const int n = i / KW, k = i - n * KW, c = k >> 4, j = k & 15;
         float v = 0.f;
-        if (c < V1_MAX_DEEP) { if (c < n_deep && j < Dp) v = W0[(size_t)n * ldw0 + (c == 0 ? off0 : off1) + j]; }
-        else if (j < n_num) v = W0[(size_t)n * ldw0 + n_off + j];
+        if (c < V1_MAX_DEEP * PC) {
+            const int f = c / PC, col = 16 * (c - f * PC) + j;
+            if (f < n_deep && col < Dp) v = W0[(size_t)n * ldw0 + (f == 0 ? off0 : off1) + col];
+        } else if (j < n_num) {
+            v = W0[(size_t)n * ldw0 + n_off + j];
+        }
         w0[i] = v;
     }
 }
@@ -74,13 +79,14 @@ struct V1Many {
     int n, ntpb;
 };
 
-template <int H0C, int H1C>
+template <int H0C, int H1C, int PC = 1>
 struct V1Lds {
     static constexpr int H0 = H0C * 16, H1 = H1C * 16;
     static constexpr int S1 = H0 + 4;                 // deep1 W^T row stride (f32 path)
-    static constexpr int SE = 32 + 4;                 // deep0 embedding-part W^T row stride (f32 path)
+    static constexpr int KE = 32 * PC;                // deep0's embedding columns: two deep fields x PC chunks of 16
+    static constexpr int SE = KE + 4;                 // deep0 embedding-part W^T row stride (f32 path)
     static constexpr int off_w1 = 0;                  // DYN: H1C*(H0C/2)*512 fragment floats; else [H1][S1]
-    static constexpr int off_w0e = off_w1 + H1 * S1;  // DYN: H0C*512 fragment floats (one K = 32 block); else [H0][SE]
+    static constexpr int off_w0e = off_w1 + H1 * S1;  // DYN: H0C*PC*512 fragment floats (PC K = 32 blocks); else [H0][SE]
     static constexpr int off_w0n = off_w0e + H0 * SE; // [H0][8] numerics columns
     static constexpr int off_b0 = off_w0n + H0 * 8;   // [H0]
     static constexpr int off_b1 = off_b0 + H0;        // [H1]
@@ -88,14 +94,14 @@ struct V1Lds {
     static constexpr int total = off_hd + H1;
     static constexpr int total_pad = (total + 255) & ~255;
     static constexpr size_t bytes = sizeof(float) * total_pad;
-    static_assert(H1C * (H0C / 2) * 512 <= H1 * S1 && H0C * 512 <= H0 * SE && H0C % 2 == 0, "fragments fit their regions");
+    static_assert(H1C * (H0C / 2) * 512 <= H1 * S1 && H0C * PC * 512 <= H0 * SE && H0C % 2 == 0, "fragments fit their regions");
 };
 
 // One-time (finalize) kernel: the LDS image.  w0 = k_v1_pack_w0's [H0][48] (deep field chunks, numerics chunk).
-template <int H0C, int H1C>
+template <int H0C, int H1C, int PC>
 __global__ __launch_bounds__(256) void k_v1_pack_image(const V1Run A, float* __restrict__ img) {
-    using LD = V1Lds<H0C, H1C>;
-    const int tid = threadIdx.x, KW = 16 * (V1_MAX_DEEP + 1);
+    using LD = V1Lds<H0C, H1C, PC>;
+    const int tid = threadIdx.x, KW = 16 * (V1_MAX_DEEP * PC + 1);
     for (int i = tid; i < LD::total_pad; i += 256) img[i] = 0.f;
     __syncthreads();
     if (A.w1frag) {
@@ -107,31 +113,34 @@ __global__ __launch_bounds__(256) void k_v1_pack_image(const V1Run A, float* __r
         }
     }
     if (A.w0frag) {
-        for (int i = tid; i < H0C * 512; i += 256) img[LD::off_w0e + i] = A.w0frag[i];
+        for (int i = tid; i < H0C * PC * 512; i += 256) img[LD::off_w0e + i] = A.w0frag[i];
     } else {
         for (int i = tid; i < LD::H0 * LD::SE; i += 256) {
             const int n = i / LD::SE, k = i - n * LD::SE;
-            img[LD::off_w0e + i] = k < 32 ? A.w0[(size_t)n * KW + k] : 0.f;
+            img[LD::off_w0e + i] = k < LD::KE ? A.w0[(size_t)n * KW + k] : 0.f;
         }
     }
-    for (int i = tid; i < LD::H0 * 8; i += 256) img[LD::off_w0n + i] = A.w0[(size_t)(i >> 3) * KW + 16 * V1_MAX_DEEP + (i & 7)];
+    for (int i = tid; i < LD::H0 * 8; i += 256) img[LD::off_w0n + i] = A.w0[(size_t)(i >> 3) * KW + 16 * V1_MAX_DEEP * PC + (i & 7)];
     for (int i = tid; i < LD::H0; i += 256) img[LD::off_b0 + i] = A.b0[i];
     for (int i = tid; i < LD::H1; i += 256) { img[LD::off_b1 + i] = A.b1[i]; img[LD::off_hd + i] = A.hdeep[i]; }
 }
 
-template <int NF>
+template <int NF, int PC>
 struct V1Set {
-    f32x4 x[NF];                          // every field's row piece
+    f32x4 x[NF][PC];                      // every field's row pieces: elements 16 pc + 4q .. +3
     float xa, xb;                         // numerics q and q + 4
     float w1a, w1b;                       // first-order weights fetched by this lane
 };
 
+// NV = 16-byte pieces per embedding row (Dp / 4): up to 4 = one piece per lane (emb_dim <= 16), 16 = four per lane (emb_dim 64,
+// BASELINE config 4: the 256-byte rows of the 27 M-row table are gathered whole -- the fold does not apply to pair dots).
 template <int NF, int NV, int H0C, int H1C, int WAVES, bool DYN, bool MB>
 __device__ __forceinline__ void v1_body(const V1Run& A, const int* __restrict__ ids0, const float* __restrict__ dense0,
                                         float* __restrict__ out0, int B, int* __restrict__ err, const V1Many* __restrict__ Mp) {
-    using LD = V1Lds<H0C, H1C>;
-    using Set = V1Set<NF>;
-    static_assert(NF >= 2 && NF <= V1_MAX_FIELDS && NV >= 1 && NV <= 4, "shape");
+    constexpr int PC = (NV + 3) / 4;
+    using LD = V1Lds<H0C, H1C, PC>;
+    using Set = V1Set<NF, PC>;
+    static_assert(NF >= 2 && NF <= V1_MAX_FIELDS && NV >= 1 && (NV <= 4 || NV % 4 == 0) && NV <= 16, "shape");
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -180,7 +189,10 @@ __device__ __forceinline__ void v1_body(const V1Run& A, const int* __restrict__ 
             sid[f] = min((unsigned)idv[f], (unsigned)A.vocab[f]);              // -1 / out of range -> the zero row at index vocab
         }
 #pragma unroll
-        for (int f = 0; f < NF; ++f) S.x[f] = q < NV ? ld4(A.table[f] + (size_t)sid[f] * A.row_floats + 4 * q) : zero;
+        for (int f = 0; f < NF; ++f)
+#pragma unroll
+            for (int pc = 0; pc < PC; ++pc)
+                S.x[f][pc] = 4 * pc + q < NV ? ld4(A.table[f] + (size_t)sid[f] * A.row_floats + 16 * pc + 4 * q) : zero;
         {
             // first order: lane (r,q) fetches field q's weight, then field q+4's
             const float* pa = A.w1[0] + sid[0];
@@ -208,7 +220,10 @@ __device__ __forceinline__ void v1_body(const V1Run& A, const int* __restrict__ 
 #pragma unroll
             for (int b = a + 1; b < NF; ++b) {
                 const float hw = A.pw[a * V1_MAX_FIELDS + b];       // wave-uniform (SGPR); zero when (a,b) is not a pair
-                const f32x4 p = S.x[a] * S.x[b];
+                if (PC > 1 && hw == 0.f) continue;                  // (wide rows: skip the products of non-pairs; wave-uniform)
+                f32x4 p = S.x[a][0] * S.x[b][0];
+#pragma unroll
+                for (int pc = 1; pc < PC; ++pc) p += S.x[a][pc] * S.x[b][pc];
                 z = fmaf(hw, (p.x + p.y) + (p.z + p.w), z);
             }
         // ---- deep0 (DeepFM.py:106-107): bias + numerics on f32 MFMA, the deep fields' rows on split f16 ----
@@ -219,26 +234,36 @@ __device__ __forceinline__ void v1_body(const V1Run& A, const int* __restrict__ 
         for (int nb = 0; nb < H0C; ++nb) h0[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(rna[nb], S.xa, h0[nb], 0, 0, 0);
 #pragma unroll
         for (int nb = 0; nb < H0C; ++nb) h0[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(rnb[nb], S.xb, h0[nb], 0, 0, 0);
-        const f32x4 e0 = S.x[0], e1 = A.n_deep > 1 ? S.x[1] : zero;
+        // the deep fields' chunks in K order: chunk c = field c / PC, pieces 16 (c % PC) + 4q; K block b = chunks 2b, 2b + 1
+        f32x4 ec[2 * PC];
+#pragma unroll
+        for (int c = 0; c < 2 * PC; ++c) ec[c] = (c / PC == 0 || A.n_deep > 1) ? S.x[c / PC][c % PC] : zero;
         if constexpr (DYN) {
             float mx = 0.f;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) mx = fmaxf(mx, fmaxf(__builtin_fabsf(e0[j]), __builtin_fabsf(e1[j])));
+            for (int c = 0; c < 2 * PC; ++c)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) mx = fmaxf(mx, __builtin_fabsf(ec[c][j]));
             mx = rows4_max(mx);
             float scale, inv;
             dyn_scale(mx, A.inv_w0_scale, scale, inv);
-            din_f16x8 bh, bl;
-            dyn_split8(e0, e1, scale, bh, bl);
             int wfo = LD::off_w0e + (r * 4 + q) * 4;              // this lane's 16 bytes inside a 1-KB fragment
             asm volatile("" : "+v"(wfo));                         // (keeps the loop-invariant LDS reads inside the task loop)
             f32x4 acc[H0C];
 #pragma unroll
-            for (int nb = 0; nb < H0C; ++nb) {
-                const din_f16x8 ah = __builtin_bit_cast(din_f16x8, ld4(smem + wfo + (nb * 2 + 0) * 256));
-                const din_f16x8 al = __builtin_bit_cast(din_f16x8, ld4(smem + wfo + (nb * 2 + 1) * 256));
-                acc[nb] = mfma_f16(ah, bh, zero);
-                acc[nb] = mfma_f16(ah, bl, acc[nb]);
-                acc[nb] = mfma_f16(al, bh, acc[nb]);
+            for (int nb = 0; nb < H0C; ++nb) acc[nb] = zero;
+#pragma unroll
+            for (int b = 0; b < PC; ++b) {
+                din_f16x8 bh, bl;
+                dyn_split8(ec[2 * b], ec[2 * b + 1], scale, bh, bl);
+#pragma unroll
+                for (int nb = 0; nb < H0C; ++nb) {
+                    const din_f16x8 ah = __builtin_bit_cast(din_f16x8, ld4(smem + wfo + ((nb * PC + b) * 2 + 0) * 256));
+                    const din_f16x8 al = __builtin_bit_cast(din_f16x8, ld4(smem + wfo + ((nb * PC + b) * 2 + 1) * 256));
+                    acc[nb] = mfma_f16(ah, bh, acc[nb]);
+                    acc[nb] = mfma_f16(ah, bl, acc[nb]);
+                    acc[nb] = mfma_f16(al, bh, acc[nb]);
+                }
             }
 #pragma unroll
             for (int nb = 0; nb < H0C; ++nb) h0[nb] = acc[nb] * inv + h0[nb];
@@ -246,8 +271,7 @@ __device__ __forceinline__ void v1_body(const V1Run& A, const int* __restrict__ 
             int w0o = LD::off_w0e + r * LD::SE + 4 * q;
             asm volatile("" : "+v"(w0o));
 #pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                const f32x4 bop = c == 0 ? e0 : e1;
+            for (int c = 0; c < 2 * PC; ++c) {
                 f32x4 a[H0C];
 #pragma unroll
                 for (int nb = 0; nb < H0C; ++nb) a[nb] = ld4(smem + w0o + nb * 16 * LD::SE + 16 * c);
@@ -255,7 +279,7 @@ __device__ __forceinline__ void v1_body(const V1Run& A, const int* __restrict__ 
                 for (int st = 0; st < 4; ++st)
 #pragma unroll
                     for (int nb = 0; nb < H0C; ++nb)
-                        h0[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[nb][st], bop[st], h0[nb], 0, 0, 0);
+                        h0[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[nb][st], ec[c][st], h0[nb], 0, 0, 0);
             }
         }
 #pragma unroll
@@ -349,8 +373,9 @@ __device__ __forceinline__ void v1_body(const V1Run& A, const int* __restrict__ 
     Set SA, SB;
     if (tA >= ntasks) {
         // a wave without work leaves after the barrier
-    } else if (ntasks <= 2 * task_stride) {
+    } else if (PC == 1 && ntasks <= 2 * task_stride) {
         // at most two tasks per wave (B <= 65 536 on a full chip): both gathers in flight before the first scoring stage
+        // (narrow rows only: two sets of wide rows would not fit the register budget of 2 waves per SIMD)
         issue_gather(tA, idA, SA);
         if (tB < ntasks) issue_gather(tB, idB, SB);
         store(tA, compute(SA));

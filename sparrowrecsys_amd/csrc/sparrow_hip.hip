@@ -1586,7 +1586,7 @@ typedef void (*V1LaunchFn)(const V1Run&, const int*, const float*, float*, int, 
 typedef void (*V1LaunchManyFn)(const V1Run&, const V1Many&, int, int*, int, hipStream_t);
 template <int NF, int NV>
 void v1_launch(const V1Run& a, const int* ids, const float* dense, float* out, int B, int* err, int grid, hipStream_t st) {
-    const size_t lds = V1Lds<4, 4>::bytes;
+    const size_t lds = V1Lds<4, 4, (NV + 3) / 4>::bytes;
     if (a.inv_w1_scale != 0.f)
         hipLaunchKernelGGL((k_deepfm_pairs<NF, NV, 4, 4, V1_WAVES, true>), dim3(grid), dim3(V1_WAVES * 64), lds, st, a, ids, dense, out, B, err);
     else
@@ -1594,17 +1594,31 @@ void v1_launch(const V1Run& a, const int* ids, const float* dense, float* out, i
 }
 template <int NF, int NV>
 void v1_launch_many(const V1Run& a, const V1Many& m, int B, int* err, int grid, hipStream_t st) {
-    const size_t lds = V1Lds<4, 4>::bytes;
+    const size_t lds = V1Lds<4, 4, (NV + 3) / 4>::bytes;
     if (a.inv_w1_scale != 0.f)
         hipLaunchKernelGGL((k_deepfm_pairs_many<NF, NV, 4, 4, V1_WAVES, true>), dim3(grid), dim3(V1_WAVES * 64), lds, st, a, m, B, err);
     else
         hipLaunchKernelGGL((k_deepfm_pairs_many<NF, NV, 4, 4, V1_WAVES, false>), dim3(grid), dim3(V1_WAVES * 64), lds, st, a, m, B, err);
 }
-struct V1Variant { int nf, nv; V1LaunchFn launch; V1LaunchManyFn launch_many; };
+template <int NF, int NV>
+int v1_prepare(const V1Run& r, float* img) {
+    constexpr int PC = (NV + 3) / 4;
+    hipLaunchKernelGGL((k_v1_pack_image<4, 4, PC>), dim3(1), dim3(256), 0, 0, r, img);
+    HIP_TRY(hipGetLastError());
+    const size_t lds = V1Lds<4, 4, PC>::bytes;
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_deepfm_pairs<NF, NV, 4, 4, V1_WAVES, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_deepfm_pairs<NF, NV, 4, 4, V1_WAVES, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_deepfm_pairs_many<NF, NV, 4, 4, V1_WAVES, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_deepfm_pairs_many<NF, NV, 4, 4, V1_WAVES, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    return SPRK_OK;
+}
+struct V1Variant { int nf, nv; V1LaunchFn launch; V1LaunchManyFn launch_many; int (*prepare)(const V1Run&, float*); size_t lds_bytes; };
+#define V1_VARIANT(NF, NV) {NF, NV, &v1_launch<NF, NV>, &v1_launch_many<NF, NV>, &v1_prepare<NF, NV>, V1Lds<4, 4, (NV + 3) / 4>::bytes}
 const V1Variant kV1Variants[] = {
-    {6, 4, &v1_launch<6, 4>, &v1_launch_many<6, 4>},   // BASELINE config 2: 6 fields, emb_dim 16, deep 64-64
-    {4, 3, &v1_launch<4, 3>, &v1_launch_many<4, 3>},   // the reference's own DeepFM.py: 4 fields, emb_dim 10 (rows padded to 12)
-    {4, 4, &v1_launch<4, 4>, &v1_launch_many<4, 4>},
+    V1_VARIANT(6, 4),    // BASELINE config 2: 6 fields, emb_dim 16, deep 64-64
+    V1_VARIANT(4, 3),    // the reference's own DeepFM.py: 4 fields, emb_dim 10 (rows padded to 12)
+    V1_VARIANT(4, 4),
+    V1_VARIANT(4, 16),   // BASELINE config 4: emb_dim 64 -- 256-byte rows gathered whole (four pieces per lane)
 };
 
 // Recognise the plan models.DeepFM emits (DeepFM.py graph: pair dots + first order + 2-layer deep part) and set up
@@ -1627,7 +1641,7 @@ int setup_deepfm_pairs(sprk_engine* h) {
         if (sg.kind == SPRK_SEG_ROWS) {
             if (nf == V1_MAX_FIELDS) return SPRK_OK;
             if (nf == 0) Dp = sg.row_stride;
-            if (sg.row_stride != Dp || sg.count * 4 != Dp || Dp > 16) return SPRK_OK;
+            if (sg.row_stride != Dp || sg.count * 4 != Dp || Dp > 64) return SPRK_OK;
             if (h->slot_bytes[sg.slot] < ((size_t)sg.vocab + 1) * Dp * sizeof(float)) return SPRK_OK;   // needs the zero row at index vocab
             r.col[nf] = sg.field; r.vocab[nf] = sg.vocab; r.table[nf] = (const float*)h->slot_ptr[sg.slot];
             row_dst[nf++] = sg.dst;
@@ -1715,11 +1729,13 @@ int setup_deepfm_pairs(sprk_engine* h) {
     if (variant < 0) return SPRK_OK;
     const int H0 = o0.N, H1 = o1.N;
     const float* W0 = (const float*)h->slot_ptr[o0.w_slot];
+    const int PC = (Dp / 4 + 3) / 4;                          // 16-float chunks per embedding row
+    const int KW = 16 * (V1_MAX_DEEP * PC + 1);
     float* w0p = nullptr;
-    HIP_TRY(hipMalloc((void**)&w0p, (size_t)H0 * 16 * (V1_MAX_DEEP + 1) * sizeof(float) + 16));
+    HIP_TRY(hipMalloc((void**)&w0p, (size_t)H0 * KW * sizeof(float) + 16));
     h->v1_bufs.push_back(w0p);
     hipLaunchKernelGGL(k_v1_pack_w0, dim3(1), dim3(256), 0, 0, W0, o0.ldw, r.n_deep, deep_off[0], deep_off[1], Dp, num_dst - s0, r.n_num,
-                       H0, w0p);
+                       H0, PC, w0p);
     HIP_TRY(hipGetLastError());
     float* hd = nullptr;
     HIP_TRY(hipMalloc((void**)&hd, (size_t)H1 * sizeof(float) + 16));
@@ -1738,15 +1754,14 @@ int setup_deepfm_pairs(sprk_engine* h) {
         float *frag = nullptr, *frag0 = nullptr;
         int rc2 = make_dyn_fragments(h, r.W1, r.ld1, H1, H0, &frag, &w_scale);
         if (rc2) return rc2;
-        if (frag && (rc2 = make_dyn_fragments(h, w0p, 16 * (V1_MAX_DEEP + 1), H0, 32, &frag0, &w0_scale))) return rc2;
+        if (frag && (rc2 = make_dyn_fragments(h, w0p, KW, H0, 32 * PC, &frag0, &w0_scale))) return rc2;
         if (frag && frag0) { r.w1frag = frag; r.inv_w1_scale = 1.0f / w_scale; r.w0frag = frag0; r.inv_w0_scale = 1.0f / w0_scale; }
     }
     {
         float* img = nullptr;
-        HIP_TRY(hipMalloc((void**)&img, V1Lds<4, 4>::bytes));
+        HIP_TRY(hipMalloc((void**)&img, kV1Variants[variant].lds_bytes));
         h->v1_bufs.push_back(img);
-        hipLaunchKernelGGL((k_v1_pack_image<4, 4>), dim3(1), dim3(256), 0, 0, r, img);
-        HIP_TRY(hipGetLastError());
+        { const int rc3 = kV1Variants[variant].prepare(r, img); if (rc3) return rc3; }
         HIP_TRY(hipDeviceSynchronize());
         r.image = img;
     }

@@ -606,6 +606,28 @@ def test_mlp_rows_kernel_vs_round1_chain_and_oracle(torch, monkeypatch, kind, B)
         np.testing.assert_array_equal(model.predict(feats)[:, 0], p)
 
 
+@pytest.mark.parametrize("B", [5003, 17, 70001])
+def test_deepfm_pairs_wide_rows_emb_dim_64(torch, monkeypatch, B):
+    """BASELINE config 4's pair-dot graph (DeepFM.py:100-103 at emb_dim 64): 256-byte rows, four 16-byte pieces per lane,
+    deep0's K = 128 embedding columns as four split-f16 K blocks -- against the fp64 oracle and the plan interpreter."""
+    fields = [("movieId", "id", 50000), ("userId", "id", 30000), ("userGenre1", "genre", 19), ("movieGenre1", "genre", 19)]
+    feats = SY.synth_fields(B, fields, seed=77, missing=0.1)
+    model = M.DeepFM(seed=41, emb_dim=64, fields=fields)
+    assert model.engine.describe()["kernel"].startswith("k_deepfm_pairs<NF=4,NV=16>")
+    p = model.predict(feats)[:, 0]
+    n = min(B, 8192)
+    ref = O.deepfm_forward({k: v[:n] for k, v in feats.items()}, model.weights, dtype=np.float64, fields=fields, pairs=model.pairs)[:, 0]
+    assert np.abs(p[:n] - ref).max() <= TIGHT and (B < 100 or ref.std() > 0.02)
+    for env in ({"SPRK_DYN_F16": "0"}, {"SPRK_V1_CHAIN": "0"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        other = M.DeepFM(weights=model.weights, emb_dim=64, fields=fields)
+        q = other.predict(feats)[:, 0]
+        for k in env:
+            monkeypatch.delenv(k)
+        assert np.abs(p - q).max() <= TIGHT, env
+
+
 def test_deepfm_pairs_kernel_properties(torch):
     """Determinism, slice invariance (ragged tails), missing ids = zero rows, out-of-range ids raise."""
     B = 5000

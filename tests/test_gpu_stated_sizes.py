@@ -69,7 +69,7 @@ def test_config4_deepfm_v2_27m_row_table(torch):
 
 def test_config4_pair_dot_deepfm_27m_row_table(torch):
     """DeepFM.py:100-103 at emb_dim 64: the fold does not apply, 256-byte rows are gathered out of the 6.9 GB table."""
-    tables = _check(torch, "deepfm_c4", 65536, "k_tile_forward")
+    tables = _check(torch, "deepfm_c4", 65536, "k_deepfm_pairs")
     assert tables > 6.9e9
 
 
