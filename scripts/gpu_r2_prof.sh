@@ -29,6 +29,13 @@ b bench_v2_ref python bench.py --workload deepfm_v2_ref --steps 400 --warmup 40 
 b bench_v2_ref_interp env SPRK_FORCE_INTERPRETER=1 python bench.py --workload deepfm_v2_ref --steps 100 --warmup 10 --cpu-seconds 0
 b bench_ncf_ref python bench.py --workload neuralcf_ref --steps 400 --warmup 40 --cpu-seconds 0
 b bench_ncf_ref_interp env SPRK_NCF_CHAIN=0 python bench.py --workload neuralcf_ref --steps 400 --warmup 40 --cpu-seconds 0
+b bench_c4_pairs_interp env SPRK_V1_CHAIN=0 python bench.py --workload deepfm_c4 --steps 100 --warmup 10 --cpu-seconds 0
+b bench_c2_forced_collective_sprk env SPRK_BENCH_FORCE_DIST=1 SPRK_FORCE_COLLECTIVE=1 python bench.py --cpu-seconds 0 --hbm-resident 0 --collective sprk
+b bench_c2_forced_collective_torch env SPRK_BENCH_FORCE_DIST=1 SPRK_FORCE_COLLECTIVE=1 python bench.py --cpu-seconds 0 --hbm-resident 0 --collective torch
+b bench_c2_gloo2 python bench.py --gpus 2 --backend gloo --steps 20 --warmup 5 --cpu-seconds 0 --hbm-resident 0 --min-region-ms 1 --regions 1 --settle-ms 0
+timeout 120 scripts/ubench/launch_floor > $O/ubench_launch_floor.log 2>&1; tail -20 $O/ubench_launch_floor.log
+timeout 900 python -m pytest tests -m gpu -q 2>&1 | tail -3 | tee $O/pytest_gpu.log
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 | tee $O/smoke.log
 echo "=== rocprofv3 kernel trace"
 cd /tmp && export TMPDIR=/tmp
 prof() { tag=$1; shift; timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$tag -o $tag -- "$@" > $O/prof_$tag.log 2>&1; f=$(find $O/prof_$tag -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/${tag}_kernel_stats.csv && head -4 $f | cut -c1-160; }
@@ -40,6 +47,7 @@ prof c2_pairs_strict python $R/bench.py --workload deepfm_c2 --steps 400 --warmu
 prof c3 python $R/bench.py --workload din_c3 --steps 64 --warmup 8 $Q
 prof c4_v2_strict python $R/bench.py --workload deepfm_v2_c4 --steps 400 --warmup 40 --launch-batches 1 --overlap-streams 0 $Q
 prof c5 python $R/bench.py --workload widedeep_c5 --steps 100 --warmup 10 $Q
+prof c4_pairs_strict python $R/bench.py --workload deepfm_c4 --steps 200 --warmup 20 --launch-batches 1 --overlap-streams 0 $Q
 prof v2_ref_strict python $R/bench.py --workload deepfm_v2_ref --steps 400 --warmup 40 --launch-batches 1 --overlap-streams 0 $Q
 prof ncf_ref_strict python $R/bench.py --workload neuralcf_ref --steps 400 --warmup 40 --launch-batches 1 --overlap-streams 0 $Q
 echo "=== PMC passes"
@@ -48,7 +56,7 @@ pass() { # tag name counters -- command...
   timeout 300 rocprofv3 --pmc "${ctr[@]}" --kernel-trace --output-format csv -d $O/pmc_${tag}_$name -o p -- "$@" > $O/pmc_${tag}_$name.log 2>&1
 }
 P="--steps 20 --warmup 5 --cpu-seconds 0 --no-check --hbm-resident 0 --regions 1 --min-region-ms 1 --settle-ms 0 --launch-batches 1 --overlap-streams 0"
-for t in c2 c2hbm pairs c3 c5 v2ref cal; do
+for t in c2 c2hbm pairs c3 c5 v2ref c4pairs cal; do
   case $t in
     c2) CMD="python $R/bench.py $P";;
     c2hbm) CMD="python $R/bench.py $P --big-vocab 8388608";;
@@ -56,6 +64,7 @@ for t in c2 c2hbm pairs c3 c5 v2ref cal; do
     c3) CMD="python $R/bench.py $P --workload din_c3";;
     c5) CMD="python $R/bench.py $P --workload widedeep_c5";;
     v2ref) CMD="python $R/bench.py $P --workload deepfm_v2_ref";;
+    c4pairs) CMD="python $R/bench.py $P --workload deepfm_c4";;
     cal) CMD="python $R/scripts/pmc_calib.py";;
   esac
   pass $t fetch FETCH_SIZE -- $CMD
