@@ -647,7 +647,7 @@ def main():
                   "timed_with": "HIP events, " + region}
             if "reference_bytes_per_sample" in roof:
                 rl["reference_bytes_per_sample"] = roof["reference_bytes_per_sample"]
-            mi = mfma_issued(roof["kernel"], roof.get("mfma_reference_flops"))
+            mi = mfma_issued(roof["kernel"], roof.get("mfma_reference_flops"), wide_rows=args.workload == "deepfm_c4")
             if mi:
                 extra["roofline_mfma"] = mfma_block(roof["kernel"], mi, B, fwd_s)
         else:
@@ -780,10 +780,12 @@ MFMA_ISSUED = {
 }
 
 
-def mfma_issued(kernel, reference_flops_per_sample):
+def mfma_issued(kernel, reference_flops_per_sample, wide_rows=False):
     m = MFMA_ISSUED.get(kernel)
     if not m:
         return None
+    if wide_rows and kernel == "k_deepfm_pairs":
+        m = {"per": 16, "f32": 8, "f16": 48 + 24}        # emb_dim 64: deep0's embedding block is four K = 32 blocks
     return {"f32_flops_per_sample": m["f32"] * 2048.0 / m["per"], "f16_flops_per_sample": m["f16"] * 16384.0 / m["per"],
             "reference_flops_per_sample": reference_flops_per_sample}
 
