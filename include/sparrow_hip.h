@@ -318,6 +318,24 @@ int sprk_comm_create(const uint8_t id[SPRK_COMM_ID_BYTES], int32_t rank, int32_t
 int sprk_comm_allgather_scores(sprk_comm c, const float* local, float* gathered, size_t count, void* stream);
 void sprk_comm_destroy(sprk_comm c);
 
+/* The same exchange as direct peer writes over xGMI: every rank stores its slice straight into all peers'
+ * receive buffers (one step on the point-to-point mesh instead of a ring's world-1 dependent hops), then waits for the peers'
+ * arrival flags -- two kernels on the caller's stream, no host synchronisation, no RCCL.  Setup: every rank calls
+ * sprk_peer_create (allocates its receive buffer [2 parities][world][slot_floats] + flags and returns the 64-byte IPC handle),
+ * the handles travel through any host channel, every rank calls sprk_peer_connect with all of them (rank order).
+ * sprk_peer_allgather_scores: local [count <= slot_floats] -> *gathered = this rank's receive buffer for this exchange,
+ * [world][slot_floats] floats (rank r's slice at r * slot_floats), valid for work enqueued on `stream` until the exchange after
+ * the next one on this communicator; one exchange in flight per communicator.  A slice that does not arrive within the deadline
+ * (2 s; SPRK_PEER_TIMEOUT_MS) raises a flag that sprk_peer_check (synchronises the stream) reports as SPRK_EHIP. */
+#define SPRK_PEER_HANDLE_BYTES 64
+typedef struct sprk_peer_s* sprk_peer;
+int sprk_peer_create(int32_t rank, int32_t world, size_t slot_floats, uint8_t handle_out[SPRK_PEER_HANDLE_BYTES], sprk_peer* out);
+int sprk_peer_connect(sprk_peer c, const uint8_t* handles /* [world][SPRK_PEER_HANDLE_BYTES] */);
+int sprk_peer_allgather_scores(sprk_peer c, const float* local, size_t count, const float** gathered, void* stream);
+int sprk_peer_check(sprk_peer c, void* stream);
+const char* sprk_peer_memory_kind(sprk_peer c);   /* "uncached" | "fine-grained" | "default": how the receive buffer was allocated */
+void sprk_peer_destroy(sprk_peer c);
+
 const char* sprk_last_error(void);
 
 #ifdef __cplusplus

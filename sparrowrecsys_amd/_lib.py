@@ -35,6 +35,7 @@ EXPORTED_SYMBOLS = [
     "sprk_check_ids", "sprk_debug_set_trace", "sprk_destroy", "sprk_embedding_gather", "sprk_cross_hash", "sprk_last_error",
     "sprk_pack_csv", "sprk_pack_csv_mt", "sprk_set_many_streams", "sprk_set_many_batches", "sprk_emb_rank",
     "sprk_describe", "sprk_comm_unique_id", "sprk_comm_create", "sprk_comm_allgather_scores", "sprk_comm_destroy",
+    "sprk_peer_create", "sprk_peer_connect", "sprk_peer_allgather_scores", "sprk_peer_check", "sprk_peer_memory_kind", "sprk_peer_destroy",
 ]
 
 
@@ -152,6 +153,14 @@ def load_library():
         lib.sprk_comm_allgather_scores.argtypes = [vp, vp, vp, sz, vp]
         lib.sprk_comm_destroy.argtypes = [vp]
         lib.sprk_comm_destroy.restype = None
+        lib.sprk_peer_create.argtypes = [i32, i32, sz, C.c_char_p, C.POINTER(vp)]
+        lib.sprk_peer_connect.argtypes = [vp, C.c_char_p]
+        lib.sprk_peer_allgather_scores.argtypes = [vp, vp, sz, C.POINTER(vp), vp]
+        lib.sprk_peer_check.argtypes = [vp, vp]
+        lib.sprk_peer_memory_kind.argtypes = [vp]
+        lib.sprk_peer_memory_kind.restype = C.c_char_p
+        lib.sprk_peer_destroy.argtypes = [vp]
+        lib.sprk_peer_destroy.restype = None
         lib.sprk_set_many_streams.argtypes = [vp, i32]
         lib.sprk_set_many_batches.argtypes = [vp, i32]
         lib.sprk_pack_csv.argtypes = [C.c_char_p, sz, C.POINTER(CsvCol), i32, C.POINTER(C.c_char_p), i32, i32, vp, vp,
@@ -160,7 +169,7 @@ def load_library():
                                          C.POINTER(i32)]
         lib.sprk_emb_rank.argtypes = [vp, vp, i32, i32, i32, vp, vp, i32, i32, vp, i32, vp, vp, vp]
         for name in EXPORTED_SYMBOLS:
-            if name not in ("sprk_last_error", "sprk_destroy", "sprk_workspace_bytes", "sprk_comm_destroy"):
+            if name not in ("sprk_last_error", "sprk_destroy", "sprk_workspace_bytes", "sprk_comm_destroy", "sprk_peer_destroy", "sprk_peer_memory_kind"):
                 getattr(lib, name).restype = C.c_int
         _lib = lib
         return lib

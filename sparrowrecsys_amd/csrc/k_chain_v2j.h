@@ -49,6 +49,7 @@ struct V2JRun {
     int j_vocab[V2J_MAX_JF];
     int s_off[V2J_MAX_JF];                // float offset of small field f's rows inside the small-table block
     int small_floats;                     // size of the small-table block (multiple of 256 floats = one LDS-DMA piece per wave)
+    int wf_off;                           // HALF: float offset, inside the small-table block, of the numerics' fold Wf [H0][8]
     const float* tab0;                    // folded rows of the big fields {P | row scalar | 0..}
     const float* small;                   // small fields' rows {P | W0^T P (+ b0 in field 0) | row scalar | 0 0 0}, V2J_SS floats each
     float h0w, fo_bias, head_bias;
@@ -100,6 +101,23 @@ __global__ __launch_bounds__(256) void k_v2_absmax(const float* __restrict__ row
     for (int d = 32; d >= 1; d >>= 1) { const float o = __shfl_xor(m, d); m = (o > m || o != o) ? o : m; }
     if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));
 }
+// How many non-zero entries sit more than 2^20 below max |x| (thresh = max * 2^-20) -> out[0], non-zero entries -> out[1].
+// With the static scale that puts max |x| in [2^14, 2^15) such an entry's lo half is an f16 subnormal (resolution 2^-24 of
+// the scaled value): it keeps fewer than ~20 significand bits, so a table full of them is not fp32-class on split f16.
+__global__ __launch_bounds__(256) void k_v2_count_small(const float* __restrict__ rows, long long nrows, int row_floats, int ncols,
+                                                        float thresh, unsigned long long* __restrict__ out) {
+    unsigned small = 0, nz = 0;
+    const long long total = nrows * ncols;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long v = i / ncols;
+        const int c = (int)(i - v * ncols);
+        const float a = fabsf(rows[v * row_floats + c]);
+        nz += a > 0.f;
+        small += (a > 0.f && a < thresh);
+    }
+    for (int d = 32; d >= 1; d >>= 1) { small += __shfl_xor(small, d); nz += __shfl_xor(nz, d); }
+    if ((threadIdx.x & 63) == 0) { atomicAdd(out, (unsigned long long)small); atomicAdd(out + 1, (unsigned long long)nz); }
+}
 // folded fp32 rows {P[16] | scalar | 0..} -> split rows {[hi4|lo4] x 4 | scalar | 0..} of P * scale
 __global__ __launch_bounds__(256) void k_v2_split_rows(const float* __restrict__ src, float* __restrict__ dst,
                                                        long long nrows, float scale) {
@@ -144,12 +162,38 @@ __global__ __launch_bounds__(256) void k_v2_fold_small(const float* __restrict__
     }
 }
 
+// One-time (finalize) kernel for HALF: the numeric group folded through deep0.  deep0 is linear in its input and the
+// numeric group's projection pn = Wn x + bn is linear in the (at most 8) numerics x (DeepFM_v2.py:118-125), so its share
+// of deep0's pre-activation is (W0n Wn) x + W0n bn:
+//     wf[m][k]  = sum_n W0[m][num_off + n] * Wn[n][k]         [H0][8], zero for k >= n_num  -> two K = 4 MFMA steps per
+//                                                              16 outputs (k = q + 4s) instead of four on a dependent pn
+//     rows0[v][KP + m] += sum_n W0[m][num_off + n] * bn[n]      the constant rides with b0 in the first small field's rows
+// (double accumulation, one rounding.)  pn itself is still formed in the kernel -- the FM sum needs it.
+__global__ __launch_bounds__(256) void k_v2j_fold_num(const float* __restrict__ W0, int ldw0, int num_off,
+                                                      const float* __restrict__ Wn, int ldn, const float* __restrict__ bn,
+                                                      int n_num, int KP, int H0, float* __restrict__ wf,
+                                                      float* __restrict__ rows0, int nrows0) {
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < H0 * 8; i += gridDim.x * 256) {
+        const int m = i >> 3, k = i & 7;
+        double acc = 0.0;
+        if (k < n_num)
+            for (int n = 0; n < KP; ++n) acc += (double)W0[(size_t)m * ldw0 + num_off + n] * (double)Wn[(size_t)n * ldn + k];
+        wf[i] = (float)acc;
+    }
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < nrows0 * H0; i += gridDim.x * 256) {
+        const int v = i / H0, m = i - v * H0;
+        double acc = 0.0;
+        for (int n = 0; n < KP; ++n) acc += (double)W0[(size_t)m * ldw0 + num_off + n] * (double)bn[n];
+        rows0[(size_t)v * V2J_SS + KP + m] = (float)((double)rows0[(size_t)v * V2J_SS + KP + m] + acc);
+    }
+}
+
 // everything one 16-sample task needs from memory, in the (r,q) lane layout
 template <int G_BIG, int NJF>
 struct V2JSet {
     f32x4 x[G_BIG];       // big fields' row pieces: 4 floats of P, or [hi4 | lo4] halfs (HALF)
     int so[NJF];          // small fields: LDS float offset of this sample's row
-    f32x4 xn;             // numerics
+    f32x4 xn;             // numerics: x[4q .. 4q+3]; HALF: {x[q], x[q+4]} only (K = 8 as two MFMA steps)
     float w1a;            // per-id logit terms fetched by this lane
 };
 
@@ -251,10 +295,15 @@ __device__ __forceinline__ void v2j_body(const V2JRun& A, const int* __restrict_
             const float* nrow = stage + 128 + r * A.ND;
             const int c0 = 4 * q, last = A.n_num - 1;
             // lane slots beyond n_num hold a duplicate finite value that only ever meets zero weights
-            S.xn.x = nrow[min(c0 + 0, last)];
-            S.xn.y = nrow[min(c0 + 1, last)];
-            S.xn.z = nrow[min(c0 + 2, last)];
-            S.xn.w = nrow[min(c0 + 3, last)];
+            if constexpr (HALF) {
+                S.xn.x = nrow[min(q, last)];
+                S.xn.y = nrow[min(q + 4, last)];
+            } else {
+                S.xn.x = nrow[min(c0 + 0, last)];
+                S.xn.y = nrow[min(c0 + 1, last)];
+                S.xn.z = nrow[min(c0 + 2, last)];
+                S.xn.w = nrow[min(c0 + 3, last)];
+            }
         }
         const char* tb = reinterpret_cast<const char*>(A.tab0);
 #pragma unroll
@@ -276,13 +325,19 @@ __device__ __forceinline__ void v2j_body(const V2JRun& A, const int* __restrict_
     f32x4 rW0[H0C][NKR], rW1[H1C][H0C];
     f32x4 rwn[KPC], rbpn[KPC], rb1[H1C], rhfm[KPC], rhd[H1C];
     f32x4 rfn = zero;
+    float rwn8[2] = {0.f, 0.f}, rfn8[2] = {0.f, 0.f}, rwf[H0C][2];   // HALF: numerics with k = q + 4s (Wn, first order, Wf)
     f16x8 hWa[HALF ? G_BIG : 1][H0C], hWb[HALF ? G_BIG : 1][H0C];   // HALF: [Whi|Whi], [Wlo|Wlo] fragments of the big fields
     f16x8 hSel = {0, 0, 0, 0, 0, 0, 0, 0};                         // HALF: 0/1 selection A operand: D[n] = hi[n] + lo[n]
     auto load_weights = [&]() {
         const float* w0r = wq + LD::off_w0 + r * LD::S0;
 #pragma unroll
         for (int n0 = 0; n0 < H0C; ++n0) {
-            rW0[n0][0] = ld4(w0r + n0 * 16 * LD::S0 + 16 * G_EMB);                     // numeric chunk
+            if constexpr (HALF) {
+                rwf[n0][0] = small_s[A.wf_off + (n0 * 16 + r) * 8 + q];              // numerics folded through deep0
+                rwf[n0][1] = small_s[A.wf_off + (n0 * 16 + r) * 8 + q + 4];
+            } else {
+                rW0[n0][0] = ld4(w0r + n0 * 16 * LD::S0 + 16 * G_EMB);                 // numeric chunk
+            }
 #pragma unroll
             for (int b = 0; b < G_BIG; ++b) {
                 const f32x4 w = ld4(w0r + n0 * 16 * LD::S0 + 16 * A.big_grp[b]);
@@ -314,6 +369,12 @@ __device__ __forceinline__ void v2j_body(const V2JRun& A, const int* __restrict_
             rhfm[nb] = ld4(wq + LD::off_hfm + nb * 16);
         }
         rfn = ld4(smem + LD::off_fn + 4 * (q & 1));
+        if constexpr (HALF) {
+            rwn8[0] = smem[LD::off_wn + r * LD::SN + q];
+            rwn8[1] = smem[LD::off_wn + r * LD::SN + q + 4];
+            rfn8[0] = smem[LD::off_fn + q];
+            rfn8[1] = smem[LD::off_fn + q + 4];
+        }
     };
 
     // ---- scoring stage ----
@@ -321,7 +382,11 @@ __device__ __forceinline__ void v2j_body(const V2JRun& A, const int* __restrict_
         const f32x4 pnum = S.xn;
         // numeric group's Dense projection (DeepFM_v2.py:118-120): two chains (even / odd K step)
         f32x4 pn;
-        {
+        if constexpr (HALF) {
+            const f32x4 e = __builtin_amdgcn_mfma_f32_16x16x4f32(rwn8[0], pnum.x, rbpn[0], 0, 0, 0);
+            const f32x4 o = __builtin_amdgcn_mfma_f32_16x16x4f32(rwn8[1], pnum.y, zero, 0, 0, 0);
+            pn = e + o;
+        } else {
             f32x4 e = rbpn[0], o = zero;
             e = __builtin_amdgcn_mfma_f32_16x16x4f32(rwn[0].x, pnum.x, e, 0, 0, 0);
             o = __builtin_amdgcn_mfma_f32_16x16x4f32(rwn[0].y, pnum.y, o, 0, 0, 0);
@@ -330,7 +395,7 @@ __device__ __forceinline__ void v2j_body(const V2JRun& A, const int* __restrict_
             pn = e + o;
         }
         // this lane's share of the per-id logit terms + numeric first-order partial (rfn = h0w * fo_num weights)
-        float zz = ((q < G_BIG) ? S.w1a : 0.f) + ((q < 2) ? dot4(rfn, pnum) : 0.f);
+        float zz = ((q < G_BIG) ? S.w1a : 0.f) + (HALF ? rfn8[0] * pnum.x + rfn8[1] * pnum.y : ((q < 2) ? dot4(rfn, pnum) : 0.f));
         // small fields, from their LDS rows: P -> FM sum, W0^T P (+ b0) -> deep0's accumulators, row scalars (one q row adds them)
         f32x4 sp = ld4(small_s + S.so[0] + 4 * q), sq[H0C];
 #pragma unroll
@@ -366,12 +431,12 @@ __device__ __forceinline__ void v2j_body(const V2JRun& A, const int* __restrict_
                 for (int n0 = 0; n0 < H0C; ++n0) aFb[n0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(hWb[b][n0], xb, aFb[n0], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);                // keep the round-robin order: the next use of a chain is 5 MFMAs away
             }
-            // numerics' chunk on f32 MFMA (its operand is computed per sample); one chain per n-block
+            // numerics' share on f32 MFMA, folded through their projection (k_v2j_fold_num): K = 8, independent of pn
 #pragma unroll
-            for (int st = 0; st < 4; ++st)
+            for (int st = 0; st < 2; ++st)
 #pragma unroll
                 for (int n0 = 0; n0 < H0C; ++n0)
-                    hA[n0] = __builtin_amdgcn_mfma_f32_16x16x4f32(rW0[n0][0][st], pn[st], hA[n0], 0, 0, 0);
+                    hA[n0] = __builtin_amdgcn_mfma_f32_16x16x4f32(rwf[n0][st], st ? pnum.y : pnum.x, hA[n0], 0, 0, 0);
             s += aS * A.unscale_s;
 #pragma unroll
             for (int n0 = 0; n0 < H0C; ++n0) hB[n0] = (aFa[n0] + aFb[n0]) * A.unscale_h;

@@ -617,6 +617,7 @@ __global__ __launch_bounds__(256) void k_zero_columns(float* __restrict__ Wt, in
 #include "k_mlp_rows.h"
 #include "k_emb_rank.h"
 #include "k_dien_seq.h"
+#include "k_peer_gather.h"
 
 // ---------------------------------------------------------------------------------------------
 // stand-alone operators
@@ -1077,6 +1078,7 @@ bool match_v2_chain(sprk_engine* h) {
 // Split the fields of a folded DeepFM_v2 engine into big ones (gathered per field) and a joint group of
 // small-vocabulary ones (one gather per sample), build the joint table.  Leaves v2j_variant = -1 when the
 // model has no small field or no instantiation fits.
+int wide_dynamic_range(const float* rows, long long nrows, int row_floats, int ncols, float mx, bool* wide);
 int setup_v2_joint(sprk_engine* h) {
     const V2Variant& vv = kV2Variants[h->v2_variant];
     const char* jm = getenv("SPRK_V2_JOINT");                 // A/B switch: "0" = per-field gathers only
@@ -1119,6 +1121,18 @@ int setup_v2_joint(sprk_engine* h) {
             if (e < -60) e = -60;
             (i == 0 ? p_scale : w_scale) = ldexpf(1.f, e);
         }
+        // an outlier row next to ordinary ones: the ordinary rows' lo halves would be subnormal -> keep the f32 variant
+        for (int b = 0; half && b < nbig; ++b) {
+            bool wide = false;
+            if (int rcw = wide_dynamic_range(h->v2_folded + (size_t)h->v2run.rowbase[big[b]] * (KP + 16),
+                                             (long long)h->v2run.vocab[big[b]] + 1, KP + 16, KP, mx[0], &wide)) return rcw;
+            if (wide) half = false;
+        }
+        if (half) {
+            bool wide = false;
+            if (int rcw = wide_dynamic_range(h->v2.W0, (long long)H0, (G + 1) * KP, (G + 1) * KP, mx[1], &wide)) return rcw;
+            if (wide) half = false;
+        }
     }
     int variant = -1;
     for (size_t v = 0; v < sizeof(kV2JVariants) / sizeof(kV2JVariants[0]); ++v)
@@ -1139,6 +1153,8 @@ int setup_v2_joint(sprk_engine* h) {
         small_floats += ((size_t)r.j_vocab[f] + 1) * V2J_SS;
     }
     small_floats = (small_floats + 255) & ~(size_t)255;          // whole 1-KB LDS-DMA pieces
+    r.wf_off = (int)small_floats;                                // HALF: the numerics' fold through deep0, [H0][8]
+    if (half) small_floats += ((size_t)H0 * 8 + 255) & ~(size_t)255;
     HIP_TRY(hipMalloc((void**)&h->v2j_tab, small_floats * sizeof(float)));
     HIP_TRY(hipMemset(h->v2j_tab, 0, small_floats * sizeof(float)));
     for (int f = 0; f < njf; ++f) {
@@ -1147,6 +1163,9 @@ int setup_v2_joint(sprk_engine* h) {
                            h->v2_folded + (size_t)h->v2run.rowbase[jf[f]] * (KP + 16), KP, H0, jf[f], h->v2.W0, (G + 1) * KP,
                            h->v2.b0, f == 0 ? 1 : 0, h->v2j_tab + r.s_off[f], rows);
     }
+    if (half)
+        hipLaunchKernelGGL(k_v2j_fold_num, dim3(8), dim3(256), 0, 0, h->v2.W0, (G + 1) * KP, G * KP, h->v2.Wp[G], h->v2.ldp_num,
+                           h->v2.bp[G], h->v2.n_num, KP, H0, h->v2j_tab + r.wf_off, h->v2j_tab + r.s_off[0], r.j_vocab[0] + 1);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
     r.small_floats = (int)small_floats;
@@ -1549,6 +1568,28 @@ int fold_first_dense(sprk_engine* h, DevPlan* dp) {
     return SPRK_OK;
 }
 
+// Dynamic-range guard for a STATIC split-f16 scale (one power of two per table from max |x|): true when more than 1 in
+// 1024 of the non-zero entries lie over 2^20 below the maximum -- their lo halves would be f16 subnormals and the entries
+// would carry fewer than ~20 significand bits (an outlier row next to ordinary ones).  The caller then keeps the f32 MFMA
+// variant of the same kernel.  SPRK_HALF_RANGE_GUARD=0 switches the check off (for the test that shows why it is there).
+int wide_dynamic_range(const float* rows, long long nrows, int row_floats, int ncols, float mx, bool* wide) {
+    *wide = false;
+    const char* g = getenv("SPRK_HALF_RANGE_GUARD");
+    if ((g && g[0] == '0') || !(mx > 0.f) || nrows <= 0) return SPRK_OK;
+    unsigned long long* d_cnt = nullptr;
+    HIP_TRY(hipMalloc((void**)&d_cnt, 2 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(d_cnt, 0, 2 * sizeof(unsigned long long)));
+    long long blocks = (nrows * ncols + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(k_v2_count_small, dim3((unsigned)blocks), dim3(256), 0, 0, rows, nrows, row_floats, ncols, ldexpf(mx, -20), d_cnt);
+    HIP_TRY(hipGetLastError());
+    unsigned long long cnt[2] = {0, 0};
+    HIP_TRY(hipMemcpy(cnt, d_cnt, sizeof(cnt), hipMemcpyDeviceToHost));
+    (void)hipFree(d_cnt);
+    *wide = cnt[0] * 1024ull > cnt[1];
+    return SPRK_OK;
+}
+
 // A Dense layer's W^T [N][ld] (K columns) as split-f16 A fragments for the per-sample dynamic-scale path (dyn_split.h):
 // static power-of-two scale putting max |W| in [2^14, 2^15).  *frag stays NULL when switched off (SPRK_DYN_F16=0), when
 // the shape does not tile (N % 16, K % 32) or the weights are not finite.
@@ -1566,6 +1607,9 @@ int make_dyn_fragments(sprk_engine* h, const float* W, int ld, int N, int K, flo
     float mx;
     memcpy(&mx, &bits, sizeof(mx));
     if (!(mx < 3.0e38f)) return SPRK_OK;
+    bool wide = false;
+    if (int rcw = wide_dynamic_range(W, (long long)N, ld, K, mx, &wide)) return rcw;
+    if (wide) return SPRK_OK;
     int e = 0;
     float w_scale = 1.f;
     if (mx > 0.f) { (void)frexpf(mx, &e); e = 15 - e; if (e > 60) e = 60; if (e < -60) e = -60; w_scale = ldexpf(1.f, e); }
@@ -2352,6 +2396,11 @@ int sprk_finalize(sprk_handle h) {
                     float mx[3];
                     memcpy(mx, bits, sizeof(mx));
                     if (!(mx[0] < 3.0e38f) || !(mx[1] < 3.0e38f) || !(mx[2] < 3.0e38f)) { want_half = false; v = (size_t)-1; continue; }   // NaN / Inf weights: rescan for the f32 kernel
+                    {
+                        bool wide = false;                      // outlier rows: the ordinary rows would lose their lo halves
+                        if (int rcw = wide_dynamic_range(d.table, (long long)s.vocab, s.row_stride, s.row_stride, mx[0], &wide)) return rcw;
+                        if (wide) { want_half = false; v = (size_t)-1; continue; }
+                    }
                     const float bound_a = mx[1] + mx[2] * mx[0];
                     int e = 0;
                     if (mx[0] > 0.f) { (void)frexpf(mx[0], &e); e = 15 - e; if (e > 60) e = 60; if (e < -60) e = -60; h_scale = ldexpf(1.f, e); }
@@ -3226,6 +3275,131 @@ int sprk_comm_allgather_scores(sprk_comm c, const float* local, float* gathered,
 void sprk_comm_destroy(sprk_comm c) {
     if (!c) return;
     if (c->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(c->comm);
+    delete c;
+}
+
+// ---- the same exchange as direct peer writes (k_peer_gather.h) ----
+}  // extern "C"
+
+struct sprk_peer_s {
+    int rank = 0, world = 1;
+    size_t slot = 0;                      // floats per rank slot
+    void* base = nullptr;                 // [2][world][slot] floats | [2][world] flags: one allocation, exported by IPC
+    size_t flags_off = 0;
+    const char* mem_kind = "";
+    void* peer_base[PEER_MAX_WORLD] = {};
+    unsigned* done = nullptr;             // [world] local workgroup counters
+    int* err = nullptr;
+    unsigned epoch = 0;
+    bool connected = false;
+    unsigned long long ticks = 200000000ull;   // 2 s of the 100 MHz wall clock
+};
+
+extern "C" {
+
+int sprk_peer_create(int32_t rank, int32_t world, size_t slot_floats, uint8_t handle_out[SPRK_PEER_HANDLE_BYTES], sprk_peer* out) {
+    static_assert(sizeof(hipIpcMemHandle_t) == SPRK_PEER_HANDLE_BYTES, "hipIpcMemHandle_t is 64 bytes");
+    if (!out || !handle_out) return fail(SPRK_EINVAL, "NULL argument");
+    *out = nullptr;
+    if (world < 1 || world > PEER_MAX_WORLD || rank < 0 || rank >= world) return fail(SPRK_EINVAL, "bad rank/world %d/%d (world <= %d)", rank, world, PEER_MAX_WORLD);
+    if (slot_floats == 0 || (slot_floats & 3)) return fail(SPRK_EINVAL, "slot_floats must be a positive multiple of 4 (16-byte stores)");
+    sprk_peer_s* c = new sprk_peer_s;
+    c->rank = rank; c->world = world; c->slot = slot_floats;
+    c->flags_off = (2 * (size_t)world * slot_floats * sizeof(float) + 255) & ~(size_t)255;
+    const size_t bytes = c->flags_off + 2 * (size_t)world * sizeof(unsigned);
+    // peers store into this buffer over xGMI while kernels of this device poll and read it: fine-grained (uncached) memory where
+    // the runtime can export it by IPC, plain device memory otherwise (same-device peers share the L2)
+    const struct { unsigned flag; const char* name; } kinds[] = {
+        {hipDeviceMallocUncached, "uncached"}, {hipDeviceMallocFinegrained, "fine-grained"}, {hipDeviceMallocDefault, "default"}};
+    hipIpcMemHandle_t hd;
+    const char* forced = getenv("SPRK_PEER_MEM");             // "default" | "fine-grained" | "uncached": pin the kind (experiments)
+    for (const auto& k : kinds) {
+        if (forced && strcmp(forced, k.name) != 0) continue;
+        void* p = nullptr;
+        if (hipExtMallocWithFlags(&p, bytes, k.flag) != hipSuccess || !p) { (void)hipGetLastError(); continue; }
+        if (hipIpcGetMemHandle(&hd, p) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(p); continue; }
+        c->base = p; c->mem_kind = k.name;
+        break;
+    }
+    if (!c->base) { delete c; return fail(SPRK_EHIP, "cannot allocate an IPC-exportable receive buffer of %zu bytes", bytes); }
+    if (hipMemset(c->base, 0, bytes) != hipSuccess || hipMalloc((void**)&c->done, PEER_MAX_WORLD * sizeof(unsigned)) != hipSuccess ||
+        hipMemset(c->done, 0, PEER_MAX_WORLD * sizeof(unsigned)) != hipSuccess || hipMalloc((void**)&c->err, sizeof(int)) != hipSuccess ||
+        hipMemset(c->err, 0, sizeof(int)) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+        (void)hipFree(c->base); if (c->done) (void)hipFree(c->done); if (c->err) (void)hipFree(c->err);
+        delete c;
+        return fail(SPRK_EHIP, "peer buffer setup failed: %s", hipGetErrorString(hipGetLastError()));
+    }
+    if (const char* t = getenv("SPRK_PEER_TIMEOUT_MS")) { const long ms = atol(t); if (ms > 0) c->ticks = (unsigned long long)ms * 100000ull; }
+    memcpy(handle_out, &hd, SPRK_PEER_HANDLE_BYTES);
+    c->peer_base[rank] = c->base;
+    *out = c;
+    return SPRK_OK;
+}
+
+int sprk_peer_connect(sprk_peer c, const uint8_t* handles) {
+    if (!c || !handles) return fail(SPRK_EINVAL, "NULL argument");
+    if (c->connected) return fail(SPRK_ESTATE, "peer communicator is already connected");
+    for (int p = 0; p < c->world; ++p) {
+        if (p == c->rank) continue;
+        hipIpcMemHandle_t hd;
+        memcpy(&hd, handles + (size_t)p * SPRK_PEER_HANDLE_BYTES, sizeof(hd));
+        void* q = nullptr;
+        const hipError_t e = hipIpcOpenMemHandle(&q, hd, hipIpcMemLazyEnablePeerAccess);
+        if (e != hipSuccess || !q) { (void)hipGetLastError(); return fail(SPRK_EHIP, "hipIpcOpenMemHandle of rank %d's buffer: %s", p, hipGetErrorString(e)); }
+        c->peer_base[p] = q;
+    }
+    c->connected = true;
+    return SPRK_OK;
+}
+
+int sprk_peer_allgather_scores(sprk_peer c, const float* local, size_t count, const float** gathered, void* stream) {
+    if (!c || !local || !gathered) return fail(SPRK_EINVAL, "NULL argument");
+    if (!c->connected) return fail(SPRK_ESTATE, "peer all-gather before sprk_peer_connect");
+    if (count > c->slot) return fail(SPRK_EINVAL, "count %zu exceeds the slot of %zu floats", count, c->slot);
+    const unsigned e = ++c->epoch;
+    const int parity = (int)(e & 1);
+    *gathered = (const float*)c->base + (size_t)parity * c->world * c->slot;
+    PeerPut a;
+    memset(&a, 0, sizeof(a));
+    for (int p = 0; p < c->world; ++p) {
+        a.dst[p] = (float*)c->peer_base[p] + ((size_t)parity * c->world + c->rank) * c->slot;
+        a.flag[p] = (unsigned*)((char*)c->peer_base[p] + c->flags_off) + parity * c->world + c->rank;
+    }
+    a.src = local; a.count = count; a.epoch = e; a.world = c->world; a.done = c->done;
+    long long bpp = ((long long)count / 4 + 1023) / 1024;      // ~4 sixteen-byte stores per thread
+    if (bpp < 1) bpp = 1;
+    if (bpp > 32) bpp = 32;
+    a.blocks_per_peer = (int)bpp;
+    hipLaunchKernelGGL(k_peer_put, dim3((unsigned)(c->world * bpp)), dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(k_peer_wait, dim3(1), dim3(64), 0, (hipStream_t)stream,
+                       (const unsigned*)((const char*)c->base + c->flags_off) + parity * c->world, c->world, e, c->ticks, c->err);
+    HIP_TRY(hipGetLastError());
+    return SPRK_OK;
+}
+
+int sprk_peer_check(sprk_peer c, void* stream) {
+    if (!c) return fail(SPRK_EINVAL, "communicator is NULL");
+    int flag = 0;
+    HIP_TRY(hipMemcpyAsync(&flag, c->err, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    if (flag) {
+        HIP_TRY(hipMemsetAsync(c->err, 0, sizeof(int), (hipStream_t)stream));
+        HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+        return fail(SPRK_EHIP, "peer all-gather: a rank's slice did not arrive within the deadline (rank %d of %d, exchange %u)", c->rank, c->world, c->epoch);
+    }
+    return SPRK_OK;
+}
+
+const char* sprk_peer_memory_kind(sprk_peer c) { return c ? c->mem_kind : ""; }
+
+void sprk_peer_destroy(sprk_peer c) {
+    if (!c) return;
+    (void)hipDeviceSynchronize();
+    for (int p = 0; p < c->world; ++p)
+        if (p != c->rank && c->peer_base[p]) (void)hipIpcCloseMemHandle(c->peer_base[p]);
+    if (c->base) (void)hipFree(c->base);
+    if (c->done) (void)hipFree(c->done);
+    if (c->err) (void)hipFree(c->err);
     delete c;
 }
 

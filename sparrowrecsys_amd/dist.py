@@ -6,6 +6,8 @@ backend "nccl" is RCCL over xGMI on ROCm; the same code runs on "gloo" for the C
 Two shapes of the same exchange:
   * ``RowShardedPredictor``  one global batch -> shard -> forward -> all-gather (latency path, what a
     single ``/getrecforyou`` request needs);
+  * ``ScoreComm`` / ``PeerScoreComm``  the exchange behind the C ABI: RCCL's all-gather, or one step of direct peer
+    writes over the xGMI mesh (every rank stores its slice into all peers' receive buffers);
   * ``GroupedScoreGather``   the ``model.predict(dataset)`` loop: a forward of one 65 536-row shard takes
     ~9 us, an RCCL all-gather of its 256 KiB score slice costs more than that in launch latency alone, so
     scores of ``group`` consecutive batches are written into one ring slot and exchanged by ONE larger
@@ -71,6 +73,92 @@ class ScoreComm:
             pass
 
 
+class _DevView:
+    """A device buffer owned by the C library, seen by torch without a copy (``torch.as_tensor(view, device=...)``)."""
+
+    def __init__(self, ptr: int, shape, owner):
+        self.owner = owner                                      # keeps the communicator (and its buffer) alive
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": "<f4", "data": (int(ptr), False), "version": 2, "strides": None}
+
+
+class PeerScoreComm:
+    """The exchange as direct peer writes over xGMI (``sprk_peer_*``, include/sparrow_hip.h): every rank
+    stores its score slice into all peers' receive buffers in one step and waits for their arrival flags -- two kernels on
+    the caller's stream, no RCCL, no ring.  The 64-byte IPC handles of the receive buffers are exchanged once through the
+    torch.distributed process group (host side).  ``slot_floats``: the largest slice a rank will ever send."""
+
+    def __init__(self, slot_floats: int, group=None, device=None):
+        import ctypes as C
+
+        import torch
+        import torch.distributed as dist
+
+        from . import _lib as L
+        self.lib = L.load_library()
+        self._L, self._C = L, C
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.slot = (int(slot_floats) + 3) & ~3
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        hd = C.create_string_buffer(64)
+        self.handle = C.c_void_p()
+        with torch.cuda.device(self.device):
+            L.check(self.lib.sprk_peer_create(self.rank, self.world, self.slot, hd, C.byref(self.handle)))
+        handles = [bytes(hd.raw)]
+        if self.world > 1:
+            handles = [None] * self.world
+            dist.all_gather_object(handles, bytes(hd.raw), group=group)
+        with torch.cuda.device(self.device):
+            L.check(self.lib.sprk_peer_connect(self.handle, C.create_string_buffer(b"".join(handles), 64 * self.world)))
+        if self.world > 1:
+            dist.barrier(group=group)                           # nobody stores into a buffer its owner has not mapped / zeroed yet
+        self.memory_kind = self.lib.sprk_peer_memory_kind(self.handle).decode()
+        self._views = {}
+        self._hip = None
+
+    def all_gather(self, local, stream=None):
+        """local [count <= slot] float32 (device) -> [world, slot] float32 view of this rank's receive buffer: row r holds rank
+        r's slice in [:count].  Asynchronous on ``stream`` (default: torch's current stream); the view stays valid for work on
+        that stream until the exchange after the next one."""
+        import torch
+        C = self._C
+        if local.dtype != torch.float32 or not local.is_cuda or not local.is_contiguous():
+            raise ValueError("PeerScoreComm.all_gather: a contiguous float32 device tensor is required")
+        if local.numel() > self.slot:
+            raise ValueError("PeerScoreComm.all_gather: %d scores exceed the slot of %d" % (local.numel(), self.slot))
+        if stream is None:
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+        out = C.c_void_p()
+        self._L.check(self.lib.sprk_peer_allgather_scores(self.handle, C.c_void_p(local.data_ptr()), local.numel(), C.byref(out), C.c_void_p(stream)))
+        if out.value not in self._views:
+            try:
+                self._views[out.value] = (torch.as_tensor(_DevView(out.value, (self.world, self.slot), self), device=self.device), False)
+            except Exception:                                   # a torch build without __cuda_array_interface__ import: one device copy
+                if self._hip is None:
+                    self._hip = C.CDLL("libamdhip64.so")
+                    self._hip.hipMemcpyAsync.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+                self._views[out.value] = (torch.empty((self.world, self.slot), dtype=torch.float32, device=self.device), True)
+        view, copy = self._views[out.value]
+        if copy:
+            rc = self._hip.hipMemcpyAsync(C.c_void_p(view.data_ptr()), out, view.numel() * 4, 3, C.c_void_p(stream))   # 3 = device to device
+            if rc != 0:
+                raise RuntimeError("hipMemcpyAsync of the receive buffer failed (%d)" % rc)
+        return view
+
+    def check(self, stream=None):
+        """Synchronises ``stream`` and raises if a peer's slice did not arrive within the deadline."""
+        import torch
+        if stream is None:
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+        self._L.check(self.lib.sprk_peer_check(self.handle, self._C.c_void_p(stream)))
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self._views = {}
+            self.lib.sprk_peer_destroy(self.handle)
+            self.handle = None
+
+
 def shard_bounds(n_rows: int, rank: int, world: int) -> Tuple[int, int]:
     """Rows [lo, hi) owned by ``rank``: contiguous, sizes differ by at most one, earlier ranks larger."""
     if world <= 0 or not 0 <= rank < world:
@@ -89,7 +177,7 @@ class RowShardedPredictor:
         import torch.distributed as dist
         self.forward = forward
         self.group = group
-        self.comm = comm                     # ScoreComm: the all-gather through the C ABI instead of torch.distributed
+        self.comm = comm                     # ScoreComm (RCCL) / PeerScoreComm (peer writes): the exchange through the C ABI
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
         self._bufs = {}                      # (rows, dtype, device) -> (slot, gathered): no allocation per request
@@ -111,6 +199,11 @@ class RowShardedPredictor:
                                torch.empty(per * self.world, dtype=local.dtype, device=local.device))
         slot, gathered = self._bufs[key]
         slot[:hi - lo] = local
+        if isinstance(self.comm, PeerScoreComm) and local.is_cuda:
+            recv = self.comm.all_gather(slot)                    # [world, comm.slot] view of the receive buffer
+            if n % self.world == 0 and recv.shape[1] == per:
+                return recv.reshape(-1)
+            return torch.cat([recv[r, :shard_bounds(n, r, self.world)[1] - shard_bounds(n, r, self.world)[0]] for r in range(self.world)])
         if self.comm is not None and local.is_cuda:
             self.comm.all_gather(slot, gathered)
         else:

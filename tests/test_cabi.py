@@ -106,3 +106,21 @@ def test_product_never_imports_the_oracle():
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), f
                 assert "plan_interp" not in src, f
+
+
+def test_peer_allgather_arguments_are_validated_before_any_device_call():
+    """sprk_peer_create's argument checks need no GPU (SPRK_EINVAL); the allocation itself fails loudly without one."""
+    import ctypes as C
+    from sparrowrecsys_amd import _lib as L
+    lib = L.load_library()
+    hd = C.create_string_buffer(64)
+    h = C.c_void_p()
+    for rank, world, slot in [(0, 0, 64), (2, 2, 64), (-1, 2, 64), (0, 17, 64), (0, 1, 0), (0, 1, 6)]:
+        assert lib.sprk_peer_create(rank, world, slot, hd, C.byref(h)) == L.EINVAL
+        assert not h.value
+    assert lib.sprk_peer_allgather_scores(None, None, 0, None, None) == L.EINVAL
+    assert lib.sprk_peer_connect(None, None) == L.EINVAL
+    import torch
+    if not torch.cuda.is_available():
+        assert lib.sprk_peer_create(0, 1, 64, hd, C.byref(h)) == L.EHIP
+        assert b"receive buffer" in lib.sprk_last_error()

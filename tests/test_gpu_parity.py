@@ -425,6 +425,39 @@ def test_deepfm_v2_split_f16_is_fp32_class(torch, monkeypatch):
         assert err["1"] <= 2 * err["0"] + 2e-6, (table_scale, err)
 
 
+def test_deepfm_v2_outlier_row_keeps_fp32_class(torch, monkeypatch):
+    """One static power-of-two scale per table comes from max |x|: a single huge row next to ordinary ones would push the
+    ordinary rows' lo halves into f16 subnormals.  The finalize-time dynamic-range guard (more than 1 in 1024
+    non-zero entries over 2^20 below the maximum) must then pick the f32 MFMA variant of the same kernel, and the scores
+    of samples that do not touch the outlier must stay fp32-class."""
+    B = 8192
+    fields = SY.CONFIG2_FIELDS
+    order = [k for k, _, _ in fields]
+    feats = SY.synth_fields(B, fields, seed=67)
+    for k in ("movieRatingCount", "userRatingCount", "releaseYear"):
+        feats[k] = (np.asarray(feats[k], np.float64) % 7).astype(np.asarray(feats[k]).dtype)
+    big_field = max(fields, key=lambda f: f[1])[0]
+    feats[big_field] = np.where(np.asarray(feats[big_field]) == 3, 4, np.asarray(feats[big_field])).astype(np.asarray(feats[big_field]).dtype)
+    base = M.DeepFMv2(seed=46, emb_dim=16, fields=fields, proj_dim=16)
+    w = dict(base.weights)
+    tab = w["emb/" + big_field].copy()
+    tab[3] *= np.float32(3.0e8)                                     # the outlier row (id 3 is referenced by nobody)
+    w["emb/" + big_field] = tab
+    ref = O.deepfm_v2_forward(feats, w, dtype=np.float64, fields=fields, order=order)[:, 0]
+    model = M.DeepFMv2(weights=w, emb_dim=16, fields=fields, proj_dim=16)
+    p = model.predict(feats)[:, 0]
+    d = model.engine.describe()
+    print("outlier row: kernel", d.get("kernel"), "max|err|", float(np.abs(p - ref).max()))
+    assert "k_deepfm_v2_joint" in d["kernel"] and "f32" in d["kernel"] and "split-f16" not in d["kernel"], d
+    assert np.abs(p - ref).max() <= TIGHT
+    monkeypatch.setenv("SPRK_HALF_RANGE_GUARD", "0")                  # what the guard prevents
+    m2 = M.DeepFMv2(weights=w, emb_dim=16, fields=fields, proj_dim=16)
+    p2 = m2.predict(feats)[:, 0]
+    assert "split-f16" in m2.engine.describe()["kernel"]
+    print("  guard off (split-f16 with subnormal lo halves): max|err| %.3g" % float(np.abs(p2 - ref).max()))
+    assert np.abs(p2 - ref).max() > np.abs(p - ref).max()
+
+
 def test_deepfm_v2_unaligned_views_and_tails(torch, config2):
     """ids/dense views that do not start on a 16-byte boundary take the element-wise staging path;
     every batch length mod 16 exercises the partial last task.  Pure data movement: bit-equal."""
@@ -556,54 +589,6 @@ def test_deepfm_pairs_kernel_vs_interpreter_and_oracle(torch, monkeypatch, shape
     assert np.abs(out["1"] - ref).max() <= 2 * np.abs(out["1f32"] - ref).max() + 2e-6
     assert np.abs(out["0"] - ref).max() <= TIGHT
     assert 0.02 < ref.std()
-
-
-@pytest.mark.parametrize("kind,B", [("embedding_mlp_ref", 4099), ("embedding_mlp", 131072), ("wide_indicator", 6007), ("wide_cross_rows", 1), ("wide_cross_rows", 33)])
-def test_mlp_rows_kernel_vs_round1_chain_and_oracle(torch, monkeypatch, kind, B):
-    """k_mlp_rows (every embedding column folded through the first Dense, genre tables in LDS, gathers a task ahead)
-    against round 1's k_mlp_chain (SPRK_MLP_ROWS=0) and the fp64 oracle; missing genre / history ids, ragged sizes,
-    a batch large enough that every wave loops over several tasks, unaligned views."""
-    V, U = (1001, 30001) if kind == "embedding_mlp_ref" else (20000, 30000)
-    D = 10 if kind == "embedding_mlp_ref" else 32
-    feats = SY.synth_embedding_mlp(B, V, U, seed=93, rated_vocab=V if kind.startswith("wide") else None)
-
-    def make():
-        if kind.startswith("embedding_mlp"):
-            return M.EmbeddingMLP(seed=51, emb_dim=D, movie_buckets=V, user_buckets=U)
-        return M.WideNDeep(seed=52, emb_dim=D, movie_buckets=V, user_buckets=U,
-                           **(dict(cross_buckets=10000, cross_dim=0) if kind == "wide_indicator" else dict(cross_buckets=200000, cross_dim=32)))
-    model = make()
-    assert model.engine.describe()["kernel"].startswith("k_mlp_rows<8,8,NBIG=2,NSMALL=8>")
-    p = model.predict(feats)[:, 0]
-    monkeypatch.setenv("SPRK_MLP_ROWS", "0")
-    old = make()
-    assert old.engine.describe()["kernel"].startswith("k_mlp_chain")
-    q = old.predict(feats)[:, 0]
-    monkeypatch.delenv("SPRK_MLP_ROWS")
-    n = min(B, 8192)
-    sub = {k: v[:n] for k, v in feats.items()}
-    if kind.startswith("embedding_mlp"):
-        ref = O.embedding_mlp_forward(sub, model.weights, dtype=np.float64, movie_buckets=V, user_buckets=U)[:, 0]
-    else:
-        ref = O.wide_n_deep_forward(sub, model.weights, dtype=np.float64, movie_buckets=V, user_buckets=U,
-                                    cross_buckets=model.cross_buckets, rated_buckets=V)[:, 0]
-    assert np.abs(p[:n] - ref).max() <= TIGHT
-    assert np.abs(p - q).max() <= TIGHT
-    # slices / unaligned row views score the same as inside the batch
-    ids, dense = model.pack(feats)
-    ti, td = _cuda(torch, ids), _cuda(torch, dense)
-    full = model.predict_device(ti, td)
-    for lo, hi in ((1, min(B, 40)), (min(B - 1, 3), min(B, 3 + 1000)), (max(0, B - 517), B)):
-        if hi > lo:
-            assert torch.equal(model.predict_device(ti[lo:hi], td[lo:hi]), full[lo:hi]), (lo, hi)
-    # out-of-range id raises, then the engine works again
-    if B > 10:
-        bad = dict(feats)
-        bad["movieId"] = feats["movieId"].copy()
-        bad["movieId"][7] = V
-        with pytest.raises(ValueError):
-            model.predict(bad)
-        np.testing.assert_array_equal(model.predict(feats)[:, 0], p)
 
 
 @pytest.mark.parametrize("B", [5003, 17, 70001])
