@@ -440,9 +440,10 @@ def main():
     ap.add_argument("--hbm-resident", type=int, default=-1,
                     help="deepfm_v2_c2 at N=1: also measure the same graph with identity tables of this many rows (HBM-resident "
                          "gather, block `roofline_hbm_resident`); default 8388608, 0 = skip")
-    ap.add_argument("--collective", default="torch", choices=["torch", "sprk"],
-                    help="N>1: who issues the all-gather of score slices -- torch.distributed (default) or the C ABI's "
-                         "sprk_comm_allgather_scores (RCCL bound inside libsparrow_hip.so, no torch on the data path)")
+    ap.add_argument("--collective", default="torch", choices=["torch", "sprk", "peer"],
+                    help="N>1: who issues the all-gather of score slices -- torch.distributed (default), the C ABI's "
+                         "sprk_comm_allgather_scores (RCCL bound inside libsparrow_hip.so, no torch on the data path), or "
+                         "sprk_peer_allgather_scores (direct peer writes into IPC-mapped receive buffers, no RCCL)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend (gloo: functional test of the N>1 path with ranks sharing one GPU)")
     ap.add_argument("--dry-run", action="store_true",
@@ -510,8 +511,10 @@ def main():
     ws = torch.empty(max(eng.many_workspace_bytes(B, max(fan, 1) * lb) // 4, 1), dtype=torch.float32, device="cuda")
     gs = None
     if dist_on:
-        from sparrowrecsys_amd.dist import GroupedScoreGather, ScoreComm
+        from sparrowrecsys_amd.dist import GroupedScoreGather, PeerScoreComm, ScoreComm
         comm = ScoreComm() if (args.collective == "sprk" and args.backend == "nccl") else None
+        if args.collective == "peer":
+            comm = PeerScoreComm(B * max(1, args.gather_group))
         gs = GroupedScoreGather(B, max(1, args.gather_group), torch.device("cuda", local_dev), comm=comm)
 
     group_run = [None, None]
@@ -714,6 +717,7 @@ def main():
                                 "sides, host clock, max over ranks; ms_per_step = median region / %d; value = the same region" % (R, K, args.min_region_ms, n_region),
                        "ms_per_step_hip_events": ev_region * 1e3 / n_region,
                        "collective": None if not dist_on else ("sprk_comm_allgather_scores (RCCL behind the C ABI)" if args.collective == "sprk"
+                                                                 else "sprk_peer_allgather_scores (direct peer writes, IPC-mapped receive buffers)" if args.collective == "peer"
                                                                  else "torch.distributed.all_gather_into_tensor (RCCL)"),
                        "parallelism": ("rows sharded over %d GPU(s), tables replicated, all-gather of scores" % world)
                                       + ("" if world == 1 else " (one collective per %d steps, overlapped; %d collectives per region)"

@@ -258,6 +258,9 @@ class GroupedScoreGather:
         self.slot, self.fill, self.groups_done, self.collectives = 0, 0, 0, 0
         self._pending = [None, None]          # (group_index, n_batches) waiting for the sink
         self._views = [None, None]            # cached per-slot output views (group_outs)
+        self._recv = [None, None]             # PeerScoreComm: the receive-buffer view a slot's exchange landed in
+        if isinstance(comm, PeerScoreComm) and comm.slot != self.G * self.B:
+            raise ValueError("PeerScoreComm slot of %d floats != group * batch_rows = %d" % (comm.slot, self.G * self.B))
 
     def out(self):
         """Tensor for the NEXT batch's scores (call once per batch, before its forward is enqueued)."""
@@ -293,7 +296,8 @@ class GroupedScoreGather:
             gi, nb = self._pending[slot]
             if self.cuda and self.done[slot] is not None:
                 self.done[slot].synchronize()
-            self.sink(gi, self.gathered[slot].view(self.world, self.G, self.B)[:, :nb], nb)
+            got = self._recv[slot] if self._recv[slot] is not None else self.gathered[slot]
+            self.sink(gi, got.view(self.world, self.G, self.B)[:, :nb], nb)
         self._pending[slot] = None
 
     def commit(self):
@@ -318,7 +322,9 @@ class GroupedScoreGather:
             ready.record(torch.cuda.current_stream())
             self.comm_stream.wait_event(ready)
             with torch.cuda.stream(self.comm_stream):
-                if self.comm is not None:
+                if isinstance(self.comm, PeerScoreComm):
+                    self._recv[slot] = self.comm.all_gather(src, self.comm_stream.cuda_stream)   # two parities = the ring's two slots
+                elif self.comm is not None:
                     self.comm.all_gather(src, dst, self.comm_stream.cuda_stream)
                 else:
                     dist.all_gather_into_tensor(dst, src, group=self.pg)
