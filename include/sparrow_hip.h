@@ -304,6 +304,18 @@ int sprk_pack_csv(const char* text, size_t len, const sprk_csv_col* id_cols, int
 int sprk_pack_csv_mt(const char* text, size_t len, const sprk_csv_col* id_cols, int32_t n_id,
                      const char* const* dense_names, int32_t n_dense, int32_t max_rows, int32_t n_threads,
                      int32_t* ids_out, float* dense_out, int32_t* rows_out);
+/* The same packing ON THE DEVICE ("GPU-side tokenizer"): `text_dev` is the CSV text in device
+ * memory (16-byte aligned; e.g. the file read straight into a pinned buffer and copied once), `ids_dev` / `dense_dev` are
+ * DEVICE arrays [max_rows, n_id] / [max_rows, n_dense].  Same rules and the same bits as sprk_pack_csv for every field that is
+ * empty or a plain decimal of at most 15 significant digits with a decimal exponent within +-22 (strtod's exact fast path) --
+ * every value the reference's sample files hold (quoted fields are split as the host tokenizer splits them; the files spell
+ * an empty string "").  It never guesses: a numeric field outside that shape ("inf", hex, blanks, 16+ digits, text, an escaped
+ * quote) fails with SPRK_EKIND and names the first such row; ids outside
+ * their bucket range fail with SPRK_ERANGE like the host tokenizer (first bad row in file order).  Synchronises `stream`
+ * (the row count comes back to the host). */
+int sprk_pack_csv_device(const char* text_dev, size_t len, const sprk_csv_col* id_cols, int32_t n_id,
+                         const char* const* dense_names, int32_t n_dense, int32_t max_rows,
+                         int32_t* ids_dev, float* dense_dev, int32_t* rows_out, void* stream);
 
 /* ---- multi-GPU: the path's one collective (the reference has no distributed path) ----
  * Batch rows are sharded over one process per GPU, tables and weights replicated; every rank ends with all scores through ONE

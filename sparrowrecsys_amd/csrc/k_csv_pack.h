@@ -1,0 +1,426 @@
+// k_csv_pack.h -- CSV text -> the packed ids [rows][n_id] int32 / dense [rows][n_dense] float32 arrays ON THE DEVICE
+// ("GPU-side tokenizer"): the device twin of sprk_pack_csv (same rules, same bits), i.e. of
+// the reference's get_dataset = tf.data.experimental.make_csv_dataset(..., na_value="0", ignore_errors=True) (DeepFM.py:14-22)
+// plus the feature columns' id resolution (DeepFM.py:54-76).  Included inside sparrow_hip.hip's anonymous namespace.
+//
+// Byte work, bound by HBM (the text is read, nothing is computed): four passes over line-sized pieces, all integer.
+//   k_csv_count      newlines per 4-KB chunk (16-byte loads)
+//   (scan)           chunk counts -> first line index of every chunk
+//   k_csv_mark       byte offset of every newline -> nl[]           (line i = (nl[i-1], nl[i]), nl[-1] = -1)
+//   k_csv_parse<OPT> the common case in ONE pass: line i is output row i - 1, lines that should have been dropped are counted and,
+//                    if there were any, the exact sequence below runs instead
+//   k_csv_keep       one thread per line: '\r' stripped, empty lines and lines whose field count differs from the header's are
+//                    dropped (ignore_errors=True)                   -> keep[]
+//                    (fields are split exactly as the host tokenizer splits them: a field that STARTS with '"' runs to its
+//                    closing quote, "" inside it is an escaped quote, whatever follows up to the next comma is ignored; the
+//                    reference's Spark-written sample files spell an empty string "")
+//   (scan)           keep[] -> output row of every kept line
+//   k_csv_parse      one thread per kept line (output row < max_rows): fields in order, the ones a column list names are
+//                    converted -- identity ids: empty -> 0, decimal -> (long long) truncation, range check; genre strings ->
+//                    position in the 19-entry vocabulary or -1; numerics: empty -> 0.0, decimal -> float
+// Decimal -> double is the exact fast path of strtod (Clinger): up to 15 significant digits m and |e10| <= 22 give m * 10^e10 or
+// m / 10^-e10 in ONE correctly rounded IEEE operation, which is what strtod returns; the host tokenizer then narrows with
+// (float), and so does this one -- bit-identical for every field of that shape.  A field outside it (more digits, larger
+// exponents, "inf", hex, blanks, text in a numeric column, an escaped quote inside a quoted number) marks its row HARD: the
+// call fails and names the row, it never guesses (the host tokenizer parses such files).  The first bad row in file order decides the error, as on the host.
+
+#define CSV_MAX_COLS 128
+#define CSV_MAX_OUT 64
+#define CSV_CHUNK 4096                        // bytes per workgroup in the newline passes: 256 threads x 16 bytes
+
+struct CsvDev {
+    int n_cols, n_id, n_dense;
+    short id_head[CSV_MAX_COLS], dense_head[CSV_MAX_COLS];   // first output fed by CSV column c (-1: none)
+    short id_next[CSV_MAX_OUT], dense_next[CSV_MAX_OUT];     // next output fed by the same column (-1: end)
+    int id_kind[CSV_MAX_OUT], id_vocab[CSV_MAX_OUT];
+    unsigned char role[CSV_MAX_COLS];                        // bit 0: column c feeds a numeric output, bit 1: a genre output
+    unsigned long long g_lo[19], g_hi[19];                   // the genre vocabulary (DeepFM.py:64-66) as 16 little-endian bytes
+    int g_len[19];
+};
+// error record of a row that cannot be packed: code 1 = identity id outside [0, vocab), 2 = HARD (see above)
+struct CsvErr { unsigned long long key; int code, out_col, is_dense; long long value; };
+
+__device__ __constant__ double kCsvP10[23] = {1e0, 1e1, 1e2, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8, 1e9, 1e10, 1e11,
+                                              1e12, 1e13, 1e14, 1e15, 1e16, 1e17, 1e18, 1e19, 1e20, 1e21, 1e22};
+
+// newlines among the 16 bytes at t + i (bytes at or beyond len do not count)
+__device__ __forceinline__ unsigned csv_nl_mask(const unsigned char* __restrict__ t, size_t i, size_t len) {
+    unsigned m = 0;
+    if (i + 16 <= len) {
+        const uint4 w = *reinterpret_cast<const uint4*>(t + i);
+        const unsigned ww[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const unsigned c = (ww[k] >> (8 * b)) & 0xFF;
+                m |= (c == '\n') ? 1u << (4 * k + b) : 0u;
+            }
+    } else {
+        for (int b = 0; b < 16 && i + b < len; ++b) {
+            const unsigned c = t[i + b];
+            m |= (c == '\n') ? 1u << b : 0u;
+        }
+    }
+    return m;
+}
+
+__global__ __launch_bounds__(256) void k_csv_count(const unsigned char* __restrict__ text, size_t len, unsigned* __restrict__ counts) {
+    const size_t i = (size_t)blockIdx.x * CSV_CHUNK + threadIdx.x * 16;
+    unsigned n = i < len ? __popc(csv_nl_mask(text, i, len)) : 0;
+    for (int d = 32; d >= 1; d >>= 1) n += __shfl_xor(n, d);
+    __shared__ unsigned part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = n;
+    __syncthreads();
+    if (threadIdx.x == 0) counts[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
+}
+
+__global__ __launch_bounds__(256) void k_csv_mark(const unsigned char* __restrict__ text, size_t len, const unsigned* __restrict__ first,
+                                                  unsigned long long* __restrict__ nl) {
+    const size_t i = (size_t)blockIdx.x * CSV_CHUNK + threadIdx.x * 16;
+    const unsigned m = i < len ? csv_nl_mask(text, i, len) : 0;
+    const unsigned n = __popc(m);
+    // exclusive prefix of n over the workgroup's 256 threads
+    unsigned incl = n;
+    for (int d = 1; d < 64; d <<= 1) { const unsigned o = __shfl_up(incl, d); if ((int)(threadIdx.x & 63) >= d) incl += o; }
+    __shared__ unsigned wsum[4];
+    if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    unsigned base = first[blockIdx.x];
+    for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) base += wsum[w];
+    unsigned k = base + incl - n;
+    for (unsigned mm = m; mm; mm &= mm - 1) nl[k++] = i + (unsigned)__builtin_ctz(mm);
+}
+
+// Readers: the text in global memory, or a workgroup's 256 lines staged in LDS.  win(i) = the 8 bytes at offsets i .. i+7
+// (little endian; bytes past the staged piece / the text are unspecified and never looked at).
+struct CsvRdGlobal {
+    const unsigned char* __restrict__ t;
+    size_t len;
+    __device__ __forceinline__ unsigned operator[](size_t i) const { return t[i]; }
+    __device__ __forceinline__ unsigned long long win(size_t i) const {
+        unsigned long long w = 0;
+        for (int k = 0; k < 8 && i + k < len; ++k) w |= (unsigned long long)t[i + k] << (8 * k);
+        return w;
+    }
+};
+struct CsvRdLds {
+    const unsigned char* lds;
+    size_t base;
+    __device__ __forceinline__ unsigned operator[](size_t i) const { return lds[(unsigned)(i - base)]; }
+    __device__ __forceinline__ unsigned long long win(size_t i) const {
+        const unsigned o = (unsigned)(i - base), sh = 8 * (o & 7);
+        const unsigned long long* q = reinterpret_cast<const unsigned long long*>(lds + (o & ~7u));
+        const unsigned long long lo = q[0], hi = q[1];             // two aligned 8-byte LDS reads
+        return sh ? (lo >> sh) | (hi << (64 - sh)) : lo;
+    }
+};
+#define CSV_LDS_SLACK 32
+
+// first byte == c among the 8 bytes of w: its index, or 8 (exact for the lowest match: the classic zero-byte test)
+__device__ __forceinline__ unsigned csv_find8(unsigned long long w, unsigned c) {
+    const unsigned long long x = w ^ (0x0101010101010101ull * c);
+    const unsigned long long z = (x - 0x0101010101010101ull) & ~x & 0x8080808080808080ull;
+    return z ? (unsigned)__builtin_ctzll(z) >> 3 : 8u;
+}
+// position of the next ',' in [p, hi), or hi -- eight bytes per step
+template <class R>
+__device__ __forceinline__ size_t csv_next_comma(const R& t, size_t p, size_t hi) {
+    while (p < hi) {
+        const unsigned k = csv_find8(t.win(p), ',');
+        if (k < 8) return p + k < hi ? p + k : hi;
+        p += 8;
+    }
+    return hi;
+}
+
+// The next field of the line [.., hi) starting at p, split as the host tokenizer's split_csv_line does: content = [a, b),
+// esc = the quoted content holds an escaped quote; p is left on the comma that ends the field (or at hi).  A field that STARTS
+// with '"' runs to its closing quote ("" inside is an escaped quote), whatever follows up to the next comma is ignored.
+template <class R>
+__device__ __forceinline__ void csv_field(const R& t, size_t hi, size_t& p, size_t& a, size_t& b, bool& esc) {
+    esc = false;
+    if (p < hi && t[p] == '"') {
+        ++p;
+        a = p;
+        b = hi;                                                   // an unclosed quote runs to the end of the line
+        while (p < hi) {
+            if (t[p] == '"') {
+                if (p + 1 < hi && t[p + 1] == '"') { esc = true; p += 2; continue; }
+                b = p;
+                ++p;
+                break;
+            }
+            ++p;
+        }
+        p = csv_next_comma(t, p, hi);
+    } else {
+        a = p;
+        p = csv_next_comma(t, p, hi);
+        b = p;
+    }
+}
+
+// Runs body(reader, i, lo, hi) for the workgroup's 256 lines [256 blockIdx.x, ..) ([lo, hi) = line i without its newline and
+// a '\r' before it): their bytes are one contiguous piece of the text, brought into LDS with 16-byte loads when it fits
+// lds_cap bytes (one thread per line then walks its line out of LDS instead of issuing 64-address global loads), read in place
+// otherwise.
+template <class Body>
+__device__ __forceinline__ void csv_stage_lines(const unsigned char* __restrict__ text, size_t len, const unsigned long long* __restrict__ nl,
+                                                unsigned n_nl, unsigned n_lines, unsigned lds_cap, Body body) {
+    unsigned char* lds = reinterpret_cast<unsigned char*>(smem);
+    const unsigned i0 = blockIdx.x * 256;
+    const unsigned i1 = i0 + 256 < n_lines ? i0 + 256 : n_lines;
+    const size_t g0 = i0 == 0 ? 0 : (size_t)nl[i0 - 1] + 1;
+    const size_t g1 = i1 - 1 < n_nl ? (size_t)nl[i1 - 1] : len;
+    const size_t base = g0 & ~(size_t)15;
+    const size_t bytes = g1 - base;
+    const unsigned i = i0 + threadIdx.x;
+    size_t lo = 0, hi = 0;
+    if (i < n_lines) {
+        lo = i == 0 ? 0 : (size_t)nl[i - 1] + 1;
+        hi = i < n_nl ? (size_t)nl[i] : len;
+    }
+    if (bytes <= lds_cap) {                                       // workgroup-uniform
+        for (size_t o = (size_t)threadIdx.x * 16; o < bytes; o += 256 * 16) {
+            if (base + o + 16 <= len) {
+                *reinterpret_cast<uint4*>(lds + o) = *reinterpret_cast<const uint4*>(text + base + o);
+            } else {
+                for (int k = 0; k < 16 && base + o + k < len; ++k) lds[o + k] = text[base + o + k];
+            }
+        }
+        __syncthreads();
+        if (i >= n_lines) return;
+        const CsvRdLds rd{lds, base};
+        if (hi > lo && rd[hi - 1] == '\r') --hi;
+        body(rd, i, lo, hi);
+    } else {
+        if (i >= n_lines) return;
+        const CsvRdGlobal rd{text, len};
+        if (hi > lo && rd[hi - 1] == '\r') --hi;
+        body(rd, i, lo, hi);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_csv_keep(const unsigned char* __restrict__ text, size_t len, const unsigned long long* __restrict__ nl,
+                                                  unsigned n_nl, unsigned n_lines, int n_cols, unsigned lds_cap, unsigned* __restrict__ keep) {
+    csv_stage_lines(text, len, nl, n_nl, n_lines, lds_cap, [&](auto rd, unsigned i, size_t lo, size_t hi) {
+        unsigned k = 0;
+        if (i > 0 && hi > lo) {                                   // line 0 is the header; empty lines are skipped
+            int fields = 0;
+            size_t p = lo, a, b;
+            bool esc;
+            for (;;) {
+                csv_field(rd, hi, p, a, b, esc);
+                ++fields;
+                if (p >= hi) break;
+                ++p;                                              // the comma
+                if (p == hi) { ++fields; break; }                 // a trailing comma: one more, empty, field
+            }
+            k = fields == n_cols;
+        }
+        keep[i] = k;
+    });
+}
+
+// decimal field [a, b) -> double; returns 0 = value, 1 = empty, 2 = HARD
+template <class R>
+__device__ __forceinline__ int csv_number(const R& t, size_t a, size_t b, double& out) {
+    out = 0.0;
+    if (a == b) return 1;
+    unsigned long long w = t.win(a);                              // the field's bytes, eight at a time
+    unsigned left = 8;
+    size_t i = a;
+    auto next = [&]() -> unsigned {
+        if (left == 0) { w = t.win(i); left = 8; }
+        const unsigned c = (unsigned)w & 0xFF;
+        w >>= 8; --left; ++i;
+        return c;
+    };
+    unsigned c = next();
+    bool neg = false;
+    if (c == '-' || c == '+') {
+        neg = c == '-';
+        if (i >= b) return 2;
+        c = next();
+    }
+    unsigned long long m = 0;
+    int nd = 0, e10 = 0;
+    bool digit = false, dot = false, hard = false;
+    for (;;) {
+        if (c >= '0' && c <= '9') {
+            digit = true;
+            if (m == 0 && c == '0') { if (dot) --e10; }               // leading zeros
+            else if (nd < 15) { m = m * 10 + (c - '0'); ++nd; if (dot) --e10; }
+            else { hard |= c != '0'; if (!dot) ++e10; }               // a 16th significant digit: exact only if it is a zero
+        } else if (c == '.') {
+            if (dot) return 2;
+            dot = true;
+        } else if (c == 'e' || c == 'E') {
+            if (!digit || i >= b) return 2;
+            c = next();
+            bool eneg = false;
+            if (c == '-' || c == '+') {
+                eneg = c == '-';
+                if (i >= b) return 2;
+                c = next();
+            }
+            int ex = 0;
+            for (;;) {
+                if (c < '0' || c > '9') return 2;
+                if (ex < 10000) ex = ex * 10 + (int)(c - '0');
+                if (i >= b) break;
+                c = next();
+            }
+            e10 += eneg ? -ex : ex;
+            break;
+        } else {
+            return 2;                                                 // blanks, "inf", "nan", hex, text: the host tokenizer decides
+        }
+        if (i >= b) break;
+        c = next();
+    }
+    if (!digit || hard) return 2;
+    double v;
+    if (m == 0) v = 0.0;
+    else if (e10 == 0) v = (double)m;
+    else if (e10 < 0 && e10 >= -22) v = (double)m / kCsvP10[-e10];
+    else if (e10 > 0 && e10 <= 22) v = (double)m * kCsvP10[e10];
+    else return 2;
+    out = neg ? -v : v;
+    return 0;
+}
+
+// OPT: the optimistic single pass -- every line i >= 1 is taken as output row i - 1; lines that would have been dropped (empty,
+// wrong field count) are counted in *drops and the host then reruns the exact keep -> scan -> parse sequence.  Sample files
+// have no such lines, so the common case reads the text one time less.
+template <bool OPT>
+__global__ __launch_bounds__(256) void k_csv_parse(const CsvDev L, const unsigned char* __restrict__ text, size_t len,
+                                                   const unsigned long long* __restrict__ nl, unsigned n_nl, unsigned n_lines,
+                                                   const unsigned* __restrict__ keep, const unsigned* __restrict__ pos, unsigned max_rows,
+                                                   unsigned lds_cap, int* __restrict__ ids, float* __restrict__ dense,
+                                                   unsigned long long* __restrict__ first_err, CsvErr* __restrict__ errs,
+                                                   unsigned* __restrict__ n_errs, unsigned* __restrict__ drops) {
+    csv_stage_lines(text, len, nl, n_nl, n_lines, lds_cap, [&](auto rd, unsigned i, size_t lo, size_t hi) {
+        unsigned row;
+        if constexpr (OPT) {
+            if (i == 0) return;
+            if (hi == lo) { atomicAdd(drops, 1u); return; }
+            row = i - 1;
+        } else {
+            if (!keep[i]) return;
+            row = pos[i];
+        }
+        if (row >= max_rows) return;
+        int c = 0;
+        auto report = [&](int code, int out_col, int is_dense, long long value) {
+            const unsigned long long key = ((unsigned long long)row << 20) | ((unsigned long long)(unsigned)c << 4) | (unsigned)code;
+            atomicMin(first_err, key);
+            const unsigned s = atomicAdd(n_errs, 1u);
+            if (s < 64) { errs[s].key = key; errs[s].code = code; errs[s].out_col = out_col; errs[s].is_dense = is_dense; errs[s].value = value; }
+        };
+        size_t p = lo;
+        for (bool more = true; more;) {
+            size_t a, b;
+            bool esc;
+            if (p == hi && c > 0) { a = b = hi; esc = false; more = false; }  // the empty field after a trailing comma
+            else {
+                csv_field(rd, hi, p, a, b, esc);
+                if (p >= hi) more = false;
+                else { ++p; more = true; }                                   // the comma; p == hi now means a trailing comma
+            }
+            // field c = [a, b)
+            const int role = c < L.n_cols ? L.role[c] : 0;
+            if (role) {
+                double v = 0.0;
+                int st = 1;
+                if (role & 1) st = esc ? 2 : csv_number(rd, a, b, v);
+                unsigned long long w0 = 0, w1 = 0;
+                const unsigned gn = (unsigned)(b - a);
+                if ((role & 2) && gn >= 1 && gn <= 16) {                   // the field's bytes as two little-endian words
+                    w0 = rd.win(a);
+                    if (gn < 8) w0 &= ~0ull >> (64 - 8 * gn);
+                    if (gn > 8) { w1 = rd.win(a + 8); if (gn < 16) w1 &= ~0ull >> (64 - 8 * (gn - 8)); }
+                }
+                for (int o = L.id_head[c]; o >= 0; o = L.id_next[o]) {
+                    int out;
+                    if (L.id_kind[o] == 1) {                          // genre vocabulary (exact match) or -1
+                        out = -1;
+                        if (gn >= 1 && gn <= 16)
+                            for (int g = 0; g < 19; ++g)
+                                if (L.g_len[g] == (int)gn && L.g_lo[g] == w0 && L.g_hi[g] == w1) out = g;
+                        if (out >= L.id_vocab[o]) out = -1;
+                    } else if (st == 2) {
+                        report(2, o, 0, 0);
+                        out = 0;
+                    } else {
+                        const long long iv = (long long)v;            // int(float(v)) of the Python packer; empty -> 0
+                        if (iv < 0 || iv >= L.id_vocab[o]) report(1, o, 0, iv);
+                        out = (int)iv;
+                    }
+                    ids[(size_t)row * L.n_id + o] = out;
+                }
+                for (int o = L.dense_head[c]; o >= 0; o = L.dense_next[o]) {
+                    if (st == 2) report(2, o, 1, 0);
+                    dense[(size_t)row * L.n_dense + o] = (float)v;
+                }
+            }
+            ++c;
+        }
+        if constexpr (OPT) {
+            if (c != L.n_cols) atomicAdd(drops, 1u);
+        }
+    });
+}
+
+// ---- exclusive scan of unsigned counters (three small kernels; totals of a few million elements) ----
+#define SCAN_TILE 2048                        // elements per workgroup: 256 threads x 8
+__global__ __launch_bounds__(256) void k_scan_tiles(const unsigned* __restrict__ in, size_t n, unsigned* __restrict__ sums) {
+    const size_t base = (size_t)blockIdx.x * SCAN_TILE + threadIdx.x * 8;
+    unsigned s = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s += base + k < n ? in[base + k] : 0u;
+    for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d);
+    __shared__ unsigned part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) sums[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
+}
+// one workgroup: sums[0 .. nb) -> exclusive prefix in place, grand total -> *total
+__global__ __launch_bounds__(256) void k_scan_sums(unsigned* __restrict__ sums, size_t nb, unsigned* __restrict__ total) {
+    __shared__ unsigned wsum[4];
+    __shared__ unsigned carry_s;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (size_t b0 = 0; b0 < nb; b0 += 256) {
+        const size_t i = b0 + threadIdx.x;
+        const unsigned v = i < nb ? sums[i] : 0u;
+        unsigned incl = v;
+        for (int d = 1; d < 64; d <<= 1) { const unsigned o = __shfl_up(incl, d); if ((int)(threadIdx.x & 63) >= d) incl += o; }
+        if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = incl;
+        __syncthreads();
+        unsigned base = carry_s;
+        for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) base += wsum[w];
+        if (i < nb) sums[i] = base + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 255) carry_s = base + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total = carry_s;
+}
+__global__ __launch_bounds__(256) void k_scan_apply(const unsigned* __restrict__ in, size_t n, const unsigned* __restrict__ sums,
+                                                    unsigned* __restrict__ out) {
+    const size_t base = (size_t)blockIdx.x * SCAN_TILE + threadIdx.x * 8;
+    unsigned v[8], s = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { v[k] = base + k < n ? in[base + k] : 0u; s += v[k]; }
+    unsigned incl = s;
+    for (int d = 1; d < 64; d <<= 1) { const unsigned o = __shfl_up(incl, d); if ((int)(threadIdx.x & 63) >= d) incl += o; }
+    __shared__ unsigned wsum[4];
+    if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    unsigned run = sums[blockIdx.x] + incl - s;
+    for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) run += wsum[w];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { if (base + k < n) out[base + k] = run; run += v[k]; }
+}

@@ -618,6 +618,7 @@ __global__ __launch_bounds__(256) void k_zero_columns(float* __restrict__ Wt, in
 #include "k_emb_rank.h"
 #include "k_dien_seq.h"
 #include "k_peer_gather.h"
+#include "k_csv_pack.h"
 
 // ---------------------------------------------------------------------------------------------
 // stand-alone operators
@@ -3186,6 +3187,195 @@ int sprk_cross_hash(const int32_t* a, const int32_t* b, int32_t B, int64_t num_b
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(k_cross_hash, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, b, B, (unsigned long long)num_buckets, (long long*)out);
     HIP_TRY(hipGetLastError());
+    return SPRK_OK;
+}
+
+}  // extern "C"
+
+// ---- device ingest: the CSV text is already in HBM (k_csv_pack.h) ----
+namespace {
+struct DevScratch {
+    void* p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes) {
+        if (bytes <= cap) return SPRK_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr; cap = 0;
+        const size_t want = bytes + bytes / 4 + 4096;
+        if (hipMalloc(&p, want) != hipSuccess) { (void)hipGetLastError(); p = nullptr; return fail(SPRK_EHIP, "device scratch of %zu bytes for the CSV tokenizer", want); }
+        cap = want;
+        return SPRK_OK;
+    }
+};
+thread_local DevScratch g_csv_scratch;
+
+// exclusive scan of n unsigned counters (in -> out, in place allowed), grand total -> *total_dev; sums = scratch of ceil(n / SCAN_TILE)
+void scan_u32(const unsigned* in, unsigned* out, size_t n, unsigned* sums, unsigned* total_dev, hipStream_t st) {
+    const size_t nb = (n + SCAN_TILE - 1) / SCAN_TILE;
+    hipLaunchKernelGGL(k_scan_tiles, dim3((unsigned)nb), dim3(256), 0, st, in, n, sums);
+    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(256), 0, st, sums, nb, total_dev);
+    hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nb), dim3(256), 0, st, in, n, (const unsigned*)sums, out);
+}
+}  // namespace
+
+extern "C" {
+
+int sprk_pack_csv_device(const char* text_dev, size_t len, const sprk_csv_col* id_cols, int32_t n_id, const char* const* dense_names,
+                         int32_t n_dense, int32_t max_rows, int32_t* ids_dev, float* dense_dev, int32_t* rows_out, void* stream) {
+    if (!text_dev || !rows_out || n_id < 0 || n_dense < 0 || max_rows < 0) return fail(SPRK_EINVAL, "bad pack_csv_device arguments");
+    if ((n_id > 0 && (!id_cols || !ids_dev)) || (n_dense > 0 && (!dense_names || !dense_dev))) return fail(SPRK_EINVAL, "NULL column list / output");
+    if (n_id > CSV_MAX_OUT || n_dense > CSV_MAX_OUT) return fail(SPRK_EINVAL, "the device tokenizer packs at most %d id and %d dense columns", CSV_MAX_OUT, CSV_MAX_OUT);
+    if ((uintptr_t)text_dev & 15) return fail(SPRK_EINVAL, "the CSV text must start on a 16-byte boundary in device memory");
+    if (len >= ((size_t)1 << 44)) return fail(SPRK_EINVAL, "CSV text too large");
+    *rows_out = 0;
+    if (len == 0) return SPRK_OK;
+    hipStream_t st = (hipStream_t)stream;
+    // header: the first line comes back to the host and goes through the host tokenizer's own field splitter
+    std::vector<char> head(len < 16384 ? len : 16384);
+    HIP_TRY(hipMemcpyAsync(head.data(), text_dev, head.size(), hipMemcpyDeviceToHost, st));
+    char last = 0;
+    HIP_TRY(hipMemcpyAsync(&last, text_dev + len - 1, 1, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    const void* q = memchr(head.data(), '\n', head.size());
+    if (!q && head.size() < len) return fail(SPRK_EINVAL, "CSV header line longer than %zu bytes", head.size());
+    const char* le = q ? (const char*)q : head.data() + head.size();
+    const char* he = (le > head.data() && le[-1] == '\r') ? le - 1 : le;
+    std::vector<CsvField> fields;
+    std::string scratch;
+    split_csv_line(head.data(), he, fields, scratch);
+    if (fields.size() > CSV_MAX_COLS) return fail(SPRK_EINVAL, "the device tokenizer reads at most %d CSV columns (header has %zu)", CSV_MAX_COLS, fields.size());
+    CsvDev L;
+    memset(&L, 0, sizeof(L));
+    L.n_cols = (int)fields.size(); L.n_id = n_id; L.n_dense = n_dense;
+    for (int c = 0; c < CSV_MAX_COLS; ++c) { L.id_head[c] = -1; L.dense_head[c] = -1; }
+    auto find = [&](const char* name) {
+        const size_t n = strlen(name);
+        for (size_t c = 0; c < fields.size(); ++c) if (fields[c].n == n && memcmp(fields[c].p, name, n) == 0) return (int)c;
+        return -1;
+    };
+    for (int j = n_id - 1; j >= 0; --j) {                          // (back to front: every column's list ends up in output order)
+        const int c = find(id_cols[j].name);
+        if (c < 0) return fail(SPRK_EINVAL, "CSV has no column %s", id_cols[j].name);
+        L.id_next[j] = L.id_head[c]; L.id_head[c] = (short)j;
+        L.id_kind[j] = id_cols[j].kind; L.id_vocab[j] = id_cols[j].vocab;
+    }
+    for (int j = n_dense - 1; j >= 0; --j) {
+        const int c = find(dense_names[j]);
+        if (c < 0) return fail(SPRK_EINVAL, "CSV has no column %s", dense_names[j]);
+        L.dense_next[j] = L.dense_head[c]; L.dense_head[c] = (short)j;
+    }
+    for (int c = 0; c < L.n_cols; ++c) {
+        for (int j = L.id_head[c]; j >= 0; j = L.id_next[j]) L.role[c] |= L.id_kind[j] == 1 ? 2 : 1;
+        if (L.dense_head[c] >= 0) L.role[c] |= 1;
+    }
+    for (int g = 0; g < 19; ++g) {
+        const size_t n = strlen(kGenreVocab[g]);
+        L.g_len[g] = (int)n;
+        for (size_t k = 0; k < n && k < 16; ++k) (k < 8 ? L.g_lo[g] : L.g_hi[g]) |= (unsigned long long)(unsigned char)kGenreVocab[g][k] << (8 * (k & 7));
+    }
+    // pass 1: newlines per chunk
+    const size_t n_chunks = (len + CSV_CHUNK - 1) / CSV_CHUNK;
+    const size_t sums_a = (n_chunks + SCAN_TILE - 1) / SCAN_TILE;
+    const size_t fixed = 256 + sizeof(CsvErr) * 64;                 // flags | totals | first_err | n_errs, then the error records
+    size_t need = fixed + (n_chunks + sums_a + 64) * sizeof(unsigned);
+    if (int rc = g_csv_scratch.ensure(need)) return rc;
+    auto carve = [&]() { return (char*)g_csv_scratch.p; };
+    unsigned* totals = (unsigned*)(carve() + 16);                   // [0] newlines, [1] kept lines
+    unsigned long long* first_err = (unsigned long long*)(carve() + 32);
+    unsigned* n_errs = (unsigned*)(carve() + 48);
+    CsvErr* errs = (CsvErr*)(carve() + 256);
+    unsigned* counts = (unsigned*)(carve() + fixed);
+    unsigned* sums = counts + n_chunks;
+    HIP_TRY(hipMemsetAsync(carve(), 0, 256, st));
+    HIP_TRY(hipMemsetAsync(first_err, 0xFF, sizeof(unsigned long long), st));
+    const unsigned char* text = (const unsigned char*)text_dev;
+    hipLaunchKernelGGL(k_csv_count, dim3((unsigned)n_chunks), dim3(256), 0, st, text, len, counts);
+    scan_u32(counts, counts, n_chunks, sums, totals, st);
+    unsigned h_nl = 0;
+    HIP_TRY(hipMemcpyAsync(&h_nl, totals, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    const size_t n_lines = (size_t)h_nl + (last != '\n' ? 1 : 0);
+    if (n_lines >= ((size_t)1 << 31)) return fail(SPRK_EINVAL, "more than 2^31 lines");
+    if (n_lines <= 1) return SPRK_OK;                              // header only
+    // passes 2-4 need nl[] and keep[] / pos[]: grow the scratch (contents so far are carried over by redoing pass 1's scan)
+    const size_t sums_b = (n_lines + SCAN_TILE - 1) / SCAN_TILE;
+    const size_t off_nl = (fixed + (n_chunks + sums_a + 64) * sizeof(unsigned) + 255) & ~(size_t)255;
+    const size_t off_keep = off_nl + ((size_t)h_nl + 1) * sizeof(unsigned long long);
+    need = off_keep + (2 * n_lines + sums_b + 64) * sizeof(unsigned);
+    if (need > g_csv_scratch.cap) {
+        // (first call on a text of this size: allocate the full scratch and run pass 1 again into it)
+        if (int rc = g_csv_scratch.ensure(need)) return rc;
+        totals = (unsigned*)(carve() + 16); first_err = (unsigned long long*)(carve() + 32);
+        n_errs = (unsigned*)(carve() + 48); errs = (CsvErr*)(carve() + 256); counts = (unsigned*)(carve() + fixed); sums = counts + n_chunks;
+        HIP_TRY(hipMemsetAsync(carve(), 0, 256, st));
+        HIP_TRY(hipMemsetAsync(first_err, 0xFF, sizeof(unsigned long long), st));
+        hipLaunchKernelGGL(k_csv_count, dim3((unsigned)n_chunks), dim3(256), 0, st, text, len, counts);
+        scan_u32(counts, counts, n_chunks, sums, totals, st);
+    }
+    unsigned long long* nl = (unsigned long long*)(carve() + off_nl);
+    unsigned* keep = (unsigned*)(carve() + off_keep);
+    unsigned* pos = keep + n_lines;
+    unsigned* sums2 = pos + n_lines;
+    unsigned* drops = (unsigned*)(carve() + 52);
+    hipLaunchKernelGGL(k_csv_mark, dim3((unsigned)n_chunks), dim3(256), 0, st, text, len, (const unsigned*)counts, nl);
+    const unsigned lb = (unsigned)((n_lines + 255) / 256);
+    // LDS piece per workgroup of 256 lines: twice the average, so that more workgroups share a CU when lines are short
+    size_t cap = (2 * 256 * (len / n_lines + 1) + 4095) & ~(size_t)4095;
+    if (cap < 8192) cap = 8192;
+    if (cap > 48 * 1024) cap = 48 * 1024;
+    const unsigned lds_cap = (unsigned)cap;
+    unsigned h_kept = 0, h_nerr = 0, h_drops = 0;
+    unsigned long long h_first = 0;
+    const char* two = getenv("SPRK_CSV_TWO_PASS");              // A/B switch: "1" = always the exact keep -> scan -> parse sequence
+    bool exact = two && two[0] == '1';
+    if (!exact) {
+        // optimistic pass over the lines that can hold the first max_rows rows if none is dropped
+        const size_t lines_opt = n_lines - 1 <= (size_t)max_rows ? n_lines : (size_t)max_rows + 1;
+        const unsigned lbo = (unsigned)((lines_opt + 255) / 256);
+        if (lines_opt > 1)
+            hipLaunchKernelGGL(k_csv_parse<true>, dim3(lbo), dim3(256), lds_cap + CSV_LDS_SLACK, st, L, text, len, (const unsigned long long*)nl, h_nl,
+                               (unsigned)lines_opt, (const unsigned*)nullptr, (const unsigned*)nullptr, (unsigned)max_rows, lds_cap, ids_dev, dense_dev,
+                               first_err, errs, n_errs, drops);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(&h_drops, drops, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(&h_first, first_err, sizeof(h_first), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(&h_nerr, n_errs, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        h_kept = (unsigned)(lines_opt - 1);
+        if (h_drops) {                                             // some line is not a row: its successors are misplaced
+            exact = true;
+            HIP_TRY(hipMemsetAsync(first_err, 0xFF, sizeof(unsigned long long), st));
+            HIP_TRY(hipMemsetAsync(n_errs, 0, sizeof(unsigned), st));
+        }
+    }
+    if (exact) {
+        hipLaunchKernelGGL(k_csv_keep, dim3(lb), dim3(256), lds_cap + CSV_LDS_SLACK, st, text, len, (const unsigned long long*)nl, h_nl, (unsigned)n_lines,
+                           L.n_cols, lds_cap, keep);
+        scan_u32(keep, pos, n_lines, sums2, totals + 1, st);
+        hipLaunchKernelGGL(k_csv_parse<false>, dim3(lb), dim3(256), lds_cap + CSV_LDS_SLACK, st, L, text, len, (const unsigned long long*)nl, h_nl,
+                           (unsigned)n_lines, (const unsigned*)keep, (const unsigned*)pos, (unsigned)max_rows, lds_cap, ids_dev, dense_dev, first_err, errs,
+                           n_errs, drops);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(&h_kept, totals + 1, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(&h_first, first_err, sizeof(h_first), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(&h_nerr, n_errs, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+    }
+    if (h_first != ~0ull) {
+        std::vector<CsvErr> rec(h_nerr < 64 ? h_nerr : 64);
+        if (!rec.empty()) HIP_TRY(hipMemcpy(rec.data(), errs, rec.size() * sizeof(CsvErr), hipMemcpyDeviceToHost));
+        const unsigned row = (unsigned)(h_first >> 20);
+        const int code = (int)(h_first & 15);
+        const CsvErr* hit = nullptr;
+        for (const CsvErr& e : rec) if (e.key == h_first) { hit = &e; break; }
+        const char* name = !hit ? "a column" : (hit->is_dense ? dense_names[hit->out_col] : id_cols[hit->out_col].name);
+        if (code == 1) {
+            if (hit) return fail(SPRK_ERANGE, "row %u: %s id %lld outside [0, %d) (reference: assert_less_than_num_buckets)", row, name, hit->value, id_cols[hit->out_col].vocab);
+            return fail(SPRK_ERANGE, "row %u: an identity id is outside its bucket range (reference: assert_less_than_num_buckets)", row);
+        }
+        return fail(SPRK_EKIND, "row %u: %s holds a value the device tokenizer does not convert exactly (not a plain decimal of at most 15 digits): use sprk_pack_csv", row, name);
+    }
+    *rows_out = (int32_t)(h_kept < (unsigned)max_rows ? h_kept : (unsigned)max_rows);
     return SPRK_OK;
 }
 

@@ -1,5 +1,6 @@
-"""Host ingest: CSV text -> the packed ``ids [B,F] int32`` / ``dense [B,N] float32`` arrays in ONE native pass
-(``sprk_pack_csv`` in libsparrow_hip.so, plain C++: no GPU involved).
+"""Ingest: CSV text -> the packed ``ids [B,F] int32`` / ``dense [B,N] float32`` arrays in ONE native pass, on the host
+(``sprk_pack_csv`` in libsparrow_hip.so, plain C++: no GPU involved) or on the device (``sprk_pack_csv_device``: HIP kernels
+over the raw text in HBM, same bits).
 
 The reference reads its sample files with ``tf.data.experimental.make_csv_dataset(..., na_value="0",
 ignore_errors=True)`` (DeepFM.py:14-22) and resolves the feature columns inside the graph (DeepFM.py:54-76);
@@ -46,3 +47,42 @@ def pack_csv_file(path: str, id_columns: Sequence[IdColumn], numeric_keys: Seque
                   max_rows: int = None, threads: int = 1) -> Tuple[np.ndarray, np.ndarray]:
     with open(path, "rb") as f:
         return pack_csv(f.read(), id_columns, numeric_keys, max_rows, threads)
+
+
+def pack_csv_device(text, id_columns: Sequence[IdColumn], numeric_keys: Sequence[str] = NUMERIC_KEYS, max_rows: int = None,
+                    stream=None):
+    """The same packing on the GPU (``sprk_pack_csv_device``: k_csv_pack.h): ``text`` is the CSV content as bytes / str (copied
+    to the device once, as raw text) or a ``torch.uint8`` device tensor already holding it; returns DEVICE tensors
+    ``(ids [rows, F] int32, dense [rows, N] float32)`` ready for ``Engine.forward``.  Bit-identical to :func:`pack_csv` for the
+    values CSV sample files hold (plain decimals of at most 15 digits); quoted fields or other number spellings raise
+    (``SparrowHipError``) and name the row -- use :func:`pack_csv` for such files.  There is no silent host fallback."""
+    import torch
+    if not torch.cuda.is_available():
+        raise RuntimeError("pack_csv_device needs a HIP device (use pack_csv for the host tokenizer)")
+    if isinstance(text, str):
+        text = text.encode("utf-8")
+    if isinstance(text, (bytes, bytearray, memoryview)):
+        n = len(text)
+        host = torch.frombuffer(bytearray(text), dtype=torch.uint8) if n else torch.empty(0, dtype=torch.uint8)
+        buf = torch.empty(n + 16, dtype=torch.uint8, device="cuda")           # torch allocations are 256-byte aligned
+        buf[:n].copy_(host, non_blocking=False)
+    else:
+        if text.dtype != torch.uint8 or not text.is_cuda or not text.is_contiguous() or text.data_ptr() % 16:
+            raise ValueError("pack_csv_device: a contiguous, 16-byte aligned torch.uint8 device tensor is required")
+        buf, n = text, text.numel()
+    lib = L.load_library()
+    if max_rows is None:
+        max_rows = int((buf[:n] == 10).sum().item()) + 1 if n else 0
+    n_id, n_dense = len(id_columns), len(numeric_keys)
+    cols = (L.CsvCol * max(n_id, 1))()
+    for j, c in enumerate(id_columns):
+        cols[j].name, cols[j].kind, cols[j].vocab = c.key.encode(), 1 if c.kind == "genre" else 0, c.vocab
+    names = (C.c_char_p * max(n_dense, 1))(*[k.encode() for k in numeric_keys])
+    ids = torch.empty((max(max_rows, 1), n_id), dtype=torch.int32, device=buf.device)
+    dense = torch.empty((max(max_rows, 1), n_dense), dtype=torch.float32, device=buf.device)
+    rows = C.c_int32(0)
+    if stream is None:
+        stream = torch.cuda.current_stream(buf.device).cuda_stream
+    L.check(lib.sprk_pack_csv_device(C.c_void_p(buf.data_ptr()), C.c_size_t(n), cols, n_id, names, n_dense, int(max_rows),
+                                     C.c_void_p(ids.data_ptr()), C.c_void_p(dense.data_ptr()), C.byref(rows), C.c_void_p(stream)))
+    return ids[:rows.value], dense[:rows.value]

@@ -1,0 +1,132 @@
+"""Device CSV tokenizer (``sprk_pack_csv_device``, k_csv_pack.h) against the host tokenizer (``sprk_pack_csv``, itself pinned
+bit for bit on the Python restatement of make_csv_dataset + feature columns over all 22 440 rows of the reference's
+testSamples.csv, tests/test_ingest.py): identical packed arrays, identical first error (``-m gpu``)."""
+import os
+
+import numpy as np
+import pytest
+
+from sparrowrecsys_amd import _lib as L
+from sparrowrecsys_amd import models as M
+from sparrowrecsys_amd import schema as S
+from sparrowrecsys_amd.ingest import pack_csv, pack_csv_device
+
+pytestmark = pytest.mark.gpu
+EXCERPT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "test_samples_512.csv")
+
+HEADER = ["movieId", "userId", "rating", "timestamp", "releaseYear", "movieGenre1", "movieGenre2", "movieGenre3",
+          "movieRatingCount", "movieAvgRating", "movieRatingStddev", "userRatedMovie1", "userRatingCount", "userAvgRating",
+          "userRatingStddev", "userGenre1", "userGenre2", "userGenre3", "userGenre4", "userGenre5"]
+
+
+@pytest.fixture(scope="module")
+def torch():
+    import torch as t
+    assert t.cuda.is_available(), "gpu tests need a HIP device"
+    return t
+
+
+def _same(text, cols, keys=S.NUMERIC_KEYS, **kw):
+    ids, dense = pack_csv(text, cols, keys, **kw)
+    dids, ddense = pack_csv_device(text, cols, keys, **kw)
+    assert dids.is_cuda and ddense.is_cuda and dids.dtype.is_floating_point is False
+    np.testing.assert_array_equal(dids.cpu().numpy(), ids)
+    np.testing.assert_array_equal(ddense.cpu().numpy().view(np.uint32), dense.view(np.uint32))      # bits, not values
+    return ids, dense
+
+
+def test_na_rules_quotes_ragged_rows_line_ends(torch):
+    cols = M.EmbeddingMLP(seed=1).id_columns
+    rows = [
+        ["1", "15555", "3.0", "900953740", "1995", "Adventure", "Animation", "Children", "10759", "3.91", "0.89", "",
+         "32", "3.47", "0.76", "Crime", "Drama", "", "", ""],
+        ["999", "1", "5.0", "1", "", "Sci-Fi", "", "NotAGenre", "", "", "", "25", "", "", "", "Film-Noir", "Musical", "IMAX", "War", "Western"],
+        ["12", "7"],                                                                   # wrong width: dropped
+        ["3", "30000", "1", "2", "2001.0", '"Comedy"', "Romance", '""', "7", "2.5", "1.25", '"1000.0"', "3", "4", "0.5",
+         "Action", "", "", "", "Thriller"],
+        [""] * 20,                                                                     # all empty: ids 0 / -1, numerics 0.0
+        ["7", "8", "1", "2", "1e3", "Drama", "Drama", "Drama", "+5", "-0", "0.000123", "007", "1.50E+2", "12345.678901234", "1E-2",
+         '"Children"junk', "Documentary", "documentary", "Film-Noir", "IMAX"],
+    ]
+    text = ",".join(HEADER) + "\n" + "\n".join(",".join(r) for r in rows) + "\n"
+    ids, dense = _same(text, cols)
+    assert ids.shape[0] == 5
+    _same(text.replace("\n", "\r\n").rstrip("\r\n"), cols)                            # \r\n line ends, no trailing newline
+    _same(text + "\n\n", cols)                                                         # empty lines
+    _same(text, cols, max_rows=2)
+    _same(",".join(HEADER) + "\n", cols)                                               # header only
+    _same(",".join(HEADER), cols)
+    # a column named twice and a column list that skips most of the file
+    two = [S.IdColumn("movieId", "id", 1001), S.IdColumn("userGenre1", "genre", 19), S.IdColumn("movieId", "id", 5000)]
+    _same(text, two, ["releaseYear", "movieAvgRating", "releaseYear"])
+
+
+def test_reference_sample_rows(torch):
+    """512 rows of the reference's own testSamples.csv (Spark wrote its empty strings as ""), three models' column sets."""
+    text = open(EXCERPT, "rb").read()
+    for model in (M.EmbeddingMLP(seed=1), M.DeepFMv2(seed=1), M.DIN(seed=1), M.WideNDeep(seed=1)):
+        ids, dense = _same(text, model.id_columns)
+        assert ids.shape[0] == 512
+
+
+def _synthetic_csv(n_rows, seed):
+    rng = np.random.default_rng(seed)
+    genres = S.GENRE_VOCAB + ["", "(no genres listed)"]
+    cols = []
+    cols.append(rng.integers(1, 1000, n_rows).astype(str))                                  # movieId
+    cols.append(rng.integers(1, 30000, n_rows).astype(str))                                 # userId
+    cols.append(np.char.mod("%.1f", rng.integers(1, 11, n_rows) / 2.0))                     # rating
+    cols.append(rng.integers(800000000, 1500000000, n_rows).astype(str))                    # timestamp
+    cols.append(np.where(rng.random(n_rows) < 0.03, "", rng.integers(1900, 2020, n_rows).astype(str)))   # releaseYear
+    for _ in range(3):
+        cols.append(np.array(genres, dtype=object)[rng.integers(0, len(genres), n_rows)])
+    cols.append(rng.integers(0, 70000, n_rows).astype(str))
+    cols.append(np.char.mod("%.2f", rng.random(n_rows) * 5))
+    cols.append(np.where(rng.random(n_rows) < 0.05, '""', np.char.mod("%.2f", rng.random(n_rows) * 2)))
+    cols.append(np.where(rng.random(n_rows) < 0.1, "", rng.integers(1, 1000, n_rows).astype(str)))       # userRatedMovie1
+    cols.append(rng.integers(0, 3000, n_rows).astype(str))
+    cols.append(np.char.mod("%.6g", rng.random(n_rows) * 5))
+    cols.append(np.char.mod("%.3e", rng.random(n_rows) * 3))
+    for _ in range(5):
+        cols.append(np.array(genres, dtype=object)[rng.integers(0, len(genres), n_rows)])
+    lines = [",".join(HEADER)]
+    lines += [",".join(map(str, r)) for r in zip(*cols)]
+    for k in rng.integers(1, n_rows, 20):                                                  # ragged rows: dropped
+        lines[k] = lines[k] + ",extra"
+    return ("\n".join(lines) + "\n").encode()
+
+
+def test_large_synthetic_file_bit_identical(torch):
+    """200 000 rows (27 MB of text, ~6 600 chunks, every scan tile and workgroup boundary crossed many times)."""
+    cols = M.EmbeddingMLP(seed=1).id_columns
+    text = _synthetic_csv(200000, 5)
+    ids, dense = _same(text, cols)
+    assert ids.shape[0] == 200000 - 20
+    # the device buffer may be handed over directly
+    buf = torch.frombuffer(bytearray(text), dtype=torch.uint8).cuda()
+    dids, ddense = pack_csv_device(buf, cols)
+    np.testing.assert_array_equal(dids.cpu().numpy(), ids)
+    np.testing.assert_array_equal(ddense.cpu().numpy(), dense)
+
+
+def test_errors_name_the_first_bad_row(torch):
+    cols = [S.IdColumn("movieId", "id", 1001), S.IdColumn("userGenre1", "genre", 19)]
+    good = "movieId,userGenre1,releaseYear\n5,Drama,1990\n6,War,1991\n"
+    text = good + "1001,Drama,1990\n7,Drama,1\n2000,Drama,1\n"
+    with pytest.raises(ValueError) as host:
+        pack_csv(text, cols, ["releaseYear"])
+    with pytest.raises(ValueError) as dev:
+        pack_csv_device(text, cols, ["releaseYear"])
+    assert str(dev.value) == str(host.value) and "row 2" in str(dev.value) and "1001" in str(dev.value)
+    ids, _ = _same(text, cols, ["releaseYear"], max_rows=2)                               # rows past max_rows are never looked at
+    assert ids.tolist() == [[5, 10], [6, 5]]
+    with pytest.raises(Exception):
+        pack_csv_device("movieId,releaseYear\n5,1990\n", cols, ["releaseYear"])             # no userGenre1 column
+    # number spellings outside strtod's exact fast path: the device tokenizer refuses and names the row; the host one parses
+    for bad in ("inf", " 5", "12345678901234567", "0x10", "1e400", "abc", '"1""2"'):
+        t = good + "8,Drama,%s\n" % bad
+        with pytest.raises(L.SparrowHipError) as e:
+            pack_csv_device(t, cols, ["releaseYear"])
+        assert e.value.code == L.EKIND and "row 2" in str(e.value) and "releaseYear" in str(e.value), (bad, str(e.value))
+    ok = good + "8,Drama,123456789012345\n9,Drama,1234567890123450000\n"                     # 15 digits; zeros beyond them
+    _same(ok, cols, ["releaseYear"])
