@@ -388,6 +388,28 @@ class CTRModel:
 
     __call__ = predict
 
+    def predict_csv(self, source, batch_size: int = 65536, max_rows: Optional[int] = None) -> np.ndarray:
+        """``model.predict(get_dataset(path))`` of the reference (DeepFM.py:14-22,131-133) without the host in the data path:
+        ``source`` = a CSV file path, its bytes, or a ``torch.uint8`` device tensor holding the text.  The raw text goes to
+        the device once, ``sprk_pack_csv_device`` tokenizes it there into the packed ids / dense arrays, the forward runs over
+        ``batch_size``-row slices of them -> ``ndarray [N, 1] float32``.  Same scores as ``predict(read_samples_csv(path))``."""
+        import torch
+
+        from .ingest import pack_csv_device
+        if isinstance(source, str):
+            with open(source, "rb") as f:
+                source = f.read()
+        ids, dense = pack_csv_device(source, self.id_columns, list(self.numeric_keys), max_rows=max_rows)
+        n = int(ids.shape[0])
+        if n == 0:
+            return np.zeros((0, 1), dtype=np.float32)
+        out = torch.empty(n, dtype=torch.float32, device=ids.device)
+        for lo in range(0, n, batch_size):
+            hi = min(n, lo + batch_size)
+            self.predict_device(ids[lo:hi], dense[lo:hi], out[lo:hi])
+        self.engine.check_ids()
+        return out.cpu().numpy().reshape(-1, 1)
+
 
 # =============================================================================================
 def _sorted_xmap(blocks: Mapping[str, Tuple[int, int]]) -> List[int]:

@@ -130,3 +130,15 @@ def test_errors_name_the_first_bad_row(torch):
         assert e.value.code == L.EKIND and "row 2" in str(e.value) and "releaseYear" in str(e.value), (bad, str(e.value))
     ok = good + "8,Drama,123456789012345\n9,Drama,1234567890123450000\n"                     # 15 digits; zeros beyond them
     _same(ok, cols, ["releaseYear"])
+
+
+def test_predict_csv_equals_predict_on_parsed_features(torch, tmp_path):
+    """File -> device tokenizer -> forward, against the host route (read_samples_csv -> pack -> forward): same scores."""
+    path = tmp_path / "s.csv"
+    path.write_bytes(open(EXCERPT, "rb").read())
+    for model in (M.DeepFMv2(seed=3), M.NeuralCF(seed=4), M.DIN(seed=5), M.WideNDeep(seed=6)):
+        want = model.predict(S.read_samples_csv(str(path)))
+        got = model.predict_csv(str(path), batch_size=200)                  # 200, 200, 112 rows
+        assert got.shape == want.shape == (512, 1)
+        np.testing.assert_array_equal(got, want)
+        np.testing.assert_array_equal(model.predict_csv(open(EXCERPT, "rb").read(), max_rows=17), want[:17])
