@@ -207,10 +207,28 @@ struct DinLds {
 // sigmoid -> pooling), not by VALU issue (cutting 14 % of the VALU instructions changed nothing), MFMA (13 % busy) or memory
 // (2.8 TB/s at the fabric): the lever is more waves per SIMD, and what stood in the way was 220 VGPRs -- the resident W12 / W4
 // fragments now live in LDS (8 ds_read_b128 per sample) and the PReLU coefficient rows are read after the MFMAs, not before.
-template <int KC, int HC, int NP, bool HALF, int WPB = 4>
+// Several batches per launch (sprk_forward_many with sprk_set_many_batches > 1): sample s of the launch is sample s % B of batch
+// s / B, every batch with its own ids / pooled buffers.  (Round 1's version of this was withdrawn over wrong pooled sums in
+// some lanes of one instantiation; the cause -- inline-asm VALU writes feeding an MFMA without the two wait states, invisible
+// to the compiler's hazard recognizer -- is fixed at its source, dyn_split.h / DESIGN.md section 8.)  A wave tracks (batch,
+// row) of its samples with scalar adds, no division per sample.
+#define DIN_ATTN_MB 16
+struct DinAttnMany {
+    const int* ids[DIN_ATTN_MB];
+    float* pooled[DIN_ATTN_MB];
+    int n;                                // batches in this launch (each of B samples)
+};
+
+struct DinAttnOne {};                     // the one-batch instantiation carries no pointer table in its kernel arguments
+template <bool MB> struct DinAttnArg { typedef DinAttnOne type; };
+template <> struct DinAttnArg<true> { typedef DinAttnMany type; };
+
+// (ONE __global__ template for both forms: wrapping the body in a device function that two kernels call changed the inliner's
+// decisions -- arrays indexed in the unrolled gather loops landed in scratch, 24-40 bytes per lane.)
+template <int KC, int HC, int NP, bool HALF, int WPB = 4, bool MB = false>
 __global__ __launch_bounds__(WPB * 64, WPB / 4 == 1 ? 2 : WPB / 4) void k_din_attn(const DinRun A, const int* __restrict__ ids,
                                                      float* __restrict__ pooled, float* __restrict__ att, int B,
-                                                     int* __restrict__ err) {
+                                                     int* __restrict__ err, const typename DinAttnArg<MB>::type Mm) {
     using LD = DinLds<KC, HC, WPB>;
     constexpr int KP = LD::KP, HP = LD::HP, hs = LD::hs, as = LD::as;
     static_assert(NP >= 1 && NP <= 8 && KC <= 2, "the 8-pass row gather covers 64 rows only for rows of <= 8 pieces");
@@ -268,6 +286,22 @@ __global__ __launch_bounds__(WPB * 64, WPB / 4 == 1 ? 2 : WPB / 4) void k_din_at
 
     const int stride = gridDim.x * WPB;
     int s = blockIdx.x * WPB + wave;
+    int Btot = B;                             // samples of this launch
+    if constexpr (MB) Btot = Mm.n * B;
+    // (batch, row inside the batch) of the sample being scored and of the sample whose ids are fetched next: wave-uniform
+    int cbi = 0, csl = s;
+    if constexpr (MB) { cbi = __builtin_amdgcn_readfirstlane(s / B); csl = s - cbi * B; }
+    int pbi = cbi, psl = csl;
+#define DIN_ADVANCE(bi, sl)                                                \
+    do {                                                                  \
+        sl = __builtin_amdgcn_readfirstlane(sl + stride);                 \
+        if constexpr (MB) {                                               \
+            while (sl >= B) {                                             \
+                sl = __builtin_amdgcn_readfirstlane(sl - B);              \
+                bi = __builtin_amdgcn_readfirstlane(bi + 1);              \
+            }                                                             \
+        }                                                                 \
+    } while (0)
     bool bad = false;
     // Software pipeline over this wave's samples: the rows of sample n+1 are in flight (in registers)
     // while sample n is scored from the LDS tile; its ids were fetched one sample earlier still.
@@ -280,8 +314,10 @@ __global__ __launch_bounds__(WPB * 64, WPB / 4 == 1 ? 2 : WPB / 4) void k_din_at
     auto pok = [&](int p) { return lrow < RPP && p * RPP + lrow < T; };
     int hid[NP], cid = 0;                 // ids of the sample whose rows are issued next
     f32x4 v[NP], cvn[KC], vcn[HC];         // rows / candidate row / vc row of the sample scored next
-    auto ld_ids = [&](int b) {
-        const int* row = ids + (size_t)b * F;
+    auto ld_ids = [&](int bi, int sl) {
+        const int* idsb = ids;
+        if constexpr (MB) idsb = Mm.ids[bi];
+        const int* row = idsb + (size_t)sl * F;
 #pragma unroll
         for (int p = 0; p < NP; ++p) hid[p] = row[A.hist_col + prow(p)];
         cid = row[A.cand_col];
@@ -310,12 +346,13 @@ __global__ __launch_bounds__(WPB * 64, WPB / 4 == 1 ? 2 : WPB / 4) void k_din_at
                         : ld4(A.table + (id * (unsigned)Dp + 4u * (unsigned)piece));   // 32-bit element offsets (checked at finalize)
         }
     };
-    if (s < B) {
-        ld_ids(s);
+    if (s < Btot) {
+        ld_ids(pbi, psl);
         issue_rows();
-        if (s + stride < B) ld_ids(s + stride);
+        DIN_ADVANCE(pbi, psl);
+        if (s + stride < Btot) ld_ids(pbi, psl);
     }
-    for (; s < B; s += stride) {
+    for (; s < Btot; s += stride) {
         // ---- hand-off: this sample's rows -> LDS tile, candidate-side operands -> registers ----
 #pragma unroll
         for (int p = 0; p < NP; ++p)
@@ -338,9 +375,10 @@ __global__ __launch_bounds__(WPB * 64, WPB / 4 == 1 ? 2 : WPB / 4) void k_din_at
         }
 #pragma unroll
         for (int nb = 0; nb < HC; ++nb) acc_init[nb] = vcn[nb];
-        if (s + stride < B) {                                    // next sample's rows fly under this sample's MFMAs
+        if (s + stride < Btot) {                                 // next sample's rows fly under this sample's MFMAs
             issue_rows();
-            if (s + 2 * stride < B) ld_ids(s + 2 * stride);
+            DIN_ADVANCE(pbi, psl);
+            if (s + 2 * stride < Btot) ld_ids(pbi, psl);
         }
         // A_b = W12 + W4 diag(c); the weight fragments come from LDS (lane-ordered, conflict free)
         f32x4 w12f[HC][KC], w4f[HC][KC];
@@ -464,7 +502,7 @@ __global__ __launch_bounds__(WPB * 64, WPB / 4 == 1 ? 2 : WPB / 4) void k_din_at
                 }
                 sum += sum1;
                 const float wgt = sigmoidf_fast(rows4_sum(sum) * (HALF ? A.unscale : 1.0f) + A.b2);   // PReLU is positively homogeneous
-                if (q == 0 && att && t < T) att[(size_t)s * T + t] = wgt;
+                if constexpr (!MB) { if (q == 0 && att && t < T) att[(size_t)s * T + t] = wgt; }
                 // weighted sum pooling (DIN.py:152-158): rows past T are all-zero in the tile, so they add nothing
                 if constexpr (HALF) {
                     // w[t] * (hi + lo): two mixed-precision FMAs per element straight from the packed halfs
@@ -500,8 +538,12 @@ __global__ __launch_bounds__(WPB * 64, WPB / 4 == 1 ? 2 : WPB / 4) void k_din_at
             int e_mine;
             const float tot = row16_reduce_scatter<EL>(pv, r, e_mine);
             const int k = kof(e_mine >> 2) + (e_mine & 3);
-            if (r < EL && k < Dp) pooled[(size_t)s * Dp + k] = HALF ? tot * A.inv_h_scale : tot;
+            float* pout = pooled;
+            if constexpr (MB) pout = Mm.pooled[cbi];
+            if (r < EL && k < Dp) pout[(size_t)csl * Dp + k] = HALF ? tot * A.inv_h_scale : tot;
         }
+        DIN_ADVANCE(cbi, csl);
     }
     if (__ballot(bad) != 0 && lane == 0) atomicOr(err, 1);
+#undef DIN_ADVANCE
 }

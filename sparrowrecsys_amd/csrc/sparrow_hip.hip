@@ -703,6 +703,7 @@ struct sprk_engine {
     size_t din_attn_lds = 0;
     int din_attn_grid_cap = 0;
     int din_wpb = 4;               // waves per k_din_attn workgroup
+    bool din_attn_many = true;     // forward_many: one attention launch per group of batches (SPRK_DIN_ATTN_MB=0: per batch)
     // register-chained fast path (k_deepfm_v2_chain); -1 = use the tile interpreter
     int v2_variant = -1;
     V2Args v2;
@@ -1438,7 +1439,13 @@ int setup_rows_ncf(sprk_engine* h) {
 typedef void (*DinLaunchFn)(const DinRun&, const int*, float*, float*, int, int*, int, size_t, hipStream_t);
 template <int KC, int HC, int NP, bool HALF, int WPB>
 void din_launch(const DinRun& a, const int* ids, float* pooled, float* att, int B, int* err, int grid, size_t lds, hipStream_t st) {
-    hipLaunchKernelGGL((k_din_attn<KC, HC, NP, HALF, WPB>), dim3(grid), dim3(WPB * 64), lds, st, a, ids, pooled, att, B, err);
+    hipLaunchKernelGGL((k_din_attn<KC, HC, NP, HALF, WPB, false>), dim3(grid), dim3(WPB * 64), lds, st, a, ids, pooled, att, B, err, DinAttnOne{});
+}
+typedef void (*DinLaunchManyFn)(const DinRun&, const DinAttnMany&, int, int*, int, size_t, hipStream_t);
+template <int KC, int HC, int NP, bool HALF, int WPB>
+void din_launch_many(const DinRun& a, const DinAttnMany& m, int B, int* err, int grid, size_t lds, hipStream_t st) {
+    hipLaunchKernelGGL((k_din_attn<KC, HC, NP, HALF, WPB, true>), dim3(grid), dim3(WPB * 64), lds, st, a, (const int*)nullptr, (float*)nullptr, (float*)nullptr, B,
+                       err, m);
 }
 struct DinVariant {
     int kc, hc, np;                   // np: gather passes compiled in (each covers 64 / (row_stride/4) history slots)
@@ -1447,14 +1454,18 @@ struct DinVariant {
     const void* fn;
     size_t lds_bytes;
     DinLaunchFn launch;
+    const void* fn_many;              // several batches per launch (12-wave forms only; NULL otherwise)
+    DinLaunchManyFn launch_many;
 };
-#define DIN_VARIANT1(KC, HC, NP, HALF, WPB) {KC, HC, NP, HALF, WPB, reinterpret_cast<const void*>(&k_din_attn<KC, HC, NP, HALF, WPB>), DinLds<KC, HC, WPB>::bytes, &din_launch<KC, HC, NP, HALF, WPB>}
+#define DIN_MANY_12(KC, HC, NP, HALF) reinterpret_cast<const void*>(&k_din_attn<KC, HC, NP, HALF, 12, true>), &din_launch_many<KC, HC, NP, HALF, 12>
+#define DIN_VARIANT1(KC, HC, NP, HALF, WPB) {KC, HC, NP, HALF, WPB, reinterpret_cast<const void*>(&k_din_attn<KC, HC, NP, HALF, WPB, false>), DinLds<KC, HC, WPB>::bytes, &din_launch<KC, HC, NP, HALF, WPB>, nullptr, nullptr}
+#define DIN_VARIANT12(KC, HC, NP) {KC, HC, NP, true, 12, reinterpret_cast<const void*>(&k_din_attn<KC, HC, NP, true, 12, false>), DinLds<KC, HC, 12>::bytes, &din_launch<KC, HC, NP, true, 12>, DIN_MANY_12(KC, HC, NP, true)}
 #define DIN_VARIANT(KC, HC, NP) DIN_VARIANT1(KC, HC, NP, true, 4), DIN_VARIANT1(KC, HC, NP, false, 4)
 const DinVariant kDinVariants[] = {     // first match wins: smallest sufficient pass count first; 12-wave forms before their 4-wave twins
-    DIN_VARIANT1(2, 2, 2, true, 12), DIN_VARIANT(2, 2, 2), DIN_VARIANT1(2, 2, 4, true, 12), DIN_VARIANT(2, 2, 4),
-    DIN_VARIANT1(2, 2, 7, true, 12),    // BASELINE config 3: emb_dim 32, 50 history slots, attention hidden 32
+    DIN_VARIANT12(2, 2, 2), DIN_VARIANT(2, 2, 2), DIN_VARIANT12(2, 2, 4), DIN_VARIANT(2, 2, 4),
+    DIN_VARIANT12(2, 2, 7),    // BASELINE config 3: emb_dim 32, 50 history slots, attention hidden 32
     DIN_VARIANT(2, 2, 7),
-    DIN_VARIANT1(2, 2, 8, true, 12), DIN_VARIANT(2, 2, 8),
+    DIN_VARIANT12(2, 2, 8), DIN_VARIANT(2, 2, 8),
     DIN_VARIANT(1, 2, 1),               // the reference's own DIN.py: emb_dim 10 (rows padded to 12), 5 slots, hidden 32
     DIN_VARIANT(1, 2, 4),
 };
@@ -2428,12 +2439,14 @@ int sprk_finalize(sprk_handle h) {
                 r.tsplit = h->din_tsplit; r.inv_h_scale = 1.0f / h_scale;
                 r.b2 = s.b2; r.table = d.table; r.w12 = h->din_w12; r.w4 = h->din_w4; r.vc = h->din_vc; r.alpha = d.alpha; r.w2 = d.w2;
                 HIP_TRY(hipFuncSetAttribute(dv.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dv.lds_bytes));
+                if (dv.fn_many) HIP_TRY(hipFuncSetAttribute(dv.fn_many, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dv.lds_bytes));
                 int wgs = (int)(160 * 1024 / dv.lds_bytes);
                 if (wgs > 2) wgs = 2;                                // launch bounds: 2 waves per SIMD
                 if (dv.wpb == 12) wgs = 1;                           // ... or one 12-wave workgroup: 3 waves per SIMD
                 if (wgs < 1) wgs = 1;
                 h->din_attn_grid_cap = h->num_cus * wgs;
                 h->din_wpb = dv.wpb;
+                { const char* am = getenv("SPRK_DIN_ATTN_MB"); h->din_attn_many = !(am && am[0] == '0'); }
                 h->din_attn_lds = dv.lds_bytes;
                 h->din_variant = (int)v;
                 break;
@@ -2780,12 +2793,22 @@ int sprk_forward_many(sprk_handle h, int32_t n_batches, const int32_t* const* id
                     float* pooled = (float*)(wbase + (size_t)j * ws_need);
                     tm.ids[j] = ids[i0 + j]; tm.dense[j] = dense[i0 + j]; tm.aux[j] = pooled; tm.out[j] = out[i0 + j];
                 }
-                // the attention kernel stays one launch per batch (50 us each: its launch floor is small change); the tail,
-                // a 16-us kernel whose waves otherwise run ONE task, is where a launch per group pays
-                int ag = (B + h->din_wpb - 1) / h->din_wpb;
-                if (ag > h->din_attn_grid_cap) ag = h->din_attn_grid_cap;
-                for (int j = 0; j < n; ++j)
-                    av.launch(h->din_run, tm.ids[j], const_cast<float*>(tm.aux[j]), nullptr, B, h->dev_err, ag, h->din_attn_lds, st);
+                // ONE attention launch for the group (k_din_attn<..., MB = true>: no launch boundary and no partial last round of waves
+                // between the batches; SPRK_DIN_ATTN_MB=0: one launch per batch), then one tail launch
+                if (av.launch_many && h->din_attn_many && n <= DIN_ATTN_MB) {
+                    DinAttnMany am;
+                    memset(&am, 0, sizeof(am));
+                    am.n = n;
+                    for (int j = 0; j < n; ++j) { am.ids[j] = tm.ids[j]; am.pooled[j] = const_cast<float*>(tm.aux[j]); }
+                    long long ag = ((long long)n * B + h->din_wpb - 1) / h->din_wpb;
+                    if (ag > h->din_attn_grid_cap) ag = h->din_attn_grid_cap;
+                    av.launch_many(h->din_run, am, B, h->dev_err, (int)ag, h->din_attn_lds, st);
+                } else {
+                    int ag = (B + h->din_wpb - 1) / h->din_wpb;
+                    if (ag > h->din_attn_grid_cap) ag = h->din_attn_grid_cap;
+                    for (int j = 0; j < n; ++j)
+                        av.launch(h->din_run, tm.ids[j], const_cast<float*>(tm.aux[j]), nullptr, B, h->dev_err, ag, h->din_attn_lds, st);
+                }
                 long long tg = ((long long)n * ntpb + DT_WAVES - 1) / DT_WAVES;
                 if (tg > h->num_cus) tg = h->num_cus;
                 tv.launch_many(h->din_tail_run, tm, B, h->dev_err, h->din_tail_image, (int)tg, st);
