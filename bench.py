@@ -628,12 +628,23 @@ def main():
     # output spot check against the oracle (outside the timed region)
     check = None
     if rank == 0 and not args.no_check:
+        # through the SAME call the timed region makes (sprk_forward_many with `lb` batches per launch over `fan` streams): the
+        # first and the last batch of a group, head and tail rows of each, against the oracle; and the one-batch entry point
+        m = min(NB, max(lb, 2))
+        chk = [torch.full((B,), -1.0, dtype=torch.float32, device="cuda") for _ in range(m)]
+        eng.set_many_batches(lb)
+        eng.set_many_streams(fan)
+        eng.forward_many([batches[j][0] for j in range(m)], [batches[j][1] for j in range(m)], chk, ws)
         eng.forward(batches[0][0], batches[0][1], outs[0], ws)
         torch.cuda.synchronize()
-        n = 4096
-        got = outs[0][:n].cpu().numpy()
-        ref = oracle_forward(args.workload, model, {k: v[:n] for k, v in feats[0].items()})[:, 0]
-        check = float(np.abs(got - ref).max())
+        n = min(2048, B)
+        check = 0.0
+        for j in sorted({0, m - 1}):
+            for sl in (slice(0, n), slice(B - n, B)):
+                ref = oracle_forward(args.workload, model, {k: v[sl] for k, v in feats[j].items()})[:, 0]
+                check = max(check, float(np.abs(chk[j][sl].cpu().numpy() - ref).max()))
+        if not torch.equal(chk[0], outs[0]):
+            raise SystemExit("bench: sprk_forward_many and sprk_forward disagree on batch 0")
         if not check <= 1e-4:
             raise SystemExit("bench outputs differ from the oracle: max|err| = %g" % check)
 

@@ -209,9 +209,9 @@ struct DinLds {
 // fragments now live in LDS (8 ds_read_b128 per sample) and the PReLU coefficient rows are read after the MFMAs, not before.
 // Several batches per launch (sprk_forward_many with sprk_set_many_batches > 1): sample s of the launch is sample s % B of batch
 // s / B, every batch with its own ids / pooled buffers.  (Round 1's version of this was withdrawn over wrong pooled sums in
-// some lanes of one instantiation; the cause -- inline-asm VALU writes feeding an MFMA without the two wait states, invisible
-// to the compiler's hazard recognizer -- is fixed at its source, dyn_split.h / DESIGN.md section 8.)  A wave tracks (batch,
-// row) of its samples with scalar adds, no division per sample.
+// some lanes of one instantiation; the cause -- a transcendental's result read by a v_fma_mix inside an asm statement without
+// the wait state, invisible to the compiler's hazard recognizer -- is guarded where the attention weight is formed, see the
+// epilogue and DESIGN.md section 8.)  A wave tracks (batch, row) of its samples with scalar adds, no division per sample.
 #define DIN_ATTN_MB 16
 struct DinAttnMany {
     const int* ids[DIN_ATTN_MB];
@@ -501,7 +501,16 @@ __global__ __launch_bounds__(WPB * 64, WPB / 4 == 1 ? 2 : WPB / 4) void k_din_at
                     sum1 = fmaf(cb[3], __builtin_fabsf(u[3]), fmaf(ca[3], u[3], sum1));
                 }
                 sum += sum1;
-                const float wgt = sigmoidf_fast(rows4_sum(sum) * (HALF ? A.unscale : 1.0f) + A.b2);   // PReLU is positively homogeneous
+                float wgt = sigmoidf_fast(rows4_sum(sum) * (HALF ? A.unscale : 1.0f) + A.b2);   // PReLU is positively homogeneous
+                // HAZARD GUARD.  wgt comes out of v_rcp_f32, a transcendental: on gfx940+ a non-transcendental VALU instruction
+                // that reads a transcendental's result needs ONE wait state, which hipcc inserts for the consumers it can see
+                // (the s_nop 0 between v_exp and v_add in sigmoidf_fast) -- but the first consumer here is the v_fma_mix_f32
+                // inside an asm statement, which the hazard recognizer does not look into.  In the several-batches-per-launch
+                // instantiation the scheduler put that v_fma_mix straight behind the v_rcp: the first pooled element of every
+                // lane was accumulated with a stale weight (columns 0, 4, 8, ... of every pooled vector wrong, everything else
+                // exact) -- round 1's withdrawn multi-batch kernel showed the same picture.  One statement that owns wgt and
+                // carries the wait state closes it wherever the scheduler puts the pooling.
+                if constexpr (HALF) asm volatile("s_nop 0" : "+v"(wgt));
                 if constexpr (!MB) { if (q == 0 && att && t < T) att[(size_t)s * T + t] = wgt; }
                 // weighted sum pooling (DIN.py:152-158): rows past T are all-zero in the tile, so they add nothing
                 if constexpr (HALF) {
