@@ -1,0 +1,111 @@
+"""Randomised shape sweep (seeded): models of shapes NO kernel instantiation was written for -- odd field counts, vocabularies
+on both sides of the LDS threshold, embedding / projection / hidden widths that do or do not tile -- through whatever the
+engine dispatches them to (fused kernels where a variant matches, the rows chain, the interpreter otherwise), every time
+against the fp64 oracle at the path's tolerance, at ragged batch sizes.  The dispatch is printed: a shape that silently falls
+to the interpreter is visible (`-m gpu -s`)."""
+import numpy as np
+import pytest
+
+from oracle import ctr_oracle as O
+from sparrowrecsys_amd import models as M
+from sparrowrecsys_amd import synthetic as SY
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+GENRES = ["userGenre1", "userGenre2", "userGenre3", "movieGenre1", "movieGenre2", "movieGenre3"]
+IDS = ["movieId", "userId", "userRatedMovie1"]
+
+
+@pytest.fixture(scope="module")
+def torch():
+    import torch as t
+    assert t.cuda.is_available(), "gpu tests need a HIP device"
+    return t
+
+
+def _fields(rng):
+    n_id = int(rng.integers(1, 4))
+    n_g = int(rng.integers(1, 5))
+    fields = [(k, "id", int(rng.choice([25, 40, 1001, 30001, 131071]))) for k in rng.permutation(IDS)[:n_id]]
+    fields += [(k, "genre", 19) for k in rng.permutation(GENRES)[:n_g]]
+    return [fields[i] for i in rng.permutation(len(fields))]
+
+
+@pytest.mark.parametrize("case", range(14))
+def test_deepfm_v2_random_shapes(torch, case):
+    rng = np.random.default_rng(1000 + case)
+    fields = _fields(rng)
+    order = [k for k, _, _ in fields]
+    emb_dim = int(rng.choice([4, 6, 10, 16, 32]))
+    proj_dim = int(rng.choice([8, 16, 24, 64]))
+    hidden = [(32, 16), (64, 32), (16,), (48, 16), (32, 32, 16)][int(rng.integers(0, 5))]
+    B = int(rng.choice([1, 17, 1000, 4099]))
+    model = M.DeepFMv2(seed=2000 + case, emb_dim=emb_dim, fields=fields, proj_dim=proj_dim, hidden=hidden)
+    feats = SY.synth_fields(B, fields, seed=3000 + case)
+    got = model.predict(feats)[:, 0]
+    ref = O.deepfm_v2_forward(feats, model.weights, dtype=np.float64, fields=fields, order=order)[:, 0]
+    err = float(np.abs(got - ref).max())
+    print("deepfm_v2 #%d: %d fields %s, emb %d, proj %d, hidden %s, B %d -> %s, max|err| %.2e"
+          % (case, len(fields), [v for _, _, v in fields], emb_dim, proj_dim, hidden, B, model.engine.describe()["kernel"], err))
+    assert err <= TOL
+
+
+@pytest.mark.parametrize("case", range(8))
+def test_deepfm_pair_dot_random_shapes(torch, case):
+    rng = np.random.default_rng(4000 + case)
+    fields = _fields(rng)
+    names = [k for k, _, _ in fields]
+    all_pairs = [(a, b) for i, a in enumerate(names) for b in names[i + 1:]]
+    pairs = [all_pairs[i] for i in rng.permutation(len(all_pairs))[:max(1, int(rng.integers(1, len(all_pairs) + 1)))]]
+    id_names = [k for k, kind, _ in fields if kind == "id"]
+    deep_emb = id_names[:int(rng.integers(1, min(2, len(id_names)) + 1))]
+    emb_dim = int(rng.choice([4, 10, 16, 64]))
+    hidden = [(64, 64), (32, 16), (128, 64)][int(rng.integers(0, 3))]
+    B = int(rng.choice([1, 33, 2051]))
+    model = M.DeepFM(seed=5000 + case, emb_dim=emb_dim, fields=fields, pairs=pairs, deep_emb=deep_emb, hidden=hidden)
+    feats = SY.synth_fields(B, fields, seed=6000 + case)
+    got = model.predict(feats)[:, 0]
+    ref = O.deepfm_forward(feats, model.weights, dtype=np.float64, fields=fields, pairs=pairs, deep_emb=deep_emb)[:, 0]
+    err = float(np.abs(got - ref).max())
+    print("deepfm #%d: %d fields, %d pairs, deep %s, emb %d, hidden %s, B %d -> %s, max|err| %.2e"
+          % (case, len(fields), len(pairs), deep_emb, emb_dim, hidden, B, model.engine.describe()["kernel"], err))
+    assert err <= TOL
+
+
+@pytest.mark.parametrize("case", range(8))
+def test_din_random_shapes(torch, case):
+    rng = np.random.default_rng(7000 + case)
+    D = int(rng.choice([6, 10, 16, 32]))
+    T = int(rng.choice([1, 5, 17, 50, 64]))
+    V, U = int(rng.choice([101, 1001, 20000])), int(rng.choice([50, 30001]))
+    hidden = [(128, 64), (64, 32)][int(rng.integers(0, 2))]
+    B = int(rng.choice([1, 13, 777, 3001]))
+    model = M.DIN(seed=8000 + case, emb_dim=D, hist_len=T, movie_buckets=V, user_buckets=U, hidden=hidden)
+    feats = SY.synth_din(B, T, V, U, seed=9000 + case)
+    got = model.predict(feats)[:, 0]
+    ref = O.din_forward(feats, model.weights, dtype=np.float64, hist_len=T, movie_buckets=V, user_buckets=U)[:, 0]
+    err = float(np.abs(got - ref).max())
+    d = model.engine.describe()
+    print("din #%d: D %d, T %d, vocab %d / %d, hidden %s, B %d -> %s + %s, max|err| %.2e" % (case, D, T, V, U, hidden, B, d["stage"], d["kernel"], err))
+    assert err <= TOL
+
+
+@pytest.mark.parametrize("case", range(6))
+def test_neuralcf_random_shapes(torch, case):
+    rng = np.random.default_rng(10000 + case)
+    D = int(rng.choice([4, 10, 16, 24]))
+    hidden = [(10, 10), (32, 16, 8), (16,), (64, 32)][int(rng.integers(0, 4))]
+    V, U = int(rng.choice([101, 1001, 50000])), int(rng.choice([77, 30001]))
+    arch = 1 if case % 3 else 2
+    B = int(rng.choice([1, 19, 5000]))
+    model = M.NeuralCF(seed=11000 + case, emb_dim=D, movie_buckets=V, user_buckets=U, hidden=hidden, arch=arch)
+    r2 = np.random.default_rng(12000 + case)
+    feats = {"movieId": r2.integers(0, V, B).astype(np.int32), "userId": r2.integers(0, U, B).astype(np.int32)}
+    got = model.predict(feats)[:, 0]
+    fwd = O.neural_cf_forward if arch == 1 else O.neural_cf2_forward
+    ref = fwd(feats, model.weights, dtype=np.float64, movie_buckets=V, user_buckets=U)[:, 0]
+    err = float(np.abs(got - ref).max())
+    print("neuralcf #%d: arch %d, D %d, hidden %s, vocab %d / %d, B %d -> %s, max|err| %.2e"
+          % (case, arch, D, hidden, V, U, B, model.engine.describe()["kernel"], err))
+    assert err <= TOL
