@@ -1821,6 +1821,30 @@ int setup_deepfm_pairs(sprk_engine* h) {
         HIP_TRY(hipDeviceSynchronize());
         r.image = img;
     }
+    r.tab = nullptr;
+    const char* rt = getenv("SPRK_V1_ROWTAB");                // A/B switch: "0" = gather from the uploaded tables
+    if (PC == 1 && !(rt && rt[0] == '0')) {
+        size_t rows = 0;
+        for (int f = 0; f < nf; ++f) rows += (size_t)r.vocab[f] + 1;
+        if (rows * 128 < ((size_t)1 << 32)) {                     // 32-bit byte offsets
+            float* tab = nullptr;
+            HIP_TRY(hipMalloc((void**)&tab, rows * 128));
+            h->v1_bufs.push_back(tab);
+            h->derived_bytes += rows * 128;
+            size_t base = 0;
+            for (int f = 0; f < nf; ++f) {
+                const long long n = (long long)r.vocab[f] + 1;
+                long long nb = (n * 32 + 255) / 256;
+                if (nb > 65536) nb = 65536;
+                hipLaunchKernelGGL(k_v1_build_rows, dim3((unsigned)nb), dim3(256), 0, 0, r.table[f], Dp, r.w1[f], n, tab + base * 32);
+                r.rowbase[f] = (unsigned)base;
+                base += (size_t)n;
+            }
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipDeviceSynchronize());
+            r.tab = tab;
+        }
+    }
     h->v1_run = r;
     h->v1_variant = variant;
     return SPRK_OK;
