@@ -32,6 +32,13 @@ b bench_ncf_ref_interp env SPRK_NCF_CHAIN=0 python bench.py --workload neuralcf_
 b bench_c4_pairs_interp env SPRK_V1_CHAIN=0 python bench.py --workload deepfm_c4 --steps 100 --warmup 10 --cpu-seconds 0
 b bench_c2_forced_collective_sprk env SPRK_BENCH_FORCE_DIST=1 SPRK_FORCE_COLLECTIVE=1 python bench.py --cpu-seconds 0 --hbm-resident 0 --collective sprk
 b bench_c2_forced_collective_torch env SPRK_BENCH_FORCE_DIST=1 SPRK_FORCE_COLLECTIVE=1 python bench.py --cpu-seconds 0 --hbm-resident 0 --collective torch
+b bench_c2_forced_collective_peer env SPRK_BENCH_FORCE_DIST=1 SPRK_FORCE_COLLECTIVE=1 python bench.py --cpu-seconds 0 --hbm-resident 0 --collective peer
+b bench_c2_gloo2_peer python bench.py --gpus 2 --backend gloo --collective peer --steps 20 --warmup 5 --cpu-seconds 0 --hbm-resident 0 --min-region-ms 1 --regions 1 --settle-ms 0
+b bench_c3_attn_per_batch env SPRK_DIN_ATTN_MB=0 python bench.py --workload din_c3 --steps 320 --warmup 32 --cpu-seconds 0
+b bench_c3_hot python bench.py --workload din_c3 --steps 320 --warmup 32 --cpu-seconds 0 --dist hot
+b bench_c2_pairs_strict python bench.py --workload deepfm_c2 --cpu-seconds 0 --launch-batches 1 --overlap-streams 0
+b bench_c2_pairs_uploaded_tables env SPRK_V1_ROWTAB=0 python bench.py --workload deepfm_c2 --cpu-seconds 0
+timeout 600 python scripts/bench_ingest.py --rows 20000000 --threads 1,128 --device > $O/bench_ingest_20m.json 2> $O/bench_ingest_20m.err; cut -c1-300 $O/bench_ingest_20m.json
 b bench_c2_gloo2 python bench.py --gpus 2 --backend gloo --steps 20 --warmup 5 --cpu-seconds 0 --hbm-resident 0 --min-region-ms 1 --regions 1 --settle-ms 0
 timeout 120 scripts/ubench/launch_floor > $O/ubench_launch_floor.log 2>&1; tail -20 $O/ubench_launch_floor.log
 timeout 900 python -m pytest tests -m gpu -q 2>&1 | tail -3 | tee $O/pytest_gpu.log
@@ -49,6 +56,7 @@ prof c4_v2_strict python $R/bench.py --workload deepfm_v2_c4 --steps 400 --warmu
 prof c5 python $R/bench.py --workload widedeep_c5 --steps 100 --warmup 10 $Q
 prof c4_pairs_strict python $R/bench.py --workload deepfm_c4 --steps 200 --warmup 20 --launch-batches 1 --overlap-streams 0 $Q
 prof v2_ref_strict python $R/bench.py --workload deepfm_v2_ref --steps 400 --warmup 40 --launch-batches 1 --overlap-streams 0 $Q
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_ingest -o ingest -- python $R/scripts/bench_ingest.py --rows 20000000 --threads 128 --device > $O/prof_ingest.log 2>&1; f=$(find $O/prof_ingest -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/ingest_kernel_stats.csv
 prof ncf_ref_strict python $R/bench.py --workload neuralcf_ref --steps 400 --warmup 40 --launch-batches 1 --overlap-streams 0 $Q
 echo "=== PMC passes"
 pass() { # tag name counters -- command...

@@ -94,7 +94,10 @@ __global__ __launch_bounds__(256) void k_csv_mark(const unsigned char* __restric
 
 // Readers: the text in global memory, or a workgroup's 256 lines staged in LDS.  win(i) = the 8 bytes at offsets i .. i+7
 // (little endian; bytes past the staged piece / the text are unspecified and never looked at).
+// Positions are offsets into the text (global reader: size_t) or into the staged piece (LDS reader: 32 bits -- the walk over a
+// line is all position arithmetic, and 64-bit compares / adds cost two VALU instructions each).
 struct CsvRdGlobal {
+    typedef size_t pos_t;
     const unsigned char* __restrict__ t;
     size_t len;
     __device__ __forceinline__ unsigned operator[](size_t i) const { return t[i]; }
@@ -105,14 +108,14 @@ struct CsvRdGlobal {
     }
 };
 struct CsvRdLds {
+    typedef unsigned pos_t;
     const unsigned char* lds;
-    size_t base;
-    __device__ __forceinline__ unsigned operator[](size_t i) const { return lds[(unsigned)(i - base)]; }
-    __device__ __forceinline__ unsigned long long win(size_t i) const {
-        const unsigned o = (unsigned)(i - base), sh = 8 * (o & 7);
+    __device__ __forceinline__ unsigned operator[](unsigned o) const { return lds[o]; }
+    __device__ __forceinline__ unsigned long long win(unsigned o) const {
+        const unsigned sh = 8 * (o & 7);
         const unsigned long long* q = reinterpret_cast<const unsigned long long*>(lds + (o & ~7u));
-        const unsigned long long lo = q[0], hi = q[1];             // two aligned 8-byte LDS reads
-        return sh ? (lo >> sh) | (hi << (64 - sh)) : lo;
+        const unsigned long long lo = q[0], hi = q[1];             // two aligned 8-byte LDS reads (one ds_read2_b64)
+        return (lo >> sh) | ((hi << 1) << (63 - sh));               // branch-free for sh == 0 too
     }
 };
 #define CSV_LDS_SLACK 32
@@ -125,7 +128,7 @@ __device__ __forceinline__ unsigned csv_find8(unsigned long long w, unsigned c) 
 }
 // position of the next ',' in [p, hi), or hi -- eight bytes per step
 template <class R>
-__device__ __forceinline__ size_t csv_next_comma(const R& t, size_t p, size_t hi) {
+__device__ __forceinline__ typename R::pos_t csv_next_comma(const R& t, typename R::pos_t p, typename R::pos_t hi) {
     while (p < hi) {
         const unsigned k = csv_find8(t.win(p), ',');
         if (k < 8) return p + k < hi ? p + k : hi;
@@ -138,7 +141,8 @@ __device__ __forceinline__ size_t csv_next_comma(const R& t, size_t p, size_t hi
 // esc = the quoted content holds an escaped quote; p is left on the comma that ends the field (or at hi).  A field that STARTS
 // with '"' runs to its closing quote ("" inside is an escaped quote), whatever follows up to the next comma is ignored.
 template <class R>
-__device__ __forceinline__ void csv_field(const R& t, size_t hi, size_t& p, size_t& a, size_t& b, bool& esc) {
+__device__ __forceinline__ void csv_field(const R& t, typename R::pos_t hi, typename R::pos_t& p, typename R::pos_t& a,
+                                          typename R::pos_t& b, bool& esc) {
     esc = false;
     if (p < hi && t[p] == '"') {
         ++p;
@@ -191,9 +195,10 @@ __device__ __forceinline__ void csv_stage_lines(const unsigned char* __restrict_
         }
         __syncthreads();
         if (i >= n_lines) return;
-        const CsvRdLds rd{lds, base};
-        if (hi > lo && rd[hi - 1] == '\r') --hi;
-        body(rd, i, lo, hi);
+        const CsvRdLds rd{lds};
+        unsigned lo32 = (unsigned)(lo - base), hi32 = (unsigned)(hi - base);
+        if (hi32 > lo32 && rd[hi32 - 1] == '\r') --hi32;
+        body(rd, i, lo32, hi32);
     } else {
         if (i >= n_lines) return;
         const CsvRdGlobal rd{text, len};
@@ -204,11 +209,11 @@ __device__ __forceinline__ void csv_stage_lines(const unsigned char* __restrict_
 
 __global__ __launch_bounds__(256) void k_csv_keep(const unsigned char* __restrict__ text, size_t len, const unsigned long long* __restrict__ nl,
                                                   unsigned n_nl, unsigned n_lines, int n_cols, unsigned lds_cap, unsigned* __restrict__ keep) {
-    csv_stage_lines(text, len, nl, n_nl, n_lines, lds_cap, [&](auto rd, unsigned i, size_t lo, size_t hi) {
+    csv_stage_lines(text, len, nl, n_nl, n_lines, lds_cap, [&](auto rd, unsigned i, auto lo, auto hi) {
         unsigned k = 0;
         if (i > 0 && hi > lo) {                                   // line 0 is the header; empty lines are skipped
             int fields = 0;
-            size_t p = lo, a, b;
+            decltype(lo) p = lo, a, b;
             bool esc;
             for (;;) {
                 csv_field(rd, hi, p, a, b, esc);
@@ -225,12 +230,12 @@ __global__ __launch_bounds__(256) void k_csv_keep(const unsigned char* __restric
 
 // decimal field [a, b) -> double; returns 0 = value, 1 = empty, 2 = HARD
 template <class R>
-__device__ __forceinline__ int csv_number(const R& t, size_t a, size_t b, double& out) {
+__device__ __forceinline__ int csv_number(const R& t, typename R::pos_t a, typename R::pos_t b, double& out) {
     out = 0.0;
     if (a == b) return 1;
     unsigned long long w = t.win(a);                              // the field's bytes, eight at a time
     unsigned left = 8;
-    size_t i = a;
+    typename R::pos_t i = a;
     auto next = [&]() -> unsigned {
         if (left == 0) { w = t.win(i); left = 8; }
         const unsigned c = (unsigned)w & 0xFF;
@@ -301,7 +306,7 @@ __global__ __launch_bounds__(256) void k_csv_parse(const CsvDev L, const unsigne
                                                    unsigned lds_cap, int* __restrict__ ids, float* __restrict__ dense,
                                                    unsigned long long* __restrict__ first_err, CsvErr* __restrict__ errs,
                                                    unsigned* __restrict__ n_errs, unsigned* __restrict__ drops) {
-    csv_stage_lines(text, len, nl, n_nl, n_lines, lds_cap, [&](auto rd, unsigned i, size_t lo, size_t hi) {
+    csv_stage_lines(text, len, nl, n_nl, n_lines, lds_cap, [&](auto rd, unsigned i, auto lo, auto hi) {
         unsigned row;
         if constexpr (OPT) {
             if (i == 0) return;
@@ -319,9 +324,9 @@ __global__ __launch_bounds__(256) void k_csv_parse(const CsvDev L, const unsigne
             const unsigned s = atomicAdd(n_errs, 1u);
             if (s < 64) { errs[s].key = key; errs[s].code = code; errs[s].out_col = out_col; errs[s].is_dense = is_dense; errs[s].value = value; }
         };
-        size_t p = lo;
+        decltype(lo) p = lo;
         for (bool more = true; more;) {
-            size_t a, b;
+            decltype(lo) a, b;
             bool esc;
             if (p == hi && c > 0) { a = b = hi; esc = false; more = false; }  // the empty field after a trailing comma
             else {
