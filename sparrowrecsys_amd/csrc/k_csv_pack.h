@@ -34,9 +34,16 @@ struct CsvDev {
     short id_next[CSV_MAX_OUT], dense_next[CSV_MAX_OUT];     // next output fed by the same column (-1: end)
     int id_kind[CSV_MAX_OUT], id_vocab[CSV_MAX_OUT];
     unsigned char role[CSV_MAX_COLS];                        // bit 0: column c feeds a numeric output, bit 1: a genre output
-    unsigned long long g_lo[19], g_hi[19];                   // the genre vocabulary (DeepFM.py:64-66) as 16 little-endian bytes
-    int g_len[19];
+    // the genre vocabulary (DeepFM.py:64-66) behind a perfect hash: slot = (key * g_mul) >> 59 with key = lo ^ hi * C ^ len; a slot
+    // holds the entry's 16 little-endian bytes, its length and its vocabulary position (-1: empty)
+    unsigned long long g_mul;
+    unsigned long long gt_lo[32], gt_hi[32];
+    signed char gt_len[32], gt_idx[32];
 };
+#define CSV_GENRE_C 0x9E3779B97F4A7C15ull
+__host__ __device__ inline unsigned csv_genre_slot(unsigned long long lo, unsigned long long hi, unsigned len, unsigned long long mul) {
+    return (unsigned)((((lo ^ (hi * CSV_GENRE_C)) ^ len) * mul) >> 59);
+}
 // error record of a row that cannot be packed: code 1 = identity id outside [0, vocab), 2 = HARD (see above)
 struct CsvErr { unsigned long long key; int code, out_col, is_dense; long long value; };
 
@@ -119,6 +126,7 @@ struct CsvRdLds {
     }
 };
 #define CSV_LDS_SLACK 32
+#define CSV_LDS_GENRE 640                      // bytes behind the staged text: the genre hash table (32 x {lo, hi}, 32 lengths, 32 positions)
 
 // first byte == c among the 8 bytes of w: its index, or 8 (exact for the lowest match: the classic zero-byte test)
 __device__ __forceinline__ unsigned csv_find8(unsigned long long w, unsigned c) {
@@ -128,11 +136,13 @@ __device__ __forceinline__ unsigned csv_find8(unsigned long long w, unsigned c) 
 }
 // position of the next ',' in [p, hi), or hi -- eight bytes per step
 template <class R>
-__device__ __forceinline__ typename R::pos_t csv_next_comma(const R& t, typename R::pos_t p, typename R::pos_t hi) {
+__device__ __forceinline__ typename R::pos_t csv_next_comma(const R& t, typename R::pos_t p, typename R::pos_t hi, unsigned long long w) {
+    // w = t.win(p), already in hand
     while (p < hi) {
-        const unsigned k = csv_find8(t.win(p), ',');
+        const unsigned k = csv_find8(w, ',');
         if (k < 8) return p + k < hi ? p + k : hi;
         p += 8;
+        if (p < hi) w = t.win(p);
     }
     return hi;
 }
@@ -144,7 +154,8 @@ template <class R>
 __device__ __forceinline__ void csv_field(const R& t, typename R::pos_t hi, typename R::pos_t& p, typename R::pos_t& a,
                                           typename R::pos_t& b, bool& esc) {
     esc = false;
-    if (p < hi && t[p] == '"') {
+    const unsigned long long w0 = p < hi ? t.win(p) : 0ull;       // ONE read serves the quote test and the first comma search
+    if (p < hi && (w0 & 0xFF) == '"') {
         ++p;
         a = p;
         b = hi;                                                   // an unclosed quote runs to the end of the line
@@ -157,10 +168,10 @@ __device__ __forceinline__ void csv_field(const R& t, typename R::pos_t hi, type
             }
             ++p;
         }
-        p = csv_next_comma(t, p, hi);
+        p = csv_next_comma(t, p, hi, p < hi ? t.win(p) : 0ull);
     } else {
         a = p;
-        p = csv_next_comma(t, p, hi);
+        p = csv_next_comma(t, p, hi, w0);
         b = p;
     }
 }
@@ -171,8 +182,18 @@ __device__ __forceinline__ void csv_field(const R& t, typename R::pos_t hi, type
 // otherwise.
 template <class Body>
 __device__ __forceinline__ void csv_stage_lines(const unsigned char* __restrict__ text, size_t len, const unsigned long long* __restrict__ nl,
-                                                unsigned n_nl, unsigned n_lines, unsigned lds_cap, Body body) {
+                                                unsigned n_nl, unsigned n_lines, unsigned lds_cap, const CsvDev* L, Body body) {
     unsigned char* lds = reinterpret_cast<unsigned char*>(smem);
+    if (L && threadIdx.x < 32) {
+        // the genre hash table next to the text: a per-lane slot lookup is an LDS read, not a dependent load from the kernel
+        // arguments (PMC after the instruction diet: 61 % of the wave cycles in s_waitcnt)
+        unsigned long long* g = reinterpret_cast<unsigned long long*>(lds + lds_cap + CSV_LDS_SLACK);
+        g[2 * threadIdx.x] = L->gt_lo[threadIdx.x];
+        g[2 * threadIdx.x + 1] = L->gt_hi[threadIdx.x];
+        signed char* gl = reinterpret_cast<signed char*>(g + 64);
+        gl[threadIdx.x] = L->gt_len[threadIdx.x];
+        gl[32 + threadIdx.x] = L->gt_idx[threadIdx.x];
+    }
     const unsigned i0 = blockIdx.x * 256;
     const unsigned i1 = i0 + 256 < n_lines ? i0 + 256 : n_lines;
     const size_t g0 = i0 == 0 ? 0 : (size_t)nl[i0 - 1] + 1;
@@ -200,6 +221,7 @@ __device__ __forceinline__ void csv_stage_lines(const unsigned char* __restrict_
         if (hi32 > lo32 && rd[hi32 - 1] == '\r') --hi32;
         body(rd, i, lo32, hi32);
     } else {
+        __syncthreads();                                          // (the genre table)
         if (i >= n_lines) return;
         const CsvRdGlobal rd{text, len};
         if (hi > lo && rd[hi - 1] == '\r') --hi;
@@ -209,7 +231,7 @@ __device__ __forceinline__ void csv_stage_lines(const unsigned char* __restrict_
 
 __global__ __launch_bounds__(256) void k_csv_keep(const unsigned char* __restrict__ text, size_t len, const unsigned long long* __restrict__ nl,
                                                   unsigned n_nl, unsigned n_lines, int n_cols, unsigned lds_cap, unsigned* __restrict__ keep) {
-    csv_stage_lines(text, len, nl, n_nl, n_lines, lds_cap, [&](auto rd, unsigned i, auto lo, auto hi) {
+    csv_stage_lines(text, len, nl, n_nl, n_lines, lds_cap, nullptr, [&](auto rd, unsigned i, auto lo, auto hi) {
         unsigned k = 0;
         if (i > 0 && hi > lo) {                                   // line 0 is the header; empty lines are skipped
             int fields = 0;
@@ -226,6 +248,43 @@ __global__ __launch_bounds__(256) void k_csv_keep(const unsigned char* __restric
         }
         keep[i] = k;
     });
+}
+
+// four ASCII digits, first character in the lowest byte -> their value (no validation)
+__device__ __forceinline__ unsigned csv_parse4(unsigned x) {
+    x -= 0x30303030u;
+    x = x * 10u + (x >> 8);                                       // bytes 0 and 2 now hold d0 d1 and d2 d3 as two-digit numbers
+    return (x & 0xFFu) * 100u + ((x >> 16) & 0xFFu);
+}
+// The common shape of a numeric field without a loop and without a branch per character: at most 8 characters,
+// [sign] digits [. digits].  true -> out; false -> anything else (the caller runs the general csv_number).
+// PMC on the first version of k_csv_parse: 3 082 SALU + 1 743 VALU instructions per wave of 64 lines, most of them exec-mask
+// bookkeeping for csv_number's per-character branches.
+template <class R>
+__device__ __forceinline__ bool csv_number_short(const R& t, typename R::pos_t a, typename R::pos_t b, double& out) {
+    const unsigned n0 = (unsigned)(b - a);                        // 1 .. 8 (checked by the caller)
+    unsigned long long w = t.win(a);
+    const unsigned c0 = (unsigned)w & 0xFFu;
+    const bool sgn = c0 == '-' || c0 == '+';
+    w = sgn ? w >> 8 : w;
+    const unsigned n = n0 - (sgn ? 1u : 0u);                      // characters after the sign, 0 .. 8
+    w &= n >= 8 ? ~0ull : (1ull << (8 * n)) - 1;                  // bytes past the field -> 0
+    const unsigned d = csv_find8(w, '.');                         // position of the first '.', 8 = none
+    const bool dot = d < 8;
+    const unsigned long long below = dot ? (1ull << (8 * d)) - 1 : ~0ull;
+    w = dot ? (w & below) | ((w >> 8) & ~below) : w;              // the dot removed: later characters move down one place
+    const unsigned nd = n - (dot ? 1u : 0u);                      // digits, in the low nd bytes
+    const unsigned frac = dot ? n - 1 - d : 0u;                   // ... of which behind the dot
+    // leading '0's in front: the digits end up in the high bytes, first character still in the lower byte
+    const unsigned long long al = nd >= 8 ? w : (w << ((8 * (8 - nd)) & 63)) | (0x3030303030303030ull >> (8 * nd));   // (nd = 0 fails below)
+    const bool digits = (al & 0xF0F0F0F0F0F0F0F0ull) == 0x3030303030303030ull &&
+                        ((al + 0x0606060606060606ull) & 0xF0F0F0F0F0F0F0F0ull) == 0x3030303030303030ull;
+    if (!(digits && nd >= 1 && nd <= 8)) return false;
+    const unsigned m = csv_parse4((unsigned)al) * 10000u + csv_parse4((unsigned)(al >> 32));
+    double v = (double)m;                                         // < 10^8: exact
+    if (frac) v = v / kCsvP10[frac];                              // one correctly rounded division, as the general path
+    out = c0 == '-' ? -v : v;
+    return true;
 }
 
 // decimal field [a, b) -> double; returns 0 = value, 1 = empty, 2 = HARD
@@ -306,7 +365,9 @@ __global__ __launch_bounds__(256) void k_csv_parse(const CsvDev L, const unsigne
                                                    unsigned lds_cap, int* __restrict__ ids, float* __restrict__ dense,
                                                    unsigned long long* __restrict__ first_err, CsvErr* __restrict__ errs,
                                                    unsigned* __restrict__ n_errs, unsigned* __restrict__ drops) {
-    csv_stage_lines(text, len, nl, n_nl, n_lines, lds_cap, [&](auto rd, unsigned i, auto lo, auto hi) {
+    const unsigned long long* g_tab = reinterpret_cast<const unsigned long long*>(reinterpret_cast<const unsigned char*>(smem) + lds_cap + CSV_LDS_SLACK);
+    const signed char* g_len = reinterpret_cast<const signed char*>(g_tab + 64);
+    csv_stage_lines(text, len, nl, n_nl, n_lines, lds_cap, &L, [&](auto rd, unsigned i, auto lo, auto hi) {
         unsigned row;
         if constexpr (OPT) {
             if (i == 0) return;
@@ -317,29 +378,35 @@ __global__ __launch_bounds__(256) void k_csv_parse(const CsvDev L, const unsigne
             row = pos[i];
         }
         if (row >= max_rows) return;
-        int c = 0;
+        int c = 0;                                                // (captured by `report`)
         auto report = [&](int code, int out_col, int is_dense, long long value) {
             const unsigned long long key = ((unsigned long long)row << 20) | ((unsigned long long)(unsigned)c << 4) | (unsigned)code;
             atomicMin(first_err, key);
             const unsigned s = atomicAdd(n_errs, 1u);
             if (s < 64) { errs[s].key = key; errs[s].code = code; errs[s].out_col = out_col; errs[s].is_dense = is_dense; errs[s].value = value; }
         };
+        // Every kept line has exactly n_cols fields, so the field loop runs a uniform n_cols times (the column's role, its output
+        // lists: scalar); a lane whose line ends early (OPT only: such a line is dropped) idles through the rest.
         decltype(lo) p = lo;
-        for (bool more = true; more;) {
+        bool ended = false, short_line = false;
+        for (c = 0; c < L.n_cols; ++c) {
+            if (ended) { short_line = true; continue; }
             decltype(lo) a, b;
             bool esc;
-            if (p == hi && c > 0) { a = b = hi; esc = false; more = false; }  // the empty field after a trailing comma
-            else {
-                csv_field(rd, hi, p, a, b, esc);
-                if (p >= hi) more = false;
-                else { ++p; more = true; }                                   // the comma; p == hi now means a trailing comma
-            }
+            csv_field(rd, hi, p, a, b, esc);                      // (p == hi on entry: the empty field after a trailing comma)
+            if (p >= hi) ended = true;
+            else ++p;                                             // the comma
             // field c = [a, b)
-            const int role = c < L.n_cols ? L.role[c] : 0;
+            const int role = L.role[c];
             if (role) {
                 double v = 0.0;
                 int st = 1;
-                if (role & 1) st = esc ? 2 : csv_number(rd, a, b, v);
+                if (role & 1) {
+                    if (esc) st = 2;
+                    else if (a == b) st = 1;
+                    else if ((unsigned)(b - a) <= 8 && csv_number_short(rd, a, b, v)) st = 0;
+                    else st = csv_number(rd, a, b, v);
+                }
                 unsigned long long w0 = 0, w1 = 0;
                 const unsigned gn = (unsigned)(b - a);
                 if ((role & 2) && gn >= 1 && gn <= 16) {                   // the field's bytes as two little-endian words
@@ -351,9 +418,10 @@ __global__ __launch_bounds__(256) void k_csv_parse(const CsvDev L, const unsigne
                     int out;
                     if (L.id_kind[o] == 1) {                          // genre vocabulary (exact match) or -1
                         out = -1;
-                        if (gn >= 1 && gn <= 16)
-                            for (int g = 0; g < 19; ++g)
-                                if (L.g_len[g] == (int)gn && L.g_lo[g] == w0 && L.g_hi[g] == w1) out = g;
+                        if (gn >= 1 && gn <= 16) {
+                            const unsigned sl = csv_genre_slot(w0, w1, gn, L.g_mul);
+                            if (g_len[sl] == (int)gn && g_tab[2 * sl] == w0 && g_tab[2 * sl + 1] == w1) out = g_len[32 + sl];
+                        }
                         if (out >= L.id_vocab[o]) out = -1;
                     } else if (st == 2) {
                         report(2, o, 0, 0);
@@ -370,10 +438,9 @@ __global__ __launch_bounds__(256) void k_csv_parse(const CsvDev L, const unsigne
                     dense[(size_t)row * L.n_dense + o] = (float)v;
                 }
             }
-            ++c;
         }
         if constexpr (OPT) {
-            if (c != L.n_cols) atomicAdd(drops, 1u);
+            if (short_line || !ended) atomicAdd(drops, 1u);       // fewer or more fields than the header: not a row
         }
     });
 }

@@ -3315,10 +3315,34 @@ int sprk_pack_csv_device(const char* text_dev, size_t len, const sprk_csv_col* i
         for (int j = L.id_head[c]; j >= 0; j = L.id_next[j]) L.role[c] |= L.id_kind[j] == 1 ? 2 : 1;
         if (L.dense_head[c] >= 0) L.role[c] |= 1;
     }
-    for (int g = 0; g < 19; ++g) {
-        const size_t n = strlen(kGenreVocab[g]);
-        L.g_len[g] = (int)n;
-        for (size_t k = 0; k < n && k < 16; ++k) (k < 8 ? L.g_lo[g] : L.g_hi[g]) |= (unsigned long long)(unsigned char)kGenreVocab[g][k] << (8 * (k & 7));
+    {
+        // perfect hash of the 19 genre strings into 32 slots: the first odd multiplier without a collision
+        unsigned long long lo[19], hi[19];
+        unsigned len[19];
+        for (int g = 0; g < 19; ++g) {
+            const size_t n = strlen(kGenreVocab[g]);
+            lo[g] = hi[g] = 0;
+            len[g] = (unsigned)n;
+            for (size_t k = 0; k < n && k < 16; ++k) (k < 8 ? lo[g] : hi[g]) |= (unsigned long long)(unsigned char)kGenreVocab[g][k] << (8 * (k & 7));
+        }
+        unsigned long long mul = 0x9E3779B97F4A7C15ull;
+        for (int tries = 0; tries < 100000; ++tries, mul += 0x632BE59BD9B4E019ull * 2) {
+            unsigned used = 0;
+            bool ok = true;
+            for (int g = 0; g < 19 && ok; ++g) {
+                const unsigned sl = csv_genre_slot(lo[g], hi[g], len[g], mul | 1);
+                ok = !(used & (1u << sl));
+                used |= 1u << sl;
+            }
+            if (ok) break;
+        }
+        L.g_mul = mul | 1;
+        for (int sl = 0; sl < 32; ++sl) { L.gt_idx[sl] = -1; L.gt_len[sl] = -1; }
+        for (int g = 0; g < 19; ++g) {
+            const unsigned sl = csv_genre_slot(lo[g], hi[g], len[g], L.g_mul);
+            if (L.gt_idx[sl] >= 0) return fail(SPRK_EINVAL, "no perfect hash for the genre vocabulary");
+            L.gt_lo[sl] = lo[g]; L.gt_hi[sl] = hi[g]; L.gt_len[sl] = (signed char)len[g]; L.gt_idx[sl] = (signed char)g;
+        }
     }
     // pass 1: newlines per chunk
     const size_t n_chunks = (len + CSV_CHUNK - 1) / CSV_CHUNK;
@@ -3380,7 +3404,7 @@ int sprk_pack_csv_device(const char* text_dev, size_t len, const sprk_csv_col* i
         const size_t lines_opt = n_lines - 1 <= (size_t)max_rows ? n_lines : (size_t)max_rows + 1;
         const unsigned lbo = (unsigned)((lines_opt + 255) / 256);
         if (lines_opt > 1)
-            hipLaunchKernelGGL(k_csv_parse<true>, dim3(lbo), dim3(256), lds_cap + CSV_LDS_SLACK, st, L, text, len, (const unsigned long long*)nl, h_nl,
+            hipLaunchKernelGGL(k_csv_parse<true>, dim3(lbo), dim3(256), lds_cap + CSV_LDS_SLACK + CSV_LDS_GENRE, st, L, text, len, (const unsigned long long*)nl, h_nl,
                                (unsigned)lines_opt, (const unsigned*)nullptr, (const unsigned*)nullptr, (unsigned)max_rows, lds_cap, ids_dev, dense_dev,
                                first_err, errs, n_errs, drops);
         HIP_TRY(hipGetLastError());
@@ -3396,10 +3420,10 @@ int sprk_pack_csv_device(const char* text_dev, size_t len, const sprk_csv_col* i
         }
     }
     if (exact) {
-        hipLaunchKernelGGL(k_csv_keep, dim3(lb), dim3(256), lds_cap + CSV_LDS_SLACK, st, text, len, (const unsigned long long*)nl, h_nl, (unsigned)n_lines,
+        hipLaunchKernelGGL(k_csv_keep, dim3(lb), dim3(256), lds_cap + CSV_LDS_SLACK + CSV_LDS_GENRE, st, text, len, (const unsigned long long*)nl, h_nl, (unsigned)n_lines,
                            L.n_cols, lds_cap, keep);
         scan_u32(keep, pos, n_lines, sums2, totals + 1, st);
-        hipLaunchKernelGGL(k_csv_parse<false>, dim3(lb), dim3(256), lds_cap + CSV_LDS_SLACK, st, L, text, len, (const unsigned long long*)nl, h_nl,
+        hipLaunchKernelGGL(k_csv_parse<false>, dim3(lb), dim3(256), lds_cap + CSV_LDS_SLACK + CSV_LDS_GENRE, st, L, text, len, (const unsigned long long*)nl, h_nl,
                            (unsigned)n_lines, (const unsigned*)keep, (const unsigned*)pos, (unsigned)max_rows, lds_cap, ids_dev, dense_dev, first_err, errs,
                            n_errs, drops);
         HIP_TRY(hipGetLastError());
