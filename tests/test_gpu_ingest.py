@@ -142,3 +142,30 @@ def test_predict_csv_equals_predict_on_parsed_features(torch, tmp_path):
         assert got.shape == want.shape == (512, 1)
         np.testing.assert_array_equal(got, want)
         np.testing.assert_array_equal(model.predict_csv(open(EXCERPT, "rb").read(), max_rows=17), want[:17])
+
+
+def test_short_decimal_fast_path_every_shape(torch):
+    """The branch-free parser for fields of at most 8 characters against strtod + (float) / (long long) on the host: every
+    placement of the sign and the dot, leading / trailing zeros, 1 .. 8 characters, random digits -- as a dense column (float
+    bits) and as an identity column (truncation)."""
+    rng = np.random.default_rng(77)
+    vals = [".5", "5.", "-0", "+0", "0", "00000000", "99999999", "-9999999", "+1234.56", "-1234.56", "1234.567", ".0000001", "0.000001",
+            "1000000.", "-.5", "+.5", "7", "-7", "0012.300", "9.999999", "4.", "000.000"]
+    for _ in range(20000):
+        n = int(rng.integers(1, 9))
+        sign = ["", "-", "+"][int(rng.integers(0, 3))] if n > 1 else ""
+        body = n - len(sign)
+        digits = "".join(rng.choice(list("0123456789"), size=body))
+        if body >= 2 and rng.random() < 0.6:
+            d = int(rng.integers(0, body))
+            digits = digits[:d] + "." + digits[d + 1:]
+        if digits == ".":
+            digits = "1"
+        vals.append(sign + digits)
+    text = "x,movieId\n" + "".join("%s,%d\n" % (v, i % 1000) for i, v in enumerate(vals))
+    cols = [S.IdColumn("movieId", "id", 1001)]
+    _same(text, cols, ["x"])
+    # as identity ids: values in [0, 2^31) only (negative ones are range errors on both sides)
+    pos = [v for v in vals if not v.startswith("-") or float(v) == 0.0]
+    text = "x,movieId\n" + "".join("%s,%d\n" % (v, i % 1000) for i, v in enumerate(pos))
+    _same(text, [S.IdColumn("x", "id", 2 ** 31 - 1), S.IdColumn("movieId", "id", 1001)], [])
