@@ -196,10 +196,15 @@ struct DinLds {
     static constexpr int hs = KP + 4;           // history-row stride (floats): 16-B aligned, (hs/4) odd
     static constexpr int as = HP + 4;           // alpha-row stride
     static constexpr int rows = 64;             // T <= 64, padded to whole 16-row groups
+    // 16 waves per workgroup (4 per SIMD): the tiles must leave room for the tables in 160 KB -- 56 rows each (T <= 56); the
+    // last 16-row group then reads 8 rows of the NEXT wave's tile (finite values, their attention weight is forced to 0), the
+    // last wave's into a zeroed slack
+    static constexpr int trows = WPB == 16 ? 56 : 64;
     static constexpr int alpha_floats = 2 * rows * as;      // two coefficient tables (see the epilogue)
     static constexpr int w_floats = 2 * HC * KC * 256;       // W12 / W4 fragments in lane order: [w12 | w4][nb][c][lane] float4
-    static constexpr int wave_floats = rows * hs;            // Hs tile
-    static constexpr size_t bytes = sizeof(float) * (alpha_floats + w_floats + WPB * wave_floats);
+    static constexpr int wave_floats = trows * hs;           // Hs tile
+    static constexpr int slack_floats = (rows - trows) * hs;
+    static constexpr size_t bytes = sizeof(float) * (alpha_floats + w_floats + WPB * wave_floats + slack_floats);
 };
 
 // WPB waves per workgroup: 4 (two workgroups per CU, 2 waves per SIMD: round 1) or 12 (ONE workgroup per CU, 3 waves per SIMD).
@@ -253,6 +258,12 @@ __global__ __launch_bounds__(WPB * 64, WPB / 4 == 1 ? 2 : WPB / 4) void k_din_at
 
     // ---- one-time: zero the wave tile (padding columns / rows stay zero for ever), stage alpha ----
     for (int i = lane; i < LD::wave_floats; i += 64) Hs[i] = 0.f;
+    if (LD::slack_floats > 0 && wave == WPB - 1)
+        for (int i = lane; i < LD::slack_floats; i += 64) Hs[LD::wave_floats + i] = 0.f;
+    // PF: the rows of sample n+1 are requested (into registers) while sample n is scored.  The 16-wave form cannot afford
+    // the 28 registers that keeps alive (128 per wave at 4 waves per SIMD): it requests a sample's rows when it starts on the
+    // sample and leaves the latency to the other three waves of its SIMD; ids are still fetched a sample ahead.
+    constexpr bool PF = WPB != 16;
     // PReLU(alpha) followed by the Dense(1) weight w2, as two coefficients per (slot t, unit n):
     //   w2 (max(u,0) + alpha min(u,0)) = ca u + cb |u|,  ca = w2 (1 + alpha) / 2,  cb = w2 (1 - alpha) / 2
     // (max(u,0) = (u + |u|)/2, min(u,0) = (u - |u|)/2): two FMAs per element, |u| is a free source modifier
@@ -348,11 +359,18 @@ __global__ __launch_bounds__(WPB * 64, WPB / 4 == 1 ? 2 : WPB / 4) void k_din_at
     };
     if (s < Btot) {
         ld_ids(pbi, psl);
-        issue_rows();
-        DIN_ADVANCE(pbi, psl);
-        if (s + stride < Btot) ld_ids(pbi, psl);
+        if constexpr (PF) {
+            issue_rows();
+            DIN_ADVANCE(pbi, psl);
+            if (s + stride < Btot) ld_ids(pbi, psl);
+        }
     }
     for (; s < Btot; s += stride) {
+        if constexpr (!PF) {
+            issue_rows();                                         // this sample's rows; then the next sample's ids
+            DIN_ADVANCE(pbi, psl);
+            if (s + stride < Btot) ld_ids(pbi, psl);
+        }
         // ---- hand-off: this sample's rows -> LDS tile, candidate-side operands -> registers ----
 #pragma unroll
         for (int p = 0; p < NP; ++p)
@@ -375,7 +393,7 @@ __global__ __launch_bounds__(WPB * 64, WPB / 4 == 1 ? 2 : WPB / 4) void k_din_at
         }
 #pragma unroll
         for (int nb = 0; nb < HC; ++nb) acc_init[nb] = vcn[nb];
-        if (s + stride < Btot) {                                 // next sample's rows fly under this sample's MFMAs
+        if (PF && s + stride < Btot) {                           // next sample's rows fly under this sample's MFMAs
             issue_rows();
             DIN_ADVANCE(pbi, psl);
             if (s + 2 * stride < Btot) ld_ids(pbi, psl);
@@ -511,6 +529,7 @@ __global__ __launch_bounds__(WPB * 64, WPB / 4 == 1 ? 2 : WPB / 4) void k_din_at
                 // exact) -- round 1's withdrawn multi-batch kernel showed the same picture.  One statement that owns wgt and
                 // carries the wait state closes it wherever the scheduler puts the pooling.
                 if constexpr (HALF) asm volatile("s_nop 0" : "+v"(wgt));
+                if constexpr (LD::trows < LD::rows) wgt = t < T ? wgt : 0.f;       // rows of the neighbouring tile: no weight
                 if constexpr (!MB) { if (q == 0 && att && t < T) att[(size_t)s * T + t] = wgt; }
                 // weighted sum pooling (DIN.py:152-158): rows past T are all-zero in the tile, so they add nothing
                 if constexpr (HALF) {

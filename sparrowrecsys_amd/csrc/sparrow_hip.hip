@@ -1460,9 +1460,12 @@ struct DinVariant {
 #define DIN_MANY_12(KC, HC, NP, HALF) reinterpret_cast<const void*>(&k_din_attn<KC, HC, NP, HALF, 12, true>), &din_launch_many<KC, HC, NP, HALF, 12>
 #define DIN_VARIANT1(KC, HC, NP, HALF, WPB) {KC, HC, NP, HALF, WPB, reinterpret_cast<const void*>(&k_din_attn<KC, HC, NP, HALF, WPB, false>), DinLds<KC, HC, WPB>::bytes, &din_launch<KC, HC, NP, HALF, WPB>, nullptr, nullptr}
 #define DIN_VARIANT12(KC, HC, NP) {KC, HC, NP, true, 12, reinterpret_cast<const void*>(&k_din_attn<KC, HC, NP, true, 12, false>), DinLds<KC, HC, 12>::bytes, &din_launch<KC, HC, NP, true, 12>, DIN_MANY_12(KC, HC, NP, true)}
+#define DIN_VARIANT16(KC, HC, NP) {KC, HC, NP, true, 16, reinterpret_cast<const void*>(&k_din_attn<KC, HC, NP, true, 16, false>), DinLds<KC, HC, 16>::bytes, &din_launch<KC, HC, NP, true, 16>, \
+                                   reinterpret_cast<const void*>(&k_din_attn<KC, HC, NP, true, 16, true>), &din_launch_many<KC, HC, NP, true, 16>}
 #define DIN_VARIANT(KC, HC, NP) DIN_VARIANT1(KC, HC, NP, true, 4), DIN_VARIANT1(KC, HC, NP, false, 4)
 const DinVariant kDinVariants[] = {     // first match wins: smallest sufficient pass count first; 12-wave forms before their 4-wave twins
     DIN_VARIANT12(2, 2, 2), DIN_VARIANT(2, 2, 2), DIN_VARIANT12(2, 2, 4), DIN_VARIANT(2, 2, 4),
+    DIN_VARIANT16(2, 2, 7),             // (chosen only with SPRK_DIN_WPB=16: T <= 56, 4 waves per SIMD, no row prefetch)
     DIN_VARIANT12(2, 2, 7),    // BASELINE config 3: emb_dim 32, 50 history slots, attention hidden 32
     DIN_VARIANT(2, 2, 7),
     DIN_VARIANT12(2, 2, 8), DIN_VARIANT(2, 2, 8),
@@ -2398,12 +2401,13 @@ int sprk_finalize(sprk_handle h) {
             (size_t)s.vocab * s.row_stride * sizeof(float) < ((size_t)4 << 30)) {   // 32-bit element offsets
             const char* hm = getenv("SPRK_DIN_HALF");            // A/B switch: "0" = f32 MFMA
             bool want_half = !(hm && hm[0] == '0');
-            const char* wm = getenv("SPRK_DIN_WPB");             // A/B switch: "4" = round 1's four-wave workgroups
-            const bool allow12 = !(wm && wm[0] == '4');
+            const char* wm = getenv("SPRK_DIN_WPB");             // A/B switch: at most this many waves per workgroup ("4" = round 1's)
+            const int max_wpb = wm ? atoi(wm) : 12;
             for (size_t v = 0; v < sizeof(kDinVariants) / sizeof(kDinVariants[0]); ++v) {
                 const DinVariant& dv = kDinVariants[v];
                 if (dv.half != want_half) continue;
-                if (dv.wpb == 12 && !allow12) continue;
+                if (dv.wpb > 4 && dv.wpb > max_wpb) continue;
+                if (dv.wpb == 16 && s.T > 56) continue;
                 if (dv.kc != kc || dv.hc != hc || dv.np * (64 / (dv.half ? kc * 4 : s.row_stride / 4)) < s.T) continue;
                 const int KP = kc * 16;
                 if (!h->din_w12) {
@@ -2466,7 +2470,7 @@ int sprk_finalize(sprk_handle h) {
                 if (dv.fn_many) HIP_TRY(hipFuncSetAttribute(dv.fn_many, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dv.lds_bytes));
                 int wgs = (int)(160 * 1024 / dv.lds_bytes);
                 if (wgs > 2) wgs = 2;                                // launch bounds: 2 waves per SIMD
-                if (dv.wpb == 12) wgs = 1;                           // ... or one 12-wave workgroup: 3 waves per SIMD
+                if (dv.wpb >= 12) wgs = 1;                           // ... or one 12- / 16-wave workgroup: 3 / 4 waves per SIMD
                 if (wgs < 1) wgs = 1;
                 h->din_attn_grid_cap = h->num_cus * wgs;
                 h->din_wpb = dv.wpb;
