@@ -312,7 +312,8 @@ int sprk_pack_csv_mt(const char* text, size_t len, const sprk_csv_col* id_cols, 
  * an empty string "").  It never guesses: a numeric field outside that shape ("inf", hex, blanks, 16+ digits, text, an escaped
  * quote) fails with SPRK_EKIND and names the first such row; ids outside
  * their bucket range fail with SPRK_ERANGE like the host tokenizer (first bad row in file order).  Synchronises `stream`
- * (the row count comes back to the host). */
+ * (the row count comes back to the host).  Device scratch (8 bytes per line + 4 per 4-KB chunk of text) is allocated on first
+ * use, grows to the largest text seen and is kept for the calling thread's lifetime. */
 int sprk_pack_csv_device(const char* text_dev, size_t len, const sprk_csv_col* id_cols, int32_t n_id,
                          const char* const* dense_names, int32_t n_dense, int32_t max_rows,
                          int32_t* ids_dev, float* dense_dev, int32_t* rows_out, void* stream);

@@ -158,6 +158,12 @@ class PeerScoreComm:
             self.lib.sprk_peer_destroy(self.handle)
             self.handle = None
 
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
 
 def shard_bounds(n_rows: int, rank: int, world: int) -> Tuple[int, int]:
     """Rows [lo, hi) owned by ``rank``: contiguous, sizes differ by at most one, earlier ranks larger."""
