@@ -25,7 +25,10 @@ __device__ __forceinline__ float rows4_max(float v) {
 // (x0..x3 | y0..y3) * scale -> packed hi halfs and lo halfs, 2 VALU per value (v_fma_mixlo/hi_f16: f16(x*scale) and
 // f16(x*scale - hi) with the f16 source taken straight from the packed register)
 __device__ __forceinline__ void dyn_split8(f32x4 x, f32x4 y, float scale, din_f16x8& hi, din_f16x8& lo) {
-    unsigned h[4] = {0u, 0u, 0u, 0u}, l[4] = {0u, 0u, 0u, 0u};
+    // (mixlo writes the low half of its destination and keeps the high half, mixhi the other way round: the even element
+    // of a pair goes first as a plain output -- whatever sits in the high half is replaced by the odd element next -- which
+    // spares the eight v_mov 0 an initialised read-modify-write operand costs)
+    unsigned h[4], l[4];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         const float v = e < 4 ? x[e] : y[e - 4];
@@ -33,8 +36,8 @@ __device__ __forceinline__ void dyn_split8(f32x4 x, f32x4 y, float scale, din_f1
             asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h[e >> 1]) : "v"(v), "v"(scale));
             asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l[e >> 1]) : "v"(v), "v"(scale), "v"(h[e >> 1]));
         } else {
-            asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "+v"(h[e >> 1]) : "v"(v), "v"(scale));
-            asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "+v"(l[e >> 1]) : "v"(v), "v"(scale), "v"(h[e >> 1]));
+            asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h[e >> 1]) : "v"(v), "v"(scale));
+            asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=&v"(l[e >> 1]) : "v"(v), "v"(scale), "v"(h[e >> 1]));
         }
     }
     // HAZARD GUARD.  The eight dwords above were written by VALU instructions INSIDE asm statements, which hipcc's hazard
