@@ -169,3 +169,23 @@ def test_short_decimal_fast_path_every_shape(torch):
     pos = [v for v in vals if not v.startswith("-") or float(v) == 0.0]
     text = "x,movieId\n" + "".join("%s,%d\n" % (v, i % 1000) for i, v in enumerate(pos))
     _same(text, [S.IdColumn("x", "id", 2 ** 31 - 1), S.IdColumn("movieId", "id", 1001)], [])
+
+
+def test_lines_too_long_for_the_lds_piece_are_read_in_place(torch):
+    """A workgroup stages its 256 lines in LDS when they fit (at most 48 KB); a file with a few enormous free-text fields
+    takes the in-place reader for those workgroups -- same bits -- and max_rows = 0 / a header-only text give no rows."""
+    cols = M.EmbeddingMLP(seed=1).id_columns
+    hdr = HEADER + ["comment"]
+    rng = np.random.default_rng(9)
+    lines = [",".join(hdr)]
+    for i in range(1500):
+        row = [str(int(rng.integers(1, 1000))), str(int(rng.integers(1, 30000))), "3.5", "1", "1999", "Drama", "", "War",
+               str(int(rng.integers(0, 5000))), "%.2f" % rng.random(), "0.5", str(int(rng.integers(1, 1000))), "12", "3.25", "1.5",
+               "Comedy", "", "", "", "IMAX"]
+        junk = "x" * (70000 if i % 400 == 7 else int(rng.integers(0, 300)))          # a 70 KB field: beyond any LDS piece
+        lines.append(",".join(row + [junk]))
+    text = "\n".join(lines) + "\n"
+    ids, dense = _same(text, cols)
+    assert ids.shape[0] == 1500
+    _same(text, cols, max_rows=0)
+    _same(text, cols, max_rows=9)
