@@ -86,3 +86,30 @@ def pack_csv_device(text, id_columns: Sequence[IdColumn], numeric_keys: Sequence
     L.check(lib.sprk_pack_csv_device(C.c_void_p(buf.data_ptr()), C.c_size_t(n), cols, n_id, names, n_dense, int(max_rows),
                                      C.c_void_p(ids.data_ptr()), C.c_void_p(dense.data_ptr()), C.byref(rows), C.c_void_p(stream)))
     return ids[:rows.value], dense[:rows.value]
+
+
+def read_csv_to_device(path: str):
+    """The file's bytes as a ``torch.uint8`` device tensor (16 spare bytes behind the text): read straight into pinned host
+    memory (one copy out of the page cache) and sent with one asynchronous host -> device copy -- what ``pack_csv_device``
+    wants as its input; ``(buffer, n_bytes)``."""
+    import os
+
+    import numpy as np
+    import torch
+    n = os.path.getsize(path)
+    host = torch.empty(n + 16, dtype=torch.uint8).pin_memory()
+    view = host.numpy()
+    with open(path, "rb", buffering=0) as f:
+        got = 0
+        while got < n:
+            k = f.readinto(memoryview(view)[got:n])
+            if not k:
+                break
+            got += k
+    if got != n:
+        raise IOError("%s: read %d of %d bytes" % (path, got, n))
+    view[n:] = 0
+    dev = torch.empty(n + 16, dtype=torch.uint8, device="cuda")
+    dev.copy_(host, non_blocking=True)
+    torch.cuda.current_stream().synchronize()                     # the pinned buffer may be released when this returns
+    return dev, n

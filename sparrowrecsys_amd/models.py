@@ -395,10 +395,10 @@ class CTRModel:
         ``batch_size``-row slices of them -> ``ndarray [N, 1] float32``.  Same scores as ``predict(read_samples_csv(path))``."""
         import torch
 
-        from .ingest import pack_csv_device
+        from .ingest import pack_csv_device, read_csv_to_device
         if isinstance(source, str):
-            with open(source, "rb") as f:
-                source = f.read()
+            buf, nbytes = read_csv_to_device(source)              # pinned read + one asynchronous copy of the raw text
+            source = buf[:nbytes]
         ids, dense = pack_csv_device(source, self.id_columns, list(self.numeric_keys), max_rows=max_rows)
         n = int(ids.shape[0])
         if n == 0:
