@@ -104,17 +104,35 @@ def to_float_column(col, key: str = "") -> np.ndarray:
     return out
 
 
+def _genre_of(v) -> int:
+    if isinstance(v, np.bytes_):
+        v = bytes(v)
+    elif isinstance(v, np.str_):
+        v = str(v)
+    return -1 if _is_missing(v) else _GENRE_INDEX.get(v, -1)
+
+
 def to_genre_index(col) -> np.ndarray:
     a = _as_list(col)
     if a.dtype.kind in "iu":           # already indices
         return a.astype(np.int64)
+    if len(a) >= (1 << 18):
+        # a column of strings holds a handful of distinct values: factorise (hash based, C speed), resolve each distinct
+        # value once, look the rest up -- 0.5 s -> 0.1 s per million rows against the per-element loop (only for columns long
+        # enough to repay importing pandas)
+        try:
+            import pandas as pd
+            codes, uniques = pd.factorize(a, use_na_sentinel=True)      # None / NaN -> code -1
+            lut = np.fromiter((_genre_of(u) for u in uniques), dtype=np.int64, count=len(uniques))
+            out = np.full(len(a), -1, dtype=np.int64)
+            ok = codes >= 0
+            out[ok] = lut[codes[ok]]
+            return out
+        except Exception:               # (unhashable elements, pandas missing: the loop decides)
+            pass
     out = np.empty(len(a), dtype=np.int64)
     for i, v in enumerate(a):
-        if isinstance(v, np.bytes_):
-            v = bytes(v)
-        elif isinstance(v, np.str_):
-            v = str(v)
-        out[i] = -1 if _is_missing(v) else _GENRE_INDEX.get(v, -1)
+        out[i] = _genre_of(v)
     return out
 
 

@@ -74,3 +74,13 @@ def test_iter_feature_batches(samples):
     assert [S.batch_size_of(b) for b in S.iter_feature_batches(ds)] == [12, 12]
     with pytest.raises(TypeError):
         list(S.iter_feature_batches([1, 2]))
+
+
+def test_genre_index_of_a_long_column_equals_the_per_element_rule():
+    """Columns of >= 2^18 strings are factorised first (one vocabulary lookup per DISTINCT value): same indices as the
+    per-element rule for str / bytes / numpy scalars / None / NaN / unknown strings."""
+    from sparrowrecsys_amd import schema as S
+    rng = np.random.default_rng(0)
+    vals = np.array(S.GENRE_VOCAB + ["", None, b"Drama", np.str_("War"), float("nan"), "NotAGenre", np.bytes_(b"IMAX")], dtype=object)
+    a = vals[rng.integers(0, len(vals), (1 << 18) + 17)]
+    np.testing.assert_array_equal(S.to_genre_index(a), np.array([S._genre_of(v) for v in a]))
