@@ -2154,6 +2154,7 @@ struct DinTailVariant {
 const DinTailVariant kDinTailVariants[] = {
     DIN_TAIL_VARIANT(8, 4, 2),        // DIN.py:161-167 widths 128 / 64, emb_dim 17..32 (BASELINE config 3)
     DIN_TAIL_VARIANT(8, 4, 1),        // ... emb_dim <= 16 (the reference's own emb_dim 10)
+    DIN_TAIL_VARIANT(4, 2, 2), DIN_TAIL_VARIANT(4, 2, 1),     // half-width tails (64 / 32)
 };
 
 // Recognise the DIN tail the first-Dense fold left behind (every embedding column folded, fc0 reading only the
