@@ -3583,7 +3583,8 @@ int sprk_peer_create(int32_t rank, int32_t world, size_t slot_floats, uint8_t ha
         if (forced && strcmp(forced, k.name) != 0) continue;
         void* p = nullptr;
         if (hipExtMallocWithFlags(&p, bytes, k.flag) != hipSuccess || !p) { (void)hipGetLastError(); continue; }
-        if (hipIpcGetMemHandle(&hd, p) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(p); continue; }
+        if (world == 1) memset(&hd, 0, sizeof(hd));               // a world of one exports nothing
+        else if (hipIpcGetMemHandle(&hd, p) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(p); continue; }
         c->base = p; c->mem_kind = k.name;
         break;
     }
