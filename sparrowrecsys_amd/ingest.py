@@ -63,7 +63,13 @@ def pack_csv_device(text, id_columns: Sequence[IdColumn], numeric_keys: Sequence
         text = text.encode("utf-8")
     if isinstance(text, (bytes, bytearray, memoryview)):
         n = len(text)
-        host = torch.frombuffer(bytearray(text), dtype=torch.uint8) if n else torch.empty(0, dtype=torch.uint8)
+        if n:
+            import warnings
+            with warnings.catch_warnings():                       # (a read-only view of the bytes: it is only copied from)
+                warnings.simplefilter("ignore")
+                host = torch.from_numpy(np.frombuffer(text, dtype=np.uint8))
+        else:
+            host = torch.empty(0, dtype=torch.uint8)
         buf = torch.empty(n + 16, dtype=torch.uint8, device="cuda")           # torch allocations are 256-byte aligned
         buf[:n].copy_(host, non_blocking=False)
     else:
