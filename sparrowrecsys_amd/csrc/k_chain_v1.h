@@ -52,6 +52,7 @@ struct V1Run {
     // narrow rows (emb_dim <= 16): ONE derived table for all fields, 128-byte rows {E[<=16] | w1 | 0..} -- an id's embedding row
     // and its first-order weight share a cache line (one fabric request per (sample, field) instead of two: PMC had the
     // kernel at 38.7 MB per 65 536 samples against 30.4 MB of algorithmic bytes), one SGPR base + 32-bit byte offsets
+    float e_scale, e_inv;                 // static split scale of the deep fields' rows and 1 / (e_scale * w0 scale); 0 = per sample
     const float* tab;                     // NULL: gather from table[] / w1[] (wide rows)
     unsigned rowbase[V1_MAX_FIELDS];      // first row of field f in tab
 };
@@ -274,14 +275,19 @@ __device__ __forceinline__ void v1_body(const V1Run& A, const int* __restrict__ 
 #pragma unroll
         for (int c = 0; c < 2 * PC; ++c) ec[c] = (c / PC == 0 || A.n_deep > 1) ? S.x[c / PC][c % PC] : zero;
         if constexpr (DYN) {
-            float mx = 0.f;
+            // the deep fields' rows come out of tables whose max |E| is known at finalize: ONE static power-of-two scale puts it
+            // in [2^14, 2^15) (e_scale; refused by the dynamic-range guard for tables with outlier rows) and spares the
+            // per-sample maximum, its cross-lane reduction and the scale arithmetic; e_scale = 0: per-sample scale
+            float scale = A.e_scale, inv = A.e_inv;
+            if (A.e_scale == 0.f) {                               // wave-uniform
+                float mx = 0.f;
 #pragma unroll
-            for (int c = 0; c < 2 * PC; ++c)
+                for (int c = 0; c < 2 * PC; ++c)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) mx = fmaxf(mx, __builtin_fabsf(ec[c][j]));
-            mx = rows4_max(mx);
-            float scale, inv;
-            dyn_scale(mx, A.inv_w0_scale, scale, inv);
+                    for (int j = 0; j < 4; ++j) mx = fmaxf(mx, __builtin_fabsf(ec[c][j]));
+                mx = rows4_max(mx);
+                dyn_scale(mx, A.inv_w0_scale, scale, inv);
+            }
             int wfo = LD::off_w0e + (r * 4 + q) * 4;              // this lane's 16 bytes inside a 1-KB fragment
             asm volatile("" : "+v"(wfo));                         // (keeps the loop-invariant LDS reads inside the task loop)
             f32x4 acc[H0C];

@@ -1824,6 +1824,40 @@ int setup_deepfm_pairs(sprk_engine* h) {
         HIP_TRY(hipDeviceSynchronize());
         r.image = img;
     }
+    r.e_scale = 0.f; r.e_inv = 0.f;
+    {
+        // static scale for deep0's embedding block: max |E| over the deep fields' tables, unless a table has outlier rows
+        const char* es = getenv("SPRK_V1_STATIC_SCALE");        // A/B switch: "0" = per-sample scale
+        if (r.w0frag && !(es && es[0] == '0')) {
+            unsigned* d_max = nullptr;
+            HIP_TRY(hipMalloc((void**)&d_max, sizeof(unsigned)));
+            HIP_TRY(hipMemset(d_max, 0, sizeof(unsigned)));
+            bool wide = false;
+            for (int f = 0; f < r.n_deep; ++f) {
+                const long long rows = (long long)r.vocab[f] + 1;
+                long long blocks = (rows * Dp + 255) / 256;
+                if (blocks > 8192) blocks = 8192;
+                hipLaunchKernelGGL(k_v2_absmax, dim3((unsigned)blocks), dim3(256), 0, 0, r.table[f], rows, Dp, Dp, d_max);
+            }
+            HIP_TRY(hipGetLastError());
+            unsigned bits = 0;
+            HIP_TRY(hipMemcpy(&bits, d_max, sizeof(bits), hipMemcpyDeviceToHost));
+            (void)hipFree(d_max);
+            float mx;
+            memcpy(&mx, &bits, sizeof(mx));
+            for (int f = 0; f < r.n_deep && !wide && mx > 0.f && mx < 3.0e38f; ++f)
+                if (int rcw = wide_dynamic_range(r.table[f], (long long)r.vocab[f] + 1, Dp, Dp, mx, &wide)) return rcw;
+            if (mx > 0.f && mx < 3.0e38f && !wide) {
+                int e = 0;
+                (void)frexpf(mx, &e);
+                e = 15 - e;
+                if (e > 60) e = 60;
+                if (e < -60) e = -60;
+                r.e_scale = ldexpf(1.f, e);
+                r.e_inv = r.inv_w0_scale / r.e_scale;
+            }
+        }
+    }
     r.tab = nullptr;
     const char* rt = getenv("SPRK_V1_ROWTAB");                // A/B switch: "0" = gather from the uploaded tables
     if (PC == 1 && !(rt && rt[0] == '0')) {
