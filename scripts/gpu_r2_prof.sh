@@ -42,7 +42,7 @@ timeout 600 python scripts/bench_ingest.py --rows 20000000 --threads 1,128 --dev
 b bench_c2_gloo2 python bench.py --gpus 2 --backend gloo --steps 20 --warmup 5 --cpu-seconds 0 --hbm-resident 0 --min-region-ms 1 --regions 1 --settle-ms 0
 [ -x scripts/ubench/launch_floor ] || hipcc --offload-arch=gfx950 -O3 -std=c++17 scripts/ubench/launch_floor.hip -o scripts/ubench/launch_floor
 timeout 120 scripts/ubench/launch_floor > $O/ubench_launch_floor.log 2>&1; tail -20 $O/ubench_launch_floor.log
-timeout 900 python -m pytest tests -m gpu -q 2>&1 | tail -3 | tee $O/pytest_gpu.log
+timeout 900 python -m pytest tests -m gpu -q --durations=5 2>&1 | grep -v "^NCCL\|^RCCL\|^HIP\|^ROCm\|^Hostname\|^Librccl\|^$" | tail -12 | tee $O/pytest_gpu.log
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 | tee $O/smoke.log
 echo "=== rocprofv3 kernel trace"
 cd /tmp && export TMPDIR=/tmp
