@@ -47,6 +47,7 @@ HBM_PEAK = 8.0e12          # B/s, MI355X spec (MI355X_MICROARCH.md)
 MFMA_F32_PEAK = 157.3e12   # FLOP/s, fp32-input MFMA (= the fp32 vector rate on gfx950)
 MFMA_F16_PEAK = 2.5e15     # FLOP/s, dense f16/bf16 MFMA
 CONFIG4_ROWS = 27_000_000  # BASELINE configs[3]: "138 k-movie x 27 M-row synthetic table"
+HBM_RESIDENT_BATCHES = 32  # distinct id batches the roofline_hbm_resident loop cycles (row working set 805 MB >> 256 MB MALL)
 
 
 def _device_table(V, D, seed, std):
@@ -446,6 +447,9 @@ def main():
                          "sprk_peer_allgather_scores (direct peer writes into IPC-mapped receive buffers, no RCCL)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend (gloo: functional test of the N>1 path with ranks sharing one GPU)")
+    ap.add_argument("--side-workloads", default="din_c3,deepfm_c2",
+                    help="default workload at N=1: also measure these (short loops) and put them under `workloads` in the same JSON "
+                         "line -- BASELINE's metric names DeepFM and DIN; '' = none")
     ap.add_argument("--dry-run", action="store_true",
                     help="no GPU, no kernels: the launcher / process-group / grouped all-gather / timing plumbing with a stand-in "
                          "forward on CPU tensors (gloo).  For the CPU test of `--gpus N` self-spawning; the line says dry_run")
@@ -763,6 +767,8 @@ def main():
         hbm_rows = args.hbm_resident if args.hbm_resident >= 0 else 8388608
         if world == 1 and not dist_on and args.workload == "deepfm_v2_c2" and not args.big_vocab and hbm_rows > 0 and roof["kernel"] == "k_deepfm_v2_joint":
             line["roofline_hbm_resident"] = hbm_resident_block(args, B, hbm_rows, K)
+        if world == 1 and not dist_on and args.workload == "deepfm_v2_c2" and not args.big_vocab and args.side_workloads:
+            line["workloads"] = {w: side_workload(args, w) for w in args.side_workloads.split(",") if w}
         if world == 1 and args.cpu_seconds > 0:
             line["cpu_baseline"] = cpu_baseline(args.workload, model, feats, args.cpu_seconds)
         # RCCL prints a version banner through C stdio, which (stdout being a pipe) would otherwise be flushed at exit,
@@ -822,9 +828,12 @@ def mfma_block(kernel, m, B, seconds):
 
 def hbm_resident_block(args, B, rows, K):
     """The headline graph with identity tables far beyond the 256 MB Infinity Cache (3 x `rows` x 128 B of folded rows):
-    every row gather is a real HBM access.  Strict order, one batch per launch, non-recycled ids (8 distinct batches)."""
+    every row gather is a real HBM access.  Strict order, one batch per launch.  The loop cycles HBM_RESIDENT_BATCHES (32)
+    distinct id batches: 32 x 65 536 x 3 rows x 128 B = 805 MB of distinct row lines between two visits of the same row --
+    three times the Infinity Cache (round 2 cycled 8 = 201 MB, which FIT it and read 3.7 points high)."""
     import torch
-    model, feats, desc, roof = build_workload("deepfm_v2_c2", B, args.dist, seed_offset=7, big_vocab=rows, NB=8)
+    nb = max(1, int(os.environ.get("SPRK_BENCH_HBM_BATCHES", HBM_RESIDENT_BATCHES)))
+    model, feats, desc, roof = build_workload("deepfm_v2_c2", B, args.dist, seed_offset=7, big_vocab=rows, NB=nb)
     eng = model.engine
     batches = []
     for f in feats:
@@ -858,7 +867,114 @@ def hbm_resident_block(args, B, rows, K):
             "unit": "GB/s", "frac": ach * 1e9 / HBM_PEAK, "algorithmic_bytes_per_sample": roof["bytes_per_sample"], "avg_launch_us": s * 1e6,
             "frac_16_batches_per_launch": roof["bytes_per_sample"] * B / s16 / HBM_PEAK, "us_per_step_16_batches_per_launch": s16 * 1e6,
             "identity_table_rows": rows, "device_table_mb": table_mb, "oracle_check_max_abs_err": check,
+            "input_batches_cycled": len(batches),
+            "working_set_mb": len(batches) * B * 3 * 128 / 1e6,
+            "working_set_note": "distinct 128-byte row lines touched between two visits of the same batch (3 big fields); "
+                                "the Infinity Cache holds 256 MB",
             "timed_with": "HIP events, strict order, %d launches" % n}
+
+
+def _event_loop(run, n, loops=3):
+    """seconds per step of `run()` (= n steps), HIP events on the current stream, median of `loops`."""
+    import torch
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    tt = []
+    for _ in range(loops):
+        torch.cuda.synchronize()
+        ev0.record(); run(); ev1.record()
+        torch.cuda.synchronize()
+        tt.append(ev0.elapsed_time(ev1) * 1e-3 / n)
+    return float(np.median(tt))
+
+
+def side_workload(args, name):
+    """One more workload inside the default driver line: BASELINE.json's metric names DeepFM AND DIN,
+    and SURVEY 8(d) config 2 names the pair-dot graph next to the sum-of-squares one.  Same measurements as the headline,
+    shorter: `value` = batches scored back to back the way `sprk_forward_many` is meant to be used (several batches per
+    launch; DIN: attention and tail of alternating groups on two streams), `roofline` = strict stream order, ONE batch
+    per launch, HIP events (what rocprofv3's kernel trace reports for `--launch-batches 1 --overlap-streams 0`)."""
+    import torch
+    B = {"din_c3": 32768}.get(name, 65536)
+    NB = 16
+    model, feats, desc, roof = build_workload(name, B, args.dist, seed_offset=11, NB=NB)
+    eng = model.engine
+    din = name == "din_c3"
+    if not din:
+        roof["kernel"] = eng.kernel_name()
+    batches = []
+    for f in feats:
+        ids, dense = model.pack(f)
+        batches.append((torch.from_numpy(ids).cuda(), torch.from_numpy(dense).cuda()))
+    outs = [torch.empty(B, dtype=torch.float32, device="cuda") for _ in range(NB)]
+    lb = 16 if (roof["kernel"] in ("k_deepfm_pairs", "k_deepfm_v2_joint", "k_rows_chain") or (din and eng.kernel_name() == "k_din_tail")) else 1
+    eng.set_many_batches(lb)
+    fan = 2 if (din and lb > 1 and eng.set_many_streams(2)) else 0
+    ws = torch.empty(max(eng.many_workspace_bytes(B, max(fan, 1) * lb) // 4, 1), dtype=torch.float32, device="cuda")
+    # timed: >= 30 ms of back-to-back steps
+    n0 = 64
+    idx = [i % NB for i in range(n0)]
+    run0 = eng.prepare_many([batches[j][0] for j in idx], [batches[j][1] for j in idx], [outs[j] for j in idx], ws)
+    run0(); torch.cuda.synchronize()
+    t0 = _event_loop(run0, n0, loops=1)
+    n = int(min(20000, max(n0, math.ceil(0.03 / max(t0, 1e-9) / 16) * 16)))
+    idx = [i % NB for i in range(n)]
+    run = eng.prepare_many([batches[j][0] for j in idx], [batches[j][1] for j in idx], [outs[j] for j in idx], ws)
+    run(); torch.cuda.synchronize()
+    step_s = _event_loop(run, n)
+    eng.check_ids()
+    # strict: one batch per launch, stream order
+    n_strict = int(min(8000, max(200, math.ceil(0.02 / max(step_s, 1e-9)))))
+    fwd_s = strict_loop(eng, batches, outs, ws, n_strict, lb, fan)
+    # oracle check through the same multi-batch call
+    check = None
+    if not args.no_check:
+        m = min(NB, max(lb, 2))
+        chk = [torch.full((B,), -1.0, dtype=torch.float32, device="cuda") for _ in range(m)]
+        eng.forward_many([batches[j][0] for j in range(m)], [batches[j][1] for j in range(m)], chk, ws)
+        torch.cuda.synchronize()
+        nr = min(1024, B)
+        check = 0.0
+        for j in sorted({0, m - 1}):
+            for sl in (slice(0, nr), slice(B - nr, B)):
+                ref = oracle_forward(name, model, {k: v[sl] for k, v in feats[j].items()})[:, 0]
+                check = max(check, float(np.abs(chk[j][sl].cpu().numpy() - ref).max()))
+        if not check <= 1e-4:
+            raise SystemExit("bench (%s) outputs differ from the oracle: max|err| = %g" % (name, check))
+    blk = {"workload": "%s: %s" % (name, desc), "batch": B, "value": B / step_s, "unit": "samples/s", "ms_per_step": step_s * 1e3,
+           "batches_per_launch": lb, "launch_overlap_streams": fan, "steps_timed": n, "input_batches_cycled": NB,
+           "value_one_batch_per_launch": B / fwd_s, "kernel": eng.kernel_name(), "oracle_check_max_abs_err": check,
+           "device_table_mb": eng.table_bytes() / 1e6}
+    if din:
+        pooled = torch.empty((B, eng.n_aux), dtype=torch.float32, device="cuda")
+        n_att = 400
+
+        def att():
+            for i in range(n_att):
+                eng.din_pool(batches[i % NB][0], pooled)
+        att(); torch.cuda.synchronize()
+        din_s = _event_loop(att, n_att)
+        ach = roof["bytes_per_sample"] * B / din_s / 1e9
+        blk["roofline"] = {"bound": "hbm", "kernel": "k_din_attn (one batch of %d rows per launch)" % B, "achieved": ach, "peak": HBM_PEAK / 1e9,
+                           "unit": "GB/s", "frac": ach * 1e9 / HBM_PEAK, "algorithmic_bytes_per_sample": roof["bytes_per_sample"],
+                           "avg_launch_us": din_s * 1e6, "step_us_all_kernels_strict": fwd_s * 1e6,
+                           "reference_flops_per_sample": roof["flops_per_sample"],
+                           "reference_equivalent_TFLOPs": roof["flops_per_sample"] * B / din_s / 1e12,
+                           "timed_with": "HIP events, attention-only loop, strict order, %d launches" % n_att}
+        blk["roofline_mfma"] = mfma_block("k_din_attn", mfma_issued("k_din_attn", roof["flops_per_sample"]), B, din_s)
+        if eng.kernel_name() == "k_din_tail":
+            blk["roofline_mfma_tail"] = mfma_block("k_din_tail", mfma_issued("k_din_tail", roof["tail_reference_flops"]), B,
+                                                   max(fwd_s - din_s, 1e-9))
+    else:
+        ach = roof["bytes_per_sample"] * B / fwd_s / 1e9
+        blk["roofline"] = {"bound": "hbm", "kernel": roof["kernel"] + " (one batch of %d rows per launch)" % B, "achieved": ach,
+                           "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": ach * 1e9 / HBM_PEAK,
+                           "algorithmic_bytes_per_sample": roof["bytes_per_sample"], "avg_launch_us": fwd_s * 1e6,
+                           "timed_with": "HIP events, strict order, %d launches" % n_strict}
+        mi = mfma_issued(roof["kernel"], roof.get("mfma_reference_flops"))
+        if mi:
+            blk["roofline_mfma"] = mfma_block(roof["kernel"], mi, B, fwd_s)
+    eng.close()
+    return blk
 
 
 def dry_run(args, rank, world):

@@ -399,16 +399,22 @@ def deepfm_forward(features: Dict, w: Dict[str, np.ndarray], dtype=np.float32,
     second-order = hand-picked pairwise Dot(axes=1); deep = DenseFeatures(numerics + movieId/
     userId embeddings) -> Dense(64, relu) x2; concatenate([first_order, dots..., deep]) ->
     Dense(1, sigmoid).  ``literal_one_hot`` materialises the [B, 31040] one-hot exactly as the
-    reference does (small B only) instead of gathering the kernel rows."""
+    reference does (small B only) instead of gathering the kernel rows.
+
+    Two tables per deep key: ``DenseFeatures([movie_emb_col])`` (DeepFM.py:91, FM dots) and
+    ``DenseFeatures(deep_feature_columns)`` (DeepFM.py:106, MLP) are two layers, and every DenseFeatures layer
+    creates its columns' variables itself (TF feature_column_v2.py _StateManagerImpl.create_variable), so the deep part
+    reads ``deep_emb/<key>``; a weight dict without that key means tied tables (``emb/<key>`` for both)."""
     ids = _field_ids(features, fields)
     emb = {k: embedding_lookup(w["emb/" + k].astype(dtype), ids[k]) for k, _, _ in fields}
+    demb = {k: (embedding_lookup(w["deep_emb/" + k].astype(dtype), ids[k]) if "deep_emb/" + k in w else emb[k]) for k in deep_emb}
     offs = first_order_offsets(fields)
     n_fo = offs["__total__"]
     hk = w["head/kernel"].astype(dtype)
     # deep part                                                            DeepFM.py:106-108
     blocks = _numeric_blocks(features, dtype)
     for k in deep_emb:
-        blocks[k + "_embedding"] = emb[k]
+        blocks[k + "_embedding"] = demb[k]
     x, _ = dense_features(blocks)
     i = 0
     while "deep%d/kernel" % i in w:

@@ -3283,10 +3283,13 @@ namespace {
 struct DevScratch {
     void* p = nullptr;
     size_t cap = 0;
+    int dev = -1;                         // the device `p` lives on: a thread that switches devices gets a new scratch there
     int ensure(size_t bytes) {
-        if (bytes <= cap) return SPRK_OK;
-        if (p) (void)hipFree(p);
-        p = nullptr; cap = 0;
+        int cur = -1;
+        if (hipGetDevice(&cur) != hipSuccess) { (void)hipGetLastError(); return fail(SPRK_EHIP, "hipGetDevice"); }
+        if (cur == dev && bytes <= cap) return SPRK_OK;
+        if (p) (void)hipFree(p);          // hipFree takes a pointer of any device
+        p = nullptr; cap = 0; dev = cur;
         const size_t want = bytes + bytes / 4 + 4096;
         if (hipMalloc(&p, want) != hipSuccess) { (void)hipGetLastError(); p = nullptr; return fail(SPRK_EHIP, "device scratch of %zu bytes for the CSV tokenizer", want); }
         cap = want;

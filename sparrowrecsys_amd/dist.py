@@ -189,6 +189,8 @@ class RowShardedPredictor:
         self._bufs = {}                      # (rows, dtype, device) -> (slot, gathered): no allocation per request
 
     def predict(self, ids, dense):
+        """Scores of all ``n`` rows, in row order, on every rank.  The result is a FRESH tensor (the staging and receive
+        buffers are reused across calls; the copy is 4 bytes per row)."""
         import torch
         import torch.distributed as dist
         n = int(ids.shape[0])
@@ -208,14 +210,14 @@ class RowShardedPredictor:
         if isinstance(self.comm, PeerScoreComm) and local.is_cuda:
             recv = self.comm.all_gather(slot)                    # [world, comm.slot] view of the receive buffer
             if n % self.world == 0 and recv.shape[1] == per:
-                return recv.reshape(-1)
+                return recv.reshape(-1).clone()                  # peers overwrite the receive buffer two exchanges later
             return torch.cat([recv[r, :shard_bounds(n, r, self.world)[1] - shard_bounds(n, r, self.world)[0]] for r in range(self.world)])
         if self.comm is not None and local.is_cuda:
             self.comm.all_gather(slot, gathered)
         else:
             dist.all_gather_into_tensor(gathered, slot, group=self.group)
         if n % self.world == 0:
-            return gathered
+            return gathered.clone()                              # `gathered` is reused by the next predict() of the same size
         pieces = []
         for r in range(self.world):
             rlo, rhi = shard_bounds(n, r, self.world)
@@ -242,7 +244,8 @@ class GroupedScoreGather:
     ([world, group*B]) on a side stream (CUDA) while the compute stream goes on with the other slot;
     ``flush()`` exchanges a partial last group and waits for everything.  Completed groups are
     handed to ``sink(group_index, gathered_view, n_batches)`` if given (views are only valid until the
-    slot is reused two groups later)."""
+    slot is reused two groups later).  With a ``PeerScoreComm`` and NO sink the groups stay in the communicator's receive
+    buffer and ``gathered`` is not filled."""
 
     def __init__(self, batch_rows: int, group: int, device, dtype=None, pg=None, sink: Optional[Callable] = None,
                  comm: Optional["ScoreComm"] = None):
@@ -264,7 +267,6 @@ class GroupedScoreGather:
         self.slot, self.fill, self.groups_done, self.collectives = 0, 0, 0, 0
         self._pending = [None, None]          # (group_index, n_batches) waiting for the sink
         self._views = [None, None]            # cached per-slot output views (group_outs)
-        self._recv = [None, None]             # PeerScoreComm: the receive-buffer view a slot's exchange landed in
         if isinstance(comm, PeerScoreComm) and comm.slot != self.G * self.B:
             raise ValueError("PeerScoreComm slot of %d floats != group * batch_rows = %d" % (comm.slot, self.G * self.B))
 
@@ -302,8 +304,7 @@ class GroupedScoreGather:
             gi, nb = self._pending[slot]
             if self.cuda and self.done[slot] is not None:
                 self.done[slot].synchronize()
-            got = self._recv[slot] if self._recv[slot] is not None else self.gathered[slot]
-            self.sink(gi, got.view(self.world, self.G, self.B)[:, :nb], nb)
+            self.sink(gi, self.gathered[slot].view(self.world, self.G, self.B)[:, :nb], nb)
         self._pending[slot] = None
 
     def commit(self):
@@ -329,7 +330,14 @@ class GroupedScoreGather:
             self.comm_stream.wait_event(ready)
             with torch.cuda.stream(self.comm_stream):
                 if isinstance(self.comm, PeerScoreComm):
-                    self._recv[slot] = self.comm.all_gather(src, self.comm_stream.cuda_stream)   # two parities = the ring's two slots
+                    recv = self.comm.all_gather(src, self.comm_stream.cuda_stream)   # two parities = the ring's two slots
+                    if self.sink is not None:
+                        # The receive buffer is only protected against peers for readers enqueued on the exchange stream
+                        # BEFORE this rank launches its next exchange (k_peer_gather.h): a sink running on the host after
+                        # commit() of the next group could see a peer's exchange e + 2 land in it.  So the group is copied
+                        # out here, on the exchange stream, ahead of `done` -- the sink reads `gathered[slot]`, which only
+                        # this rank writes.  Without a sink nobody reads the group and the copy is skipped.
+                        self.gathered[slot].copy_(recv[:, :self.G * self.B])
                 elif self.comm is not None:
                     self.comm.all_gather(src, dst, self.comm_stream.cuda_stream)
                 else:

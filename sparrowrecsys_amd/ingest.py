@@ -70,7 +70,7 @@ def pack_csv_device(text, id_columns: Sequence[IdColumn], numeric_keys: Sequence
                 host = torch.from_numpy(np.frombuffer(text, dtype=np.uint8))
         else:
             host = torch.empty(0, dtype=torch.uint8)
-        buf = torch.empty(n + 16, dtype=torch.uint8, device="cuda")           # torch allocations are 256-byte aligned
+        buf = torch.empty(n + 16, dtype=torch.uint8, device=torch.device("cuda", torch.cuda.current_device()))   # (256-byte aligned)
         buf[:n].copy_(host, non_blocking=False)
     else:
         if text.dtype != torch.uint8 or not text.is_cuda or not text.is_contiguous() or text.data_ptr() % 16:
@@ -89,8 +89,10 @@ def pack_csv_device(text, id_columns: Sequence[IdColumn], numeric_keys: Sequence
     rows = C.c_int32(0)
     if stream is None:
         stream = torch.cuda.current_stream(buf.device).cuda_stream
-    L.check(lib.sprk_pack_csv_device(C.c_void_p(buf.data_ptr()), C.c_size_t(n), cols, n_id, names, n_dense, int(max_rows),
-                                     C.c_void_p(ids.data_ptr()), C.c_void_p(dense.data_ptr()), C.byref(rows), C.c_void_p(stream)))
+    # the library launches on (and allocates its scratch on) the CURRENT device: make that the text's device
+    with torch.cuda.device(buf.device):
+        L.check(lib.sprk_pack_csv_device(C.c_void_p(buf.data_ptr()), C.c_size_t(n), cols, n_id, names, n_dense, int(max_rows),
+                                         C.c_void_p(ids.data_ptr()), C.c_void_p(dense.data_ptr()), C.byref(rows), C.c_void_p(stream)))
     return ids[:rows.value], dense[:rows.value]
 
 
@@ -115,7 +117,7 @@ def read_csv_to_device(path: str):
     if got != n:
         raise IOError("%s: read %d of %d bytes" % (path, got, n))
     view[n:] = 0
-    dev = torch.empty(n + 16, dtype=torch.uint8, device="cuda")
+    dev = torch.empty(n + 16, dtype=torch.uint8, device=torch.device("cuda", torch.cuda.current_device()))
     dev.copy_(host, non_blocking=True)
     torch.cuda.current_stream().synchronize()                     # the pinned buffer may be released when this returns
     return dev, n

@@ -289,7 +289,7 @@ class CTRModel:
         rng = np.random.default_rng(seed)
         out = {}
         for name, shape in self.weight_shapes().items():
-            if name.startswith("emb/"):
+            if name.startswith("emb/") or name.startswith("deep_emb/"):
                 if name == "emb/movie":
                     out[name] = rng.uniform(-0.05, 0.05, size=shape).astype(np.float32)
                     if trained_like:
@@ -655,15 +655,23 @@ def first_order_offsets(fields) -> Dict[str, int]:
 
 class DeepFM(CTRModel):
     """DeepFM.py:54-115 (pairwise-dot FM).  ``fields`` / ``pairs`` / ``deep_emb`` default to the
-    reference's literals; other values give the generalised shape of BASELINE config 2."""
+    reference's literals; other values give the generalised shape of BASELINE config 2.
+
+    The deep part owns its OWN embedding tables (weights ``deep_emb/<key>``): the reference hands ``movie_emb_col`` /
+    ``user_emb_col`` to two ``DenseFeatures`` layers -- ``DenseFeatures([movie_emb_col])`` for the FM dots (DeepFM.py:91-92)
+    and ``DenseFeatures(deep_feature_columns)`` for the MLP (DeepFM.py:106) -- and a DenseFeatures layer creates the
+    variables of its columns itself (TF feature_column_v2.py ``_StateManagerImpl.create_variable`` ->
+    ``layer.add_weight``), so a trained reference model holds ``dense_features/movieId_embedding`` AND
+    ``dense_features_5/movieId_embedding``.  ``share_deep_tables=True`` ties them (one table per key, ``emb/<key>``)."""
     MODEL_KIND = L.MODEL_DEEPFM
     FORWARD_SYMBOL = "sprk_forward_deepfm"
     DEFAULT_PAIRS = [("movieId", "userId"), ("movieGenre1", "userGenre1"),
                      ("movieGenre1", "userId"), ("movieId", "userGenre1")]       # DeepFM.py:100-103,111-112
 
     def __init__(self, weights=None, seed=None, emb_dim=10, fields=None, pairs=None, deep_emb=("movieId", "userId"),
-                 hidden=(64, 64)):
+                 hidden=(64, 64), share_deep_tables=False):
         self.emb_dim = emb_dim
+        self.share_deep_tables = bool(share_deep_tables)
         self.fields = list(fields) if fields is not None else _default_fields()
         self.pairs = list(pairs) if pairs is not None else list(self.DEFAULT_PAIRS)
         self.deep_emb = list(deep_emb)
@@ -690,6 +698,9 @@ class DeepFM(CTRModel):
 
     def weight_shapes(self):
         s = {"emb/" + k: (v, self.emb_dim) for k, _, v in self.fields}
+        if not self.share_deep_tables:
+            vocab = {k: v for k, _, v in self.fields}
+            s.update({"deep_emb/" + k: (vocab[k], self.emb_dim) for k in self.deep_emb})
         _, fan = self._deep_rows()
         for i, h in enumerate(self.hidden):
             s["deep%d/kernel" % i] = (fan, h)
@@ -704,8 +715,11 @@ class DeepFM(CTRModel):
         vocab = {k: v for k, _, v in self.fields}
         offs, blocks = {}, {}
         for k in self.deep_emb:                                   # deep inputs first -> one contiguous slice
-            offs[k] = pb.seg_rows(k, pad_table(w["emb/" + k]), vocab[k], D)
-            blocks[k + "_embedding"] = (offs[k], D)
+            if self.share_deep_tables:
+                offs[k] = pb.seg_rows(k, pad_table(w["emb/" + k]), vocab[k], D)
+                blocks[k + "_embedding"] = (offs[k], D)
+            else:                                                 # the deep part's own table of this key (DeepFM.py:106)
+                blocks[k + "_embedding"] = (pb.seg_rows(k, pad_table(w["deep_emb/" + k]), vocab[k], D), D)
         num_off = pb.seg_numerics(len(self.numeric_keys))
         for j, k in enumerate(self.numeric_keys):
             blocks[k] = (num_off + j, 1)

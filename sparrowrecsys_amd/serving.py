@@ -42,7 +42,8 @@ def _columns_from_instances(instances: Sequence[Mapping], fast: bool = False) ->
     if fast and instances and isinstance(instances[0], dict):
         # the common request (the Jetty ranker's): every instance carries the same keys with scalar values -- one list
         # comprehension per key instead of a Python-level double loop (0.30 -> 0.04 ms for 800 instances); anything else
-        # (missing keys, the [x] spelling of a scalar) raises here or in _to_feature_arrays and takes the general path
+        # (missing keys, the [x] spelling of a scalar -- numeric or string) raises here or in _to_feature_arrays and takes
+        # the general path
         k0 = list(instances[0])
         try:
             return {k: [i[k] for i in instances] for k in k0}
@@ -71,6 +72,11 @@ def _to_feature_arrays(cols: Mapping[str, list], n: int) -> Dict[str, np.ndarray
         if len(v) != n:
             raise ValueError("feature %r has %d values for %d instances" % (k, len(v), n))
         if k.startswith(_STRING_PREFIXES):
+            # a string column takes scalars only: str() of a list never fails, so the TF-Serving "[x]" spelling would
+            # otherwise become the text "['Action']" -- out of vocabulary, a wrong score with HTTP 200.
+            # Raising here sends the fast path to the general one, which unwraps [x]; what is still a list there is a 400.
+            if any(isinstance(x, (list, dict, tuple)) for x in v):
+                raise ValueError("feature %r must be a list of scalar strings" % k)
             feats[k] = np.array(["" if x is None else str(x) for x in v], dtype=object)
         else:
             try:
@@ -198,7 +204,13 @@ class PredictServer:
             def _send_scores(self, key: str, scores):
                 # [[p], [p], ...] written directly: 9 significant digits reproduce a float32 exactly, and formatting 800 of
                 # them this way costs 0.2 ms against 0.84 ms for json.dumps of the nested list (shortest-repr of doubles)
-                body = ('{"%s": [[' % key + "], [".join(["%.9g" % v for v in np.asarray(scores, dtype=np.float32).tolist()]) + "]]}").encode("utf-8")
+                arr = np.asarray(scores, dtype=np.float32)
+                if not np.isfinite(arr).all():
+                    # "%.9g" would print nan / inf, which is not JSON; json.dumps spells them NaN / Infinity, what Python
+                    # and Java clients' lenient parsers accept (and what this shim sent before the fast formatter)
+                    self._send(200, {key: [[float(v)] for v in arr.tolist()]})
+                    return
+                body = ('{"%s": [[' % key + "], [".join(["%.9g" % v for v in arr.tolist()]) + "]]}").encode("utf-8")
                 self.send_response(200)
                 self.send_header("Content-Type", "application/json")
                 self.send_header("Content-Length", str(len(body)))

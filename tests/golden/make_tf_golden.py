@@ -1,0 +1,232 @@
+"""Golden vectors from the reference's OWN model-building source.
+
+    python tests/golden/make_tf_golden.py [--backend auto|tf|shim] [--reference /root/reference] [--models din,deepfm,...]
+
+For every model the UNTOUCHED lines of the reference script between ``test_dataset = get_dataset(...)`` and
+``model = tf.keras.Model(...)`` (DIN.py:29-169, DeepFM.py:29-115, DeepFM_v2.py:36-157, WideNDeep.py:29-108,
+NeuralCF.py:29-74, EmbeddingMLP.py:29-78) are read from ``--reference`` and ``exec``-uted with ``tf`` bound to
+
+  * ``tensorflow`` itself when ``import tensorflow`` works (``--backend tf``; needs ``tf.feature_column`` +
+    ``tf.keras.layers.DenseFeatures``, i.e. TF <= 2.15 or ``tf_keras``) -> tests/golden/refblock_tf_<model>.npz.  THIS is
+    the file that pins SURVEY 8(a) A7 / A8 / A10-A13 for good; it does not exist yet because TensorFlow cannot be
+    installed in the build container (no network), and the tests that consume it are named ``..._unpinned_...`` and
+    xfail loudly while it is absent;
+  * oracle/keras_shim.py otherwise (``--backend shim``): a numpy stand-in for the few ``tf.*`` objects the scripts
+    touch -> tests/golden/refblock_shim_<model>.npz (committed).  The graph is then wired by the reference's code, op
+    arithmetic by the shim's restatement of each TF object.
+
+Seeded weights (the model classes' ``init_weights`` in the reference's layout) are injected with ``layer.set_weights`` --
+addressed by Keras layer name (creation order: dense, dense_1, ..., p_re_lu, dense_features_5) and variable name, the
+same way on both backends -- and ``model.predict`` runs on the first 256 rows of the reference's testSamples.csv
+(tests/golden/samples_256.npz).  ``--backend tf`` additionally writes 64 ``sparse_cross_hashed`` buckets
+(refblock_tf_cross_hash.npz) and times nothing: bench.py's cpu_baseline leg owns the timing.
+"""
+import argparse
+import hashlib
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+SCRIPT_DIR = "TFRecModel/src/com/sparrowrecsys/offline/tensorflow"
+SEEDS = {"din": 31, "deepfm": 32, "deepfm_v2": 33, "wide_n_deep": 34, "neural_cf": 35, "embedding_mlp": 36}
+GENRE_KEYS = ["userGenre%d" % i for i in range(1, 6)] + ["movieGenre%d" % i for i in range(1, 4)]
+
+
+def _dense(layer, key):
+    return [(layer, "kernel", key + "/kernel"), (layer, "bias", key + "/bias")]
+
+
+# model -> (script, [(keras layer name, substring of the variable name, key in the repo's weight dict)])
+SPECS = {
+    "din": ("DIN.py",
+            [("dense_features_2", "userGenre1_embedding", "emb/userGenre1"), ("dense_features_2", "userId_embedding", "emb/userId"),
+             ("dense_features_3", "movieGenre1_embedding", "emb/movieGenre1"), ("embedding", "embeddings", "emb/movie")]
+            + _dense("dense", "att0") + [("p_re_lu", "alpha", "att_prelu/alpha")] + _dense("dense_1", "att1")
+            + _dense("dense_2", "fc0") + [("p_re_lu_1", "alpha", "fc0_prelu/alpha")]
+            + _dense("dense_3", "fc1") + [("p_re_lu_2", "alpha", "fc1_prelu/alpha")] + _dense("dense_4", "head")),
+    "deepfm": ("DeepFM.py",
+               [("dense_features", "movieId_embedding", "emb/movieId"), ("dense_features_1", "userId_embedding", "emb/userId"),
+                ("dense_features_2", "movieGenre1_embedding", "emb/movieGenre1"), ("dense_features_3", "userGenre1_embedding", "emb/userGenre1"),
+                ("dense_features_5", "movieId_embedding", "deep_emb/movieId"), ("dense_features_5", "userId_embedding", "deep_emb/userId")]
+               + _dense("dense", "deep0") + _dense("dense_1", "deep1") + _dense("dense_2", "head")),
+    "deepfm_v2": ("DeepFM_v2.py",
+                  _dense("dense", "fo_cat") + _dense("dense_1", "fo_num")
+                  + [("dense_features_2", "movieGenre1_embedding", "emb/movieGenre1"), ("dense_features_3", "movieId_embedding", "emb/movieId"),
+                     ("dense_features_4", "userGenre1_embedding", "emb/userGenre1"), ("dense_features_5", "userId_embedding", "emb/userId")]
+                  + _dense("dense_2", "proj/movieGenre1") + _dense("dense_3", "proj/movieId") + _dense("dense_4", "proj/userGenre1")
+                  + _dense("dense_5", "proj/userId") + _dense("dense_6", "proj/num")
+                  + _dense("dense_7", "deep0") + _dense("dense_8", "deep1") + _dense("dense_9", "head")),
+    "wide_n_deep": ("WideNDeep.py",
+                    [("dense_features", k + "_embedding", "emb/" + k) for k in GENRE_KEYS + ["movieId", "userId"]]
+                    + _dense("dense", "dense0") + _dense("dense_1", "dense1") + _dense("dense_2", "head")),
+    "neural_cf": ("NeuralCF.py",
+                  [("dense_features", "movieId_embedding", "emb/movieId"), ("dense_features_1", "userId_embedding", "emb/userId")]
+                  + _dense("dense", "dense0") + _dense("dense_1", "dense1") + _dense("dense_2", "head")),
+}
+
+
+def make_model(name):
+    from sparrowrecsys_amd import models as M
+    return {"din": lambda: M.DIN(seed=SEEDS[name]), "deepfm": lambda: M.DeepFM(seed=SEEDS[name]),
+            "deepfm_v2": lambda: M.DeepFMv2(seed=SEEDS[name]), "wide_n_deep": lambda: M.WideNDeep(seed=SEEDS[name]),
+            "neural_cf": lambda: M.NeuralCF(seed=SEEDS[name])}[name]()
+
+
+def weights_digest(w):
+    h = hashlib.sha256()
+    for k in sorted(w):
+        h.update(k.encode())
+        h.update(np.ascontiguousarray(w[k]).tobytes())
+    return h.hexdigest()
+
+
+def model_block(script_path):
+    """(source text of the model-building block, 'first-last' line numbers, sha256 of the whole script)."""
+    text = open(script_path).read()
+    lines = text.split("\n")
+    start = next(i for i, ln in enumerate(lines) if ln.startswith("test_dataset = get_dataset(")) + 1
+    # the last statement that binds `model` before model.compile: `model = tf.keras.Model(...)`, `model = neural_cf_model_1(...)`
+    # or the multi-line `model = tf.keras.Sequential([...])`
+    comp = next(i for i, ln in enumerate(lines) if ln.startswith("model.compile("))
+    end = comp
+    while end > start and (lines[end - 1].strip() == "" or lines[end - 1].lstrip().startswith("#")):
+        end -= 1
+    return "\n".join(lines[start:end]) + "\n", "%d-%d" % (start + 1, end), hashlib.sha256(text.encode()).hexdigest()
+
+
+def get_backend(which):
+    """-> (name, tf module, version string).  'auto': TensorFlow if importable AND it still has DenseFeatures."""
+    if which in ("auto", "tf"):
+        try:
+            import tensorflow as tf                                  # noqa: F401  (absent in the build container)
+            if not hasattr(tf, "feature_column") or not hasattr(tf.keras.layers, "DenseFeatures"):
+                try:
+                    import tf_keras                                  # Keras 2 for TF >= 2.16
+                    tf.keras = tf_keras
+                except ImportError:
+                    raise ImportError("this TensorFlow has no tf.keras.layers.DenseFeatures (needs TF <= 2.15 or tf_keras)")
+            tf.keras.backend.clear_session()
+            return "tf", tf, tf.__version__
+        except ImportError as e:
+            if which == "tf":
+                raise SystemExit("--backend tf: %s" % e)
+    from oracle import keras_shim
+    tf = keras_shim.build_module()
+    return "shim", tf, tf.__version__
+
+
+def build_reference_model(tf, backend, script_path):
+    if backend == "tf":
+        tf.keras.backend.clear_session()                             # layer names restart at dense, dense_features, ...
+    else:
+        from oracle import keras_shim
+        tf = keras_shim.build_module()
+    src, lines, sha = model_block(script_path)
+    ns = {"tf": tf, "__name__": "reference_block"}
+    exec(compile(src, script_path, "exec"), ns)                      # the reference's own lines, untouched
+    return ns["model"], lines, sha
+
+
+def inject(model, spec, weights):
+    """set_weights addressed by (layer name, variable-name substring); every variable of the model must be covered."""
+    by_layer = {}
+    for layer, sub, key in spec:
+        by_layer.setdefault(layer, []).append((sub, key))
+    covered = 0
+    for layer in model.layers:
+        vs = list(layer.weights)
+        if not vs:
+            continue
+        if layer.name not in by_layer:
+            raise SystemExit("layer %s has variables %s but no entry in the weight map" % (layer.name, [v.name for v in vs]))
+        vals = layer.get_weights()
+        for sub, key in by_layer[layer.name]:
+            hit = [i for i, v in enumerate(vs) if sub in v.name]
+            if len(hit) != 1:
+                raise SystemExit("layer %s: %d variables match %r among %s" % (layer.name, len(hit), sub, [v.name for v in vs]))
+            a = np.asarray(weights[key], dtype=np.float32)
+            if tuple(vals[hit[0]].shape) != tuple(a.shape):
+                raise SystemExit("layer %s / %s: variable shape %s, weight %r has %s" % (layer.name, sub, vals[hit[0]].shape, key, a.shape))
+            vals[hit[0]] = a
+            covered += 1
+        if len(by_layer[layer.name]) != len(vs):
+            raise SystemExit("layer %s: %d variables, %d mapped" % (layer.name, len(vs), len(by_layer[layer.name])))
+        layer.set_weights(vals)
+    if covered != len(spec):
+        raise SystemExit("weight map has %d entries, the model consumed %d" % (len(spec), covered))
+
+
+def feed(model, samples, backend):
+    """dict {input name: array} with the dtypes the script's own Input layers declare (make_csv_dataset: empty -> 0 / "")."""
+    if backend == "shim":
+        decl = {k: str(node.dtype) for k, node in model.inputs.items()}
+    else:
+        decl = {t.name.split(":")[0]: t.dtype.name for t in model.inputs}
+    out = {}
+    for k, dt in decl.items():
+        col = samples[k]
+        if dt.startswith("float"):
+            out[k] = np.array([float(x) if str(x) != "" else 0.0 for x in col], dtype=np.float32)
+        elif dt.startswith("int"):
+            out[k] = np.array([int(x) if str(x) != "" else 0 for x in col], dtype=np.int32)
+        else:
+            out[k] = np.array([str(x) for x in col], dtype=object)
+    return out
+
+
+def run_model(name, backend, tf, reference, samples):
+    script, spec = SPECS[name]
+    path = os.path.join(reference, SCRIPT_DIR, script)
+    model, lines, sha = build_reference_model(tf, backend, path)
+    m = make_model(name)
+    inject(model, spec, m.weights)
+    x = feed(model, samples, backend)
+    if backend == "tf":
+        x = {k: (tf.constant(v.tolist()) if v.dtype == object else v) for k, v in x.items()}
+        pred = np.asarray(model.predict(x, batch_size=len(samples["movieId"]), verbose=0), dtype=np.float32)
+    else:
+        pred = model.predict(x)
+    return {"pred": pred.reshape(-1), "block_lines": lines, "script": script, "script_sha256": sha, "seed": SEEDS[name],
+            "weights_digest": weights_digest(m.weights), "n_variables": len(spec)}
+
+
+def tf_cross_hash(tf):
+    g = np.load(os.path.join(HERE, "cross_hash.npz"))
+    a, b = g["a"].astype(np.int64), g["b"].astype(np.int64)
+    out = {}
+    for nb, key in ((10000, "b10000"), (10_000_000, "b10m")):
+        sa = tf.sparse.from_dense(a.reshape(-1, 1) + 0)              # ids are >= 1 in the fixture: no implicit zeros dropped
+        sb = tf.sparse.from_dense(b.reshape(-1, 1) + 0)
+        h = tf.sparse.cross_hashed([sa, sb], num_buckets=nb)
+        out[key] = tf.sparse.to_dense(h).numpy().reshape(-1)
+    return {"a": a, "b": b, **out}
+
+
+def main():
+    ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    ap.add_argument("--backend", default="auto", choices=["auto", "tf", "shim"])
+    ap.add_argument("--reference", default="/root/reference")
+    ap.add_argument("--models", default=",".join(SPECS))
+    ap.add_argument("--out", default=HERE)
+    args = ap.parse_args()
+    backend, tf, ver = get_backend(args.backend)
+    z = np.load(os.path.join(HERE, "samples_256.npz"))
+    samples = {k: z[k].astype(object) for k in z.files}
+    for name in [m for m in args.models.split(",") if m]:
+        r = run_model(name, backend, tf, args.reference, samples)
+        path = os.path.join(args.out, "refblock_%s_%s.npz" % (backend, name))
+        np.savez_compressed(path, backend=backend, backend_version=ver, **r)
+        print("%-14s %s lines %s  %d variables  pred[:3] = %s -> %s" % (name, r["script"], r["block_lines"], r["n_variables"],
+                                                                        np.round(r["pred"][:3], 6), os.path.relpath(path, ROOT)))
+    if backend == "tf":
+        np.savez_compressed(os.path.join(args.out, "refblock_tf_cross_hash.npz"), backend_version=ver, **tf_cross_hash(tf))
+
+
+if __name__ == "__main__":
+    main()

@@ -128,3 +128,72 @@ def test_peer_allgather_two_processes_share_the_device(torch):
             assert timed_out is True
     for p in procs:
         assert p.exitcode == 0
+
+
+def _worker_sink(rank, world, port, q):
+    """GroupedScoreGather + PeerScoreComm + a sink, one rank's sink slow (the sink must never see a peer's
+    exchange e + 2 land in what it reads)."""
+    import sys
+    import time
+    import traceback
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["SPRK_PEER_TIMEOUT_MS"] = "4000"
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from sparrowrecsys_amd.dist import GroupedScoreGather, PeerScoreComm
+        torch.cuda.set_device(0)
+        B, G, n_batches = 1024, 4, 4 * 9 + 3                     # nine full groups and a ragged last one
+        comm = PeerScoreComm(slot_floats=B * G)
+        seen = []
+
+        def sink(gi, view, nb):
+            if rank == 1 and gi in (1, 2, 5):
+                time.sleep(0.25)                                 # this rank falls a group behind its peer
+            v = view.clone()
+            torch.cuda.synchronize()
+            good = True
+            for r in range(world):
+                for b in range(nb):
+                    want = float(100000 * r + 100 * (gi * G + b))
+                    good = good and bool((v[r, b] == want).all())
+            seen.append((gi, nb, good))
+
+        gs = GroupedScoreGather(B, G, torch.device("cuda", 0), sink=sink, comm=comm)
+        assert gs.comm_stream is not None
+        for i in range(n_batches):
+            gs.out().fill_(float(100000 * rank + 100 * i))
+            if gs.full():
+                gs.commit()
+        gs.flush()
+        comm.check(gs.comm_stream.cuda_stream)
+        dist.barrier()
+        q.put((rank, seen, None))
+    except Exception:
+        q.put((rank, [], traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_grouped_gather_with_sink_over_peer_writes_survives_a_slow_rank(torch):
+    import torch.multiprocessing as mp
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_sink, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, seen, tb in sorted(results):
+        assert tb is None, tb
+        assert [g for g, _, _ in seen] == list(range(10)), "rank %d: groups seen %r" % (rank, seen)
+        assert seen[-1][1] == 3
+        assert all(good for _, _, good in seen), "rank %d: a sink saw foreign data: %r" % (rank, seen)
+    for p in procs:
+        assert p.exitcode == 0

@@ -1,0 +1,147 @@
+"""Parity against the reference's OWN model-building source (generator tests/golden/make_tf_golden.py).
+
+Two fixture families, same inputs (first 256 rows of the reference's testSamples.csv) and same seeded weights:
+  refblock_shim_<model>.npz  the untouched script lines executed on oracle/keras_shim.py -- committed; pins the WIRING of
+                             DIN / DeepFM / DeepFM_v2 / Wide&Deep / NeuralCF to the reference's code (SURVEY 8(a) A7, A8,
+                             A10-A14: concat orders, PReLU shapes, pair list, no-softmax pooling, two tables per deep key);
+  refblock_tf_<model>.npz    the same lines executed on TensorFlow -- NOT in the repository yet (TensorFlow cannot be
+                             installed in the build container).  The tests that need it carry ``unpinned`` in their names
+                             and XFAIL with the reason while the file is missing; once somebody runs
+                             ``python tests/golden/make_tf_golden.py --backend tf`` they turn into the 1e-4 / bit-exact pin.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import ctr_oracle as O
+from tests.conftest import GOLDEN, HAS_REFERENCE, REFERENCE, needs_reference
+from tests.golden.make_tf_golden import SPECS, make_model, weights_digest
+
+MODELS = list(SPECS)
+FORWARD = {"din": O.din_forward, "deepfm": O.deepfm_forward, "deepfm_v2": O.deepfm_v2_forward,
+           "wide_n_deep": O.wide_n_deep_forward, "neural_cf": O.neural_cf_forward}
+SHIM_TOL = 1e-6        # oracle vs the reference's lines on the numpy shim: both fp32 numpy, different summation orders
+TF_TOL = 1e-4          # north_star: within 1e-4 of the TF2 CPU forward
+HIP_TOL = 3e-5
+UNPINNED = ("UNPINNED: tests/golden/refblock_tf_%s.npz does not exist -- no TensorFlow-produced vector pins this model yet "
+            "(TensorFlow is not installable in the build container); generate it with "
+            "`python tests/golden/make_tf_golden.py --backend tf` where `import tensorflow` (<= 2.15, or tf_keras) works")
+
+
+def _fixture(backend, name):
+    path = os.path.join(GOLDEN, "refblock_%s_%s.npz" % (backend, name))
+    return np.load(path) if os.path.exists(path) else None
+
+
+def _model(name, g):
+    m = make_model(name)
+    assert weights_digest(m.weights) == str(g["weights_digest"]), "seeded weights drifted (numpy RNG change?)"
+    return m
+
+
+@pytest.mark.parametrize("name", MODELS)
+def test_oracle_matches_the_reference_lines_on_the_shim(name, samples):
+    g = _fixture("shim", name)
+    assert g is not None and g["pred"].shape == (256,)
+    assert 0.02 < g["pred"].std() and g["pred"].min() > 1e-3 and g["pred"].max() < 1 - 1e-3      # not saturated
+    p = FORWARD[name](samples, _model(name, g).weights)[:, 0]
+    assert np.abs(p - g["pred"]).max() <= SHIM_TOL
+
+
+@needs_reference
+@pytest.mark.parametrize("name", MODELS)
+def test_live_execution_of_the_reference_lines_reproduces_the_fixture(name, samples):
+    from tests.golden.make_tf_golden import get_backend, run_model
+    g = _fixture("shim", name)
+    _, tf, _ = get_backend("shim")
+    r = run_model(name, "shim", tf, REFERENCE, samples)
+    assert r["script_sha256"] == str(g["script_sha256"]) and r["block_lines"] == str(g["block_lines"])
+    np.testing.assert_array_equal(r["pred"], g["pred"])
+
+
+def test_the_wiring_pin_is_sensitive(samples):
+    """What the shim run can catch, it must catch: each mutation below is a plausible misreading of a script."""
+    # (1) DeepFM.py: tying the deep part's tables to the FM part's (one table per key) changes the scores
+    g = _fixture("shim", "deepfm")
+    w = dict(_model("deepfm", g).weights)
+    tied = {k: v for k, v in w.items() if not k.startswith("deep_emb/")}
+    assert np.abs(O.deepfm_forward(samples, tied)[:, 0] - g["pred"]).max() > 1e-3
+    # (2) DeepFM.py:111-112: the four dots enter the head in the order item.user, itemGenre.userGenre, itemGenre.user, item.userGenre
+    hk = w["head/kernel"].copy()
+    n_fo = 31040
+    hk[[n_fo, n_fo + 3]] = hk[[n_fo + 3, n_fo]]
+    assert np.abs(O.deepfm_forward(samples, {**w, "head/kernel": hk})[:, 0] - g["pred"]).max() > 1e-4
+    # (3) DIN.py:150: PReLU alpha is per (time step, unit) -- an alpha shared over the time steps is another function
+    g = _fixture("shim", "din")
+    w = dict(_model("din", g).weights)
+    a = w["att_prelu/alpha"]
+    assert a.shape == (5, 32)
+    shared = np.repeat(a[:1], 5, axis=0)
+    assert np.abs(O.din_forward(samples, {**w, "att_prelu/alpha": shared})[:, 0] - g["pred"]).max() > 1e-5
+    # (4) DIN.py:146-147: [h - c, h, c, h * c] in THAT order: swapping two 10-row blocks of the attention kernel breaks it
+    k0 = w["att0/kernel"].copy()
+    k0[[*range(0, 10), *range(10, 20)]] = k0[[*range(10, 20), *range(0, 10)]]
+    assert np.abs(O.din_forward(samples, {**w, "att0/kernel": k0})[:, 0] - g["pred"]).max() > 1e-5
+    # (5) DeepFM_v2.py:106-110: projections stacked as movieGenre1, movieId, userGenre1, userId, numerics
+    g = _fixture("shim", "deepfm_v2")
+    w = dict(_model("deepfm_v2", g).weights)
+    k0 = w["deep0/kernel"].copy()
+    k0[[*range(0, 64), *range(64, 128)]] = k0[[*range(64, 128), *range(0, 64)]]
+    assert np.abs(O.deepfm_v2_forward(samples, {**w, "deep0/kernel": k0})[:, 0] - g["pred"]).max() > 1e-5
+
+
+def test_shim_agrees_with_the_graph_tensorflow_exported_for_neuralcf(samples):
+    """The shim itself is checked against TensorFlow's work where the reference gives the means: NeuralCF.py's lines on the
+    shim, loaded with the reference's TRAINED variables, against the outputs of the reference's exported SavedModel graph
+    (tests/golden/savedmodel_exec.npz, executed op by op) on the same rows."""
+    if not HAS_REFERENCE:
+        pytest.skip("/root/reference not mounted (GPU box)")
+    from tests.golden.make_tf_golden import SCRIPT_DIR, build_reference_model, get_backend, inject
+    from tests.test_savedmodel_pins import _ncf_w
+    g = np.load(os.path.join(GOLDEN, "savedmodel_exec.npz"))
+    ckpt = np.load(os.path.join(GOLDEN, "neuralcf_ckpt.npz"))
+    _, tf, _ = get_backend("shim")
+    model, _, _ = build_reference_model(tf, "shim", os.path.join(REFERENCE, SCRIPT_DIR, "NeuralCF.py"))
+    inject(model, SPECS["neural_cf"][1], _ncf_w(ckpt, "001"))
+    p = model.predict({"movieId": ckpt["movieId"].astype(np.int32), "userId": ckpt["userId"].astype(np.int32)})[:, 0]
+    assert np.abs(p - g["ncf_001"]).max() <= 1e-6
+
+
+@pytest.mark.parametrize("name", MODELS)
+def test_oracle_vs_tensorflow_vector_unpinned_until_the_file_exists(name, samples):
+    g = _fixture("tf", name)
+    if g is None:
+        pytest.xfail(UNPINNED % name)
+    p = FORWARD[name](samples, _model(name, g).weights)[:, 0]
+    assert np.abs(p - g["pred"]).max() <= TF_TOL
+
+
+def test_cross_hash_vs_tensorflow_vector_unpinned_until_the_file_exists():
+    path = os.path.join(GOLDEN, "refblock_tf_cross_hash.npz")
+    if not os.path.exists(path):
+        pytest.xfail(UNPINNED % "cross_hash" + " (the hash itself IS pinned by TensorFlow's published known answers: tests/test_farmhash_pins.py)")
+    g = np.load(path)
+    np.testing.assert_array_equal(O.crossed_bucket_np([g["a"], g["b"]], 10000), g["b10000"])
+    np.testing.assert_array_equal(O.crossed_bucket_np([g["a"], g["b"]], 10_000_000), g["b10m"])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# GPU: the HIP path against the same vectors
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", MODELS)
+def test_hip_matches_the_reference_lines_on_the_shim(name, samples):
+    g = _fixture("shim", name)
+    p = _model(name, g).predict(samples)[:, 0]
+    assert np.abs(p - g["pred"]).max() <= HIP_TOL
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", MODELS)
+def test_hip_vs_tensorflow_vector_unpinned_until_the_file_exists(name, samples):
+    g = _fixture("tf", name)
+    if g is None:
+        pytest.xfail(UNPINNED % name)
+    p = _model(name, g).predict(samples)[:, 0]
+    assert np.abs(p - g["pred"]).max() <= TF_TOL

@@ -100,6 +100,50 @@ def test_concurrent_requests_are_batched_and_isolated(stub_server):
     assert srv.batcher.batches < srv.batcher.requests   # at least one merged forward
 
 
+class _GenreStub:
+    """score encodes which genre strings arrived: index of the genre in a 3-entry list, -1 (-> 0.5) if unknown."""
+    VOC = {"Action": 0.1, "Drama": 0.2, "": 0.3}
+
+    def predict(self, feats):
+        g = feats["userGenre1"]
+        out = np.array([self.VOC.get(str(x), 0.5) for x in g], dtype=np.float32)
+        if "nan_please" in feats:
+            out[0] = np.nan
+        return out.reshape(-1, 1)
+
+
+def test_bracketed_string_features_are_unwrapped_not_stringified():
+    """TF Serving accepts [x] for a scalar feature; on the fast path str(['Action']) used to reach the model."""
+    srv = PredictServer(_GenreStub(), port=0).start()
+    try:
+        code, resp = _post(srv.port, {"instances": [{"userId": [1], "movieId": [2], "userGenre1": ["Action"]},
+                                                    {"userId": [3], "movieId": [4], "userGenre1": ["Drama"]}]})
+        assert code == 200
+        np.testing.assert_allclose([x[0] for x in resp["predictions"]], [0.1, 0.2], atol=1e-7)
+        code, resp = _post(srv.port, {"instances": [{"userId": 1, "movieId": 2, "userGenre1": "Action"},
+                                                    {"userId": 3, "movieId": 4, "userGenre1": None}]})
+        assert code == 200
+        np.testing.assert_allclose([x[0] for x in resp["predictions"]], [0.1, 0.3], atol=1e-7)
+        # a genuinely non-scalar string feature is a client error, not an out-of-vocabulary genre
+        code, resp = _post(srv.port, {"instances": [{"userId": 1, "movieId": 2, "userGenre1": ["Action", "Drama"]}]})
+        assert code == 400 and "error" in resp
+    finally:
+        srv.close()
+
+
+def test_non_finite_scores_still_parse():
+    """'%.9g' of NaN is not JSON; such a response falls back to json.dumps' NaN spelling."""
+    srv = PredictServer(_GenreStub(), port=0).start()
+    try:
+        code, resp = _post(srv.port, {"instances": [{"userId": 1, "movieId": 2, "userGenre1": "Action", "nan_please": 1},
+                                                    {"userId": 1, "movieId": 2, "userGenre1": "Drama", "nan_please": 1}]})
+        assert code == 200
+        p = [x[0] for x in resp["predictions"]]
+        assert np.isnan(p[0]) and abs(p[1] - 0.2) < 1e-7
+    finally:
+        srv.close()
+
+
 @pytest.mark.gpu
 def test_neuralcf_served_end_to_end_with_reference_trained_weights():
     """The reference's own trained NeuralCF (modeldata/neuralcf/001) behind the shim: the scores the Jetty
