@@ -87,8 +87,10 @@ def build_workload(name, B, dist_name, seed_offset=0, big_vocab=0, NB=8):
             kernel = "k_deepfm_v2_chain" if (env("SPRK_V2_JOINT") == "0" or env("SPRK_V2_FOLD") == "0") else "k_deepfm_v2_joint"
         else:
             model = M.DeepFM(seed=101, emb_dim=D, fields=fields, pairs=SY.CONFIG2_PAIRS)
-            desc = "DeepFM pairwise-dot FM (DeepFM graph), F=6 sparse fields, emb_dim=16, 8 pairs, deep 64-64"
+            desc = ("DeepFM pairwise-dot FM (DeepFM graph), F=6 sparse fields, emb_dim=16, 8 pairs, deep 64-64; the deep part reads its OWN "
+                    "movieId / userId tables as in the reference (DeepFM.py:106: a second DenseFeatures layer = second variables)")
             kernel = "k_tile_forward" if env("SPRK_V1_CHAIN") == "0" else "k_deepfm_pairs"
+            bytes_per_sample += 2 * D * 4                     # the deep part's two rows
         if env("SPRK_FORCE_INTERPRETER") == "1":
             kernel = "k_tile_forward"
         model._bench_fields = fields
@@ -110,6 +112,8 @@ def build_workload(name, B, dist_name, seed_offset=0, big_vocab=0, NB=8):
         for i, (k, kind, v) in enumerate(fields):
             if kind == "id":
                 w["emb/" + k] = _device_table(v, D, 1000 + i, 1.0 / math.sqrt(D))
+                if name == "deepfm_c4":                           # the deep part's own table of the same key (DeepFM.py:106)
+                    w["deep_emb/" + k] = _device_table(v, D, 2000 + i, 1.0 / math.sqrt(D))
         rng = np.random.default_rng(7)
         fo_key = "fo_cat/kernel" if name == "deepfm_v2_c4" else "head/kernel"
         model = cls(weights=_resize_first_order(small, w, fields, fo_key, rng), emb_dim=D, fields=fields, **kw)
@@ -122,7 +126,7 @@ def build_workload(name, B, dist_name, seed_offset=0, big_vocab=0, NB=8):
                     "reference_bytes_per_sample": F * (4 + D * 4 + 4) + D * 4}
         else:
             desc = "DeepFM pairwise-dot graph, emb_dim=64, 4 fields: movieId 27 M rows (6.9 GB table), userId 138 494, two genre fields; 4 pairs, deep 64-64"
-            roof = {"bound": "hbm", "kernel": "k_deepfm_pairs", "bytes_per_sample": F * (4 + D * 4 + 4) + 7 * 4 + 4}
+            roof = {"bound": "hbm", "kernel": "k_deepfm_pairs", "bytes_per_sample": F * (4 + D * 4 + 4) + 2 * D * 4 + 7 * 4 + 4}
         return model, synth(fields), desc, roof
     if name == "deepfm_v2_ref":
         # DeepFM_v2.py as written: 4 fields, emb_dim 10, Dense(64) projections, deep 32-16 -- on ML-20M-sized vocabularies
@@ -229,8 +233,9 @@ def compact_for_oracle(model, feats, fields):
             new_fields.append((k, kind, v))
     w = {}
     for name, a in model.weights.items():
-        if name.startswith("emb/") and name[4:] in uniq:
-            a = a[torch.from_numpy(uniq[name[4:]]).to(a.device)].cpu().numpy() if hasattr(a, "data_ptr") else np.asarray(a)[uniq[name[4:]]]
+        key = name.split("/", 1)[1] if (name.startswith("emb/") or name.startswith("deep_emb/")) else None
+        if key in uniq:
+            a = a[torch.from_numpy(uniq[key]).to(a.device)].cpu().numpy() if hasattr(a, "data_ptr") else np.asarray(a)[uniq[key]]
         elif hasattr(a, "data_ptr"):
             a = a.cpu().numpy()
         w[name] = a

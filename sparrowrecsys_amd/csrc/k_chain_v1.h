@@ -26,6 +26,7 @@
 
 #define V1_MAX_FIELDS 8
 #define V1_MAX_DEEP 2
+#define V1_MAX_ROWS (V1_MAX_FIELDS + V1_MAX_DEEP)
 
 struct V1Run {
     int F, ND, n_num;
@@ -33,9 +34,14 @@ struct V1Run {
     int col[V1_MAX_FIELDS];               // ids column of field f
     int vocab[V1_MAX_FIELDS];
     int row_floats;                       // floats per embedding row (Dp)
-    const float* table[V1_MAX_FIELDS];    // [vocab+1][Dp], last row zero
+    const float* table[V1_MAX_ROWS];      // [vocab+1][Dp], last row zero; entries nf.. = the deep part's own tables (sep)
     const float* w1[V1_MAX_FIELDS];       // [vocab+1] first-order weights, last zero
-    int n_deep;                           // deep embedding columns = fields 0 .. n_deep-1 (the host orders them first)
+    int n_deep;                           // deep embedding columns: looked up with the ids of fields 0 .. n_deep-1 (the host orders them first)
+    // sep = 1: the deep part reads its OWN tables (DeepFM.py:106: DenseFeatures(deep_feature_columns) creates its own
+    // movieId / userId embedding variables, distinct from the FM part's DeepFM.py:91-92) = rows nf .. nf+n_deep-1; sep = 0: tied
+    // tables, the deep columns are fields 0 .. n_deep-1's rows themselves
+    int sep;
+    int pack;                             // sep, narrow rows of <= 12 floats: the deep row rides in its field's 128-byte line at float 20
     float pw[V1_MAX_FIELDS * V1_MAX_FIELDS];   // head weight of pair (a,b), a < b, at a*V1_MAX_FIELDS + b; 0 = not a pair
     const float* w0;                      // deep0 W^T packed [H0][16*(V1_MAX_DEEP+1)]: deep field chunks, then the numerics chunk (zero padded)
     const float* b0;                      // [H0]
@@ -54,17 +60,21 @@ struct V1Run {
     // kernel at 38.7 MB per 65 536 samples against 30.4 MB of algorithmic bytes), one SGPR base + 32-bit byte offsets
     float e_scale, e_inv;                 // static split scale of the deep fields' rows and 1 / (e_scale * w0 scale); 0 = per sample
     const float* tab;                     // NULL: gather from table[] / w1[] (wide rows)
-    unsigned rowbase[V1_MAX_FIELDS];      // first row of field f in tab
+    unsigned rowbase[V1_MAX_ROWS];        // first row of field f (or deep table nf + d) in tab
 };
 
 // One-time (finalize) kernel: rows of one field of the derived table
+// (w1 == NULL: a deep-only table, no first-order weight; deep != NULL: the deep part's row of the same id packed at float 20,
+// Dp <= 12)
 __global__ __launch_bounds__(256) void k_v1_build_rows(const float* __restrict__ table, int Dp, const float* __restrict__ w1,
-                                                       long long rows, float* __restrict__ out) {
+                                                       long long rows, float* __restrict__ out, const float* __restrict__ deep) {
     const long long total = rows * 32;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
         const long long v = i >> 5;
         const int c = (int)(i & 31);
-        out[i] = c < Dp ? table[v * Dp + c] : (c == 16 ? w1[v] : 0.f);
+        float x = c < Dp ? table[v * Dp + c] : ((c == 16 && w1) ? w1[v] : 0.f);
+        if (deep && c >= 20 && c - 20 < Dp) x = deep[v * Dp + (c - 20)];
+        out[i] = x;
     }
 }
 
@@ -142,21 +152,26 @@ __global__ __launch_bounds__(256) void k_v1_pack_image(const V1Run A, float* __r
     for (int i = tid; i < LD::H1; i += 256) { img[LD::off_b1 + i] = A.b1[i]; img[LD::off_hd + i] = A.hdeep[i]; }
 }
 
-template <int NF, int PC>
+template <int NR, int PC>
 struct V1Set {
-    f32x4 x[NF][PC];                      // every field's row pieces: elements 16 pc + 4q .. +3
+    f32x4 x[NR][PC];                      // every field's (and separate deep table's) row pieces: elements 16 pc + 4q .. +3
     float xa, xb;                         // numerics q and q + 4
     float w1a, w1b;                       // first-order weights fetched by this lane
 };
 
 // NV = 16-byte pieces per embedding row (Dp / 4): up to 4 = one piece per lane (emb_dim <= 16), 16 = four per lane (emb_dim 64,
 // BASELINE config 4: the 256-byte rows of the 27 M-row table are gathered whole -- the fold does not apply to pair dots).
-template <int NF, int NV, int H0C, int H1C, int WAVES, bool DYN, bool MB>
+// SEP: the deep part's own tables are gathered as rows NF, NF + 1 (V1Run::sep).  ONE: one task per wave, no loop -- the
+// strict one-batch launch at four waves per SIMD (see k_chain_v2j1.h for the measurements behind this shape).
+template <int NF, int NV, int H0C, int H1C, int WAVES, bool DYN, bool MB, bool SEP, bool ONE = false>
 __device__ __forceinline__ void v1_body(const V1Run& A, const int* __restrict__ ids0, const float* __restrict__ dense0,
                                         float* __restrict__ out0, int B, int* __restrict__ err, const V1Many* __restrict__ Mp) {
     constexpr int PC = (NV + 3) / 4;
+    constexpr int NR = NF + (SEP ? V1_MAX_DEEP : 0);
+    constexpr int DB = SEP ? NF : 0;                                // first deep row
     using LD = V1Lds<H0C, H1C, PC>;
-    using Set = V1Set<NF, PC>;
+    using Set = V1Set<NR, PC>;
+    static_assert(!(ONE && MB) && !(ONE && PC > 1), "one-task shape: one batch, narrow rows");
     static_assert(NF >= 2 && NF <= V1_MAX_FIELDS && NV >= 1 && (NV <= 4 || NV % 4 == 0) && NV <= 16, "shape");
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -212,6 +227,16 @@ __device__ __forceinline__ void v1_body(const V1Run& A, const int* __restrict__ 
             for (int f = 0; f < NF; ++f) ro[f] = (sid[f] + A.rowbase[f]) * 128u;
 #pragma unroll
             for (int f = 0; f < NF; ++f) S.x[f][0] = q < NV ? *reinterpret_cast<const f32x4*>(tb + (ro[f] + 16u * q)) : zero;
+            if constexpr (SEP) {
+#pragma unroll
+                for (int d = 0; d < V1_MAX_DEEP; ++d) {
+                    S.x[NF + d][0] = zero;
+                    if (d < A.n_deep) {                           // (wave-uniform)
+                        const unsigned rd = A.pack ? ro[d] + 80u : (sid[d] + A.rowbase[NF + d]) * 128u;
+                        if (q < NV) S.x[NF + d][0] = *reinterpret_cast<const f32x4*>(tb + (rd + 16u * q));
+                    }
+                }
+            }
             // first order: lane (r,q) fetches field q's weight, then field q+4's -- float 16 of the row it has just asked for
             unsigned oa = ro[0], ob = ro[NF > 4 ? 4 : 0];
             if (NF > 1) oa = q == 1 ? ro[NF > 1 ? 1 : 0] : oa;
@@ -229,6 +254,13 @@ __device__ __forceinline__ void v1_body(const V1Run& A, const int* __restrict__ 
 #pragma unroll
             for (int pc = 0; pc < PC; ++pc)
                 S.x[f][pc] = 4 * pc + q < NV ? ld4(A.table[f] + (size_t)sid[f] * A.row_floats + 16 * pc + 4 * q) : zero;
+        if constexpr (SEP) {
+#pragma unroll
+            for (int d = 0; d < V1_MAX_DEEP; ++d)
+#pragma unroll
+                for (int pc = 0; pc < PC; ++pc)
+                    S.x[NF + d][pc] = (d < A.n_deep && 4 * pc + q < NV) ? ld4(A.table[NF + d] + (size_t)sid[d] * A.row_floats + 16 * pc + 4 * q) : zero;
+        }
         {
             // first order: lane (r,q) fetches field q's weight, then field q+4's
             const float* pa = A.w1[0] + sid[0];
@@ -249,19 +281,26 @@ __device__ __forceinline__ void v1_body(const V1Run& A, const int* __restrict__ 
     float rna[H0C], rnb[H0C];             // numerics' A operands: rows (nb*16 + r) of W0[:, numerics]^T, columns q and q + 4
     auto compute = [&](const Set& S) -> float {
 #pragma clang fp contract(off)
-        float z = S.w1a + S.w1b;
-        // ---- pair dots (per-lane partials; the sum over q is part of the final reduction) ----
+        // ---- pair dots (per-lane partials over this lane's 4 columns; the sum over q is part of the final reduction).  Only the
+        //      real pairs (their head weight is wave-uniform: an SGPR test), two packed multiplies + two packed FMAs per pair and
+        //      16-float chunk (round 2: all NF (NF - 1) / 2 products, 8 scalar instructions each) ----
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        f32x2 pa = {0.f, 0.f}, pb = {0.f, 0.f};
 #pragma unroll
         for (int a = 0; a < NF; ++a)
 #pragma unroll
             for (int b = a + 1; b < NF; ++b) {
                 const float hw = A.pw[a * V1_MAX_FIELDS + b];       // wave-uniform (SGPR); zero when (a,b) is not a pair
-                if (PC > 1 && hw == 0.f) continue;                  // (wide rows: skip the products of non-pairs; wave-uniform)
-                f32x4 p = S.x[a][0] * S.x[b][0];
+                if (hw == 0.f) continue;
+                const f32x2 hw2 = {hw, hw};
 #pragma unroll
-                for (int pc = 1; pc < PC; ++pc) p += S.x[a][pc] * S.x[b][pc];
-                z = fmaf(hw, (p.x + p.y) + (p.z + p.w), z);
+                for (int pc = 0; pc < PC; ++pc) {
+                    const f32x4 xa = S.x[a][pc], xb = S.x[b][pc];
+                    pa = __builtin_elementwise_fma(f32x2{xa.x, xa.y} * f32x2{xb.x, xb.y}, hw2, pa);
+                    pb = __builtin_elementwise_fma(f32x2{xa.z, xa.w} * f32x2{xb.z, xb.w}, hw2, pb);
+                }
             }
+        float z = (S.w1a + S.w1b) + ((pa[0] + pa[1]) + (pb[0] + pb[1]));
         // ---- deep0 (DeepFM.py:106-107): bias + numerics on f32 MFMA, the deep fields' rows on split f16 ----
         f32x4 h0[H0C];
 #pragma unroll
@@ -273,7 +312,7 @@ __device__ __forceinline__ void v1_body(const V1Run& A, const int* __restrict__ 
         // the deep fields' chunks in K order: chunk c = field c / PC, pieces 16 (c % PC) + 4q; K block b = chunks 2b, 2b + 1
         f32x4 ec[2 * PC];
 #pragma unroll
-        for (int c = 0; c < 2 * PC; ++c) ec[c] = (c / PC == 0 || A.n_deep > 1) ? S.x[c / PC][c % PC] : zero;
+        for (int c = 0; c < 2 * PC; ++c) ec[c] = (c / PC == 0 || A.n_deep > 1) ? S.x[DB + c / PC][c % PC] : zero;
         if constexpr (DYN) {
             // the deep fields' rows come out of tables whose max |E| is known at finalize: ONE static power-of-two scale puts it
             // in [2^14, 2^15) (e_scale; refused by the dynamic-range guard for tables with outlier rows) and spares the
@@ -398,12 +437,30 @@ __device__ __forceinline__ void v1_body(const V1Run& A, const int* __restrict__ 
 #pragma unroll
     for (int f = 0; f < NF; ++f) { idA[f] = -1; idB[f] = -1; }
     if (tA < ntasks) ld_ids(tA, idA);
-    if (tB < ntasks) ld_ids(tB, idB);
+    if (!ONE && tB < ntasks) ld_ids(tB, idB);
 #pragma unroll 1
     for (int c = wave; c < LD::total_pad / 256; c += WAVES)
         __builtin_amdgcn_global_load_lds(
             (const __attribute__((address_space(1))) void*)(A.image + c * 256 + lane * 4),
             (__attribute__((address_space(3))) void*)(smem + c * 256), 16, 0, 0);
+    Set SA, SB;
+    if constexpr (ONE) {
+        // the wave's only task: its rows are requested before the barrier (they need the ids, not the image); vmcnt retires in
+        // order, so "at most NF loads outstanding" -- at least NF row loads always follow the DMA -- means the DMA pieces are in
+        if (tA < ntasks) {
+            issue_gather(tA, idA, SA);
+            __builtin_amdgcn_s_waitcnt(0x0F70 | NF);
+        } else {
+            __builtin_amdgcn_s_waitcnt(0x0F70);
+        }
+        __builtin_amdgcn_s_barrier();
+#pragma unroll
+        for (int nb = 0; nb < H0C; ++nb) {
+            rna[nb] = smem[LD::off_w0n + (nb * 16 + r) * 8 + q];
+            rnb[nb] = smem[LD::off_w0n + (nb * 16 + r) * 8 + q + 4];
+        }
+        if (tA < ntasks) store(tA, compute(SA));
+    } else {
     __builtin_amdgcn_s_waitcnt(0x0F70);                          // vmcnt(0): ids and this wave's DMA pieces
     __builtin_amdgcn_s_barrier();
 #pragma unroll
@@ -411,7 +468,6 @@ __device__ __forceinline__ void v1_body(const V1Run& A, const int* __restrict__ 
         rna[nb] = smem[LD::off_w0n + (nb * 16 + r) * 8 + q];
         rnb[nb] = smem[LD::off_w0n + (nb * 16 + r) * 8 + q + 4];
     }
-    Set SA, SB;
     if (tA >= ntasks) {
         // a wave without work leaves after the barrier
     } else if (PC == 1 && ntasks <= 2 * task_stride) {
@@ -432,15 +488,22 @@ __device__ __forceinline__ void v1_body(const V1Run& A, const int* __restrict__ 
             store(tk, compute(cur));
         }
     }
+    }
     if (__ballot(bad) != 0 && lane == 0) atomicOr(err, 1);
 }
 
-template <int NF, int NV, int H0C, int H1C, int WAVES, bool DYN>
+template <int NF, int NV, int H0C, int H1C, int WAVES, bool DYN, bool SEP>
 __global__ __launch_bounds__(WAVES * 64, 2) void k_deepfm_pairs(const V1Run A, const int* __restrict__ ids, const float* __restrict__ dense,
                                                                 float* __restrict__ out, int B, int* __restrict__ err) {
-    v1_body<NF, NV, H0C, H1C, WAVES, DYN, false>(A, ids, dense, out, B, err, nullptr);
+    v1_body<NF, NV, H0C, H1C, WAVES, DYN, false, SEP>(A, ids, dense, out, B, err, nullptr);
 }
-template <int NF, int NV, int H0C, int H1C, int WAVES, bool DYN>
+template <int NF, int NV, int H0C, int H1C, int WAVES, bool DYN, bool SEP>
 __global__ __launch_bounds__(WAVES * 64, 2) void k_deepfm_pairs_many(const V1Run A, const V1Many M, int B, int* __restrict__ err) {
-    v1_body<NF, NV, H0C, H1C, WAVES, DYN, true>(A, nullptr, nullptr, nullptr, B, err, &M);
+    v1_body<NF, NV, H0C, H1C, WAVES, DYN, true, SEP>(A, nullptr, nullptr, nullptr, B, err, &M);
+}
+// one task per wave, four waves per SIMD: the strict one-batch launch (narrow rows, split-f16 form)
+template <int NF, int NV, int H0C, int H1C, int WAVES, bool SEP>
+__global__ __launch_bounds__(WAVES * 64, 4) void k_deepfm_pairs1(const V1Run A, const int* __restrict__ ids, const float* __restrict__ dense,
+                                                                 float* __restrict__ out, int B, int* __restrict__ err) {
+    v1_body<NF, NV, H0C, H1C, WAVES, true, false, SEP, true>(A, ids, dense, out, B, err, nullptr);
 }

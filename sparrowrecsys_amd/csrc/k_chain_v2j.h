@@ -188,6 +188,22 @@ __global__ __launch_bounds__(256) void k_v2j_fold_num(const float* __restrict__ 
     }
 }
 
+// The VALU arithmetic of the scoring stage is written with explicit fused multiply-adds under `fp contract(off)`: hipcc's
+// default (contract = fast) decides per instantiation which a*b + c pairs become one v_fma, so two instantiations of the
+// same source -- the looped kernel and its one-task-per-wave twin (k_chain_v2j1.h), or two field splits -- could differ in
+// the last bit.  With the contraction pinned they are bit-identical by construction.
+__device__ __forceinline__ f32x4 fma4s(f32x4 a, float b, f32x4 c) {
+    return f32x4{__builtin_fmaf(a.x, b, c.x), __builtin_fmaf(a.y, b, c.y), __builtin_fmaf(a.z, b, c.z), __builtin_fmaf(a.w, b, c.w)};
+}
+__device__ __forceinline__ float dot4f(f32x4 a, f32x4 b) {
+    return __builtin_fmaf(a.w, b.w, __builtin_fmaf(a.z, b.z, __builtin_fmaf(a.y, b.y, a.x * b.x)));
+}
+// s^2 - p^2 per element (FM cross minus the numeric group's own squares)
+__device__ __forceinline__ f32x4 sq_diff4(f32x4 s, f32x4 p) {
+    return f32x4{__builtin_fmaf(s.x, s.x, -(p.x * p.x)), __builtin_fmaf(s.y, s.y, -(p.y * p.y)), __builtin_fmaf(s.z, s.z, -(p.z * p.z)),
+                 __builtin_fmaf(s.w, s.w, -(p.w * p.w))};
+}
+
 // everything one 16-sample task needs from memory, in the (r,q) lane layout
 template <int G_BIG, int NJF>
 struct V2JSet {
@@ -379,6 +395,7 @@ __device__ __forceinline__ void v2j_body(const V2JRun& A, const int* __restrict_
 
     // ---- scoring stage ----
     auto compute = [&](const Set& S) -> float {
+#pragma clang fp contract(off)
         const f32x4 pnum = S.xn;
         // numeric group's Dense projection (DeepFM_v2.py:118-120): two chains (even / odd K step)
         f32x4 pn;
@@ -395,7 +412,7 @@ __device__ __forceinline__ void v2j_body(const V2JRun& A, const int* __restrict_
             pn = e + o;
         }
         // this lane's share of the per-id logit terms + numeric first-order partial (rfn = h0w * fo_num weights)
-        float zz = ((q < G_BIG) ? S.w1a : 0.f) + (HALF ? rfn8[0] * pnum.x + rfn8[1] * pnum.y : ((q < 2) ? dot4(rfn, pnum) : 0.f));
+        float zz = ((q < G_BIG) ? S.w1a : 0.f) + (HALF ? __builtin_fmaf(rfn8[1], pnum.y, rfn8[0] * pnum.x) : ((q < 2) ? dot4f(rfn, pnum) : 0.f));
         // small fields, from their LDS rows: P -> FM sum, W0^T P (+ b0) -> deep0's accumulators, row scalars (one q row adds them)
         f32x4 sp = ld4(small_s + S.so[0] + 4 * q), sq[H0C];
 #pragma unroll
@@ -437,7 +454,7 @@ __device__ __forceinline__ void v2j_body(const V2JRun& A, const int* __restrict_
 #pragma unroll
                 for (int n0 = 0; n0 < H0C; ++n0)
                     hA[n0] = __builtin_amdgcn_mfma_f32_16x16x4f32(rwf[n0][st], st ? pnum.y : pnum.x, hA[n0], 0, 0, 0);
-            s += aS * A.unscale_s;
+            s = fma4s(aS, A.unscale_s, s);
 #pragma unroll
             for (int n0 = 0; n0 < H0C; ++n0) hB[n0] = (aFa[n0] + aFb[n0]) * A.unscale_h;
         } else {
@@ -468,7 +485,7 @@ __device__ __forceinline__ void v2j_body(const V2JRun& A, const int* __restrict_
         for (int n0 = 0; n0 < H0C; ++n0) h0[n0] = relu4_fast(hA[n0] + hB[n0]);
         // FM cross (DeepFM_v2.py:147-152): sum_n hfm[n] (S_n^2 - sum_g P_g[n]^2); the fields' squares are in the
         // row scalars, the numeric group's are subtracted here
-        float z = dot4(rhfm[0], s * s - pn * pn);
+        float z = dot4f(rhfm[0], sq_diff4(s, pn));
         // deep1: Dense(relu) (DeepFM_v2.py:126) + output weights; two chains (even / odd K step)
 #pragma unroll
         for (int n1 = 0; n1 < H1C; ++n1) {
@@ -480,7 +497,7 @@ __device__ __forceinline__ void v2j_body(const V2JRun& A, const int* __restrict_
                 e = __builtin_amdgcn_mfma_f32_16x16x4f32(rW1[n1][j].z, h0[j].z, e, 0, 0, 0);
                 o = __builtin_amdgcn_mfma_f32_16x16x4f32(rW1[n1][j].w, h0[j].w, o, 0, 0, 0);
             }
-            z += dot4(rhd[n1], relu4_fast(e + o));
+            z += dot4f(rhd[n1], relu4_fast(e + o));
         }
         // output layer: concat([first, fm, deep]) . w + b -> sigmoid (DeepFM_v2.py:154-155)
         z += zz;

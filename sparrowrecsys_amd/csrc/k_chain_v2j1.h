@@ -1,0 +1,253 @@
+// k_chain_v2j1.h -- k_deepfm_v2_joint1: k_deepfm_v2_joint (k_chain_v2j.h, split-f16 form) re-shaped for ONE strict launch of
+// ONE batch: one 16-sample task per WAVE, four waves per SIMD.  Included after k_chain_v2j.h.
+//
+// Why a second shape (round 3, scripts/ubench/row_gather.hip, profiles/r03/ubench_row_gather.log).  With NO scoring work
+// at all, "ids -> 3 random 128-byte lines per sample -> one float" for 65 536 samples costs, per strict launch,
+//       2 048 waves x 2 tasks (k_deepfm_v2_joint's shape)   8.47 us from a 3.2 GB table, 6.13 us from the Infinity Cache
+//       4 096 waves x 1 task                                7.82 us                       5.93 us
+// and the fused kernel sat 1.4 / 2.25 us above its shape's floor (9.89 / 8.38 us): its two-tasks-per-wave form keeps the
+// weights in 256 VGPRs (2 waves per SIMD), issues gather B only after the image barrier + the weight fragments' split, and
+// ends every wave with two scoring stages back to back.  Here a wave owns exactly one task:
+//   * every row of the batch is requested as soon as its ids are in -- before the barrier, nothing else in front of it;
+//   * nothing is loop-carried and no weight lives in a register across tasks: the A fragments of the big fields arrive
+//     PRE-SPLIT (hi / lo halfs, k_v2j1_pack_image) in the LDS image and are read right where an MFMA consumes them, so
+//     the kernel fits 128 VGPRs = 4 waves per SIMD, and the split's VALU work is gone from the launch;
+//   * one scoring stage per wave after its rows land; four waves per SIMD interleave theirs.
+// Arithmetic, operand order and accumulation chains are those of v2j_body<HALF = true>: results are bit-identical to
+// k_deepfm_v2_joint (tests/test_gpu_parity.py::test_v2_joint1_bit_identical_to_joint).
+// Used by sprk_forward / one-batch launches with ceil(B / 16) <= V2J1_MAX_TASKS; larger batches and the several-batches-
+// per-launch form stay on the looped kernel (one image staging per workgroup is only worth 8 tasks when there are few).
+
+#define V2J1_WAVES 8
+#define V2J1_MAX_TASKS 16384                 // B <= 262 144: beyond, the looped kernel amortises the image staging better
+
+template <int G_BIG>
+struct V2J1Lds {
+    static constexpr int off_frag = 0;                              // [G_BIG][2 n-blocks][hi, lo] A fragments, 256 floats (1 KB) each
+    static constexpr int off_sel = off_frag + G_BIG * 4 * 256;      // the 0/1 selection fragment (FM sum of hi + lo)
+    static constexpr int S1 = 36;
+    static constexpr int off_w1 = off_sel + 256;                    // deep1 W^T [16][S1]
+    static constexpr int off_b1 = off_w1 + 16 * S1;                 // [16]
+    static constexpr int off_hd = off_b1 + 16;                      // [16] head weights on deep1's output
+    static constexpr int off_bpn = off_hd + 16;                     // [16] numeric projection bias
+    static constexpr int off_hfm = off_bpn + 16;                    // [16] head weights on the FM vector
+    static constexpr int off_wn8 = off_hfm + 16;                    // [16][8] numeric projection W^T (zero beyond n_num)
+    static constexpr int off_fn8 = off_wn8 + 128;                   // [8] h0w * first-order weights of the numerics
+    static constexpr int total = off_fn8 + 8;
+    static constexpr int total_pad = (total + 255) & ~255;
+};
+
+// One-time (finalize) kernel, one block.  Fragment (b, n0, part) lane l = (r = l & 15, q = l >> 4) holds 8 halfs
+// {h[0..3], h[0..3]} of W0[n0*16 + r][16*grp_b + 4q + j] * w_scale, h = hi (part 0) or lo (part 1): exactly the registers
+// v2j_body's load_weights() builds with split_half4 at every launch.
+__global__ __launch_bounds__(256) void k_v2j1_pack_image(const V2Args A, const V2JRun R, int g_big, int G, float* __restrict__ img) {
+    const int tid = threadIdx.x;
+    const int off_sel = g_big * 4 * 256, off_w1 = off_sel + 256, off_b1 = off_w1 + 16 * 36, off_hd = off_b1 + 16, off_bpn = off_hd + 16,
+              off_hfm = off_bpn + 16, off_wn8 = off_hfm + 16, off_fn8 = off_wn8 + 128, total_pad = (off_fn8 + 8 + 255) & ~255;
+    for (int i = tid; i < total_pad; i += 256) img[i] = 0.f;
+    __syncthreads();
+    f16x8* frag = reinterpret_cast<f16x8*>(img);
+    for (int i = tid; i < g_big * 2 * 64; i += 256) {
+        const int l = i & 63, n0 = (i >> 6) & 1, b = i >> 7, r = l & 15, q = l >> 4;
+        const f32x4 w = ld4(A.W0 + (size_t)(n0 * 16 + r) * (G * 16) + 16 * R.big_grp[b] + 4 * q);
+        f16x4 hi, lo;
+        split_half4(w, R.w_scale, hi, lo);
+        frag[((b * 2 + n0) * 2 + 0) * 64 + l] = f16x8{hi[0], hi[1], hi[2], hi[3], hi[0], hi[1], hi[2], hi[3]};
+        frag[((b * 2 + n0) * 2 + 1) * 64 + l] = f16x8{lo[0], lo[1], lo[2], lo[3], lo[0], lo[1], lo[2], lo[3]};
+    }
+    if (tid < 64) {
+        const int r = tid & 15, q = tid >> 4;
+        f16x8 s;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s[e] = (4 * q + (e & 3) == r) ? (_Float16)1.0f : (_Float16)0.0f;
+        reinterpret_cast<f16x8*>(img + off_sel)[tid] = s;
+    }
+    for (int i = tid; i < 16 * 32; i += 256) img[off_w1 + (i >> 5) * 36 + (i & 31)] = A.W1[i];      // deep1 W^T [16][32]
+    if (tid < 16) {
+        img[off_b1 + tid] = A.b1[tid];
+        img[off_hd + tid] = tid < A.n_hdeep ? A.hdeep[tid] : 0.f;
+        img[off_bpn + tid] = A.bp[G - 1][tid];
+        img[off_hfm + tid] = tid < A.n_hfm ? A.hfm[tid] : 0.f;
+    }
+    if (tid < 128) img[off_wn8 + tid] = (tid & 7) < A.n_num ? A.Wp[G - 1][(size_t)(tid >> 3) * A.ldp_num + (tid & 7)] : 0.f;
+    if (tid < 8) img[off_fn8 + tid] = tid < A.n_num ? A.h0w * A.fo_num_w[tid] : 0.f;
+}
+
+template <int G_BIG, int NJF>
+__global__ __launch_bounds__(V2J1_WAVES * 64, 4) void k_deepfm_v2_joint1(const V2JRun A, const int* __restrict__ ids,
+                                                                       const float* __restrict__ dense, float* __restrict__ out, int B,
+                                                                       int* __restrict__ err, const float* __restrict__ image) {
+#pragma clang fp contract(off)                                          // (pinned: see fma4s / dot4f in k_chain_v2j.h)
+    using LD = V2J1Lds<G_BIG>;
+    constexpr int WAVES = V2J1_WAVES, KP = 16, H0C = 2;
+    constexpr unsigned RB = (KP + 16) * 4;
+    static_assert(G_BIG >= 1 && G_BIG <= 3 && NJF >= 1 && NJF <= V2J_MAX_JF, "field split");
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 15, q = lane >> 4;
+    const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int ntasks = (B + 15) >> 4;
+    const int tk = blockIdx.x * WAVES + wave;
+    const bool work = tk < ntasks;                                     // wave-uniform
+    const float* small_s = smem + LD::total_pad;                       // small fields' rows, then Wf
+    float* stage = smem + LD::total_pad + A.small_floats + wave * 256; // this wave's ids / numerics slot
+    const bool fast = work && !(A.flags & 1) && tk * 16 + 16 <= B;     // aligned, full task: one 16-byte load per lane
+
+    // ---- the task's ids + numerics first, then the image pieces (they land inside the ids' latency) ----
+    f32x4 raw = zero;
+    if (fast) {
+        const bool isid = lane < 32;
+        const int j = isid ? lane : lane - 32;
+        const int n4 = 4 * (isid ? A.F : A.ND);
+        const float* src = isid ? reinterpret_cast<const float*>(ids) + (size_t)tk * 16 * A.F : dense + (size_t)tk * 16 * A.ND;
+        raw = ld4(src + 4 * (j < n4 ? j : 0));
+    }
+#pragma unroll 1
+    for (int c = wave; c < LD::total_pad / 256; c += WAVES)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(image + c * 256 + lane * 4),
+                                         (__attribute__((address_space(3))) void*)(smem + c * 256), 16, 0, 0);
+#pragma unroll 1
+    for (int c = wave; c < A.small_floats / 256; c += WAVES)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(A.small + c * 256 + lane * 4),
+                                         (__attribute__((address_space(3))) void*)(smem + LD::total_pad + c * 256), 16, 0, 0);
+
+    // ---- gather: ids through the wave-private LDS slot to the (r,q) lanes, then every row of the task ----
+    f32x4 x[G_BIG];
+    int so[NJF];
+    float xn0 = 0.f, xn1 = 0.f, w1a = 0.f;
+    bool bad = false;
+#pragma unroll
+    for (int b = 0; b < G_BIG; ++b) x[b] = zero;
+#pragma unroll
+    for (int f = 0; f < NJF; ++f) so[f] = 0;
+    if (work) {
+        if (fast) {
+            const bool isid = lane < 32;
+            const int j = isid ? lane : lane - 32;
+            const int n4 = 4 * (isid ? A.F : A.ND);
+            if (j < n4) st4(stage + (isid ? 0 : 128) + 4 * j, raw);
+        } else {
+            stage_task_slow(stage, ids, dense, A.F, A.ND, tk, B, lane);
+        }
+        const int* sid_row = reinterpret_cast<const int*>(stage) + r * A.F;   // (one wave: LDS operations complete in issue order)
+        unsigned sid[G_BIG];
+#pragma unroll
+        for (int b = 0; b < G_BIG; ++b) {
+            const int id = sid_row[A.big_col[b]];
+            bad |= (unsigned)(id + 1) > (unsigned)A.big_vocab[b];
+            sid[b] = min((unsigned)id, (unsigned)A.big_vocab[b]) + A.big_rowbase[b];
+        }
+#pragma unroll
+        for (int f = 0; f < NJF; ++f) {
+            const int id = sid_row[A.j_col[f]];
+            bad |= (unsigned)(id + 1) > (unsigned)A.j_vocab[f];
+            so[f] = A.s_off[f] + (int)min((unsigned)id, (unsigned)A.j_vocab[f]) * V2J_SS;
+        }
+        {
+            const float* nrow = stage + 128 + r * A.ND;
+            const int last = A.n_num - 1;
+            xn0 = nrow[min(q, last)];
+            xn1 = nrow[min(q + 4, last)];
+        }
+        const char* tb = reinterpret_cast<const char*>(A.tab0);
+#pragma unroll
+        for (int b = 0; b < G_BIG; ++b) x[b] = *reinterpret_cast<const f32x4*>(tb + (sid[b] * RB + 16u * q));
+        {
+            unsigned s0 = sid[0] * RB, s1 = sid[G_BIG > 1 ? 1 : 0] * RB, s2 = sid[G_BIG > 2 ? 2 : 0] * RB;
+            asm("" : "+v"(s0), "+v"(s1), "+v"(s2));
+            unsigned sx = s0;
+            if (G_BIG > 1) sx = q == 1 ? s1 : sx;
+            if (G_BIG > 2) sx = q == 2 ? s2 : sx;
+            w1a = *reinterpret_cast<const float*>(tb + (sx + 4u * KP));
+        }
+        // in-order retirement: at most NG loads outstanding <=> this wave's DMA pieces (older) have landed
+        constexpr int NG = G_BIG + 1;
+        __builtin_amdgcn_s_waitcnt(0x0F70 | NG);
+    } else {
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+    }
+    __builtin_amdgcn_s_barrier();
+    if (!work) return;
+
+    // ---- scoring: v2j_body<HALF>'s stage, weights read from LDS where they are consumed ----
+    const float* vq = smem + 4 * q;
+    const f32x4 rbpn = ld4(vq + LD::off_bpn);
+    const float rwn8a = smem[LD::off_wn8 + r * 8 + q], rwn8b = smem[LD::off_wn8 + r * 8 + q + 4];
+    f32x4 pn;
+    {
+        const f32x4 e = __builtin_amdgcn_mfma_f32_16x16x4f32(rwn8a, xn0, rbpn, 0, 0, 0);
+        const f32x4 o = __builtin_amdgcn_mfma_f32_16x16x4f32(rwn8b, xn1, zero, 0, 0, 0);
+        pn = e + o;
+    }
+    float zz = ((q < G_BIG) ? w1a : 0.f) + __builtin_fmaf(smem[LD::off_fn8 + q + 4], xn1, smem[LD::off_fn8 + q] * xn0);
+    f32x4 sp = ld4(small_s + so[0] + 4 * q), sq[H0C];
+#pragma unroll
+    for (int n0 = 0; n0 < H0C; ++n0) sq[n0] = ld4(small_s + so[0] + KP + 16 * n0 + 4 * q);
+    float ssc = small_s[so[0] + KP + 32];
+#pragma unroll
+    for (int f = 1; f < NJF; ++f) {
+        sp += ld4(small_s + so[f] + 4 * q);
+#pragma unroll
+        for (int n0 = 0; n0 < H0C; ++n0) sq[n0] += ld4(small_s + so[f] + KP + 16 * n0 + 4 * q);
+        ssc += small_s[so[f] + KP + 32];
+    }
+    zz += (q == 3) ? ssc : 0.f;
+    f32x4 hA[H0C], hB[H0C];
+#pragma unroll
+    for (int n0 = 0; n0 < H0C; ++n0) hA[n0] = sq[n0];
+    f32x4 s = sp + pn;
+    {
+        f32x4 aFa[H0C], aFb[H0C], aS = zero;
+#pragma unroll
+        for (int n0 = 0; n0 < H0C; ++n0) { aFa[n0] = zero; aFb[n0] = zero; }
+        const f16x8* frag = reinterpret_cast<const f16x8*>(smem + LD::off_frag) + lane;
+        const f16x8 hSel = reinterpret_cast<const f16x8*>(smem + LD::off_sel)[lane];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int b = 0; b < G_BIG; ++b) {
+            const f16x8 xb = __builtin_bit_cast(f16x8, x[b]);
+            f16x8 wa[H0C], wb[H0C];
+#pragma unroll
+            for (int n0 = 0; n0 < H0C; ++n0) { wa[n0] = frag[((b * 2 + n0) * 2 + 0) * 64]; wb[n0] = frag[((b * 2 + n0) * 2 + 1) * 64]; }
+#pragma unroll
+            for (int n0 = 0; n0 < H0C; ++n0) aFa[n0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[n0], xb, aFa[n0], 0, 0, 0);
+            aS = __builtin_amdgcn_mfma_f32_16x16x32_f16(hSel, xb, aS, 0, 0, 0);
+#pragma unroll
+            for (int n0 = 0; n0 < H0C; ++n0) aFb[n0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[n0], xb, aFb[n0], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        const float* wf = small_s + A.wf_off + r * 8 + q;
+#pragma unroll
+        for (int st = 0; st < 2; ++st)
+#pragma unroll
+            for (int n0 = 0; n0 < H0C; ++n0)
+                hA[n0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[n0 * 128 + 4 * st], st ? xn1 : xn0, hA[n0], 0, 0, 0);
+        s = fma4s(aS, A.unscale_s, s);
+#pragma unroll
+        for (int n0 = 0; n0 < H0C; ++n0) hB[n0] = (aFa[n0] + aFb[n0]) * A.unscale_h;
+    }
+    f32x4 h0[H0C];
+#pragma unroll
+    for (int n0 = 0; n0 < H0C; ++n0) h0[n0] = relu4_fast(hA[n0] + hB[n0]);
+    float z = dot4f(ld4(vq + LD::off_hfm), sq_diff4(s, pn));
+    {
+        f32x4 e = ld4(vq + LD::off_b1), o = zero;
+#pragma unroll
+        for (int j = 0; j < H0C; ++j) {
+            const f32x4 w = ld4(vq + LD::off_w1 + r * LD::S1 + 16 * j);
+            e = __builtin_amdgcn_mfma_f32_16x16x4f32(w.x, h0[j].x, e, 0, 0, 0);
+            o = __builtin_amdgcn_mfma_f32_16x16x4f32(w.y, h0[j].y, o, 0, 0, 0);
+            e = __builtin_amdgcn_mfma_f32_16x16x4f32(w.z, h0[j].z, e, 0, 0, 0);
+            o = __builtin_amdgcn_mfma_f32_16x16x4f32(w.w, h0[j].w, o, 0, 0, 0);
+        }
+        z += dot4f(ld4(vq + LD::off_hd), relu4_fast(e + o));
+    }
+    z += zz;
+    z += __shfl_xor(z, 16);
+    z += __shfl_xor(z, 32);
+    const float score = sigmoidf_fast(z + A.h0w * A.fo_bias + A.head_bias);
+    const int m = tk * 16 + r;
+    if (q == 0 && m < B) out[m] = score;
+    if (__ballot(bad) != 0 && lane == 0) atomicOr(err, 1);
+}

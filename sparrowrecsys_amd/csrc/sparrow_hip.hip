@@ -608,6 +608,7 @@ __global__ __launch_bounds__(256) void k_zero_columns(float* __restrict__ Wt, in
 
 #include "k_chain_v2.h"
 #include "k_chain_v2j.h"
+#include "k_chain_v2j1.h"
 #include "k_rows_chain.h"
 #include "k_din_attn.h"
 #include "dyn_split.h"
@@ -671,6 +672,7 @@ struct sprk_engine {
     hipEvent_t many_fork = nullptr, many_join[4] = {nullptr, nullptr, nullptr, nullptr};
     // register-chained pairwise-dot DeepFM (k_deepfm_pairs); -1 = the tile interpreter
     int v1_variant = -1;
+    bool v1_one = false;                  // one-batch launches use k_deepfm_pairs1 (one task per wave, four waves per SIMD)
     V1Run v1_run;
     std::vector<void*> v1_bufs;
     // register-chained DenseFeatures -> Dense -> Dense -> Dense(1) graphs (k_mlp_chain); -1 = the tile interpreter
@@ -716,6 +718,8 @@ struct sprk_engine {
     size_t v2_fo_floats = 0;
     // ... with the small-vocabulary fields folded into one joint table (k_deepfm_v2_joint); -1 = not used
     int v2j_variant = -1;
+    float* v2j1_image = nullptr;          // k_deepfm_v2_joint1 (one task per wave): its LDS image; NULL = shape not available
+    size_t v2j1_lds_bytes = 0;
     int many_batches = 1;                 // sprk_forward_many: batches scored per launch (sprk_set_many_batches)
     // "one row per id" chain (k_rows_chain): DeepFM_v2 with projections wider than 16 (the reference's Dense(64)) and NeuralCF
     int rows_variant = -1;
@@ -937,6 +941,21 @@ const V2JVariant kV2JVariants[] = {
     V2J_BOTH(3, 3),    // BASELINE config 2: movieId, userId, userRatedMovie1 + a joint table of the three genre fields
     V2J_BOTH(2, 2),    // the reference's own four fields (movieId, userId + two genres), config-4 shape
     V2J_BOTH(3, 2), V2J_BOTH(3, 1), V2J_BOTH(2, 3), V2J_BOTH(2, 1), V2J_BOTH(1, 3), V2J_BOTH(1, 2), V2J_BOTH(1, 1),
+};
+
+// k_deepfm_v2_joint1<G_BIG, NJF>: the one-task-per-wave shape of the split-f16 joint kernel (k_chain_v2j1.h)
+typedef void (*V2J1LaunchFn)(const V2JRun&, const int*, const float*, float*, int, int*, const float*, int, size_t, hipStream_t);
+template <int G_BIG, int NJF>
+void v2j1_launch(const V2JRun& a, const int* ids, const float* dense, float* out, int B, int* err, const float* image, int grid,
+                 size_t lds, hipStream_t st) {
+    hipLaunchKernelGGL((k_deepfm_v2_joint1<G_BIG, NJF>), dim3(grid), dim3(V2J1_WAVES * 64), lds, st, a, ids, dense, out, B, err, image);
+}
+struct V2J1Variant { int g_big, njf; const void* fn; V2J1LaunchFn launch; int image_floats; };
+#define V2J1_VARIANT(G_BIG, NJF) \
+    {G_BIG, NJF, reinterpret_cast<const void*>(&k_deepfm_v2_joint1<G_BIG, NJF>), &v2j1_launch<G_BIG, NJF>, V2J1Lds<G_BIG>::total_pad}
+const V2J1Variant kV2J1Variants[] = {
+    V2J1_VARIANT(3, 3), V2J1_VARIANT(2, 2), V2J1_VARIANT(3, 2), V2J1_VARIANT(3, 1), V2J1_VARIANT(2, 3), V2J1_VARIANT(2, 1),
+    V2J1_VARIANT(1, 3), V2J1_VARIANT(1, 2), V2J1_VARIANT(1, 1),
 };
 
 // Recognise the plan models.DeepFMv2 emits (DeepFM_v2.py graph) and fill the fused kernel's arguments.
@@ -1198,6 +1217,20 @@ int setup_v2_joint(sprk_engine* h) {
     HIP_TRY(hipFuncSetAttribute(kV2JVariants[variant].fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->v2j_lds_bytes));
     HIP_TRY(hipFuncSetAttribute(kV2JVariants[variant].fn_many, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->v2j_lds_bytes));
     h->v2j_variant = variant;
+    // the one-task-per-wave shape for strict one-batch launches (k_chain_v2j1.h); SPRK_V2J_ONE=0: looped kernel only
+    const char* one = getenv("SPRK_V2J_ONE");
+    if (half && !(one && one[0] == '0')) {
+        for (size_t v = 0; v < sizeof(kV2J1Variants) / sizeof(kV2J1Variants[0]); ++v) {
+            const V2J1Variant& ov = kV2J1Variants[v];
+            if (ov.g_big != nbig || ov.njf != njf) continue;
+            HIP_TRY(hipMalloc((void**)&h->v2j1_image, (size_t)ov.image_floats * sizeof(float)));
+            hipLaunchKernelGGL(k_v2j1_pack_image, dim3(1), dim3(256), 0, 0, h->v2, r, nbig, G + 1, h->v2j1_image);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipDeviceSynchronize());
+            h->v2j1_lds_bytes = ((size_t)ov.image_floats + small_floats + (size_t)V2J1_WAVES * 256) * sizeof(float);
+            HIP_TRY(hipFuncSetAttribute(ov.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->v2j1_lds_bytes));
+        }
+    }
     return SPRK_OK;
 }
 
@@ -1639,45 +1672,57 @@ int make_dyn_fragments(sprk_engine* h, const float* W, int ld, int N, int K, flo
     return SPRK_OK;
 }
 
-// ---- dispatch table for k_deepfm_pairs<NF, NV, H0C, H1C, WAVES> ----
+// ---- dispatch table for k_deepfm_pairs<NF, NV, H0C, H1C, WAVES, DYN, SEP> ----
 constexpr int V1_WAVES = 8;
+constexpr int V1_ONE_MAX_TASKS = 16384;       // one-task-per-wave shape (k_deepfm_pairs1) up to B = 262 144
 typedef void (*V1LaunchFn)(const V1Run&, const int*, const float*, float*, int, int*, int, hipStream_t);
 typedef void (*V1LaunchManyFn)(const V1Run&, const V1Many&, int, int*, int, hipStream_t);
-template <int NF, int NV>
+template <int NF, int NV, bool SEP>
 void v1_launch(const V1Run& a, const int* ids, const float* dense, float* out, int B, int* err, int grid, hipStream_t st) {
     const size_t lds = V1Lds<4, 4, (NV + 3) / 4>::bytes;
     if (a.inv_w1_scale != 0.f)
-        hipLaunchKernelGGL((k_deepfm_pairs<NF, NV, 4, 4, V1_WAVES, true>), dim3(grid), dim3(V1_WAVES * 64), lds, st, a, ids, dense, out, B, err);
+        hipLaunchKernelGGL((k_deepfm_pairs<NF, NV, 4, 4, V1_WAVES, true, SEP>), dim3(grid), dim3(V1_WAVES * 64), lds, st, a, ids, dense, out, B, err);
     else
-        hipLaunchKernelGGL((k_deepfm_pairs<NF, NV, 4, 4, V1_WAVES, false>), dim3(grid), dim3(V1_WAVES * 64), lds, st, a, ids, dense, out, B, err);
+        hipLaunchKernelGGL((k_deepfm_pairs<NF, NV, 4, 4, V1_WAVES, false, SEP>), dim3(grid), dim3(V1_WAVES * 64), lds, st, a, ids, dense, out, B, err);
 }
-template <int NF, int NV>
+// one task per wave (narrow rows, split-f16 form only): grid = ceil(tasks / waves), no cap
+template <int NF, int NV, bool SEP>
+void v1_launch_one(const V1Run& a, const int* ids, const float* dense, float* out, int B, int* err, int grid, hipStream_t st) {
+    if constexpr (NV <= 4) {
+        const size_t lds = V1Lds<4, 4, 1>::bytes;
+        hipLaunchKernelGGL((k_deepfm_pairs1<NF, NV, 4, 4, V1_WAVES, SEP>), dim3(grid), dim3(V1_WAVES * 64), lds, st, a, ids, dense, out, B, err);
+    }
+}
+template <int NF, int NV, bool SEP>
 void v1_launch_many(const V1Run& a, const V1Many& m, int B, int* err, int grid, hipStream_t st) {
     const size_t lds = V1Lds<4, 4, (NV + 3) / 4>::bytes;
     if (a.inv_w1_scale != 0.f)
-        hipLaunchKernelGGL((k_deepfm_pairs_many<NF, NV, 4, 4, V1_WAVES, true>), dim3(grid), dim3(V1_WAVES * 64), lds, st, a, m, B, err);
+        hipLaunchKernelGGL((k_deepfm_pairs_many<NF, NV, 4, 4, V1_WAVES, true, SEP>), dim3(grid), dim3(V1_WAVES * 64), lds, st, a, m, B, err);
     else
-        hipLaunchKernelGGL((k_deepfm_pairs_many<NF, NV, 4, 4, V1_WAVES, false>), dim3(grid), dim3(V1_WAVES * 64), lds, st, a, m, B, err);
+        hipLaunchKernelGGL((k_deepfm_pairs_many<NF, NV, 4, 4, V1_WAVES, false, SEP>), dim3(grid), dim3(V1_WAVES * 64), lds, st, a, m, B, err);
 }
-template <int NF, int NV>
+template <int NF, int NV, bool SEP>
 int v1_prepare(const V1Run& r, float* img) {
     constexpr int PC = (NV + 3) / 4;
     hipLaunchKernelGGL((k_v1_pack_image<4, 4, PC>), dim3(1), dim3(256), 0, 0, r, img);
     HIP_TRY(hipGetLastError());
     const size_t lds = V1Lds<4, 4, PC>::bytes;
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_deepfm_pairs<NF, NV, 4, 4, V1_WAVES, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_deepfm_pairs<NF, NV, 4, 4, V1_WAVES, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_deepfm_pairs_many<NF, NV, 4, 4, V1_WAVES, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_deepfm_pairs_many<NF, NV, 4, 4, V1_WAVES, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_deepfm_pairs<NF, NV, 4, 4, V1_WAVES, true, SEP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_deepfm_pairs<NF, NV, 4, 4, V1_WAVES, false, SEP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_deepfm_pairs_many<NF, NV, 4, 4, V1_WAVES, true, SEP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_deepfm_pairs_many<NF, NV, 4, 4, V1_WAVES, false, SEP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if constexpr (NV <= 4)
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_deepfm_pairs1<NF, NV, 4, 4, V1_WAVES, SEP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     return SPRK_OK;
 }
-struct V1Variant { int nf, nv; V1LaunchFn launch; V1LaunchManyFn launch_many; int (*prepare)(const V1Run&, float*); size_t lds_bytes; };
-#define V1_VARIANT(NF, NV) {NF, NV, &v1_launch<NF, NV>, &v1_launch_many<NF, NV>, &v1_prepare<NF, NV>, V1Lds<4, 4, (NV + 3) / 4>::bytes}
+struct V1Variant { int nf, nv; bool sep; V1LaunchFn launch; V1LaunchFn launch_one; V1LaunchManyFn launch_many; int (*prepare)(const V1Run&, float*); size_t lds_bytes; };
+#define V1_VARIANT(NF, NV, SEP) {NF, NV, SEP, &v1_launch<NF, NV, SEP>, &v1_launch_one<NF, NV, SEP>, &v1_launch_many<NF, NV, SEP>, &v1_prepare<NF, NV, SEP>, V1Lds<4, 4, (NV + 3) / 4>::bytes}
+#define V1_BOTH(NF, NV) V1_VARIANT(NF, NV, true), V1_VARIANT(NF, NV, false)
 const V1Variant kV1Variants[] = {
-    V1_VARIANT(6, 4),    // BASELINE config 2: 6 fields, emb_dim 16, deep 64-64
-    V1_VARIANT(4, 3),    // the reference's own DeepFM.py: 4 fields, emb_dim 10 (rows padded to 12)
-    V1_VARIANT(4, 4),
-    V1_VARIANT(4, 16),   // BASELINE config 4: emb_dim 64 -- 256-byte rows gathered whole (four pieces per lane)
+    V1_BOTH(6, 4),    // BASELINE config 2: 6 fields, emb_dim 16, deep 64-64 (sep = the deep part's own movieId / userId tables, DeepFM.py:106)
+    V1_BOTH(4, 3),    // the reference's own DeepFM.py: 4 fields, emb_dim 10 (rows padded to 12)
+    V1_BOTH(4, 4),
+    V1_BOTH(4, 16),   // BASELINE config 4: emb_dim 64 -- 256-byte rows gathered whole (four pieces per lane)
 };
 
 // Recognise the plan models.DeepFM emits (DeepFM.py graph: pair dots + first order + 2-layer deep part) and set up
@@ -1695,13 +1740,28 @@ int setup_deepfm_pairs(sprk_engine* h) {
     memset(&r, 0, sizeof(r));
     int row_dst[V1_MAX_FIELDS], nf = 0, Dp = 0, num_dst = -1, scal_dst[V1_MAX_FIELDS], ns = 0, scal_col[V1_MAX_FIELDS], scal_vocab[V1_MAX_FIELDS];
     const float* scal_tab[V1_MAX_FIELDS];
+    // the deep part's OWN tables (models.DeepFM without share_deep_tables; DeepFM.py:106): a ROWS segment that lands inside deep0's
+    // input slice while ANOTHER ROWS segment of the same ids column lands outside it (the FM part's table of that key)
+    const int ds0 = o0.src_off, ds1 = o0.src_off + o0.K;
+    int dsep_col[V1_MAX_DEEP], dsep_vocab[V1_MAX_DEEP], dsep_dst[V1_MAX_DEEP], n_dsep = 0;
+    const float* dsep_tab[V1_MAX_DEEP];
     for (int i = 0; i < p.n_segs; ++i) {
         const sprk_seg& sg = p.segs[i];
         if (sg.kind == SPRK_SEG_ROWS) {
-            if (nf == V1_MAX_FIELDS) return SPRK_OK;
-            if (nf == 0) Dp = sg.row_stride;
+            if (nf == 0 && n_dsep == 0) Dp = sg.row_stride;
             if (sg.row_stride != Dp || sg.count * 4 != Dp || Dp > 64) return SPRK_OK;
             if (h->slot_bytes[sg.slot] < ((size_t)sg.vocab + 1) * Dp * sizeof(float)) return SPRK_OK;   // needs the zero row at index vocab
+            bool twin_outside = false;
+            for (int j = 0; j < p.n_segs; ++j)
+                if (j != i && p.segs[j].kind == SPRK_SEG_ROWS && p.segs[j].field == sg.field &&
+                    !(p.segs[j].dst >= ds0 && p.segs[j].dst + p.segs[j].row_stride <= ds1)) twin_outside = true;
+            if (twin_outside && sg.dst >= ds0 && sg.dst + Dp <= ds1) {
+                if (n_dsep == V1_MAX_DEEP) return SPRK_OK;
+                dsep_col[n_dsep] = sg.field; dsep_vocab[n_dsep] = sg.vocab; dsep_tab[n_dsep] = (const float*)h->slot_ptr[sg.slot];
+                dsep_dst[n_dsep++] = sg.dst;
+                continue;
+            }
+            if (nf == V1_MAX_FIELDS) return SPRK_OK;
             r.col[nf] = sg.field; r.vocab[nf] = sg.vocab; r.table[nf] = (const float*)h->slot_ptr[sg.slot];
             row_dst[nf++] = sg.dst;
         } else if (sg.kind == SPRK_SEG_SCALAR) {
@@ -1745,17 +1805,30 @@ int setup_deepfm_pairs(sprk_engine* h) {
         if (a > b) { const int t = a; a = b; b = t; }
         r.pw[a * V1_MAX_FIELDS + b] += pwh[i];
     }
-    // deep part: the embedding columns inside deep0's input slice (at most V1_MAX_DEEP) become fields 0.. of the kernel
-    const int s0 = o0.src_off, s1 = o0.src_off + o0.K;
+    // deep part: the embedding columns inside deep0's input slice (at most V1_MAX_DEEP).  Tied tables: they are FM fields, which
+    // become fields 0.. of the kernel.  Own tables (n_dsep > 0): every deep column must be one of them, and the FM fields with the
+    // same ids columns become fields 0.. (the kernel looks deep row d up with field d's id).
+    const int s0 = ds0, s1 = ds1;
     if (num_dst < s0 || num_dst + r.n_num > s1) return SPRK_OK;
     int order[V1_MAX_FIELDS], no = 0, deep_off[V1_MAX_DEEP] = {0, 0};
+    const bool sep = n_dsep > 0;
     for (int f = 0; f < nf; ++f) {
         if (row_dst[f] >= s0 && row_dst[f] + Dp <= s1) {
-            if (r.n_deep == V1_MAX_DEEP) return SPRK_OK;
+            if (sep || r.n_deep == V1_MAX_DEEP) return SPRK_OK;
             deep_off[r.n_deep++] = row_dst[f] - s0;
             order[no++] = f;
         } else if (row_dst[f] < s1 && row_dst[f] + Dp > s0) {
             return SPRK_OK;
+        }
+    }
+    if (sep) {
+        for (int d = 0; d < n_dsep; ++d) {
+            int twin = -1;
+            for (int f = 0; f < nf; ++f) if (r.col[f] == dsep_col[d] && r.vocab[f] == dsep_vocab[d]) twin = f;
+            if (twin < 0) return SPRK_OK;
+            for (int i = 0; i < no; ++i) if (order[i] == twin) return SPRK_OK;
+            deep_off[r.n_deep++] = dsep_dst[d] - s0;
+            order[no++] = twin;
         }
     }
     for (int f = 0; f < nf; ++f) {
@@ -1782,9 +1855,12 @@ int setup_deepfm_pairs(sprk_engine* h) {
             }
         r = t;
     }
+    r.sep = sep ? 1 : 0;
+    for (int d = 0; d < n_dsep; ++d) r.table[nf + d] = dsep_tab[d];
+    const float* const* deep_tables = sep ? &r.table[nf] : &r.table[0];   // tables deep0's embedding block reads
     int variant = -1;
     for (size_t v = 0; v < sizeof(kV1Variants) / sizeof(kV1Variants[0]); ++v)
-        if (kV1Variants[v].nf == nf && kV1Variants[v].nv == Dp / 4) variant = (int)v;
+        if (kV1Variants[v].nf == nf && kV1Variants[v].nv == Dp / 4 && kV1Variants[v].sep == sep) variant = (int)v;
     if (variant < 0) return SPRK_OK;
     const int H0 = o0.N, H1 = o1.N;
     const float* W0 = (const float*)h->slot_ptr[o0.w_slot];
@@ -1837,7 +1913,7 @@ int setup_deepfm_pairs(sprk_engine* h) {
                 const long long rows = (long long)r.vocab[f] + 1;
                 long long blocks = (rows * Dp + 255) / 256;
                 if (blocks > 8192) blocks = 8192;
-                hipLaunchKernelGGL(k_v2_absmax, dim3((unsigned)blocks), dim3(256), 0, 0, r.table[f], rows, Dp, Dp, d_max);
+                hipLaunchKernelGGL(k_v2_absmax, dim3((unsigned)blocks), dim3(256), 0, 0, deep_tables[f], rows, Dp, Dp, d_max);
             }
             HIP_TRY(hipGetLastError());
             unsigned bits = 0;
@@ -1846,7 +1922,7 @@ int setup_deepfm_pairs(sprk_engine* h) {
             float mx;
             memcpy(&mx, &bits, sizeof(mx));
             for (int f = 0; f < r.n_deep && !wide && mx > 0.f && mx < 3.0e38f; ++f)
-                if (int rcw = wide_dynamic_range(r.table[f], (long long)r.vocab[f] + 1, Dp, Dp, mx, &wide)) return rcw;
+                if (int rcw = wide_dynamic_range(deep_tables[f], (long long)r.vocab[f] + 1, Dp, Dp, mx, &wide)) return rcw;
             if (mx > 0.f && mx < 3.0e38f && !wide) {
                 int e = 0;
                 (void)frexpf(mx, &e);
@@ -1861,26 +1937,36 @@ int setup_deepfm_pairs(sprk_engine* h) {
     r.tab = nullptr;
     const char* rt = getenv("SPRK_V1_ROWTAB");                // A/B switch: "0" = gather from the uploaded tables
     if (PC == 1 && !(rt && rt[0] == '0')) {
+        // own deep tables: rows of <= 12 floats ride in their field's line (float 20..), wider ones get rows of their own
+        const bool pack = sep && Dp <= 12;
         size_t rows = 0;
         for (int f = 0; f < nf; ++f) rows += (size_t)r.vocab[f] + 1;
+        if (sep && !pack) for (int d = 0; d < r.n_deep; ++d) rows += (size_t)r.vocab[d] + 1;
         if (rows * 128 < ((size_t)1 << 32)) {                     // 32-bit byte offsets
             float* tab = nullptr;
             HIP_TRY(hipMalloc((void**)&tab, rows * 128));
             h->v1_bufs.push_back(tab);
             h->derived_bytes += rows * 128;
             size_t base = 0;
-            for (int f = 0; f < nf; ++f) {
-                const long long n = (long long)r.vocab[f] + 1;
+            for (int f = 0; f < nf + ((sep && !pack) ? r.n_deep : 0); ++f) {
+                const bool deep_row = f >= nf;
+                const long long n = (long long)r.vocab[deep_row ? f - nf : f] + 1;
                 long long nb = (n * 32 + 255) / 256;
                 if (nb > 65536) nb = 65536;
-                hipLaunchKernelGGL(k_v1_build_rows, dim3((unsigned)nb), dim3(256), 0, 0, r.table[f], Dp, r.w1[f], n, tab + base * 32);
+                hipLaunchKernelGGL(k_v1_build_rows, dim3((unsigned)nb), dim3(256), 0, 0, r.table[f], Dp, deep_row ? (const float*)nullptr : r.w1[f], n,
+                                   tab + base * 32, (pack && f < r.n_deep) ? r.table[nf + f] : (const float*)nullptr);
                 r.rowbase[f] = (unsigned)base;
                 base += (size_t)n;
             }
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipDeviceSynchronize());
             r.tab = tab;
+            r.pack = pack ? 1 : 0;
         }
+    }
+    {
+        const char* one = getenv("SPRK_V1_ONE");               // A/B switch: "0" = looped kernel for one-batch launches too
+        h->v1_one = r.tab && r.w1frag && PC == 1 && !(one && one[0] == '0');
     }
     h->v1_run = r;
     h->v1_variant = variant;
@@ -2675,6 +2761,16 @@ int sprk_forward(sprk_handle h, const int32_t* ids, const float* dense, float* o
         if (h->v2j_variant >= 0 && !run.trace && !(run.flags & ~1)) {
             V2JRun jr = h->v2j_run;
             jr.flags = run.flags;
+            if (h->v2j1_image && ntasks <= V2J1_MAX_TASKS) {
+                // one strict launch of one batch: one task per wave, four waves per SIMD (k_chain_v2j1.h)
+                for (size_t v = 0; v < sizeof(kV2J1Variants) / sizeof(kV2J1Variants[0]); ++v)
+                    if (kV2J1Variants[v].g_big == kV2JVariants[h->v2j_variant].g_big && kV2J1Variants[v].njf == kV2JVariants[h->v2j_variant].njf) {
+                        kV2J1Variants[v].launch(jr, ids, dense, out, B, h->dev_err, h->v2j1_image, (ntasks + V2J1_WAVES - 1) / V2J1_WAVES,
+                                                h->v2j1_lds_bytes, st);
+                        HIP_TRY(hipGetLastError());
+                        return SPRK_OK;
+                    }
+            }
             kV2JVariants[h->v2j_variant].launch(jr, ids, dense, out, B, h->dev_err, h->v2_image, grid, h->v2j_lds_bytes, st);
             HIP_TRY(hipGetLastError());
             return SPRK_OK;
@@ -2697,7 +2793,10 @@ int sprk_forward(sprk_handle h, const int32_t* ids, const float* dense, float* o
         const int ntasks = (B + 15) / 16;
         int grid = (ntasks + V1_WAVES - 1) / V1_WAVES;
         if (grid > h->num_cus) grid = h->num_cus;                  // one 8-wave workgroup per CU (2 waves per SIMD; 3 per SIMD measured slower at B = 65 536)
-        kV1Variants[h->v1_variant].launch(h->v1_run, ids, dense, out, B, h->dev_err, grid, st);
+        if (h->v1_one && ntasks <= V1_ONE_MAX_TASKS)
+            kV1Variants[h->v1_variant].launch_one(h->v1_run, ids, dense, out, B, h->dev_err, (ntasks + V1_WAVES - 1) / V1_WAVES, st);
+        else
+            kV1Variants[h->v1_variant].launch(h->v1_run, ids, dense, out, B, h->dev_err, grid, st);
         HIP_TRY(hipGetLastError());
         return SPRK_OK;
     }
@@ -3015,6 +3114,7 @@ void sprk_destroy(sprk_handle h) {
     for (void* q : h->mlp_rows_bufs) if (q) (void)hipFree(q);
     for (void* p : h->v1_bufs) if (p) (void)hipFree(p);
     if (h->v2j_big) (void)hipFree(h->v2j_big);
+    if (h->v2j1_image) (void)hipFree(h->v2j1_image);
     if (h->rows_tab) (void)hipFree(h->rows_tab);
     if (h->rows_scal) (void)hipFree(h->rows_scal);
     if (h->rows_small) (void)hipFree(h->rows_small);

@@ -397,6 +397,36 @@ def test_deepfm_v2_joint_field_splits(torch, monkeypatch, fields):
         assert np.abs(o - ref).max() <= TIGHT
 
 
+@pytest.mark.parametrize("fields", [
+    SY.CONFIG2_FIELDS,
+    [("movieId", "id", 3000), ("userId", "id", 9000), ("userGenre1", "genre", 19), ("movieGenre1", "genre", 19)],
+    [("movieId", "id", 3000), ("userGenre1", "genre", 19), ("userGenre2", "genre", 19), ("movieGenre1", "genre", 19)],
+], ids=["config2", "2big+2small", "1big+3small"])
+def test_v2_joint1_bit_identical_to_joint(torch, monkeypatch, fields):
+    """k_deepfm_v2_joint1 (one task per wave, four waves per SIMD: the strict one-batch launch, k_chain_v2j1.h) against
+    k_deepfm_v2_joint (SPRK_V2J_ONE=0): same arithmetic in the same order => the same bits; ragged tails, a batch of one
+    partial task, missing ids, unaligned buffers (a row-offset view), and the oracle."""
+    order = [k for k, _, _ in fields]
+    for B in (65536, 5003, 16, 7, 1):
+        feats = SY.synth_fields(B, fields, seed=77 + B)
+        outs = []
+        for one in ("1", "0"):
+            monkeypatch.setenv("SPRK_V2J_ONE", one)
+            model = M.DeepFMv2(seed=46, emb_dim=16, fields=fields, proj_dim=16)
+            ids, dense = model.pack(feats)
+            ids_t, dense_t = torch.from_numpy(ids).cuda(), torch.from_numpy(dense).cuda()
+            got = model.predict_device(ids_t, dense_t).cpu().numpy()
+            if B > 16:                                                    # rows 1.. of the same buffers: not 16-byte aligned
+                tail = model.predict_device(ids_t[1:], dense_t[1:]).cpu().numpy()
+                assert np.array_equal(tail, got[1:])
+            model.engine.check_ids()
+            outs.append(got)
+        assert np.array_equal(outs[0], outs[1]), "B=%d: joint1 and joint differ by %g" % (B, np.abs(outs[0] - outs[1]).max())
+        n = min(B, 4096)
+        ref = O.deepfm_v2_forward({k: v[:n] for k, v in feats.items()}, model.weights, dtype=np.float64, fields=fields, order=order)[:, 0]
+        assert np.abs(outs[0][:n] - ref).max() <= TIGHT
+
+
 def test_deepfm_v2_split_f16_is_fp32_class(torch, monkeypatch):
     """The split-f16 MFMA path (hi + lo halfs, f32 accumulate) must be as close to the fp64 oracle as the
     f32 MFMA path is -- on the pre-sigmoid scale too, with O(1) numerics so that the score is not saturated
@@ -567,8 +597,12 @@ def test_din_tail_dynamic_f16_wide_activation_range(torch, monkeypatch, scale):
 # --------------------------------------------------------------------------------------------
 # k_deepfm_pairs: the pairwise-dot DeepFM graph (DeepFM.py) as a register-chained kernel
 # --------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("tied", [False, True], ids=["own-deep-tables", "tied-tables"])
 @pytest.mark.parametrize("shape", ["reference", "config2", "config2-zipf-ragged"])
-def test_deepfm_pairs_kernel_vs_interpreter_and_oracle(torch, monkeypatch, shape):
+def test_deepfm_pairs_kernel_vs_interpreter_and_oracle(torch, monkeypatch, shape, tied):
+    """``tied`` = False is the reference's graph (the deep part owns its movieId / userId tables, DeepFM.py:106: rows packed in
+    the field's line at emb_dim 10, rows of their own at emb_dim 16); True shares one table per key.  Each through the
+    one-task-per-wave kernel (the one-batch launch), the looped kernel (SPRK_V1_ONE=0), f32 MFMA, and the interpreter."""
     if shape == "reference":
         fields, pairs, D, B, dist = None, None, 10, 2049, "uniform"       # DeepFM.py literals: 4 fields, 4 pairs, emb_dim 10
         feats = SY.synth_fields(B, M._default_fields(), seed=71)
@@ -577,14 +611,19 @@ def test_deepfm_pairs_kernel_vs_interpreter_and_oracle(torch, monkeypatch, shape
         B, dist = (16384, "uniform") if shape == "config2" else (10007, "zipf")
         feats = SY.synth_fields(B, fields, seed=72, dist=dist)
     out = {}
-    for chain, dyn in (("1", "1"), ("1f32", "0"), ("0", "1")):          # chain kernel with deep1 on split-f16 / on f32 MFMA, interpreter
+    for chain, dyn, one in (("1", "1", "1"), ("1loop", "1", "0"), ("1f32", "0", "1"), ("0", "1", "1")):   # pairs1 / looped / f32 MFMA / interpreter
         monkeypatch.setenv("SPRK_V1_CHAIN", chain[0])
         monkeypatch.setenv("SPRK_DYN_F16", dyn)
-        model = M.DeepFM(seed=46, emb_dim=D, fields=fields, pairs=pairs)
+        monkeypatch.setenv("SPRK_V1_ONE", one)
+        model = M.DeepFM(seed=46, emb_dim=D, fields=fields, pairs=pairs, share_deep_tables=tied)
+        if chain != "0":
+            assert model.engine.describe()["kernel"].startswith("k_deepfm_pairs")
         out[chain] = model.predict(feats)[:, 0]
+    assert ("deep_emb/movieId" in model.weights) != tied
     kw = {} if fields is None else {"fields": fields, "pairs": pairs}
     ref = O.deepfm_forward(feats, model.weights, dtype=np.float64, **kw)[:, 0]
     assert np.abs(out["1"] - ref).max() <= TIGHT
+    assert np.array_equal(out["1"], out["1loop"]), "one-task and looped kernels differ by %g" % np.abs(out["1"] - out["1loop"]).max()
     assert np.abs(out["1f32"] - ref).max() <= TIGHT
     assert np.abs(out["1"] - ref).max() <= 2 * np.abs(out["1f32"] - ref).max() + 2e-6
     assert np.abs(out["0"] - ref).max() <= TIGHT
