@@ -145,10 +145,30 @@ def build_workload(name, B, dist_name, seed_offset=0, big_vocab=0, NB=8):
         model._bench_fields = fields
         roof = {"bound": "hbm", "kernel": "?", "bytes_per_sample": 2 * 4 + 2 * 40 + 4}
         return model, synth(fields), desc, roof
-    if name == "din_c3":
-        T, D = 50, 32
+    if name == "deepfm_ref":
+        # DeepFM.py as written (4 fields, emb_dim 10, 4 pair dots, deep 64-64, the deep part's own movieId / userId tables) on
+        # MovieLens-20M-sized vocabularies
+        fields = [("movieId", "id", SY.ML20M_MOVIE_IDS), ("userId", "id", SY.ML20M_USER_IDS),
+                  ("userGenre1", "genre", N_GENRES), ("movieGenre1", "genre", N_GENRES)]
+        model = M.DeepFM(seed=113, emb_dim=10, fields=fields)
+        model._bench_fields = fields
+        desc = "DeepFM.py literal: 4 fields, emb_dim=10, 4 pair dots, deep 64-64, own deep tables"
+        roof = {"bound": "hbm", "kernel": "?", "bytes_per_sample": 4 * 4 + 4 * 40 + 2 * 40 + 4 * 4 + 7 * 4 + 4,
+                "mfma_reference_flops": 2 * (27 * 64 + 64 * 64 + 64)}
+        return model, synth(fields), desc, roof
+    if name == "embedding_mlp_ref":
+        model = M.EmbeddingMLP(seed=115, emb_dim=10, movie_buckets=SY.ML20M_MOVIE_IDS, user_buckets=SY.ML20M_USER_IDS)
+        desc = "EmbeddingMLP.py literal: 10 embedding columns emb_dim=10 + 7 numerics, 107->128->128->1"
+        feats = [SY.synth_embedding_mlp(B, SY.ML20M_MOVIE_IDS, SY.ML20M_USER_IDS, seed=SY.SEED + 1000 * seed_offset + i, dist=dist_name)
+                 for i in range(NB)]
+        roof = {"bound": "hbm", "kernel": "?", "bytes_per_sample": 10 * 4 + 10 * 40 + 7 * 4 + 4,
+                "mfma_reference_flops": 2 * (107 * 128 + 128 * 128 + 128)}
+        return model, feats, desc, roof
+    if name in ("din_c3", "din_ref"):
+        T, D = (50, 32) if name == "din_c3" else (5, 10)         # din_ref: DIN.py as written (RECENT_MOVIES = 5, EMBEDDING_SIZE = 10)
         model = M.DIN(seed=103, emb_dim=D, hist_len=T, movie_buckets=SY.ML20M_MOVIE_IDS, user_buckets=SY.ML20M_USER_IDS)
-        desc = "DIN, hist_len=50, emb_dim=32, attention 128->32->1, tail 167->128->64->1"
+        desc = ("DIN, hist_len=50, emb_dim=32, attention 128->32->1, tail 167->128->64->1" if name == "din_c3" else
+                "DIN.py literal: hist_len=5, emb_dim=10, attention 40->32->1, tail 57->128->64->1")
         feats = [SY.synth_din(B, T, SY.ML20M_MOVIE_IDS, SY.ML20M_USER_IDS, seed=SY.SEED + 1000 * seed_offset + i, dist=dist_name) for i in range(NB)]
         flops = T * (2 * 4 * D * 32 + 2 * 32 + 3 * 32)            # the reference's count: K = 4D per (b,t)
         # what k_din_attn issues on the matrix pipe: K = D per (b,t) after folding the c-only and h-only
@@ -158,7 +178,7 @@ def build_workload(name, B, dist_name, seed_offset=0, big_vocab=0, NB=8):
         roof = {"bound": "mfma", "kernel": "k_din_pool" if legacy else "k_din_attn", "flops_per_sample": flops,
                 "executed_flops_per_sample": flops if legacy else executed,
                 "bytes_per_sample": (T + 1) * 4 + (T + 1) * D * 4 + D * 4,
-                "tail_reference_flops": 2 * (167 * 128 + 128 * 64 + 64)}
+                "tail_reference_flops": 2 * ((7 + 5 * D) * 128 + 128 * 64 + 64)}
         return model, feats, desc, roof
     if name == "widedeep_c5":
         # BASELINE configs[4], one GPU's share: Wide&Deep, hashed cross (movieId x userRatedMovie1) computed on device into a
@@ -202,8 +222,10 @@ def oracle_forward(name, model, feats, dtype=np.float32):
         feats, weights, fields = compact_for_oracle(model, feats, fields)
     if name in ("deepfm_v2_c2", "deepfm_v2_c4", "deepfm_v2_ref"):
         return O.deepfm_v2_forward(feats, weights, dtype=dtype, fields=fields, order=model.order)
-    if name in ("deepfm_c2", "deepfm_c4"):
+    if name in ("deepfm_c2", "deepfm_c4", "deepfm_ref"):
         return O.deepfm_forward(feats, weights, dtype=dtype, fields=fields, pairs=model.pairs)
+    if name == "embedding_mlp_ref":
+        return O.embedding_mlp_forward(feats, weights, dtype=dtype, movie_buckets=model.movie_buckets, user_buckets=model.user_buckets)
     if name == "neuralcf_ref":
         return O.neural_cf_forward(feats, weights, dtype=dtype, movie_buckets=model.movie_buckets, user_buckets=model.user_buckets)
     if name == "widedeep_c5":
@@ -491,12 +513,13 @@ def main():
             dist.init_process_group("gloo")
 
     B = args.batch or {"din_c3": 32768, "widedeep_c5": 131072}.get(args.workload, 65536)
-    nb_in = args.input_batches or {"deepfm_v2_c2": 32, "deepfm_c2": 16, "din_c3": 16}.get(args.workload, 8)
+    nb_in = args.input_batches or {"deepfm_v2_c2": 32, "deepfm_c2": 16, "din_c3": 16, "din_ref": 16}.get(args.workload, 8)
     if args.batch and args.batch > 262144:
         nb_in = min(nb_in, 8)
     model, feats, desc, roof = build_workload(args.workload, B, args.dist, seed_offset=rank, big_vocab=args.big_vocab, NB=nb_in)
     eng = model.engine
-    roof["kernel"] = eng.kernel_name() if args.workload != "din_c3" else roof["kernel"]   # what the handle really dispatches to
+    is_din = args.workload in ("din_c3", "din_ref")
+    roof["kernel"] = eng.kernel_name() if not is_din else roof["kernel"]   # what the handle really dispatches to
     env = os.environ.get
     lb = 1
     if args.launch_batches > 1 and env("SPRK_FORCE_INTERPRETER") != "1":
@@ -504,11 +527,11 @@ def main():
             lb = args.launch_batches
         elif roof["kernel"] == "k_deepfm_pairs":
             lb = min(args.launch_batches, 16)
-        elif args.workload == "din_c3" and env("SPRK_DIN_LEGACY") != "1" and env("SPRK_DIN_TAIL") != "0":
+        elif is_din and env("SPRK_DIN_LEGACY") != "1" and env("SPRK_DIN_TAIL") != "0" and eng.kernel_name() == "k_din_tail":
             lb = min(args.launch_batches, 16)   # groups of batches: one attention + one tail launch each, alternating streams
     if lb > 1:
         eng.set_many_batches(lb)
-        if args.workload != "din_c3":
+        if not is_din:
             args.overlap_streams = 0           # several batches per launch: strict order measured faster than the fan-out
     fan = args.overlap_streams if (args.overlap_streams >= 2 and eng.set_many_streams(args.overlap_streams)) else 0
     batches = []
@@ -617,7 +640,7 @@ def main():
     n_strict = int(max(K, min(20000, math.ceil(0.02 / max(blk / K, 1e-9)))))
     fwd_s = strict_loop(eng, batches, outs, ws, n_strict, lb, fan)
     fan2_s = None
-    if not dist_on and lb > 1 and args.workload != "din_c3":
+    if not dist_on and lb > 1 and not is_din:
         # one batch per launch, independent batches alternating over two helper streams (still a launch per batch)
         eng.set_many_batches(1)
         eng.set_many_streams(2)
@@ -993,14 +1016,25 @@ def dry_run(args, rank, world):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo")
     B, K = args.batch or 1024, args.steps
-    got = []
-    gs = GroupedScoreGather(B, max(1, args.gather_group), "cpu", sink=lambda gi, view, nb: got.append(float(view.sum()))) if dist_on else None
+    got, queued = [], []
+
+    def sink(gi, view, nb):
+        # every rank's slice of every batch of the group, in step order: rank r wrote r * 1000 + step % 7 into all B slots
+        want = [queued.pop(0) for _ in range(nb)]
+        ok = tuple(view.shape) == (world, nb, B)
+        for r in range(world):
+            for j in range(nb):
+                ok = ok and bool((view[r, j] == float(r * 1000 + want[j])).all())
+        got.append(ok)
+
+    gs = GroupedScoreGather(B, max(1, args.gather_group), "cpu", sink=sink) if dist_on else None
     scratch = torch.empty(B)
 
     def run_steps(first, count):
         for i in range(first, first + count):
             out = gs.out() if gs is not None else scratch
             out.fill_(float(rank * 1000 + i % 7))
+            queued.append(i % 7)
             if gs is not None and gs.full():
                 gs.commit()
 
@@ -1021,7 +1055,8 @@ def dry_run(args, rank, world):
                           "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic", "dry_run": True,
                           "config": {"workload": "DRY RUN (no GPU, stand-in forward): launcher / collective / timing plumbing only",
                                      "batch_per_gpu": B, "global_batch": B * world, "collectives": gs.collectives if gs else 0,
-                                     "groups_seen_by_sink": len(got)}}), flush=True)
+                                     "groups_seen_by_sink": len(got), "sink_content_ok": bool(all(got)),
+                                     "group": gs.G if gs else 0}}), flush=True)
     if dist_on:
         dist.barrier()
         dist.destroy_process_group()

@@ -215,6 +215,16 @@ int sprk_set_many_streams(sprk_handle h, int32_t n);
  * aligned buffers; every other case silently goes batch by batch (and takes sprk_set_many_streams into account). */
 int sprk_set_many_batches(sprk_handle h, int32_t n);
 
+/* sprk_forward_many with both knobs as ARGUMENTS of the call: `batches_per_launch` (1..64) and `helper_streams` (0, 2..4) mean
+ * what sprk_set_many_batches / sprk_set_many_streams set, but nothing is stored in the handle -- a finalized handle stays
+ * immutable, so threads sharing one can each use their own settings (round 2's setters changed state under a handle the
+ * header called immutable; they remain as the DEFAULTS sprk_forward_many uses and must not be called while another thread is
+ * inside a forward).  With helper_streams >= 2 the call uses the handle's helper streams and fork / join events: that form is
+ * not re-entrant on one handle; helper_streams = 0 is.  What `model.predict(dataset)` (DeepFM.py:131) replays per batch. */
+int sprk_forward_many_opts(sprk_handle h, int32_t n_batches, const int32_t* const* ids, const float* const* dense,
+                           float* const* out, int32_t B, void* workspace, size_t workspace_bytes, void* stream,
+                           int32_t batches_per_launch, int32_t helper_streams);
+
 /* Per-model entry points: identical to sprk_forward but fail with
  * SPRK_EKIND unless the handle was created from that model's plan. */
 int sprk_forward_embedding_mlp(sprk_handle h, const int32_t* ids, const float* dense, float* out, int32_t B, void* ws, size_t ws_bytes, void* stream);

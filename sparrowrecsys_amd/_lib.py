@@ -30,7 +30,7 @@ ACT_NONE, ACT_RELU, ACT_PRELU = range(3)
 # every symbol include/sparrow_hip.h declares (tests check the .so exports all of them)
 EXPORTED_SYMBOLS = [
     "sprk_runtime_info", "sprk_create", "sprk_upload", "sprk_finalize", "sprk_workspace_bytes",
-    "sprk_forward", "sprk_forward_many", "sprk_forward_embedding_mlp", "sprk_forward_widedeep", "sprk_forward_neuralcf",
+    "sprk_forward", "sprk_forward_many", "sprk_forward_many_opts", "sprk_forward_embedding_mlp", "sprk_forward_widedeep", "sprk_forward_neuralcf",
     "sprk_forward_deepfm", "sprk_forward_deepfm_v2", "sprk_forward_din", "sprk_forward_dien", "sprk_din_pool",
     "sprk_check_ids", "sprk_debug_set_trace", "sprk_destroy", "sprk_embedding_gather", "sprk_cross_hash", "sprk_last_error",
     "sprk_pack_csv", "sprk_pack_csv_mt", "sprk_pack_csv_device", "sprk_set_many_streams", "sprk_set_many_batches", "sprk_emb_rank",
@@ -147,6 +147,7 @@ def load_library():
                      "sprk_forward_deepfm", "sprk_forward_deepfm_v2", "sprk_forward_din", "sprk_forward_dien"):
             getattr(lib, name).argtypes = fwd
         lib.sprk_forward_many.argtypes = [vp, i32, vp, vp, vp, i32, vp, sz, vp]
+        lib.sprk_forward_many_opts.argtypes = [vp, i32, vp, vp, vp, i32, vp, sz, vp, i32, i32]
         lib.sprk_din_pool.argtypes = [vp, vp, vp, vp, i32, vp]
         lib.sprk_check_ids.argtypes = [vp, vp]
         lib.sprk_debug_set_trace.argtypes = [vp, vp, sz]

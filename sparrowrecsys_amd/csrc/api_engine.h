@@ -1,0 +1,400 @@
+// api_engine.h -- C ABI: sprk_last_error .. sprk_create / sprk_upload / sprk_finalize / sprk_workspace_bytes.
+// Part of sparrow_hip.hip (one translation unit); included there, not compilable on its own.
+extern "C" {
+
+const char* sprk_last_error(void) { return g_err.c_str(); }
+
+int sprk_runtime_info(int32_t info[4]) {
+    if (!info) return fail(SPRK_EINVAL, "info is NULL");
+    info[0] = SPRK_ABI_VERSION;
+    info[1] = info[2] = info[3] = 0;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); n = 0; }
+    info[1] = n;
+    if (n > 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) {
+            info[2] = prop.multiProcessorCount;
+            info[3] = strncmp(prop.gcnArchName, "gfx950", 6) == 0 ? 1 : 0;
+        }
+    }
+    return SPRK_OK;
+}
+
+int sprk_create(const sprk_plan* plan, sprk_handle* out) {
+    if (!plan || !out) return fail(SPRK_EINVAL, "plan/out is NULL");
+    *out = nullptr;
+    int rc = validate_plan(*plan);
+    if (rc) return rc;
+    sprk_engine* h = new (std::nothrow) sprk_engine();
+    if (!h) return fail(SPRK_EHIP, "out of host memory");
+    h->plan = *plan;
+    h->slot_ptr.assign(plan->n_slots, nullptr);
+    h->slot_bytes.assign(plan->n_slots, 0);
+    int off = 0;
+    for (int b = 0; b < plan->n_bufs; ++b) {
+        h->buf_stride[b] = lds_stride(plan->buf_width[b]);
+        h->buf_base[b] = off;
+        off += SPRK_TILE_M * h->buf_stride[b];
+    }
+    // the tile's ids block [64][columns some gather segment reads]
+    auto use_col = [&](int c) {
+        for (int x : h->idc) if (x == c) return;
+        h->idc.push_back(c);
+    };
+    for (int i = 0; i < plan->n_segs; ++i) {
+        const sprk_seg& sg = plan->segs[i];
+        if (sg.kind == SPRK_SEG_ROWS || sg.kind == SPRK_SEG_SCALAR || sg.kind == SPRK_SEG_CROSS_ROWS || sg.kind == SPRK_SEG_CROSS_SCALAR) use_col(sg.field);
+        if (sg.kind == SPRK_SEG_CROSS_ROWS || sg.kind == SPRK_SEG_CROSS_SCALAR) use_col(sg.field2);
+    }
+    h->ids_base = off;
+    off += (SPRK_TILE_M * (int)h->idc.size() + 3) & ~3;
+    h->tile_lds_bytes = (size_t)off * sizeof(float);
+    if (h->tile_lds_bytes > 160 * 1024) {
+        size_t need = h->tile_lds_bytes;
+        delete h;
+        return fail(SPRK_EINVAL, "plan needs %zu bytes of LDS per tile (> 160 KiB)", need);
+    }
+    *out = h;
+    return SPRK_OK;
+}
+
+int sprk_upload(sprk_handle h, int32_t slot, const void* src, size_t bytes) {
+    if (!h || !src || bytes == 0) return fail(SPRK_EINVAL, "bad upload arguments");
+    if (slot < 0 || slot >= h->plan.n_slots) return fail(SPRK_EINVAL, "slot %d outside [0,%d)", slot, h->plan.n_slots);
+    if (h->finalized) return fail(SPRK_ESTATE, "upload after finalize");
+    if (h->slot_ptr[slot]) { (void)hipFree(h->slot_ptr[slot]); h->slot_ptr[slot] = nullptr; }
+    // 16 spare bytes so a float4 tail read of a [len]-float vector never leaves the allocation
+    HIP_TRY(hipMalloc(&h->slot_ptr[slot], bytes + 16));
+    HIP_TRY(hipMemset(h->slot_ptr[slot], 0, bytes + 16));
+    HIP_TRY(hipMemcpy(h->slot_ptr[slot], src, bytes, hipMemcpyDefault));
+    h->slot_bytes[slot] = bytes;
+    return SPRK_OK;
+}
+
+int sprk_finalize(sprk_handle h) {
+    RoctxRange roctx_range_("sprk_finalize");
+    if (!h) return fail(SPRK_EINVAL, "handle is NULL");
+    if (h->finalized) return SPRK_OK;
+    h->tune = SprkTuning::from_env();                     // the ONE place an engine reads the environment
+    struct TuneScope { const SprkTuning*& slot; ~TuneScope() { slot = nullptr; } } tune_scope{g_finalize_tune};
+    g_finalize_tune = &h->tune;
+    const sprk_plan& p = h->plan;
+    DevPlan* dp = new (std::nothrow) DevPlan();
+    if (!dp) return fail(SPRK_EHIP, "out of host memory");
+    memset(dp, 0, sizeof(DevPlan));
+    struct Guard { DevPlan* p; ~Guard() { delete p; } } guard{dp};
+    dp->F = p.n_id_cols; dp->ND = p.n_dense; dp->NA = p.n_aux;
+    dp->n_segs = p.n_segs; dp->n_ops = p.n_ops; dp->n_taps = p.n_taps; dp->n_pairs = p.n_pairs; dp->n_bufs = p.n_bufs;
+    dp->head_bias = p.head_bias;
+    for (int b = 0; b < SPRK_MAX_BUFS; ++b) { dp->buf_stride[b] = h->buf_stride[b]; dp->buf_base[b] = h->buf_base[b]; }
+    dp->ids_base = h->ids_base;
+    dp->n_idc = (int)h->idc.size();
+    for (size_t i = 0; i < h->idc.size(); ++i) dp->idc[i] = h->idc[i];
+    auto compact = [&](int c) { for (size_t i = 0; i < h->idc.size(); ++i) if (h->idc[i] == c) return (int)i; return 0; };
+    for (int i = 0; i < p.n_pairs; ++i) { dp->pair_a[i] = p.pair_a[i]; dp->pair_b[i] = p.pair_b[i]; }
+    int rc;
+    for (int i = 0; i < p.n_segs; ++i) {
+        const sprk_seg& s = p.segs[i];
+        DevSeg& d = dp->segs[i];
+        d.kind = s.kind; d.field = s.field; d.field2 = s.field2; d.row_stride = s.row_stride; d.count = s.count; d.dst = s.dst; d.vocab = s.vocab;
+        if (s.kind == SPRK_SEG_ROWS || s.kind == SPRK_SEG_SCALAR || s.kind == SPRK_SEG_CROSS_ROWS || s.kind == SPRK_SEG_CROSS_SCALAR) d.field = compact(s.field);
+        if (s.kind == SPRK_SEG_CROSS_ROWS || s.kind == SPRK_SEG_CROSS_SCALAR) d.field2 = compact(s.field2);
+        d.table = nullptr;
+        if (s.kind == SPRK_SEG_ROWS || s.kind == SPRK_SEG_CROSS_ROWS) {
+            if ((rc = need_bytes(h, s.slot, (size_t)s.vocab * s.row_stride * 4, "embedding table"))) return rc;
+            d.table = (const float*)h->slot_ptr[s.slot];
+        } else if (s.kind == SPRK_SEG_SCALAR || s.kind == SPRK_SEG_CROSS_SCALAR) {
+            if ((rc = need_bytes(h, s.slot, (size_t)s.vocab * 4, "first-order table"))) return rc;
+            d.table = (const float*)h->slot_ptr[s.slot];
+        }
+    }
+    for (int i = 0; i < p.n_ops; ++i) {
+        const sprk_op& o = p.ops[i];
+        DevOp& d = dp->ops[i];
+        d.kind = o.kind; d.src_buf = o.src_buf; d.src_off = o.src_off; d.K = o.K; d.dst_buf = o.dst_buf; d.dst_off = o.dst_off;
+        d.N = o.N; d.ldw = o.ldw; d.act = o.act; d.groups = o.groups; d.group_stride = o.group_stride;
+        if (o.kind == SPRK_OP_DENSE) {
+            if ((rc = need_bytes(h, o.w_slot, (size_t)o.N * o.ldw * 4, "Dense kernel"))) return rc;
+            if ((rc = need_bytes(h, o.b_slot, (size_t)o.N * 4, "Dense bias"))) return rc;
+            d.W = (const float*)h->slot_ptr[o.w_slot];
+            d.bias = (const float*)h->slot_ptr[o.b_slot];
+            if (o.act == SPRK_ACT_PRELU) {
+                if ((rc = need_bytes(h, o.alpha_slot, (size_t)o.N * 4, "PReLU alpha"))) return rc;
+                d.alpha = (const float*)h->slot_ptr[o.alpha_slot];
+            }
+        }
+    }
+    for (int i = 0; i < p.n_taps; ++i) {
+        const sprk_tap& t = p.taps[i];
+        DevTap& d = dp->taps[i];
+        d.buf = t.buf; d.off = t.off; d.len = t.len; d.scale = t.scale; d.bias = t.bias; d.w = nullptr;
+        if (t.w_slot >= 0) {
+            if ((rc = need_bytes(h, t.w_slot, (size_t)t.len * 4, "tap weights"))) return rc;
+            d.w = (const float*)h->slot_ptr[t.w_slot];
+        }
+    }
+    HIP_TRY(hipGetDevice(&h->device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, h->device));
+    h->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (p.din.enabled == 2) {
+        const sprk_din& s = p.din;
+        DevDin& d = dp->din;
+        d.enabled = 1; d.T = s.T; d.hist_col = s.hist_col; d.cand_col = s.cand_col; d.row_stride = s.row_stride; d.vocab = s.vocab; d.hidden = s.hidden;
+        const size_t img = s.emb_dim == 10 ? DienLayout<10, 32>::total_pad : DienLayout<16, 32>::total_pad;
+        if ((rc = need_bytes(h, s.table_slot, (size_t)s.vocab * s.row_stride * 4, "DIEN table"))) return rc;
+        if ((rc = need_bytes(h, s.seq_slot, img * 4, "DIEN sequence weights"))) return rc;
+        d.table = (const float*)h->slot_ptr[s.table_slot];
+        h->dien_run.T = s.T; h->dien_run.F = p.n_id_cols; h->dien_run.hist_col = s.hist_col; h->dien_run.cand_col = s.cand_col;
+        h->dien_run.Dp = s.row_stride; h->dien_run.vocab = s.vocab; h->dien_run.NA = p.n_aux;
+        h->dien_run.table = d.table;
+        h->dien_run.image = (const float*)h->slot_ptr[s.seq_slot];
+    } else if (p.din.enabled) {
+        const sprk_din& s = p.din;
+        DevDin& d = dp->din;
+        d.enabled = 1; d.T = s.T; d.hist_col = s.hist_col; d.cand_col = s.cand_col; d.row_stride = s.row_stride; d.vocab = s.vocab; d.hidden = s.hidden; d.b2 = s.b2;
+        if ((rc = need_bytes(h, s.table_slot, (size_t)s.vocab * s.row_stride * 4, "DIN table"))) return rc;
+        if ((rc = need_bytes(h, s.w_slot, (size_t)s.hidden * 4 * s.row_stride * 4, "DIN att0 kernel"))) return rc;
+        if ((rc = need_bytes(h, s.b_slot, (size_t)s.hidden * 4, "DIN att0 bias"))) return rc;
+        if ((rc = need_bytes(h, s.alpha_slot, (size_t)s.T * s.hidden * 4, "DIN alpha"))) return rc;
+        if ((rc = need_bytes(h, s.w2_slot, (size_t)s.hidden * 4, "DIN att1 kernel"))) return rc;
+        d.table = (const float*)h->slot_ptr[s.table_slot];
+        d.W = (const float*)h->slot_ptr[s.w_slot];
+        d.bias = (const float*)h->slot_ptr[s.b_slot];
+        d.alpha = (const float*)h->slot_ptr[s.alpha_slot];
+        d.w2 = (const float*)h->slot_ptr[s.w2_slot];
+        // samples per workgroup pass: about 256 (sample, slot) rows in LDS
+        int ms = 256 / s.T;
+        if (ms < 1) ms = 1;
+        if (ms > 64) ms = 64;
+        h->din_ms = ms;
+        const int hs = s.row_stride + 4;
+        h->din_lds_bytes = ((size_t)ms * s.T * hs + (size_t)ms * hs + (size_t)ms * s.T) * sizeof(float);
+        if (h->din_lds_bytes > 160 * 1024) return fail(SPRK_EINVAL, "DIN stage needs %zu bytes of LDS", h->din_lds_bytes);
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_din_pool), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->din_lds_bytes));
+        int per_cu = (int)(160 * 1024 / h->din_lds_bytes);
+        if (per_cu > 8) per_cu = 8;
+        if (per_cu < 1) per_cu = 1;
+        h->din_grid_cap = h->num_cus * per_cu;
+        // wave-per-sample kernel when the shape has an instantiation (T <= 64 rows fit the wave's LDS tile)
+        const int kc = (s.row_stride + 15) / 16, hc = s.hidden / 16;
+        const size_t vc_bytes = (size_t)s.vocab * s.hidden * sizeof(float);
+        if (!h->tune.din_legacy && s.T <= 64 && vc_bytes < ((size_t)4 << 30) &&
+            (size_t)s.vocab * s.row_stride * sizeof(float) < ((size_t)4 << 30)) {   // 32-bit element offsets
+            bool want_half = h->tune.din_half;
+            const int max_wpb = h->tune.din_wpb;
+            for (size_t v = 0; v < sizeof(kDinVariants) / sizeof(kDinVariants[0]); ++v) {
+                const DinVariant& dv = kDinVariants[v];
+                if (dv.half != want_half) continue;
+                if (dv.wpb > 4 && dv.wpb > max_wpb) continue;
+                if (dv.wpb == 16 && s.T > 56) continue;
+                if (dv.kc != kc || dv.hc != hc || dv.np * (64 / (dv.half ? kc * 4 : s.row_stride / 4)) < s.T) continue;
+                const int KP = kc * 16;
+                if (!h->din_w12) {
+                    HIP_TRY(hipMalloc((void**)&h->din_w12, (size_t)s.hidden * KP * sizeof(float)));
+                    HIP_TRY(hipMalloc((void**)&h->din_w4, (size_t)s.hidden * KP * sizeof(float)));
+                    HIP_TRY(hipMalloc((void**)&h->din_vc, vc_bytes));
+                    h->derived_bytes += vc_bytes;
+                }
+                hipLaunchKernelGGL(k_din_prep_w, dim3(8), dim3(256), 0, 0, d.W, s.hidden, s.row_stride, KP, 1.0f, h->din_w12, h->din_w4);
+                HIP_TRY(hipGetLastError());
+                float h_scale = 1.f, a_scale = 1.f;
+                if (dv.half) {
+                    // power-of-two scales from max|E|, max|W12|, max|W4|: |A_b| <= max|W12| + max|W4| max|E|
+                    unsigned* d_max = nullptr;
+                    HIP_TRY(hipMalloc((void**)&d_max, 3 * sizeof(unsigned)));
+                    HIP_TRY(hipMemset(d_max, 0, 3 * sizeof(unsigned)));
+                    long long nb_ = ((long long)s.vocab * s.row_stride + 255) / 256;
+                    if (nb_ > 8192) nb_ = 8192;
+                    hipLaunchKernelGGL(k_v2_absmax, dim3((unsigned)nb_), dim3(256), 0, 0, d.table, (long long)s.vocab, s.row_stride, s.row_stride, d_max);
+                    hipLaunchKernelGGL(k_v2_absmax, dim3(4), dim3(256), 0, 0, h->din_w12, (long long)s.hidden, KP, KP, d_max + 1);
+                    hipLaunchKernelGGL(k_v2_absmax, dim3(4), dim3(256), 0, 0, h->din_w4, (long long)s.hidden, KP, KP, d_max + 2);
+                    HIP_TRY(hipGetLastError());
+                    unsigned bits[3];
+                    HIP_TRY(hipMemcpy(bits, d_max, sizeof(bits), hipMemcpyDeviceToHost));
+                    (void)hipFree(d_max);
+                    float mx[3];
+                    memcpy(mx, bits, sizeof(mx));
+                    if (!(mx[0] < 3.0e38f) || !(mx[1] < 3.0e38f) || !(mx[2] < 3.0e38f)) { want_half = false; v = (size_t)-1; continue; }   // NaN / Inf weights: rescan for the f32 kernel
+                    {
+                        bool wide = false;                      // outlier rows: the ordinary rows would lose their lo halves
+                        if (int rcw = wide_dynamic_range(d.table, (long long)s.vocab, s.row_stride, s.row_stride, mx[0], &wide)) return rcw;
+                        if (wide) { want_half = false; v = (size_t)-1; continue; }
+                    }
+                    const float bound_a = mx[1] + mx[2] * mx[0];
+                    int e = 0;
+                    if (mx[0] > 0.f) { (void)frexpf(mx[0], &e); e = 15 - e; if (e > 60) e = 60; if (e < -60) e = -60; h_scale = ldexpf(1.f, e); }
+                    if (bound_a > 0.f) { (void)frexpf(bound_a, &e); e = 15 - e; if (e > 60) e = 60; if (e < -60) e = -60; a_scale = ldexpf(1.f, e); }
+                    hipLaunchKernelGGL(k_din_prep_w, dim3(8), dim3(256), 0, 0, d.W, s.hidden, s.row_stride, KP, a_scale, h->din_w12, h->din_w4);
+                    HIP_TRY(hipGetLastError());
+                    if ((size_t)s.vocab * KP * sizeof(float) >= ((size_t)4 << 30)) { want_half = false; v = (size_t)-1; continue; }
+                    if (!h->din_tsplit) { HIP_TRY(hipMalloc((void**)&h->din_tsplit, (size_t)s.vocab * KP * sizeof(float) + 16)); h->derived_bytes += (size_t)s.vocab * KP * sizeof(float); }
+                    long long sb = ((long long)s.vocab * KP + 255) / 256;
+                    if (sb > 65536) sb = 65536;
+                    hipLaunchKernelGGL(k_din_split_table, dim3((unsigned)sb), dim3(256), 0, 0, d.table, (long long)s.vocab, s.row_stride, KP,
+                                       h_scale, reinterpret_cast<_Float16*>(h->din_tsplit));
+                    HIP_TRY(hipGetLastError());
+                }
+                long long blocks = ((long long)s.vocab * s.hidden + 255) / 256;
+                if (blocks > 65536) blocks = 65536;
+                hipLaunchKernelGGL(k_din_prep_vc, dim3((unsigned)blocks), dim3(256), 0, 0, d.W, d.bias, d.table, s.hidden,
+                                   s.row_stride, (long long)s.vocab, h->din_vc);
+                HIP_TRY(hipGetLastError());
+                HIP_TRY(hipDeviceSynchronize());
+                DinRun& r = h->din_run;
+                r.T = s.T; r.F = p.n_id_cols; r.hist_col = s.hist_col; r.cand_col = s.cand_col; r.Dp = s.row_stride; r.vocab = s.vocab;
+                r.h_scale = h_scale; r.acc_scale = a_scale * h_scale; r.unscale = 1.0f / (a_scale * h_scale);
+                r.tsplit = h->din_tsplit; r.inv_h_scale = 1.0f / h_scale;
+                r.b2 = s.b2; r.table = d.table; r.w12 = h->din_w12; r.w4 = h->din_w4; r.vc = h->din_vc; r.alpha = d.alpha; r.w2 = d.w2;
+                HIP_TRY(hipFuncSetAttribute(dv.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dv.lds_bytes));
+                if (dv.fn_many) HIP_TRY(hipFuncSetAttribute(dv.fn_many, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dv.lds_bytes));
+                int wgs = (int)(160 * 1024 / dv.lds_bytes);
+                if (wgs > 2) wgs = 2;                                // launch bounds: 2 waves per SIMD
+                if (dv.wpb >= 12) wgs = 1;                           // ... or one 12- / 16-wave workgroup: 3 / 4 waves per SIMD
+                if (wgs < 1) wgs = 1;
+                h->din_attn_grid_cap = h->num_cus * wgs;
+                h->din_wpb = dv.wpb;
+                h->din_attn_many = h->tune.din_attn_many;
+                h->din_attn_lds = dv.lds_bytes;
+                h->din_variant = (int)v;
+                // k_din_attn_cols: the weights as the static MFMA operand, sixteen samples per tile (k_din_cols.h).  Needs the
+                // split-f16 tables of this variant and scales that keep W4 * s4 and h * c * sP inside f16's normal range.
+                {
+                    if (dv.half && hc == 2 && (kc == 1 || kc == 2) && s.T <= 64 && h->tune.din_cols) {
+                        // U = a_scale h_scale (the accumulators' unit); sP = h_scale^2 2^-15 puts max |h c| sP in [2^13, 2^15);
+                        // W4 then carries s4 = U / sP = a_scale 2^15 / h_scale
+                        const float rho = 32768.0f / h_scale;        // s4 / a_scale
+                        float w4max = 0.f;
+                        {
+                            unsigned* d_m = nullptr;
+                            HIP_TRY(hipMalloc((void**)&d_m, sizeof(unsigned)));
+                            HIP_TRY(hipMemset(d_m, 0, sizeof(unsigned)));
+                            hipLaunchKernelGGL(k_v2_absmax, dim3(4), dim3(256), 0, 0, h->din_w4, (long long)s.hidden, KP, KP, d_m);
+                            unsigned bits = 0;
+                            HIP_TRY(hipMemcpy(&bits, d_m, sizeof(bits), hipMemcpyDeviceToHost));
+                            (void)hipFree(d_m);
+                            memcpy(&w4max, &bits, sizeof(w4max));    // max |W4| a_scale
+                        }
+                        const float w4s = w4max * rho;
+                        if (w4max == 0.f || (w4s < 60000.0f && w4s >= 16.0f)) {
+                            if (!h->din_frag) HIP_TRY(hipMalloc((void**)&h->din_frag, 2 * 4 * 64 * 16 + 2 * 64 * 36 * sizeof(float)));
+                            float* coef = h->din_frag + 2 * 4 * 64 * 4;                  // behind the 8 KB of fragments
+                            hipLaunchKernelGGL(k_din_cols_coef, dim3(1), dim3(256), 0, 0, d.alpha, d.w2, s.T, coef);
+                            hipLaunchKernelGGL(k_din_cols_pack, dim3(1), dim3(256), 0, 0, h->din_w12, h->din_w4, KP, 1.0f, rho,
+                                               reinterpret_cast<_Float16*>(h->din_frag));
+                            HIP_TRY(hipGetLastError());
+                            HIP_TRY(hipDeviceSynchronize());
+                            DinColsRun& c = h->din_cols_run;
+                            memset(&c, 0, sizeof(c));
+                            c.T = s.T; c.F = p.n_id_cols; c.hist_col = s.hist_col; c.cand_col = s.cand_col; c.Dp = s.row_stride; c.vocab = s.vocab;
+                            c.b2 = s.b2; c.acc_scale = a_scale * h_scale; c.unscale = 1.0f / (a_scale * h_scale); c.inv_h_scale = 1.0f / h_scale;
+                            c.kappa = 1.0f / 32768.0f;
+                            c.tsplit = h->din_tsplit; c.vc = h->din_vc; c.alpha = d.alpha; c.w2 = d.w2; c.frag = h->din_frag;
+                            c.coef = coef; c.idp = p.n_id_cols;
+                            const int lds_max = (2 * 64 * 36 + DC_WAVES * 16 * p.n_id_cols + DC_WAVES * 2 * 64 * 8) * 4;
+                            if (lds_max > 160 * 1024) return fail(SPRK_EINVAL, "DIN attention needs %d bytes of LDS", lds_max);
+                            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_din_attn_cols<1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+                            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_din_attn_cols<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+                            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_din_attn_cols<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+                            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_din_attn_cols<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+                            h->din_cols = true;
+                            h->din_cols_kc = kc;
+                        }
+                    }
+                }
+                break;
+            }
+        }
+    }
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile_forward), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->tile_lds_bytes));
+    {
+        int per_cu = (int)(160 * 1024 / (h->tile_lds_bytes ? h->tile_lds_bytes : 1));
+        if (per_cu > 8) per_cu = 8;
+        if (per_cu < 1) per_cu = 1;
+        h->tile_grid_cap = h->num_cus * per_cu;
+    }
+    {
+        if (!h->tune.force_interpreter && match_v2_chain(h)) {
+            const V2Variant& vv = kV2Variants[h->v2_variant];
+            HIP_TRY(hipFuncSetAttribute(vv.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)vv.lds_bytes));
+            int per_cu = (int)(160 * 1024 / vv.lds_bytes);
+            if (vv.fn_trace) HIP_TRY(hipFuncSetAttribute(vv.fn_trace, hipFuncAttributeMaxDynamicSharedMemorySize, (int)vv.lds_bytes));
+            const int by_regs = (vv.reg ? 2 : 4) * 4 / V2_WAVES;     // workgroups/CU the launch bounds allow
+            if (per_cu > by_regs) per_cu = by_regs;
+            if (h->tune.v2_wgs_per_cu > 0 && h->tune.v2_wgs_per_cu < per_cu) per_cu = h->tune.v2_wgs_per_cu;   // tuning knob (1..by_regs)
+            if (per_cu < 1) per_cu = 1;
+            h->v2_grid_cap = h->num_cus * per_cu;
+            if (h->tune.v2_grid_cap > 0 && h->tune.v2_grid_cap < h->v2_grid_cap) h->v2_grid_cap = h->tune.v2_grid_cap;
+            // first-order weight blocks back to back, so one gather instruction can serve several fields
+            HIP_TRY(hipMalloc((void**)&h->v2_fo_all, h->v2_fo_floats * sizeof(float)));
+            for (int g = 0; g < vv.g_emb; ++g)
+                HIP_TRY(hipMemcpy(h->v2_fo_all + h->v2run.fo_off[g], h->v2.w1[g], ((size_t)h->v2run.vocab[g] + 1) * sizeof(float), hipMemcpyDeviceToDevice));
+            h->v2run.fo_all = h->v2_fo_all;
+            if (vv.fold) {
+                const int KP = vv.kpc * 16;
+                size_t rows_total = 0;
+                for (int g = 0; g < vv.g_emb; ++g) { h->v2run.rowbase[g] = (unsigned)rows_total; rows_total += (size_t)h->v2run.vocab[g] + 1; }
+                HIP_TRY(hipMalloc((void**)&h->v2_folded, rows_total * (KP + 16) * sizeof(float)));
+                h->derived_bytes += rows_total * (KP + 16) * sizeof(float);
+                for (int g = 0; g < vv.g_emb; ++g) {
+                    const long long rows = (long long)h->v2run.vocab[g] + 1;
+                    long long blocks = (rows + 3) / 4;
+                    if (blocks > 65536) blocks = 65536;
+                    hipLaunchKernelGGL(k_v2_fold, dim3((unsigned)blocks), dim3(256), 0, 0, h->v2.table[g], h->v2.ldp_emb,
+                                       h->v2.Wp[g], h->v2.ldp_emb, h->v2.bp[g], h->v2.w1[g], h->v2.hfm, h->v2.n_hfm, h->v2.h0w,
+                                       h->v2_folded + (size_t)h->v2run.rowbase[g] * (KP + 16), KP, rows);
+                    HIP_TRY(hipGetLastError());
+                }
+                h->v2run.tab0 = h->v2_folded;
+                HIP_TRY(hipDeviceSynchronize());
+                if ((rc = setup_v2_joint(h))) return rc;
+            }
+            HIP_TRY(hipMalloc((void**)&h->v2_image, vv.lds_bytes));
+            HIP_TRY(hipMemset(h->v2_image, 0, vv.lds_bytes));
+            vv.pack(h->v2, h->v2_image);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipDeviceSynchronize());
+        }
+    }
+    {
+        if (!h->tune.force_interpreter && h->v2_variant < 0) {
+            if (h->rows_from_v2 && (rc = setup_rows_v2(h))) return rc;
+            if (h->rows_variant < 0 && (rc = setup_rows_ncf(h))) return rc;
+        }
+    }
+    const bool rows_on = h->rows_variant >= 0;
+    if (!rows_on && h->v2_variant < 0 && (rc = setup_deepfm_pairs(h))) return rc;
+    if (!rows_on && h->v2_variant < 0 && h->v1_variant < 0) {
+        if (!h->tune.force_interpreter && (rc = setup_mlp_rows(h))) return rc;
+    }
+    const bool mrows_on = h->mlp_rows_nbig >= 0;
+    if (!mrows_on && !rows_on && h->v2_variant < 0 && h->v1_variant < 0 && (rc = fold_first_dense(h, dp))) return rc;
+    if (!mrows_on && !rows_on && h->v2_variant < 0 && (rc = setup_din_tail(h, dp))) return rc;
+    if (!mrows_on && !rows_on && h->v2_variant < 0 && h->v1_variant < 0 && h->din_tail_variant < 0 && (rc = setup_mlp_chain(h, dp))) return rc;
+    HIP_TRY(hipMalloc((void**)&h->dev_plan, sizeof(DevPlan)));
+    HIP_TRY(hipMemcpy(h->dev_plan, dp, sizeof(DevPlan), hipMemcpyHostToDevice));
+    HIP_TRY(hipMalloc((void**)&h->dev_err, sizeof(int)));
+    HIP_TRY(hipMemset(h->dev_err, 0, sizeof(int)));
+    {
+        // helper streams for sprk_forward_many's fan-out (sprk_set_many_streams; SPRK_MANY_STREAMS presets it)
+        {
+            HIP_TRY(hipEventCreateWithFlags(&h->many_fork, hipEventDisableTiming));
+            for (int i = 0; i < 4; ++i) {
+                HIP_TRY(hipStreamCreateWithFlags(&h->many_stream[i], hipStreamNonBlocking));
+                HIP_TRY(hipEventCreateWithFlags(&h->many_join[i], hipEventDisableTiming));
+            }
+            h->many_streams = h->tune.many_streams;              // 0 = strict stream order (default), 2..4 = fan out
+        }
+    }
+    if (h->tune.v2_xflags_set) { h->v2_xflags = h->tune.v2_xflags; h->v2_xflags_set = true; }
+    h->finalized = true;
+    return SPRK_OK;
+}
+
+size_t sprk_workspace_bytes(sprk_handle h, int32_t B) {
+    if (!h || B <= 0 || !h->plan.din.enabled) return 0;
+    return (size_t)B * h->plan.n_aux * sizeof(float);
+}
+

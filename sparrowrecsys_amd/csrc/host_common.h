@@ -1,0 +1,113 @@
+// host_common.h -- error reporting, HIP_TRY, roctx ranges, SprkTuning (the environment's switches, read once per finalize).
+// Part of sparrow_hip.hip (one translation unit); included there, not compilable on its own.
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                      \
+    do {                                                                                   \
+        hipError_t e_ = (expr);                                                            \
+        if (e_ != hipSuccess) return fail(SPRK_EHIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+// ---- roctx ranges around the C ABI's entry points ("roctx ranges in the C-ABI") ----
+// SPRK_ROCTX=1 binds rocprofiler-sdk's roctx at first use (dlopen: no link-time dependency) and every forward / ingest /
+// exchange call then shows up as a named range in `rocprofv3 --marker-trace`; otherwise the cost is one predictable branch.
+struct Roctx {
+    int (*push)(const char*) = nullptr;
+    int (*pop)() = nullptr;
+    bool on = false;
+    Roctx() {
+        const char* e = getenv("SPRK_ROCTX");
+        if (!e || e[0] != '1') return;
+        void* lib = nullptr;
+        for (const char* n : {"librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "libroctx64.so.4", "libroctx64.so"}) {
+            lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+            if (lib) break;
+        }
+        if (!lib) return;
+        push = reinterpret_cast<int (*)(const char*)>(dlsym(lib, "roctxRangePushA"));
+        pop = reinterpret_cast<int (*)()>(dlsym(lib, "roctxRangePop"));
+        on = push && pop;
+    }
+};
+inline const Roctx& roctx() { static const Roctx r; return r; }
+struct RoctxRange {
+    bool live;
+    explicit RoctxRange(const char* name) : live(roctx().on) { if (live) roctx().push(name); }
+    ~RoctxRange() { if (live) roctx().pop(); }
+    RoctxRange(const RoctxRange&) = delete;
+    RoctxRange& operator=(const RoctxRange&) = delete;
+};
+
+// ---- every A/B switch and tuning knob of an engine, read from the environment ONCE, at sprk_finalize ----
+// (round 2 had 30 getenv() calls spread over the setup functions.)  The defaults are the shipped configuration; the
+// switches exist so that tests and profiles can put two code paths side by side on the same inputs (tests/test_gpu_parity.py,
+// profiles/rNN/README.md).  "off" = the variable is set and starts with '0', "on" = it starts with '1'.
+struct SprkTuning {
+    bool force_interpreter = false;   // SPRK_FORCE_INTERPRETER=1   every plan on k_tile_forward
+    bool v2_fold = true;              // SPRK_V2_FOLD=0             DeepFM_v2: projections computed per sample instead of folded tables
+    bool v2_rows = false;             // SPRK_V2_ROWS=1             DeepFM_v2 on k_rows_chain even where k_deepfm_v2_joint fits
+    bool v2_joint = true;             // SPRK_V2_JOINT=0            no LDS-resident small fields (k_deepfm_v2_chain)
+    bool v2_half = true;              // SPRK_V2_HALF=0             big fields on f32 MFMA instead of split f16
+    bool v2j_one = true;              // SPRK_V2J_ONE=0             one-batch launches on the looped kernel, not k_deepfm_v2_joint1
+    int v2_wgs_per_cu = 0;            // SPRK_V2_WGS_PER_CU=n       cap workgroups per CU of k_deepfm_v2_chain (0 = by LDS / registers)
+    int v2_grid_cap = 0;              // SPRK_V2_GRID_CAP=n         cap its grid (0 = none)
+    bool v2_xflags_set = false;       // SPRK_V2_XFLAGS=n           experiment bits handed to the kernel in V2Run::flags
+    int v2_xflags = 0;
+    bool rows_one = true;             // SPRK_ROWS_ONE=0            k_rows_chain: looped kernel for one-batch launches too
+    bool ncf_chain = true;            // SPRK_NCF_CHAIN=0           NeuralCF on the interpreter
+    bool tile_fold = true;            // SPRK_TILE_FOLD=0           interpreter without the first-Dense fold
+    bool half_range_guard = true;     // SPRK_HALF_RANGE_GUARD=0    skip the dynamic-range guard of static f16 scales (tests only)
+    bool dyn_f16 = true;              // SPRK_DYN_F16=0             hidden layers on f32 MFMA instead of dynamic split f16
+    bool v1_chain = true;             // SPRK_V1_CHAIN=0            pair-dot DeepFM on the interpreter
+    bool v1_static_scale = true;      // SPRK_V1_STATIC_SCALE=0     deep0's embedding block with a per-sample scale
+    bool v1_rowtab = true;            // SPRK_V1_ROWTAB=0           gather the uploaded tables, not the derived {E | w1} rows
+    bool v1_one = true;               // SPRK_V1_ONE=0              one-batch launches on the looped kernel, not k_deepfm_pairs1
+    bool mlp_chain = true;            // SPRK_MLP_CHAIN=0           EmbeddingMLP / Wide&Deep on the interpreter
+    bool mlp_rows = true;             // SPRK_MLP_ROWS=0            ... on round 1's k_mlp_chain
+    bool din_tail = true;             // SPRK_DIN_TAIL=0            DIN tail on the interpreter
+    bool din_legacy = false;          // SPRK_DIN_LEGACY=1          attention on the generic k_din_pool
+    bool din_half = true;             // SPRK_DIN_HALF=0            attention on f32 MFMA
+    int din_wpb = 12;                 // SPRK_DIN_WPB=n             k_din_attn: at most n waves per workgroup (4 = round 1, 16 = 4 per SIMD)
+    bool din_attn_many = true;        // SPRK_DIN_ATTN_MB=0         forward_many: one attention launch per batch
+    bool din_cols = true;             // SPRK_DIN_COLS=0            attention on k_din_attn (wave per sample), not k_din_attn_cols
+    int din_cols_ts = 0;              // SPRK_DIN_COLS_TS=1|2|4     waves per task of k_din_attn_cols (0 = by the launch's task count)
+    int many_streams = 0;             // SPRK_MANY_STREAMS=n        forward_many fans batches over n helper streams (2..4)
+    static SprkTuning from_env() {
+        auto off = [](const char* n) { const char* e = getenv(n); return e && e[0] == '0'; };
+        auto on = [](const char* n) { const char* e = getenv(n); return e && e[0] == '1'; };
+        auto num = [](const char* n, int dflt) { const char* e = getenv(n); return e ? atoi(e) : dflt; };
+        SprkTuning t;
+        t.force_interpreter = on("SPRK_FORCE_INTERPRETER");
+        t.v2_fold = !off("SPRK_V2_FOLD"); t.v2_rows = on("SPRK_V2_ROWS"); t.v2_joint = !off("SPRK_V2_JOINT"); t.v2_half = !off("SPRK_V2_HALF");
+        t.v2j_one = !off("SPRK_V2J_ONE");
+        { const char* w = getenv("SPRK_V2_WGS_PER_CU"); t.v2_wgs_per_cu = (w && w[0] >= '1' && w[0] <= '9') ? w[0] - '0' : 0; }
+        t.v2_grid_cap = num("SPRK_V2_GRID_CAP", 0);
+        t.v2_xflags_set = getenv("SPRK_V2_XFLAGS") != nullptr; t.v2_xflags = num("SPRK_V2_XFLAGS", 0);
+        t.rows_one = !off("SPRK_ROWS_ONE"); t.ncf_chain = !off("SPRK_NCF_CHAIN"); t.tile_fold = !off("SPRK_TILE_FOLD");
+        t.half_range_guard = !off("SPRK_HALF_RANGE_GUARD"); t.dyn_f16 = !off("SPRK_DYN_F16");
+        t.v1_chain = !off("SPRK_V1_CHAIN"); t.v1_static_scale = !off("SPRK_V1_STATIC_SCALE"); t.v1_rowtab = !off("SPRK_V1_ROWTAB");
+        t.v1_one = !off("SPRK_V1_ONE");
+        t.mlp_chain = !off("SPRK_MLP_CHAIN"); t.mlp_rows = !off("SPRK_MLP_ROWS");
+        t.din_tail = !off("SPRK_DIN_TAIL"); t.din_legacy = on("SPRK_DIN_LEGACY"); t.din_half = !off("SPRK_DIN_HALF");
+        t.din_wpb = num("SPRK_DIN_WPB", 12); t.din_attn_many = !off("SPRK_DIN_ATTN_MB"); t.din_cols = !off("SPRK_DIN_COLS");
+        { const int n = num("SPRK_DIN_COLS_TS", 0); t.din_cols_ts = (n == 1 || n == 2 || n == 4) ? n : 0; }
+        { const int n = num("SPRK_MANY_STREAMS", 0); t.many_streams = n < 2 ? 0 : (n > 4 ? 4 : n); }
+        return t;
+    }
+};
+thread_local const SprkTuning* g_finalize_tune = nullptr;   // the engine being finalized on this thread (helpers without a handle)
+

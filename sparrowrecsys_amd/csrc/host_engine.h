@@ -1,0 +1,103 @@
+// host_engine.h -- struct sprk_engine: everything a finalized handle owns.
+// Part of sparrow_hip.hip (one translation unit); included there, not compilable on its own.
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+struct sprk_engine {
+    sprk_plan plan;
+    std::vector<void*> slot_ptr;
+    std::vector<size_t> slot_bytes;
+    DevPlan* dev_plan = nullptr;
+    int* dev_err = nullptr;
+    bool finalized = false;
+    int device = 0;
+    int num_cus = 256;
+    int buf_stride[SPRK_MAX_BUFS] = {0, 0, 0};
+    int buf_base[SPRK_MAX_BUFS] = {0, 0, 0};
+    size_t tile_lds_bytes = 0;
+    int ids_base = 0;              // float offset of the tile's ids block inside the tile kernel's LDS
+    std::vector<int> idc;          // ids columns read by the gather segments (compact staging order)
+    int tile_grid_cap = 0;
+    std::vector<void*> fold_bufs;  // first-Dense fold: folded tables + the W^T copy (device)
+    // sprk_forward_many fan-out: independent batches alternate over helper streams (hardware queues), so that one
+    // kernel's dispatch / drain (3.3 us even for an empty kernel in a dependent launch chain) overlaps its neighbours
+    int many_streams = 0;
+    hipStream_t many_stream[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t many_fork = nullptr, many_join[4] = {nullptr, nullptr, nullptr, nullptr};
+    // register-chained pairwise-dot DeepFM (k_deepfm_pairs); -1 = the tile interpreter
+    int v1_variant = -1;
+    bool v1_one = false;                  // one-batch launches use k_deepfm_pairs1 (one task per wave, four waves per SIMD)
+    V1Run v1_run;
+    std::vector<void*> v1_bufs;
+    // register-chained DenseFeatures -> Dense -> Dense -> Dense(1) graphs (k_mlp_chain); -1 = the tile interpreter
+    int mlp_variant = -1;
+    MlpChainRun mlp_run;
+    float* mlp_image = nullptr;
+    // ... with every embedding column folded through the first layer, genre tables in LDS (k_mlp_rows); -1 = not used
+    int mlp_rows_nbig = -1;
+    MlpRowsRun mlp_rows_run;
+    float* mlp_rows_image = nullptr;
+    float* mlp_rows_small = nullptr;
+    size_t mlp_rows_lds = 0;
+    std::vector<void*> mlp_rows_bufs;
+    // register-chained DIN tail (k_din_tail); -1 = the tile interpreter runs the tail
+    int din_tail_variant = -1;
+    DinTailRun din_tail_run;
+    float* din_tail_image = nullptr;
+    // DIN launch geometry
+    int din_ms = 0;
+    size_t din_lds_bytes = 0;
+    int din_grid_cap = 0;
+    // wave-per-sample attention kernel (k_din_attn); -1 = the generic k_din_pool
+    int din_variant = -1;
+    DienRun dien_run{};
+    DinRun din_run;
+    float* din_w12 = nullptr;      // (W1+W2)^T, W4^T fragments and the per-id c-term table (device)
+    float* din_w4 = nullptr;
+    float* din_vc = nullptr;
+    float* din_tsplit = nullptr;   // HALF: the movie table pre-split into f16 hi/lo pairs
+    size_t din_attn_lds = 0;
+    int din_attn_grid_cap = 0;
+    SprkTuning tune;               // the environment's switches as sprk_finalize found them
+    int din_wpb = 4;               // waves per k_din_attn workgroup
+    bool din_cols = false;         // attention on k_din_attn_cols (16 samples per MFMA tile, static weight operand; k_din_cols.h)
+    int din_cols_kc = 0;
+    DinColsRun din_cols_run;
+    float* din_frag = nullptr;     // its A fragments
+    bool din_attn_many = true;     // forward_many: one attention launch per group of batches (SPRK_DIN_ATTN_MB=0: per batch)
+    // register-chained fast path (k_deepfm_v2_chain); -1 = use the tile interpreter
+    int v2_variant = -1;
+    V2Args v2;
+    V2Run v2run;
+    size_t v2_lds_bytes = 0;
+    int v2_grid_cap = 0;
+    float* v2_image = nullptr;     // pre-packed LDS weight image (device)
+    float* v2_fo_all = nullptr;    // concatenated first-order weight blocks (device)
+    float* v2_folded = nullptr;    // projected tables of all fields, back to back (device)
+    size_t v2_fo_floats = 0;
+    // ... with the small-vocabulary fields folded into one joint table (k_deepfm_v2_joint); -1 = not used
+    int v2j_variant = -1;
+    float* v2j1_image = nullptr;          // k_deepfm_v2_joint1 (one task per wave): its LDS image; NULL = shape not available
+    size_t v2j1_lds_bytes = 0;
+    int many_batches = 1;                 // sprk_forward_many: batches scored per launch (sprk_set_many_batches)
+    // "one row per id" chain (k_rows_chain): DeepFM_v2 with projections wider than 16 (the reference's Dense(64)) and NeuralCF
+    int rows_variant = -1;
+    bool rows_one = true;                 // one-batch launches use k_rows_chain1 (one task per wave; SPRK_ROWS_ONE=0: looped kernel)
+    bool rows_from_v2 = false;            // set by match_v2_chain: h->v2 holds the parsed DeepFM_v2 plan, tables still to build
+    int rows_g_emb = 0;
+    RowsRun rows_run;
+    float* rows_tab = nullptr;            // big fields' rows {P | Q}
+    float* rows_scal = nullptr;           // big fields' per-id scalars
+    float* rows_small = nullptr;          // small fields' LDS rows (device image)
+    float* rows_image = nullptr;          // weight image
+    size_t rows_lds_bytes = 0;
+    int n_acc_folded = 0;                 // embedding columns folded into the first Dense layer (fold_first_dense)
+    size_t derived_bytes = 0;             // device memory of tables DERIVED at finalize (folded rows, split halfs, per-id terms)
+    int v2_xflags = 0;                    // SPRK_V2_XFLAGS experiment switches, read ONCE at finalize (never on the launch path)
+    bool v2_xflags_set = false;
+    V2JRun v2j_run;
+    float* v2j_tab = nullptr;      // small fields' LDS rows (device image)
+    size_t v2j_lds_bytes = 0;
+    float* v2j_big = nullptr;      // HALF: split-half rows of the big fields (device)
+};
+

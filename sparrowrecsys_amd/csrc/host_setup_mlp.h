@@ -1,0 +1,247 @@
+// host_setup_mlp.h -- EmbeddingMLP / Wide&Deep: k_mlp_chain and k_mlp_rows set-up.
+// Part of sparrow_hip.hip (one translation unit); included there, not compilable on its own.
+// ---- k_mlp_chain<N0C, N1C, WAVES> ----
+constexpr int MC_WAVES = 8;
+// Recognise what the first-Dense fold left of an EmbeddingMLP / Wide&Deep plan (EmbeddingMLP.py:72-77, WideNDeep.py:99-107):
+// folded columns, unfolded embedding columns + numerics feeding Dense(128) -> Dense(128) -> weighted tap (+ the wide cross).
+int setup_mlp_chain(sprk_engine* h, DevPlan* dp) {
+    if (!h->tune.mlp_chain) return SPRK_OK;
+    const sprk_plan& p = h->plan;
+    if (p.din.enabled || dp->n_ops != 2 || dp->n_taps < 1 || dp->n_taps > 2 || dp->n_acc > MC_MAX_ACC) return SPRK_OK;
+    if (p.model_kind != SPRK_MODEL_EMBEDDING_MLP && p.model_kind != SPRK_MODEL_WIDE_DEEP) return SPRK_OK;
+    const DevOp &o0 = dp->ops[0], &o1 = dp->ops[1];
+    if (o0.kind != SPRK_OP_DENSE || o1.kind != SPRK_OP_DENSE || o0.act != o1.act || (o0.act != SPRK_ACT_RELU && o0.act != SPRK_ACT_PRELU)) return SPRK_OK;
+    if (o0.src_buf != 0 || o0.dst_buf == 0 || o0.dst_off != 0 || o1.src_buf != o0.dst_buf || o1.src_off != 0 || o1.K != o0.N ||
+        o1.dst_off != 0 || o0.N != 128 || o1.N != 128) return SPRK_OK;
+    MlpChainRun r;
+    memset(&r, 0, sizeof(r));
+    int col_off[MC_MAX_CHUNKS], col_w[MC_MAX_CHUNKS];
+    const int lo = o0.src_off, hi = o0.src_off + o0.K;
+    const int n_plain = dp->n_segs - dp->n_acc;
+    const DevSeg* cross = nullptr;
+    int num_dst = -1;
+    for (int i = 0; i < n_plain; ++i) {
+        const DevSeg& sg = dp->segs[i];
+        if (sg.kind == SPRK_SEG_ROWS) {
+            if (sg.dst < lo || sg.dst + 4 * sg.count > hi) return SPRK_OK;
+            for (int j = 0; j < 4 * sg.count; j += 16) {
+                if (r.n_chunks == MC_MAX_CHUNKS) return SPRK_OK;
+                const int c = r.n_chunks++;
+                r.ch_col[c] = h->idc[sg.field]; r.ch_vocab[c] = sg.vocab; r.ch_off[c] = j; r.ch_stride[c] = sg.row_stride;
+                r.ch_width[c] = 4 * sg.count - j < 16 ? 4 * sg.count - j : 16; r.ch_tab[c] = sg.table;
+                col_off[c] = sg.dst + j - lo; col_w[c] = r.ch_width[c];
+            }
+        } else if (sg.kind == SPRK_SEG_DENSE) {
+            if (num_dst >= 0 || sg.field != 0 || sg.count > 8 || sg.dst < lo || sg.dst + sg.count > hi) return SPRK_OK;
+            num_dst = sg.dst; r.n_num = sg.count;
+        } else if (sg.kind == SPRK_SEG_CROSS_ROWS || sg.kind == SPRK_SEG_CROSS_SCALAR) {
+            if (cross || (sg.dst < hi && sg.dst + (sg.kind == SPRK_SEG_CROSS_ROWS ? 4 * sg.count : 1) > lo)) return SPRK_OK;
+            cross = &sg;
+        } else if (sg.kind != SPRK_SEG_ZERO) {
+            return SPRK_OK;
+        }
+    }
+    // (an embedding table needs its zero row at index vocab for missing ids: models.pad_table provides it; ROWS segments
+    //  validated at finalize only hold vocab rows' worth of bytes when a caller built the plan by hand)
+    for (int i = 0; i < p.n_segs; ++i)
+        if (p.segs[i].kind == SPRK_SEG_ROWS && h->slot_bytes[p.segs[i].slot] < ((size_t)p.segs[i].vocab + 1) * p.segs[i].row_stride * sizeof(float)) return SPRK_OK;
+    if (num_dst >= 0) {
+        if (r.n_chunks == MC_MAX_CHUNKS) return SPRK_OK;
+        const int c = r.n_chunks++;
+        r.ch_col[c] = -1; col_off[c] = num_dst - lo; col_w[c] = r.n_num;
+    }
+    if (r.n_chunks < 1) return SPRK_OK;
+    const DevTap *tdeep = nullptr, *twide = nullptr;
+    for (int t = 0; t < dp->n_taps; ++t) {
+        const DevTap& tp = dp->taps[t];
+        if (tp.scale != 1.0f || tp.bias != 0.0f) return SPRK_OK;
+        if (tp.buf == o1.dst_buf && tp.off == 0 && tp.len <= o1.N && tp.w && !tdeep) tdeep = &tp;
+        else if (cross && tp.buf == 0 && tp.off == cross->dst && !twide) twide = &tp;
+        else return SPRK_OK;
+    }
+    if (!tdeep || (cross != nullptr) != (twide != nullptr)) return SPRK_OK;
+    if (cross) {
+        if (cross->kind == SPRK_SEG_CROSS_ROWS) {
+            if (twide->len != 4 * cross->count || !twide->w || twide->len > 32) return SPRK_OK;
+            r.wide_kind = 1; r.wide_dim = twide->len; r.wide_stride = cross->row_stride; r.wide_w = twide->w;
+        } else {
+            if (twide->len != 1 || twide->w) return SPRK_OK;
+            r.wide_kind = 2;
+        }
+        r.wide_a = h->idc[cross->field]; r.wide_b = h->idc[cross->field2]; r.wide_buckets = cross->vocab; r.wide_tab = cross->table;
+    }
+    r.n_acc = dp->n_acc;
+    for (int g = 0; g < dp->n_acc; ++g) {
+        const DevSeg& sg = dp->segs[n_plain + g];
+        r.acc_col[g] = h->idc[sg.field]; r.acc_vocab[g] = sg.vocab; r.acc_tab[g] = sg.table;
+    }
+    r.F = p.n_id_cols; r.ND = p.n_dense; r.head_bias = dp->head_bias;
+    typedef MlpChainLds<8, 8> LD;
+    HIP_TRY(hipMalloc((void**)&h->mlp_image, LD::bytes));
+    int *d_off = nullptr, *d_w = nullptr;
+    HIP_TRY(hipMalloc((void**)&d_off, sizeof(col_off)));
+    HIP_TRY(hipMalloc((void**)&d_w, sizeof(col_w)));
+    HIP_TRY(hipMemcpy(d_off, col_off, sizeof(col_off), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_w, col_w, sizeof(col_w), hipMemcpyHostToDevice));
+    float* w1frag = nullptr;
+    {
+        float w_scale = 0.f;
+        const int rc2 = make_dyn_fragments(h, o1.W, o1.ldw, o1.N, o1.K, &w1frag, &w_scale);
+        if (rc2) return rc2;
+        r.inv_w1_scale = w1frag ? 1.0f / w_scale : 0.f;
+    }
+    hipLaunchKernelGGL((k_mlp_chain_pack<8, 8>), dim3(1), dim3(256), 0, 0, o0.W, o0.ldw, r.n_chunks, d_off, d_w, o0.bias,
+                       o0.act == SPRK_ACT_PRELU ? o0.alpha : nullptr, o1.W, o1.ldw, o1.bias, o1.act == SPRK_ACT_PRELU ? o1.alpha : nullptr,
+                       tdeep->w, tdeep->len, w1frag, h->mlp_image);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    (void)hipFree(d_off); (void)hipFree(d_w);
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mlp_chain<8, 8, MC_WAVES, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LD::bytes));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mlp_chain<8, 8, MC_WAVES, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LD::bytes));
+    h->mlp_run = r;
+    h->mlp_variant = 0;
+    return SPRK_OK;
+}
+
+// ---- k_mlp_rows<8, 8, NBIG, WAVES, DYN> ----
+constexpr int MR_WAVES = 8;
+template <int NBIG>
+void mlp_rows_launch(const MlpRowsRun& a, const int* ids, const float* dense, float* out, int B, int* err, const float* image, int grid,
+                     size_t lds, hipStream_t st) {
+    if (a.inv_w1_scale != 0.f)
+        hipLaunchKernelGGL((k_mlp_rows<8, 8, NBIG, MR_WAVES, true>), dim3(grid), dim3(MR_WAVES * 64), lds, st, a, ids, dense, out, B, err, image);
+    else
+        hipLaunchKernelGGL((k_mlp_rows<8, 8, NBIG, MR_WAVES, false>), dim3(grid), dim3(MR_WAVES * 64), lds, st, a, ids, dense, out, B, err, image);
+}
+template <int NBIG>
+int mlp_rows_attr(size_t lds) {
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mlp_rows<8, 8, NBIG, MR_WAVES, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mlp_rows<8, 8, NBIG, MR_WAVES, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    return SPRK_OK;
+}
+// Recognise an EmbeddingMLP / Wide&Deep plan (EmbeddingMLP.py:72-77, WideNDeep.py:99-107) with ReLU layers of 128 and fold
+// EVERY embedding column through the first Dense layer (see k_mlp_rows.h).  Leaves mlp_rows_nbig = -1 for any other shape.
+int setup_mlp_rows(sprk_engine* h) {
+    if (!h->tune.mlp_rows || !h->tune.mlp_chain) return SPRK_OK;
+    const sprk_plan& p = h->plan;
+    if (p.din.enabled || p.n_ops != 2 || p.n_taps < 1 || p.n_taps > 2) return SPRK_OK;
+    if (p.model_kind != SPRK_MODEL_EMBEDDING_MLP && p.model_kind != SPRK_MODEL_WIDE_DEEP) return SPRK_OK;
+    if (p.n_id_cols > 12 || p.n_dense > 8 || p.n_dense < 1) return SPRK_OK;
+    const sprk_op &o0 = p.ops[0], &o1 = p.ops[1];
+    if (o0.kind != SPRK_OP_DENSE || o1.kind != SPRK_OP_DENSE || o0.act != SPRK_ACT_RELU || o1.act != SPRK_ACT_RELU) return SPRK_OK;
+    if (o0.src_buf != 0 || o0.dst_buf == 0 || o0.dst_off != 0 || o1.src_buf != o0.dst_buf || o1.src_off != 0 || o1.K != o0.N ||
+        o1.dst_off != 0 || o0.N != 128 || o1.N != 128) return SPRK_OK;
+    typedef MlpRowsLds<8, 8> LD;
+    const int lo = o0.src_off, hi = o0.src_off + o0.K, N0 = 128;
+    MlpRowsRun r;
+    memset(&r, 0, sizeof(r));
+    const sprk_seg* big_seg[MR_MAX_BIG];
+    const sprk_seg* small_seg[MR_MAX_SMALL];
+    const sprk_seg* cross = nullptr;
+    int num_dst = -1;
+    for (int i = 0; i < p.n_segs; ++i) {
+        const sprk_seg& sg = p.segs[i];
+        if (sg.kind == SPRK_SEG_ROWS) {
+            if (sg.dst < lo || sg.dst + 4 * sg.count > hi) return SPRK_OK;
+            if ((long long)sg.vocab <= 31 && r.n_small < MR_MAX_SMALL) small_seg[r.n_small++] = &sg;
+            else if (r.n_big < MR_MAX_BIG) big_seg[r.n_big++] = &sg;
+            else return SPRK_OK;
+            if ((size_t)sg.vocab * N0 * sizeof(float) > ((size_t)8 << 30)) return SPRK_OK;
+        } else if (sg.kind == SPRK_SEG_DENSE) {
+            if (num_dst >= 0 || sg.field != 0 || sg.count > 8 || sg.dst < lo || sg.dst + sg.count > hi) return SPRK_OK;
+            num_dst = sg.dst; r.n_num = sg.count;
+        } else if (sg.kind == SPRK_SEG_CROSS_ROWS || sg.kind == SPRK_SEG_CROSS_SCALAR) {
+            if (cross || (sg.dst < hi && sg.dst + (sg.kind == SPRK_SEG_CROSS_ROWS ? 4 * sg.count : 1) > lo)) return SPRK_OK;
+            cross = &sg;
+        } else if (sg.kind != SPRK_SEG_ZERO) {
+            return SPRK_OK;
+        }
+    }
+    if (r.n_big < 1 || r.n_big > 2 || num_dst < 0 || r.n_num < 1) return SPRK_OK;   // (three big columns spill: 3 x 8 float4 in flight)
+    const sprk_tap *tdeep = nullptr, *twide = nullptr;
+    for (int t = 0; t < p.n_taps; ++t) {
+        const sprk_tap& tp = p.taps[t];
+        if (tp.scale != 1.0f || tp.bias != 0.0f) return SPRK_OK;
+        if (tp.buf == o1.dst_buf && tp.off == 0 && tp.len <= o1.N && tp.w_slot >= 0 && !tdeep) tdeep = &tp;
+        else if (cross && tp.buf == 0 && tp.off == cross->dst && !twide) twide = &tp;
+        else return SPRK_OK;
+    }
+    if (!tdeep || (cross != nullptr) != (twide != nullptr)) return SPRK_OK;
+    if (cross) {
+        if (cross->kind == SPRK_SEG_CROSS_ROWS) {
+            if (twide->len != 4 * cross->count || twide->w_slot < 0 || twide->len > 32) return SPRK_OK;
+            r.wide_kind = 1; r.wide_dim = twide->len; r.wide_stride = cross->row_stride; r.wide_w = (const float*)h->slot_ptr[twide->w_slot];
+        } else {
+            if (twide->len != 1 || twide->w_slot >= 0) return SPRK_OK;
+            r.wide_kind = 2;
+        }
+        r.wide_a = cross->field; r.wide_b = cross->field2; r.wide_buckets = cross->vocab; r.wide_tab = (const float*)h->slot_ptr[cross->slot];
+    }
+    // LDS: fixed image + small tables (+ one shared zero row) + a staging slot per wave
+    size_t small_floats = 0;
+    for (int f = 0; f < r.n_small; ++f) { r.s_off[f] = (int)small_floats; small_floats += (size_t)small_seg[f]->vocab * N0; }
+    r.zero_off = (int)small_floats;
+    small_floats += N0;
+    small_floats = (small_floats + 255) & ~(size_t)255;
+    const size_t lds = ((size_t)LD::total_pad + small_floats + (size_t)MR_WAVES * MR_STAGE) * sizeof(float);
+    if (lds > 160 * 1024) return SPRK_OK;
+    const float* W0 = (const float*)h->slot_ptr[o0.w_slot];
+    HIP_TRY(hipMalloc((void**)&h->mlp_rows_small, small_floats * sizeof(float)));
+    HIP_TRY(hipMemset(h->mlp_rows_small, 0, small_floats * sizeof(float)));
+    auto fold = [&](const sprk_seg& sg, float* F) {
+        long long blocks = ((long long)sg.vocab * N0 + 255) / 256;
+        if (blocks > 65536) blocks = 65536;
+        hipLaunchKernelGGL(k_fold_dense_rows, dim3((unsigned)blocks), dim3(256), 0, 0, (const float*)h->slot_ptr[sg.slot], (long long)sg.vocab,
+                           sg.row_stride, 4 * sg.count, W0, o0.ldw, sg.dst - lo, N0, F);
+    };
+    {
+        // small columns: fold into a scratch buffer, then into the XOR-swizzled LDS layout (k_mlp_rows.h); s_off must keep the
+        // low 7 bits of a row's float offset free for the swizzle
+        float* tmp = nullptr;
+        HIP_TRY(hipMalloc((void**)&tmp, (size_t)32 * N0 * sizeof(float)));
+        for (int f = 0; f < r.n_small; ++f) {
+            r.s_col[f] = small_seg[f]->field; r.s_vocab[f] = small_seg[f]->vocab;
+            if (r.s_off[f] & 127) { (void)hipFree(tmp); return fail(SPRK_EINVAL, "small-table offset not a multiple of 128 floats"); }
+            fold(*small_seg[f], tmp);
+            hipLaunchKernelGGL(k_mlp_rows_swizzle, dim3(4), dim3(256), 0, 0, tmp, h->mlp_rows_small + r.s_off[f], small_seg[f]->vocab);
+        }
+        HIP_TRY(hipDeviceSynchronize());
+        (void)hipFree(tmp);
+    }
+    for (int b = 0; b < r.n_big; ++b) {
+        const sprk_seg& sg = *big_seg[b];
+        float* F = nullptr;
+        const size_t bytes = ((size_t)sg.vocab + 1) * N0 * sizeof(float);
+        HIP_TRY(hipMalloc((void**)&F, bytes));
+        h->mlp_rows_bufs.push_back(F);
+        h->derived_bytes += bytes;
+        HIP_TRY(hipMemset(F + (size_t)sg.vocab * N0, 0, N0 * sizeof(float)));        // the "no id" row
+        fold(sg, F);
+        r.big_col[b] = sg.field; r.big_vocab[b] = sg.vocab; r.big_tab[b] = F;
+    }
+    HIP_TRY(hipGetLastError());
+    float* w1frag = nullptr;
+    {
+        float w_scale = 0.f;
+        const int rc2 = make_dyn_fragments(h, (const float*)h->slot_ptr[o1.w_slot], o1.ldw, o1.N, o1.K, &w1frag, &w_scale);
+        if (rc2) return rc2;
+        r.inv_w1_scale = w1frag ? 1.0f / w_scale : 0.f;
+    }
+    HIP_TRY(hipMalloc((void**)&h->mlp_rows_image, (size_t)LD::total_pad * sizeof(float)));
+    hipLaunchKernelGGL((k_mlp_rows_pack<8, 8>), dim3(1), dim3(256), 0, 0, W0, o0.ldw, num_dst - lo, r.n_num, (const float*)h->slot_ptr[o0.b_slot],
+                       (const float*)h->slot_ptr[o1.w_slot], o1.ldw, (const float*)h->slot_ptr[o1.b_slot],
+                       (const float*)h->slot_ptr[tdeep->w_slot], tdeep->len, w1frag, h->mlp_rows_image);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    r.F = p.n_id_cols; r.ND = p.n_dense; r.head_bias = p.head_bias;
+    r.small = h->mlp_rows_small; r.small_floats = (int)small_floats;
+    int rc;
+    if (r.n_big == 1) rc = mlp_rows_attr<1>(lds);
+    else rc = mlp_rows_attr<2>(lds);
+    if (rc) return rc;
+    h->mlp_rows_run = r;
+    h->mlp_rows_lds = lds;
+    h->mlp_rows_nbig = r.n_big;
+    return SPRK_OK;
+}
+

@@ -73,6 +73,10 @@ __global__ __launch_bounds__(256) void k_v2j1_pack_image(const V2Args A, const V
     if (tid < 8) img[off_fn8 + tid] = tid < A.n_num ? A.h0w * A.fo_num_w[tid] : 0.f;
 }
 
+// (Tried and dropped, scripts/r03/09_joint1_frag_regs.sh: the big fields' A fragments global -> REGISTERS at kernel entry instead
+// of global -> LDS -> registers at scoring time -- half of a wave's LDS reads in the scoring stage.  8.10 instead of 7.65 us,
+// 10.3 instead of 9.2 us with HBM-resident tables: sixteen waves per CU pulling the same 12 KB through the texture path queue
+// in front of the row gathers, and 110 VGPRs leave four waves per SIMD where 71 leave seven.)
 template <int G_BIG, int NJF>
 __global__ __launch_bounds__(V2J1_WAVES * 64, 4) void k_deepfm_v2_joint1(const V2JRun A, const int* __restrict__ ids,
                                                                        const float* __restrict__ dense, float* __restrict__ out, int B,

@@ -143,7 +143,8 @@ __device__ __forceinline__ float dot4_fma(f32x4 a, f32x4 b, float acc) {
     return fmaf(a.w, b.w, acc);
 }
 
-template <int KPC, int H0C, int H1C, int G_BIG, int NJF, bool HASNUM, int WAVES, bool MB>
+// ONE: one task per wave, no loop -- the strict one-batch launch at up to four waves per SIMD (k_chain_v2j1.h has the measurements)
+template <int KPC, int H0C, int H1C, int G_BIG, int NJF, bool HASNUM, int WAVES, bool MB, bool ONE = false>
 __device__ __forceinline__ void rows_chain_body(const RowsRun& A, const int* __restrict__ ids, const float* __restrict__ dense,
                                                 float* __restrict__ out, int B, int* __restrict__ err,
                                                 const float* __restrict__ image, const RowsMany* __restrict__ Mp) {
@@ -372,8 +373,8 @@ __device__ __forceinline__ void rows_chain_body(const RowsRun& A, const int* __r
     f32x4 rawA = zero, rawB = zero;
     int tA = wave_global, tB = wave_global + task_stride;
     if (ntasks > 0) {
-        ld_raw(clampt(tA), rawA);
-        ld_raw(clampt(tB), rawB);
+        if (!ONE || tA < ntasks) ld_raw(clampt(tA), rawA);
+        if (!ONE) ld_raw(clampt(tB), rawB);
     }
 #pragma unroll 1
     for (int c = wave; c < LD::total_pad / 256; c += WAVES)
@@ -388,7 +389,22 @@ __device__ __forceinline__ void rows_chain_body(const RowsRun& A, const int* __r
                 (__attribute__((address_space(3))) void*)(smem + LD::total_pad + WAVES * LD::stage_floats + c * 256), 16, 0, 0);
     }
     constexpr int NG = G_BIG * (KPC + H0C) + (HASFM ? 1 : 0);        // VMEM loads per gather
-    constexpr bool FAST2 = NG < 16;                                   // the s_waitcnt immediate below encodes vmcnt < 16
+    // s_waitcnt vmcnt(NG), lgkmcnt / expcnt untouched: vmcnt is a 6-bit field split over bits [3:0] and [15:14]
+    constexpr int WAIT_NG = 0x0F70 | (NG & 15) | ((NG >> 4) << 14);
+    static_assert(NG < 64, "vmcnt field");
+    if constexpr (ONE) {
+        // the wave's only task: rows requested before the barrier; in-order retirement => "at most NG outstanding" = DMA landed
+        if (tA < ntasks) {
+            gather(tA, rawA, SA);
+            __builtin_amdgcn_s_waitcnt(WAIT_NG);
+        } else {
+            __builtin_amdgcn_s_waitcnt(0x0F70);
+        }
+        __builtin_amdgcn_s_barrier();
+        load_weights();
+        if (tA < ntasks) store(tA, compute(SA));
+    } else {
+    constexpr bool FAST2 = NG < 16;                                   // (round 2's encoding: vmcnt < 16)
     const bool two = FAST2 && tA < ntasks && ntasks <= 2 * task_stride;
     if (two) {
         gather(tA, rawA, SA);
@@ -422,6 +438,7 @@ __device__ __forceinline__ void rows_chain_body(const RowsRun& A, const int* __r
             if (tA >= ntasks) break;
         }
     }
+    }
     if (__ballot(bad) != 0 && lane == 0) atomicOr(err, 1);
 }
 
@@ -430,6 +447,13 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_rows_chain(const RowsRun A, c
                                                               const float* __restrict__ dense, float* __restrict__ out, int B,
                                                               int* __restrict__ err, const float* __restrict__ image) {
     rows_chain_body<KPC, H0C, H1C, G_BIG, NJF, HASNUM, WAVES, false>(A, ids, dense, out, B, err, image, nullptr);
+}
+// one task per wave (strict one-batch launch): register budget of three waves per SIMD (one gather set instead of two)
+template <int KPC, int H0C, int H1C, int G_BIG, int NJF, bool HASNUM, int WAVES>
+__global__ __launch_bounds__(WAVES * 64, 3) void k_rows_chain1(const RowsRun A, const int* __restrict__ ids,
+                                                               const float* __restrict__ dense, float* __restrict__ out, int B,
+                                                               int* __restrict__ err, const float* __restrict__ image) {
+    rows_chain_body<KPC, H0C, H1C, G_BIG, NJF, HASNUM, WAVES, false, true>(A, ids, dense, out, B, err, image, nullptr);
 }
 // several batches per launch: the per-batch pointer table travels in the kernel arguments (the kernarg segment IS the
 // cheapest transport for 1.5 KB that change every launch: +0.05 us of host time per launch measured by

@@ -71,6 +71,7 @@ class Engine:
         self.n_id_cols = plan.n_id_cols
         self.n_dense = plan.n_dense
         self.n_aux = plan.n_aux
+        self._many_batches, self._many_streams = 1, 0      # forward_many's launch shape: per-call arguments, not handle state
         self.has_din = bool(plan.din.enabled)
         self.din_T = plan.din.T
 
@@ -185,8 +186,8 @@ class Engine:
             stream = torch.cuda.current_stream().cuda_stream
         ws_ptr, ws_bytes = self._check_workspace(workspace, B)
         ids_a, dense_a, out_a = self._many_arrays(ids_list, dense_list, out_list)
-        L.check(self.lib.sprk_forward_many(self.handle, n, ids_a, dense_a, out_a, B, C.c_void_p(ws_ptr), ws_bytes,
-                                           C.c_void_p(stream)))
+        L.check(self.lib.sprk_forward_many_opts(self.handle, n, ids_a, dense_a, out_a, B, C.c_void_p(ws_ptr), ws_bytes,
+                                                C.c_void_p(stream), self._many_batches, self._many_streams))
 
     def prepare_many(self, ids_list, dense_list, out_list, workspace=None):
         """The argument marshalling (and validation) of ``forward_many`` done once: returns ``run(stream=None)`` that
@@ -201,23 +202,32 @@ class Engine:
         ws_ptr, ws_bytes = self._check_workspace(workspace, B)
         ids_a, dense_a, out_a = self._many_arrays(ids_list, dense_list, out_list)
         keep = (list(ids_list or ()), list(dense_list or ()), list(out_list), workspace)
-        fn, handle, ws_p = self.lib.sprk_forward_many, self.handle, C.c_void_p(ws_ptr)
+        fn, handle, ws_p = self.lib.sprk_forward_many_opts, self.handle, C.c_void_p(ws_ptr)
+        per_launch, streams = self._many_batches, self._many_streams        # bound NOW: a prepared run keeps its launch shape
 
         def run(stream: Optional[int] = None, _keep=keep):
             if stream is None:
                 stream = torch.cuda.current_stream().cuda_stream
-            L.check(fn(handle, n, ids_a, dense_a, out_a, B, ws_p, ws_bytes, C.c_void_p(stream)))
+            L.check(fn(handle, n, ids_a, dense_a, out_a, B, ws_p, ws_bytes, C.c_void_p(stream), per_launch, streams))
         return run
 
     def set_many_streams(self, n: int) -> bool:
         """Fan forward_many's independent batches over ``n`` helper streams (0 = strict order).  Models with a workspace
-        (DIN) additionally need ``n`` workspace slices (see ``many_workspace_bytes``)."""
-        L.check(self.lib.sprk_set_many_streams(self.handle, int(n)))
+        (DIN) additionally need ``n`` workspace slices (see ``many_workspace_bytes``).  Kept on the Python object and handed to
+        ``sprk_forward_many_opts`` with every call: the C handle is not modified."""
+        n = int(n)
+        if n < 0 or n > 4:
+            raise ValueError("stream count %d outside [0,4]" % n)
+        self._many_streams = 0 if n < 2 else n
         return True
 
     def set_many_batches(self, n: int) -> bool:
-        """Let one kernel launch score up to ``n`` of forward_many's batches (1 = a launch per batch)."""
-        L.check(self.lib.sprk_set_many_batches(self.handle, int(n)))
+        """Let one kernel launch score up to ``n`` of forward_many's batches (1 = a launch per batch).  A per-call argument
+        of ``sprk_forward_many_opts`` (see ``set_many_streams``)."""
+        n = int(n)
+        if n < 1 or n > 64:
+            raise ValueError("batches per launch %d outside [1,64]" % n)
+        self._many_batches = n
         return True
 
     def many_workspace_bytes(self, B: int, n: int) -> int:
@@ -387,6 +397,21 @@ class CTRModel:
         return scores.cpu().numpy().reshape(-1, 1)
 
     __call__ = predict
+
+    def evaluate(self, x, y=None, batch_size: Optional[int] = None):
+        """Like ``tf.keras.Model.evaluate`` under the reference's ``compile()`` (DeepFM.py:117-126): ``[loss, accuracy, roc_auc,
+        pr_auc]`` -- binary cross-entropy, accuracy at 0.5 and Keras' 200-threshold ROC / PR AUC (``metrics.py``).  ``x`` is a
+        feature dict with the labels in ``y`` (or under the key ``"label"``, as ``make_csv_dataset(label_name='label')`` splits
+        them off), or an iterable of ``(features, labels)`` batches like the reference's ``test_dataset``."""
+        from .metrics import evaluate_scores
+        if isinstance(x, Mapping):
+            labels = x["label"] if y is None else y
+            return evaluate_scores(np.asarray(labels).astype(np.float64).reshape(-1), self.predict(x, batch_size)[:, 0])
+        batches = list(x)
+        if not batches or not all(isinstance(b, (tuple, list)) and len(b) == 2 for b in batches):
+            raise ValueError("evaluate: an iterable of (features, labels) batches, or a feature dict with labels, is required")
+        labels = np.concatenate([np.asarray(b[1]).astype(np.float64).reshape(-1) for b in batches])
+        return evaluate_scores(labels, self.predict(batches, batch_size)[:, 0])
 
     def predict_csv(self, source, batch_size: int = 65536, max_rows: Optional[int] = None) -> np.ndarray:
         """``model.predict(get_dataset(path))`` of the reference (DeepFM.py:14-22,131-133) without the host in the data path:

@@ -36,6 +36,22 @@ def test_gpus_2_self_spawns_ranks_without_a_launcher():
     # 3 warm-up + 2 regions x 10 steps in groups of 4, a partial group flushed at every fence
     assert line["config"]["collectives"] >= (3 + 20) // 4
     assert line["config"]["groups_seen_by_sink"] == line["config"]["collectives"]
+    assert line["config"]["sink_content_ok"] is True
+
+
+def test_gpus_8_dry_run_with_ragged_groups():
+    """the 8-rank shape of the N>1 loop without a node -- eight gloo ranks, groups of 5 steps against
+    regions of 13 (every fence flushes a ragged group of 3), every rank's sink checks every peer's slice of every batch."""
+    res = _run(["--gpus", "8", "--dry-run", "--steps", "13", "--warmup", "3", "--gather-group", "5", "--regions", "2", "--batch", "32"], timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, res.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 8 and line["config"]["global_batch"] == 8 * 32 and line["config"]["group"] == 5
+    # warm-up: 3 steps -> one ragged group; each region: 13 steps -> 5 + 5 + 3
+    assert line["config"]["collectives"] == 1 + 2 * 3
+    assert line["config"]["groups_seen_by_sink"] == line["config"]["collectives"]
+    assert line["config"]["sink_content_ok"] is True
 
 
 def test_single_rank_dry_run_and_world_size_mismatch():

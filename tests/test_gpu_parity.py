@@ -185,8 +185,9 @@ def test_din_attention_kernel_shapes(torch, monkeypatch, T, D, B):
     V, U = 5000, 700
     feats = SY.synth_din(B, T, V, U, seed=100 + T + D)
     got = {}
-    for legacy in ("0", "1"):
-        monkeypatch.setenv("SPRK_DIN_LEGACY", legacy)
+    for legacy in ("0", "wave", "1"):                               # k_din_attn_cols / k_din_attn (wave per sample) / k_din_pool
+        monkeypatch.setenv("SPRK_DIN_LEGACY", "1" if legacy == "1" else "0")
+        monkeypatch.setenv("SPRK_DIN_COLS", "0" if legacy == "wave" else "1")
         model = M.DIN(seed=50 + T, emb_dim=D, hist_len=T, movie_buckets=V, user_buckets=U)
         ids, dense = model.pack(feats)
         eng = model.engine
@@ -200,7 +201,7 @@ def test_din_attention_kernel_shapes(torch, monkeypatch, T, D, B):
         eng.close()
     ref, parts = O.din_forward(feats, model.weights, dtype=np.float64, hist_len=T, movie_buckets=V, user_buckets=U,
                                return_parts=True)
-    for legacy in ("0", "1"):
+    for legacy in ("0", "wave", "1"):
         a, p, sc = got[legacy]
         assert np.isfinite(a).all() and np.isfinite(p).all()
         assert np.abs(a - parts["att"]).max() <= TIGHT
@@ -208,6 +209,31 @@ def test_din_attention_kernel_shapes(torch, monkeypatch, T, D, B):
         assert not p[:, D:].any()
         assert np.abs(sc - ref[:, 0]).max() <= TOL
     assert np.abs(got["0"][0] - got["1"][0]).max() <= 2e-6      # two summation orders of the same fp32 math
+    assert np.abs(got["0"][0] - got["wave"][0]).max() <= 2e-6
+
+
+@pytest.mark.parametrize("T,D", [(50, 32), (5, 10), (23, 16)])
+def test_din_cols_result_does_not_depend_on_the_launch_shape(torch, T, D):
+    """k_din_attn_cols gives a task to 1, 2 or 4 waves depending on how many tasks a launch has (time slices of the history);
+    the pooled sum is formed as (q0 + q1) + (q2 + q3) over the four quarters' in-order partial sums whichever it is, so a
+    row's pooled vector must be the SAME BITS in a 20 000-row launch (one wave per task), a 9 000-row launch (two) and a
+    600-row launch (four) -- and in the several-batches-per-launch form."""
+    V, U, B = 5000, 700, 20000
+    feats = SY.synth_din(B, T, V, U, seed=300 + T)
+    model = M.DIN(seed=60 + T, emb_dim=D, hist_len=T, movie_buckets=V, user_buckets=U)
+    ids, dense = model.pack(feats)
+    eng = model.engine
+    ti = _cuda(torch, ids)
+    full = torch.empty((B, eng.n_aux), dtype=torch.float32, device="cuda")
+    eng.din_pool(ti, full, None)
+    for n in (9000, 600, 37):
+        part = torch.empty((n, eng.n_aux), dtype=torch.float32, device="cuda")
+        eng.din_pool(ti[:n].contiguous(), part, None)
+        assert torch.equal(part, full[:n]), "pooled vectors of a %d-row launch differ from the %d-row launch" % (n, B)
+    eng.check_ids()
+    _, parts = O.din_forward({k: v[:2048] for k, v in feats.items()}, model.weights, dtype=np.float64, hist_len=T, movie_buckets=V,
+                             user_buckets=U, return_parts=True)
+    assert np.abs(full[:2048, :D].cpu().numpy() - parts["pooled"]).max() <= TIGHT
 
 
 def test_din_attention_kernel_bad_ids_raise(torch):
@@ -763,8 +789,18 @@ def test_forward_many_several_batches_per_launch(torch, B, n, k):
         torch.cuda.synchronize()
         for a, o in zip(res[1], outs):
             np.testing.assert_array_equal(a, o.cpu().numpy())
-    with pytest.raises(L.SparrowHipError):
+    with pytest.raises(ValueError):
         eng.set_many_batches(65)
+    # the C ABI keeps the setters as the DEFAULTS of sprk_forward_many; the per-call form refuses a bad shape itself
+    import ctypes as C
+    ids_a, dense_a, out_a = eng._many_arrays(ids[:2], dense[:2], outs[:2])
+    with pytest.raises(L.SparrowHipError):
+        L.check(eng.lib.sprk_forward_many_opts(eng.handle, 2, ids_a, dense_a, out_a, B, None, 0, None, 65, 0))
+    L.check(eng.lib.sprk_set_many_batches(eng.handle, 2))
+    L.check(eng.lib.sprk_forward_many(eng.handle, 2, ids_a, dense_a, out_a, B, None, 0, None))
+    torch.cuda.synchronize()
+    for a, o in zip(res[1][:2], outs[:2]):
+        np.testing.assert_array_equal(a, o.cpu().numpy())
 
 
 @pytest.mark.parametrize("shape,B,n,k", [("config2", 4099, 7, 4), ("reference", 1000, 19, 16), ("config2", 16, 3, 2)])

@@ -52,7 +52,7 @@ def _check(torch, name, B, expect_kernel, sample=SAMPLE):
     got = p.cpu().numpy()[idx]
     assert np.isfinite(got).all()
     assert np.abs(got - ref).max() <= TOL
-    assert ref.std() > 0.03                                                            # scores are spread out: not a vacuous comparison
+    assert ref.std() > 0.02                                                            # scores are spread out: not a vacuous comparison
     tables = eng.table_bytes()
     eng.close()
     return tables
