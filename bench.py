@@ -315,12 +315,89 @@ def cpu_baseline_c(name, model, feats, budget_s, note):
         return None
 
 
+def cpu_baseline_tf(name, model, feats, budget_s, note):
+    """probe ``import tensorflow`` FIRST.  When it works (it does not in the build container or on the
+    GPU box: no network), the headline graph is rebuilt with tf.keras layers from the same weights -- Embedding tables with a
+    zero row for the missing id, the per-field Dense projections, the FM sum-of-squares cross, the 32-16 MLP (DeepFM_v2.py:98-157
+    at config 2's shape; the reference script itself hard-codes 4 fields / emb_dim 10 and is what tests/golden/make_tf_golden.py
+    executes) -- checked against the oracle to 1e-4 and ``model.predict(x, batch_size=B)`` is timed on all host cores.  Returns
+    None (and says why in `note`) otherwise.  UNTESTED CODE PATH: no TensorFlow has ever been importable where this ran."""
+    if name != "deepfm_v2_c2":
+        return None
+    try:
+        import tensorflow as tf
+    except Exception as e:
+        note.append("TensorFlow not importable (%s): CPU restatement timed instead" % type(e).__name__)
+        return None
+    try:
+        from sparrowrecsys_amd import synthetic as SY
+        from sparrowrecsys_amd.models import first_order_offsets
+        fields = getattr(model, "_bench_fields", SY.CONFIG2_FIELDS)
+        w = model.weights
+        K = tf.keras
+        ids_in = K.layers.Input(shape=(len(fields),), dtype="int32")
+        num_in = K.layers.Input(shape=(7,), dtype="float32")
+        fo = first_order_offsets(fields)
+        projected, first = [], []
+        for i, (k, _, v) in enumerate(fields):
+            idc = tf.where(ids_in[:, i] < 0, v, ids_in[:, i])                    # -1 (missing / OOV) -> the zero row at index v
+            tab = np.concatenate([np.asarray(w["emb/" + k]), np.zeros((1, w["emb/" + k].shape[1]), np.float32)])
+            e = K.layers.Embedding(v + 1, tab.shape[1], weights=[tab], trainable=False)(idc)
+            projected.append(K.layers.Dense(w["proj/%s/kernel" % k].shape[1], weights=[w["proj/%s/kernel" % k], w["proj/%s/bias" % k]])(e))
+            fw = np.concatenate([np.asarray(w["fo_cat/kernel"])[fo[k]:fo[k] + v], np.zeros((1, 1), np.float32)])
+            first.append(K.layers.Embedding(v + 1, 1, weights=[fw], trainable=False)(idc))
+        order = [k for k, _, _ in fields]
+        projected = [projected[order.index(k)] for k in model.order]
+        projected.append(K.layers.Dense(w["proj/num/kernel"].shape[1], weights=[w["proj/num/kernel"], w["proj/num/bias"]])(num_in))
+        stack = tf.stack(projected, axis=1)
+        fo_num = K.layers.Dense(1, weights=[w["fo_num/kernel"], w["fo_num/bias"]])(num_in)
+        first_order = tf.add_n(first) + w["fo_cat/bias"] + fo_num
+        s = tf.reduce_sum(stack, axis=1)
+        fm = s * s - tf.reduce_sum(stack * stack, axis=1)
+        deep = K.layers.Flatten()(stack)
+        i = 0
+        while "deep%d/kernel" % i in w:
+            deep = K.layers.Dense(w["deep%d/kernel" % i].shape[1], activation="relu", weights=[w["deep%d/kernel" % i], w["deep%d/bias" % i]])(deep)
+            i += 1
+        out = K.layers.Dense(1, activation="sigmoid", weights=[w["head/kernel"], w["head/bias"]])(tf.concat([first_order, fm, deep], axis=1))
+        km = K.Model([ids_in, num_in], out)
+        ids, dense = model.pack(feats[0])
+        n = ids.shape[0]
+        got = km.predict([ids[:2048], dense[:2048]], batch_size=2048, verbose=0)[:, 0]
+        ref = oracle_forward(name, model, {k: v[:2048] for k, v in feats[0].items()})[:, 0]
+        if not (np.abs(got - ref).max() <= 1e-4):
+            note.append("TensorFlow graph disagreed with the oracle (max |diff| %g): not used" % np.abs(got - ref).max())
+            return None
+        km.predict([ids, dense], batch_size=n, verbose=0)
+        t0, done = time.perf_counter(), 0
+        while True:
+            km.predict([ids, dense], batch_size=n, verbose=0)
+            done += n
+            el = time.perf_counter() - t0
+            if el >= budget_s or done >= 64 * n:
+                break
+        return {"value": done / el, "unit": "samples/s", "cores": os.cpu_count(), "kind": "port", "ran": "tensorflow %s (tf.keras graph of the same weights)" % tf.__version__,
+                "sample": "TF2 CPU forward of the DeepFM_v2 graph at config 2's shape, model.predict(batch_size=%d), %d passes, %.1f s" % (n, done // n, el),
+                "host_cpus": os.cpu_count()}
+    except Exception as e:
+        note.append("TensorFlow leg failed (%s: %s): CPU restatement timed instead" % (type(e).__name__, e))
+        return None
+
+
 def cpu_baseline(name, model, feats, budget_s):
-    """The CPU restatement ("port": TensorFlow is not installable) timed on this host's cores over a bounded sample of
+    """TensorFlow first when it can be imported (`cpu_baseline_tf`), otherwise -- the expected case --
+    the CPU restatement ("port": TensorFlow is not installable) timed on this host's cores over a bounded sample of
     the same workload: the C restatement where there is one (DeepFM_v2, DIN), with the numpy oracle's rate reported next
-    to it; the numpy oracle otherwise.  `ran` names the one that produced `value`."""
+    to it; the numpy oracle otherwise.  `ran` names the one that produced `value`, `tensorflow` says why TF did not."""
+    note = []
+    t = cpu_baseline_tf(name, model, feats, 0.5 * budget_s, note)
+    if t is not None:
+        return t
+    tf_note = "; ".join(note)
     note = []
     c = cpu_baseline_c(name, model, feats, 0.5 * budget_s, note)
+    if c is not None and tf_note:
+        c["tensorflow"] = tf_note
     if c is not None:
         npy = cpu_baseline_numpy(name, model, feats, 0.5 * budget_s)
         c["numpy_oracle_samples_per_sec"] = npy["value"]

@@ -262,8 +262,9 @@ int setup_deepfm_pairs(sprk_engine* h) {
     }
     r.tab = nullptr;
     if (PC == 1 && h->tune.v1_rowtab) {
-        // own deep tables: rows of <= 12 floats ride in their field's line (float 20..), wider ones get rows of their own
-        const bool pack = sep && Dp <= 12;
+        // own deep tables ride in their field's 128-byte line: rows of <= 12 floats at float 20 (w1 stays at float 16), rows of 16
+        // floats at float 16 with the first-order weights of those fields moved to a compact array (V1Run::pack)
+        const int pack = !sep ? 0 : (Dp <= 12 ? 80 : (Dp == 16 ? 64 : 0));
         size_t rows = 0;
         for (int f = 0; f < nf; ++f) rows += (size_t)r.vocab[f] + 1;
         if (sep && !pack) for (int d = 0; d < r.n_deep; ++d) rows += (size_t)r.vocab[d] + 1;
@@ -272,21 +273,33 @@ int setup_deepfm_pairs(sprk_engine* h) {
             HIP_TRY(hipMalloc((void**)&tab, rows * 128));
             h->v1_bufs.push_back(tab);
             h->derived_bytes += rows * 128;
+            float* w1c = nullptr;
+            if (pack == 64) {
+                size_t nw = 0;
+                for (int d = 0; d < r.n_deep; ++d) { r.w1cbase[d] = (unsigned)nw; nw += (size_t)r.vocab[d] + 1; }
+                HIP_TRY(hipMalloc((void**)&w1c, nw * sizeof(float) + 16));
+                h->v1_bufs.push_back(w1c);
+                for (int d = 0; d < r.n_deep; ++d)
+                    HIP_TRY(hipMemcpy(w1c + r.w1cbase[d], r.w1[d], ((size_t)r.vocab[d] + 1) * sizeof(float), hipMemcpyDeviceToDevice));
+            }
             size_t base = 0;
             for (int f = 0; f < nf + ((sep && !pack) ? r.n_deep : 0); ++f) {
                 const bool deep_row = f >= nf;
+                const bool packed_here = pack && f < r.n_deep;
                 const long long n = (long long)r.vocab[deep_row ? f - nf : f] + 1;
                 long long nb = (n * 32 + 255) / 256;
                 if (nb > 65536) nb = 65536;
-                hipLaunchKernelGGL(k_v1_build_rows, dim3((unsigned)nb), dim3(256), 0, 0, r.table[f], Dp, deep_row ? (const float*)nullptr : r.w1[f], n,
-                                   tab + base * 32, (pack && f < r.n_deep) ? r.table[nf + f] : (const float*)nullptr);
+                hipLaunchKernelGGL(k_v1_build_rows, dim3((unsigned)nb), dim3(256), 0, 0, r.table[f], Dp,
+                                   (deep_row || (packed_here && pack == 64)) ? (const float*)nullptr : r.w1[f], n, tab + base * 32,
+                                   packed_here ? r.table[nf + f] : (const float*)nullptr, pack / 4);
                 r.rowbase[f] = (unsigned)base;
                 base += (size_t)n;
             }
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipDeviceSynchronize());
             r.tab = tab;
-            r.pack = pack ? 1 : 0;
+            r.pack = pack;
+            r.w1c = w1c;
         }
     }
     {

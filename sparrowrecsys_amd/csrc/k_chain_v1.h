@@ -41,7 +41,12 @@ struct V1Run {
     // movieId / userId embedding variables, distinct from the FM part's DeepFM.py:91-92) = rows nf .. nf+n_deep-1; sep = 0: tied
     // tables, the deep columns are fields 0 .. n_deep-1's rows themselves
     int sep;
-    int pack;                             // sep, narrow rows of <= 12 floats: the deep row rides in its field's 128-byte line at float 20
+    // sep, narrow rows: the deep row rides in its field's 128-byte line -- `pack` = its byte offset there (0 = rows of its own).
+    // Rows of <= 12 floats: {E 48 B | . | w1 at 64 | . | E_deep at 80}; 16 floats: {E 64 B | E_deep 64 B} and the first-order
+    // weights of these fields in the compact array w1c (an L2-resident 4-byte gather instead of a third line per deep field)
+    int pack;
+    const float* w1c;                     // pack == 64: first-order weights of fields 0 .. n_deep-1, [vocab+1] each, back to back
+    unsigned w1cbase[V1_MAX_DEEP];
     float pw[V1_MAX_FIELDS * V1_MAX_FIELDS];   // head weight of pair (a,b), a < b, at a*V1_MAX_FIELDS + b; 0 = not a pair
     const float* w0;                      // deep0 W^T packed [H0][16*(V1_MAX_DEEP+1)]: deep field chunks, then the numerics chunk (zero padded)
     const float* b0;                      // [H0]
@@ -64,16 +69,15 @@ struct V1Run {
 };
 
 // One-time (finalize) kernel: rows of one field of the derived table
-// (w1 == NULL: a deep-only table, no first-order weight; deep != NULL: the deep part's row of the same id packed at float 20,
-// Dp <= 12)
+// (w1 == NULL: no first-order weight in the row; deep != NULL: the deep part's row of the same id packed at float deep_off)
 __global__ __launch_bounds__(256) void k_v1_build_rows(const float* __restrict__ table, int Dp, const float* __restrict__ w1,
-                                                       long long rows, float* __restrict__ out, const float* __restrict__ deep) {
+                                                       long long rows, float* __restrict__ out, const float* __restrict__ deep, int deep_off) {
     const long long total = rows * 32;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
         const long long v = i >> 5;
         const int c = (int)(i & 31);
         float x = c < Dp ? table[v * Dp + c] : ((c == 16 && w1) ? w1[v] : 0.f);
-        if (deep && c >= 20 && c - 20 < Dp) x = deep[v * Dp + (c - 20)];
+        if (deep && c >= deep_off && c - deep_off < Dp) x = deep[v * Dp + (c - deep_off)];
         out[i] = x;
     }
 }
@@ -232,7 +236,7 @@ __device__ __forceinline__ void v1_body(const V1Run& A, const int* __restrict__ 
                 for (int d = 0; d < V1_MAX_DEEP; ++d) {
                     S.x[NF + d][0] = zero;
                     if (d < A.n_deep) {                           // (wave-uniform)
-                        const unsigned rd = A.pack ? ro[d] + 80u : (sid[d] + A.rowbase[NF + d]) * 128u;
+                        const unsigned rd = A.pack ? ro[d] + (unsigned)A.pack : (sid[d] + A.rowbase[NF + d]) * 128u;
                         if (q < NV) S.x[NF + d][0] = *reinterpret_cast<const f32x4*>(tb + (rd + 16u * q));
                     }
                 }
@@ -245,7 +249,12 @@ __device__ __forceinline__ void v1_body(const V1Run& A, const int* __restrict__ 
             if (NF > 5) ob = q == 1 ? ro[NF > 5 ? 5 : 0] : ob;
             if (NF > 6) ob = q == 2 ? ro[NF > 6 ? 6 : 0] : ob;
             if (NF > 7) ob = q == 3 ? ro[NF > 7 ? 7 : 0] : ob;
-            S.w1a = (q < NF) ? *reinterpret_cast<const float*>(tb + (oa + 64u)) : 0.f;
+            const float* pa = reinterpret_cast<const float*>(tb + (oa + 64u));
+            if (A.w1c) {                                          // (wave-uniform) fields 0 .. n_deep-1: the compact array
+                const unsigned ci = (q == 1 ? sid[1] + A.w1cbase[1] : sid[0] + A.w1cbase[0]);
+                pa = q < A.n_deep ? A.w1c + ci : pa;
+            }
+            S.w1a = (q < NF) ? *pa : 0.f;
             S.w1b = (NF > 4 && q + 4 < NF) ? *reinterpret_cast<const float*>(tb + (ob + 64u)) : 0.f;
             return;
         }
