@@ -175,7 +175,8 @@ def build_workload(name, B, dist_name, seed_offset=0, big_vocab=0, NB=8):
         # blocks (A_b = W12 + W4 diag(c)), over whole 16-row groups (T=50 -> 64 columns), 3 split-f16 products
         executed = ((T + 15) // 16) * 16 * 2 * D * 32
         legacy = env("SPRK_DIN_LEGACY") == "1"
-        roof = {"bound": "mfma", "kernel": "k_din_pool" if legacy else "k_din_attn", "flops_per_sample": flops,
+        att_kernel = "k_din_pool" if legacy else ("k_din_attn" if (env("SPRK_DIN_COLS") == "0" or env("SPRK_DIN_HALF") == "0") else "k_din_attn_cols")
+        roof = {"bound": "mfma", "kernel": att_kernel, "hist_len": T, "flops_per_sample": flops,
                 "executed_flops_per_sample": flops if legacy else executed,
                 "bytes_per_sample": (T + 1) * 4 + (T + 1) * D * 4 + D * 4,
                 "tail_reference_flops": 2 * ((7 + 5 * D) * 128 + 128 * 64 + 64)}
@@ -804,7 +805,7 @@ def main():
                       "frac": achieved * 1e9 / HBM_PEAK,
                       "reference_flops_per_sample": roof["flops_per_sample"],
                       "reference_equivalent_TFLOPs": roof["flops_per_sample"] * B / din_s / 1e12}
-                extra["roofline_mfma"] = mfma_block("k_din_attn", mfma_issued("k_din_attn", roof["flops_per_sample"]), B, din_s)
+                extra["roofline_mfma"] = mfma_block(roof["kernel"], mfma_issued(roof["kernel"], roof["flops_per_sample"], hist_len=roof["hist_len"]), B, din_s)
                 if eng.kernel_name() == "k_din_tail":
                     extra["roofline_mfma_tail"] = mfma_block("k_din_tail", mfma_issued("k_din_tail", roof["tail_reference_flops"]), B,
                                                              max(fwd_s - din_s, 1e-9))
@@ -903,13 +904,17 @@ MFMA_ISSUED = {
     "k_din_tail": {"per": 16, "f32": 96, "f16": 48},
     # per SAMPLE: 4 sixteen-row groups x 2 n-blocks x 3 split products
     "k_din_attn": {"per": 1, "f32": 0, "f16": 24},
+    # per (16 samples, history slot): two K blocks ([h], [h * c]) x 2 n-blocks x 3 split products; "f16" is filled in per T below
+    "k_din_attn_cols": {"per": 16, "f32": 0, "f16_per_slot": 12},
 }
 
 
-def mfma_issued(kernel, reference_flops_per_sample, wide_rows=False):
+def mfma_issued(kernel, reference_flops_per_sample, wide_rows=False, hist_len=None):
     m = MFMA_ISSUED.get(kernel)
     if not m:
         return None
+    if "f16_per_slot" in m:
+        m = {"per": m["per"], "f32": m["f32"], "f16": m["f16_per_slot"] * (hist_len or 1)}
     if wide_rows and kernel == "k_deepfm_pairs":
         m = {"per": 16, "f32": 8, "f16": 48 + 24}        # emb_dim 64: deep0's embedding block is four K = 32 blocks
     return {"f32_flops_per_sample": m["f32"] * 2048.0 / m["per"], "f16_flops_per_sample": m["f16"] * 16384.0 / m["per"],
@@ -1059,13 +1064,13 @@ def side_workload(args, name):
         att(); torch.cuda.synchronize()
         din_s = _event_loop(att, n_att)
         ach = roof["bytes_per_sample"] * B / din_s / 1e9
-        blk["roofline"] = {"bound": "hbm", "kernel": "k_din_attn (one batch of %d rows per launch)" % B, "achieved": ach, "peak": HBM_PEAK / 1e9,
+        blk["roofline"] = {"bound": "hbm", "kernel": "%s (one batch of %d rows per launch)" % (roof["kernel"], B), "achieved": ach, "peak": HBM_PEAK / 1e9,
                            "unit": "GB/s", "frac": ach * 1e9 / HBM_PEAK, "algorithmic_bytes_per_sample": roof["bytes_per_sample"],
                            "avg_launch_us": din_s * 1e6, "step_us_all_kernels_strict": fwd_s * 1e6,
                            "reference_flops_per_sample": roof["flops_per_sample"],
                            "reference_equivalent_TFLOPs": roof["flops_per_sample"] * B / din_s / 1e12,
                            "timed_with": "HIP events, attention-only loop, strict order, %d launches" % n_att}
-        blk["roofline_mfma"] = mfma_block("k_din_attn", mfma_issued("k_din_attn", roof["flops_per_sample"]), B, din_s)
+        blk["roofline_mfma"] = mfma_block(roof["kernel"], mfma_issued(roof["kernel"], roof["flops_per_sample"], hist_len=roof["hist_len"]), B, din_s)
         if eng.kernel_name() == "k_din_tail":
             blk["roofline_mfma_tail"] = mfma_block("k_din_tail", mfma_issued("k_din_tail", roof["tail_reference_flops"]), B,
                                                    max(fwd_s - din_s, 1e-9))

@@ -13,25 +13,22 @@ TensorFlow is not installable here, so every ``tf.*`` call is restated from its
 published semantics (SURVEY.md §8(c) checklist).
 
 PARITY PIN STATUS: the reference has no tests and no golden vectors
-("parity unpinned" by the reference itself).  What pins this oracle instead:
-(1) tests/test_savedmodel_pins.py -- the seven SavedModels the reference EXPORTED
-(``webroot/modeldata/{neuralcf/001,002, MLPRec/001..005}/saved_model.pb``) are
-executed op by op by oracle/tf_graph_exec.py (a numpy interpreter of their
-GraphDefs) on rows of the reference's testSamples.csv, and this oracle must agree
-to 1e-6: that pins categorical_column_with_identity + embedding_column (the
-SparseFillEmptyRows / SparseSegmentMean chain), categorical_column_with_vocabulary_list
-+ indicator_column (genre index = list position, OOV -> zero row), numeric_column,
-DenseFeatures' name-sorted concat, Dense, concatenate and Dot to the wiring
-TensorFlow itself generated for the reference; outputs are committed as
-tests/golden/savedmodel_exec.npz.  (2) tests/test_oracle_pins.py: the trained checkpoints the reference ships under
-``webroot/modeldata`` evaluated on its ``testSamples.csv`` reproduce sane
-known answers (NeuralCF/001 ROC-AUC 0.7514, NeuralCF/002 0.7321, MLPRec/004
-0.7353 only with name-sorted DenseFeatures order, two-tower MLPRec/005 0.7320)
--- these pin table/kernel layouts, concat orders and the DenseFeatures column
-sort.  STILL UNPINNED (no exported graph, no checkpoint, no vector in the
-reference): DIN's attention unit / PReLU shapes / pooling, DeepFM(_v2)'s FM wiring,
-Wide&Deep's FingerprintCat64 cross hash, DIEN -- restated semantics only (their
-feature-column inputs are the pinned ones above).
+("parity unpinned" by the reference itself).  What pins this oracle instead (DESIGN.md section 2):
+(1) tests/test_farmhash_pins.py -- the cross hash (FingerprintCat64 chain, default key, unsigned modulo) reproduces the
+known answers of TensorFlow's own sparse_cross_op_test.py (oracle/farmhash64.py).
+(2) tests/test_savedmodel_pins.py -- the seven SavedModels the reference EXPORTED
+(``webroot/modeldata/{neuralcf/001,002, MLPRec/001..005}/saved_model.pb``) executed op by op by oracle/tf_graph_exec.py
+on rows of the reference's testSamples.csv; this oracle agrees to 1e-6: pins categorical_column_with_identity +
+embedding_column, categorical_column_with_vocabulary_list + indicator_column, numeric_column, DenseFeatures' name-sorted
+concat, Dense, concatenate and Dot to the wiring TensorFlow itself generated.
+(3) tests/test_reference_blocks.py -- the reference's OWN model-building lines (DIN.py, DeepFM.py, DeepFM_v2.py,
+WideNDeep.py, NeuralCF.py), exec-uted untouched on oracle/keras_shim.py (and on TensorFlow where importable:
+tests/golden/make_tf_golden.py); this oracle agrees to 1e-6 with the shim run -- the WIRING of DIN's attention unit /
+PReLU shapes / pooling, DeepFM(_v2)'s FM crosses and Wide&Deep's crossed column is the reference's code, not a reading of
+it (that run is what found DeepFM.py's two tables per deep key).
+(4) tests/test_oracle_pins.py: the trained checkpoints' known answers (ROC-AUC 0.7514 / 0.7321 / 0.7353 / 0.7320).
+STILL WITHOUT A TENSORFLOW-PRODUCED VECTOR: DIN, DeepFM, DeepFM_v2, Wide&Deep end to end (the ``unpinned`` tests XFAIL
+until tests/golden/refblock_tf_*.npz exist), DIEN.
 
 Every function cites the reference file:line it follows.  ``dtype`` selects the
 arithmetic type: float32 reproduces the reference's fp32 CPU forward, float64 is
