@@ -14,6 +14,7 @@ library or without a HIP device ``predict`` raises ``RuntimeError``.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Dict, List, Mapping, Optional, Sequence, Tuple
 
 import numpy as np
@@ -74,6 +75,14 @@ class Engine:
         self._many_batches, self._many_streams = 1, 0      # forward_many's launch shape: per-call arguments, not handle state
         self.has_din = bool(plan.din.enabled)
         self.din_T = plan.din.T
+        d = self.describe()
+        if d.get("fused") != "1" and os.environ.get("SPRK_FORCE_INTERPRETER") != "1" and os.environ.get("SPRK_QUIET") != "1":
+            # a shape without a fused instantiation is served by the plan interpreter, correct but 6-14x slower: say so once,
+            # where the model is built, not only to whoever thinks of calling describe()
+            import warnings
+            warnings.warn("sparrowrecsys_amd: this model shape has no fused kernel and runs on the plan interpreter "
+                          "(kernel=%s, stage=%s): expect a tenth of the fused kernels' throughput; the shapes that have one are "
+                          "listed in DESIGN.md section 5" % (d.get("kernel"), d.get("stage") or "-"), RuntimeWarning, stacklevel=3)
 
     def describe(self) -> Dict[str, str]:
         """``sprk_describe``: which kernel instantiation scores a batch (``kernel``; ``k_tile_forward`` = the generic plan
