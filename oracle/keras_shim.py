@@ -132,7 +132,10 @@ def _activation(a):
     if a == "relu":
         return lambda x: np.maximum(x, F32(0))
     if a == "sigmoid":
-        return lambda x: (F32(1) / (F32(1) + np.exp(-x))).astype(F32)
+        def sig(x):
+            with np.errstate(over="ignore"):           # exp(-x) -> inf for very negative x: 1 / inf = 0, as TensorFlow's logistic
+                return (F32(1) / (F32(1) + np.exp(-x))).astype(F32)
+        return sig
     raise NotImplementedError("activation %r" % (a,))
 
 
@@ -177,6 +180,13 @@ class Layer:
         syms = inputs if isinstance(inputs, (list, tuple)) else [inputs]
         if isinstance(inputs, dict):
             syms = list(inputs.values())
+        if not any(isinstance(v, Sym) for v in syms):
+            # eager call on concrete arrays (tf.keras.Sequential builds its layers at the first batch it sees)
+            if not self.built:
+                shapes = [(None,) + tuple(np.asarray(v).shape[1:]) for v in syms]
+                self.build(shapes[0] if not isinstance(inputs, (list, tuple, dict)) else shapes)
+                self.built = True
+            return self.call(inputs)
         if not self.built:
             shapes = [s.shape for s in syms if isinstance(s, Sym)]
             self.build(shapes[0] if not isinstance(inputs, (list, tuple, dict)) else shapes)
@@ -553,6 +563,22 @@ class Model:
         return np.asarray(_eval(self.output, memo), dtype=F32)
 
 
+class Sequential:
+    """keras/engine/sequential.py: a stack of layers; without an Input layer the variables are created at the first batch."""
+
+    def __init__(self, layers=None, **kw):
+        self.layers = list(layers or [])
+
+    def compile(self, **kw):
+        pass
+
+    def predict(self, x, batch_size=None, **kw):
+        v = x
+        for layer in self.layers:
+            v = layer(v)
+        return np.asarray(v, dtype=F32)
+
+
 def _squeeze(x, axis=None):
     return _op(lambda v: np.squeeze(v, axis=axis), x)
 
@@ -581,7 +607,7 @@ def build_module():
         Concatenate=Concatenate, concatenate=concatenate, multiply=multiply, subtract=subtract, add=add, Flatten=Flatten,
         RepeatVector=RepeatVector, Permute=Permute, Reshape=Reshape, Lambda=Lambda, Layer=Layer, DenseFeatures=DenseFeatures)
     tf.keras = types.SimpleNamespace(
-        layers=layers, Model=Model,
+        layers=layers, Model=Model, Sequential=Sequential,
         backend=types.SimpleNamespace(sum=_reduce_sum, clear_session=clear_session),
         metrics=types.SimpleNamespace(AUC=_AUC))
     tf.feature_column = types.SimpleNamespace(

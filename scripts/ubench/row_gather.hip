@@ -51,6 +51,41 @@ __global__ __launch_bounds__(THREADS) void k_gather(const char* __restrict__ tab
     }
 }
 
+// ---- decomposition of what k_deepfm_v2_joint1 adds on top of the gather (512 wg x 512 thr, one task per wave) ----
+//   STAGE: every workgroup first copies `stage_kb` KB global -> LDS by LDS-DMA (its share per wave), then a barrier
+//   READS: after its rows have landed every wave reads `reads_kb` KB from LDS (16 B per lane per read)
+extern __shared__ float dyn_lds[];
+template <bool STAGE>
+__global__ __launch_bounds__(512, 4) void k_gather1(const char* __restrict__ tab, const unsigned* __restrict__ ids, float* __restrict__ out, int B,
+                                                  const float* __restrict__ image, int stage_kb, int reads_kb) {
+    const int lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4, wave = threadIdx.x >> 6;
+    const int task = blockIdx.x * 8 + wave;
+    const int m = task * 16 + r;
+    unsigned id[3];
+#pragma unroll
+    for (int f = 0; f < 3; ++f) id[f] = m < B ? ids[(size_t)m * 3 + f] : 0u;
+    if (STAGE) {
+        for (int c = wave; c < stage_kb; c += 8)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(image + c * 256 + lane * 4),
+                                             (__attribute__((address_space(3))) void*)(dyn_lds + c * 256), 16, 0, 0);
+    }
+    f32x4 x[3];
+#pragma unroll
+    for (int f = 0; f < 3; ++f) x[f] = *reinterpret_cast<const f32x4*>(tab + ((size_t)id[f] * 128u + 16u * q));
+    const unsigned s = q == 1 ? id[1] : (q == 2 ? id[2] : id[0]);
+    const float sc = *reinterpret_cast<const float*>(tab + ((size_t)s * 128u + 64u));
+    if (STAGE) {
+        __builtin_amdgcn_s_waitcnt(0x0F70 | 4);
+        __builtin_amdgcn_s_barrier();
+    }
+    f32x4 acc = x[0] + x[1] + x[2];
+    for (int k = 0; k < reads_kb; ++k) acc += *reinterpret_cast<const f32x4*>(dyn_lds + ((k * 64 + lane) * 4) % (stage_kb > 0 ? stage_kb * 256 : 256));
+    float z = acc.x + acc.y + acc.z + acc.w + (q < 3 ? sc : 0.f);
+    z += __shfl_xor(z, 16);
+    z += __shfl_xor(z, 32);
+    if (q == 0 && m < B) out[m] = z;
+}
+
 static unsigned long long rng_state = 88172645463325252ull;
 static inline unsigned long long xr() { rng_state ^= rng_state << 13; rng_state ^= rng_state >> 7; rng_state ^= rng_state << 17; return rng_state; }
 
@@ -110,6 +145,42 @@ int main(int argc, char** argv) {
             const char* sn = shape == 0 ? "256 wg x 512 thr, 2 tasks/wave" : shape == 1 ? "1024 wg x 256 thr, 1 task/wave " : "256 wg x 256 thr, 4 tasks/wave ";
             printf("  %s : %.2f us/launch (best %.2f)  = %.2f TB/s of 128-B lines, %.1f %% of 8 TB/s on 464 B/sample\n", sn, sum / reps, best,
                    196608.0 * 128 / (sum / reps) / 1e6, 464.0 * B / (sum / reps) / 8e6 * 100);
+        }
+        if (d.kind == 0 || d.kind == 1) {
+            float* image;
+            CK(hipMalloc(&image, 64 * 1024));
+            CK(hipMemset(image, 0, 64 * 1024));
+            CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gather1<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+            CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gather1<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+            struct V { const char* name; bool stage; int stage_kb, reads_kb; };
+            const V vs[] = {{"512 wg x 512 thr, 1 task/wave, gather only          ", false, 0, 0},
+                            {"  + 31 KB LDS-DMA per workgroup + barrier            ", true, 31, 0},
+                            {"  + 31 KB staging + 13 KB of LDS reads per wave      ", true, 31, 13},
+                            {"  + 31 KB staging + 26 KB of LDS reads per wave      ", true, 31, 26},
+                            {"  + 16 KB staging + 13 KB of LDS reads per wave      ", true, 16, 13}};
+            for (const V& v : vs) {
+                auto launch = [&](int b) {
+                    const unsigned* ib = ids + (size_t)b * B * 3;
+                    float* ob = out + (size_t)b * B;
+                    if (v.stage) hipLaunchKernelGGL((k_gather1<true>), dim3(512), dim3(512), 40 * 1024, 0, tab, ib, ob, B, image, v.stage_kb, v.reads_kb);
+                    else hipLaunchKernelGGL((k_gather1<false>), dim3(512), dim3(512), 4096, 0, tab, ib, ob, B, image, v.stage_kb, v.reads_kb);
+                };
+                for (int i = 0; i < 200; ++i) launch(i % NB);
+                CK(hipDeviceSynchronize());
+                double sum = 0;
+                const int n = 2000, reps = 5;
+                for (int rep = 0; rep < reps; ++rep) {
+                    CK(hipEventRecord(e0, 0));
+                    for (int i = 0; i < n; ++i) launch(i % NB);
+                    CK(hipEventRecord(e1, 0));
+                    CK(hipEventSynchronize(e1));
+                    float ms;
+                    CK(hipEventElapsedTime(&ms, e0, e1));
+                    sum += ms * 1e3 / n;
+                }
+                printf("  %s : %.2f us/launch\n", v.name, sum / reps);
+            }
+            CK(hipFree(image));
         }
         CK(hipFree(ids));
     }

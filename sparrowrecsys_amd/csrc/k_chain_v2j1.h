@@ -174,17 +174,16 @@ __global__ __launch_bounds__(V2J1_WAVES * 64, 4) void k_deepfm_v2_joint1(const V
     __builtin_amdgcn_s_barrier();
     if (!work) return;
 
-    // ---- scoring: v2j_body<HALF>'s stage, weights read from LDS where they are consumed ----
+    // ---- scoring, phase A: everything that does NOT need the rows -- every LDS read of the stage (fragments, small fields'
+    //      rows, W1, the small vectors: 26 KB per wave) and the numerics' MFMAs -- is issued HERE, while the rows are still
+    //      in flight.  (The first version read each fragment where an MFMA consumed it, i.e. after the rows had landed, when
+    //      all sixteen waves of a CU want the LDS at once: scripts/ubench/row_gather.hip prices 13 KB of LDS reads per wave in
+    //      that position at 1.2-1.4 us per launch.  110 VGPRs instead of 71: still the four waves per SIMD a 65 536-row
+    //      launch can use.) ----
     const float* vq = smem + 4 * q;
     const f32x4 rbpn = ld4(vq + LD::off_bpn);
     const float rwn8a = smem[LD::off_wn8 + r * 8 + q], rwn8b = smem[LD::off_wn8 + r * 8 + q + 4];
-    f32x4 pn;
-    {
-        const f32x4 e = __builtin_amdgcn_mfma_f32_16x16x4f32(rwn8a, xn0, rbpn, 0, 0, 0);
-        const f32x4 o = __builtin_amdgcn_mfma_f32_16x16x4f32(rwn8b, xn1, zero, 0, 0, 0);
-        pn = e + o;
-    }
-    float zz = ((q < G_BIG) ? w1a : 0.f) + __builtin_fmaf(smem[LD::off_fn8 + q + 4], xn1, smem[LD::off_fn8 + q] * xn0);
+    const float rfn8a = smem[LD::off_fn8 + q], rfn8b = smem[LD::off_fn8 + q + 4];
     f32x4 sp = ld4(small_s + so[0] + 4 * q), sq[H0C];
 #pragma unroll
     for (int n0 = 0; n0 < H0C; ++n0) sq[n0] = ld4(small_s + so[0] + KP + 16 * n0 + 4 * q);
@@ -196,37 +195,57 @@ __global__ __launch_bounds__(V2J1_WAVES * 64, 4) void k_deepfm_v2_joint1(const V
         for (int n0 = 0; n0 < H0C; ++n0) sq[n0] += ld4(small_s + so[f] + KP + 16 * n0 + 4 * q);
         ssc += small_s[so[f] + KP + 32];
     }
+    f16x8 wa[G_BIG][H0C], wb[G_BIG][H0C];
+    {
+        const f16x8* frag = reinterpret_cast<const f16x8*>(smem + LD::off_frag) + lane;
+#pragma unroll
+        for (int b = 0; b < G_BIG; ++b)
+#pragma unroll
+            for (int n0 = 0; n0 < H0C; ++n0) { wa[b][n0] = frag[((b * 2 + n0) * 2 + 0) * 64]; wb[b][n0] = frag[((b * 2 + n0) * 2 + 1) * 64]; }
+    }
+    const f16x8 hSel = reinterpret_cast<const f16x8*>(smem + LD::off_sel)[lane];
+    float rwf[H0C][2];
+    {
+        const float* wf = small_s + A.wf_off + r * 8 + q;
+#pragma unroll
+        for (int n0 = 0; n0 < H0C; ++n0) { rwf[n0][0] = wf[n0 * 128]; rwf[n0][1] = wf[n0 * 128 + 4]; }
+    }
+    f32x4 rW1[H0C];
+#pragma unroll
+    for (int j = 0; j < H0C; ++j) rW1[j] = ld4(vq + LD::off_w1 + r * LD::S1 + 16 * j);
+    const f32x4 rb1 = ld4(vq + LD::off_b1), rhd = ld4(vq + LD::off_hd), rhfm = ld4(vq + LD::off_hfm);
+    f32x4 pn;
+    {
+        const f32x4 e = __builtin_amdgcn_mfma_f32_16x16x4f32(rwn8a, xn0, rbpn, 0, 0, 0);
+        const f32x4 o = __builtin_amdgcn_mfma_f32_16x16x4f32(rwn8b, xn1, zero, 0, 0, 0);
+        pn = e + o;
+    }
+    float zz = ((q < G_BIG) ? w1a : 0.f) + __builtin_fmaf(rfn8b, xn1, rfn8a * xn0);
     zz += (q == 3) ? ssc : 0.f;
     f32x4 hA[H0C], hB[H0C];
 #pragma unroll
     for (int n0 = 0; n0 < H0C; ++n0) hA[n0] = sq[n0];
+#pragma unroll
+    for (int st = 0; st < 2; ++st)
+#pragma unroll
+        for (int n0 = 0; n0 < H0C; ++n0) hA[n0] = __builtin_amdgcn_mfma_f32_16x16x4f32(rwf[n0][st], st ? xn1 : xn0, hA[n0], 0, 0, 0);
     f32x4 s = sp + pn;
+    // ---- phase B: the rows (the compiler's s_waitcnt vmcnt lands at their first use, below this fence) ----
+    __builtin_amdgcn_sched_barrier(0);
     {
         f32x4 aFa[H0C], aFb[H0C], aS = zero;
 #pragma unroll
         for (int n0 = 0; n0 < H0C; ++n0) { aFa[n0] = zero; aFb[n0] = zero; }
-        const f16x8* frag = reinterpret_cast<const f16x8*>(smem + LD::off_frag) + lane;
-        const f16x8 hSel = reinterpret_cast<const f16x8*>(smem + LD::off_sel)[lane];
-        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int b = 0; b < G_BIG; ++b) {
             const f16x8 xb = __builtin_bit_cast(f16x8, x[b]);
-            f16x8 wa[H0C], wb[H0C];
 #pragma unroll
-            for (int n0 = 0; n0 < H0C; ++n0) { wa[n0] = frag[((b * 2 + n0) * 2 + 0) * 64]; wb[n0] = frag[((b * 2 + n0) * 2 + 1) * 64]; }
-#pragma unroll
-            for (int n0 = 0; n0 < H0C; ++n0) aFa[n0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[n0], xb, aFa[n0], 0, 0, 0);
+            for (int n0 = 0; n0 < H0C; ++n0) aFa[n0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[b][n0], xb, aFa[n0], 0, 0, 0);
             aS = __builtin_amdgcn_mfma_f32_16x16x32_f16(hSel, xb, aS, 0, 0, 0);
 #pragma unroll
-            for (int n0 = 0; n0 < H0C; ++n0) aFb[n0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[n0], xb, aFb[n0], 0, 0, 0);
+            for (int n0 = 0; n0 < H0C; ++n0) aFb[n0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[b][n0], xb, aFb[n0], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
-        const float* wf = small_s + A.wf_off + r * 8 + q;
-#pragma unroll
-        for (int st = 0; st < 2; ++st)
-#pragma unroll
-            for (int n0 = 0; n0 < H0C; ++n0)
-                hA[n0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[n0 * 128 + 4 * st], st ? xn1 : xn0, hA[n0], 0, 0, 0);
         s = fma4s(aS, A.unscale_s, s);
 #pragma unroll
         for (int n0 = 0; n0 < H0C; ++n0) hB[n0] = (aFa[n0] + aFb[n0]) * A.unscale_h;
@@ -234,18 +253,17 @@ __global__ __launch_bounds__(V2J1_WAVES * 64, 4) void k_deepfm_v2_joint1(const V
     f32x4 h0[H0C];
 #pragma unroll
     for (int n0 = 0; n0 < H0C; ++n0) h0[n0] = relu4_fast(hA[n0] + hB[n0]);
-    float z = dot4f(ld4(vq + LD::off_hfm), sq_diff4(s, pn));
+    float z = dot4f(rhfm, sq_diff4(s, pn));
     {
-        f32x4 e = ld4(vq + LD::off_b1), o = zero;
+        f32x4 e = rb1, o = zero;
 #pragma unroll
         for (int j = 0; j < H0C; ++j) {
-            const f32x4 w = ld4(vq + LD::off_w1 + r * LD::S1 + 16 * j);
-            e = __builtin_amdgcn_mfma_f32_16x16x4f32(w.x, h0[j].x, e, 0, 0, 0);
-            o = __builtin_amdgcn_mfma_f32_16x16x4f32(w.y, h0[j].y, o, 0, 0, 0);
-            e = __builtin_amdgcn_mfma_f32_16x16x4f32(w.z, h0[j].z, e, 0, 0, 0);
-            o = __builtin_amdgcn_mfma_f32_16x16x4f32(w.w, h0[j].w, o, 0, 0, 0);
+            e = __builtin_amdgcn_mfma_f32_16x16x4f32(rW1[j].x, h0[j].x, e, 0, 0, 0);
+            o = __builtin_amdgcn_mfma_f32_16x16x4f32(rW1[j].y, h0[j].y, o, 0, 0, 0);
+            e = __builtin_amdgcn_mfma_f32_16x16x4f32(rW1[j].z, h0[j].z, e, 0, 0, 0);
+            o = __builtin_amdgcn_mfma_f32_16x16x4f32(rW1[j].w, h0[j].w, o, 0, 0, 0);
         }
-        z += dot4f(ld4(vq + LD::off_hd), relu4_fast(e + o));
+        z += dot4f(rhd, relu4_fast(e + o));
     }
     z += zz;
     z += __shfl_xor(z, 16);

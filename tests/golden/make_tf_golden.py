@@ -65,6 +65,9 @@ SPECS = {
     "wide_n_deep": ("WideNDeep.py",
                     [("dense_features", k + "_embedding", "emb/" + k) for k in GENRE_KEYS + ["movieId", "userId"]]
                     + _dense("dense", "dense0") + _dense("dense_1", "dense1") + _dense("dense_2", "head")),
+    "embedding_mlp": ("EmbeddingMLP.py",
+                      [("dense_features", k + "_embedding", "emb/" + k) for k in GENRE_KEYS + ["movieId", "userId"]]
+                      + _dense("dense", "dense0") + _dense("dense_1", "dense1") + _dense("dense_2", "head")),
     "neural_cf": ("NeuralCF.py",
                   [("dense_features", "movieId_embedding", "emb/movieId"), ("dense_features_1", "userId_embedding", "emb/userId")]
                   + _dense("dense", "dense0") + _dense("dense_1", "dense1") + _dense("dense_2", "head")),
@@ -75,7 +78,7 @@ def make_model(name):
     from sparrowrecsys_amd import models as M
     return {"din": lambda: M.DIN(seed=SEEDS[name]), "deepfm": lambda: M.DeepFM(seed=SEEDS[name]),
             "deepfm_v2": lambda: M.DeepFMv2(seed=SEEDS[name]), "wide_n_deep": lambda: M.WideNDeep(seed=SEEDS[name]),
-            "neural_cf": lambda: M.NeuralCF(seed=SEEDS[name])}[name]()
+            "neural_cf": lambda: M.NeuralCF(seed=SEEDS[name]), "embedding_mlp": lambda: M.EmbeddingMLP(seed=SEEDS[name])}[name]()
 
 
 def weights_digest(w):
@@ -164,7 +167,12 @@ def inject(model, spec, weights):
 
 def feed(model, samples, backend):
     """dict {input name: array} with the dtypes the script's own Input layers declare (make_csv_dataset: empty -> 0 / "")."""
-    if backend == "shim":
+    if not getattr(model, "inputs", None):
+        # tf.keras.Sequential over DenseFeatures (EmbeddingMLP.py:72-77) declares no inputs: the CSV's dtypes (make_csv_dataset)
+        from sparrowrecsys_amd.schema import FLOAT_KEYS
+        decl = {k: ("float32" if k in FLOAT_KEYS else ("string" if "Genre" in k else "int32")) for k in samples
+                if k not in ("rating", "timestamp", "label", "userAvgReleaseYear", "userReleaseYearStddev")}
+    elif backend == "shim":
         decl = {k: str(node.dtype) for k, node in model.inputs.items()}
     else:
         decl = {t.name.split(":")[0]: t.dtype.name for t in model.inputs}
@@ -185,8 +193,11 @@ def run_model(name, backend, tf, reference, samples):
     path = os.path.join(reference, SCRIPT_DIR, script)
     model, lines, sha = build_reference_model(tf, backend, path)
     m = make_model(name)
-    inject(model, spec, m.weights)
     x = feed(model, samples, backend)
+    if not getattr(model, "inputs", None):                               # Sequential: variables exist after the first batch
+        two = {k: v[:2] for k, v in x.items()}
+        model.predict({k: (tf.constant(v.tolist()) if (backend == "tf" and v.dtype == object) else v) for k, v in two.items()})
+    inject(model, spec, m.weights)
     if backend == "tf":
         x = {k: (tf.constant(v.tolist()) if v.dtype == object else v) for k, v in x.items()}
         pred = np.asarray(model.predict(x, batch_size=len(samples["movieId"]), verbose=0), dtype=np.float32)

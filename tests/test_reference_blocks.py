@@ -20,7 +20,7 @@ from tests.golden.make_tf_golden import SPECS, make_model, weights_digest
 
 MODELS = list(SPECS)
 FORWARD = {"din": O.din_forward, "deepfm": O.deepfm_forward, "deepfm_v2": O.deepfm_v2_forward,
-           "wide_n_deep": O.wide_n_deep_forward, "neural_cf": O.neural_cf_forward}
+           "wide_n_deep": O.wide_n_deep_forward, "neural_cf": O.neural_cf_forward, "embedding_mlp": O.embedding_mlp_forward}
 SHIM_TOL = 1e-6        # oracle vs the reference's lines on the numpy shim: both fp32 numpy, different summation orders
 TF_TOL = 1e-4          # north_star: within 1e-4 of the TF2 CPU forward
 HIP_TOL = 3e-5
