@@ -842,7 +842,7 @@ def main():
                        "ms_per_step_hip_events": ev_region * 1e3 / n_region,
                        "collective": None if not dist_on else ("sprk_comm_allgather_scores (RCCL behind the C ABI)" if args.collective == "sprk"
                                                                  else "sprk_peer_allgather_scores (direct peer writes, IPC-mapped receive buffers)" if args.collective == "peer"
-                                                                 else "torch.distributed.all_gather_into_tensor (RCCL)"),
+                                                                 else "torch.distributed.all_gather_into_tensor (%s)" % ("RCCL" if args.backend == "nccl" else "gloo: functional run only")),
                        "parallelism": ("rows sharded over %d GPU(s), tables replicated, all-gather of scores" % world)
                                       + ("" if world == 1 else " (one collective per %d steps, overlapped; %d collectives per region)"
                                          % (gs.G, (n_region + gs.G - 1) // gs.G)),
