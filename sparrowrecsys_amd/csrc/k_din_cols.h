@@ -263,6 +263,9 @@ __global__ __launch_bounds__(DC_WAVES * 64, 4) void k_din_attn_cols(const DinCol
         for (int nb = 0; nb < 2; ++nb) acc[nb] = mfma_f16(aW[nb][3], qh, acc[nb]);
         // PReLU(alpha[t][n]) -> Dense(1) -> sigmoid (DIN.py:150-151): lane (r,q) holds u[n = nb*16 + 4q + j] of sample r; the
         // coefficient rows are wave-uniform addresses (LDS broadcast)
+        // ca . u as packed FMAs (two units per instruction), cb . |u| as scalar FMAs with the free |.| source modifier
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        f32x2 sp2 = {0.f, 0.f};
         float sum = 0.f, sum1 = 0.f;
         const int tc = min(t, ROWS - 1);
 #pragma unroll
@@ -270,12 +273,14 @@ __global__ __launch_bounds__(DC_WAVES * 64, 4) void k_din_attn_cols(const DinCol
             const f32x4 ca = ld4(ca_s + tc * AS + nb * 16 + 4 * q);
             const f32x4 cb = ld4(cb_s + tc * AS + nb * 16 + 4 * q);
             const f32x4 u = acc[nb];
-            sum = fmaf(cb[0], __builtin_fabsf(u[0]), fmaf(ca[0], u[0], sum));
-            sum1 = fmaf(cb[1], __builtin_fabsf(u[1]), fmaf(ca[1], u[1], sum1));
-            sum = fmaf(cb[2], __builtin_fabsf(u[2]), fmaf(ca[2], u[2], sum));
-            sum1 = fmaf(cb[3], __builtin_fabsf(u[3]), fmaf(ca[3], u[3], sum1));
+            sp2 = __builtin_elementwise_fma(f32x2{ca[0], ca[1]}, f32x2{u[0], u[1]}, sp2);
+            sp2 = __builtin_elementwise_fma(f32x2{ca[2], ca[3]}, f32x2{u[2], u[3]}, sp2);
+            sum = fmaf(cb[0], __builtin_fabsf(u[0]), sum);
+            sum1 = fmaf(cb[1], __builtin_fabsf(u[1]), sum1);
+            sum = fmaf(cb[2], __builtin_fabsf(u[2]), sum);
+            sum1 = fmaf(cb[3], __builtin_fabsf(u[3]), sum1);
         }
-        sum += sum1;
+        sum = (sum + sum1) + (sp2[0] + sp2[1]);
         float wgt = sigmoidf_fast(rows4_sum(sum) * A.unscale + A.b2);       // PReLU is positively homogeneous: unscale the logit
         wgt = step < nsteps ? wgt : 0.f;                                      // padding steps of the ping-pong pair
         if constexpr (!MB) { if (att && q == 0 && step < nsteps && m < B) att[(size_t)m * T + t] = wgt; }
@@ -367,10 +372,15 @@ __global__ __launch_bounds__(DC_WAVES * 64, 4) void k_din_attn_cols(const DinCol
         }
     }
     if (work && slice == 0 && m < B) {
+        float* prow = pooled_b + (size_t)m * A.Dp + EL * q;
+        if (A.Dp == KP) {                                     // (wave-uniform) full-width rows: this lane's EL floats as 16-byte stores
 #pragma unroll
-        for (int e = 0; e < EL; ++e) {
-            const int k = EL * q + e;
-            if (k < A.Dp) pooled_b[(size_t)m * A.Dp + k] = res[e] * A.inv_h_scale;
+            for (int c = 0; c < KC; ++c)
+                st4(prow + 4 * c, f32x4{res[4 * c] * A.inv_h_scale, res[4 * c + 1] * A.inv_h_scale, res[4 * c + 2] * A.inv_h_scale, res[4 * c + 3] * A.inv_h_scale});
+        } else {
+#pragma unroll
+            for (int e = 0; e < EL; ++e)
+                if (EL * q + e < A.Dp) prow[e] = res[e] * A.inv_h_scale;
         }
     }
     if (__ballot(bad) != 0 && lane == 0) atomicOr(err, 1);
