@@ -191,7 +191,7 @@ def build_workload(name, B, dist_name, seed_offset=0, big_vocab=0, NB=8):
         feats = [SY.synth_embedding_mlp(B, SY.ML20M_MOVIE_IDS, SY.ML20M_USER_IDS, seed=SY.SEED + 1000 * seed_offset + i, dist=dist_name,
                                         rated_vocab=SY.ML20M_MOVIE_IDS) for i in range(NB)]
         # 8 B ids + 128 B cross row per sample for the wide part; + the deep part's 11 ids, 10 rows, numerics, score
-        roof = {"bound": "hbm", "kernel": "k_tile_forward" if env("SPRK_MLP_CHAIN") == "0" else "k_mlp_chain",
+        roof = {"bound": "hbm", "kernel": "k_tile_forward" if env("SPRK_MLP_CHAIN") == "0" else "k_mlp_rows",
                 "bytes_per_sample": 8 + D * 4 + 9 * 4 + 10 * D * 4 + 7 * 4 + 4,
                 "mfma_reference_flops": 2 * (327 * 128 + 128 * 128 + 128)}
         return model, feats, desc, roof
@@ -902,7 +902,6 @@ MFMA_ISSUED = {
     # numerics two steps x 8 n-blocks; second layer 8 n-blocks x 4 K-blocks x 3 split products (every embedding column is folded)
     "k_mlp_rows": {"per": 16, "f32": 16, "f16": 96},
     # round 1: 5 K-chunks x 4 steps x 8 n-blocks on f32 + the same second layer
-    "k_mlp_chain": {"per": 16, "f32": 160, "f16": 96},
     # fc0's per-sample part: pooled history (K = 32) + numerics chunk = 3 K-chunks x 4 steps x 8 n-blocks; fc1 4 n-blocks x 4 K-blocks x 3
     "k_din_tail": {"per": 16, "f32": 96, "f16": 48},
     # per SAMPLE: 4 sixteen-row groups x 2 n-blocks x 3 split products

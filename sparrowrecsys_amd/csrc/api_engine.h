@@ -372,7 +372,6 @@ int sprk_finalize(sprk_handle h) {
     const bool mrows_on = h->mlp_rows_nbig >= 0;
     if (!mrows_on && !rows_on && h->v2_variant < 0 && h->v1_variant < 0 && (rc = fold_first_dense(h, dp))) return rc;
     if (!mrows_on && !rows_on && h->v2_variant < 0 && (rc = setup_din_tail(h, dp))) return rc;
-    if (!mrows_on && !rows_on && h->v2_variant < 0 && h->v1_variant < 0 && h->din_tail_variant < 0 && (rc = setup_mlp_chain(h, dp))) return rc;
     HIP_TRY(hipMalloc((void**)&h->dev_plan, sizeof(DevPlan)));
     HIP_TRY(hipMemcpy(h->dev_plan, dp, sizeof(DevPlan), hipMemcpyHostToDevice));
     HIP_TRY(hipMalloc((void**)&h->dev_err, sizeof(int)));

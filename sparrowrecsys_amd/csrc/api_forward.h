@@ -148,20 +148,6 @@ int sprk_forward(sprk_handle h, const int32_t* ids, const float* dense, float* o
         HIP_TRY(hipGetLastError());
         return SPRK_OK;
     }
-    if (h->mlp_variant >= 0) {
-        const int ntasks = (B + 15) / 16;
-        int grid = (ntasks + MC_WAVES - 1) / MC_WAVES;
-        if (grid > h->num_cus) grid = h->num_cus;                  // one 8-wave workgroup per CU (120 KB of LDS weights)
-        const size_t lds = MlpChainLds<8, 8>::bytes;
-        if (h->mlp_run.inv_w1_scale != 0.f)
-            hipLaunchKernelGGL((k_mlp_chain<8, 8, MC_WAVES, true>), dim3(grid), dim3(MC_WAVES * 64), lds, st, h->mlp_run, ids, dense, out, B,
-                               h->dev_err, h->mlp_image);
-        else
-            hipLaunchKernelGGL((k_mlp_chain<8, 8, MC_WAVES, false>), dim3(grid), dim3(MC_WAVES * 64), lds, st, h->mlp_run, ids, dense, out, B,
-                               h->dev_err, h->mlp_image);
-        HIP_TRY(hipGetLastError());
-        return SPRK_OK;
-    }
     if (h->din_tail_variant >= 0) {
         const int ntasks = (B + 15) / 16;
         int grid = (ntasks + DT_WAVES - 1) / DT_WAVES;
@@ -420,8 +406,6 @@ int sprk_describe(sprk_handle h, char* buf, size_t buf_bytes) {
         snprintf(kern, sizeof(kern), "k_rows_chain<KPC=%d,H0C=%d,H1C=%d,G_BIG=%d,NJF=%d>", rv.kpc, rv.h0c, rv.h1c, rv.g_big, rv.njf);
     } else if (h->mlp_rows_nbig >= 0) {
         snprintf(kern, sizeof(kern), "k_mlp_rows<8,8,NBIG=%d,NSMALL=%d>", h->mlp_rows_nbig, h->mlp_rows_run.n_small);
-    } else if (h->mlp_variant >= 0) {
-        snprintf(kern, sizeof(kern), "k_mlp_chain<8,8>");
     } else if (h->din_tail_variant >= 0) {
         const DinTailVariant& tv = kDinTailVariants[h->din_tail_variant];
         snprintf(kern, sizeof(kern), "k_din_tail<%d,%d,%d>", tv.n0c, tv.n1c, tv.kpc);
@@ -476,7 +460,6 @@ void sprk_destroy(sprk_handle h) {
     for (int i = 0; i < 4; ++i) { if (h->many_stream[i]) (void)hipStreamDestroy(h->many_stream[i]); if (h->many_join[i]) (void)hipEventDestroy(h->many_join[i]); }
     if (h->many_fork) (void)hipEventDestroy(h->many_fork);
     if (h->din_tail_image) (void)hipFree(h->din_tail_image);
-    if (h->mlp_image) (void)hipFree(h->mlp_image);
     if (h->mlp_rows_image) (void)hipFree(h->mlp_rows_image);
     if (h->mlp_rows_small) (void)hipFree(h->mlp_rows_small);
     for (void* q : h->mlp_rows_bufs) if (q) (void)hipFree(q);

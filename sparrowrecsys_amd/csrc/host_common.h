@@ -77,7 +77,6 @@ struct SprkTuning {
     bool v1_rowtab = true;            // SPRK_V1_ROWTAB=0           gather the uploaded tables, not the derived {E | w1} rows
     bool v1_one = true;               // SPRK_V1_ONE=0              one-batch launches on the looped kernel, not k_deepfm_pairs1
     bool mlp_chain = true;            // SPRK_MLP_CHAIN=0           EmbeddingMLP / Wide&Deep on the interpreter
-    bool mlp_rows = true;             // SPRK_MLP_ROWS=0            ... on round 1's k_mlp_chain
     bool din_tail = true;             // SPRK_DIN_TAIL=0            DIN tail on the interpreter
     bool din_legacy = false;          // SPRK_DIN_LEGACY=1          attention on the generic k_din_pool
     bool din_half = true;             // SPRK_DIN_HALF=0            attention on f32 MFMA
@@ -101,7 +100,7 @@ struct SprkTuning {
         t.half_range_guard = !off("SPRK_HALF_RANGE_GUARD"); t.dyn_f16 = !off("SPRK_DYN_F16");
         t.v1_chain = !off("SPRK_V1_CHAIN"); t.v1_static_scale = !off("SPRK_V1_STATIC_SCALE"); t.v1_rowtab = !off("SPRK_V1_ROWTAB");
         t.v1_one = !off("SPRK_V1_ONE");
-        t.mlp_chain = !off("SPRK_MLP_CHAIN"); t.mlp_rows = !off("SPRK_MLP_ROWS");
+        t.mlp_chain = !off("SPRK_MLP_CHAIN");
         t.din_tail = !off("SPRK_DIN_TAIL"); t.din_legacy = on("SPRK_DIN_LEGACY"); t.din_half = !off("SPRK_DIN_HALF");
         t.din_wpb = num("SPRK_DIN_WPB", 12); t.din_attn_many = !off("SPRK_DIN_ATTN_MB"); t.din_cols = !off("SPRK_DIN_COLS");
         { const int n = num("SPRK_DIN_COLS_TS", 0); t.din_cols_ts = (n == 1 || n == 2 || n == 4) ? n : 0; }

@@ -29,11 +29,8 @@ struct sprk_engine {
     bool v1_one = false;                  // one-batch launches use k_deepfm_pairs1 (one task per wave, four waves per SIMD)
     V1Run v1_run;
     std::vector<void*> v1_bufs;
-    // register-chained DenseFeatures -> Dense -> Dense -> Dense(1) graphs (k_mlp_chain); -1 = the tile interpreter
-    int mlp_variant = -1;
-    MlpChainRun mlp_run;
-    float* mlp_image = nullptr;
-    // ... with every embedding column folded through the first layer, genre tables in LDS (k_mlp_rows); -1 = not used
+    // DenseFeatures -> Dense -> Dense -> Dense(1) graphs with every embedding column folded through the first layer, genre tables
+    // in LDS (k_mlp_rows); -1 = the tile interpreter
     int mlp_rows_nbig = -1;
     MlpRowsRun mlp_rows_run;
     float* mlp_rows_image = nullptr;

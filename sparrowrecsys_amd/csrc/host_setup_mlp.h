@@ -1,108 +1,5 @@
-// host_setup_mlp.h -- EmbeddingMLP / Wide&Deep: k_mlp_chain and k_mlp_rows set-up.
+// host_setup_mlp.h -- EmbeddingMLP / Wide&Deep: k_mlp_rows set-up.
 // Part of sparrow_hip.hip (one translation unit); included there, not compilable on its own.
-// ---- k_mlp_chain<N0C, N1C, WAVES> ----
-constexpr int MC_WAVES = 8;
-// Recognise what the first-Dense fold left of an EmbeddingMLP / Wide&Deep plan (EmbeddingMLP.py:72-77, WideNDeep.py:99-107):
-// folded columns, unfolded embedding columns + numerics feeding Dense(128) -> Dense(128) -> weighted tap (+ the wide cross).
-int setup_mlp_chain(sprk_engine* h, DevPlan* dp) {
-    if (!h->tune.mlp_chain) return SPRK_OK;
-    const sprk_plan& p = h->plan;
-    if (p.din.enabled || dp->n_ops != 2 || dp->n_taps < 1 || dp->n_taps > 2 || dp->n_acc > MC_MAX_ACC) return SPRK_OK;
-    if (p.model_kind != SPRK_MODEL_EMBEDDING_MLP && p.model_kind != SPRK_MODEL_WIDE_DEEP) return SPRK_OK;
-    const DevOp &o0 = dp->ops[0], &o1 = dp->ops[1];
-    if (o0.kind != SPRK_OP_DENSE || o1.kind != SPRK_OP_DENSE || o0.act != o1.act || (o0.act != SPRK_ACT_RELU && o0.act != SPRK_ACT_PRELU)) return SPRK_OK;
-    if (o0.src_buf != 0 || o0.dst_buf == 0 || o0.dst_off != 0 || o1.src_buf != o0.dst_buf || o1.src_off != 0 || o1.K != o0.N ||
-        o1.dst_off != 0 || o0.N != 128 || o1.N != 128) return SPRK_OK;
-    MlpChainRun r;
-    memset(&r, 0, sizeof(r));
-    int col_off[MC_MAX_CHUNKS], col_w[MC_MAX_CHUNKS];
-    const int lo = o0.src_off, hi = o0.src_off + o0.K;
-    const int n_plain = dp->n_segs - dp->n_acc;
-    const DevSeg* cross = nullptr;
-    int num_dst = -1;
-    for (int i = 0; i < n_plain; ++i) {
-        const DevSeg& sg = dp->segs[i];
-        if (sg.kind == SPRK_SEG_ROWS) {
-            if (sg.dst < lo || sg.dst + 4 * sg.count > hi) return SPRK_OK;
-            for (int j = 0; j < 4 * sg.count; j += 16) {
-                if (r.n_chunks == MC_MAX_CHUNKS) return SPRK_OK;
-                const int c = r.n_chunks++;
-                r.ch_col[c] = h->idc[sg.field]; r.ch_vocab[c] = sg.vocab; r.ch_off[c] = j; r.ch_stride[c] = sg.row_stride;
-                r.ch_width[c] = 4 * sg.count - j < 16 ? 4 * sg.count - j : 16; r.ch_tab[c] = sg.table;
-                col_off[c] = sg.dst + j - lo; col_w[c] = r.ch_width[c];
-            }
-        } else if (sg.kind == SPRK_SEG_DENSE) {
-            if (num_dst >= 0 || sg.field != 0 || sg.count > 8 || sg.dst < lo || sg.dst + sg.count > hi) return SPRK_OK;
-            num_dst = sg.dst; r.n_num = sg.count;
-        } else if (sg.kind == SPRK_SEG_CROSS_ROWS || sg.kind == SPRK_SEG_CROSS_SCALAR) {
-            if (cross || (sg.dst < hi && sg.dst + (sg.kind == SPRK_SEG_CROSS_ROWS ? 4 * sg.count : 1) > lo)) return SPRK_OK;
-            cross = &sg;
-        } else if (sg.kind != SPRK_SEG_ZERO) {
-            return SPRK_OK;
-        }
-    }
-    // (an embedding table needs its zero row at index vocab for missing ids: models.pad_table provides it; ROWS segments
-    //  validated at finalize only hold vocab rows' worth of bytes when a caller built the plan by hand)
-    for (int i = 0; i < p.n_segs; ++i)
-        if (p.segs[i].kind == SPRK_SEG_ROWS && h->slot_bytes[p.segs[i].slot] < ((size_t)p.segs[i].vocab + 1) * p.segs[i].row_stride * sizeof(float)) return SPRK_OK;
-    if (num_dst >= 0) {
-        if (r.n_chunks == MC_MAX_CHUNKS) return SPRK_OK;
-        const int c = r.n_chunks++;
-        r.ch_col[c] = -1; col_off[c] = num_dst - lo; col_w[c] = r.n_num;
-    }
-    if (r.n_chunks < 1) return SPRK_OK;
-    const DevTap *tdeep = nullptr, *twide = nullptr;
-    for (int t = 0; t < dp->n_taps; ++t) {
-        const DevTap& tp = dp->taps[t];
-        if (tp.scale != 1.0f || tp.bias != 0.0f) return SPRK_OK;
-        if (tp.buf == o1.dst_buf && tp.off == 0 && tp.len <= o1.N && tp.w && !tdeep) tdeep = &tp;
-        else if (cross && tp.buf == 0 && tp.off == cross->dst && !twide) twide = &tp;
-        else return SPRK_OK;
-    }
-    if (!tdeep || (cross != nullptr) != (twide != nullptr)) return SPRK_OK;
-    if (cross) {
-        if (cross->kind == SPRK_SEG_CROSS_ROWS) {
-            if (twide->len != 4 * cross->count || !twide->w || twide->len > 32) return SPRK_OK;
-            r.wide_kind = 1; r.wide_dim = twide->len; r.wide_stride = cross->row_stride; r.wide_w = twide->w;
-        } else {
-            if (twide->len != 1 || twide->w) return SPRK_OK;
-            r.wide_kind = 2;
-        }
-        r.wide_a = h->idc[cross->field]; r.wide_b = h->idc[cross->field2]; r.wide_buckets = cross->vocab; r.wide_tab = cross->table;
-    }
-    r.n_acc = dp->n_acc;
-    for (int g = 0; g < dp->n_acc; ++g) {
-        const DevSeg& sg = dp->segs[n_plain + g];
-        r.acc_col[g] = h->idc[sg.field]; r.acc_vocab[g] = sg.vocab; r.acc_tab[g] = sg.table;
-    }
-    r.F = p.n_id_cols; r.ND = p.n_dense; r.head_bias = dp->head_bias;
-    typedef MlpChainLds<8, 8> LD;
-    HIP_TRY(hipMalloc((void**)&h->mlp_image, LD::bytes));
-    int *d_off = nullptr, *d_w = nullptr;
-    HIP_TRY(hipMalloc((void**)&d_off, sizeof(col_off)));
-    HIP_TRY(hipMalloc((void**)&d_w, sizeof(col_w)));
-    HIP_TRY(hipMemcpy(d_off, col_off, sizeof(col_off), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(d_w, col_w, sizeof(col_w), hipMemcpyHostToDevice));
-    float* w1frag = nullptr;
-    {
-        float w_scale = 0.f;
-        const int rc2 = make_dyn_fragments(h, o1.W, o1.ldw, o1.N, o1.K, &w1frag, &w_scale);
-        if (rc2) return rc2;
-        r.inv_w1_scale = w1frag ? 1.0f / w_scale : 0.f;
-    }
-    hipLaunchKernelGGL((k_mlp_chain_pack<8, 8>), dim3(1), dim3(256), 0, 0, o0.W, o0.ldw, r.n_chunks, d_off, d_w, o0.bias,
-                       o0.act == SPRK_ACT_PRELU ? o0.alpha : nullptr, o1.W, o1.ldw, o1.bias, o1.act == SPRK_ACT_PRELU ? o1.alpha : nullptr,
-                       tdeep->w, tdeep->len, w1frag, h->mlp_image);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipDeviceSynchronize());
-    (void)hipFree(d_off); (void)hipFree(d_w);
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mlp_chain<8, 8, MC_WAVES, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LD::bytes));
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mlp_chain<8, 8, MC_WAVES, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LD::bytes));
-    h->mlp_run = r;
-    h->mlp_variant = 0;
-    return SPRK_OK;
-}
-
 // ---- k_mlp_rows<8, 8, NBIG, WAVES, DYN> ----
 constexpr int MR_WAVES = 8;
 template <int NBIG>
@@ -122,7 +19,7 @@ int mlp_rows_attr(size_t lds) {
 // Recognise an EmbeddingMLP / Wide&Deep plan (EmbeddingMLP.py:72-77, WideNDeep.py:99-107) with ReLU layers of 128 and fold
 // EVERY embedding column through the first Dense layer (see k_mlp_rows.h).  Leaves mlp_rows_nbig = -1 for any other shape.
 int setup_mlp_rows(sprk_engine* h) {
-    if (!h->tune.mlp_rows || !h->tune.mlp_chain) return SPRK_OK;
+    if (!h->tune.mlp_chain) return SPRK_OK;
     const sprk_plan& p = h->plan;
     if (p.din.enabled || p.n_ops != 2 || p.n_taps < 1 || p.n_taps > 2) return SPRK_OK;
     if (p.model_kind != SPRK_MODEL_EMBEDDING_MLP && p.model_kind != SPRK_MODEL_WIDE_DEEP) return SPRK_OK;

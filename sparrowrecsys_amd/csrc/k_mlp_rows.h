@@ -1,7 +1,7 @@
 // k_mlp_rows.h -- k_mlp_rows: the "DenseFeatures -> Dense(relu) -> Dense(relu) -> Dense(1, sigmoid)" graphs (reference
 // EmbeddingMLP.py:72-77, the deep part of WideNDeep.py:99-107 + its hashed-cross wide part; BASELINE config 5) with EVERY
 // embedding column folded through the first Dense layer, one WAVE per 16 samples.  Included inside sparrow_hip.hip's
-// anonymous namespace, after k_mlp_chain.h (the round-1 kernel it replaces for ReLU graphs; that one stays for PReLU / A/B).
+// anonymous namespace.  It replaced round 1's k_mlp_chain (retired in round 3; its A/B numbers are in profiles/r02).
 //
 // What round 1's k_mlp_chain did per 16 samples: the 8 genre columns folded to per-id tables F_g = W0_g^T E_g (512-byte rows,
 // 19 of them per column) and gathered from L2 -- 4 KB per SAMPLE of cache traffic -- while movieId / userId rows went through

@@ -48,7 +48,6 @@
 #include "k_din_cols.h"
 #include "k_din_tail.h"
 #include "k_chain_v1.h"
-#include "k_mlp_chain.h"
 #include "k_mlp_rows.h"
 #include "k_emb_rank.h"
 #include "k_dien_seq.h"
@@ -61,7 +60,7 @@
 #include "host_setup_rows.h"         // k_rows_chain (literal DeepFM_v2, NeuralCF): dispatch table and set-up
 #include "host_setup_common.h"       // k_din_attn dispatch table, the interpreter's first-Dense fold, the dynamic-range guard, split-f16 fragment packing
 #include "host_setup_pairs.h"        // pair-dot DeepFM: k_deepfm_pairs / _pairs1 dispatch table, plan matcher and set-up
-#include "host_setup_mlp.h"          // EmbeddingMLP / Wide&Deep: k_mlp_chain and k_mlp_rows set-up
+#include "host_setup_mlp.h"          // EmbeddingMLP / Wide&Deep: k_mlp_rows set-up
 #include "host_setup_din_tail.h"     // DIN / DIEN tail: k_din_tail dispatch table and set-up -- closes the host helpers' anonymous namespace
 #include "api_engine.h"              // C ABI: sprk_last_error .. sprk_create / sprk_upload / sprk_finalize / sprk_workspace_bytes
 #include "api_forward.h"             // C ABI: sprk_din_pool, sprk_forward, sprk_forward_many, sprk_describe, sprk_check_ids, sprk_destroy, operators, emb ranker

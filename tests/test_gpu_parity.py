@@ -869,7 +869,7 @@ def test_forward_many_several_batches_per_launch_din(torch, Bd, n, k, streams):
 
 
 # --------------------------------------------------------------------------------------------
-# k_mlp_chain: EmbeddingMLP / Wide&Deep graphs as a register-chained kernel
+# k_mlp_rows: EmbeddingMLP / Wide&Deep graphs as a register-chained kernel
 # --------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("kind", ["embedding_mlp", "wide_indicator", "wide_cross_rows"])
 def test_mlp_chain_vs_interpreter_and_oracle(torch, monkeypatch, kind):
@@ -877,7 +877,7 @@ def test_mlp_chain_vs_interpreter_and_oracle(torch, monkeypatch, kind):
     V, U = 20000, 30000
     feats = SY.synth_embedding_mlp(B, V, U, seed=91, rated_vocab=V if kind != "embedding_mlp" else None)
     out = {}
-    for chain, dyn in (("1", "1"), ("1f32", "0"), ("0", "1")):   # chain kernel with layer 2 on split-f16 / f32 MFMA; interpreter
+    for chain, dyn in (("1", "1"), ("1f32", "0"), ("0", "1")):   # fused kernel with layer 2 on split-f16 / f32 MFMA; interpreter
         monkeypatch.setenv("SPRK_MLP_CHAIN", chain[0])
         monkeypatch.setenv("SPRK_DYN_F16", dyn)
         if kind == "embedding_mlp":
@@ -899,9 +899,9 @@ def test_mlp_chain_vs_interpreter_and_oracle(torch, monkeypatch, kind):
 
 
 @pytest.mark.parametrize("kind,B", [("embedding_mlp_ref", 4099), ("embedding_mlp", 131072), ("wide_indicator", 6007), ("wide_cross_rows", 1), ("wide_cross_rows", 33)])
-def test_mlp_rows_kernel_vs_round1_chain_and_oracle(torch, monkeypatch, kind, B):
+def test_mlp_rows_kernel_vs_interpreter_and_oracle(torch, monkeypatch, kind, B):
     """k_mlp_rows (every embedding column folded through the first Dense, genre tables in LDS, gathers a task ahead)
-    against round 1's k_mlp_chain (SPRK_MLP_ROWS=0) and the fp64 oracle; missing genre / history ids, ragged sizes,
+    against the plan interpreter (SPRK_MLP_CHAIN=0) and the fp64 oracle; missing genre / history ids, ragged sizes,
     a batch large enough that every wave loops over several tasks, unaligned views."""
     V, U = (1001, 30001) if kind == "embedding_mlp_ref" else (20000, 30000)
     D = 10 if kind == "embedding_mlp_ref" else 32
@@ -915,11 +915,11 @@ def test_mlp_rows_kernel_vs_round1_chain_and_oracle(torch, monkeypatch, kind, B)
     model = make()
     assert model.engine.describe()["kernel"].startswith("k_mlp_rows<8,8,NBIG=2,NSMALL=8>")
     p = model.predict(feats)[:, 0]
-    monkeypatch.setenv("SPRK_MLP_ROWS", "0")
+    monkeypatch.setenv("SPRK_MLP_CHAIN", "0")
     old = make()
-    assert old.engine.describe()["kernel"].startswith("k_mlp_chain")
+    assert old.engine.describe()["kernel"].startswith("k_tile_forward")
     q = old.predict(feats)[:, 0]
-    monkeypatch.delenv("SPRK_MLP_ROWS")
+    monkeypatch.delenv("SPRK_MLP_CHAIN")
     n = min(B, 8192)
     sub = {k: v[:n] for k, v in feats.items()}
     if kind.startswith("embedding_mlp"):
