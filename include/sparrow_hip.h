@@ -327,6 +327,11 @@ int sprk_pack_csv_mt(const char* text, size_t len, const sprk_csv_col* id_cols, 
 int sprk_pack_csv_device(const char* text_dev, size_t len, const sprk_csv_col* id_cols, int32_t n_id,
                          const char* const* dense_names, int32_t n_dense, int32_t max_rows,
                          int32_t* ids_dev, float* dense_dev, int32_t* rows_out, void* stream);
+/* Which kernels the calling thread's last sprk_pack_csv_device ran the text through (diagnostics / tests): 1 = the optimistic
+ * pass alone (every line of the text is a row: line i is output row i - 1), 2 = the exact keep -> scan -> parse sequence (some
+ * line is empty or has another field count than the header: ignore_errors=True drops it), -1 = no call yet / no data line / the
+ * call failed early.  The packed arrays are the same bits whichever ran. */
+int sprk_csv_last_path(void);
 
 /* ---- multi-GPU: the path's one collective (the reference has no distributed path) ----
  * Batch rows are sharded over one process per GPU, tables and weights replicated; every rank ends with all scores through ONE

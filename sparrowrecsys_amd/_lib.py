@@ -33,7 +33,7 @@ EXPORTED_SYMBOLS = [
     "sprk_forward", "sprk_forward_many", "sprk_forward_many_opts", "sprk_forward_embedding_mlp", "sprk_forward_widedeep", "sprk_forward_neuralcf",
     "sprk_forward_deepfm", "sprk_forward_deepfm_v2", "sprk_forward_din", "sprk_forward_dien", "sprk_din_pool",
     "sprk_check_ids", "sprk_debug_set_trace", "sprk_destroy", "sprk_embedding_gather", "sprk_cross_hash", "sprk_last_error",
-    "sprk_pack_csv", "sprk_pack_csv_mt", "sprk_pack_csv_device", "sprk_set_many_streams", "sprk_set_many_batches", "sprk_emb_rank",
+    "sprk_pack_csv", "sprk_pack_csv_mt", "sprk_pack_csv_device", "sprk_csv_last_path", "sprk_set_many_streams", "sprk_set_many_batches", "sprk_emb_rank",
     "sprk_describe", "sprk_comm_unique_id", "sprk_comm_create", "sprk_comm_allgather_scores", "sprk_comm_destroy",
     "sprk_peer_create", "sprk_peer_connect", "sprk_peer_allgather_scores", "sprk_peer_check", "sprk_peer_memory_kind", "sprk_peer_destroy",
 ]
@@ -176,6 +176,7 @@ def load_library():
         lib.sprk_pack_csv_mt.argtypes = [C.c_char_p, sz, C.POINTER(CsvCol), i32, C.POINTER(C.c_char_p), i32, i32, i32, vp, vp,
                                          C.POINTER(i32)]
         lib.sprk_pack_csv_device.argtypes = [vp, sz, C.POINTER(CsvCol), i32, C.POINTER(C.c_char_p), i32, i32, vp, vp, C.POINTER(i32), vp]
+        lib.sprk_csv_last_path.argtypes = []
         lib.sprk_emb_rank.argtypes = [vp, vp, i32, i32, i32, vp, vp, i32, i32, vp, i32, vp, vp, vp]
         for name in EXPORTED_SYMBOLS:
             if name not in ("sprk_last_error", "sprk_destroy", "sprk_workspace_bytes", "sprk_comm_destroy", "sprk_peer_destroy", "sprk_peer_memory_kind"):

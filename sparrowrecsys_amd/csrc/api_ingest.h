@@ -257,6 +257,7 @@ struct DevScratch {
     }
 };
 thread_local DevScratch g_csv_scratch;
+thread_local int g_csv_last_path = -1;
 
 // exclusive scan of n unsigned counters (in -> out, in place allowed), grand total -> *total_dev; sums = scratch of ceil(n / SCAN_TILE)
 void scan_u32(const unsigned* in, unsigned* out, size_t n, unsigned* sums, unsigned* total_dev, hipStream_t st) {
@@ -278,6 +279,7 @@ int sprk_pack_csv_device(const char* text_dev, size_t len, const sprk_csv_col* i
     if ((uintptr_t)text_dev & 15) return fail(SPRK_EINVAL, "the CSV text must start on a 16-byte boundary in device memory");
     if (len >= ((size_t)1 << 44)) return fail(SPRK_EINVAL, "CSV text too large");
     *rows_out = 0;
+    g_csv_last_path = -1;
     if (len == 0) return SPRK_OK;
     hipStream_t st = (hipStream_t)stream;
     // header: the first line comes back to the host and goes through the host tokenizer's own field splitter
@@ -365,7 +367,11 @@ int sprk_pack_csv_device(const char* text_dev, size_t len, const sprk_csv_col* i
     const unsigned char* text = (const unsigned char*)text_dev;
     hipLaunchKernelGGL(k_csv_count, dim3((unsigned)n_chunks), dim3(256), 0, st, text, len, counts);
     scan_u32(counts, counts, n_chunks, sums, totals, st);
-    unsigned h_nl = 0;
+    unsigned* drops = (unsigned*)(carve() + 52);
+    unsigned h_nl = 0, h_kept = 0, h_nerr = 0, h_drops = 0;
+    unsigned long long h_first = ~0ull;
+    const char* two = getenv("SPRK_CSV_TWO_PASS");              // A/B switch: "1" = always the exact keep -> scan -> parse sequence
+    bool exact = two && two[0] == '1';
     HIP_TRY(hipMemcpyAsync(&h_nl, totals, sizeof(unsigned), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     const size_t n_lines = (size_t)h_nl + (last != '\n' ? 1 : 0);
@@ -390,7 +396,7 @@ int sprk_pack_csv_device(const char* text_dev, size_t len, const sprk_csv_col* i
     unsigned* keep = (unsigned*)(carve() + off_keep);
     unsigned* pos = keep + n_lines;
     unsigned* sums2 = pos + n_lines;
-    unsigned* drops = (unsigned*)(carve() + 52);
+    drops = (unsigned*)(carve() + 52);
     hipLaunchKernelGGL(k_csv_mark, dim3((unsigned)n_chunks), dim3(256), 0, st, text, len, (const unsigned*)counts, nl);
     const unsigned lb = (unsigned)((n_lines + 255) / 256);
     // LDS piece per workgroup of 256 lines: twice the average, so that more workgroups share a CU when lines are short
@@ -398,10 +404,6 @@ int sprk_pack_csv_device(const char* text_dev, size_t len, const sprk_csv_col* i
     if (cap < 8192) cap = 8192;
     if (cap > 48 * 1024) cap = 48 * 1024;
     const unsigned lds_cap = (unsigned)cap;
-    unsigned h_kept = 0, h_nerr = 0, h_drops = 0;
-    unsigned long long h_first = 0;
-    const char* two = getenv("SPRK_CSV_TWO_PASS");              // A/B switch: "1" = always the exact keep -> scan -> parse sequence
-    bool exact = two && two[0] == '1';
     if (!exact) {
         // optimistic pass over the lines that can hold the first max_rows rows if none is dropped
         const size_t lines_opt = n_lines - 1 <= (size_t)max_rows ? n_lines : (size_t)max_rows + 1;
@@ -416,6 +418,7 @@ int sprk_pack_csv_device(const char* text_dev, size_t len, const sprk_csv_col* i
         HIP_TRY(hipMemcpyAsync(&h_nerr, n_errs, sizeof(unsigned), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         h_kept = (unsigned)(lines_opt - 1);
+        g_csv_last_path = 1;
         if (h_drops) {                                             // some line is not a row: its successors are misplaced
             exact = true;
             HIP_TRY(hipMemsetAsync(first_err, 0xFF, sizeof(unsigned long long), st));
@@ -423,6 +426,7 @@ int sprk_pack_csv_device(const char* text_dev, size_t len, const sprk_csv_col* i
         }
     }
     if (exact) {
+        g_csv_last_path = 2;
         hipLaunchKernelGGL(k_csv_keep, dim3(lb), dim3(256), lds_cap + CSV_LDS_SLACK + CSV_LDS_GENRE, st, text, len, (const unsigned long long*)nl, h_nl, (unsigned)n_lines,
                            L.n_cols, lds_cap, keep);
         scan_u32(keep, pos, n_lines, sums2, totals + 1, st);
@@ -452,5 +456,7 @@ int sprk_pack_csv_device(const char* text_dev, size_t len, const sprk_csv_col* i
     *rows_out = (int32_t)(h_kept < (unsigned)max_rows ? h_kept : (unsigned)max_rows);
     return SPRK_OK;
 }
+
+int sprk_csv_last_path(void) { return g_csv_last_path; }
 
 }  // extern "C"

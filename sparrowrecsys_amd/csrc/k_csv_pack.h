@@ -355,6 +355,65 @@ __device__ __forceinline__ int csv_number(const R& t, typename R::pos_t a, typen
     return 0;
 }
 
+// where the packed values and the error records go
+struct CsvSink {
+    int* __restrict__ ids;
+    float* __restrict__ dense;
+    unsigned long long* __restrict__ first_err;
+    CsvErr* __restrict__ errs;
+    unsigned* __restrict__ n_errs;
+    __device__ __forceinline__ void report(unsigned row, int c, int code, int out_col, int is_dense, long long value) const {
+        const unsigned long long key = ((unsigned long long)row << 20) | ((unsigned long long)(unsigned)c << 4) | (unsigned)code;
+        atomicMin(first_err, key);
+        const unsigned s = atomicAdd(n_errs, 1u);
+        if (s < 64) { errs[s].key = key; errs[s].code = code; errs[s].out_col = out_col; errs[s].is_dense = is_dense; errs[s].value = value; }
+    }
+};
+// Field c = [a, b) of output row `row` (esc: its quoted content holds an escaped quote): converted for every output the column
+// lists name.  T = the layout (kernel argument, or its copy in LDS when c differs per lane), g_tab / g_len = the genre hash table.
+template <class R, class P>
+__device__ __forceinline__ void csv_emit(const CsvDev& T, const unsigned long long* g_tab, const signed char* g_len, const R& rd, P a, P b,
+                                         bool esc, int role, int c, unsigned row, const CsvSink& out) {
+    double v = 0.0;
+    int st = 1;
+    if (role & 1) {
+        if (esc) st = 2;
+        else if (a == b) st = 1;
+        else if ((unsigned)(b - a) <= 8 && csv_number_short(rd, a, b, v)) st = 0;
+        else st = csv_number(rd, a, b, v);
+    }
+    unsigned long long w0 = 0, w1 = 0;
+    const unsigned gn = (unsigned)(b - a);
+    if ((role & 2) && gn >= 1 && gn <= 16) {                   // the field's bytes as two little-endian words
+        w0 = rd.win(a);
+        if (gn < 8) w0 &= ~0ull >> (64 - 8 * gn);
+        if (gn > 8) { w1 = rd.win(a + 8); if (gn < 16) w1 &= ~0ull >> (64 - 8 * (gn - 8)); }
+    }
+    for (int o = T.id_head[c]; o >= 0; o = T.id_next[o]) {
+        int val;
+        if (T.id_kind[o] == 1) {                                  // genre vocabulary (exact match) or -1
+            val = -1;
+            if (gn >= 1 && gn <= 16) {
+                const unsigned sl = csv_genre_slot(w0, w1, gn, T.g_mul);
+                if (g_len[sl] == (int)gn && g_tab[2 * sl] == w0 && g_tab[2 * sl + 1] == w1) val = g_len[32 + sl];
+            }
+            if (val >= T.id_vocab[o]) val = -1;
+        } else if (st == 2) {
+            out.report(row, c, 2, o, 0, 0);
+            val = 0;
+        } else {
+            const long long iv = (long long)v;                    // int(float(v)) of the Python packer; empty -> 0
+            if (iv < 0 || iv >= T.id_vocab[o]) out.report(row, c, 1, o, 0, iv);
+            val = (int)iv;
+        }
+        out.ids[(size_t)row * T.n_id + o] = val;
+    }
+    for (int o = T.dense_head[c]; o >= 0; o = T.dense_next[o]) {
+        if (st == 2) out.report(row, c, 2, o, 1, 0);
+        out.dense[(size_t)row * T.n_dense + o] = (float)v;
+    }
+}
+
 // OPT: the optimistic single pass -- every line i >= 1 is taken as output row i - 1; lines that would have been dropped (empty,
 // wrong field count) are counted in *drops and the host then reruns the exact keep -> scan -> parse sequence.  Sample files
 // have no such lines, so the common case reads the text one time less.
@@ -378,66 +437,20 @@ __global__ __launch_bounds__(256) void k_csv_parse(const CsvDev L, const unsigne
             row = pos[i];
         }
         if (row >= max_rows) return;
-        int c = 0;                                                // (captured by `report`)
-        auto report = [&](int code, int out_col, int is_dense, long long value) {
-            const unsigned long long key = ((unsigned long long)row << 20) | ((unsigned long long)(unsigned)c << 4) | (unsigned)code;
-            atomicMin(first_err, key);
-            const unsigned s = atomicAdd(n_errs, 1u);
-            if (s < 64) { errs[s].key = key; errs[s].code = code; errs[s].out_col = out_col; errs[s].is_dense = is_dense; errs[s].value = value; }
-        };
+        const CsvSink sink{ids, dense, first_err, errs, n_errs};
         // Every kept line has exactly n_cols fields, so the field loop runs a uniform n_cols times (the column's role, its output
         // lists: scalar); a lane whose line ends early (OPT only: such a line is dropped) idles through the rest.
         decltype(lo) p = lo;
         bool ended = false, short_line = false;
-        for (c = 0; c < L.n_cols; ++c) {
+        for (int c = 0; c < L.n_cols; ++c) {
             if (ended) { short_line = true; continue; }
             decltype(lo) a, b;
             bool esc;
             csv_field(rd, hi, p, a, b, esc);                      // (p == hi on entry: the empty field after a trailing comma)
             if (p >= hi) ended = true;
             else ++p;                                             // the comma
-            // field c = [a, b)
             const int role = L.role[c];
-            if (role) {
-                double v = 0.0;
-                int st = 1;
-                if (role & 1) {
-                    if (esc) st = 2;
-                    else if (a == b) st = 1;
-                    else if ((unsigned)(b - a) <= 8 && csv_number_short(rd, a, b, v)) st = 0;
-                    else st = csv_number(rd, a, b, v);
-                }
-                unsigned long long w0 = 0, w1 = 0;
-                const unsigned gn = (unsigned)(b - a);
-                if ((role & 2) && gn >= 1 && gn <= 16) {                   // the field's bytes as two little-endian words
-                    w0 = rd.win(a);
-                    if (gn < 8) w0 &= ~0ull >> (64 - 8 * gn);
-                    if (gn > 8) { w1 = rd.win(a + 8); if (gn < 16) w1 &= ~0ull >> (64 - 8 * (gn - 8)); }
-                }
-                for (int o = L.id_head[c]; o >= 0; o = L.id_next[o]) {
-                    int out;
-                    if (L.id_kind[o] == 1) {                          // genre vocabulary (exact match) or -1
-                        out = -1;
-                        if (gn >= 1 && gn <= 16) {
-                            const unsigned sl = csv_genre_slot(w0, w1, gn, L.g_mul);
-                            if (g_len[sl] == (int)gn && g_tab[2 * sl] == w0 && g_tab[2 * sl + 1] == w1) out = g_len[32 + sl];
-                        }
-                        if (out >= L.id_vocab[o]) out = -1;
-                    } else if (st == 2) {
-                        report(2, o, 0, 0);
-                        out = 0;
-                    } else {
-                        const long long iv = (long long)v;            // int(float(v)) of the Python packer; empty -> 0
-                        if (iv < 0 || iv >= L.id_vocab[o]) report(1, o, 0, iv);
-                        out = (int)iv;
-                    }
-                    ids[(size_t)row * L.n_id + o] = out;
-                }
-                for (int o = L.dense_head[c]; o >= 0; o = L.dense_next[o]) {
-                    if (st == 2) report(2, o, 1, 0);
-                    dense[(size_t)row * L.n_dense + o] = (float)v;
-                }
-            }
+            if (role) csv_emit(L, g_tab, g_len, rd, a, b, esc, role, c, row, sink);
         }
         if constexpr (OPT) {
             if (short_line || !ended) atomicAdd(drops, 1u);       // fewer or more fields than the header: not a row

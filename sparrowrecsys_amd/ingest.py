@@ -96,6 +96,12 @@ def pack_csv_device(text, id_columns: Sequence[IdColumn], numeric_keys: Sequence
     return ids[:rows.value], dense[:rows.value]
 
 
+def last_device_path() -> int:
+    """Which kernels this thread's last ``pack_csv_device`` ran: 1 = the optimistic pass alone (every line a row), 2 = the
+    exact keep -> scan -> parse sequence (``sprk_csv_last_path``)."""
+    return int(L.load_library().sprk_csv_last_path())
+
+
 def read_csv_to_device(path: str):
     """The file's bytes as a ``torch.uint8`` device tensor (16 spare bytes behind the text): read straight into pinned host
     memory (one copy out of the page cache) and sent with one asynchronous host -> device copy -- what ``pack_csv_device``

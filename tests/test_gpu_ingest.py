@@ -9,7 +9,7 @@ import pytest
 from sparrowrecsys_amd import _lib as L
 from sparrowrecsys_amd import models as M
 from sparrowrecsys_amd import schema as S
-from sparrowrecsys_amd.ingest import pack_csv, pack_csv_device
+from sparrowrecsys_amd.ingest import last_device_path, pack_csv, pack_csv_device
 
 pytestmark = pytest.mark.gpu
 EXCERPT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "test_samples_512.csv")
@@ -69,7 +69,7 @@ def test_reference_sample_rows(torch):
         assert ids.shape[0] == 512
 
 
-def _synthetic_csv(n_rows, seed):
+def _synthetic_csv(n_rows, seed, ragged=20):
     rng = np.random.default_rng(seed)
     genres = S.GENRE_VOCAB + ["", "(no genres listed)"]
     cols = []
@@ -91,7 +91,7 @@ def _synthetic_csv(n_rows, seed):
         cols.append(np.array(genres, dtype=object)[rng.integers(0, len(genres), n_rows)])
     lines = [",".join(HEADER)]
     lines += [",".join(map(str, r)) for r in zip(*cols)]
-    for k in rng.integers(1, n_rows, 20):                                                  # ragged rows: dropped
+    for k in rng.integers(1, n_rows, ragged):                                              # ragged rows: dropped
         lines[k] = lines[k] + ",extra"
     return ("\n".join(lines) + "\n").encode()
 
@@ -102,6 +102,7 @@ def test_large_synthetic_file_bit_identical(torch):
     text = _synthetic_csv(200000, 5)
     ids, dense = _same(text, cols)
     assert ids.shape[0] == 200000 - 20
+    assert last_device_path() == 2                                 # (ragged rows: the exact keep -> scan -> parse sequence)
     # the device buffer may be handed over directly
     buf = torch.frombuffer(bytearray(text), dtype=torch.uint8).cuda()
     dids, ddense = pack_csv_device(buf, cols)
@@ -189,3 +190,101 @@ def test_lines_too_long_for_the_lds_piece_are_read_in_place(torch):
     assert ids.shape[0] == 1500
     _same(text, cols, max_rows=0)
     _same(text, cols, max_rows=9)
+
+
+# --------------------------------------------------------------------------------------------
+# which kernels ran (sprk_csv_last_path): the optimistic pass alone on texts whose every line is a row, the exact sequence otherwise
+# --------------------------------------------------------------------------------------------
+def test_optimistic_pass_runs_alone_when_every_line_is_a_row(torch, monkeypatch):
+    """The reference's sample rows and a 200 000-row synthetic file without ragged rows take ONE parse pass
+    (sprk_csv_last_path() == 1) and give the host tokenizer's bits: with max_rows, \\r\\n line ends, no trailing newline;
+    SPRK_CSV_TWO_PASS=1 (the exact keep -> scan -> parse sequence) gives the same arrays."""
+    text = open(EXCERPT, "rb").read()
+    for model in (M.EmbeddingMLP(seed=1), M.DeepFMv2(seed=1), M.DIN(seed=1), M.WideNDeep(seed=1)):
+        _same(text, model.id_columns)
+        assert last_device_path() == 1
+    cols = M.EmbeddingMLP(seed=1).id_columns
+    text = _synthetic_csv(200000, 6, ragged=0)
+    ids, dense = _same(text, cols)
+    assert ids.shape[0] == 200000 and last_device_path() == 1
+    for kw in (dict(max_rows=1), dict(max_rows=12345), dict(max_rows=199999)):
+        _same(text, cols, **kw)
+        assert last_device_path() == 1
+    _same(text.rstrip(b"\n"), cols)
+    _same(text.replace(b"\n", b"\r\n"), cols)
+    _same(text.replace(b"\n", b"\r\n")[:-2], cols)
+    assert last_device_path() == 1
+    monkeypatch.setenv("SPRK_CSV_TWO_PASS", "1")
+    a, b = _same(text, cols)
+    assert last_device_path() == 2
+    np.testing.assert_array_equal(a, ids)
+
+
+def test_every_alignment_of_rows_to_the_4kb_chunks(torch):
+    """Rows, quoted empty strings, \\r\\n pairs and the end of the text at every offset relative to a 4-KB chunk boundary of the
+    newline passes: the first row carries a pad field of 0 .. 47 bytes that shifts everything behind it; lengths that are exact
+    multiples of 4 096 with and without the final newline."""
+    cols = [S.IdColumn("movieId", "id", 100000), S.IdColumn("userGenre1", "genre", 19), S.IdColumn("q", "id", 10)]
+    rng = np.random.default_rng(5)
+    genres = S.GENRE_VOCAB + ["", '""', '"Drama"', "(none)"]
+    body = ["%d,%s,%s,%s,p" % (rng.integers(0, 100000), genres[int(rng.integers(0, len(genres)))],
+                             ["1990", "1990.5", "", '"1995"', "-3.25e1"][int(rng.integers(0, 5))], ['""', "", "7", '"3"'][int(rng.integers(0, 4))])
+            for _ in range(420)]
+    head = "movieId,userGenre1,releaseYear,q,pad"
+    for eol in ("\n", "\r\n"):
+        for shift in range(48):
+            rows = [body[0] + "x" * shift] + body[1:]
+            text = head + eol + eol.join(rows) + (eol if shift % 2 else "")
+            ids, _ = _same(text, cols, ["releaseYear"])
+            assert ids.shape[0] == 420 and last_device_path() == 1, (eol, shift)
+    for trailing in (True, False):
+        for extra in (-1, 0, 1):
+            base_text = head + "\n" + "\n".join(body) + ("\n" if trailing else "")
+            want = ((len(base_text) + 4095) // 4096) * 4096 + extra
+            pad = want - len(base_text)
+            rows = [body[0] + "x" * pad] + body[1:]
+            text = head + "\n" + "\n".join(rows) + ("\n" if trailing else "")
+            assert len(text) == want
+            ids, _ = _same(text, cols, ["releaseYear"])
+            assert ids.shape[0] == 420 and last_device_path() == 1, (trailing, extra, pad)
+
+
+def test_quotes_the_host_splitter_reads_in_its_own_way(torch):
+    """A comma / an escaped quote inside quotes, text after a closing quote, an unclosed quote, stray quotes, a 1.5-KB field, a
+    56-digit number, '\\r' inside quotes, every field quoted -- at the start, in the middle (straddling a chunk boundary for some
+    placements) and at the end of a 6-KB text: the device arrays are the host's bits, and the exact sequence runs exactly when the
+    host drops a line."""
+    cols = [S.IdColumn("movieId", "id", 1001), S.IdColumn("userGenre1", "genre", 19)]
+    head = "movieId,userGenre1,releaseYear,note\n"
+    good = "".join("%d,Drama,19%02d,n%d\n" % (i % 1000, i % 100, i) for i in range(300))
+    rows = good.splitlines(keepends=True)
+    kept = ['5,"Drama,War",1990,x', '5,"Dra""ma",1990,x', '5,"Drama"junk,1990,x', '5,Dra"ma,1990,x', '5,Drama",1990,x',
+            "5,Drama,1990," + "y" * 1500, "5,Drama," + "0" * 55 + "7,x", '5,Drama,1990,"a\r"', '5,"Drama\r",1990,x', '"5","Drama","1990",""',
+            '5,Drama,1990,"x,y,z"']
+    dropped = ['5,"Drama,1990,x', '5,",1990,x', "", "5,Drama,1990", "5,Drama,1990,x,extra", "\r"]
+    for line in kept + dropped:
+        for where in (0, 150, 190, 200, 210, 300):
+            text = head + "".join(rows[:where]) + line + "\n" + "".join(rows[where:])
+            ids, _ = _same(text, cols, ["releaseYear"])
+            assert ids.shape[0] == 300 + (line in kept), (line[:30], where)
+            assert last_device_path() == (1 if line in kept else 2), (line[:30], where)
+    # one column: every non-empty line is a row
+    one = "movieId\n" + "".join("%d\n" % (i % 1000) for i in range(3000))
+    _same(one, cols[:1], [])
+    assert last_device_path() == 1
+    _same(one.replace("\n", "\r\n"), cols[:1], [])
+    assert last_device_path() == 1
+    cut = one.index("\n", 5000) + 1
+    _same(one[:cut] + "\n" + one[cut:], cols[:1], [])                       # an empty line: not a row
+    assert last_device_path() == 2
+    crlf = one.replace("\n", "\r\n")
+    cut = crlf.index("\n", 6000) + 1
+    _same(crlf[:cut] + "\r\n" + crlf[cut:], cols[:1], [])
+    assert last_device_path() == 2
+    # an id outside its buckets in the middle of a clean text: the host's message
+    bad = head + good + "1001,Drama,1990,x\n" + good
+    with pytest.raises(ValueError) as host:
+        pack_csv(bad, cols, ["releaseYear"])
+    with pytest.raises(ValueError) as dev:
+        pack_csv_device(bad, cols, ["releaseYear"])
+    assert str(dev.value) == str(host.value) and "row 300" in str(dev.value)
