@@ -310,10 +310,56 @@ def cpu_baseline_c(name, model, feats, budget_s, note):
         return {"value": done / el, "unit": "samples/s", "cores": threads, "kind": "port", "ran": "oracle/ctr_c.c",
                 "sample": "plain-C restatement of the %s forward (oracle/ctr_c.c, OpenMP, -march=native; TensorFlow unavailable), "
                           "%d passes over one packed batch of %d rows, %.1f s" % (what, done // n, n, el),
-                "host_cpus": os.cpu_count()}
+                "host_cpus": os.cpu_count(), "cpu_model": cpu_model()}
     except Exception as e:                                    # no compiler on this host, ...: say so, fall back to numpy
         note.append("C restatement unavailable (%s: %s)" % (type(e).__name__, e))
         return None
+
+
+def cpu_model():
+    """The host CPU's model name ("always print core count and CPU model")."""
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.lower().startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return None
+
+
+def hardware_block(torch, dev):
+    """the device's own facts and a MEASURED streaming bandwidth next to the 8.0 TB/s every fraction is quoted
+    against.  copy = torch's device-to-device copy of 1 GiB (bytes read + bytes written per second), read = a sum reduction over
+    the same 1 GiB (bytes read per second); HIP events, median of 5 after a warm-up.  These are what simple streaming kernels
+    reach on this box, not a different denominator: `frac` stays against 8.0e12 B/s."""
+    p = torch.cuda.get_device_properties(dev)
+    out = {"name": p.name, "arch": getattr(p, "gcnArchName", None), "compute_units": p.multi_processor_count,
+           "memory_GiB": round(p.total_memory / 2 ** 30, 1), "hbm_peak_GBps_quoted": HBM_PEAK / 1e9}
+    for k in ("clock_rate", "memory_clock_rate", "memory_bus_width", "L2_cache_size"):
+        if hasattr(p, k):
+            out[k] = getattr(p, k)
+    try:
+        n = 1 << 28                                                # 2^28 floats = 1 GiB
+        src = torch.empty(n, dtype=torch.float32, device=dev).fill_(1.0)
+        dst = torch.empty_like(src)
+        def timed(fn):
+            fn(); torch.cuda.synchronize(dev)
+            tt = []
+            for _ in range(5):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(); fn(); e1.record(); torch.cuda.synchronize(dev)
+                tt.append(e0.elapsed_time(e1) * 1e-3)
+            return float(np.median(tt))
+        t_copy = timed(lambda: dst.copy_(src))
+        t_read = timed(lambda: src.sum())
+        out["measured_device_copy_GBps"] = round(2 * n * 4 / t_copy / 1e9, 1)
+        out["measured_read_GBps"] = round(n * 4 / t_read / 1e9, 1)
+        out["measured_with"] = "torch d2d copy / sum of 1 GiB, HIP events, median of 5"
+        del src, dst
+        torch.cuda.empty_cache()
+    except Exception as e:                                          # (never fail the bench over a probe)
+        out["measured_error"] = "%s: %s" % (type(e).__name__, e)
+    return out
 
 
 def cpu_baseline_tf(name, model, feats, budget_s, note):
@@ -379,7 +425,7 @@ def cpu_baseline_tf(name, model, feats, budget_s, note):
                 break
         return {"value": done / el, "unit": "samples/s", "cores": os.cpu_count(), "kind": "port", "ran": "tensorflow %s (tf.keras graph of the same weights)" % tf.__version__,
                 "sample": "TF2 CPU forward of the DeepFM_v2 graph at config 2's shape, model.predict(batch_size=%d), %d passes, %.1f s" % (n, done // n, el),
-                "host_cpus": os.cpu_count()}
+                "host_cpus": os.cpu_count(), "cpu_model": cpu_model()}
     except Exception as e:
         note.append("TensorFlow leg failed (%s: %s): CPU restatement timed instead" % (type(e).__name__, e))
         return None
@@ -432,7 +478,7 @@ def cpu_baseline_numpy(name, model, feats, budget_s):
     return {"value": done / el, "unit": "samples/s", "cores": cores, "kind": "port",
             "sample": "numpy oracle (CPU restatement; TensorFlow unavailable), %d passes of %d rows of the same synthetic batch, %.1f s"
                       % (done // sample, sample, el),
-            "host_cpus": os.cpu_count()}
+            "host_cpus": os.cpu_count(), "cpu_model": cpu_model()}
 
 
 def _free_port():
@@ -522,6 +568,7 @@ def main():
     ap.add_argument("--dist", default="uniform", choices=["uniform", "zipf", "hot"], help="id distribution")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget (0 = skip)")
     ap.add_argument("--no-check", action="store_true", help="skip the oracle spot check of the outputs")
+    ap.add_argument("--no-hardware-probe", action="store_true", help="skip the device facts / measured copy bandwidth block")
     ap.add_argument("--min-region-ms", type=float, default=50.0,
                     help="a timed region = R back-to-back repetitions of the K-step block, R chosen so that it lasts at least this long")
     ap.add_argument("--regions", type=int, default=5, help="timed regions; ms_per_step is the median region / (R*K)")
@@ -880,6 +927,8 @@ def main():
             line["workloads"] = {w: side_workload(args, w) for w in args.side_workloads.split(",") if w}
         if world == 1 and args.cpu_seconds > 0:
             line["cpu_baseline"] = cpu_baseline(args.workload, model, feats, args.cpu_seconds)
+        if not args.no_hardware_probe:
+            line["hardware"] = hardware_block(torch, torch.device("cuda", local_dev))
         # RCCL prints a version banner through C stdio, which (stdout being a pipe) would otherwise be flushed at exit,
         # AFTER this line: flush it first so the JSON is the last line of output
         try:
