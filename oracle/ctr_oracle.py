@@ -542,7 +542,9 @@ def dien_forward(features: Dict, w: Dict[str, np.ndarray], dtype=np.float32,
                  hist_len: int = 5, movie_buckets=MOVIE_BUCKETS, user_buckets=USER_BUCKETS,
                  return_parts: bool = False):
     """DIEN.py:114-250, the y_pred output (the second model output, the auxiliary loss of DIEN.py:253-292, needs labels
-    and sampled negatives and is training-only).  PARITY UNPINNED: no trained DIEN checkpoint, no golden vector.
+    and sampled negatives and is training-only).  PARITY: the wiring is pinned by the reference's own lines (DIEN.py:51-296
+    executed on oracle/keras_shim.py, tests/golden/refblock_shim_dien.npz: 6e-8); the arithmetic of Keras' GRU is restated
+    from its source in both places; no TensorFlow-produced vector (tests/test_reference_blocks.py ..._unpinned_...).
 
     * ids as numeric columns with default 0 -> shared Embedding(1001, D, mask_zero=True) (DIEN.py:111-121,163-169).
     * tf.keras.layers.GRU(D, return_sequences=True) (DIEN.py:173) -- TF2 defaults: reset_after=True, tanh / sigmoid,

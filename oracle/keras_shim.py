@@ -1,6 +1,6 @@
 """CPU ORACLE, part 3 (test infrastructure, NOT the product): a numpy stand-in for the slice of the ``tensorflow`` API the
 reference's model scripts touch, so that the reference's OWN model-building source -- the untouched lines of
-``TFRecModel/src/com/sparrowrecsys/offline/tensorflow/{DIN,DeepFM,DeepFM_v2,WideNDeep,EmbeddingMLP,NeuralCF}.py`` between
+``TFRecModel/src/com/sparrowrecsys/offline/tensorflow/{DIN,DeepFM,DeepFM_v2,WideNDeep,EmbeddingMLP,NeuralCF,DIEN}.py`` between
 the dataset definition and ``model = tf.keras.Model(...)`` -- can be ``exec``-uted in a container where TensorFlow cannot be
 installed (tests/golden/make_tf_golden.py does that; with a real ``import tensorflow`` the very same harness runs the very
 same lines on TensorFlow instead).
@@ -136,26 +136,68 @@ def _activation(a):
             with np.errstate(over="ignore"):           # exp(-x) -> inf for very negative x: 1 / inf = 0, as TensorFlow's logistic
                 return (F32(1) / (F32(1) + np.exp(-x))).astype(F32)
         return sig
+    if a == "tanh":
+        return lambda x: np.tanh(x).astype(F32)
     raise NotImplementedError("activation %r" % (a,))
 
 
+class _T(np.ndarray):
+    """What a custom layer's ``call`` sees: an array that answers ``x == None`` with False, as a TensorFlow tensor does
+    (DIEN.py:217 ``if Z_t_inputs==None:``), and otherwise is the ndarray."""
+
+    def __eq__(self, other):
+        return False if other is None else np.ndarray.__eq__(self, other)
+
+    def __ne__(self, other):
+        return True if other is None else np.ndarray.__ne__(self, other)
+
+    __hash__ = None
+
+
+def _wrap(v):
+    return np.asarray(v).view(_T) if isinstance(v, np.ndarray) and v.dtype != object else v
+
+
+def _unwrap(v):
+    return np.asarray(v) if isinstance(v, _T) else v
+
+
 class Layer:
-    """keras/engine/base_layer.py: __call__ builds once from the input shape, then calls ``call``."""
+    """keras/engine/base_layer.py: __call__ builds once from the input shape, then calls ``call``.  A layer that holds other
+    layers as attributes (a subclass written in the reference script: DIEN.py's attention / GRU_gate_parameter / AUGRU) reports
+    their variables behind its own, in attribute-creation order, names prefixed with its own -- Keras' layer tracking."""
 
     def __init__(self, name: Optional[str] = None, **kwargs):
         self.name = name or _unique(_snake(type(self).__name__))
-        self.weights: List[Var] = []
+        self._w: List[Var] = []
         self.built = False
         _ALL_LAYERS.append(self)
 
     def _ensure_base(self):                         # a subclass that forgot nothing: ReduceLayer calls super().__init__()
-        if not hasattr(self, "weights"):
+        if not hasattr(self, "_w"):
             Layer.__init__(self)
 
     def add_weight(self, name, value):
         v = Var("%s/%s:0" % (self.name, name), value)
-        self.weights.append(v)
+        self._w.append(v)
         return v
+
+    def _sublayers(self):
+        return [v for v in vars(self).values() if isinstance(v, Layer)]
+
+    @property
+    def weights(self):
+        out = list(self._w)
+        for sub in self._sublayers():
+            for v in sub.weights:
+                out.append(types.SimpleNamespace(name="%s/%s" % (self.name, v.name), var=getattr(v, "var", v)))
+        return out
+
+    def add_loss(self, *a, **kw):                   # training-only bookkeeping (DIEN.py:288-290)
+        pass
+
+    def add_metric(self, *a, **kw):
+        pass
 
     def build(self, input_shape):
         pass
@@ -164,19 +206,30 @@ class Layer:
         raise NotImplementedError
 
     def get_weights(self):
-        return [v.value for v in self.weights]
+        return [getattr(v, "var", v).value for v in self.weights]
 
     def set_weights(self, values):
-        if len(values) != len(self.weights):
-            raise ValueError("%s: %d values for %d weights" % (self.name, len(values), len(self.weights)))
-        for v, a in zip(self.weights, values):
+        ws = self.weights
+        if len(values) != len(ws):
+            raise ValueError("%s: %d values for %d weights" % (self.name, len(values), len(ws)))
+        for v, a in zip(ws, values):
             a = np.asarray(a, dtype=F32)
-            if a.shape != v.value.shape:
-                raise ValueError("%s: shape %s for weight %s of shape %s" % (self.name, a.shape, v.name, v.value.shape))
-            v.value = a
+            var = getattr(v, "var", v)
+            if a.shape != var.value.shape:
+                raise ValueError("%s: shape %s for weight %s of shape %s" % (self.name, a.shape, v.name, var.value.shape))
+            var.value = a
 
-    def __call__(self, inputs, **kwargs):
+    def __call__(self, inputs, *args, **kwargs):
         self._ensure_base()
+        custom = type(self).__module__ != __name__                # a Layer subclass defined by the executed script
+        if custom:
+            base_call = self.call
+
+            def call(x, *a, **kw):
+                x = [_wrap(v) for v in x] if isinstance(x, (list, tuple)) else _wrap(x)
+                return _unwrap(base_call(x, *[_wrap(v) for v in a], **{k: _wrap(v) for k, v in kw.items()}))
+        else:
+            call = self.call
         syms = inputs if isinstance(inputs, (list, tuple)) else [inputs]
         if isinstance(inputs, dict):
             syms = list(inputs.values())
@@ -186,17 +239,17 @@ class Layer:
                 shapes = [(None,) + tuple(np.asarray(v).shape[1:]) for v in syms]
                 self.build(shapes[0] if not isinstance(inputs, (list, tuple, dict)) else shapes)
                 self.built = True
-            return self.call(inputs)
+            return call(inputs, *args, **kwargs)
         if not self.built:
             shapes = [s.shape for s in syms if isinstance(s, Sym)]
             self.build(shapes[0] if not isinstance(inputs, (list, tuple, dict)) else shapes)
             self.built = True
         if isinstance(inputs, dict):
             keys = list(inputs.keys())
-            return Sym(lambda *vals: self.call(dict(zip(keys, vals))), [inputs[k] for k in keys], name=self.name)
+            return Sym(lambda *vals: call(dict(zip(keys, vals))), [inputs[k] for k in keys], name=self.name)
         if isinstance(inputs, (list, tuple)):
-            return Sym(lambda *vals: self.call(list(vals)), list(inputs), name=self.name)
-        return Sym(lambda v: self.call(v), [inputs], name=self.name)
+            return Sym(lambda *vals: call(list(vals), *args, **kwargs), list(inputs), name=self.name)
+        return Sym(lambda v: call(v, *args, **kwargs), [inputs], name=self.name)
 
 
 # ----------------------------------------------------------------------------------------------------------------------
@@ -227,9 +280,9 @@ class Dense(Layer):
             self.add_weight("bias", np.zeros((self.units,), F32))
 
     def call(self, x, **kw):
-        y = np.matmul(x.astype(F32), self.weights[0].value)
+        y = np.matmul(x.astype(F32), self._w[0].value)
         if self.use_bias:
-            y = y + self.weights[1].value
+            y = y + self._w[1].value
         return self.act(y.astype(F32))
 
 
@@ -249,7 +302,65 @@ class Embedding(Layer):
         ids = x if np.issubdtype(np.asarray(x).dtype, np.integer) else np.asarray(x).astype(np.int32)   # C-style truncation
         if ids.size and (ids.min() < 0 or ids.max() >= self.input_dim):
             raise ValueError("InvalidArgumentError: indices out of range [0, %d)" % self.input_dim)
-        return self.weights[0].value[ids]
+        return self._w[0].value[ids]
+
+    def __call__(self, inputs, *args, **kwargs):
+        out = super().__call__(inputs, *args, **kwargs)
+        if self.mask_zero and isinstance(out, Sym):
+            out.mask = _op(lambda v: np.asarray(v) != 0, inputs)      # compute_mask: not_equal(inputs, 0)
+        return out
+
+
+class GRU(Layer):
+    """keras/layers/recurrent_v2.py GRU(units, return_sequences=True), TF2 defaults: activation tanh, recurrent_activation
+    sigmoid, reset_after=True, zero initial state.  Variables (gru/gru_cell/...): kernel [in, 3u], recurrent_kernel [u, 3u],
+    bias [2, 3u] (input row, recurrent row), gate order z | r | h (recurrent.py GRUCell.call, reset_after branch):
+        z = sig(x Wz + bz + h Uz + cz)   r = sig(x Wr + br + h Ur + cr)   hh = tanh(x Wh + bh + r * (h Uh + ch))
+        h' = z * h + (1 - z) * hh
+    An incoming mask (Embedding(mask_zero=True)) is consumed (keras/backend.py rnn, mask branch): at a masked step the state
+    is kept and the OUTPUT repeats the previous output -- zeros before the first unmasked step."""
+
+    def __init__(self, units, return_sequences=False, **kw):
+        super().__init__(**kw)
+        assert return_sequences, "only the form DIEN.py:169 uses"
+        self.units = int(units)
+
+    def build(self, input_shape):
+        u, d = self.units, int(input_shape[-1])
+        self.add_weight("gru_cell/kernel", _glorot((d, 3 * u), _RNG))
+        self.add_weight("gru_cell/recurrent_kernel", _glorot((u, 3 * u), _RNG))
+        self.add_weight("gru_cell/bias", np.zeros((2, 3 * u), F32))
+
+    def run(self, x, mask):
+        K, U, b = (v.value for v in self._w)
+        u = self.units
+        B, T, _ = x.shape
+        sig = _activation("sigmoid")
+        h = np.zeros((B, u), F32)
+        prev = np.zeros((B, u), F32)
+        out = np.zeros((B, T, u), F32)
+        for t in range(T):
+            mx = (np.matmul(x[:, t, :].astype(F32), K) + b[0]).astype(F32)
+            mh = (np.matmul(h, U) + b[1]).astype(F32)
+            z = sig(mx[:, :u] + mh[:, :u])
+            r = sig(mx[:, u:2 * u] + mh[:, u:2 * u])
+            hh = np.tanh(mx[:, 2 * u:] + r * mh[:, 2 * u:]).astype(F32)
+            hn = (z * h + (F32(1) - z) * hh).astype(F32)
+            m = np.ones((B, 1), bool) if mask is None else mask[:, t].reshape(B, 1)
+            h = np.where(m, hn, h)
+            prev = np.where(m, hn, prev)
+            out[:, t, :] = prev
+        return out
+
+    def __call__(self, inputs, *args, **kwargs):
+        self._ensure_base()
+        if not self.built:
+            self.build(inputs.shape)
+            self.built = True
+        mask = getattr(inputs, "mask", None)
+        if mask is None:
+            return Sym(lambda v: self.run(v, None), [inputs], name=self.name)
+        return Sym(lambda v, m: self.run(v, m), [inputs, mask], name=self.name)
 
 
 class PReLU(Layer):
@@ -260,7 +371,7 @@ class PReLU(Layer):
         self.add_weight("alpha", np.zeros(tuple(int(d) for d in input_shape[1:]), F32))
 
     def call(self, x, **kw):
-        a = self.weights[0].value
+        a = self._w[0].value
         return (np.maximum(x, F32(0)) + (-a) * np.maximum(-x, F32(0))).astype(F32)
 
 
@@ -269,7 +380,7 @@ class Dot(Layer):
 
     def __init__(self, axes, normalize=False, **kw):
         super().__init__(**kw)
-        assert axes == 1 and not normalize
+        assert axes in (1, (1, 1)) and not normalize
         self.axes = axes
 
     def call(self, xs, **kw):
@@ -537,7 +648,8 @@ class Model:
             order.append(n)
         import sys
         sys.setrecursionlimit(max(10000, sys.getrecursionlimit()))
-        walk(outputs)
+        for o in (outputs if isinstance(outputs, (list, tuple)) else [outputs]):
+            walk(o)
         names = {n.name for n in order}
         self.layers = [l for l in _ALL_LAYERS if l.name in names]
 
@@ -560,6 +672,8 @@ class Model:
             else:
                 v = v.astype(np.dtype(node.dtype))
             memo[id(node)] = v
+        if isinstance(self.output, (list, tuple)):
+            return [np.asarray(_eval(o, memo), dtype=F32) for o in self.output]
         return np.asarray(_eval(self.output, memo), dtype=F32)
 
 
@@ -595,6 +709,42 @@ class _AUC:
     def __init__(self, curve="ROC", **kw):
         self.curve = curve
 
+    def update_state(self, *a, **kw):               # training-only bookkeeping (DIEN.py:289-290)
+        pass
+
+    def result(self):
+        return F32(0)
+
+
+def _reshape(x, shape):
+    return _op(lambda v: np.reshape(v, tuple(shape)), x)
+
+
+def _binary_crossentropy(y_true, y_pred):
+    """keras/losses.py binary_crossentropy (from_logits=False): mean over the last axis of the clipped log loss."""
+    def f(t, p):
+        eps = F32(1e-7)
+        p = np.clip(np.asarray(p, F32), eps, F32(1) - eps)
+        t = np.asarray(t, F32)
+        return np.mean(-(t * np.log(p) + (F32(1) - t) * np.log(F32(1) - p)), axis=-1).astype(F32)
+    return _op(f, y_true, y_pred)
+
+
+# tf.keras.initializers.GlorotUniform()(shape): random per call in TensorFlow.  DIEN.py:238-239 draws the AUGRU's initial
+# state that way INSIDE call() -- the reference's own forward pass is not reproducible -- so the harness installs the value it
+# wants the run to use (make_tf_golden.py does the same to tensorflow when that backend runs).
+INITIALIZER_OVERRIDE: Optional[Callable] = None
+
+
+class _GlorotUniform:
+    def __init__(self, seed=None):
+        pass
+
+    def __call__(self, shape, dtype=None):
+        if INITIALIZER_OVERRIDE is not None:
+            return np.asarray(INITIALIZER_OVERRIDE(tuple(shape)), F32)
+        return _glorot(tuple(shape), _RNG)
+
 
 def build_module():
     """A fresh ``tf`` namespace (and a fresh Keras name scope: ``clear_session``)."""
@@ -605,14 +755,15 @@ def build_module():
     layers = types.SimpleNamespace(
         Input=Input, Dense=Dense, Embedding=Embedding, PReLU=PReLU, Dot=Dot, Add=Add, Subtract=Subtract, Multiply=Multiply,
         Concatenate=Concatenate, concatenate=concatenate, multiply=multiply, subtract=subtract, add=add, Flatten=Flatten,
-        RepeatVector=RepeatVector, Permute=Permute, Reshape=Reshape, Lambda=Lambda, Layer=Layer, DenseFeatures=DenseFeatures)
+        RepeatVector=RepeatVector, Permute=Permute, Reshape=Reshape, Lambda=Lambda, Layer=Layer, DenseFeatures=DenseFeatures, GRU=GRU)
     tf.keras = types.SimpleNamespace(
         layers=layers, Model=Model, Sequential=Sequential,
         backend=types.SimpleNamespace(sum=_reduce_sum, clear_session=clear_session),
-        metrics=types.SimpleNamespace(AUC=_AUC))
+        metrics=types.SimpleNamespace(AUC=_AUC), losses=types.SimpleNamespace(binary_crossentropy=_binary_crossentropy),
+        initializers=types.SimpleNamespace(GlorotUniform=_GlorotUniform))
     tf.feature_column = types.SimpleNamespace(
         numeric_column=NumericColumn, categorical_column_with_identity=IdentityCategoricalColumn,
         categorical_column_with_vocabulary_list=VocabularyListCategoricalColumn, embedding_column=EmbeddingColumn,
         indicator_column=IndicatorColumn, crossed_column=CrossedColumn)
-    tf.squeeze, tf.reduce_sum, tf.reduce_mean = _squeeze, _reduce_sum, _reduce_mean
+    tf.squeeze, tf.reduce_sum, tf.reduce_mean, tf.reshape = _squeeze, _reduce_sum, _reduce_mean, _reshape
     return tf

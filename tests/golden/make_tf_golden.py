@@ -4,7 +4,7 @@
 
 For every model the UNTOUCHED lines of the reference script between ``test_dataset = get_dataset(...)`` and
 ``model = tf.keras.Model(...)`` (DIN.py:29-169, DeepFM.py:29-115, DeepFM_v2.py:36-157, WideNDeep.py:29-108,
-NeuralCF.py:29-74, EmbeddingMLP.py:29-78) are read from ``--reference`` and ``exec``-uted with ``tf`` bound to
+NeuralCF.py:29-74, EmbeddingMLP.py:29-78, DIEN.py:52-296) are read from ``--reference`` and ``exec``-uted with ``tf`` bound to
 
   * ``tensorflow`` itself when ``import tensorflow`` works (``--backend tf``; needs ``tf.feature_column`` +
     ``tf.keras.layers.DenseFeatures``, i.e. TF <= 2.15 or ``tf_keras``) -> tests/golden/refblock_tf_<model>.npz.  THIS is
@@ -34,7 +34,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 SCRIPT_DIR = "TFRecModel/src/com/sparrowrecsys/offline/tensorflow"
-SEEDS = {"din": 31, "deepfm": 32, "deepfm_v2": 33, "wide_n_deep": 34, "neural_cf": 35, "embedding_mlp": 36}
+SEEDS = {"din": 31, "deepfm": 32, "deepfm_v2": 33, "wide_n_deep": 34, "neural_cf": 35, "embedding_mlp": 36, "dien": 37}
 GENRE_KEYS = ["userGenre%d" % i for i in range(1, 6)] + ["movieGenre%d" % i for i in range(1, 4)]
 
 
@@ -68,17 +68,38 @@ SPECS = {
     "embedding_mlp": ("EmbeddingMLP.py",
                       [("dense_features", k + "_embedding", "emb/" + k) for k in GENRE_KEYS + ["movieId", "userId"]]
                       + _dense("dense", "dense0") + _dense("dense_1", "dense1") + _dense("dense_2", "head")),
+    # DIEN.py: the Dense layers live INSIDE the script's own Layer subclasses and are numbered in creation order -- attention.__init__
+    # (dense, dense_1), the three GRU_gate_parameter.__init__ of AUGRU.build (Dense_sigmoid / Dense_tanh: dense_2..7; R_t and Z_t never
+    # build their tanh layer, H_t_next never its sigmoid one), their build at the first time step (input_w / hidden_w: dense_8..13),
+    # the tail (dense_14..16); the auxiliary-loss layer (dense_17..20, DIEN.py:261-292) is training-only and keeps its initial values
+    "dien": ("DIEN.py",
+             [("dense_features_3", "userGenre1_embedding", "emb/userGenre1"), ("dense_features_3", "userId_embedding", "emb/userId"),
+              ("dense_features_4", "movieGenre1_embedding", "emb/movieGenre1"), ("embedding", "embeddings", "emb/movie"),
+              ("gru", "gru_cell/kernel", "gru/kernel"), ("gru", "recurrent_kernel", "gru_rec/kernel"), ("gru", "bias", "gru/bias"),
+              ("attention", "dense/kernel", "att0/kernel"), ("attention", "dense/bias", "att0/bias"),
+              ("attention", "dense_1/kernel", "att1/kernel"), ("attention", "dense_1/bias", "att1/bias")]
+             + [("augru", "dense_%d/%s" % (n, v), "augru_%s_%s/%s" % (g, part, v))
+                for g, (n_out, n_in, n_hid) in (("r", (2, 8, 9)), ("z", (4, 10, 11)), ("h", (7, 12, 13)))
+                for part, n, vs in (("out", n_out, ("kernel", "bias")), ("in", n_in, ("kernel", "bias")), ("hid", n_hid, ("kernel",)))
+                for v in vs]
+             + _dense("dense_14", "fc0") + [("p_re_lu", "alpha", "fc0_prelu/alpha")]
+             + _dense("dense_15", "fc1") + [("p_re_lu_1", "alpha", "fc1_prelu/alpha")] + _dense("dense_16", "head")),
     "neural_cf": ("NeuralCF.py",
                   [("dense_features", "movieId_embedding", "emb/movieId"), ("dense_features_1", "userId_embedding", "emb/userId")]
                   + _dense("dense", "dense0") + _dense("dense_1", "dense1") + _dense("dense_2", "head")),
 }
 
 
+# layers whose variables only feed the training loss (DIEN.py:261-292: the second model output): left at their initial values
+TRAINING_ONLY_LAYERS = ("auxiliary_loss_layer",)
+
+
 def make_model(name):
     from sparrowrecsys_amd import models as M
     return {"din": lambda: M.DIN(seed=SEEDS[name]), "deepfm": lambda: M.DeepFM(seed=SEEDS[name]),
             "deepfm_v2": lambda: M.DeepFMv2(seed=SEEDS[name]), "wide_n_deep": lambda: M.WideNDeep(seed=SEEDS[name]),
-            "neural_cf": lambda: M.NeuralCF(seed=SEEDS[name]), "embedding_mlp": lambda: M.EmbeddingMLP(seed=SEEDS[name])}[name]()
+            "neural_cf": lambda: M.NeuralCF(seed=SEEDS[name]), "embedding_mlp": lambda: M.EmbeddingMLP(seed=SEEDS[name]),
+            "dien": lambda: M.DIEN(seed=SEEDS[name])}[name]()
 
 
 def weights_digest(w):
@@ -93,7 +114,7 @@ def model_block(script_path):
     """(source text of the model-building block, 'first-last' line numbers, sha256 of the whole script)."""
     text = open(script_path).read()
     lines = text.split("\n")
-    start = next(i for i, ln in enumerate(lines) if ln.startswith("test_dataset = get_dataset(")) + 1
+    start = next(i for i, ln in enumerate(lines) if ln.startswith("test_dataset = get_dataset")) + 1     # (DIEN.py: get_dataset_with_negtive_movie)
     # the last statement that binds `model` before model.compile: `model = tf.keras.Model(...)`, `model = neural_cf_model_1(...)`
     # or the multi-line `model = tf.keras.Sequential([...])`
     comp = next(i for i, ln in enumerate(lines) if ln.startswith("model.compile("))
@@ -124,12 +145,24 @@ def get_backend(which):
     return "shim", tf, tf.__version__
 
 
-def build_reference_model(tf, backend, script_path):
+def build_reference_model(tf, backend, script_path, glorot_value=None):
+    """glorot_value: what ``tf.keras.initializers.GlorotUniform()(shape)`` returns while the block runs and afterwards.  DIEN.py:
+    238-239 draws the AUGRU's initial state with it INSIDE call(): random per forward pass in the reference; the harness pins it to
+    the repo model's ``augru/h0`` on either backend."""
     if backend == "tf":
         tf.keras.backend.clear_session()                             # layer names restart at dense, dense_features, ...
+        if glorot_value is not None:
+            class _Pinned:
+                def __init__(self, *a, **kw):
+                    pass
+
+                def __call__(self, shape, dtype=None):
+                    return tf.constant(np.asarray(glorot_value, np.float32).reshape(tuple(shape)))
+            tf.keras.initializers.GlorotUniform = _Pinned             # (Dense's default initialiser is resolved by NAME: untouched)
     else:
         from oracle import keras_shim
         tf = keras_shim.build_module()
+        keras_shim.INITIALIZER_OVERRIDE = (lambda shape: np.asarray(glorot_value, np.float32).reshape(shape)) if glorot_value is not None else None
     src, lines, sha = model_block(script_path)
     ns = {"tf": tf, "__name__": "reference_block"}
     exec(compile(src, script_path, "exec"), ns)                      # the reference's own lines, untouched
@@ -145,6 +178,8 @@ def inject(model, spec, weights):
     for layer in model.layers:
         vs = list(layer.weights)
         if not vs:
+            continue
+        if layer.name in TRAINING_ONLY_LAYERS:
             continue
         if layer.name not in by_layer:
             raise SystemExit("layer %s has variables %s but no entry in the weight map" % (layer.name, [v.name for v in vs]))
@@ -177,8 +212,10 @@ def feed(model, samples, backend):
     else:
         decl = {t.name.split(":")[0]: t.dtype.name for t in model.inputs}
     out = {}
+    n_rows = len(samples["movieId"])
     for k, dt in decl.items():
-        col = samples[k]
+        # DIEN.py:83-88 also declares the sampled negatives (training-only: they feed the auxiliary loss) -- absent from the CSV: zeros
+        col = samples[k] if k in samples else np.zeros(n_rows, dtype=np.int64).astype(object)
         if dt.startswith("float"):
             out[k] = np.array([float(x) if str(x) != "" else 0.0 for x in col], dtype=np.float32)
         elif dt.startswith("int"):
@@ -191,8 +228,8 @@ def feed(model, samples, backend):
 def run_model(name, backend, tf, reference, samples):
     script, spec = SPECS[name]
     path = os.path.join(reference, SCRIPT_DIR, script)
-    model, lines, sha = build_reference_model(tf, backend, path)
     m = make_model(name)
+    model, lines, sha = build_reference_model(tf, backend, path, glorot_value=m.weights.get("augru/h0"))
     x = feed(model, samples, backend)
     if not getattr(model, "inputs", None):                               # Sequential: variables exist after the first batch
         two = {k: v[:2] for k, v in x.items()}
@@ -200,9 +237,12 @@ def run_model(name, backend, tf, reference, samples):
     inject(model, spec, m.weights)
     if backend == "tf":
         x = {k: (tf.constant(v.tolist()) if v.dtype == object else v) for k, v in x.items()}
-        pred = np.asarray(model.predict(x, batch_size=len(samples["movieId"]), verbose=0), dtype=np.float32)
+        pred = model.predict(x, batch_size=len(samples["movieId"]), verbose=0)
     else:
         pred = model.predict(x)
+    if isinstance(pred, (list, tuple)):                                  # DIEN.py:296: outputs=[y_pred, auxiliary_loss_value]
+        pred = pred[0]
+    pred = np.asarray(pred, dtype=np.float32)
     return {"pred": pred.reshape(-1), "block_lines": lines, "script": script, "script_sha256": sha, "seed": SEEDS[name],
             "weights_digest": weights_digest(m.weights), "n_variables": len(spec)}
 

@@ -2,8 +2,9 @@
 
 Two fixture families, same inputs (first 256 rows of the reference's testSamples.csv) and same seeded weights:
   refblock_shim_<model>.npz  the untouched script lines executed on oracle/keras_shim.py -- committed; pins the WIRING of
-                             DIN / DeepFM / DeepFM_v2 / Wide&Deep / NeuralCF to the reference's code (SURVEY 8(a) A7, A8,
-                             A10-A14: concat orders, PReLU shapes, pair list, no-softmax pooling, two tables per deep key);
+                             DIN / DeepFM / DeepFM_v2 / Wide&Deep / NeuralCF / EmbeddingMLP / DIEN to the reference's code
+                             (SURVEY 8(a) A7, A8, A10-A14, 8(f) DIEN: concat orders, PReLU shapes, pair list, no-softmax pooling,
+                             two tables per deep key, DIEN.py's own attention / GRU_gate_parameter / AUGRU classes);
   refblock_tf_<model>.npz    the same lines executed on TensorFlow -- NOT in the repository yet (TensorFlow cannot be
                              installed in the build container).  The tests that need it carry ``unpinned`` in their names
                              and XFAIL with the reason while the file is missing; once somebody runs
@@ -20,7 +21,8 @@ from tests.golden.make_tf_golden import SPECS, make_model, weights_digest
 
 MODELS = list(SPECS)
 FORWARD = {"din": O.din_forward, "deepfm": O.deepfm_forward, "deepfm_v2": O.deepfm_v2_forward,
-           "wide_n_deep": O.wide_n_deep_forward, "neural_cf": O.neural_cf_forward, "embedding_mlp": O.embedding_mlp_forward}
+           "wide_n_deep": O.wide_n_deep_forward, "neural_cf": O.neural_cf_forward, "embedding_mlp": O.embedding_mlp_forward,
+           "dien": O.dien_forward}
 SHIM_TOL = 1e-6        # oracle vs the reference's lines on the numpy shim: both fp32 numpy, different summation orders
 TF_TOL = 1e-4          # north_star: within 1e-4 of the TF2 CPU forward
 HIP_TOL = 3e-5
@@ -83,6 +85,16 @@ def test_the_wiring_pin_is_sensitive(samples):
     k0 = w["att0/kernel"].copy()
     k0[[*range(0, 10), *range(10, 20)]] = k0[[*range(10, 20), *range(0, 10)]]
     assert np.abs(O.din_forward(samples, {**w, "att0/kernel": k0})[:, 0] - g["pred"]).max() > 1e-5
+    # (6) DIEN.py:241-245: the attention scales the gate called R_t and the candidate state sees h * Z_t -- as written, not as in the
+    # paper: swapping the two gates' weights is another function
+    g = _fixture("shim", "dien")
+    w = dict(_model("dien", g).weights)
+    sw = dict(w)
+    for part in ("in/kernel", "in/bias", "hid/kernel", "out/kernel", "out/bias"):
+        sw["augru_r_" + part], sw["augru_z_" + part] = w["augru_z_" + part], w["augru_r_" + part]
+    assert np.abs(O.dien_forward(samples, sw)[:, 0] - g["pred"]).max() > 1e-5
+    # (the fixture's rows include empty history slots: the GRU's mask branch -- state kept, previous output repeated -- is exercised)
+    assert (np.stack([np.asarray(samples["userRatedMovie%d" % i]).astype(str) for i in range(1, 6)], 1) == "").any()
     # (5) DeepFM_v2.py:106-110: projections stacked as movieGenre1, movieId, userGenre1, userId, numerics
     g = _fixture("shim", "deepfm_v2")
     w = dict(_model("deepfm_v2", g).weights)
