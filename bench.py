@@ -579,14 +579,14 @@ def main():
                     help="with --launch-batches 1: fan sprk_forward_many's independent batches over S helper HIP streams (2..4; "
                          "0 = strict stream order) in the TIMED region.  The roofline block is always measured in strict order "
                          "(one kernel at a time), in its own loop after the timed regions.")
-    ap.add_argument("--launch-batches", type=int, default=16,
+    ap.add_argument("--launch-batches", type=int, default=64,
                     help="batches ONE kernel launch scores in the timed region (sprk_set_many_batches, up to 64; 1 = a launch per "
                          "batch).  Each batch keeps its own buffers of --batch rows.  With N > 1 the launches of the timed region run "
                          "in strict order (no stream fan-out).  `roofline` and `value_one_batch_per_launch` stay ONE batch per "
                          "launch; `roofline_timed_region` describes the N-batch launches.")
     ap.add_argument("--input-batches", type=int, default=0,
-                    help="distinct synthetic input batches the steps cycle through (default: 32 for the headline workload -- no "
-                         "two batches of one 16-batch launch share buffers -- 16 for din_c3, 8 otherwise)")
+                    help="distinct synthetic input batches the steps cycle through (default: 64 for the headline workload -- no "
+                         "two batches of one 64-batch launch share buffers -- 16 for din_c3, 8 otherwise)")
     ap.add_argument("--big-vocab", type=int, default=0,
                     help="deepfm_v2_c2 / deepfm_c2: rows of each identity table (e.g. 8388608 = 1 GiB of folded rows per table, "
                          "far beyond the Infinity Cache); default 0 = the MovieLens-20M-shaped vocabularies of the config")
@@ -638,7 +638,7 @@ def main():
             dist.init_process_group("gloo")
 
     B = args.batch or {"din_c3": 32768, "widedeep_c5": 131072}.get(args.workload, 65536)
-    nb_in = args.input_batches or {"deepfm_v2_c2": 32, "deepfm_c2": 16, "din_c3": 16, "din_ref": 16}.get(args.workload, 8)
+    nb_in = args.input_batches or {"deepfm_v2_c2": 64, "deepfm_c2": 16, "din_c3": 16, "din_ref": 16}.get(args.workload, 8)
     if args.batch and args.batch > 262144:
         nb_in = min(nb_in, 8)
     model, feats, desc, roof = build_workload(args.workload, B, args.dist, seed_offset=rank, big_vocab=args.big_vocab, NB=nb_in)
