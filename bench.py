@@ -47,7 +47,8 @@ HBM_PEAK = 8.0e12          # B/s, MI355X spec (MI355X_MICROARCH.md)
 MFMA_F32_PEAK = 157.3e12   # FLOP/s, fp32-input MFMA (= the fp32 vector rate on gfx950)
 MFMA_F16_PEAK = 2.5e15     # FLOP/s, dense f16/bf16 MFMA
 CONFIG4_ROWS = 27_000_000  # BASELINE configs[3]: "138 k-movie x 27 M-row synthetic table"
-HBM_RESIDENT_BATCHES = 32  # distinct id batches the roofline_hbm_resident loop cycles (row working set 805 MB >> 256 MB MALL)
+HBM_RESIDENT_BATCHES = 32      # distinct id batches the roofline_hbm_resident loop cycles (row working set 805 MB >> 256 MB MALL)
+STRICT_CYCLE = 32              # input batches the strict one-batch-per-launch loop cycles through (see main())
 
 
 def _device_table(V, D, seed, std):
@@ -763,13 +764,18 @@ def main():
     # kernel time for the roofline: HIP events on the launch stream around forwards in STRICT order, ONE batch per
     # launch (what rocprofv3's per-kernel duration measures), in its own loop after the timed regions
     n_strict = int(max(K, min(20000, math.ceil(0.02 / max(blk / K, 1e-9)))))
-    fwd_s = strict_loop(eng, batches, outs, ws, n_strict, lb, fan)
+    # The strict loop cycles at most 32 input batches (round 2's count).  The headline's timed region needs 64 distinct ones -- no
+    # two batches of a 64-batch launch may share buffers -- but 64 x 2.6 MB of ids / numerics / scores next to the 130 MB of tables no
+    # longer fit the 256 MB Infinity Cache together, and the strict launch then reads 7.9 instead of 7.5 us: a working-set effect of
+    # the BENCH's input count, which `roofline_hbm_resident` reports on purpose and this block should not pick up by accident.
+    NBS = min(NB, STRICT_CYCLE)
+    fwd_s = strict_loop(eng, batches[:NBS], outs[:NBS], ws, n_strict, lb, fan)
     fan2_s = None
     if not dist_on and lb > 1 and not is_din:
         # one batch per launch, independent batches alternating over two helper streams (still a launch per batch)
         eng.set_many_batches(1)
         eng.set_many_streams(2)
-        idx = [i % NB for i in range(n_strict)]
+        idx = [i % NBS for i in range(n_strict)]
         run2 = eng.prepare_many([batches[j][0] for j in idx], [batches[j][1] for j in idx], [outs[j] for j in idx], ws)
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         tt = []
@@ -807,7 +813,7 @@ def main():
 
     if rank == 0:
         value = B * world * n_region / elapsed
-        region = "strict-order one-batch-per-launch loop after the timed regions (%d launches, median of 3 loops)" % n_strict
+        region = "strict-order one-batch-per-launch loop after the timed regions (%d launches over %d input batches, median of 3 loops)" % (n_strict, NBS)
         legacy_din = env("SPRK_DIN_LEGACY") == "1"
         extra = {}
         if roof["bound"] == "hbm":

@@ -10,7 +10,7 @@ mkdir -p $O
 rocminfo | grep -E "Marketing Name|gfx|Compute Unit" | head -6 > $O/rocminfo.txt 2>&1
 STRICT="--cpu-seconds 0 --no-check --launch-batches 1 --overlap-streams 0 --hbm-resident 0 --side-workloads="
 declare -A WL
-WL[c2]="--steps 400 --warmup 40"
+WL[c2]="--steps 400 --warmup 40 --input-batches 32"
 WL[c2_hbm]="--steps 400 --warmup 40 --big-vocab 8388608 --input-batches 32"
 WL[c2_pairs]="--steps 400 --warmup 40 --workload deepfm_c2"
 WL[c3]="--steps 60 --warmup 6 --workload din_c3"
@@ -30,7 +30,7 @@ for w in c2 c2_hbm c2_pairs c3 c4_v2 c4_pairs c5 v2_ref ncf_ref deepfm_ref din_r
   rm -rf $O/trace_$w
   echo "$w: $(head -2 $O/${w}_strict_kernel_stats.csv | tail -1 | cut -c1-120)"
 done
-# the driver's own command (16 batches per launch) under the tracer
+# the driver's own command (64 batches per launch) under the tracer
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_drv -o t -- python $R/bench.py --steps 400 --warmup 40 --cpu-seconds 0 --no-check --hbm-resident 0 --side-workloads= > $O/c2_driver.log 2>&1
 grep '^{"metric"' $O/c2_driver.log | tail -1 > $O/c2_driver_bench.json
 f=$(find $O/trace_drv -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/c2_driver_kernel_stats.csv; rm -rf $O/trace_drv

@@ -7,7 +7,7 @@ O=$R/gpurun_out/r03_prof
 mkdir -p $O
 STRICT="--cpu-seconds 0 --no-check --launch-batches 1 --overlap-streams 0 --hbm-resident 0 --side-workloads="
 declare -A WL
-WL[c2]="--steps 400 --warmup 40"
+WL[c2]="--steps 400 --warmup 40 --input-batches 32"
 WL[c2_hbm]="--steps 400 --warmup 40 --big-vocab 8388608 --input-batches 32"
 WL[c2_pairs]="--steps 400 --warmup 40 --workload deepfm_c2"
 WL[c3]="--steps 60 --warmup 6 --workload din_c3"
