@@ -403,7 +403,8 @@ int sprk_describe(sprk_handle h, char* buf, size_t buf_bytes) {
         snprintf(kern, sizeof(kern), "k_deepfm_pairs<NF=%d,NV=%d>", kV1Variants[h->v1_variant].nf, kV1Variants[h->v1_variant].nv);
     } else if (h->rows_variant >= 0) {
         const RowsVariant& rv = kRowsVariants[h->rows_variant];
-        snprintf(kern, sizeof(kern), "k_rows_chain<KPC=%d,H0C=%d,H1C=%d,G_BIG=%d,NJF=%d>", rv.kpc, rv.h0c, rv.h1c, rv.g_big, rv.njf);
+        snprintf(kern, sizeof(kern), "k_rows_chain<KPC=%d,H0C=%d,H1C=%d,G_BIG=%d,NJF=%d%s>", rv.kpc, rv.h0c, rv.h1c, rv.g_big, rv.njf,
+                 rv.unf ? ",UNF" : "");
     } else if (h->mlp_rows_nbig >= 0) {
         snprintf(kern, sizeof(kern), "k_mlp_rows<8,8,NBIG=%d,NSMALL=%d>", h->mlp_rows_nbig, h->mlp_rows_run.n_small);
     } else if (h->din_tail_variant >= 0) {

@@ -4,26 +4,27 @@
 constexpr int RC_WAVES = 8;
 typedef void (*RowsLaunchFn)(const RowsRun&, const int*, const float*, float*, int, int*, const float*, int, size_t, hipStream_t);
 typedef void (*RowsLaunchManyFn)(const RowsRun&, const RowsMany&, int, int*, const float*, int, size_t, hipStream_t);
-template <int KPC, int H0C, int H1C, int G_BIG, int NJF, bool HASNUM>
+template <int KPC, int H0C, int H1C, int G_BIG, int NJF, bool HASNUM, bool UNF>
 void rows_launch(const RowsRun& a, const int* ids, const float* dense, float* out, int B, int* err, const float* image, int grid,
                  size_t lds, hipStream_t st) {
-    hipLaunchKernelGGL((k_rows_chain<KPC, H0C, H1C, G_BIG, NJF, HASNUM, RC_WAVES>), dim3(grid), dim3(RC_WAVES * 64), lds, st, a, ids, dense,
+    hipLaunchKernelGGL((k_rows_chain<KPC, H0C, H1C, G_BIG, NJF, HASNUM, RC_WAVES, UNF>), dim3(grid), dim3(RC_WAVES * 64), lds, st, a, ids, dense,
                        out, B, err, image);
 }
-template <int KPC, int H0C, int H1C, int G_BIG, int NJF, bool HASNUM>
+template <int KPC, int H0C, int H1C, int G_BIG, int NJF, bool HASNUM, bool UNF>
 void rows_launch_one(const RowsRun& a, const int* ids, const float* dense, float* out, int B, int* err, const float* image, int grid,
                      size_t lds, hipStream_t st) {
-    hipLaunchKernelGGL((k_rows_chain1<KPC, H0C, H1C, G_BIG, NJF, HASNUM, RC_WAVES>), dim3(grid), dim3(RC_WAVES * 64), lds, st, a, ids, dense,
+    hipLaunchKernelGGL((k_rows_chain1<KPC, H0C, H1C, G_BIG, NJF, HASNUM, RC_WAVES, UNF>), dim3(grid), dim3(RC_WAVES * 64), lds, st, a, ids, dense,
                        out, B, err, image);
 }
-template <int KPC, int H0C, int H1C, int G_BIG, int NJF, bool HASNUM>
+template <int KPC, int H0C, int H1C, int G_BIG, int NJF, bool HASNUM, bool UNF>
 void rows_launch_many(const RowsRun& a, const RowsMany& m, int B, int* err, const float* image, int grid, size_t lds, hipStream_t st) {
-    hipLaunchKernelGGL((k_rows_chain_many<KPC, H0C, H1C, G_BIG, NJF, HASNUM, RC_WAVES>), dim3(grid), dim3(RC_WAVES * 64), lds, st, a, m, B,
+    hipLaunchKernelGGL((k_rows_chain_many<KPC, H0C, H1C, G_BIG, NJF, HASNUM, RC_WAVES, UNF>), dim3(grid), dim3(RC_WAVES * 64), lds, st, a, m, B,
                        err, image);
 }
 struct RowsVariant {
     int kpc, h0c, h1c, g_big, njf;
     bool hasnum;
+    bool unf;                             // big fields as raw split-f16 rows, projected on the matrix pipe (k_rows_chain.h, UNF)
     const void* fn;
     const void* fn_many;
     const void* fn_one;
@@ -32,14 +33,17 @@ struct RowsVariant {
     RowsLaunchManyFn launch_many;
     int image_floats, ss, rb;
 };
-#define ROWS_VARIANT(KPC, H0C, H1C, G_BIG, NJF, HASNUM)                                                                          \
-    {KPC, H0C, H1C, G_BIG, NJF, HASNUM, reinterpret_cast<const void*>(&k_rows_chain<KPC, H0C, H1C, G_BIG, NJF, HASNUM, RC_WAVES>),   \
-     reinterpret_cast<const void*>(&k_rows_chain_many<KPC, H0C, H1C, G_BIG, NJF, HASNUM, RC_WAVES>),                               \
-     reinterpret_cast<const void*>(&k_rows_chain1<KPC, H0C, H1C, G_BIG, NJF, HASNUM, RC_WAVES>),                                   \
-     &rows_launch<KPC, H0C, H1C, G_BIG, NJF, HASNUM>, &rows_launch_one<KPC, H0C, H1C, G_BIG, NJF, HASNUM>,                         \
-     &rows_launch_many<KPC, H0C, H1C, G_BIG, NJF, HASNUM>,                                                                          \
-     RowsLds<KPC, H0C, H1C, HASNUM>::total_pad, RowsLds<KPC, H0C, H1C, HASNUM>::SS, RowsLds<KPC, H0C, H1C, HASNUM>::RB}
+#define ROWS_VARIANT_X(KPC, H0C, H1C, G_BIG, NJF, HASNUM, UNF)                                                                          \
+    {KPC, H0C, H1C, G_BIG, NJF, HASNUM, UNF, reinterpret_cast<const void*>(&k_rows_chain<KPC, H0C, H1C, G_BIG, NJF, HASNUM, RC_WAVES, UNF>),   \
+     reinterpret_cast<const void*>(&k_rows_chain_many<KPC, H0C, H1C, G_BIG, NJF, HASNUM, RC_WAVES, UNF>),                               \
+     reinterpret_cast<const void*>(&k_rows_chain1<KPC, H0C, H1C, G_BIG, NJF, HASNUM, RC_WAVES, UNF>),                                   \
+     &rows_launch<KPC, H0C, H1C, G_BIG, NJF, HASNUM, UNF>, &rows_launch_one<KPC, H0C, H1C, G_BIG, NJF, HASNUM, UNF>,                         \
+     &rows_launch_many<KPC, H0C, H1C, G_BIG, NJF, HASNUM, UNF>,                                                                          \
+     RowsLds<KPC, H0C, H1C, HASNUM, UNF>::total_pad, RowsLds<KPC, H0C, H1C, HASNUM, UNF>::SS, RowsLds<KPC, H0C, H1C, HASNUM, UNF>::RB}
+#define ROWS_VARIANT(KPC, H0C, H1C, G_BIG, NJF, HASNUM) ROWS_VARIANT_X(KPC, H0C, H1C, G_BIG, NJF, HASNUM, false)
 const RowsVariant kRowsVariants[] = {
+    ROWS_VARIANT_X(4, 2, 1, 2, 2, true, true),   // DeepFM_v2.py as written, big fields unfolded (raw split rows + MFMA projection)
+    ROWS_VARIANT_X(4, 2, 1, 2, 1, true, true), ROWS_VARIANT_X(4, 2, 1, 1, 1, true, true), ROWS_VARIANT_X(2, 2, 1, 2, 2, true, true),
     ROWS_VARIANT(4, 2, 1, 2, 2, true),     // DeepFM_v2.py as written: Dense(64) projections, deep 32-16, movieId + userId + two genre fields
     ROWS_VARIANT(4, 2, 1, 2, 1, true), ROWS_VARIANT(4, 2, 1, 1, 1, true), ROWS_VARIANT(4, 2, 1, 3, 3, true), ROWS_VARIANT(4, 2, 1, 3, 1, true),
     ROWS_VARIANT(2, 2, 1, 2, 2, true),     // projection width 32
@@ -47,10 +51,10 @@ const RowsVariant kRowsVariants[] = {
     ROWS_VARIANT(1, 2, 1, 3, 3, true),     // BASELINE config 2's shape on this kernel (A/B against k_deepfm_v2_joint: SPRK_V2_ROWS=1)
     ROWS_VARIANT(0, 1, 1, 2, 0, false),    // NeuralCF.py:45-53: two embedding columns -> Dense(10) -> Dense(10) -> Dense(1)
 };
-int find_rows_variant(int kpc, int h0c, int h1c, int g_big, int njf, bool hasnum) {
+int find_rows_variant(int kpc, int h0c, int h1c, int g_big, int njf, bool hasnum, bool unf = false) {
     for (size_t v = 0; v < sizeof(kRowsVariants) / sizeof(kRowsVariants[0]); ++v) {
         const RowsVariant& r = kRowsVariants[v];
-        if (r.kpc == kpc && r.h0c == h0c && r.h1c == h1c && r.g_big == g_big && r.njf == njf && r.hasnum == hasnum) return (int)v;
+        if (r.kpc == kpc && r.h0c == h0c && r.h1c == h1c && r.g_big == g_big && r.njf == njf && r.hasnum == hasnum && r.unf == unf) return (int)v;
     }
     return -1;
 }
@@ -87,9 +91,40 @@ int setup_rows_v2(sprk_engine* h) {
         else big[nbig++] = g;
     }
     if (nbig < 1 || nbig > RC_MAX_BIG) return SPRK_OK;
-    const int variant = find_rows_variant(KP / 16, H0 / 16, H1 / 16, nbig, nsm, true);
+    // UNF: the big fields' tables keep the raw embedding (16 padded values, split f16) and the projections run per task on the
+    // matrix pipe -- when the fold would multiply the bytes per row (emb_dim 10 -> 96 floats for DeepFM_v2.py as written)
+    int variant = -1;
+    float p_scale = 1.f;
+    if (h->tune.rows_unf && h->tune.dyn_f16 && nbig <= 2 && Dp <= 16 && KP + H0 > 16) {
+        const int vu = find_rows_variant(KP / 16, H0 / 16, H1 / 16, nbig, nsm, true, true);
+        if (vu >= 0) {
+            unsigned* d_max = nullptr;
+            HIP_TRY(hipMalloc((void**)&d_max, sizeof(unsigned)));
+            HIP_TRY(hipMemset(d_max, 0, sizeof(unsigned)));
+            for (int b = 0; b < nbig; ++b)
+                hipLaunchKernelGGL(k_v2_absmax, dim3(1024), dim3(256), 0, 0, a.table[big[b]], (long long)a.emb_vocab[big[b]] + 1, Dp, Dp, d_max);
+            unsigned bits = 0;
+            HIP_TRY(hipMemcpy(&bits, d_max, sizeof(bits), hipMemcpyDeviceToHost));
+            (void)hipFree(d_max);
+            float mx;
+            memcpy(&mx, &bits, sizeof(mx));
+            bool ok = mx < 3.0e38f;
+            for (int b = 0; ok && b < nbig; ++b) {
+                bool wide = false;
+                if (int rcw = wide_dynamic_range(a.table[big[b]], (long long)a.emb_vocab[big[b]] + 1, Dp, Dp, mx, &wide)) return rcw;
+                if (wide) ok = false;                              // an outlier row: its neighbours' lo halves would be subnormal
+            }
+            if (ok) {
+                int e = 0;
+                if (mx > 0.f) { (void)frexpf(mx, &e); e = 15 - e; if (e > 60) e = 60; if (e < -60) e = -60; p_scale = ldexpf(1.f, e); }
+                variant = vu;
+            }
+        }
+    }
+    if (variant < 0) variant = find_rows_variant(KP / 16, H0 / 16, H1 / 16, nbig, nsm, true);
     if (variant < 0) return SPRK_OK;
     const RowsVariant& rv = kRowsVariants[variant];
+    const bool unf = rv.unf;
     // first-order weights in embedding-group order (one ids column feeds both)
     const float* w1g[V2_MAX_FIELDS];
     for (int g = 0; g < G; ++g) {
@@ -130,8 +165,37 @@ int setup_rows_v2(sprk_engine* h) {
                            a.W0, d0.ldw, g * KP, H0, KP, (const float*)nullptr, w1g[g], a.hfm, a.n_hfm, a.h0w, out, out_stride, scal_out,
                            scal_out ? 0 : 1);
     };
-    for (int b = 0; b < nbig; ++b)
-        build(big[b], h->rows_tab + (size_t)r.big_rowbase[b] * (rv.rb / 4), rv.rb / 4, h->rows_scal + r.big_scal[b]);
+    // UNF: lin[b][d][n] = column d of {Wp^T | (Wp W0_b)^T} (the builder run on unit vectors without bias), cst[b][n] = {bp | W0_b^T bp}
+    std::vector<std::vector<float>> lin(nbig), cst(nbig);
+    for (int b = 0; b < nbig; ++b) {
+        if (!unf) {
+            build(big[b], h->rows_tab + (size_t)r.big_rowbase[b] * (rv.rb / 4), rv.rb / 4, h->rows_scal + r.big_scal[b]);
+            continue;
+        }
+        const int g = big[b];
+        const long long rows = (long long)a.emb_vocab[g] + 1;
+        build(g, nullptr, 0, h->rows_scal + r.big_scal[b]);                       // the per-id scalars only
+        long long nb = (rows * 16 + 255) / 256;
+        if (nb > 65536) nb = 65536;
+        hipLaunchKernelGGL(k_rows_unf_split, dim3((unsigned)nb), dim3(256), 0, 0, a.table[g], Dp, rows, p_scale,
+                           reinterpret_cast<_Float16*>(reinterpret_cast<char*>(h->rows_tab) + (size_t)r.big_rowbase[b] * 64));
+        std::vector<float> ident((size_t)(Dp + 1) * Dp, 0.f);
+        for (int d = 0; d < Dp; ++d) ident[(size_t)d * Dp + d] = 1.f;
+        float *d_id = nullptr, *d_out = nullptr;
+        const int W = KP + H0;
+        HIP_TRY(hipMalloc((void**)&d_id, ident.size() * sizeof(float)));
+        HIP_TRY(hipMalloc((void**)&d_out, (size_t)(Dp + 1) * W * sizeof(float)));
+        HIP_TRY(hipMemcpy(d_id, ident.data(), ident.size() * sizeof(float), hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(k_rows_build, dim3(4), dim3(256), 0, 0, (const float*)d_id, Dp, (long long)Dp, a.Wp[g], a.ldp_emb, (const float*)nullptr, KP,
+                           a.W0, d0.ldw, g * KP, H0, KP, (const float*)nullptr, (const float*)nullptr, a.hfm, 0, 0.f, d_out, W, (float*)nullptr, 0);
+        hipLaunchKernelGGL(k_rows_build, dim3(1), dim3(256), 0, 0, (const float*)(d_id + (size_t)Dp * Dp), Dp, 1ll, a.Wp[g], a.ldp_emb, a.bp[g], KP,
+                           a.W0, d0.ldw, g * KP, H0, KP, (const float*)nullptr, (const float*)nullptr, a.hfm, 0, 0.f, d_out + (size_t)Dp * W, W,
+                           (float*)nullptr, 0);
+        HIP_TRY(hipGetLastError());
+        int rcp;
+        if ((rcp = pull(lin[b], d_out, (size_t)Dp * W)) || (rcp = pull(cst[b], d_out + (size_t)Dp * W, W))) return rcp;
+        (void)hipFree(d_id); (void)hipFree(d_out);
+    }
     for (int f = 0; f < nsm; ++f) build(sm[f], h->rows_small + r.s_off[f], rv.ss, nullptr);
     HIP_TRY(hipGetLastError());
     // weight image (host): Wn, bn, M = W0[:, num block] Wn, c0 = b0 + W0[:, num block] bn, W1, b1, hfm, hd, fn
@@ -152,6 +216,8 @@ int setup_rows_v2(sprk_engine* h) {
     const int off_hfm = off; off += KP;
     const int off_hd = off; off += H1;
     const int off_fn = off; off += 8;
+    const int off_cp = off; if (unf) off += KP;
+    const int off_af = (off + 3) & ~3; if (unf) off = off_af + (KP + H0) / 16 * 2 * 256;
     if (off > rv.image_floats) return fail(SPRK_EINVAL, "rows image layout mismatch");
     for (int n = 0; n < KP; ++n) {
         for (int k = 0; k < a.n_num && k < 8; ++k) img[off_wn + n * SN + k] = Wn[(size_t)n * a.ldp_num + k];
@@ -175,6 +241,30 @@ int setup_rows_v2(sprk_engine* h) {
     for (int n = 0; n < a.n_hfm && n < KP; ++n) img[off_hfm + n] = hfm[n];
     for (int n = 0; n < a.n_hdeep && n < H1; ++n) img[off_hd + n] = hd[n];
     for (int k = 0; k < a.n_num && k < 8; ++k) img[off_fn + k] = a.h0w * fnw[k];
+    r.unscale = 1.f;
+    if (unf) {
+        const int W = KP + H0;
+        float amax = 0.f;
+        for (int b = 0; b < nbig; ++b) {
+            for (float v : lin[b]) amax = fmaxf(amax, fabsf(v));
+            for (int n = 0; n < KP; ++n) img[off_cp + n] += cst[b][n];
+            for (int m = 0; m < H0; ++m) img[off_c0 + m] += cst[b][KP + m];
+        }
+        if (!(amax < 3.0e38f)) return fail(SPRK_EINVAL, "non-finite projection weights");
+        float w_scale = 1.f;
+        { int e = 0; if (amax > 0.f) { (void)frexpf(amax, &e); e = 15 - e; if (e > 60) e = 60; if (e < -60) e = -60; w_scale = ldexpf(1.f, e); } }
+        _Float16* fh = reinterpret_cast<_Float16*>(&img[off_af]);
+        for (int nb = 0; nb < W / 16; ++nb)
+            for (int ln = 0; ln < 64; ++ln)
+                for (int e = 0; e < 8; ++e) {
+                    const int n = nb * 16 + (ln & 15), k = 8 * (ln >> 4) + e, b = k >> 4, d = k & 15;
+                    const float x = (b < nbig && d < Dp) ? lin[b][(size_t)d * W + n] * w_scale : 0.f;
+                    const _Float16 hi = (_Float16)x;
+                    fh[(size_t)(2 * nb) * 512 + ln * 8 + e] = hi;
+                    fh[(size_t)(2 * nb + 1) * 512 + ln * 8 + e] = (_Float16)(x - (float)hi);
+                }
+        r.unscale = 1.f / (p_scale * w_scale);
+    }
     r.rows = h->rows_tab; r.scal = h->rows_scal; r.small = h->rows_small; r.small_floats = (int)small_floats;
     r.bias = a.head_bias + a.h0w * a.fo_bias;
     if ((rc = rows_finish(h, rv, img, small_floats))) return rc;

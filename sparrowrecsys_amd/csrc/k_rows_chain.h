@@ -25,6 +25,17 @@
 //
 // Arithmetic: exact fp32 throughout (f32 MFMA + VALU); only the association differs from the reference's (a row's P and Q
 // are rounded once at finalize).
+//
+// UNF ("unfolded" big rows, round 3).  A row {P | Q} of the literal DeepFM_v2 is 96 floats = 384 bytes for an embedding of 10
+// floats: the fold trades bytes for flops, and PMC showed the strict launch moving 1.61x its algorithmic bytes at ~5 TB/s, i.e.
+// bound by the traffic the fold created.  With UNF the big fields' table holds the RAW embedding, pre-split into f16 hi / lo
+// halves with a static power-of-two scale (16 padded values: 32 + 32 bytes, ONE 64-byte row per id instead of six 64-byte
+// pieces), and {sum_f P_f | sum_f Q_f} = [A_0 | A_1] [E_0 ; E_1] is computed per task on the matrix pipe: the two big fields'
+// 16 values are the K = 32 of one v_mfma_f32_16x16x32_f16 (lane (r, q) gathers the 8 halfs k = 8q .. 8q+7 of sample r: field
+// q >> 1, half q & 1), the (KPC + H0C) static A fragments A = {Wp^T | (Wp W0_f)^T} (hi and lo) come out of the LDS image, three
+// products per 16 outputs (hi.hi + lo.hi + hi.lo: 22 significand bits), and the result lands in the very C/D layout the folded
+// rows were summed in.  The projections' biases move into constants (cP in the image, cQ folded into c0); per-id scalars are
+// unchanged.  Per sample: 2 x (64 + 4) bytes instead of 2 x (384 + 4).
 
 #define RC_MAX_BIG 3
 #define RC_MAX_SMALL 3
@@ -45,6 +56,7 @@ struct RowsRun {
     const float* small;                   // small fields' rows {P | Q | s | pad}, SS floats each (device image of the LDS block)
     float bias;                           // every constant term of the logit
     int flags;                            // 1 = ids/dense not 16-byte aligned: stage element-wise
+    float unscale;                        // UNF: 1 / (row scale * fragment scale)
 };
 struct RowsMany {                         // several batches per launch (sprk_set_many_batches), see V2JMany
     const int* ids[RC_MB];
@@ -53,11 +65,11 @@ struct RowsMany {                         // several batches per launch (sprk_se
     int n, ntpb;
 };
 
-template <int KPC, int H0C, int H1C, bool HASNUM>
+template <int KPC, int H0C, int H1C, bool HASNUM, bool UNF = false>
 struct RowsLds {
     static constexpr int KP = KPC * 16, H0 = H0C * 16, H1 = H1C * 16;
     static constexpr int SS = KP + H0 + 4;            // floats per small-field row ((SS / 4) odd: LDS banks)
-    static constexpr int RB = ((KP + H0) * 4 + 63) & ~63;   // bytes per big-field row
+    static constexpr int RB = UNF ? 64 : (((KP + H0) * 4 + 63) & ~63);   // bytes per big-field row (UNF: 16 hi + 16 lo halfs)
     static constexpr int SN = 12;                     // row stride of the K = 8 numeric matrices
     static constexpr int S1 = H0 + 4;                 // deep1 W^T row stride
     static constexpr int off_wn = 0;                  // Wn^T [KP][SN]           (HASNUM)
@@ -69,7 +81,9 @@ struct RowsLds {
     static constexpr int off_hfm = off_b1 + H1;       // [KP]
     static constexpr int off_hd = off_hfm + KP;       // [H1]
     static constexpr int off_fn = off_hd + H1;        // [8]
-    static constexpr int total = off_fn + 8;
+    static constexpr int off_cp = off_fn + 8;         // UNF: sum of the big fields' projection biases [KP]
+    static constexpr int off_af = (off_cp + (UNF ? KP : 0) + 3) & ~3;   // UNF: A fragments, (KPC + H0C) x {hi, lo} x 256 floats
+    static constexpr int total = off_af + (UNF ? (KPC + H0C) * 2 * 256 : 0);
     static constexpr int total_pad = (total + 255) & ~255;
     static constexpr int stage_floats = 256;          // per-wave ids / numerics slot
     static_assert((SS / 4) % 2 == 1, "small-row stride must be an odd number of 16-byte slots");
@@ -95,7 +109,7 @@ __global__ __launch_bounds__(256) void k_rows_build(const float* __restrict__ ta
         if (KP > 0) {
             if (n < KP) {
                 const float* w = Wp + (size_t)n * ldp;
-                p = bp[n];
+                p = bp ? bp[n] : 0.f;
                 for (int c = 0; c < row_floats; c += 16)
                     for (int s = 0; s < 4; ++s)
                         for (int q = 0; q < 4; ++q) {
@@ -109,9 +123,9 @@ __global__ __launch_bounds__(256) void k_rows_build(const float* __restrict__ ta
         sP[wv][n] = p;                                          // one wave: LDS operations complete in issue order
         float sqw = (KP > 0 && n < n_hfm && n < KP) ? hfm[n] * p * p : 0.f;
         for (int d = 32; d >= 1; d >>= 1) sqw += __shfl_xor(sqw, d);
-        float* o = out + v * out_stride;
-        if (n < KP) o[n] = p;
-        for (int m = n; m < H0; m += 64) {
+        float* o = out ? out + v * out_stride : nullptr;  // (out == NULL: scalars only -- the UNF tables hold raw rows)
+        if (o && n < KP) o[n] = p;
+        for (int m = n; o && m < H0; m += 64) {
             const float* w = W0t + (size_t)m * ld0 + col0;
             float acc = qbias ? qbias[m] : 0.f;
             for (int k = 0; k < nsrc; ++k) acc = fmaf(w[k], sP[wv][k], acc);
@@ -120,10 +134,31 @@ __global__ __launch_bounds__(256) void k_rows_build(const float* __restrict__ ta
         const float s = w1 ? h0w * w1[v] - sqw : 0.f;
         if (n == 0) {
             if (scal_out) scal_out[v] = s;
-            if (scal_in_row) o[KP + H0] = s;
+            if (o && scal_in_row) o[KP + H0] = s;
         }
     }
 }
+
+// UNF, one-time: raw embedding rows -> {16 hi halfs | 16 lo halfs} of E * scale (values beyond row_floats: 0)
+__global__ __launch_bounds__(256) void k_rows_unf_split(const float* __restrict__ table, int row_floats, long long rows, float scale,
+                                                        _Float16* __restrict__ out) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < rows * 16; i += (long long)gridDim.x * 256) {
+        const long long v = i >> 4;
+        const int k = (int)(i & 15);
+        const float x = k < row_floats ? table[v * row_floats + k] * scale : 0.f;
+        const _Float16 hi = (_Float16)x;
+        out[v * 32 + k] = hi;
+        out[v * 32 + 16 + k] = (_Float16)(x - (float)hi);
+    }
+}
+typedef _Float16 rows_f16x8 __attribute__((ext_vector_type(8)));
+template <int G_BIG, int KPC, int H0C>
+struct RowsSetUnf {
+    rows_f16x8 ehi, elo;                                  // this lane's 8 halfs of the K = 32 operand (field q >> 1, half q & 1)
+    int so[RC_MAX_SMALL];
+    float xa, xb;
+    float sc;
+};
 
 template <int G_BIG, int KPC, int H0C>
 struct RowsSet {
@@ -144,12 +179,13 @@ __device__ __forceinline__ float dot4_fma(f32x4 a, f32x4 b, float acc) {
 }
 
 // ONE: one task per wave, no loop -- the strict one-batch launch at up to four waves per SIMD (k_chain_v2j1.h has the measurements)
-template <int KPC, int H0C, int H1C, int G_BIG, int NJF, bool HASNUM, int WAVES, bool MB, bool ONE = false>
+template <int KPC, int H0C, int H1C, int G_BIG, int NJF, bool HASNUM, int WAVES, bool MB, bool ONE = false, bool UNF = false>
 __device__ __forceinline__ void rows_chain_body(const RowsRun& A, const int* __restrict__ ids, const float* __restrict__ dense,
                                                 float* __restrict__ out, int B, int* __restrict__ err,
                                                 const float* __restrict__ image, const RowsMany* __restrict__ Mp) {
-    using LD = RowsLds<KPC, H0C, H1C, HASNUM>;
-    using Set = RowsSet<G_BIG, KPC, H0C>;
+    using LD = RowsLds<KPC, H0C, H1C, HASNUM, UNF>;
+    using Set = typename std::conditional<UNF, RowsSetUnf<G_BIG, KPC, H0C>, RowsSet<G_BIG, KPC, H0C>>::type;
+    static_assert(!UNF || (G_BIG <= 2 && KPC > 0), "UNF: two big fields are one K = 32 block");
     constexpr int KP = LD::KP, H0 = LD::H0;
     constexpr unsigned RB = LD::RB;
     constexpr bool HASFM = KPC > 0;
@@ -230,6 +266,15 @@ __device__ __forceinline__ void rows_chain_body(const RowsRun& A, const int* __r
             S.xb = nrow[min(q + 4, last)];
         }
         const char* tb = reinterpret_cast<const char*>(A.rows);
+        if constexpr (UNF) {
+            // lane (r, q): field q >> 1 (a lane beyond the last field reads field 0's all-zero "no id" row), halfs 8 (q & 1) ..
+            unsigned sq = sid[0];
+            if (G_BIG > 1) sq = (q >> 1) ? sid[G_BIG > 1 ? 1 : 0] : sq;
+            else sq = (q >> 1) ? (unsigned)A.big_vocab[0] + A.big_rowbase[0] : sq;
+            const size_t ro = (size_t)sq * RB + 16u * (q & 1);
+            S.ehi = *reinterpret_cast<const rows_f16x8*>(tb + ro);
+            S.elo = *reinterpret_cast<const rows_f16x8*>(tb + ro + 32u);
+        } else {
 #pragma unroll
         for (int b = 0; b < G_BIG; ++b) {
             const size_t ro = (size_t)sid[b] * RB + 16u * q;
@@ -237,6 +282,7 @@ __device__ __forceinline__ void rows_chain_body(const RowsRun& A, const int* __r
             for (int nb = 0; nb < KPC; ++nb) S.xp[b][nb] = *reinterpret_cast<const f32x4*>(tb + ro + 64u * nb);
 #pragma unroll
             for (int n0 = 0; n0 < H0C; ++n0) S.xq[b][n0] = *reinterpret_cast<const f32x4*>(tb + ro + 4u * KP + 64u * n0);
+        }
         }
         if constexpr (HASFM) {
             // per-id logit terms of the big fields: lane (r,q) fetches big field q's scalar
@@ -306,18 +352,34 @@ __device__ __forceinline__ void rows_chain_body(const RowsRun& A, const int* __r
         if constexpr (HASFM) zz += (q < G_BIG) ? S.sc : 0.f;
         // field sums: big fields from the gathered registers, small fields from their LDS rows
         f32x4 s[HASFM ? KPC : 1];
+        f32x4 hq[H0C];
+        if constexpr (UNF) {
+            // {sum_f P_f | sum_f Q_f} = [A_0 | A_1] [E_0 ; E_1]: three split-f16 products per 16 outputs, fragments from the image
+            const float* af = smem + LD::off_af + 4 * lane;
+#pragma unroll
+            for (int nb = 0; nb < KPC + H0C; ++nb) {
+                const rows_f16x8 ahi = __builtin_bit_cast(rows_f16x8, ld4(af + (2 * nb) * 256));
+                const rows_f16x8 alo = __builtin_bit_cast(rows_f16x8, ld4(af + (2 * nb + 1) * 256));
+                f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(alo, S.ehi, zero, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, S.elo, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, S.ehi, acc, 0, 0, 0);
+                const f32x4 v = f32x4{acc.x * A.unscale, acc.y * A.unscale, acc.z * A.unscale, acc.w * A.unscale};
+                if (nb < KPC) s[nb < KPC ? nb : 0] = ld4(wq + LD::off_cp + (nb < KPC ? nb : 0) * 16) + v;
+                else hq[nb >= KPC ? nb - KPC : 0] = v;
+            }
+        } else {
 #pragma unroll
         for (int nb = 0; nb < KPC; ++nb) {
             s[nb] = S.xp[0][nb];
 #pragma unroll
             for (int b = 1; b < G_BIG; ++b) s[nb] += S.xp[b][nb];
         }
-        f32x4 hq[H0C];
 #pragma unroll
         for (int n0 = 0; n0 < H0C; ++n0) {
             hq[n0] = S.xq[0][n0];
 #pragma unroll
             for (int b = 1; b < G_BIG; ++b) hq[n0] += S.xq[b][n0];
+        }
         }
         float ssc = 0.f;
 #pragma unroll
@@ -388,7 +450,7 @@ __device__ __forceinline__ void rows_chain_body(const RowsRun& A, const int* __r
                 (const __attribute__((address_space(1))) void*)(A.small + c * 256 + lane * 4),
                 (__attribute__((address_space(3))) void*)(smem + LD::total_pad + WAVES * LD::stage_floats + c * 256), 16, 0, 0);
     }
-    constexpr int NG = G_BIG * (KPC + H0C) + (HASFM ? 1 : 0);        // VMEM loads per gather
+    constexpr int NG = (UNF ? 2 : G_BIG * (KPC + H0C)) + (HASFM ? 1 : 0);   // VMEM loads per gather
     // s_waitcnt vmcnt(NG), lgkmcnt / expcnt untouched: vmcnt is a 6-bit field split over bits [3:0] and [15:14]
     constexpr int WAIT_NG = 0x0F70 | (NG & 15) | ((NG >> 4) << 14);
     static_assert(NG < 64, "vmcnt field");
@@ -442,24 +504,24 @@ __device__ __forceinline__ void rows_chain_body(const RowsRun& A, const int* __r
     if (__ballot(bad) != 0 && lane == 0) atomicOr(err, 1);
 }
 
-template <int KPC, int H0C, int H1C, int G_BIG, int NJF, bool HASNUM, int WAVES>
+template <int KPC, int H0C, int H1C, int G_BIG, int NJF, bool HASNUM, int WAVES, bool UNF = false>
 __global__ __launch_bounds__(WAVES * 64, 2) void k_rows_chain(const RowsRun A, const int* __restrict__ ids,
                                                               const float* __restrict__ dense, float* __restrict__ out, int B,
                                                               int* __restrict__ err, const float* __restrict__ image) {
-    rows_chain_body<KPC, H0C, H1C, G_BIG, NJF, HASNUM, WAVES, false>(A, ids, dense, out, B, err, image, nullptr);
+    rows_chain_body<KPC, H0C, H1C, G_BIG, NJF, HASNUM, WAVES, false, false, UNF>(A, ids, dense, out, B, err, image, nullptr);
 }
 // one task per wave (strict one-batch launch): register budget of three waves per SIMD (one gather set instead of two)
-template <int KPC, int H0C, int H1C, int G_BIG, int NJF, bool HASNUM, int WAVES>
-__global__ __launch_bounds__(WAVES * 64, 3) void k_rows_chain1(const RowsRun A, const int* __restrict__ ids,
+template <int KPC, int H0C, int H1C, int G_BIG, int NJF, bool HASNUM, int WAVES, bool UNF = false>
+__global__ __launch_bounds__(WAVES * 64, UNF ? 4 : 3) void k_rows_chain1(const RowsRun A, const int* __restrict__ ids,
                                                                const float* __restrict__ dense, float* __restrict__ out, int B,
                                                                int* __restrict__ err, const float* __restrict__ image) {
-    rows_chain_body<KPC, H0C, H1C, G_BIG, NJF, HASNUM, WAVES, false, true>(A, ids, dense, out, B, err, image, nullptr);
+    rows_chain_body<KPC, H0C, H1C, G_BIG, NJF, HASNUM, WAVES, false, true, UNF>(A, ids, dense, out, B, err, image, nullptr);
 }
 // several batches per launch: the per-batch pointer table travels in the kernel arguments (the kernarg segment IS the
 // cheapest transport for 1.5 KB that change every launch: +0.05 us of host time per launch measured by
 // scripts/ubench/launch_floor.hip, no device-side cost); only this instantiation carries it
-template <int KPC, int H0C, int H1C, int G_BIG, int NJF, bool HASNUM, int WAVES>
+template <int KPC, int H0C, int H1C, int G_BIG, int NJF, bool HASNUM, int WAVES, bool UNF = false>
 __global__ __launch_bounds__(WAVES * 64, 2) void k_rows_chain_many(const RowsRun A, const RowsMany M, int B,
                                                                    int* __restrict__ err, const float* __restrict__ image) {
-    rows_chain_body<KPC, H0C, H1C, G_BIG, NJF, HASNUM, WAVES, true>(A, nullptr, nullptr, nullptr, B, err, image, &M);
+    rows_chain_body<KPC, H0C, H1C, G_BIG, NJF, HASNUM, WAVES, true, false, UNF>(A, nullptr, nullptr, nullptr, B, err, image, &M);
 }

@@ -150,3 +150,35 @@ def test_rows_chain_unaligned_views_and_every_tail_length(torch):
             eng.forward(ids_t[start:start + n], dense_t[start:start + n], out)     # row views: contiguous, not 16-byte aligned
             torch.cuda.synchronize()
             assert torch.equal(out, full[start:start + n]), (start, n)
+
+
+@pytest.mark.parametrize("fields,proj,emb", [(REF_FIELDS, 64, 10), (REF_FIELDS, 32, 16),
+                                             ([("movieId", "id", 5000), ("userGenre1", "genre", N_GENRES)], 64, 16)])
+def test_unfolded_big_rows_equal_the_folded_rows(torch, monkeypatch, fields, proj, emb):
+    """UNF (raw split-f16 rows of the big fields, projections on the matrix pipe: 64 bytes per id instead of 384) against the folded
+    {P | Q} rows (SPRK_ROWS_UNF=0, exact fp32) and the fp64 oracle: missing ids (the all-zero row), one and two big fields, every
+    launch form (one task per wave, the task loop, several batches per launch)."""
+    B = 40000
+    feats = SY.synth_fields(B, fields, seed=11, missing=0.15)
+    new = M.DeepFMv2(seed=29, emb_dim=emb, fields=fields, proj_dim=proj)
+    assert ",UNF>" in new.engine.describe()["kernel"], new.engine.describe()
+    p = new.predict(feats)[:, 0]
+    monkeypatch.setenv("SPRK_ROWS_UNF", "0")
+    old = M.DeepFMv2(seed=29, emb_dim=emb, fields=fields, proj_dim=proj)
+    assert "UNF" not in old.engine.describe()["kernel"]
+    q = old.predict(feats)[:, 0]
+    monkeypatch.delenv("SPRK_ROWS_UNF")
+    n = 8192
+    ref = _oracle_v2(new, {k: v[:n] for k, v in feats.items()})
+    assert np.abs(p - q).max() <= 3e-6 and np.abs(p[:n] - ref).max() <= TIGHT and p.std() > 0.02
+    assert new.engine.table_bytes() < old.engine.table_bytes()
+    # the looped kernel (a launch of more tasks than one-per-wave allows) and small launches give the same bits per row
+    ids, dense = new.pack(feats)
+    ti, td = torch.from_numpy(ids).cuda(), torch.from_numpy(dense).cuda()
+    full = new.predict_device(ti, td)
+    for lo, hi in ((0, 17), (5, 4101), (B - 33, B)):
+        assert torch.equal(new.predict_device(ti[lo:hi], td[lo:hi]), full[lo:hi]), (lo, hi)
+    big = {k: np.concatenate([v] * 8) for k, v in feats.items()}              # 320 000 rows: beyond V2J1_MAX_TASKS * 16
+    pb = new.predict(big)[:, 0]
+    np.testing.assert_array_equal(pb[:B], p)
+    np.testing.assert_array_equal(pb[-B:], p)
