@@ -751,6 +751,14 @@ def main():
         blk = float(t.item())
     R = int(max(1, min(math.ceil(args.min_region_ms * 1e-3 / max(blk, 1e-9)), max(1, 2_000_000 // max(K, 1)))))
     timer.region(R * K)                        # untimed: builds the region's prepared launch list, one more warm-up pass
+    # the K-step calibration block is ONE short launch list (K = 20 < 64 batches per launch) and reads slower per step than the
+    # region's full launches: correct R on the region's own time so that it really lasts >= --min-region-ms
+    for _ in range(3):
+        w_reg, _ = timer.region(R * K)         # (already the max over ranks: every rank takes the same decision)
+        if w_reg * 1e3 >= args.min_region_ms or R >= max(1, 2_000_000 // max(K, 1)):
+            break
+        R = int(min(math.ceil(R * args.min_region_ms * 1.08e-3 / max(w_reg, 1e-9)), max(1, 2_000_000 // max(K, 1))))
+        timer.region(R * K)                    # (builds the new list)
     # ---- timed regions ----
     walls, evs = [], []
     for _ in range(max(1, args.regions)):
