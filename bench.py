@@ -25,6 +25,7 @@ Workloads (BASELINE.json configs):
   deepfm_v2_c4 configs[3], one GPU's replica: DeepFM_v2 graph, emb_dim 64, tables of 138 493 users x 27 M rows (6.9 GB), B = 65 536
   deepfm_c4    configs[3] for the pairwise-dot graph: real 256-byte row gathers out of the 6.9 GB table
   widedeep_c5  configs[4], one GPU's share: Wide&Deep with the 10 M-bucket x 32 hashed cross table, B = 131 072
+  dien_ref     DIEN.py as written (hist_len 5, emb_dim 10): sequence stage k_dien_seq + the DIN tail
   deepfm_v2_ref / neuralcf_ref   the reference's own literal shapes (DeepFM_v2.py: 4 fields, emb_dim 10, Dense(64)
                projections; NeuralCF.py: 2 fields, emb_dim 10, 20->10->10->1) on MovieLens-20M-sized vocabularies
 """
@@ -182,6 +183,18 @@ def build_workload(name, B, dist_name, seed_offset=0, big_vocab=0, NB=8):
                 "bytes_per_sample": (T + 1) * 4 + (T + 1) * D * 4 + D * 4,
                 "tail_reference_flops": 2 * ((7 + 5 * D) * 128 + 128 * 64 + 64)}
         return model, feats, desc, roof
+    if name == "dien_ref":
+        # DIEN.py as written (RECENT_MOVIES = 5, EMBEDDING_SIZE = 10): GRU -> attention gate -> AUGRU (k_dien_seq, one lane per
+        # sample) -> the DIN tail; the sequence stage is priced like DIN's pooling: ids + (T + 1) rows + the pooled vector
+        T, D = 5, 10
+        model = M.DIEN(seed=117, emb_dim=D, hist_len=T, movie_buckets=SY.ML20M_MOVIE_IDS, user_buckets=SY.ML20M_USER_IDS)
+        desc = "DIEN.py literal: hist_len=5, emb_dim=10, GRU(10) -> attention 10->32->1 -> AUGRU, tail 57->128->64->1"
+        feats = [SY.synth_din(B, T, SY.ML20M_MOVIE_IDS, SY.ML20M_USER_IDS, seed=SY.SEED + 1000 * seed_offset + i, dist=dist_name) for i in range(NB)]
+        flops = T * (2 * 2 * D * 3 * D + 2 * D * 32 + 2 * 32 + 3 * (2 * 3 * D * D))      # GRU (x, h) + gate MLP + three AUGRU gates of 3 Dense each
+        roof = {"bound": "mfma", "kernel": "k_dien_seq", "hist_len": T, "flops_per_sample": flops, "executed_flops_per_sample": flops,
+                "bytes_per_sample": (T + 1) * 4 + (T + 1) * D * 4 + D * 4,
+                "tail_reference_flops": 2 * ((7 + 5 * D) * 128 + 128 * 64 + 64)}
+        return model, feats, desc, roof
     if name == "widedeep_c5":
         # BASELINE configs[4], one GPU's share: Wide&Deep, hashed cross (movieId x userRatedMovie1) computed on device into a
         # 10 M-bucket x 32 embedding table (1.28 GB), emb_dim 32, deep 128-128
@@ -234,6 +247,9 @@ def oracle_forward(name, model, feats, dtype=np.float32):
         return O.wide_n_deep_forward(feats, weights, dtype=dtype, movie_buckets=model.movie_buckets,
                                      user_buckets=model.user_buckets, cross_buckets=model.cross_buckets,
                                      rated_buckets=model.rated_buckets)
+    if name == "dien_ref":
+        return O.dien_forward(feats, weights, dtype=dtype, hist_len=model.hist_len,
+                              movie_buckets=model.movie_buckets, user_buckets=model.user_buckets)
     return O.din_forward(feats, weights, dtype=dtype, hist_len=model.hist_len,
                          movie_buckets=model.movie_buckets, user_buckets=model.user_buckets)
 
@@ -639,12 +655,12 @@ def main():
             dist.init_process_group("gloo")
 
     B = args.batch or {"din_c3": 32768, "widedeep_c5": 131072}.get(args.workload, 65536)
-    nb_in = args.input_batches or {"deepfm_v2_c2": 64, "deepfm_c2": 16, "din_c3": 16, "din_ref": 16}.get(args.workload, 8)
+    nb_in = args.input_batches or {"deepfm_v2_c2": 64, "deepfm_c2": 16, "din_c3": 16, "din_ref": 16, "dien_ref": 16}.get(args.workload, 8)
     if args.batch and args.batch > 262144:
         nb_in = min(nb_in, 8)
     model, feats, desc, roof = build_workload(args.workload, B, args.dist, seed_offset=rank, big_vocab=args.big_vocab, NB=nb_in)
     eng = model.engine
-    is_din = args.workload in ("din_c3", "din_ref")
+    is_din = args.workload in ("din_c3", "din_ref", "dien_ref")
     roof["kernel"] = eng.kernel_name() if not is_din else roof["kernel"]   # what the handle really dispatches to
     env = os.environ.get
     lb = 1
@@ -653,7 +669,7 @@ def main():
             lb = args.launch_batches
         elif roof["kernel"] == "k_deepfm_pairs":
             lb = min(args.launch_batches, 16)
-        elif is_din and env("SPRK_DIN_LEGACY") != "1" and env("SPRK_DIN_TAIL") != "0" and eng.kernel_name() == "k_din_tail":
+        elif is_din and args.workload != "dien_ref" and env("SPRK_DIN_LEGACY") != "1" and env("SPRK_DIN_TAIL") != "0" and eng.kernel_name() == "k_din_tail":
             lb = min(args.launch_batches, 16)   # groups of batches: one attention + one tail launch each, alternating streams
     if lb > 1:
         eng.set_many_batches(lb)
@@ -866,7 +882,9 @@ def main():
                       "frac": achieved * 1e9 / HBM_PEAK,
                       "reference_flops_per_sample": roof["flops_per_sample"],
                       "reference_equivalent_TFLOPs": roof["flops_per_sample"] * B / din_s / 1e12}
-                extra["roofline_mfma"] = mfma_block(roof["kernel"], mfma_issued(roof["kernel"], roof["flops_per_sample"], hist_len=roof["hist_len"]), B, din_s)
+                mi_att = mfma_issued(roof["kernel"], roof["flops_per_sample"], hist_len=roof["hist_len"])
+                if mi_att:                                        # (k_dien_seq runs on the VALU: nothing to report)
+                    extra["roofline_mfma"] = mfma_block(roof["kernel"], mi_att, B, din_s)
                 if eng.kernel_name() == "k_din_tail":
                     extra["roofline_mfma_tail"] = mfma_block("k_din_tail", mfma_issued("k_din_tail", roof["tail_reference_flops"]), B,
                                                              max(fwd_s - din_s, 1e-9))

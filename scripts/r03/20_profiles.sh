@@ -22,8 +22,9 @@ WL[ncf_ref]="--steps 400 --warmup 40 --workload neuralcf_ref"
 WL[deepfm_ref]="--steps 400 --warmup 40 --workload deepfm_ref"
 WL[din_ref]="--steps 100 --warmup 10 --workload din_ref"
 WL[embedding_mlp_ref]="--steps 200 --warmup 20 --workload embedding_mlp_ref"
+WL[dien_ref]="--steps 100 --warmup 10 --workload dien_ref"
 cd /tmp && export TMPDIR=/tmp
-for w in c2 c2_hbm c2_pairs c3 c4_v2 c4_pairs c5 v2_ref ncf_ref deepfm_ref din_ref embedding_mlp_ref; do
+for w in c2 c2_hbm c2_pairs c3 c4_v2 c4_pairs c5 v2_ref ncf_ref deepfm_ref din_ref embedding_mlp_ref dien_ref; do
   timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_$w -o t -- python $R/bench.py ${WL[$w]} $STRICT > $O/${w}_strict.log 2>&1
   grep '^{"metric"' $O/${w}_strict.log | tail -1 > $O/${w}_strict_bench.json
   f=$(find $O/trace_$w -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/${w}_strict_kernel_stats.csv

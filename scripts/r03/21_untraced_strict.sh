@@ -19,7 +19,8 @@ WL[ncf_ref]="--steps 400 --warmup 40 --workload neuralcf_ref"
 WL[deepfm_ref]="--steps 400 --warmup 40 --workload deepfm_ref"
 WL[din_ref]="--steps 100 --warmup 10 --workload din_ref"
 WL[embedding_mlp_ref]="--steps 200 --warmup 20 --workload embedding_mlp_ref"
-for w in c2 c2_hbm c2_pairs c3 c4_v2 c4_pairs c5 v2_ref ncf_ref deepfm_ref din_ref embedding_mlp_ref; do
+WL[dien_ref]="--steps 100 --warmup 10 --workload dien_ref"
+for w in c2 c2_hbm c2_pairs c3 c4_v2 c4_pairs c5 v2_ref ncf_ref deepfm_ref din_ref embedding_mlp_ref dien_ref; do
   timeout 400 python bench.py ${WL[$w]} $STRICT 2>/dev/null | grep '^{"metric"' | tail -1 > $O/${w}_strict_untraced.json
   python -c "
 import json,sys

@@ -23,8 +23,8 @@ HBM_PEAK = 8.0e12
 # workload tag -> (the kernel whose launches ARE the steps, substring of its rocprof name)
 DOMINANT = {"c2": "k_deepfm_v2_joint1", "c2_hbm": "k_deepfm_v2_joint1", "c2_pairs": "k_deepfm_pairs1", "c3": "k_din_attn_cols",
             "c4_v2": "k_deepfm_v2_joint1", "c4_pairs": "k_deepfm_pairs<", "c5": "k_mlp_rows", "v2_ref": "k_rows_chain1", "ncf_ref": "k_rows_chain1",
-            "deepfm_ref": "k_deepfm_pairs1", "din_ref": "k_din_attn_cols", "embedding_mlp_ref": "k_mlp_rows"}
-ORDER = ["c2", "c2_hbm", "c2_pairs", "c3", "c4_v2", "c4_pairs", "c5", "v2_ref", "ncf_ref", "deepfm_ref", "din_ref", "embedding_mlp_ref"]
+            "deepfm_ref": "k_deepfm_pairs1", "din_ref": "k_din_attn_cols", "embedding_mlp_ref": "k_mlp_rows", "dien_ref": "k_dien_seq"}
+ORDER = ["c2", "c2_hbm", "c2_pairs", "c3", "c4_v2", "c4_pairs", "c5", "v2_ref", "ncf_ref", "deepfm_ref", "din_ref", "embedding_mlp_ref", "dien_ref"]
 
 
 def kernel_rows(path):
