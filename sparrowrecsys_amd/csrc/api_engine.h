@@ -151,6 +151,24 @@ int sprk_finalize(sprk_handle h) {
         h->dien_run.Dp = s.row_stride; h->dien_run.vocab = s.vocab; h->dien_run.NA = p.n_aux;
         h->dien_run.table = d.table;
         h->dien_run.image = (const float*)h->slot_ptr[s.seq_slot];
+        if (h->tune.dien_mfma && h->tune.dyn_f16 && s.hidden == 32 && (s.emb_dim == 10 || s.emb_dim == 16)) {
+            // sixteen samples per wave on the matrix pipe (k_dien_mfma.h): the host's packed image -> split-f16 MFMA A fragments with
+            // static scales from max|E| and the weights' row sums; non-finite weights keep the lane-per-sample kernel
+            const size_t fl = s.emb_dim == 10 ? DienFrag<10, 32>::total_pad : DienFrag<16, 32>::total_pad;
+            const size_t ok_at = s.emb_dim == 10 ? DienFrag<10, 32>::S_OK : DienFrag<16, 32>::S_OK;
+            unsigned* d_max = nullptr;
+            HIP_TRY(hipMalloc((void**)&d_max, sizeof(unsigned)));
+            HIP_TRY(hipMemset(d_max, 0, sizeof(unsigned)));
+            hipLaunchKernelGGL(k_v2_absmax, dim3(1024), dim3(256), 0, 0, d.table, (long long)s.vocab, s.row_stride, s.row_stride, d_max);
+            HIP_TRY(hipMalloc((void**)&h->dien_frag, fl * sizeof(float)));
+            if (s.emb_dim == 10) hipLaunchKernelGGL((k_dien_mfma_pack<10, 32>), dim3(1), dim3(256), 0, 0, h->dien_run.image, (const unsigned*)d_max, h->dien_frag);
+            else hipLaunchKernelGGL((k_dien_mfma_pack<16, 32>), dim3(1), dim3(256), 0, 0, h->dien_run.image, (const unsigned*)d_max, h->dien_frag);
+            HIP_TRY(hipGetLastError());
+            float ok = 0.f;
+            HIP_TRY(hipMemcpy(&ok, h->dien_frag + ok_at, sizeof(float), hipMemcpyDeviceToHost));
+            (void)hipFree(d_max);
+            if (ok != 1.f) { (void)hipFree(h->dien_frag); h->dien_frag = nullptr; }
+        }
     } else if (p.din.enabled) {
         const sprk_din& s = p.din;
         DevDin& d = dp->din;

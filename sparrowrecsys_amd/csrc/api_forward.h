@@ -31,6 +31,20 @@ static int launch_din_cols(sprk_handle h, const int32_t* ids, float* pooled, flo
 static int launch_din(sprk_handle h, const int32_t* ids, float* pooled, float* att, int32_t B, hipStream_t st) {
     if (h->plan.din.enabled == 2) {                               // DIEN: GRU -> attention gate -> AUGRU, one lane per sample
         if (att) return fail(SPRK_EINVAL, "DIEN stage has no attention output");
+        if (h->dien_frag) {
+            DienRun run = h->dien_run;
+            run.image = h->dien_frag;
+            const int ntiles = (B + 15) / 16;
+            int gridm = (ntiles + DM_WAVES - 1) / DM_WAVES;
+            if (gridm > h->num_cus * 8) gridm = h->num_cus * 8;
+            const size_t lds10 = DienFrag<10, 32>::total_pad * sizeof(float), lds16 = DienFrag<16, 32>::total_pad * sizeof(float);
+            if (h->plan.din.emb_dim == 10)
+                hipLaunchKernelGGL((k_dien_seq_mfma<10, 32>), dim3(gridm), dim3(DM_WAVES * 64), lds10, st, run, ids, pooled, B, h->dev_err);
+            else
+                hipLaunchKernelGGL((k_dien_seq_mfma<16, 32>), dim3(gridm), dim3(DM_WAVES * 64), lds16, st, run, ids, pooled, B, h->dev_err);
+            HIP_TRY(hipGetLastError());
+            return SPRK_OK;
+        }
         int grid = (B + 63) / 64;
         if (grid > h->num_cus * 8) grid = h->num_cus * 8;
         if (h->plan.din.emb_dim == 10)
@@ -414,7 +428,7 @@ int sprk_describe(sprk_handle h, char* buf, size_t buf_bytes) {
         snprintf(kern, sizeof(kern), "k_tile_forward");
     }
     const char* stage = "";
-    if (h->plan.din.enabled == 2) stage = "k_dien_seq";
+    if (h->plan.din.enabled == 2) stage = h->dien_frag ? "k_dien_seq_mfma" : "k_dien_seq";
     else if (h->plan.din.enabled == 1) stage = h->din_variant >= 0 ? "k_din_attn" : "k_din_pool";
     size_t uploaded = 0;
     for (size_t b : h->slot_bytes) uploaded += b;
@@ -468,6 +482,7 @@ void sprk_destroy(sprk_handle h) {
     if (h->v2j_big) (void)hipFree(h->v2j_big);
     if (h->v2j1_image) (void)hipFree(h->v2j1_image);
     if (h->din_frag) (void)hipFree(h->din_frag);
+    if (h->dien_frag) (void)hipFree(h->dien_frag);
     if (h->rows_tab) (void)hipFree(h->rows_tab);
     if (h->rows_scal) (void)hipFree(h->rows_scal);
     if (h->rows_small) (void)hipFree(h->rows_small);

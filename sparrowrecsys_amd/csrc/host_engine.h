@@ -48,6 +48,7 @@ struct sprk_engine {
     // wave-per-sample attention kernel (k_din_attn); -1 = the generic k_din_pool
     int din_variant = -1;
     DienRun dien_run{};
+    float* dien_frag = nullptr;          // k_dien_seq_mfma's fragment image (NULL: the lane-per-sample kernel)
     DinRun din_run;
     float* din_w12 = nullptr;      // (W1+W2)^T, W4^T fragments and the per-id c-term table (device)
     float* din_w4 = nullptr;

@@ -980,6 +980,39 @@ def test_dien_vs_oracle(torch, monkeypatch, D, T, B, holes):
     assert np.abs(out["1"][1] - out["0"][1]).max() <= TIGHT
 
 
+@pytest.mark.parametrize("D,T,B", [(10, 5, 65536 + 5), (16, 7, 4099), (10, 3, 15)])
+def test_dien_matrix_pipe_stage_equals_the_lane_per_sample_stage(torch, monkeypatch, D, T, B):
+    """k_dien_seq_mfma (16 samples per wave, every Dense of the recurrence as four f32 MFMAs) against k_dien_seq (one lane per
+    sample, SPRK_DIEN_MFMA=0): same fp32 arithmetic, another association -- the AUGRU state within 2e-6, masked slots, ragged
+    tile, bad ids flagged by both."""
+    V, U = 3000, 900
+    feats = SY.synth_din(B, T, V, U, seed=41 + T)
+    h = feats["userRatedMovies"]
+    h[np.random.default_rng(T).random(h.shape) < 0.25] = 0
+    h[0] = 0
+    out = {}
+    for sw in ("1", "0"):
+        monkeypatch.setenv("SPRK_DIEN_MFMA", sw)
+        model = M.DIEN(seed=63, emb_dim=D, hist_len=T, movie_buckets=V, user_buckets=U)
+        assert model.engine.describe()["stage"] == ("k_dien_seq_mfma" if sw == "1" else "k_dien_seq")
+        ids, dense = model.pack(feats)
+        aux = torch.full((B, model.engine.n_aux), float("nan"), dtype=torch.float32, device="cuda")
+        model.engine.din_pool(_cuda(torch, ids), aux, None)
+        model.engine.check_ids()
+        out[sw] = (aux.cpu().numpy(), model.predict(feats)[:, 0])
+        bad = ids.copy()
+        bad[B // 2, 2] = V                                           # a history id outside the table
+        model.engine.din_pool(_cuda(torch, bad), aux, None)
+        with pytest.raises(ValueError):
+            model.engine.check_ids()
+    assert np.abs(out["1"][0] - out["0"][0]).max() <= 2e-6 and not out["1"][0][:, D:].any()
+    assert np.abs(out["1"][1] - out["0"][1]).max() <= 2e-6 and out["1"][1].std() > 0.005
+    n = min(B, 4096)
+    ref, parts = O.dien_forward({k: v[:n] for k, v in feats.items()}, model.weights, dtype=np.float64, hist_len=T, movie_buckets=V,
+                                user_buckets=U, return_parts=True)
+    assert np.abs(out["1"][0][:n, :D] - parts["augru"]).max() <= TIGHT
+
+
 def test_dien_reference_schema_and_bad_ids(torch, samples):
     model = M.DIEN(seed=6)
     got = model.predict(samples)[:, 0]
