@@ -191,10 +191,11 @@ int setup_rows_v2(sprk_engine* h) {
         hipLaunchKernelGGL(k_rows_build, dim3(1), dim3(256), 0, 0, (const float*)(d_id + (size_t)Dp * Dp), Dp, 1ll, a.Wp[g], a.ldp_emb, a.bp[g], KP,
                            a.W0, d0.ldw, g * KP, H0, KP, (const float*)nullptr, (const float*)nullptr, a.hfm, 0, 0.f, d_out + (size_t)Dp * W, W,
                            (float*)nullptr, 0);
-        HIP_TRY(hipGetLastError());
-        int rcp;
-        if ((rcp = pull(lin[b], d_out, (size_t)Dp * W)) || (rcp = pull(cst[b], d_out + (size_t)Dp * W, W))) return rcp;
+        int rcp = hipGetLastError() == hipSuccess ? SPRK_OK : fail(SPRK_EHIP, "rows chain: projection probe launch failed");
+        if (!rcp) rcp = pull(lin[b], d_out, (size_t)Dp * W);
+        if (!rcp) rcp = pull(cst[b], d_out + (size_t)Dp * W, W);
         (void)hipFree(d_id); (void)hipFree(d_out);
+        if (rcp) return rcp;
     }
     for (int f = 0; f < nsm; ++f) build(sm[f], h->rows_small + r.s_off[f], rv.ss, nullptr);
     HIP_TRY(hipGetLastError());
