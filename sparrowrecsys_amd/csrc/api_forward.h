@@ -164,8 +164,9 @@ int sprk_forward(sprk_handle h, const int32_t* ids, const float* dense, float* o
     }
     if (h->din_tail_variant >= 0) {
         const int ntasks = (B + 15) / 16;
-        int grid = (ntasks + DT_WAVES - 1) / DT_WAVES;
-        if (grid > h->num_cus) grid = h->num_cus;                  // one 8-wave workgroup per CU (2 waves per SIMD)
+        const int tw = h->din_tail_run.e_unscale != 0.f ? DT_WAVES_UNF : DT_WAVES;
+        int grid = (ntasks + tw - 1) / tw;
+        if (grid > h->num_cus) grid = h->num_cus;                  // one workgroup per CU (8 waves, or 16 with raw embedding rows)
         kDinTailVariants[h->din_tail_variant].launch(h->din_tail_run, ids, dense, aux, out, B, h->dev_err, h->din_tail_image, grid, st);
         HIP_TRY(hipGetLastError());
         return SPRK_OK;
@@ -323,7 +324,8 @@ static int forward_many_impl(sprk_handle h, int32_t n_batches, const int32_t* co
                     for (int j = 0; j < n; ++j)
                         av.launch(h->din_run, tm.ids[j], const_cast<float*>(tm.aux[j]), nullptr, B, h->dev_err, ag, h->din_attn_lds, st);
                 }
-                long long tg = ((long long)n * ntpb + DT_WAVES - 1) / DT_WAVES;
+                const int tw = h->din_tail_run.e_unscale != 0.f ? DT_WAVES_UNF : DT_WAVES;
+                long long tg = ((long long)n * ntpb + tw - 1) / tw;
                 if (tg > h->num_cus) tg = h->num_cus;
                 tv.launch_many(h->din_tail_run, tm, B, h->dev_err, h->din_tail_image, (int)tg, st);
                 HIP_TRY(hipGetLastError());
@@ -423,7 +425,7 @@ int sprk_describe(sprk_handle h, char* buf, size_t buf_bytes) {
         snprintf(kern, sizeof(kern), "k_mlp_rows<8,8,NBIG=%d,NSMALL=%d>", h->mlp_rows_nbig, h->mlp_rows_run.n_small);
     } else if (h->din_tail_variant >= 0) {
         const DinTailVariant& tv = kDinTailVariants[h->din_tail_variant];
-        snprintf(kern, sizeof(kern), "k_din_tail<%d,%d,%d>", tv.n0c, tv.n1c, tv.kpc);
+        snprintf(kern, sizeof(kern), "k_din_tail<%d,%d,%d%s>", tv.n0c, tv.n1c, tv.kpc, h->din_tail_run.e_unscale != 0.f ? ",UNF" : "");
     } else {
         snprintf(kern, sizeof(kern), "k_tile_forward");
     }

@@ -65,7 +65,7 @@ __device__ __forceinline__ void dyn_scale(float m, float inv_w_scale, float& sca
 // One-time (finalize) kernel: W^T [N][ld] (K columns) * w_scale -> A fragments of v_mfma_f32_16x16x32_f16 in the
 // K-block layout above.  out: for (n block nb, K block b): [hi: 16 rows x 4 q x 8 halfs][lo: same] = 2 x 1 KB.
 __global__ __launch_bounds__(256) void k_dyn_pack_w(const float* __restrict__ W, int ld, int N, int K, float w_scale,
-                                                    _Float16* __restrict__ out) {
+                                                    _Float16* __restrict__ out, int kvalid) {
     const int KB = K / 32;
     const int total = (N / 16) * KB * 2 * 512;                           // halfs
     for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
@@ -73,7 +73,7 @@ __global__ __launch_bounds__(256) void k_dyn_pack_w(const float* __restrict__ W,
         const int nb = blk / KB, b = blk - nb * KB;
         const int n = nb * 16 + rr;
         const int kl = e < 4 ? 4 * qq + e : 16 + 4 * qq + (e - 4);
-        const float x = W[(size_t)n * ld + 32 * b + kl] * w_scale;
+        const float x = 32 * b + kl < kvalid ? W[(size_t)n * ld + 32 * b + kl] * w_scale : 0.f;   // (columns beyond kvalid: padding of the K block)
         const _Float16 hi = (_Float16)x;
         out[i] = hl ? (_Float16)(x - (float)hi) : hi;
     }

@@ -68,6 +68,8 @@ struct SprkTuning {
     bool v2_xflags_set = false;       // SPRK_V2_XFLAGS=n           experiment bits handed to the kernel in V2Run::flags
     int v2_xflags = 0;
     bool rows_one = true;             // SPRK_ROWS_ONE=0            k_rows_chain: looped kernel for one-batch launches too
+    bool tail_unf = true;             // SPRK_TAIL_UNF=0            k_din_tail: folded 512-byte rows for the embedding columns even when emb_dim <= 16
+    bool tail_pooled_f16 = true;      // SPRK_TAIL_POOLED_F16=0     k_din_tail: the pooled-history columns of fc0 on f32 MFMA (round 2) instead of split f16
     bool dien_mfma = true;            // SPRK_DIEN_MFMA=0           DIEN sequence stage: one lane per sample (k_dien_seq) instead of 16 samples per MFMA tile
     bool rows_unf = true;             // SPRK_ROWS_UNF=0            k_rows_chain: folded {P | Q} rows for the big fields even when raw rows are 6x smaller
     bool ncf_chain = true;            // SPRK_NCF_CHAIN=0           NeuralCF on the interpreter
@@ -98,7 +100,7 @@ struct SprkTuning {
         { const char* w = getenv("SPRK_V2_WGS_PER_CU"); t.v2_wgs_per_cu = (w && w[0] >= '1' && w[0] <= '9') ? w[0] - '0' : 0; }
         t.v2_grid_cap = num("SPRK_V2_GRID_CAP", 0);
         t.v2_xflags_set = getenv("SPRK_V2_XFLAGS") != nullptr; t.v2_xflags = num("SPRK_V2_XFLAGS", 0);
-        t.rows_one = !off("SPRK_ROWS_ONE"); t.rows_unf = !off("SPRK_ROWS_UNF"); t.dien_mfma = !off("SPRK_DIEN_MFMA"); t.ncf_chain = !off("SPRK_NCF_CHAIN"); t.tile_fold = !off("SPRK_TILE_FOLD");
+        t.rows_one = !off("SPRK_ROWS_ONE"); t.rows_unf = !off("SPRK_ROWS_UNF"); t.dien_mfma = !off("SPRK_DIEN_MFMA"); t.tail_pooled_f16 = !off("SPRK_TAIL_POOLED_F16"); t.tail_unf = !off("SPRK_TAIL_UNF"); t.ncf_chain = !off("SPRK_NCF_CHAIN"); t.tile_fold = !off("SPRK_TILE_FOLD");
         t.half_range_guard = !off("SPRK_HALF_RANGE_GUARD"); t.dyn_f16 = !off("SPRK_DYN_F16");
         t.v1_chain = !off("SPRK_V1_CHAIN"); t.v1_static_scale = !off("SPRK_V1_STATIC_SCALE"); t.v1_rowtab = !off("SPRK_V1_ROWTAB");
         t.v1_one = !off("SPRK_V1_ONE");

@@ -172,13 +172,15 @@ int wide_dynamic_range(const float* rows, long long nrows, int row_floats, int n
 // A Dense layer's W^T [N][ld] (K columns) as split-f16 A fragments for the per-sample dynamic-scale path (dyn_split.h):
 // static power-of-two scale putting max |W| in [2^14, 2^15).  *frag stays NULL when switched off (SPRK_DYN_F16=0), when
 // the shape does not tile (N % 16, K % 32) or the weights are not finite.
-int make_dyn_fragments(sprk_engine* h, const float* W, int ld, int N, int K, float** frag, float* w_scale_out) {
+// kvalid >= 0: only the first kvalid columns of W^T's rows belong to the matrix (the K block is padded with zeros up to K)
+int make_dyn_fragments(sprk_engine* h, const float* W, int ld, int N, int K, float** frag, float* w_scale_out, int kvalid = -1) {
     *frag = nullptr;
-    if (!h->tune.dyn_f16 || (N & 15) || (K & 31)) return SPRK_OK;
+    if (kvalid < 0) kvalid = K;
+    if (!h->tune.dyn_f16 || (N & 15) || (K & 31) || kvalid < 1 || kvalid > K) return SPRK_OK;
     unsigned* d_max = nullptr;
     HIP_TRY(hipMalloc((void**)&d_max, sizeof(unsigned)));
     HIP_TRY(hipMemset(d_max, 0, sizeof(unsigned)));
-    hipLaunchKernelGGL(k_v2_absmax, dim3(8), dim3(256), 0, 0, W, (long long)N, ld, K, d_max);
+    hipLaunchKernelGGL(k_v2_absmax, dim3(8), dim3(256), 0, 0, W, (long long)N, ld, kvalid, d_max);
     unsigned bits = 0;
     HIP_TRY(hipMemcpy(&bits, d_max, sizeof(bits), hipMemcpyDeviceToHost));
     (void)hipFree(d_max);
@@ -186,7 +188,7 @@ int make_dyn_fragments(sprk_engine* h, const float* W, int ld, int N, int K, flo
     memcpy(&mx, &bits, sizeof(mx));
     if (!(mx < 3.0e38f)) return SPRK_OK;
     bool wide = false;
-    if (int rcw = wide_dynamic_range(W, (long long)N, ld, K, mx, &wide)) return rcw;
+    if (int rcw = wide_dynamic_range(W, (long long)N, ld, kvalid, mx, &wide)) return rcw;
     if (wide) return SPRK_OK;
     int e = 0;
     float w_scale = 1.f;
@@ -195,7 +197,7 @@ int make_dyn_fragments(sprk_engine* h, const float* W, int ld, int N, int K, flo
     float* f = nullptr;
     HIP_TRY(hipMalloc((void**)&f, frag_floats * sizeof(float)));
     h->fold_bufs.push_back(f);
-    hipLaunchKernelGGL(k_dyn_pack_w, dim3(32), dim3(256), 0, 0, W, ld, N, K, w_scale, reinterpret_cast<_Float16*>(f));
+    hipLaunchKernelGGL(k_dyn_pack_w, dim3(32), dim3(256), 0, 0, W, ld, N, K, w_scale, reinterpret_cast<_Float16*>(f), kvalid);
     HIP_TRY(hipGetLastError());
     *frag = f;
     *w_scale_out = w_scale;

@@ -2,16 +2,20 @@
 // Part of sparrow_hip.hip (one translation unit); included there, not compilable on its own.
 // ---- dispatch table for k_din_tail<N0C, N1C, KPC, WAVES> ----
 constexpr int DT_WAVES = 8;
+constexpr int DT_WAVES_UNF = 16;       // UNF: 146 -> <= 128 VGPRs, sixteen waves per CU: at B = 65 536 every wave has ONE task
 typedef void (*DinTailLaunchFn)(const DinTailRun&, const int*, const float*, const float*, float*, int, int*, const float*, int, hipStream_t);
 typedef void (*DinTailLaunchManyFn)(const DinTailRun&, const DinTailMany&, int, int*, const float*, int, hipStream_t);
 typedef void (*DinTailPackFn)(const float*, int, int, int, int, int, const float*, const float*, const float*, int, const float*,
-                              const float*, const float*, int, const float*, float*);
+                              const float*, const float*, int, const float*, float*, const float*, const float*);
 template <int N0C, int N1C, int KPC>
 void din_tail_launch(const DinTailRun& a, const int* ids, const float* dense, const float* aux, float* out, int B, int* err,
                      const float* image, int grid, hipStream_t st) {
     const size_t lds = DinTailLds<N0C, N1C, KPC>::bytes;
     static const DinTailMany none{};
-    if (a.inv_w1_scale != 0.f)
+    if (a.e_unscale != 0.f)
+        hipLaunchKernelGGL((k_din_tail<N0C, N1C, KPC, DT_WAVES_UNF, true, false, true>), dim3(grid), dim3(DT_WAVES_UNF * 64), lds, st,
+                           a, ids, dense, aux, out, B, err, image, none);
+    else if (a.inv_w1_scale != 0.f)
         hipLaunchKernelGGL((k_din_tail<N0C, N1C, KPC, DT_WAVES, true, false>), dim3(grid), dim3(DT_WAVES * 64), lds, st,
                            a, ids, dense, aux, out, B, err, image, none);
     else
@@ -21,7 +25,10 @@ void din_tail_launch(const DinTailRun& a, const int* ids, const float* dense, co
 template <int N0C, int N1C, int KPC>
 void din_tail_launch_many(const DinTailRun& a, const DinTailMany& m, int B, int* err, const float* image, int grid, hipStream_t st) {
     const size_t lds = DinTailLds<N0C, N1C, KPC>::bytes;
-    if (a.inv_w1_scale != 0.f)
+    if (a.e_unscale != 0.f)
+        hipLaunchKernelGGL((k_din_tail<N0C, N1C, KPC, DT_WAVES_UNF, true, true, true>), dim3(grid), dim3(DT_WAVES_UNF * 64), lds, st,
+                           a, (const int*)nullptr, (const float*)nullptr, (const float*)nullptr, (float*)nullptr, B, err, image, m);
+    else if (a.inv_w1_scale != 0.f)
         hipLaunchKernelGGL((k_din_tail<N0C, N1C, KPC, DT_WAVES, true, true>), dim3(grid), dim3(DT_WAVES * 64), lds, st,
                            a, (const int*)nullptr, (const float*)nullptr, (const float*)nullptr, (float*)nullptr, B, err, image, m);
     else
@@ -31,13 +38,13 @@ void din_tail_launch_many(const DinTailRun& a, const DinTailMany& m, int B, int*
 template <int N0C, int N1C, int KPC>
 void din_tail_pack(const float* W0, int ldw0, int p_off, int Dp, int n_off, int n_num, const float* b0, const float* a0,
                    const float* W1, int ldw1, const float* b1, const float* a1, const float* hw, int n_hw, const float* w1frag,
-                   float* img) {
+                   float* img, const float* w0pfrag, const float* w0efrag) {
     hipLaunchKernelGGL((k_din_tail_pack<N0C, N1C, KPC>), dim3(1), dim3(256), 0, 0, W0, ldw0, p_off, Dp, n_off, n_num, b0, a0, W1, ldw1,
-                       b1, a1, hw, n_hw, w1frag, img);
+                       b1, a1, hw, n_hw, w1frag, img, w0pfrag, w0efrag);
 }
 struct DinTailVariant {
     int n0c, n1c, kpc;
-    const void* fn[4];                // [DYN][MB] instantiations
+    const void* fn[6];                // [DYN][MB] instantiations, then UNF [MB]
     size_t lds_bytes;
     DinTailLaunchFn launch;
     DinTailLaunchManyFn launch_many;
@@ -46,7 +53,9 @@ struct DinTailVariant {
 #define DIN_TAIL_VARIANT(N0C, N1C, KPC) {N0C, N1C, KPC, {reinterpret_cast<const void*>(&k_din_tail<N0C, N1C, KPC, DT_WAVES, false, false>), \
                                          reinterpret_cast<const void*>(&k_din_tail<N0C, N1C, KPC, DT_WAVES, false, true>),               \
                                          reinterpret_cast<const void*>(&k_din_tail<N0C, N1C, KPC, DT_WAVES, true, false>),               \
-                                         reinterpret_cast<const void*>(&k_din_tail<N0C, N1C, KPC, DT_WAVES, true, true>)},               \
+                                         reinterpret_cast<const void*>(&k_din_tail<N0C, N1C, KPC, DT_WAVES, true, true>),                \
+                                         reinterpret_cast<const void*>(&k_din_tail<N0C, N1C, KPC, DT_WAVES_UNF, true, false, true>),     \
+                                         reinterpret_cast<const void*>(&k_din_tail<N0C, N1C, KPC, DT_WAVES_UNF, true, true, true>)},     \
                                          DinTailLds<N0C, N1C, KPC>::bytes, &din_tail_launch<N0C, N1C, KPC>, &din_tail_launch_many<N0C, N1C, KPC>, \
                                          &din_tail_pack<N0C, N1C, KPC>}
 const DinTailVariant kDinTailVariants[] = {
@@ -101,10 +110,106 @@ int setup_din_tail(sprk_engine* h, DevPlan* dp) {
         if (rc2) return rc2;
         if (w1frag) r.inv_w1_scale = 1.0f / w_scale;
     }
-    tv.pack(o0.W, o0.ldw, p_off, Dp, n_off, n_num, o0.bias, o0.alpha, o1.W, o1.ldw, o1.bias, o1.alpha, tp.w, tp.len, w1frag, h->din_tail_image);
+    // [r3] DYN: fc0's pooled-history columns W0^T[:, p_off .. p_off + Dp) as split-f16 fragments (K block padded with zeros)
+    float* w0pfrag = nullptr;
+    if (w1frag && h->tune.tail_pooled_f16) {
+        float w_scale = 0.f;
+        const int rc3 = make_dyn_fragments(h, o0.W + p_off, o0.ldw, o0.N, 32 * ((kpc + 1) / 2), &w0pfrag, &w_scale, Dp);
+        if (rc3) return rc3;
+        if (w0pfrag) r.inv_w0p_scale = 1.0f / w_scale;
+    }
+    // [r3] UNF: raw split rows of the embedding columns + fc0's columns for them as fragments (k_din_tail.h, DinTailRun::Etab)
+    float* w0efrag = nullptr;
+    if (w1frag && w0pfrag && h->tune.tail_unf && p.ops[0].kind == SPRK_OP_DENSE && p.ops[0].w_slot >= 0) {
+        const sprk_op& q0 = p.ops[0];                              // the ORIGINAL first Dense (o0.W has the folded columns zeroed)
+        const float* W0full = (const float*)h->slot_ptr[q0.w_slot];
+        const sprk_seg* raw[DT_MAX_COLS] = {nullptr, nullptr, nullptr, nullptr};
+        bool ok = true;
+        for (int g = 0; g < dp->n_acc && ok; ++g) {
+            const DevSeg& sg = dp->segs[n_plain + g];
+            for (int i = 0; i < p.n_segs; ++i)
+                if (p.segs[i].kind == SPRK_SEG_ROWS && p.segs[i].field == h->idc[sg.field] && p.segs[i].vocab == sg.vocab &&   // (DevSeg::field is the compact index)
+                    p.segs[i].dst >= q0.src_off && p.segs[i].dst + 4 * p.segs[i].count <= q0.src_off + q0.K) { raw[g] = &p.segs[i]; break; }
+            ok = raw[g] && 4 * raw[g]->count <= 16 && raw[g]->row_stride <= 16;
+            for (int g2 = 0; g2 < g && ok; ++g2) ok = raw[g2] != raw[g];
+        }
+        // one static scale for all columns' rows; an outlier row keeps the folded tables
+        float mx = 0.f;
+        if (ok) {
+            unsigned* d_max = nullptr;
+            HIP_TRY(hipMalloc((void**)&d_max, sizeof(unsigned)));
+            HIP_TRY(hipMemset(d_max, 0, sizeof(unsigned)));
+            for (int g = 0; g < dp->n_acc; ++g)
+                hipLaunchKernelGGL(k_v2_absmax, dim3(256), dim3(256), 0, 0, (const float*)h->slot_ptr[raw[g]->slot], (long long)raw[g]->vocab,
+                                   raw[g]->row_stride, 4 * raw[g]->count, d_max);
+            unsigned bits = 0;
+            HIP_TRY(hipMemcpy(&bits, d_max, sizeof(bits), hipMemcpyDeviceToHost));
+            (void)hipFree(d_max);
+            memcpy(&mx, &bits, sizeof(mx));
+            ok = mx < 3.0e38f;
+            for (int g = 0; g < dp->n_acc && ok; ++g) {
+                bool wide = false;
+                if (int rcw = wide_dynamic_range((const float*)h->slot_ptr[raw[g]->slot], (long long)raw[g]->vocab, raw[g]->row_stride,
+                                                 4 * raw[g]->count, mx, &wide)) return rcw;
+                ok = !wide;
+            }
+        }
+        if (ok) {
+            auto pow2_scale = [](float m, int top) { int e = 0; if (m > 0.f) { (void)frexpf(m, &e); e = top - e; } e = e > 60 ? 60 : (e < -60 ? -60 : e); return ldexpf(1.f, e); };
+            const float e_scale = pow2_scale(mx, 15);
+            std::vector<float> W0h;
+            int rcp = pull(W0h, W0full, (size_t)q0.N * q0.ldw);
+            if (rcp) return rcp;
+            float amax = 0.f;
+            for (int g = 0; g < dp->n_acc; ++g)
+                for (int n = 0; n < q0.N; ++n)
+                    for (int d = 0; d < 4 * raw[g]->count; ++d) amax = fmaxf(amax, fabsf(W0h[(size_t)n * q0.ldw + raw[g]->dst - q0.src_off + d]));
+            ok = amax < 3.0e38f;
+            if (ok) {
+                const float w_scale = pow2_scale(amax, 15);
+                std::vector<float> fr((size_t)n0c * 2 * 512, 0.f);
+                _Float16* fh = reinterpret_cast<_Float16*>(fr.data());
+                for (int nb = 0; nb < n0c; ++nb)
+                    for (int pb = 0; pb < 2; ++pb)
+                        for (int ln = 0; ln < 64; ++ln)
+                            for (int e = 0; e < 8; ++e) {
+                                const int n = nb * 16 + (ln & 15), k = 8 * (ln >> 4) + e, g = 2 * pb + (k >> 4), d = k & 15;
+                                float x = 0.f;
+                                if (g < dp->n_acc && d < 4 * raw[g]->count) x = W0h[(size_t)n * q0.ldw + raw[g]->dst - q0.src_off + d] * w_scale;
+                                const _Float16 hi = (_Float16)x;
+                                const size_t base = (size_t)((nb * 2 + pb) * 2) * 512;
+                                fh[base + ln * 8 + e] = hi;
+                                fh[base + 512 + ln * 8 + e] = (_Float16)(x - (float)hi);
+                            }
+                HIP_TRY(hipMalloc((void**)&w0efrag, fr.size() * sizeof(float)));
+                h->fold_bufs.push_back(w0efrag);
+                HIP_TRY(hipMemcpy(w0efrag, fr.data(), fr.size() * sizeof(float), hipMemcpyHostToDevice));
+                for (int g = 0; g < DT_MAX_COLS; ++g) r.Etab[g] = nullptr;
+                for (int g = 0; g < dp->n_acc; ++g) {
+                    const long long rows = (long long)raw[g]->vocab;
+                    float* et = nullptr;
+                    HIP_TRY(hipMalloc((void**)&et, (size_t)(rows + 1) * 64));
+                    HIP_TRY(hipMemset(et, 0, (size_t)(rows + 1) * 64));
+                    h->fold_bufs.push_back(et);
+                    h->derived_bytes += (size_t)(rows + 1) * 64;
+                    long long nbk = (rows * 16 + 255) / 256;
+                    if (nbk > 65536) nbk = 65536;
+                    if (nbk > 0)
+                        hipLaunchKernelGGL(k_rows_unf_split, dim3((unsigned)nbk), dim3(256), 0, 0, (const float*)h->slot_ptr[raw[g]->slot], raw[g]->row_stride,
+                                           rows, e_scale, reinterpret_cast<_Float16*>(et));
+                    r.Etab[g] = reinterpret_cast<const _Float16*>(et);
+                }
+                for (int g = dp->n_acc; g < DT_MAX_COLS; ++g) r.Etab[g] = r.Etab[0];
+                HIP_TRY(hipGetLastError());
+                r.e_unscale = 1.f / (e_scale * w_scale);
+            }
+        }
+    }
+    tv.pack(o0.W, o0.ldw, p_off, Dp, n_off, n_num, o0.bias, o0.alpha, o1.W, o1.ldw, o1.bias, o1.alpha, tp.w, tp.len, w1frag, h->din_tail_image, w0pfrag,
+            w0efrag);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
-    for (int i = 0; i < 4; ++i) HIP_TRY(hipFuncSetAttribute(tv.fn[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)tv.lds_bytes));
+    for (int i = 0; i < 6; ++i) HIP_TRY(hipFuncSetAttribute(tv.fn[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)tv.lds_bytes));
     h->din_tail_variant = variant;
     return SPRK_OK;
 }

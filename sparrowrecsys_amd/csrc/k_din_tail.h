@@ -27,6 +27,14 @@ struct DinTailRun {
     int n_num;                            // numerics used (<= 8)
     float head_bias;
     float inv_w1_scale;                   // DYN: 1 / (static power-of-two scale of fc1's split weights)
+    float inv_w0p_scale;                  // DYN: 1 / (scale of fc0's pooled-history columns as split-f16 fragments); 0 = f32 MFMA
+    // UNF ([r3], emb_dim <= 16): the embedding columns are NOT folded through fc0 -- a folded row is N0 = 128 floats for an embedding
+    // of 10, and one task gathered 32 pieces of 16 bytes per lane in two dependent rounds (k_din_tail took 21 us per 65 536 samples
+    // of DIN.py's shape, twice the attention stage).  Etab[g] holds column g's RAW rows, 16 padded values pre-split into f16
+    // hi | lo with a static scale (64 bytes per id, an all-zero row at index vocab); columns (0, 1) and (2, 3) are the two K = 32
+    // operands of fc0's embedding part: lane (r, q) gathers 16 + 16 bytes of column 2 pb + (q >> 1), half q & 1, per block.
+    const _Float16* Etab[DT_MAX_COLS];
+    float e_unscale;                      // 1 / (row scale * fragment scale); 0 = folded rows
 };
 
 // Multi-batch launch (sprk_set_many_batches): launch task t is task t % ntpb of batch t / ntpb, every batch with its own
@@ -56,7 +64,15 @@ struct DinTailLds {
     static constexpr int off_b1 = off_a0 + N0;        // [N1]
     static constexpr int off_a1 = off_b1 + N1;        // [N1]
     static constexpr int off_hw = off_a1 + N1;        // [N1]
-    static constexpr int total = off_hw + N1;
+    // [r3] fc0's pooled-history columns as split-f16 fragments (N0C x ceil(KPC / 2) blocks of 2 KB): v_mfma_f32_16x16x4_f32 takes 32
+    // cycles and holds up the SIMD's VALU issue while it runs (measured on the DIEN stage, k_dien_mfma.h); the pooled chunk(s) cost
+    // 4 * KPC * N0C of them per task, the f16 form 3 * N0C * ceil(KPC / 2) of 16 cycles
+    static constexpr int KB0 = (KPC + 1) / 2;
+    static constexpr int w0h_floats = N0C * KB0 * 512;
+    static constexpr int off_w0h = (off_hw + N1 + 3) & ~3;
+    static constexpr int w0e_floats = N0C * 2 * 512;  // UNF: fc0's embedding columns, N0C x 2 blocks of {hi, lo} fragments
+    static constexpr int off_w0e = off_w0h + w0h_floats;
+    static constexpr int total = off_w0e + w0e_floats;
     static constexpr int total_pad = (total + 255) & ~255;
     static constexpr size_t bytes = sizeof(float) * total_pad;
 };
@@ -68,9 +84,12 @@ __global__ __launch_bounds__(256) void k_din_tail_pack(const float* __restrict__
                                                        int n_num, const float* __restrict__ b0, const float* __restrict__ a0,
                                                        const float* __restrict__ W1, int ldw1, const float* __restrict__ b1,
                                                        const float* __restrict__ a1, const float* __restrict__ hw, int n_hw,
-                                                       const float* __restrict__ w1frag, float* __restrict__ img) {
+                                                       const float* __restrict__ w1frag, float* __restrict__ img,
+                                                       const float* __restrict__ w0pfrag, const float* __restrict__ w0efrag) {
     using LD = DinTailLds<N0C, N1C, KPC>;
     const int tid = threadIdx.x;
+    for (int i = tid; i < LD::w0h_floats; i += 256) img[LD::off_w0h + i] = w0pfrag ? w0pfrag[i] : 0.f;
+    for (int i = tid; i < LD::w0e_floats; i += 256) img[LD::off_w0e + i] = w0efrag ? w0efrag[i] : 0.f;
     for (int i = tid; i < LD::N0 * LD::S0; i += 256) {
         const int n = i / LD::S0, k = i - n * LD::S0;
         float v = 0.f;
@@ -95,8 +114,8 @@ __global__ __launch_bounds__(256) void k_din_tail_pack(const float* __restrict__
     for (int i = LD::total + tid; i < LD::total_pad; i += 256) img[i] = 0.f;
 }
 
-template <int N0C, int N1C, int KPC, int WAVES, bool DYN, bool MB = false>
-__global__ __launch_bounds__(WAVES * 64, 2) void k_din_tail(const DinTailRun A, const int* __restrict__ ids0,
+template <int N0C, int N1C, int KPC, int WAVES, bool DYN, bool MB = false, bool UNF = false>
+__global__ __launch_bounds__(WAVES * 64, WAVES >= 16 ? 4 : 2) void k_din_tail(const DinTailRun A, const int* __restrict__ ids0,
                                                             const float* __restrict__ dense0, const float* __restrict__ aux0,
                                                             float* __restrict__ out0, int B, int* __restrict__ err,
                                                             const float* __restrict__ image, const DinTailMany M) {
@@ -150,22 +169,52 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_din_tail(const DinTailRun A, 
         float* out = MB ? M.out[bi] : out0;
         const int m = min(tl * 16 + r, B - 1);
         // ---- per-sample operands: pooled history (aux) and numerics, in B-operand layout ----
-        f32x4 xp[KPC], xn;
+        f32x4 xp[KPC];
+        float xna, xnb;                                           // numerics q and q + 4 of this sample: K = 8 is two steps, k = q + 4 s
 #pragma unroll
         for (int c = 0; c < KPC; ++c) xp[c] = (16 * c + 4 * q < A.NA) ? ld4(aux + (size_t)m * A.NA + 16 * c + 4 * q) : zero;
         {
             const float* nrow = dense + (size_t)m * A.ND;
             const int last = A.n_num - 1;
             // slots beyond n_num hold a duplicate finite value that only ever meets zero weights
-            xn.x = nrow[min(4 * q + 0, last)];
-            xn.y = nrow[min(4 * q + 1, last)];
-            xn.z = nrow[min(4 * q + 2, last)];
-            xn.w = nrow[min(4 * q + 3, last)];
+            xna = nrow[min(q, last)];
+            xnb = nrow[min(q + 4, last)];
         }
         // ---- folded embedding columns gathered straight into fc0's accumulators ----
         f32x4 z0[N0C];
 #pragma unroll
         for (int nb = 0; nb < N0C; ++nb) z0[nb] = ld4(smem + LD::off_b0 + nb * 16 + 4 * q);
+        if constexpr (UNF) {
+            static_assert(DYN && DT_MAX_COLS == 4, "two K = 32 blocks of two columns");
+            din_f16x8 eh[2], el[2];
+#pragma unroll
+            for (int pb = 0; pb < 2; ++pb) {
+                // (static indices only: a lane-dependent index into the kernel argument's arrays would move them to scratch)
+                const bool up = (q >> 1) != 0;
+                const int id = up ? idv[2 * pb + 1] : idv[2 * pb];
+                const bool have = 2 * pb + (up ? 1 : 0) < A.n_cols;
+                int voc = up ? A.vocab[2 * pb + 1] : A.vocab[2 * pb];
+                const _Float16* tab = up ? A.Etab[2 * pb + 1] : A.Etab[2 * pb];
+                if (!have) { voc = A.vocab[0]; tab = A.Etab[0]; }           // an absent column: column 0's all-zero row
+                const bool ok = have && (unsigned)id < (unsigned)voc;
+                bad |= have && !ok && id != -1;
+                const char* row = reinterpret_cast<const char*>(tab) + (size_t)(ok ? id : voc) * 64 + 16 * (q & 1);
+                eh[pb] = *reinterpret_cast<const din_f16x8*>(row);           // (a missing id / an absent column: the all-zero row)
+                el[pb] = *reinterpret_cast<const din_f16x8*>(row + 32);
+            }
+            const float* wf = smem + LD::off_w0e + 4 * lane;
+#pragma unroll
+            for (int pb = 0; pb < 2; ++pb)
+#pragma unroll
+                for (int nb = 0; nb < N0C; ++nb) {
+                    const din_f16x8 ah = __builtin_bit_cast(din_f16x8, ld4(wf + ((nb * 2 + pb) * 2 + 0) * 256));
+                    const din_f16x8 al = __builtin_bit_cast(din_f16x8, ld4(wf + ((nb * 2 + pb) * 2 + 1) * 256));
+                    f32x4 acc = mfma_f16(al, eh[pb], zero);
+                    acc = mfma_f16(ah, el[pb], acc);
+                    acc = mfma_f16(ah, eh[pb], acc);
+                    z0[nb] += acc * A.e_unscale;
+                }
+        } else {
 #pragma unroll
         for (int g0 = 0; g0 < DT_MAX_COLS; g0 += 2) {             // two columns = 2*N0C loads in flight at a time
             f32x4 f[2][N0C];
@@ -183,24 +232,57 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_din_tail(const DinTailRun A, 
 #pragma unroll
                 for (int nb = 0; nb < N0C; ++nb) z0[nb] += f[g][nb];
         }
+        }
         if (tk + task_stride < ntasks) ld_ids(tk + task_stride);   // next task's ids fly under this task's MFMAs
 
         // ---- fc0's per-sample part: pooled chunks, then the numeric chunk (N0C independent chains) ----
         const float* w0r = smem + LD::off_w0 + r * LD::S0 + 4 * q;
+        {
+            // the numeric chunk: A = W0^T[n][numeric q + 4 s] (two scalar LDS reads per block), two MFMAs per 16 outputs
+            const float* wn = smem + LD::off_w0 + r * LD::S0 + KPC * 16 + q;
 #pragma unroll
-        for (int c = 0; c <= KPC; ++c) {
-            const f32x4 b = c < KPC ? xp[c < KPC ? c : 0] : xn;
-            f32x4 a[N0C];
+            for (int nb = 0; nb < N0C; ++nb) z0[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wn[nb * 16 * LD::S0], xna, z0[nb], 0, 0, 0);
 #pragma unroll
-            for (int nb = 0; nb < N0C; ++nb) {
-                a[nb] = ld4(w0r + nb * 16 * LD::S0 + 16 * c);
-                if (c == KPC && q >= 2) a[nb] = zero;             // the numeric chunk is 8 wide: k = 4q + s < 8
+            for (int nb = 0; nb < N0C; ++nb) z0[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wn[nb * 16 * LD::S0 + 4], xnb, z0[nb], 0, 0, 0);
+        }
+        if (UNF || (DYN && A.inv_w0p_scale != 0.f)) {             // (wave-uniform; UNF is only set up together with the pooled fragments)
+            // pooled history on the f16 pipe: per-sample dynamic scale (DIN's attention weights are not normalised), hi / lo split
+            float mx = 0.f;
+#pragma unroll
+            for (int c = 0; c < KPC; ++c)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) mx = fmaxf(mx, __builtin_fabsf(xp[c][j]));
+            mx = rows4_max(mx);
+            float scale, inv;
+            dyn_scale(mx, A.inv_w0p_scale, scale, inv);
+            const float* wf = smem + LD::off_w0h + (r * 4 + q) * 4;
+#pragma unroll
+            for (int b = 0; b < LD::KB0; ++b) {
+                din_f16x8 bh, bl;
+                dyn_split8(xp[2 * b], 2 * b + 1 < KPC ? xp[2 * b + 1 < KPC ? 2 * b + 1 : 0] : zero, scale, bh, bl);
+#pragma unroll
+                for (int nb = 0; nb < N0C; ++nb) {
+                    const din_f16x8 ah = __builtin_bit_cast(din_f16x8, ld4(wf + ((nb * LD::KB0 + b) * 2 + 0) * 256));
+                    const din_f16x8 al = __builtin_bit_cast(din_f16x8, ld4(wf + ((nb * LD::KB0 + b) * 2 + 1) * 256));
+                    f32x4 acc = mfma_f16(al, bh, zero);
+                    acc = mfma_f16(ah, bl, acc);
+                    acc = mfma_f16(ah, bh, acc);
+                    z0[nb] += acc * inv;
+                }
             }
+        } else {
 #pragma unroll
-            for (int st = 0; st < 4; ++st)
+            for (int c = 0; c < KPC; ++c) {
+                const f32x4 b = xp[c];
+                f32x4 a[N0C];
 #pragma unroll
-                for (int nb = 0; nb < N0C; ++nb)
-                    z0[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[nb][st], b[st], z0[nb], 0, 0, 0);
+                for (int nb = 0; nb < N0C; ++nb) a[nb] = ld4(w0r + nb * 16 * LD::S0 + 16 * c);
+#pragma unroll
+                for (int st = 0; st < 4; ++st)
+#pragma unroll
+                    for (int nb = 0; nb < N0C; ++nb)
+                        z0[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[nb][st], b[st], z0[nb], 0, 0, 0);
+            }
         }
         // PReLU(alpha0) (DIN.py:164)
 #pragma unroll

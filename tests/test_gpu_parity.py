@@ -1013,6 +1013,38 @@ def test_dien_matrix_pipe_stage_equals_the_lane_per_sample_stage(torch, monkeypa
     assert np.abs(out["1"][0][:n, :D] - parts["augru"]).max() <= TIGHT
 
 
+@pytest.mark.parametrize("kind,D,T", [("din", 10, 5), ("din", 16, 12), ("dien", 10, 5)])
+def test_tail_with_raw_embedding_rows_equals_the_folded_tail(torch, monkeypatch, kind, D, T):
+    """k_din_tail UNF (emb_dim <= 16: the embedding columns as raw split-f16 rows, fc0's share of them on the matrix pipe) against
+    the folded 512-byte rows (SPRK_TAIL_UNF=0) and the oracle: missing genre ids, ragged batch, several batches per launch."""
+    V, U, B = 3000, 900, 20011
+    feats = SY.synth_din(B, T, V, U, seed=77 + T)
+    feats["userGenre1"][::7] = -1                                   # no id: the all-zero row
+    out = {}
+    for sw in ("1", "0"):
+        monkeypatch.setenv("SPRK_TAIL_UNF", sw)
+        cls = M.DIN if kind == "din" else M.DIEN
+        model = cls(seed=71, emb_dim=D, hist_len=T, movie_buckets=V, user_buckets=U)
+        k = model.engine.describe()["kernel"]
+        assert k.startswith("k_din_tail<") and (",UNF>" in k) == (sw == "1"), k
+        out[sw] = model.predict(feats)[:, 0]
+        if sw == "1":
+            ids, dense = model.pack(feats)
+            ti, td = _cuda(torch, ids), _cuda(torch, dense)
+            full = model.predict_device(ti, td)
+            assert torch.equal(model.predict_device(ti[5:1029], td[5:1029]), full[5:1029])
+            bad = dict(feats)
+            bad["userId"] = feats["userId"].copy()
+            bad["userId"][11] = U                                    # outside userId's buckets
+            with pytest.raises(ValueError):
+                model.predict(bad)
+            np.testing.assert_array_equal(model.predict(feats)[:, 0], out[sw])
+    fwd = O.din_forward if kind == "din" else O.dien_forward
+    n = 4096
+    ref = fwd({k: v[:n] for k, v in feats.items()}, model.weights, dtype=np.float64, hist_len=T, movie_buckets=V, user_buckets=U)[:, 0]
+    assert np.abs(out["1"] - out["0"]).max() <= 3e-6 and np.abs(out["1"][:n] - ref).max() <= TOL and out["1"].std() > 0.005
+
+
 def test_dien_reference_schema_and_bad_ids(torch, samples):
     model = M.DIEN(seed=6)
     got = model.predict(samples)[:, 0]
