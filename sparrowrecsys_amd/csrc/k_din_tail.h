@@ -11,8 +11,10 @@
 // rows are gathered straight into the accumulators (16-byte pieces), fc0's remaining contraction, PReLU,
 // fc1 (K = 128: its B operand IS h1's registers), PReLU, the output dot and the sigmoid all stay in
 // registers.  Weights sit in LDS (pre-packed image, LDS-DMA), read as A fragments right before use.
-// fc0's per-sample part (raw numerics, pooled history) runs on f32 MFMA; fc1 runs on the f16 matrix pipe with a
-// per-sample DYNAMIC power-of-two scale of its input (dyn_split.h), since hidden activations have data-dependent range.
+// fc0's numerics (K = 8: two steps, k = q + 4 s) run on f32 MFMA; fc1 and, since round 3, fc0's pooled-history columns run on the
+// f16 matrix pipe with a per-sample DYNAMIC power-of-two scale of their input (dyn_split.h): hidden activations and DIN's pooled
+// history have data-dependent range.  Round 3 also added UNF (DinTailRun::Etab below): for emb_dim <= 16 the embedding columns are
+// NOT folded -- raw split-f16 rows, two K = 32 blocks on the matrix pipe, sixteen waves per workgroup.
 // The interpreter ran this tail as a chain of memory round trips at one tile per workgroup (28 us at
 // B = 32 768); here every load of a task is in flight at once.
 
