@@ -83,3 +83,54 @@ def test_dien_reference_schema(samples):
     np.testing.assert_allclose(got, ref, atol=2e-7)
     f32 = O.dien_forward(samples, model.weights, dtype=np.float32)[:, 0]
     assert np.abs(f32 - ref).max() < 1e-5
+
+
+def test_keras_stand_in_gru_matches_torch_gru_and_the_mask_rule():
+    """oracle/keras_shim.py's GRU layer -- the one DIEN.py:169 runs on when the reference's lines are executed without TensorFlow --
+    against torch.nn.GRU (an independent implementation of the same recurrence) on an unmasked batch, and against the oracle's
+    restatement of Keras' mask-consuming step (state kept, previous output repeated) on a batch with holes."""
+    import torch
+    from oracle import keras_shim as KS
+    D, T, B, V = 10, 6, 29, 40
+    rng = np.random.default_rng(5)
+    tf = KS.build_module()
+    ids = tf.keras.layers.Input(name="h", shape=(T,), dtype="float32")
+    emb_layer = tf.keras.layers.Embedding(input_dim=V, output_dim=D, mask_zero=True)
+    emb = emb_layer(ids)
+    gru_layer = tf.keras.layers.GRU(D, return_sequences=True)
+    out = gru_layer(emb)
+    model = tf.keras.Model(inputs={"h": ids}, outputs=out)
+    table = rng.normal(0, 0.5, (V, D)).astype(np.float32)
+    K, U, b = (rng.normal(0, 0.4, s).astype(np.float32) for s in ((D, 3 * D), (D, 3 * D), (2, 3 * D)))
+    emb_layer.set_weights([table])
+    gru_layer.set_weights([K, U, b])
+    assert [v.name for v in gru_layer.weights] == ["gru/gru_cell/kernel:0", "gru/gru_cell/recurrent_kernel:0", "gru/gru_cell/bias:0"]
+    # (1) no masked slot: torch.nn.GRU with the gates permuted z|r|h -> r|z|n
+    h = rng.integers(1, V, (B, T))
+    got = model.predict({"h": h.astype(np.float32)})
+    gru = torch.nn.GRU(D, D, batch_first=True).double()
+    perm = np.r_[D:2 * D, 0:D, 2 * D:3 * D]
+    with torch.no_grad():
+        gru.weight_ih_l0.copy_(torch.from_numpy(K.astype(np.float64).T[perm]))
+        gru.weight_hh_l0.copy_(torch.from_numpy(U.astype(np.float64).T[perm]))
+        gru.bias_ih_l0.copy_(torch.from_numpy(b[0].astype(np.float64)[perm]))
+        gru.bias_hh_l0.copy_(torch.from_numpy(b[1].astype(np.float64)[perm]))
+        want, _ = gru(torch.from_numpy(table.astype(np.float64)[h]))
+    assert np.abs(got - want.numpy()).max() <= 2e-6
+    # (2) holes: a masked slot repeats the previous output (zeros before the first live one) and does not advance the state
+    h2 = h.copy()
+    h2[rng.random(h2.shape) < 0.35] = 0
+    h2[0] = 0
+    g2 = model.predict({"h": h2.astype(np.float32)})
+    assert (g2[0] == 0).all()
+    for r in range(B):
+        live = [t for t in range(T) if h2[r, t] != 0]
+        packed = np.zeros((1, T), np.int64)
+        packed[0, :len(live)] = h2[r, live]                       # the same ids without the holes: same states in order
+        ref = model.predict({"h": np.maximum(packed, 1).astype(np.float32)})[0]
+        k = -1
+        for t in range(T):
+            if h2[r, t] != 0:
+                k += 1
+            want_t = ref[k] if k >= 0 else np.zeros(D, np.float32)
+            np.testing.assert_array_equal(g2[r, t], want_t)
