@@ -21,14 +21,16 @@ known answers of TensorFlow's own sparse_cross_op_test.py (oracle/farmhash64.py)
 on rows of the reference's testSamples.csv; this oracle agrees to 1e-6: pins categorical_column_with_identity +
 embedding_column, categorical_column_with_vocabulary_list + indicator_column, numeric_column, DenseFeatures' name-sorted
 concat, Dense, concatenate and Dot to the wiring TensorFlow itself generated.
-(3) tests/test_reference_blocks.py -- the reference's OWN model-building lines (DIN.py, DeepFM.py, DeepFM_v2.py,
-WideNDeep.py, NeuralCF.py), exec-uted untouched on oracle/keras_shim.py (and on TensorFlow where importable:
+(3) tests/test_reference_blocks.py -- the reference's OWN model-building lines (all seven scripts: DIN.py, DeepFM.py, DeepFM_v2.py,
+WideNDeep.py, NeuralCF.py, EmbeddingMLP.py, DIEN.py with its own attention / GRU_gate_parameter / AUGRU classes), exec-uted untouched
+on oracle/keras_shim.py (and on TensorFlow where importable:
 tests/golden/make_tf_golden.py); this oracle agrees to 1e-6 with the shim run -- the WIRING of DIN's attention unit /
 PReLU shapes / pooling, DeepFM(_v2)'s FM crosses and Wide&Deep's crossed column is the reference's code, not a reading of
 it (that run is what found DeepFM.py's two tables per deep key).
 (4) tests/test_oracle_pins.py: the trained checkpoints' known answers (ROC-AUC 0.7514 / 0.7321 / 0.7353 / 0.7320).
-STILL WITHOUT A TENSORFLOW-PRODUCED VECTOR: DIN, DeepFM, DeepFM_v2, Wide&Deep end to end (the ``unpinned`` tests XFAIL
-until tests/golden/refblock_tf_*.npz exist), DIEN.
+(5) tests/test_dien_cpu.py: the GRU recurrence of this file AND of the stand-in against torch.nn.GRU (an independent implementation).
+STILL WITHOUT A TENSORFLOW-PRODUCED VECTOR: DIN, DeepFM, DeepFM_v2, Wide&Deep, DIEN end to end (the ``unpinned`` tests XFAIL
+until tests/golden/refblock_tf_*.npz exist).
 
 Every function cites the reference file:line it follows.  ``dtype`` selects the
 arithmetic type: float32 reproduces the reference's fp32 CPU forward, float64 is
