@@ -164,7 +164,7 @@ int sprk_forward(sprk_handle h, const int32_t* ids, const float* dense, float* o
     }
     if (h->din_tail_variant >= 0) {
         const int ntasks = (B + 15) / 16;
-        const int tw = h->din_tail_run.e_unscale != 0.f ? DT_WAVES_UNF : DT_WAVES;
+        const int tw = h->din_tail_run.e_unscale != 0.f ? dt_waves_unf(kDinTailVariants[h->din_tail_variant].kpc) : DT_WAVES;
         int grid = (ntasks + tw - 1) / tw;
         if (grid > h->num_cus) grid = h->num_cus;                  // one workgroup per CU (8 waves, or 16 with raw embedding rows)
         kDinTailVariants[h->din_tail_variant].launch(h->din_tail_run, ids, dense, aux, out, B, h->dev_err, h->din_tail_image, grid, st);
@@ -324,7 +324,7 @@ static int forward_many_impl(sprk_handle h, int32_t n_batches, const int32_t* co
                     for (int j = 0; j < n; ++j)
                         av.launch(h->din_run, tm.ids[j], const_cast<float*>(tm.aux[j]), nullptr, B, h->dev_err, ag, h->din_attn_lds, st);
                 }
-                const int tw = h->din_tail_run.e_unscale != 0.f ? DT_WAVES_UNF : DT_WAVES;
+                const int tw = h->din_tail_run.e_unscale != 0.f ? dt_waves_unf(kDinTailVariants[h->din_tail_variant].kpc) : DT_WAVES;
                 long long tg = ((long long)n * ntpb + tw - 1) / tw;
                 if (tg > h->num_cus) tg = h->num_cus;
                 tv.launch_many(h->din_tail_run, tm, B, h->dev_err, h->din_tail_image, (int)tg, st);

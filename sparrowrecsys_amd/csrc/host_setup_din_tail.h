@@ -2,7 +2,9 @@
 // Part of sparrow_hip.hip (one translation unit); included there, not compilable on its own.
 // ---- dispatch table for k_din_tail<N0C, N1C, KPC, WAVES> ----
 constexpr int DT_WAVES = 8;
-constexpr int DT_WAVES_UNF = 16;       // UNF: 146 -> <= 128 VGPRs, sixteen waves per CU: at B = 65 536 every wave has ONE task
+// UNF: emb_dim <= 16 fits 128 VGPRs -> sixteen waves per CU, ONE task per wave at B = 65 536; emb_dim <= 32 holds four operand pairs
+// and would spill 81 dwords at that cap: eight waves
+constexpr int dt_waves_unf(int kpc) { return kpc >= 2 ? 8 : 16; }
 typedef void (*DinTailLaunchFn)(const DinTailRun&, const int*, const float*, const float*, float*, int, int*, const float*, int, hipStream_t);
 typedef void (*DinTailLaunchManyFn)(const DinTailRun&, const DinTailMany&, int, int*, const float*, int, hipStream_t);
 typedef void (*DinTailPackFn)(const float*, int, int, int, int, int, const float*, const float*, const float*, int, const float*,
@@ -13,7 +15,7 @@ void din_tail_launch(const DinTailRun& a, const int* ids, const float* dense, co
     const size_t lds = DinTailLds<N0C, N1C, KPC>::bytes;
     static const DinTailMany none{};
     if (a.e_unscale != 0.f)
-        hipLaunchKernelGGL((k_din_tail<N0C, N1C, KPC, DT_WAVES_UNF, true, false, true>), dim3(grid), dim3(DT_WAVES_UNF * 64), lds, st,
+        hipLaunchKernelGGL((k_din_tail<N0C, N1C, KPC, dt_waves_unf(KPC), true, false, true>), dim3(grid), dim3(dt_waves_unf(KPC) * 64), lds, st,
                            a, ids, dense, aux, out, B, err, image, none);
     else if (a.inv_w1_scale != 0.f)
         hipLaunchKernelGGL((k_din_tail<N0C, N1C, KPC, DT_WAVES, true, false>), dim3(grid), dim3(DT_WAVES * 64), lds, st,
@@ -26,7 +28,7 @@ template <int N0C, int N1C, int KPC>
 void din_tail_launch_many(const DinTailRun& a, const DinTailMany& m, int B, int* err, const float* image, int grid, hipStream_t st) {
     const size_t lds = DinTailLds<N0C, N1C, KPC>::bytes;
     if (a.e_unscale != 0.f)
-        hipLaunchKernelGGL((k_din_tail<N0C, N1C, KPC, DT_WAVES_UNF, true, true, true>), dim3(grid), dim3(DT_WAVES_UNF * 64), lds, st,
+        hipLaunchKernelGGL((k_din_tail<N0C, N1C, KPC, dt_waves_unf(KPC), true, true, true>), dim3(grid), dim3(dt_waves_unf(KPC) * 64), lds, st,
                            a, (const int*)nullptr, (const float*)nullptr, (const float*)nullptr, (float*)nullptr, B, err, image, m);
     else if (a.inv_w1_scale != 0.f)
         hipLaunchKernelGGL((k_din_tail<N0C, N1C, KPC, DT_WAVES, true, true>), dim3(grid), dim3(DT_WAVES * 64), lds, st,
@@ -54,8 +56,8 @@ struct DinTailVariant {
                                          reinterpret_cast<const void*>(&k_din_tail<N0C, N1C, KPC, DT_WAVES, false, true>),               \
                                          reinterpret_cast<const void*>(&k_din_tail<N0C, N1C, KPC, DT_WAVES, true, false>),               \
                                          reinterpret_cast<const void*>(&k_din_tail<N0C, N1C, KPC, DT_WAVES, true, true>),                \
-                                         reinterpret_cast<const void*>(&k_din_tail<N0C, N1C, KPC, DT_WAVES_UNF, true, false, true>),     \
-                                         reinterpret_cast<const void*>(&k_din_tail<N0C, N1C, KPC, DT_WAVES_UNF, true, true, true>)},     \
+                                         reinterpret_cast<const void*>(&k_din_tail<N0C, N1C, KPC, dt_waves_unf(KPC), true, false, true>),     \
+                                         reinterpret_cast<const void*>(&k_din_tail<N0C, N1C, KPC, dt_waves_unf(KPC), true, true, true>)},     \
                                          DinTailLds<N0C, N1C, KPC>::bytes, &din_tail_launch<N0C, N1C, KPC>, &din_tail_launch_many<N0C, N1C, KPC>, \
                                          &din_tail_pack<N0C, N1C, KPC>}
 const DinTailVariant kDinTailVariants[] = {
@@ -124,13 +126,14 @@ int setup_din_tail(sprk_engine* h, DevPlan* dp) {
         const sprk_op& q0 = p.ops[0];                              // the ORIGINAL first Dense (o0.W has the folded columns zeroed)
         const float* W0full = (const float*)h->slot_ptr[q0.w_slot];
         const sprk_seg* raw[DT_MAX_COLS] = {nullptr, nullptr, nullptr, nullptr};
-        bool ok = true;
+        const int epb = kpc >= 2 ? 32 : 16, nblk = kpc >= 2 ? 4 : 2;    // DinTailLds::EPB / NBLK
+        bool ok = kpc <= 2;
         for (int g = 0; g < dp->n_acc && ok; ++g) {
             const DevSeg& sg = dp->segs[n_plain + g];
             for (int i = 0; i < p.n_segs; ++i)
                 if (p.segs[i].kind == SPRK_SEG_ROWS && p.segs[i].field == h->idc[sg.field] && p.segs[i].vocab == sg.vocab &&   // (DevSeg::field is the compact index)
                     p.segs[i].dst >= q0.src_off && p.segs[i].dst + 4 * p.segs[i].count <= q0.src_off + q0.K) { raw[g] = &p.segs[i]; break; }
-            ok = raw[g] && 4 * raw[g]->count <= 16 && raw[g]->row_stride <= 16;
+            ok = raw[g] && 4 * raw[g]->count <= epb && raw[g]->row_stride <= epb;
             for (int g2 = 0; g2 < g && ok; ++g2) ok = raw[g2] != raw[g];
         }
         // one static scale for all columns' rows; an outlier row keeps the folded tables
@@ -167,17 +170,18 @@ int setup_din_tail(sprk_engine* h, DevPlan* dp) {
             ok = amax < 3.0e38f;
             if (ok) {
                 const float w_scale = pow2_scale(amax, 15);
-                std::vector<float> fr((size_t)n0c * 2 * 512, 0.f);
+                std::vector<float> fr((size_t)n0c * nblk * 512, 0.f);
                 _Float16* fh = reinterpret_cast<_Float16*>(fr.data());
                 for (int nb = 0; nb < n0c; ++nb)
-                    for (int pb = 0; pb < 2; ++pb)
+                    for (int pb = 0; pb < nblk; ++pb)
                         for (int ln = 0; ln < 64; ++ln)
                             for (int e = 0; e < 8; ++e) {
-                                const int n = nb * 16 + (ln & 15), k = 8 * (ln >> 4) + e, g = 2 * pb + (k >> 4), d = k & 15;
+                                const int n = nb * 16 + (ln & 15), k = 8 * (ln >> 4) + e;
+                                const int g = epb == 16 ? 2 * pb + (k >> 4) : pb, d = epb == 16 ? (k & 15) : k;
                                 float x = 0.f;
                                 if (g < dp->n_acc && d < 4 * raw[g]->count) x = W0h[(size_t)n * q0.ldw + raw[g]->dst - q0.src_off + d] * w_scale;
                                 const _Float16 hi = (_Float16)x;
-                                const size_t base = (size_t)((nb * 2 + pb) * 2) * 512;
+                                const size_t base = (size_t)((nb * nblk + pb) * 2) * 512;
                                 fh[base + ln * 8 + e] = hi;
                                 fh[base + 512 + ln * 8 + e] = (_Float16)(x - (float)hi);
                             }
@@ -188,15 +192,15 @@ int setup_din_tail(sprk_engine* h, DevPlan* dp) {
                 for (int g = 0; g < dp->n_acc; ++g) {
                     const long long rows = (long long)raw[g]->vocab;
                     float* et = nullptr;
-                    HIP_TRY(hipMalloc((void**)&et, (size_t)(rows + 1) * 64));
-                    HIP_TRY(hipMemset(et, 0, (size_t)(rows + 1) * 64));
+                    HIP_TRY(hipMalloc((void**)&et, (size_t)(rows + 1) * 4 * epb));
+                    HIP_TRY(hipMemset(et, 0, (size_t)(rows + 1) * 4 * epb));
                     h->fold_bufs.push_back(et);
-                    h->derived_bytes += (size_t)(rows + 1) * 64;
-                    long long nbk = (rows * 16 + 255) / 256;
+                    h->derived_bytes += (size_t)(rows + 1) * 4 * epb;
+                    long long nbk = (rows * epb + 255) / 256;
                     if (nbk > 65536) nbk = 65536;
                     if (nbk > 0)
                         hipLaunchKernelGGL(k_rows_unf_split, dim3((unsigned)nbk), dim3(256), 0, 0, (const float*)h->slot_ptr[raw[g]->slot], raw[g]->row_stride,
-                                           rows, e_scale, reinterpret_cast<_Float16*>(et));
+                                           rows, e_scale, reinterpret_cast<_Float16*>(et), epb);
                     r.Etab[g] = reinterpret_cast<const _Float16*>(et);
                 }
                 for (int g = dp->n_acc; g < DT_MAX_COLS; ++g) r.Etab[g] = r.Etab[0];

@@ -72,7 +72,11 @@ struct DinTailLds {
     static constexpr int KB0 = (KPC + 1) / 2;
     static constexpr int w0h_floats = N0C * KB0 * 512;
     static constexpr int off_w0h = (off_hw + N1 + 3) & ~3;
-    static constexpr int w0e_floats = N0C * 2 * 512;  // UNF: fc0's embedding columns, N0C x 2 blocks of {hi, lo} fragments
+    // UNF: fc0's embedding columns as {hi, lo} fragments.  emb_dim <= 16 (KPC = 1): two K = 32 blocks of two columns each, rows of
+    // 16 + 16 halfs; emb_dim <= 32 (KPC = 2, BASELINE config 3): one block per column, rows of 32 + 32 halfs
+    static constexpr int EPB = KPC >= 2 ? 32 : 16;
+    static constexpr int NBLK = KPC >= 2 ? 4 : 2;
+    static constexpr int w0e_floats = N0C * NBLK * 512;
     static constexpr int off_w0e = off_w0h + w0h_floats;
     static constexpr int total = off_w0e + w0e_floats;
     static constexpr int total_pad = (total + 255) & ~255;
@@ -187,30 +191,33 @@ __global__ __launch_bounds__(WAVES * 64, WAVES >= 16 ? 4 : 2) void k_din_tail(co
 #pragma unroll
         for (int nb = 0; nb < N0C; ++nb) z0[nb] = ld4(smem + LD::off_b0 + nb * 16 + 4 * q);
         if constexpr (UNF) {
-            static_assert(DYN && DT_MAX_COLS == 4, "two K = 32 blocks of two columns");
-            din_f16x8 eh[2], el[2];
+            static_assert(DYN && DT_MAX_COLS == 4, "two K = 32 blocks of two columns, or four of one");
+            constexpr int NBLK = LD::NBLK;
+            din_f16x8 eh[NBLK], el[NBLK];
 #pragma unroll
-            for (int pb = 0; pb < 2; ++pb) {
+            for (int pb = 0; pb < NBLK; ++pb) {
                 // (static indices only: a lane-dependent index into the kernel argument's arrays would move them to scratch)
-                const bool up = (q >> 1) != 0;
-                const int id = up ? idv[2 * pb + 1] : idv[2 * pb];
-                const bool have = 2 * pb + (up ? 1 : 0) < A.n_cols;
-                int voc = up ? A.vocab[2 * pb + 1] : A.vocab[2 * pb];
-                const _Float16* tab = up ? A.Etab[2 * pb + 1] : A.Etab[2 * pb];
+                const bool up = LD::EPB == 16 && (q >> 1) != 0;
+                const int g0 = LD::EPB == 16 ? 2 * pb : pb, g1 = LD::EPB == 16 ? 2 * pb + 1 : pb;
+                const int id = up ? idv[g1] : idv[g0];
+                const bool have = (up ? g1 : g0) < A.n_cols;
+                int voc = up ? A.vocab[g1] : A.vocab[g0];
+                const _Float16* tab = up ? A.Etab[g1] : A.Etab[g0];
                 if (!have) { voc = A.vocab[0]; tab = A.Etab[0]; }           // an absent column: column 0's all-zero row
                 const bool ok = have && (unsigned)id < (unsigned)voc;
                 bad |= have && !ok && id != -1;
-                const char* row = reinterpret_cast<const char*>(tab) + (size_t)(ok ? id : voc) * 64 + 16 * (q & 1);
+                const char* row = reinterpret_cast<const char*>(tab) + (size_t)(ok ? id : voc) * (4 * LD::EPB) +
+                                  16 * (LD::EPB == 16 ? (q & 1) : q);
                 eh[pb] = *reinterpret_cast<const din_f16x8*>(row);           // (a missing id / an absent column: the all-zero row)
-                el[pb] = *reinterpret_cast<const din_f16x8*>(row + 32);
+                el[pb] = *reinterpret_cast<const din_f16x8*>(row + 2 * LD::EPB);
             }
             const float* wf = smem + LD::off_w0e + 4 * lane;
 #pragma unroll
-            for (int pb = 0; pb < 2; ++pb)
+            for (int pb = 0; pb < NBLK; ++pb)
 #pragma unroll
                 for (int nb = 0; nb < N0C; ++nb) {
-                    const din_f16x8 ah = __builtin_bit_cast(din_f16x8, ld4(wf + ((nb * 2 + pb) * 2 + 0) * 256));
-                    const din_f16x8 al = __builtin_bit_cast(din_f16x8, ld4(wf + ((nb * 2 + pb) * 2 + 1) * 256));
+                    const din_f16x8 ah = __builtin_bit_cast(din_f16x8, ld4(wf + ((nb * NBLK + pb) * 2 + 0) * 256));
+                    const din_f16x8 al = __builtin_bit_cast(din_f16x8, ld4(wf + ((nb * NBLK + pb) * 2 + 1) * 256));
                     f32x4 acc = mfma_f16(al, eh[pb], zero);
                     acc = mfma_f16(ah, el[pb], acc);
                     acc = mfma_f16(ah, eh[pb], acc);

@@ -139,16 +139,16 @@ __global__ __launch_bounds__(256) void k_rows_build(const float* __restrict__ ta
     }
 }
 
-// UNF, one-time: raw embedding rows -> {16 hi halfs | 16 lo halfs} of E * scale (values beyond row_floats: 0)
+// UNF, one-time: raw embedding rows -> {W hi halfs | W lo halfs} of E * scale, W = 16 or 32 (values beyond row_floats: 0)
 __global__ __launch_bounds__(256) void k_rows_unf_split(const float* __restrict__ table, int row_floats, long long rows, float scale,
-                                                        _Float16* __restrict__ out) {
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < rows * 16; i += (long long)gridDim.x * 256) {
-        const long long v = i >> 4;
-        const int k = (int)(i & 15);
+                                                        _Float16* __restrict__ out, int W = 16) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < rows * W; i += (long long)gridDim.x * 256) {
+        const long long v = i / W;
+        const int k = (int)(i - v * W);
         const float x = k < row_floats ? table[v * row_floats + k] * scale : 0.f;
         const _Float16 hi = (_Float16)x;
-        out[v * 32 + k] = hi;
-        out[v * 32 + 16 + k] = (_Float16)(x - (float)hi);
+        out[v * 2 * W + k] = hi;
+        out[v * 2 * W + W + k] = (_Float16)(x - (float)hi);
     }
 }
 typedef _Float16 rows_f16x8 __attribute__((ext_vector_type(8)));

@@ -1014,9 +1014,9 @@ def test_dien_matrix_pipe_stage_equals_the_lane_per_sample_stage(torch, monkeypa
     assert np.abs(out["1"][0][:n, :D] - parts["augru"]).max() <= TIGHT
 
 
-@pytest.mark.parametrize("kind,D,T", [("din", 10, 5), ("din", 16, 12), ("dien", 10, 5)])
+@pytest.mark.parametrize("kind,D,T", [("din", 10, 5), ("din", 16, 12), ("dien", 10, 5), ("din", 32, 9), ("din", 20, 50)])
 def test_tail_with_raw_embedding_rows_equals_the_folded_tail(torch, monkeypatch, kind, D, T):
-    """k_din_tail UNF (emb_dim <= 16: the embedding columns as raw split-f16 rows, fc0's share of them on the matrix pipe) against
+    """k_din_tail UNF (emb_dim <= 32: the embedding columns as raw split-f16 rows, fc0's share of them on the matrix pipe) against
     the folded 512-byte rows (SPRK_TAIL_UNF=0) and the oracle: missing genre ids, ragged batch, several batches per launch."""
     V, U, B = 3000, 900, 20011
     feats = SY.synth_din(B, T, V, U, seed=77 + T)
