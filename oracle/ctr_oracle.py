@@ -393,7 +393,7 @@ def first_order_offsets(fields) -> Dict[str, int]:
 
 def deepfm_forward(features: Dict, w: Dict[str, np.ndarray], dtype=np.float32,
                    fields=DEEPFM_FIELDS, pairs=DEEPFM_PAIRS, deep_emb=DEEPFM_DEEP_EMB,
-                   literal_one_hot: bool = False) -> np.ndarray:
+                   literal_one_hot: bool = False, share_deep_tables: bool = False) -> np.ndarray:
     """DeepFM.py:54-113.  first-order = indicator columns fed straight into the output Dense;
     second-order = hand-picked pairwise Dot(axes=1); deep = DenseFeatures(numerics + movieId/
     userId embeddings) -> Dense(64, relu) x2; concatenate([first_order, dots..., deep]) ->
@@ -403,10 +403,19 @@ def deepfm_forward(features: Dict, w: Dict[str, np.ndarray], dtype=np.float32,
     Two tables per deep key: ``DenseFeatures([movie_emb_col])`` (DeepFM.py:91, FM dots) and
     ``DenseFeatures(deep_feature_columns)`` (DeepFM.py:106, MLP) are two layers, and every DenseFeatures layer
     creates its columns' variables itself (TF feature_column_v2.py _StateManagerImpl.create_variable), so the deep part
-    reads ``deep_emb/<key>``; a weight dict without that key means tied tables (``emb/<key>`` for both)."""
+    reads ``deep_emb/<key>``.  Tied tables (``emb/<key>`` for both, rounds 1-2's reading) only on request
+    (``share_deep_tables=True``, the same switch as ``sparrowrecsys_amd.models.DeepFM``): a weight dict without
+    ``deep_emb/<key>`` is an error here as it is there, never a silent fallback."""
     ids = _field_ids(features, fields)
     emb = {k: embedding_lookup(w["emb/" + k].astype(dtype), ids[k]) for k, _, _ in fields}
-    demb = {k: (embedding_lookup(w["deep_emb/" + k].astype(dtype), ids[k]) if "deep_emb/" + k in w else emb[k]) for k in deep_emb}
+    if share_deep_tables:
+        demb = {k: emb[k] for k in deep_emb}
+    else:
+        for k in deep_emb:
+            if "deep_emb/" + k not in w:
+                raise KeyError("missing weight %r: DeepFM.py's deep part owns its own table of %r (DeepFM.py:106); "
+                               "pass share_deep_tables=True for tied tables" % ("deep_emb/" + k, k))
+        demb = {k: embedding_lookup(w["deep_emb/" + k].astype(dtype), ids[k]) for k in deep_emb}
     offs = first_order_offsets(fields)
     n_fo = offs["__total__"]
     hk = w["head/kernel"].astype(dtype)

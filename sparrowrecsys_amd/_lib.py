@@ -105,6 +105,8 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
             tmp = "%s.tmp.%d" % (LIB_PATH, os.getpid())
             cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-pthread",
                    "-I", INCLUDE_DIR, "-I", os.path.dirname(SRC_PATH), SRC_PATH, "-o", tmp]
+            if os.environ.get("SPRK_BUILD_DEFINES"):              # experiment builds (e.g. -DSPRK_DF_XP: k_din_fused's ablation variants)
+                cmd[1:1] = os.environ["SPRK_BUILD_DEFINES"].split()
             if verbose:
                 print(" ".join(cmd))
             res = subprocess.run(cmd, capture_output=True, text=True)

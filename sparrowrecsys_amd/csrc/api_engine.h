@@ -319,6 +319,31 @@ int sprk_finalize(sprk_handle h) {
                             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_din_attn_cols<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
                             h->din_cols = true;
                             h->din_cols_kc = kc;
+                            // k_din_fused (k_din_fused.h) takes the same tables; its tail half is set up by setup_din_tail
+                            // (a trip of its slot loop is four slots: for the reference's own hist_len = 5 that is 8 slots of work for 5, and
+                            // k_din_attn_cols' three-slot trips measure 10.7 us against 12.5 -- so short histories stay there)
+                            if (h->tune.din_fused && s.T >= 12) {
+                                DinFusedRun& f = h->din_fused_run;
+                                memset(&f, 0, sizeof(f));
+                                f.T = c.T; f.F = c.F; f.hist_col = c.hist_col; f.cand_col = c.cand_col; f.Dp = c.Dp; f.vocab = c.vocab;
+                                f.b2 = c.b2; f.acc_scale = c.acc_scale; f.unscale = c.unscale; f.inv_h_scale = c.inv_h_scale; f.kappa = c.kappa;
+                                f.tsplit = c.tsplit; f.vc = c.vc; f.frag = c.frag; f.coef = c.coef; f.idp = c.idp;
+                                const int lds_attn = (DF_COEF_FLOATS + DF_WAVES * 16 * p.n_id_cols + DF_WAVES * 2 * 64 * 8) * 4;
+                                if (lds_attn <= 160 * 1024) {
+                                    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_din_fused<1, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_attn));
+                                    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_din_fused<1, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_attn));
+                                    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_din_fused<2, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_attn));
+                                    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_din_fused<2, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_attn));
+                                    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_din_fused<1, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_attn));
+                                    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_din_fused<2, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_attn));
+#ifdef SPRK_DF_XP
+#define DF_XP_ATTR(X) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_din_fused<2, false, false, false, X>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_attn));
+                                    DF_XP_ATTR(1) DF_XP_ATTR(2) DF_XP_ATTR(4) DF_XP_ATTR(8) DF_XP_ATTR(16) DF_XP_ATTR(32) DF_XP_ATTR(64) DF_XP_ATTR(3) DF_XP_ATTR(56) DF_XP_ATTR(60) DF_XP_ATTR(63) DF_XP_ATTR(127) DF_XP_ATTR(65) DF_XP_ATTR(126)
+#undef DF_XP_ATTR
+#endif
+                                    h->din_fused_attn = true;
+                                }
+                            }
                         }
                     }
                 }

@@ -28,6 +28,48 @@ static int launch_din_cols(sprk_handle h, const int32_t* ids, float* pooled, flo
     return SPRK_OK;
 }
 
+// k_din_fused: `n` batches of B rows (n = 1: ids / dense / out; n > 1: the per-batch pointers of `many`).  tail: scores out (the whole
+// DIN forward); else pooled vectors out (the attention stage alone: sprk_din_pool, the two-launch path)
+static int launch_din_fused(sprk_handle h, const int32_t* ids, const float* dense, float* out, float* att, int32_t B, const DinFusedMany* many,
+                            bool tail, hipStream_t st) {
+    DinFusedRun c = h->din_fused_run;
+    const long long ntasks = (long long)(many ? many->n : 1) * ((B + 15) / 16);
+    // time slices per task: one 8-wave workgroup per CU; spread a small launch over the chip
+    const long long slots = (long long)h->num_cus * DF_WAVES;
+    c.ts = (c.T >= 16 && ntasks * 4 <= slots) ? 4 : ((c.T >= 8 && ntasks * 2 <= slots) ? 2 : 1);
+    if (h->tune.din_cols_ts) c.ts = h->tune.din_cols_ts;
+    c.ts_log2 = c.ts == 4 ? 2 : (c.ts == 2 ? 1 : 0);
+    c.ql = ((c.T + 3) / 4 + 3) & ~3;                          // slots per quarter, a multiple of four: a trip of the slot loop (two pairs) never straddles one
+    const int kc = h->din_cols_kc;
+    const size_t lds = ((size_t)DF_COEF_FLOATS + (tail ? (size_t)DinFusedImg::total_pad : 0) + (size_t)DF_WAVES * 16 * c.idp + (size_t)DF_WAVES * 2 * 64 * 4 * kc) * sizeof(float);
+    const long long grid = (ntasks * c.ts + DF_WAVES - 1) / DF_WAVES;
+#define DF_LAUNCH(KC, MB, TAIL, marg)                                                                                                   \
+    hipLaunchKernelGGL((k_din_fused<KC, MB, TAIL>), dim3((unsigned)grid), dim3(DF_WAVES * 64), lds, st, c, MB ? (const int*)nullptr : ids, \
+                       MB ? (const float*)nullptr : dense, MB ? (float*)nullptr : out, MB ? (float*)nullptr : att, B, h->dev_err, marg)
+#ifdef SPRK_DF_XP
+    if (h->tune.df_xp && kc == 2 && !many && !tail && !att) {     // ablation builds only (scripts/r04): garbage out, the time is the point
+#define DF_XP(X) case X: hipLaunchKernelGGL((k_din_fused<2, false, false, false, X>), dim3((unsigned)grid), dim3(DF_WAVES * 64), lds, st, c, ids, dense, out, att, B, h->dev_err, DinFusedOne{}); break;
+        switch (h->tune.df_xp) { DF_XP(1) DF_XP(2) DF_XP(4) DF_XP(8) DF_XP(16) DF_XP(32) DF_XP(64) DF_XP(3) DF_XP(56) DF_XP(60) DF_XP(63) DF_XP(127) DF_XP(65) DF_XP(126) default: return fail(SPRK_EINVAL, "SPRK_DF_XP=%d is not compiled in", h->tune.df_xp); }
+#undef DF_XP
+        HIP_TRY(hipGetLastError());
+        return SPRK_OK;
+    }
+#endif
+    if (many) {
+        if (kc == 2) { if (tail) DF_LAUNCH(2, true, true, *many); else DF_LAUNCH(2, true, false, *many); }
+        else { if (tail) DF_LAUNCH(1, true, true, *many); else DF_LAUNCH(1, true, false, *many); }
+    } else {
+        if (att && !tail) {                                     // attention weights out (tests, inspection): its own instantiation
+            if (kc == 2) hipLaunchKernelGGL((k_din_fused<2, false, false, true>), dim3((unsigned)grid), dim3(DF_WAVES * 64), lds, st, c, ids, dense, out, att, B, h->dev_err, DinFusedOne{});
+            else hipLaunchKernelGGL((k_din_fused<1, false, false, true>), dim3((unsigned)grid), dim3(DF_WAVES * 64), lds, st, c, ids, dense, out, att, B, h->dev_err, DinFusedOne{});
+        } else if (kc == 2) { if (tail) DF_LAUNCH(2, false, true, DinFusedOne{}); else DF_LAUNCH(2, false, false, DinFusedOne{}); }
+        else { if (tail) DF_LAUNCH(1, false, true, DinFusedOne{}); else DF_LAUNCH(1, false, false, DinFusedOne{}); }
+    }
+#undef DF_LAUNCH
+    HIP_TRY(hipGetLastError());
+    return SPRK_OK;
+}
+
 static int launch_din(sprk_handle h, const int32_t* ids, float* pooled, float* att, int32_t B, hipStream_t st) {
     if (h->plan.din.enabled == 2) {                               // DIEN: GRU -> attention gate -> AUGRU, one lane per sample
         if (att) return fail(SPRK_EINVAL, "DIEN stage has no attention output");
@@ -54,6 +96,7 @@ static int launch_din(sprk_handle h, const int32_t* ids, float* pooled, float* a
         HIP_TRY(hipGetLastError());
         return SPRK_OK;
     }
+    if (h->din_variant >= 0 && h->din_cols && h->din_fused_attn) return launch_din_fused(h, ids, nullptr, pooled, att, B, nullptr, false, st);
     if (h->din_variant >= 0 && h->din_cols) return launch_din_cols(h, ids, pooled, att, B, nullptr, st);
     if (h->din_variant >= 0) {
         int grid = (B + h->din_wpb - 1) / h->din_wpb;
@@ -93,6 +136,12 @@ int sprk_forward(sprk_handle h, const int32_t* ids, const float* dense, float* o
     if (h->plan.din.enabled) {
         const size_t need = sprk_workspace_bytes(h, B);
         if (!workspace || workspace_bytes < need) return fail(SPRK_EINVAL, "workspace too small: %zu < %zu bytes", workspace_bytes, need);
+        // DIN in one launch: attention + pooling + tail (k_din_fused); the workspace contract stays, the buffer is not touched.  One
+        // 8-wave workgroup per CU carries the tail's weights, so the fused form pays while a launch is ONE round of workgroups (up to
+        // 16 rows x 8 waves x CUs = 32 768 rows on an MI355X: BASELINE config 3, and every latency-bound request below it); beyond
+        // that the two-launch path's free-running tail kernel is faster (measured: profiles/r04)
+        if (h->plan.din.enabled == 1 && h->din_fused && (h->tune.din_fused_always || (long long)((B + 15) / 16) <= (long long)h->num_cus * DF_WAVES))
+            return launch_din_fused(h, ids, dense, out, nullptr, B, nullptr, true, st);
         int rc = launch_din(h, ids, (float*)workspace, nullptr, B, st);
         if (rc) return rc;
         aux = (const float*)workspace;
@@ -190,7 +239,7 @@ static int forward_many_impl(sprk_handle h, int32_t n_batches, const int32_t* co
     // a model with a workspace (DIN: attention kernel -> pooled vectors -> tail kernel) needs one workspace slice per
     // stream; with a single slice its forwards stay in strict order
     const size_t ws_need = (sprk_workspace_bytes(h, B) + 255) & ~(size_t)255;
-    if (S >= 2 && ws_need > 0) {
+    if (S >= 2 && ws_need > 0 && !(h->finalized && h->plan.din.enabled == 1 && h->din_fused)) {
         while (S >= 2 && (!workspace || workspace_bytes < (size_t)S * ws_need)) --S;
         if (S < 2) S = 0;
     }
@@ -266,6 +315,37 @@ static int forward_many_impl(sprk_handle h, int32_t n_batches, const int32_t* co
             return SPRK_OK;
         }
     }
+    // DIN on k_din_fused: up to DF_MB batches per launch, one launch does everything; groups alternate over the helper streams
+    // (SPRK_DIN_FUSED_MB=1 only: at several batches per launch the two-launch pipeline below -- attention of group g + 1 beside the tail of
+    // group g on a second stream -- measures 34.5 us per batch against 38.8 for this form)
+    if (h->finalized && many_batches > 1 && n_batches > 1 && h->plan.din.enabled == 1 && h->din_fused && h->tune.din_fused_mb && B > 0 && ids && dense) {
+        const int per = many_batches < DF_MB ? many_batches : DF_MB;
+        bool ok = true;
+        for (int32_t i = 0; i < n_batches && ok; ++i) ok = ids[i] && dense[i] && out[i];
+        if (ok) {
+            const int SG = S >= 2 ? S : 1;
+            if (SG >= 2) {
+                HIP_TRY(hipEventRecord(h->many_fork, (hipStream_t)stream));
+                for (int s = 0; s < SG; ++s) HIP_TRY(hipStreamWaitEvent(h->many_stream[s], h->many_fork, 0));
+            }
+            int g = 0;
+            for (int32_t i0 = 0; i0 < n_batches; i0 += per, ++g) {
+                DinFusedMany fm;
+                memset(&fm, 0, sizeof(fm));
+                fm.n = n_batches - i0 < per ? n_batches - i0 : per;
+                for (int j = 0; j < fm.n; ++j) { fm.ids[j] = ids[i0 + j]; fm.dense[j] = dense[i0 + j]; fm.out[j] = out[i0 + j]; }
+                const int rcf = launch_din_fused(h, nullptr, nullptr, nullptr, nullptr, B, &fm, true, SG >= 2 ? h->many_stream[g % SG] : (hipStream_t)stream);
+                if (rcf) return rcf;
+            }
+            if (SG >= 2) {
+                for (int s = 0; s < SG; ++s) {
+                    HIP_TRY(hipEventRecord(h->many_join[s], h->many_stream[s]));
+                    HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, h->many_join[s], 0));
+                }
+            }
+            return SPRK_OK;
+        }
+    }
     // DIN (k_din_attn -> pooled vectors -> k_din_tail): the attention launches of a group of batches, then ONE tail launch for
     // the group; a workspace slice per batch of the group.  Groups alternate over the helper streams when there are slices for that.
     if (h->finalized && many_batches > 1 && n_batches > 1 && h->plan.din.enabled == 1 && h->din_variant >= 0 &&
@@ -298,7 +378,14 @@ static int forward_many_impl(sprk_handle h, int32_t n_batches, const int32_t* co
                 }
                 // ONE attention launch for the group (k_din_attn<..., MB = true>: no launch boundary and no partial last round of waves
                 // between the batches; SPRK_DIN_ATTN_MB=0: one launch per batch), then one tail launch
-                if (h->din_cols && h->din_attn_many && n <= DC_MB) {
+                if (h->din_cols && h->din_fused_attn && h->tune.din_mb_attn_fused && h->din_attn_many && n <= DF_MB) {
+                    DinFusedMany fm;
+                    memset(&fm, 0, sizeof(fm));
+                    fm.n = n;
+                    for (int j = 0; j < n; ++j) { fm.ids[j] = tm.ids[j]; fm.out[j] = const_cast<float*>(tm.aux[j]); }
+                    const int rcc = launch_din_fused(h, nullptr, nullptr, nullptr, nullptr, B, &fm, false, st);
+                    if (rcc) return rcc;
+                } else if (h->din_cols && h->din_attn_many && n <= DC_MB) {
                     DinColsMany cm;
                     memset(&cm, 0, sizeof(cm));
                     cm.n = n;
@@ -431,7 +518,8 @@ int sprk_describe(sprk_handle h, char* buf, size_t buf_bytes) {
     }
     const char* stage = "";
     if (h->plan.din.enabled == 2) stage = h->dien_frag ? "k_dien_seq_mfma" : "k_dien_seq";
-    else if (h->plan.din.enabled == 1) stage = h->din_variant >= 0 ? "k_din_attn" : "k_din_pool";
+    else if (h->plan.din.enabled == 1) stage = h->din_variant < 0 ? "k_din_pool" : (h->din_cols ? (h->din_fused_attn ? "k_din_fused" : "k_din_attn_cols") : "k_din_attn");
+    if (h->plan.din.enabled == 1 && h->din_fused) snprintf(kern, sizeof(kern), "k_din_fused<KC=%d,tail 128/64>", h->din_cols_kc);
     size_t uploaded = 0;
     for (size_t b : h->slot_bytes) uploaded += b;
     const int n = snprintf(buf, buf_bytes, "kernel=%s;stage=%s;stage_waves_per_workgroup=%d;fused=%d;uploaded_bytes=%zu;derived_bytes=%zu;first_dense_fold=%d", kern, stage,
@@ -477,6 +565,7 @@ void sprk_destroy(sprk_handle h) {
     for (int i = 0; i < 4; ++i) { if (h->many_stream[i]) (void)hipStreamDestroy(h->many_stream[i]); if (h->many_join[i]) (void)hipEventDestroy(h->many_join[i]); }
     if (h->many_fork) (void)hipEventDestroy(h->many_fork);
     if (h->din_tail_image) (void)hipFree(h->din_tail_image);
+    if (h->din_fused_image) (void)hipFree(h->din_fused_image);
     if (h->mlp_rows_image) (void)hipFree(h->mlp_rows_image);
     if (h->mlp_rows_small) (void)hipFree(h->mlp_rows_small);
     for (void* q : h->mlp_rows_bufs) if (q) (void)hipFree(q);

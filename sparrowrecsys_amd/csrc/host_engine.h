@@ -62,6 +62,11 @@ struct sprk_engine {
     int din_cols_kc = 0;
     DinColsRun din_cols_run;
     float* din_frag = nullptr;     // its A fragments
+    // the whole DIN forward in one launch (k_din_fused: attention + pooling + tail; k_din_fused.h)
+    bool din_fused = false;        // TAIL instantiations usable (attention on the cols formulation AND the 128 / 64 tail recognised)
+    bool din_fused_attn = false;   // TAIL = false instantiations replace k_din_attn_cols (sprk_din_pool, the unfused two-launch path)
+    DinFusedRun din_fused_run;
+    float* din_fused_image = nullptr;
     bool din_attn_many = true;     // forward_many: one attention launch per group of batches (SPRK_DIN_ATTN_MB=0: per batch)
     // register-chained fast path (k_deepfm_v2_chain); -1 = use the tile interpreter
     int v2_variant = -1;

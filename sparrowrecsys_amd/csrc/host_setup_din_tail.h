@@ -215,6 +215,34 @@ int setup_din_tail(sprk_engine* h, DevPlan* dp) {
     HIP_TRY(hipDeviceSynchronize());
     for (int i = 0; i < 6; ++i) HIP_TRY(hipFuncSetAttribute(tv.fn[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)tv.lds_bytes));
     h->din_tail_variant = variant;
+    // k_din_fused: the same tail as the epilogue of the attention kernel (k_din_fused.h).  Needs the cols formulation of the attention
+    // (set up before this function), DIN.py's widths 128 / 64, fc1 AND fc0's pooled columns as split-f16 fragments, folded rows for
+    // every embedding column, and LDS for both halves.
+    if (h->din_fused_attn && p.model_kind == SPRK_MODEL_DIN && p.din.enabled == 1 && n0c == DinFusedImg::N0C && n1c == DinFusedImg::N1C &&
+        w1frag && w0pfrag && Dp <= 16 * h->din_cols_kc && tp.len <= DinFusedImg::N1) {
+        const int kc = h->din_cols_kc;
+        const int lds_full = (DF_COEF_FLOATS + DinFusedImg::total_pad + DF_WAVES * 16 * p.n_id_cols + DF_WAVES * 2 * 64 * 4 * kc) * 4;
+        bool rows_ok = true;
+        for (int g = 0; g < dp->n_acc; ++g) rows_ok = rows_ok && r.Ftab[g] != nullptr;
+        if (rows_ok && lds_full <= 160 * 1024) {
+            HIP_TRY(hipMalloc((void**)&h->din_fused_image, DinFusedImg::total_pad * sizeof(float)));
+            hipLaunchKernelGGL(k_din_fused_pack, dim3(1), dim3(256), 0, 0, o0.W, o0.ldw, p_off, Dp, n_off, n_num, 1.0f / r.inv_w0p_scale, 4 * kc,
+                               o0.bias, o0.alpha, w1frag, o1.bias, o1.alpha, tp.w, tp.len, h->din_fused_image);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipDeviceSynchronize());
+            DinFusedRun& f = h->din_fused_run;
+            f.ND = r.ND; f.n_cols = r.n_cols; f.n_num = r.n_num;
+            for (int g = 0; g < DT_MAX_COLS; ++g) { f.col[g] = r.col[g]; f.tvocab[g] = r.vocab[g]; f.Ftab[g] = g < r.n_cols ? r.Ftab[g] : r.Ftab[0]; }
+            f.head_bias = r.head_bias; f.inv_w1_scale = r.inv_w1_scale; f.inv_w0p_scale = r.inv_w0p_scale;
+            f.b0_slot = n_num < 8 ? n_num : -1;
+            f.image = h->din_fused_image;
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_din_fused<1, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_full));
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_din_fused<1, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_full));
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_din_fused<2, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_full));
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_din_fused<2, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_full));
+            h->din_fused = true;
+        }
+    }
     return SPRK_OK;
 }
 

@@ -1,0 +1,659 @@
+// k_din_fused.h -- k_din_fused: the whole DIN forward (reference DIN.py:132-167) in ONE launch: activation unit + weighted sum
+// pooling over the history (16 samples per MFMA tile, the weights as the static operand -- k_din_cols.h's formulation), and the
+// tail MLP concat([user profile, pooled history, candidate, context]) -> Dense(128) PReLU -> Dense(64) PReLU -> Dense(1, sigmoid)
+// as the EPILOGUE of the same wave: the pooled vectors never leave the registers, there is no second launch.
+// Included after k_din_cols.h / k_din_tail.h / dyn_split.h.
+//
+// What round 4 measured before writing it (scripts/ubench/issue_rates.hip, profiles/r04/ubench_issue_rates.log):
+//  * k_din_attn_cols is NOT memory bound: ids drawn from a 1 024-row window (every row an L1 / L2 hit) 31.7 us, uniform ids 33.5 us.
+//  * 1, 2 and 4 waves per task measure alike (2 or 4 waves per SIMD): a SIMD spends ~680 cycles per (16 samples, slot) however
+//    many waves share it -- the kernel is bound by the SUM of its instructions' issue times.  On gfx950 the f16 matrix pipe and
+//    the VALU overlap only partly (12 MFMAs + 60 v_fma per step: 320 cycles, against 210 for the MFMAs alone and 190 for the
+//    v_fma alone), so every VALU instruction removed is time removed.
+//  * per instruction and SIMD (wave64): v_fma_f32 3.1 cycles, v_pk_fma_f32 6.0 (NOT a gain over two v_fma), v_fma_mix_f32 4.6,
+//    v_fma_mixlo/hi_f16 8.7 (!), v_pk_mul/fma_f16 4.4, v_exp / v_rcp 8.3, v_permlane16/32_swap 8.2, v_cvt_pk_f16_f32 4.3,
+//    v_mfma_f32_16x16x32_f16 17.6.  k_din_attn_cols spent 139 of its ~340 VALU cycles per slot in sixteen v_fma_mix{lo,hi}_f16
+//    (forming and splitting h * c) and 61 in a cross-row sum + sigmoid that all four 16-lane rows compute redundantly.
+// What changed against k_din_attn_cols, per (16 samples, slot):
+//  * h * c * sP as PACKED f16 arithmetic on the halfs that are already in the registers: with h = hh + hl (the table's split) and
+//    c' = c kappa = ch + cl (split once per task), ph = hh ch (v_pk_mul_f16), r = fma(hh, ch, -ph) (the EXACT rounding error of
+//    ph), pl = fma(hl, ch, fma(hh, cl, r)): four packed instructions per two elements, 70 cycles instead of 139, the same 22
+//    significand bits (only hl cl, 2^-22 relative, is dropped); all of it compiler-visible (no asm, no hand-placed hazard nops).
+//  * slots are scored in PAIRS: the two slots' partial logits are reduced over the four 16-lane rows by ONE transposing
+//    v_permlane16_swap + one v_permlane32_swap (row 0 / 2: slot a, row 1 / 3: slot b; same summation order as rows4_sum), ONE
+//    sigmoid serves both, one more swap hands every lane both weights: 12 instructions per pair instead of 24, half the
+//    transcendentals.
+//  * eight waves per workgroup, ONE workgroup per CU (2 waves per SIMD -- measured equal to 4), which buys 256 VGPRs: the
+//    quarter sums stay in registers (k_din_attn_cols parked them in LDS), rows are requested a PAIR ahead into a ring of four
+//    register sets, and the LDS has room for the tail's weights (54 KB) next to the coefficient tables.
+//  * the first four slots' rows are requested in the prologue's own round trip (the ids are all they need), not behind the staging
+//    barrier.
+//  * TAIL: the wave that owns a task's pooled vectors (time slice 0) runs the tail for its sixteen samples after the slot loop: fc0's
+//    four embedding columns as FOLDED rows F_g[id] = W_g^T E_g[id] (k_din_tail.h; 4 x 512 bytes per sample straight into the
+//    accumulators' layout, all 32 loads of a lane in ONE round trip -- the loop's registers are free by then), the numerics on f32
+//    MFMA (K = 8 in two steps, fc0's bias in the free eighth slot), the pooled history on the f16 pipe from the registers it was
+//    accumulated in (per-sample dynamic scale; A fragments in the attention's own k order), fc1 on split-f16 (dyn_split.h), PReLU,
+//    Dense(1), sigmoid.  The splits use v_cvt_pk_f16_f32 (gfx950) instead of v_fma_mixlo/hi_f16.
+// What was measured and NOT kept (profiles/r04/; all on one box): the slot loop as a software pipeline over pairs (the
+// matrix half of pair i + 1 in one block with the VALU half of pair i): 42.5 us per fused launch against 42.2; the tail's rows
+// gathered in the PROLOGUE and held in registers through the loop: 43.7 against 41.7 -- they are 67 MB per batch, a third of the
+// history's bytes, and cost bandwidth wherever they are put; the fused form at several batches per launch: 39.2 us per batch against
+// 34.0 for the two-launch pipeline, whose tail kernel shares the CUs with the next group's attention kernel.
+// What bounds the slot loop (scripts/ubench/gather_pattern.hip): the same rows gathered by a kernel that does NOTHING else take
+// 30.0 us per 32 768 x 50 slots in this lane layout (a quad of consecutive lanes touches four different rows) and 25.6 us fully
+// coalesced -- 7.0 / 8.2 TB/s out of L2 + Infinity Cache; the ablated loop without its loads takes 26.4 us.  The stage is within
+// 10 % of both its memory and its issue bound at once; what the fusion buys is the second launch, not a faster loop.
+// Launch-shape invariance is kept: the pooled sum is always (q0 + q1) + (q2 + q3) of the history's quarters (a quarter is a
+// multiple of four slots, so a trip of the slot loop never straddles one), whatever `ts` is, and the tail is one wave's fixed instruction sequence.
+
+#define DF_WAVES 8
+#define DF_MB 16
+struct DinFusedRun {
+    // ---- activation unit + pooling (as DinColsRun) ----
+    int T, F, hist_col, cand_col, Dp, vocab;
+    float b2, acc_scale, unscale, inv_h_scale, kappa;
+    const float* tsplit;  // [vocab][KP floats]: per q group [hi(EL halfs) | lo(EL halfs)] of E * sH (k_din_split_table)
+    const float* vc;      // [vocab][32]
+    const float* frag;    // A fragments of W12 sA, W4 s4 (k_din_cols_pack)
+    const float* coef;    // [2][64][36] PReLU . Dense(1) coefficient tables (k_din_cols_coef)
+    int ts, ts_log2, ql, idp;
+    // ---- tail (DIN.py:161-167); unused by the TAIL = false instantiations ----
+    int ND, n_cols, n_num;
+    int col[DT_MAX_COLS], tvocab[DT_MAX_COLS];
+    const float* Ftab[DT_MAX_COLS];       // [vocab][128] folded rows of fc0 (fold_first_dense)
+    float head_bias, inv_w1_scale, inv_w0p_scale;
+    int b0_slot;                          // fc0's bias rides in this (free) numeric slot against a constant 1; -1: added by the VALU
+    const float* image;                   // DinFusedImg, built once by k_din_fused_pack
+};
+struct DinFusedMany {
+    const int* ids[DF_MB];
+    const float* dense[DF_MB];
+    float* out[DF_MB];                    // TAIL: scores [B]; else pooled vectors [B][Dp]
+    int n;
+};
+struct DinFusedOne {};
+template <bool MB> struct DinFusedArg { typedef DinFusedOne type; };
+template <> struct DinFusedArg<true> { typedef DinFusedMany type; };
+
+// The tail's LDS image (floats).  N0 = 128, N1 = 64 (DIN.py:163-166).
+struct DinFusedImg {
+    static constexpr int N0C = 8, N1C = 4, N0 = 128, N1 = 64;
+    static constexpr int off_w0p = 0;                               // [N0C][hi 256 | lo 256]: fc0's pooled columns, k = EL q + e
+    static constexpr int off_wn = off_w0p + N0C * 512;              // [N0C][2 steps][64 lanes]: fc0's numeric columns, f32
+    static constexpr int off_w1 = off_wn + N0C * 2 * 64;            // [N1C][N0C / 2][hi 256 | lo 256]: fc1 (k_dyn_pack_w's K-block layout)
+    static constexpr int off_b0 = off_w1 + N1C * (N0C / 2) * 512;   // b0[128] a0[128] b1[64] a1[64] hw[64]
+    static constexpr int off_a0 = off_b0 + N0, off_b1 = off_a0 + N0, off_a1 = off_b1 + N1, off_hw = off_a1 + N1;
+    static constexpr int total = off_hw + N1;
+    static constexpr int total_pad = (total + 255) & ~255;
+};
+constexpr int DF_COEF_FLOATS = 2 * 64 * 36;
+
+// One-time (finalize) kernel: the tail image.  W0: fc0's W^T [128][ldw0] (folded columns zeroed by fold_first_dense), pooled
+// columns at p_off (Dp of them), numerics at n_off; w1frag: fc1's split fragments (make_dyn_fragments); EL = 4 KC.
+__global__ __launch_bounds__(256) void k_din_fused_pack(const float* __restrict__ W0, int ldw0, int p_off, int Dp, int n_off, int n_num,
+                                                        float w0p_scale, int EL, const float* __restrict__ b0, const float* __restrict__ a0,
+                                                        const float* __restrict__ w1frag, const float* __restrict__ b1,
+                                                        const float* __restrict__ a1, const float* __restrict__ hw, int n_hw,
+                                                        float* __restrict__ img) {
+    using IM = DinFusedImg;
+    const int tid = threadIdx.x;
+    _Float16* wp = reinterpret_cast<_Float16*>(img + IM::off_w0p);
+    for (int i = tid; i < IM::N0C * 2 * 512; i += 256) {            // halfs: [nb][hi | lo][lane][8]
+        const int e = i & 7, lane = (i >> 3) & 63, hl = (i >> 9) & 1, nb = i >> 10;
+        const int r = lane & 15, q = lane >> 4;
+        const int d = EL * q + e;
+        float x = 0.f;
+        if (e < EL && d < Dp) x = W0[(size_t)(nb * 16 + r) * ldw0 + p_off + d] * w0p_scale;
+        const _Float16 hi = (_Float16)x;
+        wp[i] = hl ? (_Float16)(x - (float)hi) : hi;
+    }
+    for (int i = tid; i < IM::N0C * 2 * 64; i += 256) {
+        const int lane = i & 63, s = (i >> 6) & 1, nb = i >> 7;
+        const int r = lane & 15, q = lane >> 4, k = q + 4 * s;
+        // numeric slot n_num (when there is one) carries fc0's bias: the kernel feeds it a constant 1
+        img[IM::off_wn + i] = k < n_num ? W0[(size_t)(nb * 16 + r) * ldw0 + n_off + k] : (k == n_num ? b0[nb * 16 + r] : 0.f);
+    }
+    for (int i = tid; i < IM::N1C * (IM::N0C / 2) * 512; i += 256) img[IM::off_w1 + i] = w1frag[i];
+    for (int i = tid; i < IM::N0; i += 256) { img[IM::off_b0 + i] = b0[i]; img[IM::off_a0 + i] = a0[i]; }
+    for (int i = tid; i < IM::N1; i += 256) {
+        img[IM::off_b1 + i] = b1[i];
+        img[IM::off_a1 + i] = a1[i];
+        img[IM::off_hw + i] = i < n_hw ? hw[i] : 0.f;
+    }
+    for (int i = IM::total + tid; i < IM::total_pad; i += 256) img[i] = 0.f;
+}
+
+typedef _Float16 df_h2 __attribute__((ext_vector_type(2)));
+typedef float df_f2 __attribute__((ext_vector_type(2)));
+
+// (x0, x1) * scale -> one dword of hi halfs, one of lo halfs: hi = f16(x s) (v_cvt_pk_f16_f32, round to nearest even),
+// lo = f16(x s - hi).  Everything is visible to the compiler (it pads its own hazards).
+__device__ __forceinline__ void df_split2(float x0, float x1, float scale, df_h2& hi, df_h2& lo) {
+    const df_f2 v = df_f2{x0, x1} * scale;
+    hi = __builtin_convertvector(v, df_h2);
+    const df_f2 rest = v - __builtin_convertvector(hi, df_f2);
+    lo = __builtin_convertvector(rest, df_h2);
+}
+// (x0..x3 | y0..y3) * scale -> the two K = 32 operand vectors
+__device__ __forceinline__ void df_split8(f32x4 x, f32x4 y, float scale, din_f16x8& hi, din_f16x8& lo) {
+    df_h2 h[4], l[4];
+    df_split2(x[0], x[1], scale, h[0], l[0]);
+    df_split2(x[2], x[3], scale, h[1], l[1]);
+    df_split2(y[0], y[1], scale, h[2], l[2]);
+    df_split2(y[2], y[3], scale, h[3], l[3]);
+    hi = din_f16x8{h[0][0], h[0][1], h[1][0], h[1][1], h[2][0], h[2][1], h[3][0], h[3][1]};
+    lo = din_f16x8{l[0][0], l[0][1], l[1][0], l[1][1], l[2][0], l[2][1], l[3][0], l[3][1]};
+}
+
+// XP: ablation bits for scripts/r04 experiments (only instantiated under -DSPRK_DF_XP): 1 no MFMAs, 2 no product split, 4 no h32,
+// 8 no PReLU dot, 16 no reduce / sigmoid, 32 no pooling, 64 no row loads in the loop -- results are garbage, the time is the point
+template <int KC, bool MB, bool TAIL, bool ATT = false, int XP = 0>
+__global__ __launch_bounds__(DF_WAVES * 64, 2) void k_din_fused(const DinFusedRun A, const int* __restrict__ ids, const float* __restrict__ dense,
+                                                              float* __restrict__ out, float* __restrict__ att, int B, int* __restrict__ err,
+                                                              const typename DinFusedArg<MB>::type Mm) {
+#pragma clang fp contract(off)
+    constexpr int EL = 4 * KC, KP = 16 * KC, HP = 32, AS = HP + 4, ROWS = 64, NP = EL / 2;
+    constexpr int N0C = DinFusedImg::N0C, N1C = DinFusedImg::N1C;
+    typedef _Float16 f16xe __attribute__((ext_vector_type(EL)));
+    using IM = DinFusedImg;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 15, q = lane >> 4;
+    const int T = A.T;
+    const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
+    float* ca_s = smem;                                   // [64][AS]  w2 (1 + alpha) / 2
+    float* cb_s = smem + ROWS * AS;                       // [64][AS]  w2 (1 - alpha) / 2
+    float* img_s = smem + DF_COEF_FLOATS;                 // TAIL: the tail's weights
+    constexpr int img_floats = TAIL ? IM::total_pad : 0;
+    int* ids_s = reinterpret_cast<int*>(smem + DF_COEF_FLOATS + img_floats) + wave * 16 * A.idp;
+    float* park_s = smem + DF_COEF_FLOATS + img_floats + DF_WAVES * 16 * A.idp + wave * 2 * 64 * EL;   // two parking slots per wave: S0, S1
+
+    // ---- coefficient tables and (TAIL) the tail image by LDS-DMA: 1-KB pieces, wave w takes w, w + 8, ... ----
+#pragma unroll 1
+    for (int c = wave; c < DF_COEF_FLOATS / 256; c += DF_WAVES)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(A.coef + c * 256 + lane * 4),
+                                         (__attribute__((address_space(3))) void*)(smem + c * 256), 16, 0, 0);
+    if constexpr (TAIL) {
+#pragma unroll 1
+        for (int c = wave; c < IM::total_pad / 256; c += DF_WAVES)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(A.image + c * 256 + lane * 4),
+                                             (__attribute__((address_space(3))) void*)(img_s + c * 256), 16, 0, 0);
+    }
+
+    // ---- this wave's (task, time slice) ----
+    const int ntpb = (B + 15) >> 4;
+    int nb_batches = 1;
+    if constexpr (MB) nb_batches = Mm.n;
+    const int ntasks = nb_batches * ntpb;
+    const int gw = blockIdx.x * DF_WAVES + wave;
+    const int task = gw >> A.ts_log2, slice = gw & (A.ts - 1);
+    const bool work = task < ntasks;                      // wave-uniform
+    int bi = 0, tl = task;
+    if constexpr (MB) { bi = __builtin_amdgcn_readfirstlane(task / ntpb); tl = task - bi * ntpb; }
+    const int* ids_b = ids;
+    const float* dense_b = dense;
+    float* out_b = out;
+    if constexpr (MB) { ids_b = Mm.ids[work ? bi : 0]; dense_b = Mm.dense[work ? bi : 0]; out_b = Mm.out[work ? bi : 0]; }
+    const int nq = 4 >> A.ts_log2;                        // quarters of this wave; a quarter is A.ql slots (a multiple of FOUR: see the slot loop)
+    const int Tq = nq * A.ql;
+    const int t0 = slice * Tq;
+    const int nsteps = work ? max(0, min(T, t0 + Tq) - t0) : 0;
+    const int m = tl * 16 + r;
+    const int mc = min(m, B - 1);
+    const bool tail_wave = TAIL && work && slice == 0;    // wave-uniform
+
+    // the task's ids block (16 consecutive rows of F ints: contiguous) -> LDS with coalesced 16-byte loads, all in flight together
+    if (work) {
+        const int nint = 16 * A.F;
+        if (tl * 16 + 16 <= B && !((uintptr_t)ids_b & 15) && A.idp == A.F) {
+            const f32x4* src = reinterpret_cast<const f32x4*>(ids_b + (size_t)tl * nint);
+            f32x4* dst = reinterpret_cast<f32x4*>(ids_s);
+            for (int c = lane; c < nint / 4; c += 64) dst[c] = src[c];
+        } else {
+            for (int i = lane; i < nint; i += 64) {
+                const int s = i / A.F, col = i - s * A.F;
+                ids_s[s * A.idp + col] = ids_b[(size_t)min(tl * 16 + s, B - 1) * A.F + col];
+            }
+        }
+    }
+    // TAIL: this sample's numerics, K = 8 as two steps (k = q and q + 4); slot n_num carries 1.0 against fc0's bias (b0_slot), slots
+    // beyond duplicate a finite value that only ever meets zero weights.  Requested now, used after the slot loop.
+    float xna = 0.f, xnb = 0.f;
+    if constexpr (TAIL) {
+        if (tail_wave) {
+            const float* nrow = dense_b + (size_t)mc * A.ND;
+            const int last = A.n_num - 1;
+            xna = nrow[min(q, last)];
+            xnb = nrow[min(q + 4, last)];
+            xna = q == A.b0_slot ? 1.0f : xna;
+            xnb = q + 4 == A.b0_slot ? 1.0f : xnb;
+        }
+    }
+    // candidate: its row (for h * c), its vc row (the accumulators' start)
+    unsigned maxid = 0;                                   // the largest id seen (as unsigned: a negative id is huge): ONE range check at the end
+    df_h2 cch[NP], ccl[NP];                               // c' = c sH kappa of this lane's k = EL q + e, split into halfs, as pairs
+    f32x4 acc_init[2];
+    {
+        const unsigned cid = work ? (unsigned)ids_s[r * A.idp + A.cand_col] : 0u;   // (one wave: LDS operations complete in issue order)
+        maxid = cid;
+        const unsigned csafe = min(cid, (unsigned)A.vocab - 1u);
+        f32x4 cp[KC];
+#pragma unroll
+        for (int c = 0; c < KC; ++c) cp[c] = ld4(A.tsplit + csafe * (unsigned)KP + EL * q + 4 * c);
+        f16xe chi, clo;
+        unpack_halfs<KC>(cp, chi, clo);
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            // kappa is a power of two: both scalings are exact (up to f16's subnormal spacing, 2^-24 absolute against products of 2^14)
+            cch[j] = df_h2{(_Float16)((float)chi[2 * j] * A.kappa), (_Float16)((float)chi[2 * j + 1] * A.kappa)};
+            ccl[j] = df_h2{(_Float16)((float)clo[2 * j] * A.kappa), (_Float16)((float)clo[2 * j + 1] * A.kappa)};
+        }
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) acc_init[nb] = ld4(A.vc + csafe * (unsigned)HP + nb * 16 + 4 * q) * A.acc_scale;
+    }
+    // A fragments -> registers (the same eight for every slot)
+    f16xe aW[2][4];
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const f32x4 f = ld4(A.frag + ((nb * 4 + k) * 64 + lane) * 4);
+            if constexpr (KC == 2) aW[nb][k] = __builtin_bit_cast(f16xe, f);
+            else { const din_f16x8 both = __builtin_bit_cast(din_f16x8, f); aW[nb][k] = f16xe{both[0], both[1], both[2], both[3]}; }
+        }
+    // TAIL: fc0's embedding columns NOW, in the round trip the candidate's rows are on anyway -- folded rows F_g[id] straight into
+    // the accumulators' layout (lane (r,q): outputs 16 nb + 4q .. + 3 of sample r), two columns = 16 loads in flight at a time, summed
+    // in column order.  z0 waits in registers until the pooled history exists: the epilogue touches no global memory.
+    f32x4 z0[TAIL ? N0C : 1];
+    bool tbad = false;
+    int tid_g[DT_MAX_COLS];                               // the folded columns' ids: read now, gathered after the slot loop
+#pragma unroll
+    for (int g = 0; g < DT_MAX_COLS; ++g) tid_g[g] = -1;
+    if constexpr (TAIL) {
+        if (tail_wave) {
+#pragma unroll
+            for (int g = 0; g < DT_MAX_COLS; ++g) if (g < A.n_cols) tid_g[g] = ids_s[r * A.idp + A.col[g]];
+        }
+    }
+    // the first FOUR slots' rows are requested here, in the round trip the candidate's rows and the tables are on anyway (the ids are
+    // all they need) -- not after the barrier, where they were a round trip of their own in front of the first MFMA.  They are
+    // hidden loads like the loop's (below); the vmcnt(0) in front of the barrier lands them together with everything else.
+    f32x4 rowA[KC], rowB[KC], rowC[KC], rowD[KC];
+    const char* tbase = reinterpret_cast<const char*>(A.tsplit);
+    const unsigned qoff = (unsigned)(EL * 4) * (unsigned)q, vmax = (unsigned)A.vocab - 1u;
+    auto load = [&](int step, f32x4 (&rw)[KC]) {           // rows of slot t0 + step (clamped: steps past the end re-read the last slot)
+        const int tt = nsteps > 0 ? t0 + min(step, nsteps - 1) : 0;                 // (a wave without slots: slot 0, a valid id, never used)
+        const unsigned id = (unsigned)ids_s[r * A.idp + A.hist_col + tt];
+        maxid = max(maxid, id);
+        const unsigned voff = (min(id, vmax) << (KC == 2 ? 7 : 6)) | qoff;          // row bytes KP * 4; < 4 GiB (checked at finalize)
+        if constexpr (KC == 2)
+            asm volatile("global_load_dwordx4 %0, %2, %3\n\tglobal_load_dwordx4 %1, %2, %3 offset:16"
+                         : "=&v"(rw[0]), "=&v"(rw[1]) : "v"(voff), "s"(tbase));
+        else
+            asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(rw[0]) : "v"(voff), "s"(tbase));
+    };
+    load(0, rowA); load(1, rowB); load(2, rowC); load(3, rowD);   // (unconditional: no path on which these registers are anything else)
+    __builtin_amdgcn_s_waitcnt(0x0F70);                   // vmcnt(0): this wave's DMA pieces (and everything above) have landed
+    __syncthreads();                                      // tables staged by every wave
+
+    // ---- slot loop ----
+    float pacc[EL];
+#pragma unroll
+    for (int e = 0; e < EL; ++e) pacc[e] = 0.f;
+    const float one = 1.0f;
+    // park(j) retires local quarter j < nq - 1 (wave-uniform j) into the wave's two LDS slots (three times per task: registers are the
+    // scarcer resource of this kernel):
+    //   nq = 2: S0 = q0          nq = 4: S0 = q0; S1 = S0 + q1; S0 = q2          -- the wave's LAST quarter stays in pacc, and
+    //   finish: nq = 1: q        nq = 2: S0 + q1                 nq = 4: S1 + (S0 + q3)
+    float* S0 = park_s;
+    float* S1 = park_s + 64 * EL;
+    auto park = [&](int j) {
+        if ((j & 1) == 0) {
+#pragma unroll
+            for (int e = 0; e < EL; ++e) S0[e * 64 + lane] = pacc[e];
+        } else {
+#pragma unroll
+            for (int e = 0; e < EL; ++e) S1[e * 64 + lane] = S0[e * 64 + lane] + pacc[e];
+        }
+#pragma unroll
+        for (int e = 0; e < EL; ++e) pacc[e] = 0.f;
+    };
+    // ---- a pair of slots, first half: u = W12 h + W4 (h * c) + vc[cand] of both slots on the matrix pipe; h back to f32 ----
+    // PReLU(alpha[t][n]) -> Dense(1) (DIN.py:150-151) as ca u + cb |u| summed over this lane's eight units; the coefficient rows are
+    // wave-uniform LDS addresses (broadcast)
+    auto prelu_dot = [&](int t, const f32x4 (&uu)[2]) -> float {
+        if constexpr (XP & 8) return uu[0][0] + uu[1][1];
+        const int tc = min(t, ROWS - 1);
+        float sa = 0.f, sb = 0.f;
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+            const f32x4 ca = ld4(ca_s + tc * AS + nb * 16 + 4 * q);
+            const f32x4 cb = ld4(cb_s + tc * AS + nb * 16 + 4 * q);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                sa = fmaf(ca[j], uu[nb][j], sa);
+                sb = fmaf(cb[j], __builtin_fabsf(uu[nb][j]), sb);
+            }
+        }
+        return sa + sb;
+    };
+    // (slot a's partial logit is formed here, under slot b's MFMAs; slot b's units travel to the second half)
+    auto mfma_part = [&](int step, const f32x4 (&ra)[KC], const f32x4 (&rb)[KC], float& lga, f32x4 (&ub)[2], float (&h32)[2][EL]) {
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+            const f32x4 (&rw)[KC] = x ? rb : ra;
+            f16xe bh, bl;
+            unpack_halfs<KC>(rw, bh, bl);
+            f32x4 acc[2] = {acc_init[0], acc_init[1]};
+            // W12 . (hi + lo): independent of the product below -- the matrix pipe works while the VALU forms h * c
+            if constexpr (!(XP & 1)) {
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) acc[nb] = mfma_f16(aW[nb][0], bh, acc[nb]);
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) acc[nb] = mfma_f16(aW[nb][0], bl, acc[nb]);
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) acc[nb] = mfma_f16(aW[nb][1], bh, acc[nb]);
+            }
+            // h * c * sP, split: packed f16 arithmetic on the halfs (header)
+            f16xe qh = bh, ql = bl;
+            if constexpr (!(XP & 2)) {
+#pragma unroll
+            for (int j = 0; j < NP; ++j) {
+                const df_h2 hh = {bh[2 * j], bh[2 * j + 1]}, hl = {bl[2 * j], bl[2 * j + 1]};
+                const df_h2 ph = hh * cch[j];
+                df_h2 pl = __builtin_elementwise_fma(hh, cch[j], -ph);
+                pl = __builtin_elementwise_fma(hh, ccl[j], pl);
+                pl = __builtin_elementwise_fma(hl, cch[j], pl);
+                qh[2 * j] = ph[0]; qh[2 * j + 1] = ph[1];
+                ql[2 * j] = pl[0]; ql[2 * j + 1] = pl[1];
+            }
+            }
+            if constexpr (!(XP & 1)) {
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) acc[nb] = mfma_f16(aW[nb][2], qh, acc[nb]);
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) acc[nb] = mfma_f16(aW[nb][2], ql, acc[nb]);
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) acc[nb] = mfma_f16(aW[nb][3], qh, acc[nb]);
+            } else {
+                acc[0][0] += (float)qh[0] + (float)ql[1];
+                acc[1][1] += (float)bh[0] + (float)bl[1];
+            }
+            if (x == 0) lga = prelu_dot(t0 + step, acc);
+            else { ub[0] = acc[0]; ub[1] = acc[1]; }
+            // h back to f32 (sH units): one v_fma_mix_f32 per element (inputs: loaded registers; outputs go to compiler-visible VALU)
+#pragma unroll
+            for (int e = 0; e < EL; ++e) {
+                const float hp = KC == 2 ? rw[0][e >> 1] : rw[0][e >> 1];
+                const float lp = KC == 2 ? rw[KC - 1][e >> 1] : rw[0][2 + (e >> 1)];
+                if constexpr (XP & 4) h32[x][e] = hp;
+                else h32[x][e] = (e & 1) ? halfs_sum<true>(one, hp, lp) : halfs_sum<false>(one, hp, lp);
+            }
+        }
+    };
+    // ---- second half: slot b's partial logit, the pair's two partial logits reduced over the four 16-lane rows by a transposing
+    // swap ((row0 + row1) + (row2 + row3), rows4_sum's order), ONE sigmoid, one swap to hand both weights to every row, weighted
+    // sum pooling (DIN.py:152-158): this lane owns pooled[r][EL*q + e] ----
+    auto finish = [&](int step, float lga, const f32x4 (&ub)[2], const float (&h32)[2][EL]) {
+        float lg[2];
+        lg[0] = lga;
+        lg[1] = prelu_dot(t0 + step + 1, ub);
+        float wa, wb;
+        if constexpr (XP & 16) { wa = lg[0]; wb = lg[1]; } else {
+        float xx = lg[0], yy = lg[1];
+        asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(xx), "+v"(yy));   // xx = [a0 b0 a2 b2], yy = [a1 b1 a3 b3]
+        xx += yy;                                                                     // [a01 b01 a23 b23]
+        yy = xx;
+        asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(xx), "+v"(yy));   // xx = [a01 b01 a01 b01], yy = [a23 b23 a23 b23]
+        const float z = xx + yy;                                                      // rows 0, 2: slot a; rows 1, 3: slot b
+        wa = sigmoidf_fast(z * A.unscale + A.b2);                                     // PReLU is positively homogeneous: unscale the logit
+        wb = wa;
+        // (s_nop 1 also covers the one wait state a transcendental's result needs before a non-transcendental VALU reads it)
+        asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(wa), "+v"(wb));   // wa = [a a a a], wb = [b b b b]
+        }
+        wa = step < nsteps ? wa : 0.f;                                                // (a pair past the end: the pipeline's last, unused, round)
+        wb = step + 1 < nsteps ? wb : 0.f;                                            // the padding slot of an odd history
+        if constexpr (ATT) {
+            if (att && q == 0 && m < B) {
+                if (step < nsteps) att[(size_t)m * T + t0 + step] = wa;
+                if (step + 1 < nsteps) att[(size_t)m * T + t0 + step + 1] = wb;
+            }
+        }
+        if constexpr (XP & 32) {
+            pacc[0] += wa + wb;
+#pragma unroll
+            for (int e = 0; e < EL; ++e) pacc[1] += h32[0][e] + h32[1][e];
+        } else {
+#pragma unroll
+        for (int e = 0; e < EL; ++e) pacc[e] = fmaf(wa, h32[0][e], pacc[e]);
+#pragma unroll
+        for (int e = 0; e < EL; ++e) pacc[e] = fmaf(wb, h32[1][e], pacc[e]);
+        }
+    };
+    {
+        // at most N younger SETS outstanding => this set has landed (vmcnt retires in order; a set is KC loads).  No "memory" clobber:
+        // the statements are volatile (kept in order among themselves) and tied to their registers; nothing else in the loop loads from
+        // global memory, and stores only add YOUNGER operations -- so the compiler may move LDS reads and arithmetic across them
+        auto wait3 = [&](f32x4 (&rw)[KC]) {
+            if constexpr (KC == 2) asm volatile("s_waitcnt vmcnt(6)" : "+v"(rw[0]), "+v"(rw[1]));
+            else asm volatile("s_waitcnt vmcnt(3)" : "+v"(rw[0]));
+        };
+        auto wait2 = [&](f32x4 (&rw)[KC]) {
+            if constexpr (KC == 2) asm volatile("s_waitcnt vmcnt(4)" : "+v"(rw[0]), "+v"(rw[1]));
+            else asm volatile("s_waitcnt vmcnt(2)" : "+v"(rw[0]));
+        };
+        // every compiler-visible load of the prologue is "used" here, i.e. has landed before the hidden loads start (k_din_cols.h)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) asm volatile("" : "+v"(aW[nb][k]));
+            asm volatile("" : "+v"(acc_init[nb]));
+        }
+#pragma unroll
+        for (int j = 0; j < NP; ++j) { asm volatile("" : "+v"(cch[j])); asm volatile("" : "+v"(ccl[j])); }
+        if constexpr (TAIL) {
+            asm volatile("" : "+v"(xna));
+            asm volatile("" : "+v"(xnb));
+        }
+        // One trip = two pairs = four slots, straight-line: the four register sets of the ring keep their roles statically (an if / else
+        // on a round's parity made hipcc merge the two arms' tails and COPY row registers with loads still in flight; a loop per quarter
+        // inside a loop over the quarters made it copy them at the inner loop's entry -- scripts/r04/check_din_fused_isa.py walks the ISA
+        // of every instantiation for exactly that).  A quarter is a multiple of four slots, so a trip never straddles one; a history
+        // that ends inside a trip leaves slots whose weights are forced to zero.  Rows are requested two pairs ahead, as soon as the
+        // matrix half has consumed the set.  (A software-pipelined form -- the matrix half of pair i + 1 in one block with the VALU half
+        // of pair i -- measured 0.3 us SLOWER on the same box, 42.5 against 42.2 us per fused launch: profiles/r04)
+        f32x4 u0[2];
+        float l0 = 0.f;
+        float h0[2][EL];
+        int jq = 0, qnext = A.ql;                             // current local quarter, the first slot of the next one (wave-uniform)
+        for (int step = 0; step < nsteps; step += 4) {
+            if (step == qnext) { park(jq); ++jq; qnext += A.ql; }
+            if constexpr (!(XP & 64)) { wait3(rowA); wait2(rowB); }
+            mfma_part(step, rowA, rowB, l0, u0, h0);
+            if constexpr (!(XP & 64)) { load(step + 4, rowA); load(step + 5, rowB); }
+            finish(step, l0, u0, h0);
+            if constexpr (!(XP & 64)) { wait3(rowC); wait2(rowD); }
+            mfma_part(step + 2, rowC, rowD, l0, u0, h0);
+            if constexpr (!(XP & 64)) { load(step + 6, rowC); load(step + 7, rowD); }
+            finish(step + 2, l0, u0, h0);
+        }
+        for (; jq < nq - 1; ++jq) park(jq);                    // quarters without slots hold exact zeros: retired the same way
+        // nothing may still be in flight towards these registers when they are reused
+        if constexpr (KC == 2)
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(rowA[0]), "+v"(rowA[1]), "+v"(rowB[0]), "+v"(rowB[1]), "+v"(rowC[0]), "+v"(rowC[1]),
+                         "+v"(rowD[0]), "+v"(rowD[1]));
+        else
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(rowA[0]), "+v"(rowB[0]), "+v"(rowC[0]), "+v"(rowD[0]));
+    }
+    float res[EL];
+    if (nq == 1) {
+#pragma unroll
+        for (int e = 0; e < EL; ++e) res[e] = pacc[e];
+    } else if (nq == 2) {
+#pragma unroll
+        for (int e = 0; e < EL; ++e) res[e] = S0[e * 64 + lane] + pacc[e];
+    } else {
+#pragma unroll
+        for (int e = 0; e < EL; ++e) res[e] = S1[e * 64 + lane] + (S0[e * 64 + lane] + pacc[e]);
+    }
+    // ---- several waves per task: their results through LDS, slice 0 sums in the fixed order ----
+    if (A.ts > 1) {
+        if (slice != 0) {
+#pragma unroll
+            for (int e = 0; e < EL; ++e) S0[e * 64 + lane] = res[e];           // (a wave's S0 is free by now)
+        }
+        __syncthreads();
+        if (slice == 0) {
+            const float* P = park_s + 2 * 64 * EL;           // the next wave's S0
+            if (A.ts == 2) {
+#pragma unroll
+                for (int e = 0; e < EL; ++e) res[e] = res[e] + P[e * 64 + lane];
+            } else {
+#pragma unroll
+                for (int e = 0; e < EL; ++e)
+                    res[e] = (res[e] + P[e * 64 + lane]) + (P[2 * 64 * EL + e * 64 + lane] + P[4 * 64 * EL + e * 64 + lane]);
+            }
+        }
+    }
+    const bool bad = (work && maxid >= (unsigned)A.vocab) || tbad;
+    if (__ballot(bad) != 0 && lane == 0) atomicOr(err, 1);
+    if (!(work && slice == 0)) return;
+
+    if constexpr (!TAIL) {
+        if (m < B) {
+            float* prow = out_b + (size_t)m * A.Dp + EL * q;
+            if (A.Dp == KP) {                                     // (wave-uniform) full-width rows: this lane's EL floats as 16-byte stores
+#pragma unroll
+                for (int c = 0; c < KC; ++c)
+                    st4(prow + 4 * c, f32x4{res[4 * c] * A.inv_h_scale, res[4 * c + 1] * A.inv_h_scale, res[4 * c + 2] * A.inv_h_scale, res[4 * c + 3] * A.inv_h_scale});
+            } else {
+#pragma unroll
+                for (int e = 0; e < EL; ++e)
+                    if (EL * q + e < A.Dp) prow[e] = res[e] * A.inv_h_scale;
+            }
+        }
+        return;
+    } else {
+        // ================= the tail (DIN.py:161-167) for this wave's sixteen samples: registers and LDS only =================
+        // the numeric chunk: A = W0^T[n][numeric q + 4 s] (one scalar LDS read per block and step), two f32 MFMAs per 16 outputs on
+        // top of the embedding columns' sum; fc0's bias rides in numeric slot b0_slot against a constant 1 (else it is added here)
+        {
+            // fc0's embedding columns: folded rows straight into the accumulators' layout (lane (r,q): outputs 16 nb + 4q .. + 3 of
+            // sample r), two columns = 16 loads in flight at a time
+#pragma unroll
+            for (int nb = 0; nb < N0C; ++nb) z0[nb] = zero;
+            bool tb2 = false;
+            {
+                // (all four columns = 32 loads in ONE round trip: the slot loop's registers are free by now)
+                f32x4 f[DT_MAX_COLS][N0C];
+#pragma unroll
+                for (int g = 0; g < DT_MAX_COLS; ++g) {
+                    const int id = tid_g[g];
+                    const bool ok = g < A.n_cols && (unsigned)id < (unsigned)A.tvocab[g];
+                    tb2 |= g < A.n_cols && !ok && id != -1;
+                    const float* frow = A.Ftab[g] + (size_t)(ok ? id : 0) * IM::N0 + 4 * q;
+#pragma unroll
+                    for (int nb = 0; nb < N0C; ++nb) f[g][nb] = ok ? ld4(frow + nb * 16) : zero;
+                }
+#pragma unroll
+                for (int g = 0; g < DT_MAX_COLS; ++g)
+#pragma unroll
+                    for (int nb = 0; nb < N0C; ++nb) z0[nb] += f[g][nb];
+            }
+            if (__ballot(tb2) != 0 && lane == 0) atomicOr(err, 1);
+        }
+        {
+            const float* wn = img_s + IM::off_wn + lane;
+#pragma unroll
+            for (int nb = 0; nb < N0C; ++nb) z0[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wn[(nb * 2 + 0) * 64], xna, z0[nb], 0, 0, 0);
+#pragma unroll
+            for (int nb = 0; nb < N0C; ++nb) z0[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wn[(nb * 2 + 1) * 64], xnb, z0[nb], 0, 0, 0);
+            if (A.b0_slot < 0) {
+#pragma unroll
+                for (int nb = 0; nb < N0C; ++nb) z0[nb] += ld4(img_s + IM::off_b0 + nb * 16 + 4 * q);
+            }
+        }
+        // the pooled history on the f16 pipe, from the registers it was accumulated in (k = EL q + e): per-sample dynamic scale
+        // (DIN's attention weights are not normalised), hi / lo split, three products per 16 outputs
+        {
+            float xp[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) xp[e] = e < EL ? res[e < EL ? e : 0] * A.inv_h_scale : 0.f;
+            float mx = 0.f;
+#pragma unroll
+            for (int e = 0; e < EL; ++e) mx = fmaxf(mx, __builtin_fabsf(xp[e]));
+            mx = rows4_max(mx);
+            float scale, inv;
+            dyn_scale(mx, A.inv_w0p_scale, scale, inv);
+            din_f16x8 bh, bl;
+            df_split8(f32x4{xp[0], xp[1], xp[2], xp[3]}, f32x4{xp[4], xp[5], xp[6], xp[7]}, scale, bh, bl);
+            const float* wf = img_s + IM::off_w0p + lane * 4;
+#pragma unroll
+            for (int nb = 0; nb < N0C; ++nb) {
+                const din_f16x8 ah = __builtin_bit_cast(din_f16x8, ld4(wf + nb * 512));
+                const din_f16x8 al = __builtin_bit_cast(din_f16x8, ld4(wf + nb * 512 + 256));
+                f32x4 acc = mfma_f16(al, bh, zero);
+                acc = mfma_f16(ah, bl, acc);
+                acc = mfma_f16(ah, bh, acc);
+                z0[nb] += acc * inv;
+            }
+        }
+        // PReLU(alpha0) (DIN.py:164)
+#pragma unroll
+        for (int nb = 0; nb < N0C; ++nb) {
+            const f32x4 al = ld4(img_s + IM::off_a0 + nb * 16 + 4 * q);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float uu = z0[nb][j];
+                z0[nb][j] = fmaf(al[j], fminf(uu, 0.f), fmaxf(uu, 0.f));
+            }
+        }
+        // fc1 on split f16 (dyn_split.h's K-block layout: chunks 2b, 2b + 1 of h1 are block b's operand as they sit in the registers)
+        f32x4 z1[N1C];
+        {
+            float mx = 0.f;
+#pragma unroll
+            for (int nb = 0; nb < N0C; ++nb)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) mx = fmaxf(mx, __builtin_fabsf(z0[nb][j]));
+            mx = rows4_max(mx);
+            float scale, inv;
+            dyn_scale(mx, A.inv_w1_scale, scale, inv);
+            f32x4 acc[N1C];
+#pragma unroll
+            for (int n1 = 0; n1 < N1C; ++n1) acc[n1] = zero;
+            const float* wf = img_s + IM::off_w1 + (r * 4 + q) * 4;          // this lane's 16 bytes inside a 1-KB fragment (k_dyn_pack_w)
+#pragma unroll
+            for (int b = 0; b < N0C / 2; ++b) {
+                din_f16x8 bh, bl;
+                df_split8(z0[2 * b], z0[2 * b + 1], scale, bh, bl);
+#pragma unroll
+                for (int n1 = 0; n1 < N1C; ++n1) {
+                    const din_f16x8 ah = __builtin_bit_cast(din_f16x8, ld4(wf + ((n1 * (N0C / 2) + b) * 2 + 0) * 256));
+                    const din_f16x8 al = __builtin_bit_cast(din_f16x8, ld4(wf + ((n1 * (N0C / 2) + b) * 2 + 1) * 256));
+                    acc[n1] = mfma_f16(ah, bh, acc[n1]);
+                    acc[n1] = mfma_f16(ah, bl, acc[n1]);
+                    acc[n1] = mfma_f16(al, bh, acc[n1]);
+                }
+            }
+#pragma unroll
+            for (int n1 = 0; n1 < N1C; ++n1) z1[n1] = acc[n1] * inv + ld4(img_s + IM::off_b1 + n1 * 16 + 4 * q);
+        }
+        // PReLU(alpha1) (DIN.py:166) -> Dense(1) -> sigmoid (DIN.py:167)
+        float z = 0.f;
+#pragma unroll
+        for (int n1 = 0; n1 < N1C; ++n1) {
+            const f32x4 al = ld4(img_s + IM::off_a1 + n1 * 16 + 4 * q);
+            const f32x4 hw = ld4(img_s + IM::off_hw + n1 * 16 + 4 * q);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float uu = z1[n1][j];
+                const float h2 = fmaf(al[j], fminf(uu, 0.f), fmaxf(uu, 0.f));
+                z = fmaf(hw[j], h2, z);
+            }
+        }
+        z = rows4_sum(z);
+        if (q == 0 && m < B) out_b[m] = sigmoidf_acc(z + A.head_bias);
+    }
+}

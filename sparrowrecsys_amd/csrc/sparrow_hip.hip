@@ -47,6 +47,7 @@
 #include "dyn_split.h"
 #include "k_din_cols.h"
 #include "k_din_tail.h"
+#include "k_din_fused.h"
 #include "k_chain_v1.h"
 #include "k_mlp_rows.h"
 #include "k_emb_rank.h"

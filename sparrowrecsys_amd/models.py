@@ -716,6 +716,16 @@ class DeepFM(CTRModel):
     def _id_columns(self):
         return [IdColumn(k, kind, v) for k, kind, v in self.fields]
 
+    def set_weights(self, weights):
+        # a round-2 weight dict (or a converter that only knows emb/<key>) has no deep_emb/<key>: say what that means instead of
+        # "missing weight" -- tied tables are a choice the caller makes, the oracle follows the same rule
+        if not self.share_deep_tables:
+            missing = ["deep_emb/" + k for k in self.deep_emb if "deep_emb/" + k not in weights]
+            if missing:
+                raise KeyError("missing weight %r: DeepFM.py's deep part owns its own movieId / userId tables (DeepFM.py:106); "
+                               "construct the model with share_deep_tables=True to tie them to emb/<key>" % missing[0])
+        super().set_weights(weights)
+
     def _deep_rows(self):
         names = [k + "_embedding" for k in self.deep_emb] + list(self.numeric_keys)
         widths = {k + "_embedding": self.emb_dim for k in self.deep_emb}

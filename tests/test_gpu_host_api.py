@@ -72,7 +72,7 @@ def test_din_workspace_is_validated(torch):
 
 
 @pytest.mark.parametrize("name,kernel,stage", [
-    ("deepfm_v2_c2", "k_deepfm_v2_joint", ""), ("deepfm_c2", "k_deepfm_pairs", ""), ("din_c3", "k_din_tail", "k_din_attn"),
+    ("deepfm_v2_c2", "k_deepfm_v2_joint", ""), ("deepfm_c2", "k_deepfm_pairs", ""), ("din_c3", "k_din_fused", "k_din_fused"),
     ("embedding_mlp", "k_mlp_rows", ""), ("dien", "k_din_tail", "k_dien_seq_mfma")])
 def test_describe_reports_the_dispatched_kernels(torch, name, kernel, stage):
     if name == "deepfm_v2_c2":

@@ -185,9 +185,11 @@ def test_din_attention_kernel_shapes(torch, monkeypatch, T, D, B):
     V, U = 5000, 700
     feats = SY.synth_din(B, T, V, U, seed=100 + T + D)
     got = {}
-    for legacy in ("0", "wave", "1"):                               # k_din_attn_cols / k_din_attn (wave per sample) / k_din_pool
+    modes = ("0", "cols", "wave", "1")                              # k_din_fused / k_din_attn_cols + k_din_tail / k_din_attn (wave per sample) / k_din_pool
+    for legacy in modes:
         monkeypatch.setenv("SPRK_DIN_LEGACY", "1" if legacy == "1" else "0")
         monkeypatch.setenv("SPRK_DIN_COLS", "0" if legacy == "wave" else "1")
+        monkeypatch.setenv("SPRK_DIN_FUSED", "1" if legacy == "0" else "0")
         model = M.DIN(seed=50 + T, emb_dim=D, hist_len=T, movie_buckets=V, user_buckets=U)
         ids, dense = model.pack(feats)
         eng = model.engine
@@ -201,7 +203,7 @@ def test_din_attention_kernel_shapes(torch, monkeypatch, T, D, B):
         eng.close()
     ref, parts = O.din_forward(feats, model.weights, dtype=np.float64, hist_len=T, movie_buckets=V, user_buckets=U,
                                return_parts=True)
-    for legacy in ("0", "wave", "1"):
+    for legacy in modes:
         a, p, sc = got[legacy]
         assert np.isfinite(a).all() and np.isfinite(p).all()
         assert np.abs(a - parts["att"]).max() <= TIGHT
@@ -210,6 +212,8 @@ def test_din_attention_kernel_shapes(torch, monkeypatch, T, D, B):
         assert np.abs(sc - ref[:, 0]).max() <= TOL
     assert np.abs(got["0"][0] - got["1"][0]).max() <= 2e-6      # two summation orders of the same fp32 math
     assert np.abs(got["0"][0] - got["wave"][0]).max() <= 2e-6
+    assert np.abs(got["0"][0] - got["cols"][0]).max() <= 2e-6
+    assert np.abs(got["0"][2] - got["cols"][2]).max() <= 3e-6     # the whole forward: one launch against attention -> pooled -> tail
 
 
 @pytest.mark.parametrize("T,D", [(50, 32), (5, 10), (23, 16)])
@@ -234,6 +238,46 @@ def test_din_cols_result_does_not_depend_on_the_launch_shape(torch, T, D):
     _, parts = O.din_forward({k: v[:2048] for k, v in feats.items()}, model.weights, dtype=np.float64, hist_len=T, movie_buckets=V,
                              user_buckets=U, return_parts=True)
     assert np.abs(full[:2048, :D].cpu().numpy() - parts["pooled"]).max() <= TIGHT
+
+
+@pytest.mark.parametrize("T,D,B", [(50, 32, 4099), (12, 10, 1000), (23, 16, 37), (64, 32, 600)])
+def test_din_fused_scores_do_not_depend_on_the_launch_shape(torch, monkeypatch, T, D, B):
+    """k_din_fused (attention + pooling + tail in ONE launch, DIN.py:132-167): the same bits whether a task's history is walked by one,
+    two or four waves (SPRK_DIN_COLS_TS), for a slice of the batch, and in the several-batches-per-launch form; <= 3e-6 from the
+    two-launch path (k_din_fused<TAIL = false> -> pooled vectors -> k_din_tail) and within the bar of the fp64 oracle; an id outside
+    a tail column's table (userId) is flagged like one outside the history's."""
+    V, U = 5000, 700
+    feats = SY.synth_din(B, T, V, U, seed=400 + T)
+    feats["movieGenre1"][::5] = -1                                  # no id: the all-zero row of the folded table
+    got = {}
+    for tag, env in (("ts1", {"SPRK_DIN_COLS_TS": "1"}), ("ts2", {"SPRK_DIN_COLS_TS": "2"}), ("ts4", {"SPRK_DIN_COLS_TS": "4"}),
+                     ("auto", {"SPRK_DIN_COLS_TS": "0"}), ("two", {"SPRK_DIN_COLS_TS": "0", "SPRK_DIN_FUSED": "0"})):
+        monkeypatch.setenv("SPRK_DIN_FUSED", "1")
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        model = M.DIN(seed=90 + T, emb_dim=D, hist_len=T, movie_buckets=V, user_buckets=U)
+        assert model.engine.describe()["kernel"].startswith("k_din_fused" if tag != "two" else "k_din_tail")
+        ids, dense = model.pack(feats)
+        ti, td = _cuda(torch, ids), _cuda(torch, dense)
+        full = model.predict_device(ti, td)
+        model.engine.check_ids()
+        got[tag] = full.cpu().numpy()
+        if tag == "auto":
+            lo, hi = B // 3, B // 3 + min(B // 2, 513)
+            assert torch.equal(model.predict_device(ti[lo:hi].contiguous(), td[lo:hi].contiguous()), full[lo:hi])
+            bad = ids.copy()
+            bad[B // 2, 1 + T] = U + 3                                               # userId (columns: candidate, T history slots, userId, two genres): one of the tail's folded columns
+            eng = model.engine
+            eng.forward(_cuda(torch, bad), td, torch.empty(B, dtype=torch.float32, device="cuda"),
+                        torch.empty(eng.workspace_bytes(B) // 4, dtype=torch.float32, device="cuda"))
+            with pytest.raises(ValueError):
+                eng.check_ids()
+        model.engine.close()
+    for tag in ("ts2", "ts4", "auto"):
+        np.testing.assert_array_equal(got[tag], got["ts1"])
+    assert np.abs(got["ts1"] - got["two"]).max() <= 3e-6
+    ref = O.din_forward(feats, model.weights, dtype=np.float64, hist_len=T, movie_buckets=V, user_buckets=U)[:, 0]
+    assert np.abs(got["ts1"] - ref).max() <= TIGHT
 
 
 def test_din_attention_kernel_bad_ids_raise(torch):
@@ -571,7 +615,8 @@ def test_din_tail_paths(torch, monkeypatch, T, D, B):
     V, U = SY.ML20M_MOVIE_IDS if D == 32 else 4000, SY.ML20M_USER_IDS if D == 32 else 900
     feats = SY.synth_din(B, T, V, U, seed=21)
     out = {}
-    for tag, env in (("chain", {"SPRK_TILE_FOLD": "1", "SPRK_DIN_TAIL": "1", "SPRK_DYN_F16": "1"}),
+    for tag, env in (("fused", {"SPRK_TILE_FOLD": "1", "SPRK_DIN_TAIL": "1", "SPRK_DYN_F16": "1", "SPRK_DIN_FUSED": "1"}),     # k_din_fused (one launch)
+                     ("chain", {"SPRK_TILE_FOLD": "1", "SPRK_DIN_TAIL": "1", "SPRK_DYN_F16": "1", "SPRK_DIN_FUSED": "0"}),     # attention -> pooled -> k_din_tail
                      ("chain_f32", {"SPRK_TILE_FOLD": "1", "SPRK_DIN_TAIL": "1", "SPRK_DYN_F16": "0"}),
                      ("fold", {"SPRK_TILE_FOLD": "1", "SPRK_DIN_TAIL": "0"}),
                      ("plain", {"SPRK_TILE_FOLD": "0", "SPRK_DIN_TAIL": "0"})):
@@ -583,6 +628,8 @@ def test_din_tail_paths(torch, monkeypatch, T, D, B):
     for tag in out:
         assert np.abs(out[tag] - ref).max() <= TOL, tag
     assert np.abs(out["chain"] - out["plain"]).max() <= TIGHT
+    assert np.abs(out["fused"] - out["plain"]).max() <= TIGHT
+    assert np.abs(out["fused"] - out["chain"]).max() <= 3e-6
     assert np.abs(out["chain_f32"] - out["plain"]).max() <= TIGHT
     assert np.abs(out["fold"] - out["plain"]).max() <= TIGHT
 
@@ -647,7 +694,7 @@ def test_deepfm_pairs_kernel_vs_interpreter_and_oracle(torch, monkeypatch, shape
         out[chain] = model.predict(feats)[:, 0]
     assert ("deep_emb/movieId" in model.weights) != tied
     kw = {} if fields is None else {"fields": fields, "pairs": pairs}
-    ref = O.deepfm_forward(feats, model.weights, dtype=np.float64, **kw)[:, 0]
+    ref = O.deepfm_forward(feats, model.weights, dtype=np.float64, share_deep_tables=tied, **kw)[:, 0]
     assert np.abs(out["1"] - ref).max() <= TIGHT
     assert np.array_equal(out["1"], out["1loop"]), "one-task and looped kernels differ by %g" % np.abs(out["1"] - out["1loop"]).max()
     assert np.abs(out["1f32"] - ref).max() <= TIGHT
@@ -832,10 +879,15 @@ def test_forward_many_several_batches_per_launch_pairs(torch, shape, B, n, k):
     assert np.abs(res[k][-1] - ref).max() <= TIGHT
 
 
+@pytest.mark.parametrize("mode", ["two_launch", "fused"])
 @pytest.mark.parametrize("Bd,n,k,streams", [(2049, 5, 4, 0), (4096, 9, 16, 0), (1000, 7, 3, 2), (16, 4, 2, 2)])
-def test_forward_many_several_batches_per_launch_din(torch, Bd, n, k, streams):
-    """DIN with sprk_set_many_batches(k): the group's k_din_attn launches, then ONE k_din_tail launch for the k batches (a workspace
-    slice per batch of the group; groups alternate over the helper streams when slices allow): bit-identical scores."""
+def test_forward_many_several_batches_per_launch_din(torch, monkeypatch, Bd, n, k, streams, mode):
+    """DIN with sprk_set_many_batches(k), bit-identical to a launch per batch in both forms: two_launch = the group's attention launch,
+    then ONE k_din_tail launch for the k batches (a workspace slice per batch of the group; groups alternate over the helper streams
+    when slices allow) against attention + tail per batch (SPRK_DIN_FUSED=0); fused = k_din_fused<MB> walking the k batches' tasks as
+    one grid (SPRK_DIN_FUSED_MB=1) against one k_din_fused launch per batch -- other (task, time slice) shapes, same bits."""
+    monkeypatch.setenv("SPRK_DIN_FUSED", "0" if mode == "two_launch" else "1")
+    monkeypatch.setenv("SPRK_DIN_FUSED_MB", "0" if mode == "two_launch" else "1")
     T = 50
     din = M.DIN(seed=59, emb_dim=32, hist_len=T, movie_buckets=5000, user_buckets=7000)
     eng = din.engine
@@ -1021,6 +1073,7 @@ def test_tail_with_raw_embedding_rows_equals_the_folded_tail(torch, monkeypatch,
     V, U, B = 3000, 900, 20011
     feats = SY.synth_din(B, T, V, U, seed=77 + T)
     feats["userGenre1"][::7] = -1                                   # no id: the all-zero row
+    monkeypatch.setenv("SPRK_DIN_FUSED", "0")                       # (k_din_tail itself: the two-launch path)
     out = {}
     for sw in ("1", "0"):
         monkeypatch.setenv("SPRK_TAIL_UNF", sw)

@@ -59,7 +59,7 @@ def _check(torch, name, B, expect_kernel, sample=SAMPLE):
 
 
 def test_config3_din_at_stated_size(torch):
-    _check(torch, "din_c3", 32768, "k_din_tail")
+    _check(torch, "din_c3", 32768, "k_din_fused")
 
 
 def test_config4_deepfm_v2_27m_row_table(torch):

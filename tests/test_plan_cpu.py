@@ -46,6 +46,25 @@ def test_config2_deepfm_pairs_shape():
     np.testing.assert_allclose(got, ref, atol=2e-7)
 
 
+def test_deepfm_without_deep_tables_names_the_switch():
+    """a weight dict without deep_emb/<key> (a round-2 dict, a converter that only knows emb/<key>) is an error that
+    names share_deep_tables in the model AND in the oracle; with the switch both tie the deep part to emb/<key> and agree."""
+    B = 300
+    feats = SY.synth_fields(B, SY.CONFIG2_FIELDS, seed=6)
+    full = M.DeepFM(seed=24, emb_dim=16, fields=SY.CONFIG2_FIELDS, pairs=SY.CONFIG2_PAIRS)
+    old = {k: v for k, v in full.weights.items() if not k.startswith("deep_emb/")}
+    with pytest.raises(KeyError, match="share_deep_tables"):
+        M.DeepFM(weights=old, emb_dim=16, fields=SY.CONFIG2_FIELDS, pairs=SY.CONFIG2_PAIRS)
+    with pytest.raises(KeyError, match="share_deep_tables"):
+        O.deepfm_forward(feats, old, fields=SY.CONFIG2_FIELDS, pairs=SY.CONFIG2_PAIRS)
+    tied = M.DeepFM(weights=old, emb_dim=16, fields=SY.CONFIG2_FIELDS, pairs=SY.CONFIG2_PAIRS, share_deep_tables=True)
+    plan, slots = tied.build_plan()
+    ids, dense = tied.pack(feats)
+    got = run_plan(plan, slots, ids, dense, np.float64)
+    ref = O.deepfm_forward(feats, old, dtype=np.float64, fields=SY.CONFIG2_FIELDS, pairs=SY.CONFIG2_PAIRS, share_deep_tables=True)[:, 0]
+    np.testing.assert_allclose(got, ref, atol=2e-7)
+
+
 def test_config3_din_shape():
     B, T, D = 256, 50, 32
     feats = SY.synth_din(B, T, 5000, 7000, seed=5)

@@ -68,7 +68,9 @@ def test_the_wiring_pin_is_sensitive(samples):
     g = _fixture("shim", "deepfm")
     w = dict(_model("deepfm", g).weights)
     tied = {k: v for k, v in w.items() if not k.startswith("deep_emb/")}
-    assert np.abs(O.deepfm_forward(samples, tied)[:, 0] - g["pred"]).max() > 1e-3
+    assert np.abs(O.deepfm_forward(samples, tied, share_deep_tables=True)[:, 0] - g["pred"]).max() > 1e-3
+    with pytest.raises(KeyError, match="share_deep_tables"):          # never a silent fallback
+        O.deepfm_forward(samples, tied)
     # (2) DeepFM.py:111-112: the four dots enter the head in the order item.user, itemGenre.userGenre, itemGenre.user, item.userGenre
     hk = w["head/kernel"].copy()
     n_fo = 31040
