@@ -156,7 +156,8 @@ int sprk_finalize(sprk_handle h) {
             // static scales from max|E| and the weights' row sums; non-finite weights keep the lane-per-sample kernel
             const size_t fl = s.emb_dim == 10 ? DienFrag<10, 32>::total_pad : DienFrag<16, 32>::total_pad;
             const size_t ok_at = s.emb_dim == 10 ? DienFrag<10, 32>::S_OK : DienFrag<16, 32>::S_OK;
-            unsigned* d_max = nullptr;
+            DevProbe d_max_probe;
+            unsigned*& d_max = d_max_probe.p;
             HIP_TRY(hipMalloc((void**)&d_max, sizeof(unsigned)));
             HIP_TRY(hipMemset(d_max, 0, sizeof(unsigned)));
             hipLaunchKernelGGL(k_v2_absmax, dim3(1024), dim3(256), 0, 0, d.table, (long long)s.vocab, s.row_stride, s.row_stride, d_max);
@@ -166,7 +167,6 @@ int sprk_finalize(sprk_handle h) {
             HIP_TRY(hipGetLastError());
             float ok = 0.f;
             HIP_TRY(hipMemcpy(&ok, h->dien_frag + ok_at, sizeof(float), hipMemcpyDeviceToHost));
-            (void)hipFree(d_max);
             if (ok != 1.f) { (void)hipFree(h->dien_frag); h->dien_frag = nullptr; }
         }
     } else if (p.din.enabled) {
@@ -221,7 +221,8 @@ int sprk_finalize(sprk_handle h) {
                 float h_scale = 1.f, a_scale = 1.f;
                 if (dv.half) {
                     // power-of-two scales from max|E|, max|W12|, max|W4|: |A_b| <= max|W12| + max|W4| max|E|
-                    unsigned* d_max = nullptr;
+                    DevProbe d_max_probe;
+                    unsigned*& d_max = d_max_probe.p;
                     HIP_TRY(hipMalloc((void**)&d_max, 3 * sizeof(unsigned)));
                     HIP_TRY(hipMemset(d_max, 0, 3 * sizeof(unsigned)));
                     long long nb_ = ((long long)s.vocab * s.row_stride + 255) / 256;
@@ -232,7 +233,6 @@ int sprk_finalize(sprk_handle h) {
                     HIP_TRY(hipGetLastError());
                     unsigned bits[3];
                     HIP_TRY(hipMemcpy(bits, d_max, sizeof(bits), hipMemcpyDeviceToHost));
-                    (void)hipFree(d_max);
                     float mx[3];
                     memcpy(mx, bits, sizeof(mx));
                     if (!(mx[0] < 3.0e38f) || !(mx[1] < 3.0e38f) || !(mx[2] < 3.0e38f)) { want_half = false; v = (size_t)-1; continue; }   // NaN / Inf weights: rescan for the f32 kernel
@@ -286,13 +286,13 @@ int sprk_finalize(sprk_handle h) {
                         const float rho = 32768.0f / h_scale;        // s4 / a_scale
                         float w4max = 0.f;
                         {
-                            unsigned* d_m = nullptr;
+                            DevProbe d_m_probe;
+                            unsigned*& d_m = d_m_probe.p;
                             HIP_TRY(hipMalloc((void**)&d_m, sizeof(unsigned)));
                             HIP_TRY(hipMemset(d_m, 0, sizeof(unsigned)));
                             hipLaunchKernelGGL(k_v2_absmax, dim3(4), dim3(256), 0, 0, h->din_w4, (long long)s.hidden, KP, KP, d_m);
                             unsigned bits = 0;
                             HIP_TRY(hipMemcpy(&bits, d_m, sizeof(bits), hipMemcpyDeviceToHost));
-                            (void)hipFree(d_m);
                             memcpy(&w4max, &bits, sizeof(w4max));    // max |W4| a_scale
                         }
                         const float w4s = w4max * rho;

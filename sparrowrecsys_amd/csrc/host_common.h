@@ -23,6 +23,16 @@ int fail(int code, const char* fmt, ...) {
     } while (0)
 
 // ---- roctx ranges around the C ABI's entry points ("roctx ranges in the C-ABI") ----
+// A finalize-time probe buffer (an abs-max word, a flag): freed on EVERY way out of its scope, also when a HIP_TRY in between returns
+// (the early returns between hipMalloc and hipFree leaked it).
+struct DevProbe {
+    unsigned* p = nullptr;
+    ~DevProbe() { if (p) (void)hipFree(p); }
+    DevProbe() = default;
+    DevProbe(const DevProbe&) = delete;
+    DevProbe& operator=(const DevProbe&) = delete;
+};
+
 // SPRK_ROCTX=1 binds rocprofiler-sdk's roctx at first use (dlopen: no link-time dependency) and every forward / ingest /
 // exchange call then shows up as a named range in `rocprofv3 --marker-trace`; otherwise the cost is one predictable branch.
 struct Roctx {

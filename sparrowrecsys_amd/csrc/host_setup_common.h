@@ -177,13 +177,13 @@ int make_dyn_fragments(sprk_engine* h, const float* W, int ld, int N, int K, flo
     *frag = nullptr;
     if (kvalid < 0) kvalid = K;
     if (!h->tune.dyn_f16 || (N & 15) || (K & 31) || kvalid < 1 || kvalid > K) return SPRK_OK;
-    unsigned* d_max = nullptr;
+    DevProbe d_max_probe;
+    unsigned*& d_max = d_max_probe.p;
     HIP_TRY(hipMalloc((void**)&d_max, sizeof(unsigned)));
     HIP_TRY(hipMemset(d_max, 0, sizeof(unsigned)));
     hipLaunchKernelGGL(k_v2_absmax, dim3(8), dim3(256), 0, 0, W, (long long)N, ld, kvalid, d_max);
     unsigned bits = 0;
     HIP_TRY(hipMemcpy(&bits, d_max, sizeof(bits), hipMemcpyDeviceToHost));
-    (void)hipFree(d_max);
     float mx;
     memcpy(&mx, &bits, sizeof(mx));
     if (!(mx < 3.0e38f)) return SPRK_OK;

@@ -139,15 +139,16 @@ int setup_din_tail(sprk_engine* h, DevPlan* dp) {
         // one static scale for all columns' rows; an outlier row keeps the folded tables
         float mx = 0.f;
         if (ok) {
-            unsigned* d_max = nullptr;
+            DevProbe d_max_probe;
+            unsigned*& d_max = d_max_probe.p;
             HIP_TRY(hipMalloc((void**)&d_max, sizeof(unsigned)));
             HIP_TRY(hipMemset(d_max, 0, sizeof(unsigned)));
             for (int g = 0; g < dp->n_acc; ++g)
                 hipLaunchKernelGGL(k_v2_absmax, dim3(256), dim3(256), 0, 0, (const float*)h->slot_ptr[raw[g]->slot], (long long)raw[g]->vocab,
                                    raw[g]->row_stride, 4 * raw[g]->count, d_max);
+            HIP_TRY(hipGetLastError());
             unsigned bits = 0;
             HIP_TRY(hipMemcpy(&bits, d_max, sizeof(bits), hipMemcpyDeviceToHost));
-            (void)hipFree(d_max);
             memcpy(&mx, &bits, sizeof(mx));
             ok = mx < 3.0e38f;
             for (int g = 0; g < dp->n_acc && ok; ++g) {
@@ -201,6 +202,7 @@ int setup_din_tail(sprk_engine* h, DevPlan* dp) {
                     if (nbk > 0)
                         hipLaunchKernelGGL(k_rows_unf_split, dim3((unsigned)nbk), dim3(256), 0, 0, (const float*)h->slot_ptr[raw[g]->slot], raw[g]->row_stride,
                                            rows, e_scale, reinterpret_cast<_Float16*>(et), epb);
+                    HIP_TRY(hipGetLastError());
                     r.Etab[g] = reinterpret_cast<const _Float16*>(et);
                 }
                 for (int g = dp->n_acc; g < DT_MAX_COLS; ++g) r.Etab[g] = r.Etab[0];

@@ -231,7 +231,8 @@ int setup_deepfm_pairs(sprk_engine* h) {
     {
         // static scale for deep0's embedding block: max |E| over the deep fields' tables, unless a table has outlier rows
         if (r.w0frag && h->tune.v1_static_scale) {
-            unsigned* d_max = nullptr;
+            DevProbe d_max_probe;
+            unsigned*& d_max = d_max_probe.p;
             HIP_TRY(hipMalloc((void**)&d_max, sizeof(unsigned)));
             HIP_TRY(hipMemset(d_max, 0, sizeof(unsigned)));
             bool wide = false;
@@ -244,7 +245,6 @@ int setup_deepfm_pairs(sprk_engine* h) {
             HIP_TRY(hipGetLastError());
             unsigned bits = 0;
             HIP_TRY(hipMemcpy(&bits, d_max, sizeof(bits), hipMemcpyDeviceToHost));
-            (void)hipFree(d_max);
             float mx;
             memcpy(&mx, &bits, sizeof(mx));
             for (int f = 0; f < r.n_deep && !wide && mx > 0.f && mx < 3.0e38f; ++f)

@@ -98,14 +98,14 @@ int setup_rows_v2(sprk_engine* h) {
     if (h->tune.rows_unf && h->tune.dyn_f16 && nbig <= 2 && Dp <= 16 && KP + H0 > 16) {
         const int vu = find_rows_variant(KP / 16, H0 / 16, H1 / 16, nbig, nsm, true, true);
         if (vu >= 0) {
-            unsigned* d_max = nullptr;
+            DevProbe d_max_probe;
+            unsigned*& d_max = d_max_probe.p;
             HIP_TRY(hipMalloc((void**)&d_max, sizeof(unsigned)));
             HIP_TRY(hipMemset(d_max, 0, sizeof(unsigned)));
             for (int b = 0; b < nbig; ++b)
                 hipLaunchKernelGGL(k_v2_absmax, dim3(1024), dim3(256), 0, 0, a.table[big[b]], (long long)a.emb_vocab[big[b]] + 1, Dp, Dp, d_max);
             unsigned bits = 0;
             HIP_TRY(hipMemcpy(&bits, d_max, sizeof(bits), hipMemcpyDeviceToHost));
-            (void)hipFree(d_max);
             float mx;
             memcpy(&mx, &bits, sizeof(mx));
             bool ok = mx < 3.0e38f;

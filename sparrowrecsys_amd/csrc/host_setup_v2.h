@@ -249,7 +249,8 @@ int setup_v2_joint(sprk_engine* h) {
     bool half = h->tune.v2_half;
     float p_scale = 1.f, w_scale = 1.f;
     if (half) {
-        unsigned* d_max = nullptr;
+        DevProbe d_max_probe;
+        unsigned*& d_max = d_max_probe.p;
         HIP_TRY(hipMalloc((void**)&d_max, 2 * sizeof(unsigned)));
         HIP_TRY(hipMemset(d_max, 0, 2 * sizeof(unsigned)));
         for (int b = 0; b < nbig; ++b) {
@@ -263,7 +264,6 @@ int setup_v2_joint(sprk_engine* h) {
         HIP_TRY(hipGetLastError());
         unsigned bits[2];
         HIP_TRY(hipMemcpy(bits, d_max, sizeof(bits), hipMemcpyDeviceToHost));
-        (void)hipFree(d_max);
         float mx[2];
         memcpy(mx, bits, sizeof(mx));
         for (int i = 0; i < 2; ++i) {

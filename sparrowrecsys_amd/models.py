@@ -72,7 +72,14 @@ class Engine:
         self.n_id_cols = plan.n_id_cols
         self.n_dense = plan.n_dense
         self.n_aux = plan.n_aux
-        self._many_batches, self._many_streams = 1, 0      # forward_many's launch shape: per-call arguments, not handle state
+        # forward_many's launch shape: per-call arguments of sprk_forward_many_opts, not handle state.  SPRK_MANY_STREAMS presets the
+        # stream count here as it presets the handle's default for C callers of sprk_forward_many (the switch was dead
+        # for Python users)
+        try:
+            env_streams = int(os.environ.get("SPRK_MANY_STREAMS", "0"))
+        except ValueError:
+            env_streams = 0
+        self._many_batches, self._many_streams = 1, (0 if env_streams < 2 else min(env_streams, 4))
         self.has_din = bool(plan.din.enabled)
         self.din_T = plan.din.T
         d = self.describe()

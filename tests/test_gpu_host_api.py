@@ -91,6 +91,15 @@ def test_describe_reports_the_dispatched_kernels(torch, name, kernel, stage):
     assert model.engine.kernel_name() == kernel
 
 
+def test_many_streams_switch_reaches_python_users(torch, monkeypatch):
+    """SPRK_MANY_STREAMS presets the helper-stream count of Engine.forward_many (it used to preset only the C handle's
+    default, which the Python path never reads)."""
+    monkeypatch.setenv("SPRK_MANY_STREAMS", "3")
+    assert M.DeepFMv2(seed=1, emb_dim=16, fields=SY.CONFIG2_FIELDS, proj_dim=16).engine._many_streams == 3
+    monkeypatch.setenv("SPRK_MANY_STREAMS", "1")
+    assert M.DeepFMv2(seed=1, emb_dim=16, fields=SY.CONFIG2_FIELDS, proj_dim=16).engine._many_streams == 0
+
+
 def test_describe_shows_an_interpreter_fallback(torch, monkeypatch):
     monkeypatch.setenv("SPRK_FORCE_INTERPRETER", "1")
     model = M.DeepFMv2(seed=1, emb_dim=16, fields=SY.CONFIG2_FIELDS, proj_dim=16)
