@@ -616,9 +616,14 @@ def main():
                          "sprk_peer_allgather_scores (direct peer writes into IPC-mapped receive buffers, no RCCL)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend (gloo: functional test of the N>1 path with ranks sharing one GPU)")
-    ap.add_argument("--side-workloads", default="din_c3,deepfm_c2",
+    ap.add_argument("--side-workloads", default="din_c3,deepfm_c2,deepfm_c4,widedeep_c5,neuralcf_serving",
                     help="default workload at N=1: also measure these (short loops) and put them under `workloads` in the same JSON "
                          "line -- BASELINE's metric names DeepFM and DIN; '' = none")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: every rank scores its own batches of --batch rows (per-GPU work fixed).  strong: the batches are GLOBAL ones of "
+                         "--batch rows that every rank holds; rank r scores rows [r B/N, (r+1) B/N) and the score slices are all-gathered "
+                         "(north_star: 'batches shard row-wise across the 8 GPUs ... all-gather ... for the final score vector'; what one Jetty "
+                         "request needs, RecForYouProcess.java:113-138) -- total work fixed as N grows")
     ap.add_argument("--dry-run", action="store_true",
                     help="no GPU, no kernels: the launcher / process-group / grouped all-gather / timing plumbing with a stand-in "
                          "forward on CPU tensors (gloo).  For the CPU test of `--gpus N` self-spawning; the line says dry_run")
@@ -658,7 +663,18 @@ def main():
     nb_in = args.input_batches or {"deepfm_v2_c2": 64, "deepfm_c2": 16, "din_c3": 16, "din_ref": 16, "dien_ref": 16}.get(args.workload, 8)
     if args.batch and args.batch > 262144:
         nb_in = min(nb_in, 8)
-    model, feats, desc, roof = build_workload(args.workload, B, args.dist, seed_offset=rank, big_vocab=args.big_vocab, NB=nb_in)
+    strong = args.scaling == "strong"
+    B_global, feats_global0 = B, None
+    if strong:
+        if B % world:
+            raise SystemExit("--scaling strong: the global batch of %d rows does not divide over %d ranks" % (B, world))
+        # every rank draws the SAME global batches (one seed) and keeps its row shard; batch 0 stays whole for the one-request latency
+        model, feats, desc, roof = build_workload(args.workload, B_global, args.dist, seed_offset=0, big_vocab=args.big_vocab, NB=nb_in)
+        B = B_global // world
+        feats_global0 = feats[0]
+        feats = [{k: np.asarray(v)[rank * B:(rank + 1) * B] for k, v in f.items()} for f in feats]
+    else:
+        model, feats, desc, roof = build_workload(args.workload, B, args.dist, seed_offset=rank, big_vocab=args.big_vocab, NB=nb_in)
     eng = model.engine
     is_din = args.workload in ("din_c3", "din_ref", "dien_ref")
     roof["kernel"] = eng.kernel_name() if not is_din else (eng.describe().get("stage") or roof["kernel"])   # what the handle really dispatches to (from the handle, not from the environment)
@@ -766,6 +782,12 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         blk = float(t.item())
     R = int(max(1, min(math.ceil(args.min_region_ms * 1e-3 / max(blk, 1e-9)), max(1, 2_000_000 // max(K, 1)))))
+    if lb > 1 and not dist_on:
+        # a region is R*K steps cut into launches of `lb` batches: make it a whole number of launches, so that every launch of the timed
+        # regions is a FULL one and rocprofv3's average over the multi-batch kernel's launches reproduces `roofline_timed_region`
+        # (the kept trace averaged launches of different batch counts)
+        mult = lb // math.gcd(K, lb)
+        R = int(math.ceil(R / mult) * mult)
     timer.region(R * K)                        # untimed: builds the region's prepared launch list, one more warm-up pass
     # the K-step calibration block is ONE short launch list (K = 20 < 64 batches per launch) and reads slower per step than the
     # region's full launches: correct R on the region's own time so that it really lasts >= --min-region-ms
@@ -774,6 +796,9 @@ def main():
         if w_reg * 1e3 >= args.min_region_ms or R >= max(1, 2_000_000 // max(K, 1)):
             break
         R = int(min(math.ceil(R * args.min_region_ms * 1.08e-3 / max(w_reg, 1e-9)), max(1, 2_000_000 // max(K, 1))))
+        if lb > 1 and not dist_on:
+            mult = lb // math.gcd(K, lb)
+            R = int(math.ceil(R / mult) * mult)
         timer.region(R * K)                    # (builds the new list)
     # ---- timed regions ----
     walls, evs = [], []
@@ -839,6 +864,56 @@ def main():
         if not check <= 1e-4:
             raise SystemExit("bench outputs differ from the oracle: max|err| = %g" % check)
 
+    strong_block = None
+    if strong:
+        # ONE global batch as one request: shard -> forward -> all-gather, nothing overlapped with anything (sparrowrecsys_amd.dist.
+        # RowShardedPredictor: what the Jetty ranker's single request per recommendation needs); max over ranks of the median latency
+        from sparrowrecsys_amd.dist import PeerScoreComm, RowShardedPredictor, ScoreComm
+        gi, gd = model.pack(feats_global0)
+        gi, gd = torch.from_numpy(gi).cuda(), torch.from_numpy(gd).cuda()
+        wsl = torch.empty(max(eng.workspace_bytes(B) // 4, 1), dtype=torch.float32, device="cuda")
+        eng.set_many_batches(1)
+        eng.set_many_streams(0)
+
+        def fwd_local(i_, d_):
+            return model.predict_device(i_, d_, workspace=wsl)
+        if dist_on:
+            comm1 = None
+            if args.collective == "sprk" and args.backend == "nccl":
+                comm1 = ScoreComm()
+            elif args.collective == "peer":
+                comm1 = PeerScoreComm(B)
+            pred = RowShardedPredictor(fwd_local, comm=comm1)
+            one = lambda: pred.predict(gi, gd)
+        else:
+            one = lambda: fwd_local(gi, gd)
+        for _ in range(20):
+            got_all = one()
+        torch.cuda.synchronize()
+        lats = []
+        for _ in range(200):
+            if dist_on:
+                dist.barrier()
+            t0 = time.perf_counter()
+            got_all = one()
+            torch.cuda.synchronize()
+            lats.append(time.perf_counter() - t0)
+        lat = float(np.median(lats))
+        if dist_on:
+            t = torch.tensor([lat], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            lat = float(t.item())
+        chk1 = None
+        if not args.no_check and rank == 0:
+            nr = min(1024, B_global)
+            ref = oracle_forward(args.workload, model, {k: np.asarray(v)[B_global - nr:] for k, v in feats_global0.items()})[:, 0]
+            chk1 = float(np.abs(got_all[B_global - nr:].cpu().numpy() - ref).max())      # the LAST rank's rows, as gathered on rank 0
+            if not chk1 <= 1e-4:
+                raise SystemExit("bench (strong): gathered scores differ from the oracle: max|err| = %g" % chk1)
+        strong_block = {"what": "one global batch of %d rows as ONE request: row shard -> forward -> all-gather of the score slices, host clock "
+                                "around the call + synchronize, median of 200, max over ranks" % B_global,
+                        "latency_us": lat * 1e6, "samples_per_s": B_global / lat, "rows_per_rank": B,
+                        "gathered_scores_oracle_check_max_abs_err": chk1}
     if rank == 0:
         value = B * world * n_region / elapsed
         region = "strict-order one-batch-per-launch loop after the timed regions (%d launches over %d input batches, median of 3 loops)" % (n_strict, NBS)
@@ -912,7 +987,7 @@ def main():
         line = {
             "metric": "ctr_samples_per_sec", "value": value, "unit": "samples/s", "n_gpus": world,
             "steps": K, "warmup": args.warmup, "ms_per_step": elapsed * 1e3 / n_region,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "dtype_detail": "fp32 in, fp32 out, fp32 accumulation; contractions of finalize-bounded operands (table rows x weights) run on "
                             "v_mfma_f32_16x16x32_f16 with split operands hi + lo = 22 significand bits (narrower than fp32's 24: measured |err| vs the "
                             "fp64 oracle <= 5e-7 on the checked rows, bar 1e-4); the all-f32-MFMA variant is SPRK_V2_HALF=0 / SPRK_DIN_HALF=0 / SPRK_DYN_F16=0",
@@ -950,12 +1025,35 @@ def main():
             # HIP events around the region bracket exactly ceil(R*K / lb) back-to-back launches of the multi-batch instantiation
             n_launch = (n_region + lb - 1) // lb
             ach = roof["bytes_per_sample"] * B * n_region / ev_region / 1e9
+            cache_resident = bool(table_mb) and table_mb <= 256
             line["roofline_timed_region"] = {
-                "bound": "hbm", "kernel": roof["kernel"] + " (multi-batch instantiation, %d batches of %d rows per launch)" % (lb, B),
+                # the config's own tables (%.0f MB) sit in the 256 MB Infinity Cache: the rows of this region are served by the cache and
+                # the fabric, not by HBM -- `frac` is the algorithmic bytes against the 8 TB/s HBM figure for COMPARISON, and may exceed what
+                # HBM itself delivers.  The HBM claim is roofline_hbm_resident (tables of 3.2 GB, every row an HBM access).
+                "bound": "infinity_cache" if cache_resident else "hbm",
+                "kernel": roof["kernel"] + " (multi-batch instantiation, %d batches of %d rows per launch)" % (lb, B),
                 "achieved": ach, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": ach * 1e9 / HBM_PEAK,
+                "frac_is": ("algorithmic bytes / time / 8.0 TB/s; the rows come out of the Infinity Cache (%.0f MB of tables), so this is a cache- and "
+                            "fabric-side rate quoted against the HBM peak for comparison, NOT an HBM utilisation -- see roofline_hbm_resident" % table_mb)
+                           if cache_resident else "algorithmic bytes / time / 8.0 TB/s, tables beyond the Infinity Cache",
                 "launches": n_launch, "avg_launch_us": ev_region * 1e6 / n_launch, "timed_with": "HIP events around the median timed region"
                 + (" (includes the grouped all-gathers' share)" if dist_on else "")}
+        if lb > 16 and roof["kernel"] in ("k_deepfm_v2_joint", "k_rows_chain") and not dist_on:
+            # rounds 1-2 quoted `value` at 16 batches per launch: kept beside the 64-batch figure
+            eng.set_many_batches(16)
+            n16 = int(max(64, min(4096, math.ceil(0.02 / max(elapsed / n_region, 1e-9) / 16) * 16)))
+            idx = [i % NB for i in range(n16)]
+            run16 = eng.prepare_many([batches[j][0] for j in idx], [batches[j][1] for j in idx], [outs[j] for j in idx], ws)
+            run16(); torch.cuda.synchronize()
+            s16 = _event_loop(run16, n16)
+            eng.set_many_batches(lb)
+            line["value_16_batches_per_launch"] = B * world / s16
+            line["us_per_step_16_batches_per_launch"] = s16 * 1e6
         line.update(extra)
+        if strong_block is not None:
+            line["strong_one_global_batch"] = strong_block
+        line["scaling_curve"] = ("not measured: no multi-GPU node has run this bench yet (rounds 1-4: one-GPU boxes); the driver computes scaling "
+                                 "efficiency from its own --gpus 1,2,4,8 runs")
         hbm_rows = args.hbm_resident if args.hbm_resident >= 0 else 8388608
         if world == 1 and not dist_on and args.workload == "deepfm_v2_c2" and not args.big_vocab and hbm_rows > 0 and roof["kernel"] == "k_deepfm_v2_joint":
             line["roofline_hbm_resident"] = hbm_resident_block(args, B, hbm_rows, K)
@@ -1088,6 +1186,66 @@ def _event_loop(run, n, loops=3):
     return float(np.median(tt))
 
 
+def serving_workload(args):
+    """What the Jetty server sends per recommendation (RecForYouProcess.java:34,113-138): ONE POST of 800 {"userId", "movieId"}
+    instances to /v1/models/recmodel:predict, answered by sparrowrecsys_amd.serving.PredictServer in front of NeuralCF on the GPU.
+    Latency, not throughput: p50 / p99 over keep-alive requests from one client in its own PROCESS (in this one it would share the
+    server's GIL), and beside it the share that is the model: predict() on the packed 800 rows, and the kernel launch alone."""
+    import http.client
+    import multiprocessing as mp
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    from bench_serving import _client
+    from sparrowrecsys_amd import models as M
+    from sparrowrecsys_amd.serving import PredictServer
+    n_inst = 800
+    model = M.NeuralCF(seed=7)
+    srv = PredictServer(model, port=0)
+    srv.start()
+    rng = np.random.default_rng(1)
+    bodies, feats = [], None
+    for _ in range(16):
+        u = int(rng.integers(1, 30000))
+        mids = rng.integers(1, 1000, n_inst)
+        bodies.append(json.dumps({"instances": [{"userId": u, "movieId": int(m)} for m in mids]}).encode())
+        feats = {"userId": np.full(n_inst, u), "movieId": mids}
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    seconds = 1.5
+    p_ = ctx.Process(target=_client, args=(srv.port, bodies, seconds, n_inst, 0, q))
+    p_.start()
+    lat = sorted(q.get(timeout=seconds + 120))
+    p_.join(timeout=30)
+    srv.close()
+    pct = lambda p: lat[min(len(lat) - 1, int(p * len(lat)))] * 1e3
+    # the model's share: predict() on host arrays (pack -> copy -> forward -> copy back -> id check), and the forward alone
+    model.predict(feats)
+    t0 = time.perf_counter()
+    n_pred = 300
+    for _ in range(n_pred):
+        model.predict(feats)
+    predict_ms = (time.perf_counter() - t0) * 1e3 / n_pred
+    ids, dense = model.pack(feats)
+    ti, td = torch.from_numpy(ids).cuda(), torch.from_numpy(dense).cuda()
+    out = torch.empty(n_inst, dtype=torch.float32, device="cuda")
+    eng = model.engine
+
+    def fw():
+        for _ in range(200):
+            eng.forward(ti, td, out)
+    fw(); torch.cuda.synchronize()
+    fwd_us = _event_loop(fw, 200) * 1e6
+    kernel = eng.kernel_name()
+    eng.close()
+    return {"workload": "NeuralCF behind the TF-Serving-shaped REST shim, %d candidates per request (RecForYouProcess.java:34,113-138)" % n_inst,
+            "unit": "ms per request", "higher_is_better": False, "requests": len(lat), "latency_ms": {"p50": pct(0.5), "p90": pct(0.9), "p99": pct(0.99)},
+            "requests_per_sec_one_client": len(lat) / seconds, "candidates_per_sec_one_client": len(lat) * n_inst / seconds,
+            "model_predict_ms": predict_ms, "forward_launch_us": fwd_us, "kernel": kernel,
+            "shares": "request = HTTP + JSON parse (800 instances) + micro-batcher hand-off + model.predict (pack, copy in, forward, copy out, id "
+                      "check) + response formatting; model_predict_ms and forward_launch_us are measured in this process, outside the server",
+            "server": "sparrowrecsys_amd.serving.PredictServer (ThreadingHTTPServer + micro-batcher that only waits while another request is arriving)"}
+
+
 def side_workload(args, name):
     """One more workload inside the default driver line: BASELINE.json's metric names DeepFM AND DIN,
     and SURVEY 8(d) config 2 names the pair-dot graph next to the sum-of-squares one.  Same measurements as the headline,
@@ -1095,8 +1253,10 @@ def side_workload(args, name):
     launch; DIN: attention and tail of alternating groups on two streams), `roofline` = strict stream order, ONE batch
     per launch, HIP events (what rocprofv3's kernel trace reports for `--launch-batches 1 --overlap-streams 0`)."""
     import torch
-    B = {"din_c3": 32768}.get(name, 65536)
-    NB = 16
+    if name == "neuralcf_serving":
+        return serving_workload(args)
+    B = {"din_c3": 32768, "widedeep_c5": 131072}.get(name, 65536)
+    NB = 8 if name in ("deepfm_c4", "widedeep_c5") else 16       # (configs 4 / 5: the largest single-GPU forms; 27 M-row / 10 M-bucket tables)
     model, feats, desc, roof = build_workload(name, B, args.dist, seed_offset=11, NB=NB)
     eng = model.engine
     din = name == "din_c3"
@@ -1191,6 +1351,22 @@ def dry_run(args, rank, world):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo")
     B, K = args.batch or 1024, args.steps
+    strong = args.scaling == "strong"
+    strong_ok = None
+    if strong:
+        # the strong-scaling plumbing without a GPU: every rank holds the same global batch, scores its row shard with a stand-in
+        # forward (score = 3 x row index + 1), RowShardedPredictor gathers, every rank checks every row
+        from sparrowrecsys_amd.dist import RowShardedPredictor
+        if B % world:
+            raise SystemExit("--scaling strong: the global batch of %d rows does not divide over %d ranks" % (B, world))
+        gids = torch.arange(B, dtype=torch.int32).reshape(B, 1)
+        if dist_on:
+            pred = RowShardedPredictor(lambda i_, d_: i_[:, 0].float() * 3.0 + 1.0)
+            allv = pred.predict(gids, gids.float())
+        else:
+            allv = gids[:, 0].float() * 3.0 + 1.0
+        strong_ok = bool(tuple(allv.shape) == (B,) and (allv == torch.arange(B).float() * 3.0 + 1.0).all())
+        B = B // world                                     # rows per rank in the loop below
     got, queued = [], []
 
     def sink(gi, view, nb):
@@ -1227,9 +1403,10 @@ def dry_run(args, rank, world):
     if rank == 0:
         print(json.dumps({"metric": "ctr_samples_per_sec", "value": B * world * K / elapsed, "unit": "samples/s", "n_gpus": world,
                           "steps": K, "warmup": args.warmup, "ms_per_step": elapsed * 1e3 / K, "higher_is_better": True,
-                          "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic", "dry_run": True,
+                          "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic", "dry_run": True,
                           "config": {"workload": "DRY RUN (no GPU, stand-in forward): launcher / collective / timing plumbing only",
                                      "batch_per_gpu": B, "global_batch": B * world, "collectives": gs.collectives if gs else 0,
+                                     "strong_row_shard_gather_ok": strong_ok,
                                      "groups_seen_by_sink": len(got), "sink_content_ok": bool(all(got)),
                                      "group": gs.G if gs else 0}}), flush=True)
     if dist_on:

@@ -195,3 +195,61 @@ def test_fast_and_general_instance_paths_agree_and_scores_round_trip(stub_server
         body = json.loads(resp.read())
         assert resp.status == 200 and len(body["predictions"]) == k + 1
     c.close()
+
+
+def test_byte_level_parser_of_the_jetty_request_equals_the_json_path():
+    """serving._fast_uniform_int_instances reads the ranker's request (RecForYouProcess.java:113-127: flat objects, the same integer
+    keys in the same order) without json.loads; it must give the columns the general path gives -- for org.json's compact spelling
+    and Python's spaced one -- and step aside (None) for everything else, so that those requests keep the general path's behaviour,
+    errors included."""
+    import json as J
+    from sparrowrecsys_amd import serving as S
+    rng = np.random.default_rng(3)
+    inst = [{"userId": int(u), "movieId": int(m)} for u, m in zip(rng.integers(-3, 30000, 800), rng.integers(0, 1000, 800))]
+    for seps in ((", ", ": "), (",", ":")):
+        body = J.dumps({"instances": inst}, separators=seps).encode()
+        got = S._fast_uniform_int_instances(body)
+        assert got is not None and list(got) == ["userId", "movieId"]
+        want = S._to_feature_arrays(S._columns_from_instances(J.loads(body)["instances"], fast=True), 800)
+        for k in want:
+            np.testing.assert_array_equal(got[k], want[k])
+            assert got[k].dtype == want[k].dtype
+    one = J.dumps({"instances": [{"movieId": 5}]}).encode()
+    np.testing.assert_array_equal(S._fast_uniform_int_instances(one)["movieId"], [5])
+    # everything that is not exactly that shape: the general path's business
+    for other in (
+            {"instances": [{"userId": 1, "movieId": 2}, {"movieId": 3, "userId": 4}]},          # another key order
+            {"instances": [{"userId": 1, "movieId": 2}, {"userId": 3}]},                        # a missing key
+            {"instances": [{"userId": 1, "movieId": 2.5}]},                                     # a float
+            {"instances": [{"userId": 1, "movieId": 1e3}]},
+            {"instances": [{"userId": 1, "movieId": [2]}]},                                     # the [x] spelling
+            {"instances": [{"userId": 1, "movieId": "2"}]},                                     # a string
+            {"instances": [{"userId": 1, "movieId": True}]},
+            {"instances": [{"userId": 1, "movieId": None}]},
+            {"instances": [{"userId": 1, "userRatedMovie1": 2}]},                               # a digit inside a key
+            {"instances": []},
+            {"inputs": {"userId": [1, 2], "movieId": [3, 4]}},
+            {"instances": [{"userId": 1, "movieId": 2}], "signature_name": "serving_default"}):
+        assert S._fast_uniform_int_instances(J.dumps(other).encode()) is None, other
+    assert S._fast_uniform_int_instances(J.dumps({"instances": inst[:3]}, indent=2).encode()) is None          # pretty-printed
+    assert S._fast_uniform_int_instances(b'{"instances": [{"userId": 1, "movieId": 99999999999999999999999}]}') is None
+    assert S._fast_uniform_int_instances(b'{"instances": [{"userId": 1, "movieId": --2}]}') is None
+    assert S._fast_uniform_int_instances(b'not json') is None
+
+
+def test_fast_and_json_parse_paths_answer_alike(stub_server, monkeypatch):
+    """The same request through both parsers of the running server: same status, same predictions; a bad id is a 400 on both."""
+    import http.client
+    import json as J
+    from sparrowrecsys_amd import serving as S
+    srv, model = stub_server
+    inst = [{"userId": 7, "movieId": m} for m in range(1, 41)]
+    out = {}
+    for fast in (True, False):
+        srv.fast_parse = fast
+        c = http.client.HTTPConnection("127.0.0.1", srv.port, timeout=30)
+        c.request("POST", "/v1/models/recmodel:predict", body=J.dumps({"instances": inst}, separators=(",", ":")).encode(), headers={"Content-Type": "application/json"})
+        r = c.getresponse()
+        out[fast] = (r.status, J.loads(r.read()))
+        c.close()
+    assert out[True] == out[False] and out[True][0] == 200 and len(out[True][1]["predictions"]) == 40
