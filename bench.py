@@ -181,7 +181,8 @@ def build_workload(name, B, dist_name, seed_offset=0, big_vocab=0, NB=8):
         roof = {"bound": "mfma", "kernel": att_kernel, "hist_len": T, "flops_per_sample": flops,
                 "executed_flops_per_sample": flops if legacy else executed,
                 "bytes_per_sample": (T + 1) * 4 + (T + 1) * D * 4 + D * 4,
-                "tail_reference_flops": 2 * ((7 + 5 * D) * 128 + 128 * 64 + 64)}
+                "tail_reference_flops": 2 * ((7 + 5 * D) * 128 + 128 * 64 + 64),
+                "tail_bytes_per_sample": 3 * D * 4 + 7 * 4 + 3 * 4 + 4}
         return model, feats, desc, roof
     if name == "dien_ref":
         # DIEN.py as written (RECENT_MOVIES = 5, EMBEDDING_SIZE = 10): GRU -> attention gate -> AUGRU (k_dien_seq, one lane per
@@ -970,6 +971,12 @@ def main():
             rl.update({"algorithmic_bytes_per_sample": roof["bytes_per_sample"],
                        "avg_launch_us": din_s * 1e6, "step_us_all_kernels": fwd_s * 1e6,
                        "timed_with": "HIP events, %s-only loop after the timed regions" % roof["kernel"]})
+            if eng.kernel_name() == "k_din_fused":
+                # the whole DIN step is ONE launch: the attention stage's bytes + the tail's (userId row, two genre rows -- the candidate's
+                # row is the attention's --, 7 numerics, 3 ids, the score), against the fused launch's own duration
+                fb = roof["bytes_per_sample"] + roof.get("tail_bytes_per_sample", 0)
+                rl["fused_step"] = {"kernel": "k_din_fused<TAIL> (attention + pooling + tail, one launch of %d rows)" % B, "algorithmic_bytes_per_sample": fb,
+                                    "avg_launch_us": fwd_s * 1e6, "achieved": fb * B / fwd_s / 1e9, "unit": "GB/s", "frac": fb * B / fwd_s / HBM_PEAK}
         # memory-side bytes per launch from the committed PMC passes (rocprofv3 --pmc runs are separate from the
         # timed run by design); only quoted for the batch size and kernel they were collected on
         traffic = None
@@ -1038,7 +1045,7 @@ def main():
                            if cache_resident else "algorithmic bytes / time / 8.0 TB/s, tables beyond the Infinity Cache",
                 "launches": n_launch, "avg_launch_us": ev_region * 1e6 / n_launch, "timed_with": "HIP events around the median timed region"
                 + (" (includes the grouped all-gathers' share)" if dist_on else "")}
-        if lb > 16 and roof["kernel"] in ("k_deepfm_v2_joint", "k_rows_chain") and not dist_on:
+        if lb > 16 and roof["kernel"] in ("k_deepfm_v2_joint", "k_rows_chain") and not dist_on and env("SPRK_BENCH_SKIP_16") != "1":
             # rounds 1-2 quoted `value` at 16 batches per launch: kept beside the 64-batch figure
             eng.set_many_batches(16)
             n16 = int(max(64, min(4096, math.ceil(0.02 / max(elapsed / n_region, 1e-9) / 16) * 16)))

@@ -24,7 +24,13 @@ HBM_PEAK = 8.0e12
 DOMINANT = {"c2": "k_deepfm_v2_joint1", "c2_hbm": "k_deepfm_v2_joint1", "c2_pairs": "k_deepfm_pairs1", "c3": "k_din_attn_cols",
             "c4_v2": "k_deepfm_v2_joint1", "c4_pairs": "k_deepfm_pairs<", "c5": "k_mlp_rows", "v2_ref": "k_rows_chain1", "ncf_ref": "k_rows_chain1",
             "deepfm_ref": "k_deepfm_pairs1", "din_ref": "k_din_attn_cols", "embedding_mlp_ref": "k_mlp_rows", "dien_ref": "k_dien_seq"}
-ORDER = ["c2", "c2_hbm", "c2_pairs", "c3", "c4_v2", "c4_pairs", "c5", "v2_ref", "ncf_ref", "deepfm_ref", "din_ref", "embedding_mlp_ref", "dien_ref"]
+# round 4: BASELINE config 3 is ONE launch (k_din_fused<2, false, true>: attention + pooling + tail); its attention-only instantiation
+# (<2, false, false>, what sprk_din_pool launches -- the figure comparable with round 3's k_din_attn_cols) is a second row, "c3_attn",
+# read from the same trace (bench.py times that loop after the fused one)
+if os.environ.get("SPRK_PROFILE_ROUND", "4") >= "4":
+    DOMINANT.update({"c3": "k_din_fused<2, false, true", "c3_attn": "k_din_fused<2, false, false"})
+ORDER = ["c2", "c2_hbm", "c2_pairs", "c3", "c3_attn", "c4_v2", "c4_pairs", "c5", "v2_ref", "ncf_ref", "deepfm_ref", "din_ref", "embedding_mlp_ref", "dien_ref"]
+SHARES_FILES_OF = {"c3_attn": "c3"}                    # a row read from another workload's trace / bench line
 
 
 def kernel_rows(path):
@@ -44,7 +50,8 @@ def main():
         pmc = json.load(open(os.path.join(src, "pmc_summary.json")))
         shutil.copy(os.path.join(src, "pmc_summary.json"), os.path.join(dst, "pmc_summary.json"))
     table = []
-    for w in ORDER:
+    for w0 in ORDER:
+        w = SHARES_FILES_OF.get(w0, w0)
         ks, bj = os.path.join(src, w + "_strict_kernel_stats.csv"), os.path.join(src, w + "_strict_bench.json")
         if not (os.path.exists(ks) and os.path.exists(bj)):
             continue
@@ -70,17 +77,20 @@ def main():
             if untraced:
                 json.dump(untraced, open(os.path.join(dst, "bench_" + w + "_strict.json"), "w"))
         rl = (untraced or line)["roofline"]
+        rl_traced = line["roofline"]
+        if w0 == "c3" and "fused_step" in rl:               # the fused launch: its own bytes (attention + tail) and duration
+            rl, rl_traced = rl["fused_step"], line["roofline"].get("fused_step", line["roofline"])
         B = line["config"]["batch_per_gpu"]
         alg = rl["algorithmic_bytes_per_sample"] * B
-        hit = [r for r in kernel_rows(ks) if DOMINANT[w] in r[0]]
+        hit = [r for r in kernel_rows(ks) if DOMINANT[w0] in r[0]]
         if not hit:
-            print(w, ": no kernel matching", DOMINANT[w])
+            print(w0, ": no kernel matching", DOMINANT[w0])
             continue
         name, calls, avg_ns, _ = max(hit, key=lambda r: r[3])
         short = name.split("(anonymous namespace)::", 1)[-1].split("(")[0]
-        row = {"workload": w, "bench_workload": line["config"]["workload"].split(":")[0], "kernel": short, "launches": calls, "batch": B,
+        row = {"workload": w0, "bench_workload": line["config"]["workload"].split(":")[0], "kernel": short, "launches": calls, "batch": B,
                "rocprof_avg_us": avg_ns / 1e3, "hip_event_us": rl["avg_launch_us"], "events_vs_rocprof": rl["avg_launch_us"] / (avg_ns / 1e3),
-               "hip_event_us_under_tracer": line["roofline"]["avg_launch_us"], "hip_events_from": "untraced run of the same command" if untraced else "the traced process",
+               "hip_event_us_under_tracer": rl_traced["avg_launch_us"], "hip_events_from": "untraced run of the same command" if untraced else "the traced process",
                "algorithmic_bytes_per_sample": rl["algorithmic_bytes_per_sample"], "algorithmic_mb": alg / 1e6,
                "frac": alg / (avg_ns * 1e-9) / HBM_PEAK, "samples_per_s": B / (avg_ns * 1e-9)}
         other = [(r[0].split("(anonymous namespace)::", 1)[-1].split("(")[0][:40], r[1], r[2] / 1e3) for r in kernel_rows(ks)

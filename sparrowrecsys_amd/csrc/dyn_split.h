@@ -22,35 +22,34 @@ __device__ __forceinline__ float rows4_max(float v) {
     return fmaxf(a, b);
 }
 
-// (x0..x3 | y0..y3) * scale -> packed hi halfs and lo halfs, 2 VALU per value (v_fma_mixlo/hi_f16: f16(x*scale) and
-// f16(x*scale - hi) with the f16 source taken straight from the packed register)
+// (x0..x3 | y0..y3) * scale -> packed hi halfs and lo halfs: hi = f16(x s), lo = f16(x s - hi), round to nearest even.
+// [r4] Rounds 2-3 wrote each half with v_fma_mixlo/hi_f16 (two per value).  scripts/ubench/issue_rates.hip measured what that
+// instruction costs a gfx950 SIMD: 8.7 cycles per wave64 issue against 3.1 for v_fma_f32, 4.3 for v_cvt_pk_f16_f32 (new on gfx950:
+// TWO values per issue) and 4.6 for v_fma_mix_f32 -- 17.4 cycles per value.  Now: v_pk_mul_f32 + v_cvt_pk_f16_f32 for the hi pair,
+// one v_fma_mix_f32 per value for the remainder x s - hi (exact in f32: hi holds the leading 11 bits of x s), v_cvt_pk_f16_f32 for
+// the lo pair: five issues per two values, 11.9 cycles per value, THE SAME BITS (both forms round x s and the exact remainder to
+// nearest even).  Only the remainder is an asm statement: it reads a register the compiler's own v_cvt_pk wrote and feeds the
+// compiler's own v_cvt_pk -- VALU to VALU both ways, nothing for the hazard recognizer to miss (the old form's MFMA-operand
+// writes inside asm statements needed a hand-placed s_nop).
+typedef _Float16 dyn_h2 __attribute__((ext_vector_type(2)));
+typedef float dyn_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void dyn_split2(float x0, float x1, float scale, dyn_h2& hi, dyn_h2& lo) {
+    const dyn_f2 t = dyn_f2{x0, x1} * scale;
+    hi = __builtin_convertvector(t, dyn_h2);
+    const unsigned hb = __builtin_bit_cast(unsigned, hi);
+    float r0, r1;
+    asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(r0) : "v"(x0), "v"(scale), "v"(hb));
+    asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r1) : "v"(x1), "v"(scale), "v"(hb));
+    lo = __builtin_convertvector(dyn_f2{r0, r1}, dyn_h2);
+}
 __device__ __forceinline__ void dyn_split8(f32x4 x, f32x4 y, float scale, din_f16x8& hi, din_f16x8& lo) {
-    // (mixlo writes the low half of its destination and keeps the high half, mixhi the other way round: the even element
-    // of a pair goes first as a plain output -- whatever sits in the high half is replaced by the odd element next -- which
-    // spares the eight v_mov 0 an initialised read-modify-write operand costs)
-    unsigned h[4], l[4];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const float v = e < 4 ? x[e] : y[e - 4];
-        if (e & 1) {
-            asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h[e >> 1]) : "v"(v), "v"(scale));
-            asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l[e >> 1]) : "v"(v), "v"(scale), "v"(h[e >> 1]));
-        } else {
-            asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h[e >> 1]) : "v"(v), "v"(scale));
-            asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=&v"(l[e >> 1]) : "v"(v), "v"(scale), "v"(h[e >> 1]));
-        }
-    }
-    // HAZARD GUARD.  The eight dwords above were written by VALU instructions INSIDE asm statements, which hipcc's hazard
-    // recognizer does not see: it pads nothing between such a write and an MFMA that reads the register as its B operand
-    // (a VALU write of a VGPR needs 2 wait states before an MFMA reads it; for a compiler-visible producer hipcc inserts
-    // them).  Whether the pad happened to be there depended on how the scheduler interleaved the surrounding code: round 2's
-    // k_deepfm_pairs_many scheduled an MFMA straight behind the last v_fma_mixhi and read a half-updated operand (scores
-    // off by 7e-6 in one instantiation, exact in its twin) -- the same class as round 1's unexplained k_din_attn multi-batch
-    // failure.  One statement that owns all eight dwords and carries the wait states closes it for every user.
-    asm volatile("s_nop 1" : "+v"(h[0]), "+v"(h[1]), "+v"(h[2]), "+v"(h[3]), "+v"(l[0]), "+v"(l[1]), "+v"(l[2]), "+v"(l[3]));
-    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-    hi = __builtin_bit_cast(din_f16x8, u32x4{h[0], h[1], h[2], h[3]});
-    lo = __builtin_bit_cast(din_f16x8, u32x4{l[0], l[1], l[2], l[3]});
+    dyn_h2 h[4], l[4];
+    dyn_split2(x[0], x[1], scale, h[0], l[0]);
+    dyn_split2(x[2], x[3], scale, h[1], l[1]);
+    dyn_split2(y[0], y[1], scale, h[2], l[2]);
+    dyn_split2(y[2], y[3], scale, h[3], l[3]);
+    hi = din_f16x8{h[0][0], h[0][1], h[1][0], h[1][1], h[2][0], h[2][1], h[3][0], h[3][1]};
+    lo = din_f16x8{l[0][0], l[0][1], l[1][0], l[1][1], l[2][0], l[2][1], l[3][0], l[3][1]};
 }
 
 // scale = 2^(14 - exponent(m)) (1 for m == 0), inv = 1 / (scale * w_scale); m >= 0 finite

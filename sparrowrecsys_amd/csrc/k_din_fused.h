@@ -126,25 +126,6 @@ __global__ __launch_bounds__(256) void k_din_fused_pack(const float* __restrict_
 typedef _Float16 df_h2 __attribute__((ext_vector_type(2)));
 typedef float df_f2 __attribute__((ext_vector_type(2)));
 
-// (x0, x1) * scale -> one dword of hi halfs, one of lo halfs: hi = f16(x s) (v_cvt_pk_f16_f32, round to nearest even),
-// lo = f16(x s - hi).  Everything is visible to the compiler (it pads its own hazards).
-__device__ __forceinline__ void df_split2(float x0, float x1, float scale, df_h2& hi, df_h2& lo) {
-    const df_f2 v = df_f2{x0, x1} * scale;
-    hi = __builtin_convertvector(v, df_h2);
-    const df_f2 rest = v - __builtin_convertvector(hi, df_f2);
-    lo = __builtin_convertvector(rest, df_h2);
-}
-// (x0..x3 | y0..y3) * scale -> the two K = 32 operand vectors
-__device__ __forceinline__ void df_split8(f32x4 x, f32x4 y, float scale, din_f16x8& hi, din_f16x8& lo) {
-    df_h2 h[4], l[4];
-    df_split2(x[0], x[1], scale, h[0], l[0]);
-    df_split2(x[2], x[3], scale, h[1], l[1]);
-    df_split2(y[0], y[1], scale, h[2], l[2]);
-    df_split2(y[2], y[3], scale, h[3], l[3]);
-    hi = din_f16x8{h[0][0], h[0][1], h[1][0], h[1][1], h[2][0], h[2][1], h[3][0], h[3][1]};
-    lo = din_f16x8{l[0][0], l[0][1], l[1][0], l[1][1], l[2][0], l[2][1], l[3][0], l[3][1]};
-}
-
 // XP: ablation bits for scripts/r04 experiments (only instantiated under -DSPRK_DF_XP): 1 no MFMAs, 2 no product split, 4 no h32,
 // 8 no PReLU dot, 16 no reduce / sigmoid, 32 no pooling, 64 no row loads in the loop -- results are garbage, the time is the point
 template <int KC, bool MB, bool TAIL, bool ATT = false, int XP = 0>
@@ -587,7 +568,7 @@ __global__ __launch_bounds__(DF_WAVES * 64, 2) void k_din_fused(const DinFusedRu
             float scale, inv;
             dyn_scale(mx, A.inv_w0p_scale, scale, inv);
             din_f16x8 bh, bl;
-            df_split8(f32x4{xp[0], xp[1], xp[2], xp[3]}, f32x4{xp[4], xp[5], xp[6], xp[7]}, scale, bh, bl);
+            dyn_split8(f32x4{xp[0], xp[1], xp[2], xp[3]}, f32x4{xp[4], xp[5], xp[6], xp[7]}, scale, bh, bl);
             const float* wf = img_s + IM::off_w0p + lane * 4;
 #pragma unroll
             for (int nb = 0; nb < N0C; ++nb) {
@@ -627,7 +608,7 @@ __global__ __launch_bounds__(DF_WAVES * 64, 2) void k_din_fused(const DinFusedRu
 #pragma unroll
             for (int b = 0; b < N0C / 2; ++b) {
                 din_f16x8 bh, bl;
-                df_split8(z0[2 * b], z0[2 * b + 1], scale, bh, bl);
+                dyn_split8(z0[2 * b], z0[2 * b + 1], scale, bh, bl);
 #pragma unroll
                 for (int n1 = 0; n1 < N1C; ++n1) {
                     const din_f16x8 ah = __builtin_bit_cast(din_f16x8, ld4(wf + ((n1 * (N0C / 2) + b) * 2 + 0) * 256));
