@@ -9,10 +9,11 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
-enum { K_FMA, K_PKFMA, K_MIX, K_MIXLO, K_EXP, K_RCP, K_PERM16, K_CNDMASK, K_MFMA, K_LDS, K_SALU, K_PKMULH, K_PKFMAH, K_CVTPK, K_CNDS, K_PKADD, K_MAX, K_CVT32, K_FMAABS, K_NKINDS };
+enum { K_FMA, K_PKFMA, K_MIX, K_MIXLO, K_EXP, K_RCP, K_PERM16, K_CNDMASK, K_MFMA, K_LDS, K_SALU, K_PKMULH, K_PKFMAH, K_CVTPK, K_CNDS, K_PKADD, K_MAX, K_CVT32, K_FMAABS, K_CND64VCC, K_CMPCND32, K_CMPCND64, K_CMP32, K_NKINDS };
 static const char* kind_name[] = {"v_fma_f32", "v_pk_fma_f32", "v_fma_mix_f32", "v_fma_mixlo_f16", "v_exp_f32", "v_rcp_f32",
                                   "v_permlane16_swap", "v_cndmask_b32", "v_mfma_16x16x32_f16", "ds_read_b128", "s_add_u32",
-                                  "v_pk_mul_f16", "v_pk_fma_f16", "v_cvt_pkrtz_f16_f32", "v_cndmask_b32_e64 sgpr", "v_pk_add_f32", "v_max_f32", "v_cvt_f32_f16", "v_fma_f32 |abs|"};
+                                  "v_pk_mul_f16", "v_pk_fma_f16", "v_cvt_pkrtz_f16_f32", "v_cndmask_b32_e64 sgpr", "v_pk_add_f32", "v_max_f32", "v_cvt_f32_f16", "v_fma_f32 |abs|",
+                                  "v_cndmask_b32_e64 vcc", "v_cmp_e32 + v_cndmask_e32 (pair)", "v_cmp_e64 sgpr + v_cndmask_e64 (pair)", "v_cmp_gt_f32_e32"};
 
 extern __shared__ float smem[];
 
@@ -24,7 +25,7 @@ __global__ __launch_bounds__(256) void k_kind(float* out, int iters, float a, fl
     f32x4 acc[4] = {{0, 0, 0, 0}, {0, 0, 0, 1}, {0, 0, 0, 2}, {0, 0, 0, 3}};
     f32x4 l[8];
     unsigned sreg = 0;
-    const unsigned long long mask64 = __builtin_amdgcn_read_exec() ^ (unsigned long long)iters;
+    unsigned long long mask64 = __builtin_amdgcn_read_exec() ^ (unsigned long long)iters;
 #pragma unroll
     for (int i = 0; i < 8; ++i) { v[i] = threadIdx.x + i; p[i] = f32x2{v[i], v[i] + 1}; l[i] = f32x4{0, 0, 0, 0}; }
     f16x8 ah, bh;
@@ -59,6 +60,10 @@ __global__ __launch_bounds__(256) void k_kind(float* out, int iters, float a, fl
                 if (KIND == K_MAX) asm volatile("v_max_f32 %0, %0, %1" : "+v"(v[i]) : "v"(av));
                 if (KIND == K_CVT32) asm volatile("v_cvt_f32_f16 %0, %0" : "+v"(v[i]));
                 if (KIND == K_FMAABS) asm volatile("v_fma_f32 %0, %1, |%0|, %2" : "+v"(v[i]) : "v"(av), "v"(b));
+                if (KIND == K_CND64VCC) asm volatile("v_cndmask_b32_e64 %0, %0, %1, vcc" : "+v"(v[i]) : "v"(av));
+                if (KIND == K_CMPCND32) asm volatile("v_cmp_gt_f32_e32 vcc, %1, %0\n\tv_cndmask_b32_e32 %0, %0, %1, vcc" : "+v"(v[i]) : "v"(av) : "vcc");
+                if (KIND == K_CMPCND64) asm volatile("v_cmp_gt_f32_e64 %1, %2, %0\n\tv_cndmask_b32_e64 %0, %0, %2, %1" : "+v"(v[i]), "+s"(mask64) : "v"(av));
+                if (KIND == K_CMP32) asm volatile("v_cmp_gt_f32_e32 vcc, %1, %0" : : "v"(v[i]), "v"(av) : "vcc");
             }
             if (KIND == K_LDS) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
@@ -144,6 +149,7 @@ int main() {
     run_kind<K_FMA>(out); run_kind<K_PKFMA>(out); run_kind<K_MIX>(out); run_kind<K_MIXLO>(out); run_kind<K_EXP>(out); run_kind<K_RCP>(out);
     run_kind<K_PERM16>(out); run_kind<K_CNDMASK>(out); run_kind<K_MFMA>(out); run_kind<K_LDS>(out); run_kind<K_SALU>(out);
     run_kind<K_PKMULH>(out); run_kind<K_PKFMAH>(out); run_kind<K_CVTPK>(out); run_kind<K_CNDS>(out); run_kind<K_PKADD>(out); run_kind<K_MAX>(out); run_kind<K_CVT32>(out); run_kind<K_FMAABS>(out);
+    run_kind<K_CND64VCC>(out); run_kind<K_CMPCND32>(out); run_kind<K_CMPCND64>(out); run_kind<K_CMP32>(out);
     run_mix<12, 0, 0, 0>(out); run_mix<0, 60, 0, 0>(out);
     run_mix<12, 60, 0, 0>(out); run_mix<12, 60, 1, 0>(out); run_mix<12, 60, 0, 1>(out);
     run_mix<12, 36, 1, 0>(out); run_mix<12, 24, 1, 0>(out); run_mix<12, 12, 1, 0>(out);
