@@ -52,11 +52,32 @@ HBM_RESIDENT_BATCHES = 32      # distinct id batches the roofline_hbm_resident l
 STRICT_CYCLE = 32              # input batches the strict one-batch-per-launch loop cycles through (see main())
 
 
-def _device_table(V, D, seed, std):
+SHARD_TABLES = False
+_SHARDED_TABLES = []                       # (kept alive for the life of the process: engines read them in place)
+
+
+def _device_table(V, D, seed, std, shard=False):
     """[V, D] float32 table drawn ON the device (a 27 M x 64 table is 6.9 GB: numpy would need minutes and as much host
-    memory).  Truncated at 2 sigma like tf's truncated_normal initialiser."""
+    memory).  Truncated at 2 sigma like tf's truncated_normal initialiser.  shard: the table ROW-SHARDED over the ranks
+    (--shard-tables; sparrowrecsys_amd.dist.ShardedTable: every rank draws only its own rows and maps the peers' shards into one
+    virtual range) -- BASELINE config 4 read literally; handed to the model without a copy."""
     import torch
     g = torch.Generator(device="cuda")
+    if shard:
+        import torch.distributed as dist
+        from sparrowrecsys_amd.dist import ShardedTable
+        st = ShardedTable(V, D)
+        g.manual_seed(seed * 1009 + st.rank)
+
+        def draw(lo, hi):
+            t = torch.empty((hi - lo, D), dtype=torch.float32, device="cuda")
+            return t.normal_(0.0, 1.0, generator=g).clamp_(-2.0, 2.0).mul_(std)
+        st.fill_local(draw)
+        torch.cuda.synchronize()
+        if dist.is_available() and dist.is_initialized():
+            dist.barrier()                   # every shard is filled before any rank folds or gathers from it
+        _SHARDED_TABLES.append(st)
+        return st.table()
     g.manual_seed(seed)
     t = torch.empty((V, D), dtype=torch.float32, device="cuda")
     t.normal_(0.0, 1.0, generator=g).clamp_(-2.0, 2.0).mul_(std)
@@ -113,9 +134,10 @@ def build_workload(name, B, dist_name, seed_offset=0, big_vocab=0, NB=8):
         w = dict(small.weights)
         for i, (k, kind, v) in enumerate(fields):
             if kind == "id":
-                w["emb/" + k] = _device_table(v, D, 1000 + i, 1.0 / math.sqrt(D))
+                sh = SHARD_TABLES and v == CONFIG4_ROWS                 # (--shard-tables: the 27 M-row item table; userId's 138 k rows stay replicated)
+                w["emb/" + k] = _device_table(v, D, 1000 + i, 1.0 / math.sqrt(D), shard=sh)
                 if name == "deepfm_c4":                           # the deep part's own table of the same key (DeepFM.py:106)
-                    w["deep_emb/" + k] = _device_table(v, D, 2000 + i, 1.0 / math.sqrt(D))
+                    w["deep_emb/" + k] = _device_table(v, D, 2000 + i, 1.0 / math.sqrt(D), shard=sh)
         rng = np.random.default_rng(7)
         fo_key = "fo_cat/kernel" if name == "deepfm_v2_c4" else "head/kernel"
         model = cls(weights=_resize_first_order(small, w, fields, fo_key, rng), emb_dim=D, fields=fields, **kw)
@@ -625,6 +647,9 @@ def main():
                          "--batch rows that every rank holds; rank r scores rows [r B/N, (r+1) B/N) and the score slices are all-gathered "
                          "(north_star: 'batches shard row-wise across the 8 GPUs ... all-gather ... for the final score vector'; what one Jetty "
                          "request needs, RecForYouProcess.java:113-138) -- total work fixed as N grows")
+    ap.add_argument("--shard-tables", action="store_true",
+                    help="deepfm_c4 / deepfm_v2_c4: the 27 M-row item table(s) ROW-SHARDED over the ranks (BASELINE config 4's wording) instead of "
+                         "replicated: sparrowrecsys_amd.dist.ShardedTable, peers' rows loaded over xGMI by the unchanged fused kernel")
     ap.add_argument("--dry-run", action="store_true",
                     help="no GPU, no kernels: the launcher / process-group / grouped all-gather / timing plumbing with a stand-in "
                          "forward on CPU tensors (gloo).  For the CPU test of `--gpus N` self-spawning; the line says dry_run")
@@ -664,6 +689,8 @@ def main():
     nb_in = args.input_batches or {"deepfm_v2_c2": 64, "deepfm_c2": 16, "din_c3": 16, "din_ref": 16, "dien_ref": 16}.get(args.workload, 8)
     if args.batch and args.batch > 262144:
         nb_in = min(nb_in, 8)
+    global SHARD_TABLES
+    SHARD_TABLES = bool(args.shard_tables)
     strong = args.scaling == "strong"
     B_global, feats_global0 = B, None
     if strong:
@@ -1012,6 +1039,8 @@ def main():
                                       + ("" if world == 1 else " (one collective per %d steps, overlapped; %d collectives per region)"
                                          % (gs.G, (n_region + gs.G - 1) // gs.G)),
                        "oracle_check_max_abs_err": check,
+                       "tables_row_sharded": ("%d table(s) of %d rows row-sharded over %d rank(s), one virtual range per rank (sprk_vtable_*), peers' rows "
+                                              "loaded by the fused kernel" % (len(_SHARDED_TABLES), CONFIG4_ROWS, world)) if _SHARDED_TABLES else None,
                        "launch_overlap_streams": fan, "batches_per_launch": lb,
                        "tables": "%.0f MB of device tables: %s" % (table_mb, "beyond the 256 MB Infinity Cache (HBM-resident gather)" if table_mb > 512
                                                                       else "resident in the 256 MB Infinity Cache -- `roofline` is a fabric/cache-side rate for this "

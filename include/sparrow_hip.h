@@ -364,6 +364,31 @@ int sprk_peer_check(sprk_peer c, void* stream);
 const char* sprk_peer_memory_kind(sprk_peer c);   /* "uncached" | "fine-grained" | "default": how the receive buffer was allocated */
 void sprk_peer_destroy(sprk_peer c);
 
+/* [r4] BASELINE.json configs[3]: "DeepFM emb_dim=64, 138 k-movie x 27 M-row synthetic table, ROW-SHARDED across 8 x MI355X" (the
+ * reference holds its tables as ordinary tf.Variables of one process -- embedding_column, DeepFM.py:54-60 -- so there is no
+ * reference interface to mirror; SURVEY.md section 8(e) names the variant).  A sprk_vtable is an embedding table of rows_total rows
+ * whose rows [r S, (r + 1) S) live in rank r's HBM and which EVERY rank sees as one contiguous device array: HIP virtual memory maps
+ * the peers' allocations into one reserved range, so the fused kernels gather table[id] unchanged and a row another GPU owns is
+ * loaded over the xGMI link between the two -- no collective, no staging pass (the textbook form is an all-to-all of ids and one
+ * of rows in front of every forward).  Set-up, once: every rank calls sprk_vtable_create (collective in effect: same geometry
+ * everywhere; allocates and zero-fills its own shard), sprk_vtable_export (a POSIX file descriptor of that shard, to be sent to the
+ * other ranks of the node with SCM_RIGHTS -- sparrowrecsys_amd/dist.py ShardedTable does it over Unix sockets) and, for each peer's
+ * descriptor, sprk_vtable_import.  sprk_vtable_info: the base of the whole table (rank r's rows start at r * shard_rows), rows per
+ * rank (ceil(rows_total / world) rounded up so that shards are whole allocation granules), shards mapped so far.  row_bytes must be a
+ * multiple of 16.  The table outlives every engine that was given it through sprk_upload_external. */
+typedef struct sprk_vtable_s* sprk_vtable;
+int sprk_vtable_create(int64_t rows_total, int32_t row_bytes, int32_t world, int32_t rank, sprk_vtable* out);
+int sprk_vtable_export(sprk_vtable v, int32_t* fd_out);
+int sprk_vtable_import(sprk_vtable v, int32_t peer_rank, int32_t fd);
+int sprk_vtable_info(sprk_vtable v, void** base, int64_t* shard_rows, int32_t* ranks_mapped);
+void sprk_vtable_destroy(sprk_vtable v);
+
+/* [r4] sprk_upload without the copy: the slot READS `bytes` of caller-owned device memory at dev_ptr (16-byte aligned, in the
+ * slot's device layout -- a table as [vocab + 1][Dp] floats with its last row zero) for as long as the handle lives; the engine
+ * never frees it.  For tables that are already where they should be: a sprk_vtable, or a 6.9 GB tensor that sprk_upload would
+ * duplicate (embedding_column's variable, DeepFM.py:55,60). */
+int sprk_upload_external(sprk_handle h, int32_t slot, const void* dev_ptr, size_t bytes);
+
 const char* sprk_last_error(void);
 
 #ifdef __cplusplus

@@ -36,6 +36,7 @@ EXPORTED_SYMBOLS = [
     "sprk_pack_csv", "sprk_pack_csv_mt", "sprk_pack_csv_device", "sprk_csv_last_path", "sprk_set_many_streams", "sprk_set_many_batches", "sprk_emb_rank",
     "sprk_describe", "sprk_comm_unique_id", "sprk_comm_create", "sprk_comm_allgather_scores", "sprk_comm_destroy",
     "sprk_peer_create", "sprk_peer_connect", "sprk_peer_allgather_scores", "sprk_peer_check", "sprk_peer_memory_kind", "sprk_peer_destroy",
+    "sprk_vtable_create", "sprk_vtable_export", "sprk_vtable_import", "sprk_vtable_info", "sprk_vtable_destroy", "sprk_upload_external",
 ]
 
 
@@ -171,6 +172,13 @@ def load_library():
         lib.sprk_peer_memory_kind.restype = C.c_char_p
         lib.sprk_peer_destroy.argtypes = [vp]
         lib.sprk_peer_destroy.restype = None
+        lib.sprk_vtable_create.argtypes = [C.c_int64, i32, i32, i32, C.POINTER(vp)]
+        lib.sprk_vtable_export.argtypes = [vp, C.POINTER(i32)]
+        lib.sprk_vtable_import.argtypes = [vp, i32, i32]
+        lib.sprk_vtable_info.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_int64), C.POINTER(i32)]
+        lib.sprk_vtable_destroy.argtypes = [vp]
+        lib.sprk_vtable_destroy.restype = None
+        lib.sprk_upload_external.argtypes = [vp, i32, vp, sz]
         lib.sprk_set_many_streams.argtypes = [vp, i32]
         lib.sprk_set_many_batches.argtypes = [vp, i32]
         lib.sprk_pack_csv.argtypes = [C.c_char_p, sz, C.POINTER(CsvCol), i32, C.POINTER(C.c_char_p), i32, i32, vp, vp,
@@ -181,7 +189,7 @@ def load_library():
         lib.sprk_csv_last_path.argtypes = []
         lib.sprk_emb_rank.argtypes = [vp, vp, i32, i32, i32, vp, vp, i32, i32, vp, i32, vp, vp, vp]
         for name in EXPORTED_SYMBOLS:
-            if name not in ("sprk_last_error", "sprk_destroy", "sprk_workspace_bytes", "sprk_comm_destroy", "sprk_peer_destroy", "sprk_peer_memory_kind"):
+            if name not in ("sprk_last_error", "sprk_destroy", "sprk_workspace_bytes", "sprk_comm_destroy", "sprk_peer_destroy", "sprk_peer_memory_kind", "sprk_vtable_destroy"):
                 getattr(lib, name).restype = C.c_int
         _lib = lib
         return lib

@@ -32,6 +32,7 @@ int sprk_create(const sprk_plan* plan, sprk_handle* out) {
     h->plan = *plan;
     h->slot_ptr.assign(plan->n_slots, nullptr);
     h->slot_bytes.assign(plan->n_slots, 0);
+    h->slot_external.assign(plan->n_slots, 0);
     int off = 0;
     for (int b = 0; b < plan->n_bufs; ++b) {
         h->buf_stride[b] = lds_stride(plan->buf_width[b]);
@@ -64,7 +65,9 @@ int sprk_upload(sprk_handle h, int32_t slot, const void* src, size_t bytes) {
     if (!h || !src || bytes == 0) return fail(SPRK_EINVAL, "bad upload arguments");
     if (slot < 0 || slot >= h->plan.n_slots) return fail(SPRK_EINVAL, "slot %d outside [0,%d)", slot, h->plan.n_slots);
     if (h->finalized) return fail(SPRK_ESTATE, "upload after finalize");
-    if (h->slot_ptr[slot]) { (void)hipFree(h->slot_ptr[slot]); h->slot_ptr[slot] = nullptr; }
+    if (h->slot_ptr[slot] && !h->slot_external[slot]) (void)hipFree(h->slot_ptr[slot]);
+    h->slot_ptr[slot] = nullptr;
+    h->slot_external[slot] = 0;
     // 16 spare bytes so a float4 tail read of a [len]-float vector never leaves the allocation
     HIP_TRY(hipMalloc(&h->slot_ptr[slot], bytes + 16));
     HIP_TRY(hipMemset(h->slot_ptr[slot], 0, bytes + 16));

@@ -554,8 +554,8 @@ int sprk_debug_set_trace(sprk_handle h, void* dev_buf, size_t bytes) {
 
 void sprk_destroy(sprk_handle h) {
     if (!h) return;
-    for (void* p : h->slot_ptr)
-        if (p) (void)hipFree(p);
+    for (size_t i = 0; i < h->slot_ptr.size(); ++i)
+        if (h->slot_ptr[i] && !h->slot_external[i]) (void)hipFree(h->slot_ptr[i]);
     if (h->dev_plan) (void)hipFree(h->dev_plan);
     if (h->v2_image) (void)hipFree(h->v2_image);
     if (h->v2_fo_all) (void)hipFree(h->v2_fo_all);

@@ -7,6 +7,7 @@ struct sprk_engine {
     sprk_plan plan;
     std::vector<void*> slot_ptr;
     std::vector<size_t> slot_bytes;
+    std::vector<char> slot_external;      // [r4] sprk_upload_external: the slot reads caller-owned device memory (never freed here)
     DevPlan* dev_plan = nullptr;
     int* dev_err = nullptr;
     bool finalized = false;

@@ -22,6 +22,7 @@
 // anonymous namespaces (kernels, host helpers) and are meaningful only in this order:
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
+#include <unistd.h>
 
 #include <cstdarg>
 #include <cstdint>
@@ -67,4 +68,5 @@
 #include "api_engine.h"              // C ABI: sprk_last_error .. sprk_create / sprk_upload / sprk_finalize / sprk_workspace_bytes
 #include "api_forward.h"             // C ABI: sprk_din_pool, sprk_forward, sprk_forward_many, sprk_describe, sprk_check_ids, sprk_destroy, operators, emb ranker
 #include "api_ingest.h"              // C ABI: CSV ingest on the host (sprk_pack_csv[_mt]) and on the device (sprk_pack_csv_device), sprk_cross_hash
-#include "api_comm.h"                // C ABI: the score all-gather over RCCL (sprk_comm_*) and as direct peer writes (sprk_peer_*)
+#include "api_comm.h"
+#include "api_vtable.h"              // C ABI: a row-sharded table every rank sees as one (sprk_vtable_*: HIP virtual memory over xGMI), sprk_upload_external                // C ABI: the score all-gather over RCCL (sprk_comm_*) and as direct peer writes (sprk_peer_*)

@@ -165,6 +165,138 @@ class PeerScoreComm:
             pass
 
 
+def exchange_fds(my_fd: int, group=None) -> dict:
+    """Every rank of a NODE hands one open file descriptor to every other rank: {peer rank: the peer's descriptor, open in this
+    process}.  Descriptors cross process boundaries only as SCM_RIGHTS ancillary data of a Unix-domain socket, so: rank 0 makes a
+    private directory and broadcasts its name through the process group, every rank listens on <dir>/<rank>, a barrier, every
+    rank connects to every peer and sends (its rank, its descriptor), then accepts world - 1 connections.  Works on any backend
+    (the descriptors never touch the collective); CPU test: tests/test_dist_cpu.py over gloo with pipe descriptors."""
+    import shutil
+    import socket
+    import tempfile
+
+    import torch.distributed as dist
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    if world == 1:
+        return {}
+    box = [tempfile.mkdtemp(prefix="sprk_fds_") if rank == 0 else None]
+    dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+    d = box[0]
+    srv = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
+    got = {}
+    try:
+        srv.bind(os.path.join(d, str(rank)))
+        srv.listen(world)
+        dist.barrier(group=group)                              # everybody listens
+        for peer in range(world):
+            if peer == rank:
+                continue
+            c = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
+            c.connect(os.path.join(d, str(peer)))
+            socket.send_fds(c, [("%d" % rank).encode()], [my_fd])
+            c.close()
+        for _ in range(world - 1):
+            conn, _addr = srv.accept()
+            msg, fds, _flags, _a = socket.recv_fds(conn, 64, 1)
+            conn.close()
+            if len(fds) != 1:
+                raise RuntimeError("exchange_fds: a peer sent %d descriptors" % len(fds))
+            got[int(msg.decode())] = fds[0]
+        dist.barrier(group=group)                              # nobody removes the directory under a peer that still connects
+    finally:
+        srv.close()
+        if rank == 0:
+            shutil.rmtree(d, ignore_errors=True)
+    if sorted(got) != [r for r in range(world) if r != rank]:
+        raise RuntimeError("exchange_fds: descriptors from ranks %s, expected all of the %d peers" % (sorted(got), world - 1))
+    return got
+
+
+class _DevView:
+    """A raw device pointer as something torch.as_tensor can wrap without copying (__cuda_array_interface__ v3)."""
+
+    def __init__(self, ptr: int, shape, owner=None):
+        self.__cuda_array_interface__ = {"shape": tuple(int(x) for x in shape), "typestr": "<f4", "data": (int(ptr), False), "version": 3, "strides": None}
+        self._owner = owner
+
+
+class ShardedTable:
+    """An embedding table of ``rows`` x ``dim`` float32 ROW-SHARDED over the ranks of a node, which every rank reads as ONE device
+    array (include/sparrow_hip.h sprk_vtable_*: HIP virtual memory maps the peers' shards into one range; a row another GPU owns is
+    LOADED over the xGMI link between the two by the same fused kernel that gathers a replicated table -- no all-to-all of ids and
+    rows in front of the forward).  BASELINE config 4 read literally ("27 M-row table, row-sharded across 8 x MI355X").
+
+    ``local``  this rank's rows as a torch view ``[shard_rows, Dp]`` -- fill it (a checkpoint shard, an initialiser); global row g
+               lives on rank ``g // shard_rows`` at local row ``g % shard_rows``;
+    ``table()``  the whole table as a ``plan.DeviceTable`` (device layout ``[rows + 1, Dp]``, the all-zero row at index ``rows``) to
+               hand to a model as its ``emb/<key>`` weight.
+    Collective: every rank of the group constructs it with the same geometry.  The table must outlive the engines built on it."""
+
+    def __init__(self, rows: int, dim: int, group=None):
+        import ctypes as C
+
+        import torch
+        import torch.distributed as dist
+
+        from . import _lib as L
+        from .plan import pad4
+        self.lib, self._L, self._C = L.load_library(), L, C
+        on = dist.is_available() and dist.is_initialized()
+        self.rank = dist.get_rank(group) if on else 0
+        self.world = dist.get_world_size(group) if on else 1
+        self.rows, self.dim, self.Dp = int(rows), int(dim), pad4(int(dim))
+        self.handle = C.c_void_p()
+        L.check(self.lib.sprk_vtable_create(self.rows + 1, self.Dp * 4, self.world, self.rank, C.byref(self.handle)))
+        try:
+            if self.world > 1:
+                fd = C.c_int32(-1)
+                L.check(self.lib.sprk_vtable_export(self.handle, C.byref(fd)))
+                peers = exchange_fds(int(fd.value), group)
+                for peer, pfd in sorted(peers.items()):
+                    try:
+                        L.check(self.lib.sprk_vtable_import(self.handle, peer, pfd))
+                    finally:
+                        os.close(pfd)                              # (the import holds its own reference)
+            base, srows, mapped = C.c_void_p(), C.c_int64(), C.c_int32()
+            L.check(self.lib.sprk_vtable_info(self.handle, C.byref(base), C.byref(srows), C.byref(mapped)))
+            if mapped.value != self.world:
+                raise RuntimeError("ShardedTable: %d of %d shards mapped" % (mapped.value, self.world))
+        except Exception:
+            self.close()
+            raise
+        self.base, self.shard_rows = int(base.value), int(srows.value)
+        dev = torch.device("cuda", torch.cuda.current_device())
+        self.local = torch.as_tensor(_DevView(self.base + self.rank * self.shard_rows * self.Dp * 4, (self.shard_rows, self.Dp), self), device=dev)
+        self._full = torch.as_tensor(_DevView(self.base, (self.rows + 1, self.Dp), self), device=dev)
+
+    def owned_rows(self) -> Tuple[int, int]:
+        """Global rows [lo, hi) that live in this rank's shard (clipped to the table)."""
+        lo = min(self.rank * self.shard_rows, self.rows)
+        return lo, min(lo + self.shard_rows, self.rows)
+
+    def fill_local(self, rows_lo_hi_to_values: Callable):
+        """``local[: hi - lo, : dim] = f(lo, hi)`` for this rank's global row range -- f returns a [hi - lo, dim] CUDA tensor."""
+        lo, hi = self.owned_rows()
+        if hi > lo:
+            self.local[:hi - lo, :self.dim] = rows_lo_hi_to_values(lo, hi)
+
+    def table(self):
+        from .plan import DeviceTable
+        return DeviceTable(self._full, self.rows, self.dim, keepalive=self)
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.local = self._full = None
+            self.lib.sprk_vtable_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def shard_bounds(n_rows: int, rank: int, world: int) -> Tuple[int, int]:
     """Rows [lo, hi) owned by ``rank``: contiguous, sizes differ by at most one, earlier ranks larger."""
     if world <= 0 or not 0 <= rank < world:

@@ -20,7 +20,7 @@ from typing import Dict, List, Mapping, Optional, Sequence, Tuple
 import numpy as np
 
 from . import _lib as L
-from .plan import PlanBuilder, pad4, pad16, pad_table
+from .plan import DeviceTable, PlanBuilder, pad4, pad16, pad_table
 from .schema import (GENRE_VOCAB, HISTORY_KEYS, MOVIE_BUCKETS, MOVIE_GENRE_KEYS, N_GENRES, NUMERIC_KEYS,
                      USER_BUCKETS, USER_GENRE_KEYS, IdColumn, iter_feature_batches, pack_dense, pack_ids,
                      to_int_column)
@@ -55,9 +55,14 @@ class Engine:
             raise RuntimeError("no HIP device visible: the SparrowRecSys HIP forward has no CPU fallback")
         self._plan = plan
         self.handle = C.c_void_p()
+        self._external = []
         L.check(self.lib.sprk_create(C.byref(plan), C.byref(self.handle)))
         try:
             for i, a in enumerate(slots):
+                if isinstance(a, DeviceTable):                    # already where it should be (6.9 GB tables, row-sharded tables): no copy
+                    L.check(self.lib.sprk_upload_external(self.handle, i, C.c_void_p(a.data_ptr()), a.nbytes))
+                    self._external.append(a)                      # (the table must outlive the handle)
+                    continue
                 if hasattr(a, "data_ptr"):
                     ptr, nbytes = a.data_ptr(), a.numel() * a.element_size()
                 else:

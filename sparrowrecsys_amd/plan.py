@@ -30,11 +30,59 @@ def pad16(n: int) -> int:
     return (n + 15) & ~15
 
 
+class DeviceTable:
+    """An embedding table that is ALREADY in the device layout -- ``[V + 1, Dp]`` float32, rows padded to 16-byte lanes, row V all
+    zero -- in device memory its owner keeps alive: ``pad_table`` hands it through and the engine takes it with
+    ``sprk_upload_external`` (no copy).  Two uses: a table too large to duplicate (BASELINE config 4's 27 M x 64 is 6.9 GB; the
+    padded copy plus ``sprk_upload``'s copy made three of them), and a ROW-SHARDED table (``sparrowrecsys_amd.dist.ShardedTable``:
+    one virtual range over every rank's shard, include/sparrow_hip.h sprk_vtable_*).  Quacks like the ``[V, D]`` weight it stands
+    for where the host code looks at weights: ``shape``, ``data_ptr()``, ``device``, row indexing (what bench.py's oracle check
+    pulls)."""
+
+    def __init__(self, tensor, vocab: int, dim: int, keepalive=None):
+        if tuple(tensor.shape) != (vocab + 1, pad4(dim)) or not tensor.is_contiguous() or str(tensor.dtype) != "torch.float32":
+            raise ValueError("DeviceTable wants a contiguous float32 [vocab + 1, pad4(dim)] device tensor, got %s %s" % (tuple(tensor.shape), tensor.dtype))
+        self.tensor, self.vocab, self.dim, self.keepalive = tensor, int(vocab), int(dim), keepalive
+
+    @classmethod
+    def from_rows(cls, table):
+        """A [V, D] CUDA tensor -> device layout, ONE copy (instead of pad_table's copy plus sprk_upload's)."""
+        import torch
+        V, D = table.shape
+        out = torch.zeros((V + 1, pad4(D)), dtype=torch.float32, device=table.device)
+        out[:V, :D] = table
+        return cls(out, V, D)
+
+    @property
+    def shape(self):
+        return (self.vocab, self.dim)
+
+    @property
+    def device(self):
+        return self.tensor.device
+
+    @property
+    def nbytes(self):
+        return self.tensor.numel() * 4
+
+    def data_ptr(self):
+        return self.tensor.data_ptr()
+
+    def __getitem__(self, idx):
+        return self.tensor[:self.vocab, :self.dim][idx]
+
+    def cpu(self):
+        return self.tensor[:self.vocab, :self.dim].cpu()
+
+
 def pad_table(table):
     """[V, D] -> device layout [V+1, Dp]: rows padded to whole 16-byte lanes, plus ONE all-zero row at
     index V.  The fused kernels point a missing / out-of-vocabulary id at that row, so "no id ->
     zero vector" (safe_embedding_lookup_sparse) costs no select; valid rows are copied bit-exactly.
-    A torch CUDA tensor (tables too large to build on the host, e.g. BASELINE config 4's 27 M x 64) is padded on its device."""
+    A torch CUDA tensor (tables too large to build on the host, e.g. BASELINE config 4's 27 M x 64) is padded on its device; a
+    ``DeviceTable`` is in that layout already."""
+    if isinstance(table, DeviceTable):
+        return table
     if hasattr(table, "data_ptr"):
         import torch
         V, D = table.shape

@@ -141,3 +141,46 @@ def test_grouped_score_gather_two_ranks():
             for r in range(world):
                 for j in range(nb):
                     np.testing.assert_array_equal(v[r, j], np.arange(8, dtype=np.float32) + 1000 * r + 100 * (3 * gi + j))
+
+
+def _fd_worker(rank, world, port, q):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from sparrowrecsys_amd.dist import exchange_fds
+        rd, wr = os.pipe()                                   # this rank keeps the read end, the peers get the write end
+        peers = exchange_fds(wr, None)
+        os.close(wr)
+        for peer, fd in sorted(peers.items()):
+            os.write(fd, b"%d->%d;" % (rank, peer))          # through the PEER's pipe, opened in this process by SCM_RIGHTS
+            os.close(fd)
+        dist.barrier()
+        data = b""
+        while data.count(b";") < world - 1:
+            data += os.read(rd, 256)
+        q.put((rank, sorted(peers), data))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_ranks_exchange_file_descriptors(world):
+    """What sparrowrecsys_amd.dist.ShardedTable needs from the host side: every rank's descriptor (there: the shareable handle of
+    its shard of a row-sharded table, include/sparrow_hip.h sprk_vtable_export) open in every other rank -- here pipe ends, so each
+    rank can prove it holds the peers' descriptors by writing through them."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_fd_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, peers, data in results:
+        assert peers == [r for r in range(world) if r != rank]
+        assert sorted(data.decode().strip(";").split(";")) == sorted("%d->%d" % (r, rank) for r in range(world) if r != rank)
