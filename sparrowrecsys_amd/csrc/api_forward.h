@@ -41,13 +41,21 @@ static int launch_din_fused(sprk_handle h, const int32_t* ids, const float* dens
     c.ts_log2 = c.ts == 4 ? 2 : (c.ts == 2 ? 1 : 0);
     c.ql = ((c.T + 3) / 4 + 3) & ~3;                          // slots per quarter, a multiple of four: a trip of the slot loop (two pairs) never straddles one
     const int kc = h->din_cols_kc;
-    const size_t lds = ((size_t)DF_COEF_FLOATS + (tail ? (size_t)DinFusedImg::total_pad : 0) + (size_t)DF_WAVES * 16 * c.idp + (size_t)DF_WAVES * 2 * 64 * 4 * kc) * sizeof(float);
+    const size_t lds = ((size_t)DF_COEF_FLOATS + (tail ? (size_t)DinFusedImg::total_pad + DinFusedImg::unf_floats : 0) + (size_t)DF_WAVES * 16 * c.idp +
+                        (size_t)DF_WAVES * (tail ? 1 : 2) * 64 * 4 * kc) * sizeof(float);   // (k_din_fused.h: PREG)
     const long long grid = (ntasks * c.ts + DF_WAVES - 1) / DF_WAVES;
 #define DF_LAUNCH(KC, MB, TAIL, marg)                                                                                                   \
     hipLaunchKernelGGL((k_din_fused<KC, MB, TAIL>), dim3((unsigned)grid), dim3(DF_WAVES * 64), lds, st, c, MB ? (const int*)nullptr : ids, \
                        MB ? (const float*)nullptr : dense, MB ? (float*)nullptr : out, MB ? (float*)nullptr : att, B, h->dev_err, marg)
 #ifdef SPRK_DF_XP
-    if (h->tune.df_xp && kc == 2 && !many && !tail && !att) {     // ablation builds only (scripts/r04): garbage out, the time is the point
+    if (h->tune.df_xp >= 128 && kc == 2 && !many && tail) {       // the tail's ablations
+#define DF_XPT(X) case X: hipLaunchKernelGGL((k_din_fused<2, false, true, false, X>), dim3((unsigned)grid), dim3(DF_WAVES * 64), lds, st, c, ids, dense, out, att, B, h->dev_err, DinFusedOne{}); break;
+        switch (h->tune.df_xp) { DF_XPT(128) DF_XPT(256) DF_XPT(512) DF_XPT(896) default: return fail(SPRK_EINVAL, "SPRK_DF_XP=%d is not compiled in", h->tune.df_xp); }
+#undef DF_XPT
+        HIP_TRY(hipGetLastError());
+        return SPRK_OK;
+    }
+    if (h->tune.df_xp && h->tune.df_xp < 128 && kc == 2 && !many && !tail && !att) {     // ablation builds only (scripts/r04): garbage out, the time is the point
 #define DF_XP(X) case X: hipLaunchKernelGGL((k_din_fused<2, false, false, false, X>), dim3((unsigned)grid), dim3(DF_WAVES * 64), lds, st, c, ids, dense, out, att, B, h->dev_err, DinFusedOne{}); break;
         switch (h->tune.df_xp) { DF_XP(1) DF_XP(2) DF_XP(4) DF_XP(8) DF_XP(16) DF_XP(32) DF_XP(64) DF_XP(3) DF_XP(56) DF_XP(60) DF_XP(63) DF_XP(127) DF_XP(65) DF_XP(126) default: return fail(SPRK_EINVAL, "SPRK_DF_XP=%d is not compiled in", h->tune.df_xp); }
 #undef DF_XP

@@ -62,6 +62,12 @@ struct DinFusedRun {
     int col[DT_MAX_COLS], tvocab[DT_MAX_COLS];
     const float* Ftab[DT_MAX_COLS];       // [vocab][128] folded rows of fc0 (fold_first_dense)
     float head_bias, inv_w1_scale, inv_w0p_scale;
+    // UNF: columns unf_g[0 .. n_unf) of the tail's column list arrive as RAW rows Etab (k_din_tail.h: [hi 32 halfs | lo 32 halfs] * e_scale,
+    // 128 bytes per id, an all-zero row at index vocab) and meet their A fragments (image + total_pad) on the matrix pipe; the other
+    // columns stay folded rows.  n_unf = 0: every column folded.
+    int n_unf, unf_g[2];
+    const _Float16* Etab[2];
+    float e_unscale;
     int b0_slot;                          // fc0's bias rides in this (free) numeric slot against a constant 1; -1: added by the VALU
     const float* image;                   // DinFusedImg, built once by k_din_fused_pack
 };
@@ -85,6 +91,9 @@ struct DinFusedImg {
     static constexpr int off_a0 = off_b0 + N0, off_b1 = off_a0 + N0, off_a1 = off_b1 + N1, off_hw = off_a1 + N1;
     static constexpr int total = off_hw + N1;
     static constexpr int total_pad = (total + 255) & ~255;
+    // UNF (emb_dim 17..32): up to two LARGE-vocabulary embedding columns of fc0 (DIN: userId, the candidate's movieId) as raw split
+    // rows on the matrix pipe instead of folded rows -- their A fragments [2 columns][N0C][hi 256 | lo 256] behind the image
+    static constexpr int unf_floats = 2 * N0C * 512;
 };
 constexpr int DF_COEF_FLOATS = 2 * 64 * 36;
 
@@ -94,7 +103,7 @@ __global__ __launch_bounds__(256) void k_din_fused_pack(const float* __restrict_
                                                         float w0p_scale, int EL, const float* __restrict__ b0, const float* __restrict__ a0,
                                                         const float* __restrict__ w1frag, const float* __restrict__ b1,
                                                         const float* __restrict__ a1, const float* __restrict__ hw, int n_hw,
-                                                        float* __restrict__ img) {
+                                                        float* __restrict__ img, const float* __restrict__ w0efrag, int n_unf, int unf_g0, int unf_g1) {
     using IM = DinFusedImg;
     const int tid = threadIdx.x;
     _Float16* wp = reinterpret_cast<_Float16*>(img + IM::off_w0p);
@@ -121,13 +130,19 @@ __global__ __launch_bounds__(256) void k_din_fused_pack(const float* __restrict_
         img[IM::off_hw + i] = i < n_hw ? hw[i] : 0.f;
     }
     for (int i = IM::total + tid; i < IM::total_pad; i += 256) img[i] = 0.f;
+    // UNF: the A fragments of columns unf_g[u] out of k_din_tail's fragment buffer w0efrag ([nb][4 columns][hi 256 | lo 256] floats)
+    for (int i = tid; i < IM::unf_floats; i += 256) {
+        const int w = i & 511, nb = (i >> 9) % IM::N0C, u = i / (512 * IM::N0C);
+        img[IM::total_pad + i] = (w0efrag && u < n_unf) ? w0efrag[((size_t)(nb * 4 + (u == 0 ? unf_g0 : unf_g1)) * 2) * 256 + w] : 0.f;
+    }
 }
 
 typedef _Float16 df_h2 __attribute__((ext_vector_type(2)));
 typedef float df_f2 __attribute__((ext_vector_type(2)));
 
 // XP: ablation bits for scripts/r04 experiments (only instantiated under -DSPRK_DF_XP): 1 no MFMAs, 2 no product split, 4 no h32,
-// 8 no PReLU dot, 16 no reduce / sigmoid, 32 no pooling, 64 no row loads in the loop -- results are garbage, the time is the point
+// 8 no PReLU dot, 16 no reduce / sigmoid, 32 no pooling, 64 no row loads in the loop; TAIL: 128 no folded-row gathers, 256 no fc1, 512 no
+// fc0 MFMAs (numerics + pooled) -- results are garbage, the time is the point
 template <int KC, bool MB, bool TAIL, bool ATT = false, int XP = 0>
 __global__ __launch_bounds__(DF_WAVES * 64, 2) void k_din_fused(const DinFusedRun A, const int* __restrict__ ids, const float* __restrict__ dense,
                                                               float* __restrict__ out, float* __restrict__ att, int B, int* __restrict__ err,
@@ -146,9 +161,13 @@ __global__ __launch_bounds__(DF_WAVES * 64, 2) void k_din_fused(const DinFusedRu
     float* ca_s = smem;                                   // [64][AS]  w2 (1 + alpha) / 2
     float* cb_s = smem + ROWS * AS;                       // [64][AS]  w2 (1 - alpha) / 2
     float* img_s = smem + DF_COEF_FLOATS;                 // TAIL: the tail's weights
-    constexpr int img_floats = TAIL ? IM::total_pad : 0;
+    constexpr int img_floats = TAIL ? IM::total_pad + IM::unf_floats : 0;
     int* ids_s = reinterpret_cast<int*>(smem + DF_COEF_FLOATS + img_floats) + wave * 16 * A.idp;
-    float* park_s = smem + DF_COEF_FLOATS + img_floats + DF_WAVES * 16 * A.idp + wave * 2 * 64 * EL;   // two parking slots per wave: S0, S1
+    // TAIL: the quarter sums stay in registers (the LDS they would park in holds the UNF fragments) and only the cross-wave combine
+    // of ts > 1 goes through ONE slot per wave; attention only: two parking slots per wave in LDS, S0, S1
+    constexpr bool PREG = TAIL;
+    constexpr int PSL = PREG ? 1 : 2;
+    float* park_s = smem + DF_COEF_FLOATS + img_floats + DF_WAVES * 16 * A.idp + wave * PSL * 64 * EL;
 
     // ---- coefficient tables and (TAIL) the tail image by LDS-DMA: 1-KB pieces, wave w takes w, w + 8, ... ----
 #pragma unroll 1
@@ -157,7 +176,7 @@ __global__ __launch_bounds__(DF_WAVES * 64, 2) void k_din_fused(const DinFusedRu
                                          (__attribute__((address_space(3))) void*)(smem + c * 256), 16, 0, 0);
     if constexpr (TAIL) {
 #pragma unroll 1
-        for (int c = wave; c < IM::total_pad / 256; c += DF_WAVES)
+        for (int c = wave; c < (IM::total_pad + (A.n_unf ? IM::unf_floats : 0)) / 256; c += DF_WAVES)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(A.image + c * 256 + lane * 4),
                                              (__attribute__((address_space(3))) void*)(img_s + c * 256), 16, 0, 0);
     }
@@ -289,7 +308,23 @@ __global__ __launch_bounds__(DF_WAVES * 64, 2) void k_din_fused(const DinFusedRu
     //   finish: nq = 1: q        nq = 2: S0 + q1                 nq = 4: S1 + (S0 + q3)
     float* S0 = park_s;
     float* S1 = park_s + 64 * EL;
+    float R0[PREG ? EL : 1], R1[PREG ? EL : 1];
+    if constexpr (PREG) {
+#pragma unroll
+        for (int e = 0; e < EL; ++e) { R0[e] = 0.f; R1[e] = 0.f; }
+    }
     auto park = [&](int j) {
+        if constexpr (PREG) {
+            // (selects, not two branches: hipcc merged the branches' stores into ONE store through a scratch slot with a dynamic address)
+            const bool odd = (j & 1) != 0;
+#pragma unroll
+            for (int e = 0; e < EL; ++e) {
+                const float sm = R0[e] + pacc[e];
+                R1[e] = odd ? sm : R1[e];
+                R0[e] = odd ? R0[e] : pacc[e];
+                pacc[e] = 0.f;
+            }
+        } else {
         if ((j & 1) == 0) {
 #pragma unroll
             for (int e = 0; e < EL; ++e) S0[e * 64 + lane] = pacc[e];
@@ -299,6 +334,7 @@ __global__ __launch_bounds__(DF_WAVES * 64, 2) void k_din_fused(const DinFusedRu
         }
 #pragma unroll
         for (int e = 0; e < EL; ++e) pacc[e] = 0.f;
+        }
     };
     // ---- a pair of slots, first half: u = W12 h + W4 (h * c) + vc[cand] of both slots on the matrix pipe; h back to f32 ----
     // PReLU(alpha[t][n]) -> Dense(1) (DIN.py:150-151) as ca u + cb |u| summed over this lane's eight units; the coefficient rows are
@@ -473,10 +509,10 @@ __global__ __launch_bounds__(DF_WAVES * 64, 2) void k_din_fused(const DinFusedRu
         for (int e = 0; e < EL; ++e) res[e] = pacc[e];
     } else if (nq == 2) {
 #pragma unroll
-        for (int e = 0; e < EL; ++e) res[e] = S0[e * 64 + lane] + pacc[e];
+        for (int e = 0; e < EL; ++e) res[e] = (PREG ? R0[PREG ? e : 0] : S0[e * 64 + lane]) + pacc[e];
     } else {
 #pragma unroll
-        for (int e = 0; e < EL; ++e) res[e] = S1[e * 64 + lane] + (S0[e * 64 + lane] + pacc[e]);
+        for (int e = 0; e < EL; ++e) res[e] = (PREG ? R1[PREG ? e : 0] : S1[e * 64 + lane]) + ((PREG ? R0[PREG ? e : 0] : S0[e * 64 + lane]) + pacc[e]);
     }
     // ---- several waves per task: their results through LDS, slice 0 sums in the fixed order ----
     if (A.ts > 1) {
@@ -486,14 +522,14 @@ __global__ __launch_bounds__(DF_WAVES * 64, 2) void k_din_fused(const DinFusedRu
         }
         __syncthreads();
         if (slice == 0) {
-            const float* P = park_s + 2 * 64 * EL;           // the next wave's S0
+            const float* P = park_s + PSL * 64 * EL;         // the next wave's S0
             if (A.ts == 2) {
 #pragma unroll
                 for (int e = 0; e < EL; ++e) res[e] = res[e] + P[e * 64 + lane];
             } else {
 #pragma unroll
                 for (int e = 0; e < EL; ++e)
-                    res[e] = (res[e] + P[e * 64 + lane]) + (P[2 * 64 * EL + e * 64 + lane] + P[4 * 64 * EL + e * 64 + lane]);
+                    res[e] = (res[e] + P[e * 64 + lane]) + (P[PSL * 64 * EL + e * 64 + lane] + P[2 * PSL * 64 * EL + e * 64 + lane]);
             }
         }
     }
@@ -526,25 +562,62 @@ __global__ __launch_bounds__(DF_WAVES * 64, 2) void k_din_fused(const DinFusedRu
             for (int nb = 0; nb < N0C; ++nb) z0[nb] = zero;
             bool tb2 = false;
             {
-                // (all four columns = 32 loads in ONE round trip: the slot loop's registers are free by now)
+                // (every column's loads in ONE round trip: the slot loop's registers are free by now)
+                // UNF columns: 128 bytes per id -- lane (r,q) takes hi / lo halfs 8q .. 8q+7 of sample r's row: the B operand
+                din_f16x8 eh[2], el[2];
+                if constexpr (KC == 2) {
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        eh[u] = din_f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                        el[u] = eh[u];
+                        if (u < A.n_unf) {                        // (wave-uniform)
+                            const int g = A.unf_g[u];
+                            const int id = g == 0 ? tid_g[0] : (g == 1 ? tid_g[1] : (g == 2 ? tid_g[2] : tid_g[3]));
+                            const int voc = g == 0 ? A.tvocab[0] : (g == 1 ? A.tvocab[1] : (g == 2 ? A.tvocab[2] : A.tvocab[3]));
+                            const bool ok = (unsigned)id < (unsigned)voc;
+                            tb2 |= !ok && id != -1;
+                            const char* row = reinterpret_cast<const char*>(A.Etab[u]) + (size_t)(ok ? id : voc) * 128 + 16 * q;
+                            eh[u] = *reinterpret_cast<const din_f16x8*>(row);
+                            el[u] = *reinterpret_cast<const din_f16x8*>(row + 64);
+                        }
+                    }
+                }
                 f32x4 f[DT_MAX_COLS][N0C];
 #pragma unroll
                 for (int g = 0; g < DT_MAX_COLS; ++g) {
                     const int id = tid_g[g];
-                    const bool ok = g < A.n_cols && (unsigned)id < (unsigned)A.tvocab[g];
-                    tb2 |= g < A.n_cols && !ok && id != -1;
+                    const bool unf = KC == 2 && ((A.n_unf > 0 && A.unf_g[0] == g) || (A.n_unf > 1 && A.unf_g[1] == g));   // (wave-uniform)
+                    const bool ok = g < A.n_cols && !unf && (unsigned)id < (unsigned)A.tvocab[g];
+                    tb2 |= g < A.n_cols && !unf && !ok && id != -1;
                     const float* frow = A.Ftab[g] + (size_t)(ok ? id : 0) * IM::N0 + 4 * q;
 #pragma unroll
-                    for (int nb = 0; nb < N0C; ++nb) f[g][nb] = ok ? ld4(frow + nb * 16) : zero;
+                    for (int nb = 0; nb < N0C; ++nb) f[g][nb] = (ok && !(XP & 128)) ? ld4(frow + nb * 16) : zero;
                 }
 #pragma unroll
                 for (int g = 0; g < DT_MAX_COLS; ++g)
 #pragma unroll
                     for (int nb = 0; nb < N0C; ++nb) z0[nb] += f[g][nb];
+                if constexpr (KC == 2) {
+                    const float* wf = img_s + IM::total_pad + lane * 4;
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        if (u < A.n_unf) {                        // (wave-uniform)
+#pragma unroll
+                            for (int nb = 0; nb < N0C; ++nb) {
+                                const din_f16x8 ah = __builtin_bit_cast(din_f16x8, ld4(wf + (u * N0C + nb) * 512));
+                                const din_f16x8 al = __builtin_bit_cast(din_f16x8, ld4(wf + (u * N0C + nb) * 512 + 256));
+                                f32x4 acc = mfma_f16(al, eh[u], zero);
+                                acc = mfma_f16(ah, el[u], acc);
+                                acc = mfma_f16(ah, eh[u], acc);
+                                z0[nb] += acc * A.e_unscale;
+                            }
+                        }
+                    }
+                }
             }
             if (__ballot(tb2) != 0 && lane == 0) atomicOr(err, 1);
         }
-        {
+        if constexpr (!(XP & 512)) {
             const float* wn = img_s + IM::off_wn + lane;
 #pragma unroll
             for (int nb = 0; nb < N0C; ++nb) z0[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wn[(nb * 2 + 0) * 64], xna, z0[nb], 0, 0, 0);
@@ -557,7 +630,7 @@ __global__ __launch_bounds__(DF_WAVES * 64, 2) void k_din_fused(const DinFusedRu
         }
         // the pooled history on the f16 pipe, from the registers it was accumulated in (k = EL q + e): per-sample dynamic scale
         // (DIN's attention weights are not normalised), hi / lo split, three products per 16 outputs
-        {
+        if constexpr (XP & 512) { z0[0][0] += res[0]; } else {
             float xp[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) xp[e] = e < EL ? res[e < EL ? e : 0] * A.inv_h_scale : 0.f;
@@ -606,7 +679,7 @@ __global__ __launch_bounds__(DF_WAVES * 64, 2) void k_din_fused(const DinFusedRu
             for (int n1 = 0; n1 < N1C; ++n1) acc[n1] = zero;
             const float* wf = img_s + IM::off_w1 + (r * 4 + q) * 4;          // this lane's 16 bytes inside a 1-KB fragment (k_dyn_pack_w)
 #pragma unroll
-            for (int b = 0; b < N0C / 2; ++b) {
+            for (int b = 0; b < ((XP & 256) ? 0 : N0C / 2); ++b) {
                 din_f16x8 bh, bl;
                 dyn_split8(z0[2 * b], z0[2 * b + 1], scale, bh, bl);
 #pragma unroll
