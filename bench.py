@@ -883,9 +883,9 @@ def main():
             for sl in (slice(0, n), slice(B - n, B)):
                 ref = oracle_forward(args.workload, model, {k: v[sl] for k, v in feats[j].items()})[:, 0]
                 check = max(check, float(np.abs(chk[j][sl].cpu().numpy() - ref).max()))
-        # (DIN on k_din_fused: a launch per batch is ONE fused launch, several batches per launch are the attention + tail pipeline --
-        # two instruction sequences for the tail's fc0, equal to 3e-6, tests/test_gpu_parity.py::test_din_tail_paths; every other
-        # graph: the same bits)
+        # (DIN on k_din_fused: the same bits from a launch per batch and from the persistent several-batches launch; under
+        # SPRK_DIN_FUSED_MB=0 several batches per launch are the attention + tail pipeline -- another instruction sequence for the
+        # tail's fc0, equal to 3e-6, tests/test_gpu_parity.py::test_din_tail_paths; every other graph: the same bits)
         same = torch.equal(chk[0], outs[0]) or (eng.kernel_name() == "k_din_fused" and float((chk[0] - outs[0]).abs().max()) <= 3e-6)
         if not same:
             raise SystemExit("bench: sprk_forward_many and sprk_forward disagree on batch 0")
@@ -1127,10 +1127,11 @@ MFMA_ISSUED = {
     "k_din_attn": {"per": 1, "f32": 0, "f16": 24},
     # per (16 samples, history slot): two K blocks ([h], [h * c]) x 2 n-blocks x 3 split products; "f16" is filled in per T below
     "k_din_attn_cols": {"per": 16, "f32": 0, "f16_per_slot": 12},
-    # [r4] the same formulation in k_din_fused's slot loop; its tail epilogue: numerics two steps x 8 n-blocks on f32, the pooled
-    # history 8 n-blocks x 3 and fc1 4 x 4 K-blocks x 3 on split f16 (the embedding columns arrive as folded rows: no MFMA)
+    # [r4] the same formulation in k_din_fused's slot loop; its tail epilogue: numerics two steps x 8 n-blocks on f32; on split f16 the
+    # pooled history 8 n-blocks x 3, userId and the candidate's movieId as raw rows 2 x 8 x 3 (emb_dim 17..32; the genre columns
+    # arrive as folded rows: no MFMA) and fc1 4 x 4 K-blocks x 3
     "k_din_fused": {"per": 16, "f32": 0, "f16_per_slot": 12},
-    "k_din_fused (tail epilogue)": {"per": 16, "f32": 16, "f16": 24 + 48},
+    "k_din_fused (tail epilogue)": {"per": 16, "f32": 16, "f16": 24 + 48 + 48},
 }
 
 
@@ -1360,8 +1361,8 @@ def side_workload(args, name):
         if eng.kernel_name() in ("k_din_tail", "k_din_fused"):
             tk = "k_din_tail" if eng.kernel_name() == "k_din_tail" else "k_din_fused (tail epilogue)"
             blk["roofline_mfma_tail"] = mfma_block(tk, mfma_issued(tk, roof["tail_reference_flops"]), B, max(fwd_s - din_s, 1e-9))
-        blk["dispatch"] = ("one launch per batch: k_din_fused (attention + pooling + tail); several batches per launch: the attention launch of a group "
-                           "(k_din_fused<TAIL = false>) and ONE k_din_tail launch per group, groups alternating over two streams"
+        blk["dispatch"] = ("one launch per batch: k_din_fused (attention + pooling + tail); several batches per launch: ONE persistent k_din_fused<MB> "
+                           "launch per group of up to 16 batches (tables staged once, every wave walks its tasks), groups alternating over two streams"
                            if eng.kernel_name() == "k_din_fused" else "attention launch -> pooled vectors -> tail launch")
     else:
         ach = roof["bytes_per_sample"] * B / fwd_s / 1e9

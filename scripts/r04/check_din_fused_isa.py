@@ -39,55 +39,61 @@ for sym in names:
         print("%s: no hidden loads found" % inst); bad += 1; continue
     lo, hi = min(loads), max(drain)
     labels = {re.match(r"^(\.LBB\d+_\d+):", l).group(1): i for i, l in enumerate(body) if re.match(r"^\.LBB\d+_\d+:", l)}
-    # blocks laid out inside the region but reached only from BEFORE it (hipcc moves cold prologue arms behind the loop) are not on
-    # any path with a load in flight: skip them
-    targets = {}
-    for i, l in enumerate(body):
-        bm = re.match(r"\s*s_c?branch\w*\s+(\.LBB\d+_\d+)", l)
-        if bm: targets.setdefault(bm.group(1), []).append(i)
-    order = sorted(labels.items(), key=lambda kv: kv[1])
-    skip = set()
-    for k, (lab, pos) in enumerate(order):
-        if pos <= lo or pos > hi: continue
-        prev = pos - 1
-        while prev > 0 and (not body[prev].strip() or body[prev].strip().startswith((";", "."))): prev -= 1
-        falls_in = not re.match(r"\s*(s_branch|s_endpgm|s_setpc)", body[prev]) and prev not in skip
-        if not falls_in and all(t < lo or t in skip for t in targets.get(lab, [])):
-            end = order[k + 1][1] if k + 1 < len(order) else len(body)
-            skip |= set(range(pos, end))
-    pending = []            # FIFO of (set of registers) per outstanding hidden load
-    taken, i, steps, touches, seen_waits = set(), lo, 0, [], 0
-    loop_lines = set()
-    while i <= hi and steps < 200000:
-        steps += 1
-        t = body[i].strip()
-        if i in skip:
+    # A worklist over the control-flow graph from the first hidden load: a state is the FIFO of outstanding operations (the registers
+    # each one owns); a conditional branch forks, an edge is re-walked only with a state not seen on it before, a walk ends at the
+    # final drain (vmcnt(0) with nothing left), at s_endpgm, or where it leaves [first hidden load's block .. last drain] backwards
+    # (the next task of a persistent launch starts drained).
+    def key(p): return tuple(tuple(sorted(x)) for x in p)
+    dma_lines, wait_lines, touches, loop_lines, skip = set(), set(), [], set(), set()
+    work, seen = [(lo, [])], set()
+    steps = 0
+    while work and steps < 2000000:
+        i, pending = work.pop()
+        pending = list(pending)
+        while i < len(body) and steps < 2000000:
+            steps += 1
+            t = body[i].strip()
+            if i in asm_lines:
+                dm = re.search(r"global_load_dwordx4 v\[(\d+):(\d+)\]", t)
+                wm = re.search(r"s_waitcnt vmcnt\((\d+)\)", t)
+                if dm: pending.append(set(range(int(dm.group(1)), int(dm.group(2)) + 1)))
+                elif wm:
+                    wait_lines.add(i)
+                    n = int(wm.group(1))
+                    if len(pending) > n: pending = pending[len(pending) - n:]
+                    if i == hi: break                          # the final drain of the task
+            elif "global_load_lds_dwordx4" in t:
+                pending.append(set())                         # an LDS-DMA piece: occupies a vmcnt slot, owns no register
+                dma_lines.add(i)
+            elif t and not t.startswith((";", ".")):
+                if t.startswith("s_endpgm"): break
+                bm = re.match(r"(s_c?branch\w*)\s+(\.LBB\d+_\d+)", t)
+                if bm:
+                    tgt = labels[bm.group(2)]
+                    k = (i, tgt, key(pending))
+                    if tgt >= lo - 400 and k not in seen:    # (a branch far back: the task loop's back edge, taken drained)
+                        seen.add(k)
+                        if bm.group(1) == "s_branch": i = tgt; continue
+                        work.append((tgt, list(pending)))
+                    elif bm.group(1) == "s_branch": break
+                else:
+                    inflight = set().union(*pending) if pending else set()
+                    if regs(t) & inflight and not t.startswith("s_"): touches.append((i, t[:100]))
             i += 1
-            continue
-        if i in asm_lines:
-            dm = re.search(r"global_load_dwordx4 v\[(\d+):(\d+)\]", t)
-            wm = re.search(r"s_waitcnt vmcnt\((\d+)\)", t)
-            if dm: pending.append(set(range(int(dm.group(1)), int(dm.group(2)) + 1)))
-            elif wm:
-                seen_waits += 1
-                n = int(wm.group(1))
-                if len(pending) > n: pending = pending[len(pending) - n:]
-        elif t and not t.startswith((";", ".")):
-            bm = re.match(r"s_c?branch\w*\s+(\.LBB\d+_\d+)", t)
-            if bm and labels.get(bm.group(1), 1 << 30) <= i and lo <= labels[bm.group(1)] and (i, bm.group(1)) not in taken:
-                taken.add((i, bm.group(1)))
-                loop_lines |= set(range(labels[bm.group(1)], i + 1))
-                i = labels[bm.group(1)]
-                continue
-            inflight = set().union(*pending) if pending else set()
-            hit = regs(t) & inflight
-            if hit and not t.startswith("s_"):
-                touches.append((i, t[:100]))
-        i += 1
+    dma, seen_waits = len(dma_lines), len(wait_lines)
+    # the slot loop(s): loops (hipcc marks their header labels) behind the first hidden load that hold a manual wait with a count
+    for lab, pos in labels.items():
+        if pos < lo or "Loop Header" not in body[pos]: continue
+        back = [i for i, l in enumerate(body) if i >= pos and re.match(r"\s*s_c?branch\w*\s+%s\b" % re.escape(lab), l)]
+        if back and any(pos <= w <= max(back) and "vmcnt(0)" not in body[w] for w in wait_lines): loop_lines |= set(range(pos, max(back) + 1))
     stray = [i for i in sorted(loop_lines) if "vmcnt" in body[i] and i not in asm_lines]
+    # compiler-placed waits between the first hidden load and the loop: each is as strict as the operations the COMPILER knows to be
+    # younger (the DMA pieces), so it may only show up with a count >= the pieces still wanted in flight
+    early = [(i, body[i].strip()) for i in range(lo, hi) if "vmcnt" in body[i] and i not in asm_lines and i not in loop_lines and i not in skip]
     uniq = sorted(set(touches))
     for ln, t in uniq[:6]: print("   %s: line %d touches a register with a load in flight: %s" % (inst, ln, t))
     for ln in stray[:6]: print("   %s: compiler-placed wait inside the slot loop, line %d: %s" % (inst, ln, body[ln].strip()))
-    print("%s: %d hidden loads, %d manual waits walked, early touches %d, compiler vmcnt waits inside the loop %d" % (inst, len(loads), seen_waits, len(uniq), len(stray)))
+    print("%s: %d hidden loads, %d DMA pieces behind them, %d manual waits walked, early touches %d, compiler vmcnt waits inside the loop %d, outside it %s" %
+          (inst, len(loads), dma, seen_waits, len(uniq), len(stray), [re.search(r"vmcnt\((\d+)\)", t).group(1) for _, t in early][:8]))
     bad += len(uniq) + len(stray)
 sys.exit(1 if bad else 0)

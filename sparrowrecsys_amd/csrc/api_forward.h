@@ -8,6 +8,7 @@ static int launch_din_cols(sprk_handle h, const int32_t* ids, float* pooled, flo
     const long long slots = (long long)h->num_cus * 16;
     c.ts = (c.T >= 16 && ntasks * 4 <= slots) ? 4 : ((c.T >= 8 && ntasks * 2 <= slots) ? 2 : 1);
     if (h->tune.din_cols_ts) c.ts = h->tune.din_cols_ts;
+    if (many) c.ts = 1;                                        // several batches: the persistent form, one wave per task (k_din_fused.h)
     c.ts_log2 = c.ts == 4 ? 2 : (c.ts == 2 ? 1 : 0);
     c.ql = (c.T + 3) / 4;
     const int EL = 4 * h->din_cols_kc;
@@ -41,16 +42,23 @@ static int launch_din_fused(sprk_handle h, const int32_t* ids, const float* dens
     c.ts_log2 = c.ts == 4 ? 2 : (c.ts == 2 ? 1 : 0);
     c.ql = ((c.T + 3) / 4 + 3) & ~3;                          // slots per quarter, a multiple of four: a trip of the slot loop (two pairs) never straddles one
     const int kc = h->din_cols_kc;
-    const size_t lds = ((size_t)DF_COEF_FLOATS + (tail ? (size_t)DinFusedImg::total_pad + DinFusedImg::unf_floats : 0) + (size_t)DF_WAVES * 16 * c.idp +
+    const size_t lds = ((size_t)DF_COEF_FLOATS + (tail ? (size_t)DinFusedImg::dma_floats : 0) + (size_t)DF_WAVES * 16 * c.idp +
                         (size_t)DF_WAVES * (tail ? 1 : 2) * 64 * 4 * kc) * sizeof(float);   // (k_din_fused.h: PREG)
-    const long long grid = (ntasks * c.ts + DF_WAVES - 1) / DF_WAVES;
+    long long grid = (ntasks * c.ts + DF_WAVES - 1) / DF_WAVES;
+    if (many && grid > h->num_cus) grid = h->num_cus;         // persistent: the waves walk the tasks
 #define DF_LAUNCH(KC, MB, TAIL, marg)                                                                                                   \
     hipLaunchKernelGGL((k_din_fused<KC, MB, TAIL>), dim3((unsigned)grid), dim3(DF_WAVES * 64), lds, st, c, MB ? (const int*)nullptr : ids, \
                        MB ? (const float*)nullptr : dense, MB ? (float*)nullptr : out, MB ? (float*)nullptr : att, B, h->dev_err, marg)
 #ifdef SPRK_DF_XP
+    if (h->tune.df_xp == 128 && kc == 2 && many && tail) {        // the persistent form without the folded rows' gathers
+        hipLaunchKernelGGL((k_din_fused<2, true, true, false, 128>), dim3((unsigned)grid), dim3(DF_WAVES * 64), lds, st, c, (const int*)nullptr,
+                           (const float*)nullptr, (float*)nullptr, (float*)nullptr, B, h->dev_err, *many);
+        HIP_TRY(hipGetLastError());
+        return SPRK_OK;
+    }
     if (h->tune.df_xp >= 128 && kc == 2 && !many && tail) {       // the tail's ablations
 #define DF_XPT(X) case X: hipLaunchKernelGGL((k_din_fused<2, false, true, false, X>), dim3((unsigned)grid), dim3(DF_WAVES * 64), lds, st, c, ids, dense, out, att, B, h->dev_err, DinFusedOne{}); break;
-        switch (h->tune.df_xp) { DF_XPT(128) DF_XPT(256) DF_XPT(512) DF_XPT(896) default: return fail(SPRK_EINVAL, "SPRK_DF_XP=%d is not compiled in", h->tune.df_xp); }
+        switch (h->tune.df_xp) { DF_XPT(128) DF_XPT(256) DF_XPT(512) DF_XPT(896) DF_XPT(1024) default: return fail(SPRK_EINVAL, "SPRK_DF_XP=%d is not compiled in", h->tune.df_xp); }
 #undef DF_XPT
         HIP_TRY(hipGetLastError());
         return SPRK_OK;
@@ -323,9 +331,9 @@ static int forward_many_impl(sprk_handle h, int32_t n_batches, const int32_t* co
             return SPRK_OK;
         }
     }
-    // DIN on k_din_fused: up to DF_MB batches per launch, one launch does everything; groups alternate over the helper streams
-    // (SPRK_DIN_FUSED_MB=1 only: at several batches per launch the two-launch pipeline below -- attention of group g + 1 beside the tail of
-    // group g on a second stream -- measures 34.5 us per batch against 38.8 for this form)
+    // DIN on k_din_fused: up to DF_MB batches per launch, one PERSISTENT launch does everything (k_din_fused.h: tables staged once, the
+    // waves walk the tasks on their own); groups alternate over the helper streams.  32.2 us per batch of BASELINE config 3 against
+    // 33.4 for the two-launch pipeline below on the same box (profiles/r04; SPRK_DIN_FUSED_MB=0 brings the pipeline back)
     if (h->finalized && many_batches > 1 && n_batches > 1 && h->plan.din.enabled == 1 && h->din_fused && h->tune.din_fused_mb && B > 0 && ids && dense) {
         const int per = many_batches < DF_MB ? many_batches : DF_MB;
         bool ok = true;
@@ -561,6 +569,17 @@ int sprk_debug_set_trace(sprk_handle h, void* dev_buf, size_t bytes) {
 }
 
 void sprk_destroy(sprk_handle h) {
+#ifdef SPRK_DF_XP
+    if (h && h->tune.df_xp == 1024) {                              // the timeline build: the LAST launch's stamps -> $SPRK_DF_TS_FILE
+        if (const char* path = getenv("SPRK_DF_TS_FILE")) {
+            std::vector<unsigned long long> ts((size_t)DF_TS_WAVES * 8);
+            hipDeviceSynchronize();
+            if (hipMemcpyFromSymbol(ts.data(), HIP_SYMBOL(g_df_ts), ts.size() * 8) == hipSuccess) {
+                if (FILE* fp = fopen(path, "wb")) { fwrite(ts.data(), 8, ts.size(), fp); fclose(fp); }
+            }
+        }
+    }
+#endif
     if (!h) return;
     for (size_t i = 0; i < h->slot_ptr.size(); ++i)
         if (h->slot_ptr[i] && !h->slot_external[i]) (void)hipFree(h->slot_ptr[i]);

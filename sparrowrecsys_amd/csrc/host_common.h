@@ -98,7 +98,7 @@ struct SprkTuning {
     bool din_attn_many = true;        // SPRK_DIN_ATTN_MB=0         forward_many: one attention launch per batch
     bool din_cols = true;             // SPRK_DIN_COLS=0            attention on k_din_attn (wave per sample), not k_din_attn_cols
     bool din_fused = true;            // SPRK_DIN_FUSED=0           DIN as two launches (k_din_attn_cols -> pooled vectors -> k_din_tail), not k_din_fused
-    bool din_fused_mb = false;        // SPRK_DIN_FUSED_MB=1        forward_many groups on k_din_fused<MB> instead of the attention + tail pipeline
+    bool din_fused_mb = true;         // SPRK_DIN_FUSED_MB=0        forward_many groups on the attention + tail pipeline instead of the persistent k_din_fused<MB>
     bool din_mb_attn_fused = false;   // SPRK_DIN_MB_ATTN_FUSED=1   the several-batches-per-launch pipeline's attention launch on k_din_fused<TAIL = false> instead of k_din_attn_cols
     bool din_fused_unf = true;        // SPRK_DIN_FUSED_UNF=0       k_din_fused's tail with folded rows for every embedding column (no raw split rows on the matrix pipe)
     bool din_fused_always = false;    // SPRK_DIN_FUSED_ALWAYS=1    k_din_fused also for launches of more than one round of workgroups
@@ -122,7 +122,7 @@ struct SprkTuning {
         t.v1_one = !off("SPRK_V1_ONE");
         t.mlp_chain = !off("SPRK_MLP_CHAIN");
         t.din_tail = !off("SPRK_DIN_TAIL"); t.din_legacy = on("SPRK_DIN_LEGACY"); t.din_half = !off("SPRK_DIN_HALF");
-        t.din_wpb = num("SPRK_DIN_WPB", 12); t.din_attn_many = !off("SPRK_DIN_ATTN_MB"); t.din_cols = !off("SPRK_DIN_COLS"); t.din_fused = !off("SPRK_DIN_FUSED"); t.df_xp = num("SPRK_DF_XP", 0); t.din_fused_mb = on("SPRK_DIN_FUSED_MB"); t.din_fused_always = on("SPRK_DIN_FUSED_ALWAYS"); t.din_fused_unf = !off("SPRK_DIN_FUSED_UNF"); t.din_mb_attn_fused = on("SPRK_DIN_MB_ATTN_FUSED");
+        t.din_wpb = num("SPRK_DIN_WPB", 12); t.din_attn_many = !off("SPRK_DIN_ATTN_MB"); t.din_cols = !off("SPRK_DIN_COLS"); t.din_fused = !off("SPRK_DIN_FUSED"); t.df_xp = num("SPRK_DF_XP", 0); t.din_fused_mb = !off("SPRK_DIN_FUSED_MB"); t.din_fused_always = on("SPRK_DIN_FUSED_ALWAYS"); t.din_fused_unf = !off("SPRK_DIN_FUSED_UNF"); t.din_mb_attn_fused = on("SPRK_DIN_MB_ATTN_FUSED");
         { const int n = num("SPRK_DIN_COLS_TS", 0); t.din_cols_ts = (n == 1 || n == 2 || n == 4) ? n : 0; }
         { const int n = num("SPRK_MANY_STREAMS", 0); t.many_streams = n < 2 ? 0 : (n > 4 ? 4 : n); }
         return t;

@@ -223,7 +223,7 @@ int setup_din_tail(sprk_engine* h, DevPlan* dp) {
     if (h->din_fused_attn && p.model_kind == SPRK_MODEL_DIN && p.din.enabled == 1 && n0c == DinFusedImg::N0C && n1c == DinFusedImg::N1C &&
         w1frag && w0pfrag && Dp <= 16 * h->din_cols_kc && tp.len <= DinFusedImg::N1) {
         const int kc = h->din_cols_kc;
-        const int lds_full = (DF_COEF_FLOATS + DinFusedImg::total_pad + DinFusedImg::unf_floats + DF_WAVES * 16 * p.n_id_cols + DF_WAVES * 64 * 4 * kc) * 4;
+        const int lds_full = (DF_COEF_FLOATS + DinFusedImg::dma_floats + DF_WAVES * 16 * p.n_id_cols + DF_WAVES * 64 * 4 * kc) * 4;
         bool rows_ok = true;
         for (int g = 0; g < dp->n_acc; ++g) rows_ok = rows_ok && r.Ftab[g] != nullptr;
         if (rows_ok && lds_full <= 160 * 1024) {
@@ -235,22 +235,31 @@ int setup_din_tail(sprk_engine* h, DevPlan* dp) {
                 for (int pass = 0; pass < 2; ++pass) {
                     int best = -1;
                     for (int g = 0; g < dp->n_acc; ++g)
-                        if (r.vocab[g] > 64 && !(n_unf == 1 && unf_g[0] == g) && (best < 0 || r.vocab[g] > r.vocab[best])) best = g;
+                        if (r.vocab[g] > 64 && (long long)(r.vocab[g] + 1) * 128 < (1LL << 32) && !(n_unf == 1 && unf_g[0] == g) && (best < 0 || r.vocab[g] > r.vocab[best])) best = g;
                     if (best >= 0) unf_g[n_unf++] = best;
                 }
             }
-            HIP_TRY(hipMalloc((void**)&h->din_fused_image, (DinFusedImg::total_pad + DinFusedImg::unf_floats) * sizeof(float)));
+            HIP_TRY(hipMalloc((void**)&h->din_fused_image, DinFusedImg::dma_floats * sizeof(float)));
             hipLaunchKernelGGL(k_din_fused_pack, dim3(1), dim3(256), 0, 0, o0.W, o0.ldw, p_off, Dp, n_off, n_num, 1.0f / r.inv_w0p_scale, 4 * kc,
                                o0.bias, o0.alpha, w1frag, o1.bias, o1.alpha, tp.w, tp.len, h->din_fused_image, (const float*)w0efrag, n_unf, unf_g[0], unf_g[1]);
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipDeviceSynchronize());
             DinFusedRun& f = h->din_fused_run;
-            f.ND = r.ND; f.n_cols = r.n_cols; f.n_num = r.n_num;
-            for (int g = 0; g < DT_MAX_COLS; ++g) { f.col[g] = r.col[g]; f.tvocab[g] = r.vocab[g]; f.Ftab[g] = g < r.n_cols ? r.Ftab[g] : r.Ftab[0]; }
+            f.ND = r.ND; f.n_num = r.n_num;
+            // the folded columns (in the tail's order) and, apart from them, the raw-row columns
+            f.n_cols = 0;
+            for (int g = 0; g < r.n_cols; ++g) {
+                if ((n_unf > 0 && unf_g[0] == g) || (n_unf > 1 && unf_g[1] == g)) continue;
+                f.col[f.n_cols] = r.col[g]; f.tvocab[f.n_cols] = r.vocab[g]; f.Ftab[f.n_cols] = r.Ftab[g]; ++f.n_cols;
+            }
+            for (int g = f.n_cols; g < DT_MAX_COLS; ++g) { f.col[g] = r.col[0]; f.tvocab[g] = r.vocab[0]; f.Ftab[g] = r.Ftab[0]; }
             f.head_bias = r.head_bias; f.inv_w1_scale = r.inv_w1_scale; f.inv_w0p_scale = r.inv_w0p_scale;
             f.b0_slot = n_num < 8 ? n_num : -1;
             f.n_unf = n_unf; f.e_unscale = r.e_unscale;
-            for (int u = 0; u < 2; ++u) { f.unf_g[u] = u < n_unf ? unf_g[u] : -1; f.Etab[u] = u < n_unf ? r.Etab[unf_g[u]] : nullptr; }
+            for (int u = 0; u < 2; ++u) {
+                f.ucol[u] = u < n_unf ? r.col[unf_g[u]] : r.col[0]; f.uvocab[u] = u < n_unf ? r.vocab[unf_g[u]] : 0;
+                f.Etab[u] = u < n_unf ? r.Etab[unf_g[u]] : nullptr;
+            }
             f.image = h->din_fused_image;
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_din_fused<1, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_full));
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_din_fused<1, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_full));
@@ -258,7 +267,8 @@ int setup_din_tail(sprk_engine* h, DevPlan* dp) {
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_din_fused<2, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_full));
 #ifdef SPRK_DF_XP
 #define DF_XPT_ATTR(X) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_din_fused<2, false, true, false, X>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_full));
-            DF_XPT_ATTR(128) DF_XPT_ATTR(256) DF_XPT_ATTR(512) DF_XPT_ATTR(896)
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_din_fused<2, true, true, false, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_full));
+            DF_XPT_ATTR(128) DF_XPT_ATTR(256) DF_XPT_ATTR(512) DF_XPT_ATTR(896) DF_XPT_ATTR(1024)
 #undef DF_XPT_ATTR
 #endif
             h->din_fused = true;

@@ -64,8 +64,8 @@ struct DinFusedRun {
     float head_bias, inv_w1_scale, inv_w0p_scale;
     // UNF: columns unf_g[0 .. n_unf) of the tail's column list arrive as RAW rows Etab (k_din_tail.h: [hi 32 halfs | lo 32 halfs] * e_scale,
     // 128 bytes per id, an all-zero row at index vocab) and meet their A fragments (image + total_pad) on the matrix pipe; the other
-    // columns stay folded rows.  n_unf = 0: every column folded.
-    int n_unf, unf_g[2];
+    // columns stay folded rows (col[0 .. n_cols)).  n_unf = 0: every column folded.
+    int n_unf, ucol[2], uvocab[2];       // (col / tvocab / Ftab / n_cols above: the FOLDED columns only, these: the raw-row columns)
     const _Float16* Etab[2];
     float e_unscale;
     int b0_slot;                          // fc0's bias rides in this (free) numeric slot against a constant 1; -1: added by the VALU
@@ -94,6 +94,9 @@ struct DinFusedImg {
     // UNF (emb_dim 17..32): up to two LARGE-vocabulary embedding columns of fc0 (DIN: userId, the candidate's movieId) as raw split
     // rows on the matrix pipe instead of folded rows -- their A fragments [2 columns][N0C][hi 256 | lo 256] behind the image
     static constexpr int unf_floats = 2 * N0C * 512;
+    // LDS-DMA pieces (256 floats) of image + UNF fragments, the same number for each of the eight waves (k_din_fused's waits count them)
+    static constexpr int pieces_per_wave = ((total_pad + unf_floats) / 256 + 7) / 8;
+    static constexpr int dma_floats = pieces_per_wave * 8 * 256;
 };
 constexpr int DF_COEF_FLOATS = 2 * 64 * 36;
 
@@ -131,6 +134,7 @@ __global__ __launch_bounds__(256) void k_din_fused_pack(const float* __restrict_
     }
     for (int i = IM::total + tid; i < IM::total_pad; i += 256) img[i] = 0.f;
     // UNF: the A fragments of columns unf_g[u] out of k_din_tail's fragment buffer w0efrag ([nb][4 columns][hi 256 | lo 256] floats)
+    for (int i = IM::total_pad + IM::unf_floats + tid; i < IM::dma_floats; i += 256) img[i] = 0.f;
     for (int i = tid; i < IM::unf_floats; i += 256) {
         const int w = i & 511, nb = (i >> 9) % IM::N0C, u = i / (512 * IM::N0C);
         img[IM::total_pad + i] = (w0efrag && u < n_unf) ? w0efrag[((size_t)(nb * 4 + (u == 0 ? unf_g0 : unf_g1)) * 2) * 256 + w] : 0.f;
@@ -143,6 +147,12 @@ typedef float df_f2 __attribute__((ext_vector_type(2)));
 // XP: ablation bits for scripts/r04 experiments (only instantiated under -DSPRK_DF_XP): 1 no MFMAs, 2 no product split, 4 no h32,
 // 8 no PReLU dot, 16 no reduce / sigmoid, 32 no pooling, 64 no row loads in the loop; TAIL: 128 no folded-row gathers, 256 no fc1, 512 no
 // fc0 MFMAs (numerics + pooled) -- results are garbage, the time is the point
+template <int N> struct DfInt { static constexpr int value = N; };
+#ifdef SPRK_DF_XP
+// XP & 1024: a timeline -- every wave stamps the constant 100 MHz clock at kernel entry, loop entry, loop exit, after fc0, after fc1, exit
+#define DF_TS_WAVES 4096
+__device__ unsigned long long g_df_ts[DF_TS_WAVES * 8];
+#endif
 template <int KC, bool MB, bool TAIL, bool ATT = false, int XP = 0>
 __global__ __launch_bounds__(DF_WAVES * 64, 2) void k_din_fused(const DinFusedRun A, const int* __restrict__ ids, const float* __restrict__ dense,
                                                               float* __restrict__ out, float* __restrict__ att, int B, int* __restrict__ err,
@@ -161,7 +171,7 @@ __global__ __launch_bounds__(DF_WAVES * 64, 2) void k_din_fused(const DinFusedRu
     float* ca_s = smem;                                   // [64][AS]  w2 (1 + alpha) / 2
     float* cb_s = smem + ROWS * AS;                       // [64][AS]  w2 (1 - alpha) / 2
     float* img_s = smem + DF_COEF_FLOATS;                 // TAIL: the tail's weights
-    constexpr int img_floats = TAIL ? IM::total_pad + IM::unf_floats : 0;
+    constexpr int img_floats = TAIL ? IM::dma_floats : 0;
     int* ids_s = reinterpret_cast<int*>(smem + DF_COEF_FLOATS + img_floats) + wave * 16 * A.idp;
     // TAIL: the quarter sums stay in registers (the LDS they would park in holds the UNF fragments) and only the cross-wave combine
     // of ts > 1 goes through ONE slot per wave; attention only: two parking slots per wave in LDS, S0, S1
@@ -169,25 +179,47 @@ __global__ __launch_bounds__(DF_WAVES * 64, 2) void k_din_fused(const DinFusedRu
     constexpr int PSL = PREG ? 1 : 2;
     float* park_s = smem + DF_COEF_FLOATS + img_floats + DF_WAVES * 16 * A.idp + wave * PSL * 64 * EL;
 
-    // ---- coefficient tables and (TAIL) the tail image by LDS-DMA: 1-KB pieces, wave w takes w, w + 8, ... ----
-#pragma unroll 1
-    for (int c = wave; c < DF_COEF_FLOATS / 256; c += DF_WAVES)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(A.coef + c * 256 + lane * 4),
-                                         (__attribute__((address_space(3))) void*)(smem + c * 256), 16, 0, 0);
-    if constexpr (TAIL) {
-#pragma unroll 1
-        for (int c = wave; c < (IM::total_pad + (A.n_unf ? IM::unf_floats : 0)) / 256; c += DF_WAVES)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(A.image + c * 256 + lane * 4),
-                                             (__attribute__((address_space(3))) void*)(img_s + c * 256), 16, 0, 0);
-    }
-
+    unsigned long long ts_entry = 0;
+    if constexpr ((XP & 1024) != 0) ts_entry = __builtin_amdgcn_s_memrealtime();
     // ---- this wave's (task, time slice) ----
     const int ntpb = (B + 15) >> 4;
     int nb_batches = 1;
     if constexpr (MB) nb_batches = Mm.n;
     const int ntasks = nb_batches * ntpb;
     const int gw = blockIdx.x * DF_WAVES + wave;
-    const int task = gw >> A.ts_log2, slice = gw & (A.ts - 1);
+    // MB: a PERSISTENT launch -- the tables and the tail's image are staged once, then every wave walks tasks gw, gw + (waves of the
+    // grid), ... on its own: no workgroup-wide barrier per task, so the waves of a CU drift apart and one wave's round trips and
+    // epilogue (matrix pipe, LDS) run under the other waves' slot loops (the fabric).  One wave per task (ts = 1).
+    if constexpr (MB) {
+#pragma unroll 1
+        for (int c = wave; c < DF_COEF_FLOATS / 256; c += DF_WAVES)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(A.coef + c * 256 + lane * 4),
+                                             (__attribute__((address_space(3))) void*)(smem + c * 256), 16, 0, 0);
+        if constexpr (TAIL) {
+#pragma unroll 1
+            for (int c = wave; c < IM::dma_floats / 256; c += DF_WAVES)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(A.image + c * 256 + lane * 4),
+                                                 (__attribute__((address_space(3))) void*)(img_s + c * 256), 16, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+    // (persistent: the attention's A fragments are the same for every task -- requested once, 8 KB per wave instead of per task)
+    f32x4 aWr[2][4];
+    if constexpr (MB) {
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) aWr[nb][k] = ld4(A.frag + ((nb * 4 + k) * 64 + lane) * 4);
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) asm volatile("" : "+v"(aWr[nb][k]));      // (landed before the first hidden load is requested)
+    }
+    const int task_stride = MB ? (int)gridDim.x * DF_WAVES : 0;
+#pragma unroll 1
+    for (int task = MB ? gw : (gw >> A.ts_log2); MB ? task < ntasks : true; task += task_stride) {
+    const int slice = MB ? 0 : (gw & (A.ts - 1));
     const bool work = task < ntasks;                      // wave-uniform
     int bi = 0, tl = task;
     if constexpr (MB) { bi = __builtin_amdgcn_readfirstlane(task / ntpb); tl = task - bi * ntpb; }
@@ -195,30 +227,27 @@ __global__ __launch_bounds__(DF_WAVES * 64, 2) void k_din_fused(const DinFusedRu
     const float* dense_b = dense;
     float* out_b = out;
     if constexpr (MB) { ids_b = Mm.ids[work ? bi : 0]; dense_b = Mm.dense[work ? bi : 0]; out_b = Mm.out[work ? bi : 0]; }
-    const int nq = 4 >> A.ts_log2;                        // quarters of this wave; a quarter is A.ql slots (a multiple of FOUR: see the slot loop)
+    const int nq = MB ? 4 : (4 >> A.ts_log2);             // quarters of this wave; a quarter is A.ql slots (a multiple of FOUR: see the slot loop)
     const int Tq = nq * A.ql;
     const int t0 = slice * Tq;
     const int nsteps = work ? max(0, min(T, t0 + Tq) - t0) : 0;
     const int m = tl * 16 + r;
     const int mc = min(m, B - 1);
     const bool tail_wave = TAIL && work && slice == 0;    // wave-uniform
-
-    // the task's ids block (16 consecutive rows of F ints: contiguous) -> LDS with coalesced 16-byte loads, all in flight together
-    if (work) {
-        const int nint = 16 * A.F;
-        if (tl * 16 + 16 <= B && !((uintptr_t)ids_b & 15) && A.idp == A.F) {
-            const f32x4* src = reinterpret_cast<const f32x4*>(ids_b + (size_t)tl * nint);
-            f32x4* dst = reinterpret_cast<f32x4*>(ids_s);
-            for (int c = lane; c < nint / 4; c += 64) dst[c] = src[c];
-        } else {
-            for (int i = lane; i < nint; i += 64) {
-                const int s = i / A.F, col = i - s * A.F;
-                ids_s[s * A.idp + col] = ids_b[(size_t)min(tl * 16 + s, B - 1) * A.F + col];
-            }
+    auto stamp = [&](int k) {
+#ifdef SPRK_DF_XP
+        if constexpr ((XP & 1024) != 0) {
+            const unsigned long long t = __builtin_amdgcn_s_memrealtime();
+            if (lane == 0 && gw < DF_TS_WAVES) { g_df_ts[gw * 8 + k] = t; if (k == 1) g_df_ts[gw * 8] = ts_entry; }
         }
-    }
-    // TAIL: this sample's numerics, K = 8 as two steps (k = q and q + 4); slot n_num carries 1.0 against fc0's bias (b0_slot), slots
-    // beyond duplicate a finite value that only ever meets zero weights.  Requested now, used after the slot loop.
+#endif
+    };
+
+    // ================= prologue: TWO round trips (ids; then every row and table the first trip needs), the tail's image behind them =========
+    // Everything of the second round trip is a HIDDEN load (asm, like the slot loop's): hipcc's own waits sit in front of the first
+    // use, and a use between two requests is a round trip of its own -- round 4's first form had FOUR at the head of every task
+    // (ids 16 bytes at a time with a wait each, the candidate's rows, the first slots' rows, and the 88 KB image in front of it all).
+    // TAIL: this sample's numerics, K = 8 as two steps (k = q and q + 4); requested first, used in the epilogue
     float xna = 0.f, xnb = 0.f;
     if constexpr (TAIL) {
         if (tail_wave) {
@@ -226,59 +255,77 @@ __global__ __launch_bounds__(DF_WAVES * 64, 2) void k_din_fused(const DinFusedRu
             const int last = A.n_num - 1;
             xna = nrow[min(q, last)];
             xnb = nrow[min(q + 4, last)];
-            xna = q == A.b0_slot ? 1.0f : xna;
-            xnb = q + 4 == A.b0_slot ? 1.0f : xnb;
         }
     }
-    // candidate: its row (for h * c), its vc row (the accumulators' start)
+    // the task's ids block (16 consecutive rows of F ints: contiguous) -> LDS by LDS-DMA, 1-KB pieces all in flight together
+    if (work) {
+        const int nint = 16 * A.F;
+        if (tl * 16 + 16 <= B && !((uintptr_t)ids_b & 15) && A.idp == A.F) {
+            const int* src = ids_b + (size_t)tl * nint;
+#pragma unroll 1
+            for (int c = 0; c * 256 < nint; ++c)
+                if (c * 256 + lane * 4 < nint)             // (16 F ints: a multiple of four)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + c * 256 + lane * 4),
+                                                     (__attribute__((address_space(3))) void*)(ids_s + c * 256), 16, 0, 0);
+        } else {
+            for (int i = lane; i < nint; i += 64) {
+                const int s = i / A.F, col = i - s * A.F;
+                ids_s[s * A.idp + col] = ids_b[(size_t)min(tl * 16 + s, B - 1) * A.F + col];
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the ids are in LDS (one wave: its own LDS operations complete in issue order)
+    stamp(3);
+    // ---- round trip two: the candidate's row (for h * c) and vc row (the accumulators' start), the A fragments (the same eight for
+    // every slot), TAIL: the UNF columns' raw split rows (128 bytes per id: lane (r,q) takes hi / lo halfs 8q .. 8q+7 of sample r's
+    // row, the B operand of fc0's blocks for that column -- sixteen registers through the slot loop, but random rows that miss every
+    // cache and an epilogue with nothing to hide their round trip behind), the first FOUR slots' rows ----
     unsigned maxid = 0;                                   // the largest id seen (as unsigned: a negative id is huge): ONE range check at the end
     df_h2 cch[NP], ccl[NP];                               // c' = c sH kappa of this lane's k = EL q + e, split into halfs, as pairs
-    f32x4 acc_init[2];
-    {
-        const unsigned cid = work ? (unsigned)ids_s[r * A.idp + A.cand_col] : 0u;   // (one wave: LDS operations complete in issue order)
-        maxid = cid;
-        const unsigned csafe = min(cid, (unsigned)A.vocab - 1u);
-        f32x4 cp[KC];
-#pragma unroll
-        for (int c = 0; c < KC; ++c) cp[c] = ld4(A.tsplit + csafe * (unsigned)KP + EL * q + 4 * c);
-        f16xe chi, clo;
-        unpack_halfs<KC>(cp, chi, clo);
-#pragma unroll
-        for (int j = 0; j < NP; ++j) {
-            // kappa is a power of two: both scalings are exact (up to f16's subnormal spacing, 2^-24 absolute against products of 2^14)
-            cch[j] = df_h2{(_Float16)((float)chi[2 * j] * A.kappa), (_Float16)((float)chi[2 * j + 1] * A.kappa)};
-            ccl[j] = df_h2{(_Float16)((float)clo[2 * j] * A.kappa), (_Float16)((float)clo[2 * j + 1] * A.kappa)};
-        }
-#pragma unroll
-        for (int nb = 0; nb < 2; ++nb) acc_init[nb] = ld4(A.vc + csafe * (unsigned)HP + nb * 16 + 4 * q) * A.acc_scale;
-    }
-    // A fragments -> registers (the same eight for every slot)
-    f16xe aW[2][4];
-#pragma unroll
-    for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const f32x4 f = ld4(A.frag + ((nb * 4 + k) * 64 + lane) * 4);
-            if constexpr (KC == 2) aW[nb][k] = __builtin_bit_cast(f16xe, f);
-            else { const din_f16x8 both = __builtin_bit_cast(din_f16x8, f); aW[nb][k] = f16xe{both[0], both[1], both[2], both[3]}; }
-        }
-    // TAIL: fc0's embedding columns NOW, in the round trip the candidate's rows are on anyway -- folded rows F_g[id] straight into
-    // the accumulators' layout (lane (r,q): outputs 16 nb + 4q .. + 3 of sample r), two columns = 16 loads in flight at a time, summed
-    // in column order.  z0 waits in registers until the pooled history exists: the epilogue touches no global memory.
-    f32x4 z0[TAIL ? N0C : 1];
+    f32x4 acc_init[2], cp[KC];
+    constexpr bool UNFK = TAIL && KC == 2;
+    f32x4 er[UNFK ? 4 : 1];
     bool tbad = false;
-    int tid_g[DT_MAX_COLS];                               // the folded columns' ids: read now, gathered after the slot loop
+    int tid_g[DT_MAX_COLS];                               // the tail's embedding columns' ids
 #pragma unroll
     for (int g = 0; g < DT_MAX_COLS; ++g) tid_g[g] = -1;
+    auto hload = [&](f32x4& dst, unsigned voff, const void* base) { asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(dst) : "v"(voff), "s"(base)); };
+    {
+        const unsigned cid = work ? (unsigned)ids_s[r * A.idp + A.cand_col] : 0u;
+        maxid = cid;
+        const unsigned csafe = min(cid, (unsigned)A.vocab - 1u);
+#pragma unroll
+        for (int c = 0; c < KC; ++c) hload(cp[c], (csafe * (unsigned)KP + EL * q + 4 * c) * 4u, A.tsplit);   // (< 4 GiB: checked at finalize)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) hload(acc_init[nb], (csafe * (unsigned)HP + nb * 16 + 4 * q) * 4u, A.vc);
+        if constexpr (!MB) {
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) hload(aWr[nb][k], (unsigned)(((nb * 4 + k) * 64 + lane) * 16), A.frag);
+        }
+    }
     if constexpr (TAIL) {
         if (tail_wave) {
 #pragma unroll
             for (int g = 0; g < DT_MAX_COLS; ++g) if (g < A.n_cols) tid_g[g] = ids_s[r * A.idp + A.col[g]];
         }
+        if constexpr (UNFK) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                // (unconditional: a wave or a column without raw rows reads the first bytes of the history table, and nobody looks)
+                const bool have = tail_wave && u < A.n_unf;   // (wave-uniform)
+                const int id = have ? ids_s[r * A.idp + A.ucol[u]] : -1;
+                const int voc = A.uvocab[u];
+                const bool ok = (unsigned)id < (unsigned)voc;
+                tbad |= have && !ok && id != -1;
+                const void* eb = have ? (const void*)A.Etab[u] : (const void*)A.tsplit;
+                const unsigned voff = have ? (unsigned)(ok ? id : voc) * 128u + 16u * q : 16u * q;   // (index vocab: the all-zero row; < 4 GiB: setup)
+                hload(er[2 * u], voff, eb);
+                hload(er[2 * u + 1], voff + 64u, eb);
+            }
+        }
     }
-    // the first FOUR slots' rows are requested here, in the round trip the candidate's rows and the tables are on anyway (the ids are
-    // all they need) -- not after the barrier, where they were a round trip of their own in front of the first MFMA.  They are
-    // hidden loads like the loop's (below); the vmcnt(0) in front of the barrier lands them together with everything else.
     f32x4 rowA[KC], rowB[KC], rowC[KC], rowD[KC];
     const char* tbase = reinterpret_cast<const char*>(A.tsplit);
     const unsigned qoff = (unsigned)(EL * 4) * (unsigned)q, vmax = (unsigned)A.vocab - 1u;
@@ -294,8 +341,66 @@ __global__ __launch_bounds__(DF_WAVES * 64, 2) void k_din_fused(const DinFusedRu
             asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(rw[0]) : "v"(voff), "s"(tbase));
     };
     load(0, rowA); load(1, rowB); load(2, rowC); load(3, rowD);   // (unconditional: no path on which these registers are anything else)
-    __builtin_amdgcn_s_waitcnt(0x0F70);                   // vmcnt(0): this wave's DMA pieces (and everything above) have landed
-    __syncthreads();                                      // tables staged by every wave
+    // ---- LDS-DMA, 1-KB pieces, a COMPILE-TIME number per wave (the waits count them): the attention's coefficient tables (wave w
+    // takes w, w + 8, w + 16; a piece past the end repeats the last), then TAIL: the tail's image (weights as fragments, 88 KB).
+    // Nothing reads the image before the epilogue; requested first (round 4's first form) it sat in front of the ids and the first
+    // rows in every queue: 6.4 us from kernel entry to the first slot against 3.4 us without a tail (profiles/r04, the stamped timeline)
+    constexpr int NCW = (DF_COEF_FLOATS / 256 + DF_WAVES - 1) / DF_WAVES;
+    constexpr int NPW = (TAIL && !MB) ? IM::pieces_per_wave : 0;
+    if constexpr (!MB) {
+#pragma unroll
+        for (int i = 0; i < NCW; ++i) {
+            const int c = min(wave + DF_WAVES * i, DF_COEF_FLOATS / 256 - 1);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(A.coef + c * 256 + lane * 4),
+                                             (__attribute__((address_space(3))) void*)(smem + c * 256), 16, 0, 0);
+        }
+    }
+    if constexpr (TAIL && !MB) {
+#pragma unroll
+        for (int i = 0; i < NPW; ++i) {
+            const int c = wave + DF_WAVES * i;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(A.image + c * 256 + lane * 4),
+                                             (__attribute__((address_space(3))) void*)(img_s + c * 256), 16, 0, 0);
+        }
+    }
+    // everything but the image pieces has landed: this wave's coefficient pieces, the second round trip, the first four row sets
+    // (volatile statements keep their order: the empty ones tie the remaining registers to the wait in front of them)
+    if constexpr (MB)
+        asm volatile("s_waitcnt vmcnt(%3)" : "+v"(cp[0]), "+v"(acc_init[0]), "+v"(acc_init[1]) : "n"(NPW));
+    else
+        asm volatile("s_waitcnt vmcnt(%11)" : "+v"(cp[0]), "+v"(acc_init[0]), "+v"(acc_init[1]), "+v"(aWr[0][0]), "+v"(aWr[0][1]), "+v"(aWr[0][2]),
+                     "+v"(aWr[0][3]), "+v"(aWr[1][0]), "+v"(aWr[1][1]), "+v"(aWr[1][2]), "+v"(aWr[1][3]) : "n"(NPW));
+    if constexpr (KC == 2) asm volatile("" : "+v"(cp[KC - 1]));
+    if constexpr (UNFK) asm volatile("" : "+v"(er[0]), "+v"(er[UNFK ? 1 : 0]), "+v"(er[UNFK ? 2 : 0]), "+v"(er[UNFK ? 3 : 0]));
+    stamp(7);
+    f16xe aW[2][4];
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if constexpr (KC == 2) aW[nb][k] = __builtin_bit_cast(f16xe, aWr[nb][k]);
+            else { const din_f16x8 both = __builtin_bit_cast(din_f16x8, aWr[nb][k]); aW[nb][k] = f16xe{both[0], both[1], both[2], both[3]}; }
+        }
+    din_f16x8 eh[UNFK ? 2 : 1], el[UNFK ? 2 : 1];
+    if constexpr (UNFK) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) { eh[u] = __builtin_bit_cast(din_f16x8, er[2 * u]); el[u] = __builtin_bit_cast(din_f16x8, er[2 * u + 1]); }
+    }
+    {
+        f16xe chi, clo;
+        unpack_halfs<KC>(cp, chi, clo);
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            // kappa is a power of two: both scalings are exact (up to f16's subnormal spacing, 2^-24 absolute against products of 2^14)
+            cch[j] = df_h2{(_Float16)((float)chi[2 * j] * A.kappa), (_Float16)((float)chi[2 * j + 1] * A.kappa)};
+            ccl[j] = df_h2{(_Float16)((float)clo[2 * j] * A.kappa), (_Float16)((float)clo[2 * j + 1] * A.kappa)};
+        }
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) acc_init[nb] = acc_init[nb] * A.acc_scale;
+    }
+    f32x4 z0[TAIL ? N0C : 1];
+    if constexpr (!MB) __builtin_amdgcn_s_barrier();      // coefficient tables staged by every wave
+    stamp(1);
 
     // ---- slot loop ----
     float pacc[EL];
@@ -452,27 +557,17 @@ __global__ __launch_bounds__(DF_WAVES * 64, 2) void k_din_fused(const DinFusedRu
         // at most N younger SETS outstanding => this set has landed (vmcnt retires in order; a set is KC loads).  No "memory" clobber:
         // the statements are volatile (kept in order among themselves) and tied to their registers; nothing else in the loop loads from
         // global memory, and stores only add YOUNGER operations -- so the compiler may move LDS reads and arithmetic across them
-        auto wait3 = [&](f32x4 (&rw)[KC]) {
-            if constexpr (KC == 2) asm volatile("s_waitcnt vmcnt(6)" : "+v"(rw[0]), "+v"(rw[1]));
-            else asm volatile("s_waitcnt vmcnt(3)" : "+v"(rw[0]));
+        // (X: younger operations that are NOT row sets -- the image pieces during the first trip)
+        auto wait3 = [&](f32x4 (&rw)[KC], auto x) {
+            constexpr int X = decltype(x)::value;
+            if constexpr (KC == 2) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(rw[0]), "+v"(rw[1]) : "n"(6 + X));
+            else asm volatile("s_waitcnt vmcnt(%1)" : "+v"(rw[0]) : "n"(3 + X));
         };
-        auto wait2 = [&](f32x4 (&rw)[KC]) {
-            if constexpr (KC == 2) asm volatile("s_waitcnt vmcnt(4)" : "+v"(rw[0]), "+v"(rw[1]));
-            else asm volatile("s_waitcnt vmcnt(2)" : "+v"(rw[0]));
+        auto wait2 = [&](f32x4 (&rw)[KC], auto x) {
+            constexpr int X = decltype(x)::value;
+            if constexpr (KC == 2) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(rw[0]), "+v"(rw[1]) : "n"(4 + X));
+            else asm volatile("s_waitcnt vmcnt(%1)" : "+v"(rw[0]) : "n"(2 + X));
         };
-        // every compiler-visible load of the prologue is "used" here, i.e. has landed before the hidden loads start (k_din_cols.h)
-#pragma unroll
-        for (int nb = 0; nb < 2; ++nb) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) asm volatile("" : "+v"(aW[nb][k]));
-            asm volatile("" : "+v"(acc_init[nb]));
-        }
-#pragma unroll
-        for (int j = 0; j < NP; ++j) { asm volatile("" : "+v"(cch[j])); asm volatile("" : "+v"(ccl[j])); }
-        if constexpr (TAIL) {
-            asm volatile("" : "+v"(xna));
-            asm volatile("" : "+v"(xnb));
-        }
         // One trip = two pairs = four slots, straight-line: the four register sets of the ring keep their roles statically (an if / else
         // on a round's parity made hipcc merge the two arms' tails and COPY row registers with loads still in flight; a loop per quarter
         // inside a loop over the quarters made it copy them at the inner loop's entry -- scripts/r04/check_din_fused_isa.py walks the ISA
@@ -484,16 +579,29 @@ __global__ __launch_bounds__(DF_WAVES * 64, 2) void k_din_fused(const DinFusedRu
         float l0 = 0.f;
         float h0[2][EL];
         int jq = 0, qnext = A.ql;                             // current local quarter, the first slot of the next one (wave-uniform)
-        for (int step = 0; step < nsteps; step += 4) {
-            if (step == qnext) { park(jq); ++jq; qnext += A.ql; }
-            if constexpr (!(XP & 64)) { wait3(rowA); wait2(rowB); }
+        auto trip = [&](int step, auto x) {
+            if constexpr (!(XP & 64)) { wait3(rowA, x); wait2(rowB, x); }
             mfma_part(step, rowA, rowB, l0, u0, h0);
             if constexpr (!(XP & 64)) { load(step + 4, rowA); load(step + 5, rowB); }
             finish(step, l0, u0, h0);
-            if constexpr (!(XP & 64)) { wait3(rowC); wait2(rowD); }
+            if constexpr (!(XP & 64)) { wait3(rowC, x); wait2(rowD, x); }
             mfma_part(step + 2, rowC, rowD, l0, u0, h0);
             if constexpr (!(XP & 64)) { load(step + 6, rowC); load(step + 7, rowD); }
             finish(step + 2, l0, u0, h0);
+        };
+        int step = 0;
+        if constexpr (TAIL && !MB) {
+            // the first trip runs under the image's DMA (its pieces are younger than the four row sets it waits for), by EVERY wave
+            // (one without slots works on zero weights), then the wave's pieces have landed -- at most the four re-requested row
+            // sets stay in flight -- and the workgroup meets once more: from here on the image is readable by all of it
+            trip(0, DfInt<NPW>{});
+            asm volatile("s_waitcnt vmcnt(%0)" :: "n"(4 * KC));
+            __builtin_amdgcn_s_barrier();
+            step = 4;
+        }
+        for (; step < nsteps; step += 4) {
+            if (step == qnext) { park(jq); ++jq; qnext += A.ql; }
+            trip(step, DfInt<0>{});
         }
         for (; jq < nq - 1; ++jq) park(jq);                    // quarters without slots hold exact zeros: retired the same way
         // nothing may still be in flight towards these registers when they are reused
@@ -503,6 +611,7 @@ __global__ __launch_bounds__(DF_WAVES * 64, 2) void k_din_fused(const DinFusedRu
         else
             asm volatile("s_waitcnt vmcnt(0)" : "+v"(rowA[0]), "+v"(rowB[0]), "+v"(rowC[0]), "+v"(rowD[0]));
     }
+    stamp(2);
     float res[EL];
     if (nq == 1) {
 #pragma unroll
@@ -515,7 +624,7 @@ __global__ __launch_bounds__(DF_WAVES * 64, 2) void k_din_fused(const DinFusedRu
         for (int e = 0; e < EL; ++e) res[e] = (PREG ? R1[PREG ? e : 0] : S1[e * 64 + lane]) + ((PREG ? R0[PREG ? e : 0] : S0[e * 64 + lane]) + pacc[e]);
     }
     // ---- several waves per task: their results through LDS, slice 0 sums in the fixed order ----
-    if (A.ts > 1) {
+    if (!MB && A.ts > 1) {                                // (a persistent launch: one wave per task)
         if (slice != 0) {
 #pragma unroll
             for (int e = 0; e < EL; ++e) S0[e * 64 + lane] = res[e];           // (a wave's S0 is free by now)
@@ -535,7 +644,7 @@ __global__ __launch_bounds__(DF_WAVES * 64, 2) void k_din_fused(const DinFusedRu
     }
     const bool bad = (work && maxid >= (unsigned)A.vocab) || tbad;
     if (__ballot(bad) != 0 && lane == 0) atomicOr(err, 1);
-    if (!(work && slice == 0)) return;
+    if (!(work && slice == 0)) { if constexpr (MB) continue; else return; }
 
     if constexpr (!TAIL) {
         if (m < B) {
@@ -550,74 +659,37 @@ __global__ __launch_bounds__(DF_WAVES * 64, 2) void k_din_fused(const DinFusedRu
                     if (EL * q + e < A.Dp) prow[e] = res[e] * A.inv_h_scale;
             }
         }
-        return;
+        if constexpr (MB) continue; else return;
     } else {
         // ================= the tail (DIN.py:161-167) for this wave's sixteen samples: registers and LDS only =================
-        // the numeric chunk: A = W0^T[n][numeric q + 4 s] (one scalar LDS read per block and step), two f32 MFMAs per 16 outputs on
-        // top of the embedding columns' sum; fc0's bias rides in numeric slot b0_slot against a constant 1 (else it is added here)
-        {
-            // fc0's embedding columns: folded rows straight into the accumulators' layout (lane (r,q): outputs 16 nb + 4q .. + 3 of
-            // sample r), two columns = 16 loads in flight at a time
+        // fc0 = numerics (f32 MFMA) + UNF columns + pooled history (split f16 MFMA) + folded rows.  The folded rows' loads go out
+        // FIRST and are added LAST: the matrix work in between needs registers and LDS only.
+        bool tb2 = false;
+        // (two columns = 16 loads in flight; with raw-row columns the folded ones ARE two -- DIN.py's genre columns)
+        f32x4 f[2][N0C];
+        auto fold_load = [&](int g0) {
 #pragma unroll
-            for (int nb = 0; nb < N0C; ++nb) z0[nb] = zero;
-            bool tb2 = false;
-            {
-                // (every column's loads in ONE round trip: the slot loop's registers are free by now)
-                // UNF columns: 128 bytes per id -- lane (r,q) takes hi / lo halfs 8q .. 8q+7 of sample r's row: the B operand
-                din_f16x8 eh[2], el[2];
-                if constexpr (KC == 2) {
+            for (int g = 0; g < 2; ++g) {
+                // folded rows straight into the accumulators' layout (lane (r,q): outputs 16 nb + 4q .. + 3 of sample r)
+                const int id = g0 == 0 ? tid_g[g] : tid_g[2 + g];
+                const int voc = g0 == 0 ? A.tvocab[g] : A.tvocab[2 + g];
+                const float* tab = g0 == 0 ? A.Ftab[g] : A.Ftab[2 + g];
+                const bool ok = g0 + g < A.n_cols && (unsigned)id < (unsigned)voc;
+                tb2 |= g0 + g < A.n_cols && !ok && id != -1;
+                const float* frow = tab + (size_t)(ok ? id : 0) * IM::N0 + 4 * q;
 #pragma unroll
-                    for (int u = 0; u < 2; ++u) {
-                        eh[u] = din_f16x8{0, 0, 0, 0, 0, 0, 0, 0};
-                        el[u] = eh[u];
-                        if (u < A.n_unf) {                        // (wave-uniform)
-                            const int g = A.unf_g[u];
-                            const int id = g == 0 ? tid_g[0] : (g == 1 ? tid_g[1] : (g == 2 ? tid_g[2] : tid_g[3]));
-                            const int voc = g == 0 ? A.tvocab[0] : (g == 1 ? A.tvocab[1] : (g == 2 ? A.tvocab[2] : A.tvocab[3]));
-                            const bool ok = (unsigned)id < (unsigned)voc;
-                            tb2 |= !ok && id != -1;
-                            const char* row = reinterpret_cast<const char*>(A.Etab[u]) + (size_t)(ok ? id : voc) * 128 + 16 * q;
-                            eh[u] = *reinterpret_cast<const din_f16x8*>(row);
-                            el[u] = *reinterpret_cast<const din_f16x8*>(row + 64);
-                        }
-                    }
-                }
-                f32x4 f[DT_MAX_COLS][N0C];
-#pragma unroll
-                for (int g = 0; g < DT_MAX_COLS; ++g) {
-                    const int id = tid_g[g];
-                    const bool unf = KC == 2 && ((A.n_unf > 0 && A.unf_g[0] == g) || (A.n_unf > 1 && A.unf_g[1] == g));   // (wave-uniform)
-                    const bool ok = g < A.n_cols && !unf && (unsigned)id < (unsigned)A.tvocab[g];
-                    tb2 |= g < A.n_cols && !unf && !ok && id != -1;
-                    const float* frow = A.Ftab[g] + (size_t)(ok ? id : 0) * IM::N0 + 4 * q;
-#pragma unroll
-                    for (int nb = 0; nb < N0C; ++nb) f[g][nb] = (ok && !(XP & 128)) ? ld4(frow + nb * 16) : zero;
-                }
-#pragma unroll
-                for (int g = 0; g < DT_MAX_COLS; ++g)
-#pragma unroll
-                    for (int nb = 0; nb < N0C; ++nb) z0[nb] += f[g][nb];
-                if constexpr (KC == 2) {
-                    const float* wf = img_s + IM::total_pad + lane * 4;
-#pragma unroll
-                    for (int u = 0; u < 2; ++u) {
-                        if (u < A.n_unf) {                        // (wave-uniform)
-#pragma unroll
-                            for (int nb = 0; nb < N0C; ++nb) {
-                                const din_f16x8 ah = __builtin_bit_cast(din_f16x8, ld4(wf + (u * N0C + nb) * 512));
-                                const din_f16x8 al = __builtin_bit_cast(din_f16x8, ld4(wf + (u * N0C + nb) * 512 + 256));
-                                f32x4 acc = mfma_f16(al, eh[u], zero);
-                                acc = mfma_f16(ah, el[u], acc);
-                                acc = mfma_f16(ah, eh[u], acc);
-                                z0[nb] += acc * A.e_unscale;
-                            }
-                        }
-                    }
-                }
+                for (int nb = 0; nb < N0C; ++nb) f[g][nb] = (ok && !(XP & 128)) ? ld4(frow + nb * 16) : zero;
             }
-            if (__ballot(tb2) != 0 && lane == 0) atomicOr(err, 1);
-        }
+        };
+        fold_load(0);
+        // the numeric chunk: A = W0^T[n][numeric q + 4 s] (one scalar LDS read per block and step), two f32 MFMAs per 16 outputs;
+        // fc0's bias rides in numeric slot b0_slot against a constant 1 (else it is added here)
+#pragma unroll
+        for (int nb = 0; nb < N0C; ++nb) z0[nb] = zero;
         if constexpr (!(XP & 512)) {
+            // slot n_num carries 1.0 against fc0's bias (b0_slot); slots beyond duplicate a finite value that only ever meets zero weights
+            xna = q == A.b0_slot ? 1.0f : xna;
+            xnb = q + 4 == A.b0_slot ? 1.0f : xnb;
             const float* wn = img_s + IM::off_wn + lane;
 #pragma unroll
             for (int nb = 0; nb < N0C; ++nb) z0[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wn[(nb * 2 + 0) * 64], xna, z0[nb], 0, 0, 0);
@@ -626,6 +698,23 @@ __global__ __launch_bounds__(DF_WAVES * 64, 2) void k_din_fused(const DinFusedRu
             if (A.b0_slot < 0) {
 #pragma unroll
                 for (int nb = 0; nb < N0C; ++nb) z0[nb] += ld4(img_s + IM::off_b0 + nb * 16 + 4 * q);
+            }
+        }
+        if constexpr (KC == 2) {
+            const float* wf = img_s + IM::total_pad + lane * 4;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                if (u < A.n_unf) {                                // (wave-uniform)
+#pragma unroll
+                    for (int nb = 0; nb < N0C; ++nb) {
+                        const din_f16x8 ah = __builtin_bit_cast(din_f16x8, ld4(wf + (u * N0C + nb) * 512));
+                        const din_f16x8 al = __builtin_bit_cast(din_f16x8, ld4(wf + (u * N0C + nb) * 512 + 256));
+                        f32x4 acc = mfma_f16(al, eh[u], zero);
+                        acc = mfma_f16(ah, el[u], acc);
+                        acc = mfma_f16(ah, eh[u], acc);
+                        z0[nb] += acc * A.e_unscale;
+                    }
+                }
             }
         }
         // the pooled history on the f16 pipe, from the registers it was accumulated in (k = EL q + e): per-sample dynamic scale
@@ -653,6 +742,20 @@ __global__ __launch_bounds__(DF_WAVES * 64, 2) void k_din_fused(const DinFusedRu
                 z0[nb] += acc * inv;
             }
         }
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int nb = 0; nb < N0C; ++nb) z0[nb] += f[g][nb];
+        if (A.n_cols > 2) {                                     // (wave-uniform) every column folded: the second pair, a round trip of its own
+            fold_load(2);
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+#pragma unroll
+                for (int nb = 0; nb < N0C; ++nb) z0[nb] += f[g][nb];
+        }
+        if (__ballot(tb2) != 0 && lane == 0) atomicOr(err, 1);
+        if constexpr ((XP & 1024) != 0) { if (z0[0][0] + z0[7][3] == 123.456f) stamp(7); }   // (the stamp below waits for fc0's results)
+        stamp(4);
         // PReLU(alpha0) (DIN.py:164)
 #pragma unroll
         for (int nb = 0; nb < N0C; ++nb) {
@@ -694,6 +797,8 @@ __global__ __launch_bounds__(DF_WAVES * 64, 2) void k_din_fused(const DinFusedRu
 #pragma unroll
             for (int n1 = 0; n1 < N1C; ++n1) z1[n1] = acc[n1] * inv + ld4(img_s + IM::off_b1 + n1 * 16 + 4 * q);
         }
+        if constexpr ((XP & 1024) != 0) { if (z1[0][0] + z1[3][3] == 123.456f) stamp(7); }
+        stamp(5);
         // PReLU(alpha1) (DIN.py:166) -> Dense(1) -> sigmoid (DIN.py:167)
         float z = 0.f;
 #pragma unroll
@@ -709,5 +814,8 @@ __global__ __launch_bounds__(DF_WAVES * 64, 2) void k_din_fused(const DinFusedRu
         }
         z = rows4_sum(z);
         if (q == 0 && m < B) out_b[m] = sigmoidf_acc(z + A.head_bias);
+        stamp(6);
     }
+    if constexpr (!MB) break;
+    }   // (tasks of this wave)
 }
