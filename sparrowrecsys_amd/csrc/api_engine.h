@@ -205,7 +205,7 @@ int sprk_finalize(sprk_handle h) {
         if (!h->tune.din_legacy && s.T <= 64 && vc_bytes < ((size_t)4 << 30) &&
             (size_t)s.vocab * s.row_stride * sizeof(float) < ((size_t)4 << 30)) {   // 32-bit element offsets
             bool want_half = h->tune.din_half;
-            const int max_wpb = h->tune.din_wpb;
+            const int max_wpb = 12;                                // (4 = round 1's workgroup, 16 = four waves per SIMD: measured slower)
             for (size_t v = 0; v < sizeof(kDinVariants) / sizeof(kDinVariants[0]); ++v) {
                 const DinVariant& dv = kDinVariants[v];
                 if (dv.half != want_half) continue;
@@ -277,7 +277,7 @@ int sprk_finalize(sprk_handle h) {
                 if (wgs < 1) wgs = 1;
                 h->din_attn_grid_cap = h->num_cus * wgs;
                 h->din_wpb = dv.wpb;
-                h->din_attn_many = h->tune.din_attn_many;
+                h->din_attn_many = true;
                 h->din_attn_lds = dv.lds_bytes;
                 h->din_variant = (int)v;
                 // k_din_attn_cols: the weights as the static MFMA operand, sixteen samples per tile (k_din_cols.h).  Needs the
@@ -369,10 +369,8 @@ int sprk_finalize(sprk_handle h) {
             if (vv.fn_trace) HIP_TRY(hipFuncSetAttribute(vv.fn_trace, hipFuncAttributeMaxDynamicSharedMemorySize, (int)vv.lds_bytes));
             const int by_regs = (vv.reg ? 2 : 4) * 4 / V2_WAVES;     // workgroups/CU the launch bounds allow
             if (per_cu > by_regs) per_cu = by_regs;
-            if (h->tune.v2_wgs_per_cu > 0 && h->tune.v2_wgs_per_cu < per_cu) per_cu = h->tune.v2_wgs_per_cu;   // tuning knob (1..by_regs)
             if (per_cu < 1) per_cu = 1;
             h->v2_grid_cap = h->num_cus * per_cu;
-            if (h->tune.v2_grid_cap > 0 && h->tune.v2_grid_cap < h->v2_grid_cap) h->v2_grid_cap = h->tune.v2_grid_cap;
             // first-order weight blocks back to back, so one gather instruction can serve several fields
             HIP_TRY(hipMalloc((void**)&h->v2_fo_all, h->v2_fo_floats * sizeof(float)));
             for (int g = 0; g < vv.g_emb; ++g)
@@ -433,7 +431,6 @@ int sprk_finalize(sprk_handle h) {
             h->many_streams = h->tune.many_streams;              // 0 = strict stream order (default), 2..4 = fan out
         }
     }
-    if (h->tune.v2_xflags_set) { h->v2_xflags = h->tune.v2_xflags; h->v2_xflags_set = true; }
     h->finalized = true;
     return SPRK_OK;
 }

@@ -153,11 +153,16 @@ int sprk_forward(sprk_handle h, const int32_t* ids, const float* dense, float* o
         const size_t need = sprk_workspace_bytes(h, B);
         if (!workspace || workspace_bytes < need) return fail(SPRK_EINVAL, "workspace too small: %zu < %zu bytes", workspace_bytes, need);
         // DIN in one launch: attention + pooling + tail (k_din_fused); the workspace contract stays, the buffer is not touched.  One
-        // 8-wave workgroup per CU carries the tail's weights, so the fused form pays while a launch is ONE round of workgroups (up to
-        // 16 rows x 8 waves x CUs = 32 768 rows on an MI355X: BASELINE config 3, and every latency-bound request below it); beyond
-        // that the two-launch path's free-running tail kernel is faster (measured: profiles/r04)
-        if (h->plan.din.enabled == 1 && h->din_fused && (h->tune.din_fused_always || (long long)((B + 15) / 16) <= (long long)h->num_cus * DF_WAVES))
-            return launch_din_fused(h, ids, dense, out, nullptr, B, nullptr, true, st);
+        // 8-wave workgroup per CU carries the tail's weights: up to ONE round of workgroups (16 rows x 8 waves x CUs = 32 768 rows on an
+        // MI355X: BASELINE config 3, and every latency-bound request below it) a wave owns one task; a larger batch goes to the
+        // persistent form (a "several batches" launch of one batch: every wave walks its tasks, tables staged once)
+        if (h->plan.din.enabled == 1 && h->din_fused) {
+            if ((long long)((B + 15) / 16) <= (long long)h->num_cus * DF_WAVES) return launch_din_fused(h, ids, dense, out, nullptr, B, nullptr, true, st);
+            DinFusedMany fm;
+            memset(&fm, 0, sizeof(fm));
+            fm.n = 1; fm.ids[0] = ids; fm.dense[0] = dense; fm.out[0] = out;
+            return launch_din_fused(h, nullptr, nullptr, nullptr, nullptr, B, &fm, true, st);
+        }
         int rc = launch_din(h, ids, (float*)workspace, nullptr, B, st);
         if (rc) return rc;
         aux = (const float*)workspace;
@@ -168,7 +173,6 @@ int sprk_forward(sprk_handle h, const int32_t* ids, const float* dense, float* o
         if (grid > h->v2_grid_cap) grid = h->v2_grid_cap;
         V2Run run = h->v2run;
         run.flags = (((uintptr_t)ids | (uintptr_t)dense) & 15) ? 1 : 0;    // unaligned inputs: element-wise staging
-        run.flags |= h->v2_xflags;                                          // experiment switches (cached at finalize)
         const V2Variant& vv = kV2Variants[h->v2_variant];
         if (h->v2j_variant >= 0 && !run.trace && !(run.flags & ~1)) {
             V2JRun jr = h->v2j_run;
@@ -262,7 +266,7 @@ static int forward_many_impl(sprk_handle h, int32_t n_batches, const int32_t* co
     // several batches per launch (sprk_set_many_batches): the fused DeepFM_v2 kernel takes up to V2J_MB batches' buffers
     // and walks their tasks as one grid; everything else (other models, unaligned buffers, tracing) goes batch by batch
     if (h->finalized && many_batches > 1 && n_batches > 1 && h->v2_variant >= 0 && h->v2j_variant >= 0 && !h->v2run.trace &&
-        !h->v2_xflags_set && B > 0 && ids && dense) {
+        B > 0 && ids && dense) {
         bool ok = true;
         for (int32_t i = 0; i < n_batches && ok; ++i)
             ok = ids[i] && dense[i] && out[i] && !(((uintptr_t)ids[i] | (uintptr_t)dense[i]) & 15);
@@ -393,15 +397,8 @@ static int forward_many_impl(sprk_handle h, int32_t n_batches, const int32_t* co
                     tm.ids[j] = ids[i0 + j]; tm.dense[j] = dense[i0 + j]; tm.aux[j] = pooled; tm.out[j] = out[i0 + j];
                 }
                 // ONE attention launch for the group (k_din_attn<..., MB = true>: no launch boundary and no partial last round of waves
-                // between the batches; SPRK_DIN_ATTN_MB=0: one launch per batch), then one tail launch
-                if (h->din_cols && h->din_fused_attn && h->tune.din_mb_attn_fused && h->din_attn_many && n <= DF_MB) {
-                    DinFusedMany fm;
-                    memset(&fm, 0, sizeof(fm));
-                    fm.n = n;
-                    for (int j = 0; j < n; ++j) { fm.ids[j] = tm.ids[j]; fm.out[j] = const_cast<float*>(tm.aux[j]); }
-                    const int rcc = launch_din_fused(h, nullptr, nullptr, nullptr, nullptr, B, &fm, false, st);
-                    if (rcc) return rcc;
-                } else if (h->din_cols && h->din_attn_many && n <= DC_MB) {
+                // between the batches), then one tail launch
+                if (h->din_cols && h->din_attn_many && n <= DC_MB) {
                     DinColsMany cm;
                     memset(&cm, 0, sizeof(cm));
                     cm.n = n;

@@ -68,7 +68,9 @@ __global__ __launch_bounds__(256) void k_dyn_pack_w(const float* __restrict__ W,
     const int KB = K / 32;
     const int total = (N / 16) * KB * 2 * 512;                           // halfs
     for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
-        const int e = i & 7, qq = (i >> 3) & 3, rr = (i >> 5) & 15, hl = (i >> 9) & 1, blk = i >> 10;
+        // (lane order inside a 1-KB fragment: lane l = 16 q + r at 16 l bytes -- a ds_read_b128 over 64 consecutive 16-byte pieces is
+        // conflict-free; rounds 2-4 kept sample-major order (r * 4 + q), whose 64-byte stride inside a 16-lane group is a 2-way bank conflict)
+        const int e = i & 7, rr = (i >> 3) & 15, qq = (i >> 7) & 3, hl = (i >> 9) & 1, blk = i >> 10;
         const int nb = blk / KB, b = blk - nb * KB;
         const int n = nb * 16 + rr;
         const int kl = e < 4 ? 4 * qq + e : 16 + 4 * qq + (e - 4);

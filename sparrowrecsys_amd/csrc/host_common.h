@@ -73,11 +73,6 @@ struct SprkTuning {
     bool v2_joint = true;             // SPRK_V2_JOINT=0            no LDS-resident small fields (k_deepfm_v2_chain)
     bool v2_half = true;              // SPRK_V2_HALF=0             big fields on f32 MFMA instead of split f16
     bool v2j_one = true;              // SPRK_V2J_ONE=0             one-batch launches on the looped kernel, not k_deepfm_v2_joint1
-    int v2_wgs_per_cu = 0;            // SPRK_V2_WGS_PER_CU=n       cap workgroups per CU of k_deepfm_v2_chain (0 = by LDS / registers)
-    int v2_grid_cap = 0;              // SPRK_V2_GRID_CAP=n         cap its grid (0 = none)
-    bool v2_xflags_set = false;       // SPRK_V2_XFLAGS=n           experiment bits handed to the kernel in V2Run::flags
-    int v2_xflags = 0;
-    bool rows_one = true;             // SPRK_ROWS_ONE=0            k_rows_chain: looped kernel for one-batch launches too
     bool tail_unf = true;             // SPRK_TAIL_UNF=0            k_din_tail: folded 512-byte rows for the embedding columns even when emb_dim <= 16
     bool tail_pooled_f16 = true;      // SPRK_TAIL_POOLED_F16=0     k_din_tail: the pooled-history columns of fc0 on f32 MFMA (round 2) instead of split f16
     bool dien_mfma = true;            // SPRK_DIEN_MFMA=0           DIEN sequence stage: one lane per sample (k_dien_seq) instead of 16 samples per MFMA tile
@@ -87,21 +82,15 @@ struct SprkTuning {
     bool half_range_guard = true;     // SPRK_HALF_RANGE_GUARD=0    skip the dynamic-range guard of static f16 scales (tests only)
     bool dyn_f16 = true;              // SPRK_DYN_F16=0             hidden layers on f32 MFMA instead of dynamic split f16
     bool v1_chain = true;             // SPRK_V1_CHAIN=0            pair-dot DeepFM on the interpreter
-    bool v1_static_scale = true;      // SPRK_V1_STATIC_SCALE=0     deep0's embedding block with a per-sample scale
-    bool v1_rowtab = true;            // SPRK_V1_ROWTAB=0           gather the uploaded tables, not the derived {E | w1} rows
     bool v1_one = true;               // SPRK_V1_ONE=0              one-batch launches on the looped kernel, not k_deepfm_pairs1
     bool mlp_chain = true;            // SPRK_MLP_CHAIN=0           EmbeddingMLP / Wide&Deep on the interpreter
     bool din_tail = true;             // SPRK_DIN_TAIL=0            DIN tail on the interpreter
     bool din_legacy = false;          // SPRK_DIN_LEGACY=1          attention on the generic k_din_pool
     bool din_half = true;             // SPRK_DIN_HALF=0            attention on f32 MFMA
-    int din_wpb = 12;                 // SPRK_DIN_WPB=n             k_din_attn: at most n waves per workgroup (4 = round 1, 16 = 4 per SIMD)
-    bool din_attn_many = true;        // SPRK_DIN_ATTN_MB=0         forward_many: one attention launch per batch
     bool din_cols = true;             // SPRK_DIN_COLS=0            attention on k_din_attn (wave per sample), not k_din_attn_cols
     bool din_fused = true;            // SPRK_DIN_FUSED=0           DIN as two launches (k_din_attn_cols -> pooled vectors -> k_din_tail), not k_din_fused
     bool din_fused_mb = true;         // SPRK_DIN_FUSED_MB=0        forward_many groups on the attention + tail pipeline instead of the persistent k_din_fused<MB>
-    bool din_mb_attn_fused = false;   // SPRK_DIN_MB_ATTN_FUSED=1   the several-batches-per-launch pipeline's attention launch on k_din_fused<TAIL = false> instead of k_din_attn_cols
     bool din_fused_unf = true;        // SPRK_DIN_FUSED_UNF=0       k_din_fused's tail with folded rows for every embedding column (no raw split rows on the matrix pipe)
-    bool din_fused_always = false;    // SPRK_DIN_FUSED_ALWAYS=1    k_din_fused also for launches of more than one round of workgroups
     int df_xp = 0;                    // SPRK_DF_XP=bits            k_din_fused ablation variants (only in a -DSPRK_DF_XP build of the library)
     int din_cols_ts = 0;              // SPRK_DIN_COLS_TS=1|2|4     waves per task of k_din_attn_cols (0 = by the launch's task count)
     int many_streams = 0;             // SPRK_MANY_STREAMS=n        forward_many fans batches over n helper streams (2..4)
@@ -113,16 +102,13 @@ struct SprkTuning {
         t.force_interpreter = on("SPRK_FORCE_INTERPRETER");
         t.v2_fold = !off("SPRK_V2_FOLD"); t.v2_rows = on("SPRK_V2_ROWS"); t.v2_joint = !off("SPRK_V2_JOINT"); t.v2_half = !off("SPRK_V2_HALF");
         t.v2j_one = !off("SPRK_V2J_ONE");
-        { const char* w = getenv("SPRK_V2_WGS_PER_CU"); t.v2_wgs_per_cu = (w && w[0] >= '1' && w[0] <= '9') ? w[0] - '0' : 0; }
-        t.v2_grid_cap = num("SPRK_V2_GRID_CAP", 0);
-        t.v2_xflags_set = getenv("SPRK_V2_XFLAGS") != nullptr; t.v2_xflags = num("SPRK_V2_XFLAGS", 0);
-        t.rows_one = !off("SPRK_ROWS_ONE"); t.rows_unf = !off("SPRK_ROWS_UNF"); t.dien_mfma = !off("SPRK_DIEN_MFMA"); t.tail_pooled_f16 = !off("SPRK_TAIL_POOLED_F16"); t.tail_unf = !off("SPRK_TAIL_UNF"); t.ncf_chain = !off("SPRK_NCF_CHAIN"); t.tile_fold = !off("SPRK_TILE_FOLD");
+        t.rows_unf = !off("SPRK_ROWS_UNF"); t.dien_mfma = !off("SPRK_DIEN_MFMA"); t.tail_pooled_f16 = !off("SPRK_TAIL_POOLED_F16"); t.tail_unf = !off("SPRK_TAIL_UNF"); t.ncf_chain = !off("SPRK_NCF_CHAIN"); t.tile_fold = !off("SPRK_TILE_FOLD");
         t.half_range_guard = !off("SPRK_HALF_RANGE_GUARD"); t.dyn_f16 = !off("SPRK_DYN_F16");
-        t.v1_chain = !off("SPRK_V1_CHAIN"); t.v1_static_scale = !off("SPRK_V1_STATIC_SCALE"); t.v1_rowtab = !off("SPRK_V1_ROWTAB");
+        t.v1_chain = !off("SPRK_V1_CHAIN");
         t.v1_one = !off("SPRK_V1_ONE");
         t.mlp_chain = !off("SPRK_MLP_CHAIN");
         t.din_tail = !off("SPRK_DIN_TAIL"); t.din_legacy = on("SPRK_DIN_LEGACY"); t.din_half = !off("SPRK_DIN_HALF");
-        t.din_wpb = num("SPRK_DIN_WPB", 12); t.din_attn_many = !off("SPRK_DIN_ATTN_MB"); t.din_cols = !off("SPRK_DIN_COLS"); t.din_fused = !off("SPRK_DIN_FUSED"); t.df_xp = num("SPRK_DF_XP", 0); t.din_fused_mb = !off("SPRK_DIN_FUSED_MB"); t.din_fused_always = on("SPRK_DIN_FUSED_ALWAYS"); t.din_fused_unf = !off("SPRK_DIN_FUSED_UNF"); t.din_mb_attn_fused = on("SPRK_DIN_MB_ATTN_FUSED");
+        t.din_cols = !off("SPRK_DIN_COLS"); t.din_fused = !off("SPRK_DIN_FUSED"); t.df_xp = num("SPRK_DF_XP", 0); t.din_fused_mb = !off("SPRK_DIN_FUSED_MB"); t.din_fused_unf = !off("SPRK_DIN_FUSED_UNF");
         { const int n = num("SPRK_DIN_COLS_TS", 0); t.din_cols_ts = (n == 1 || n == 2 || n == 4) ? n : 0; }
         { const int n = num("SPRK_MANY_STREAMS", 0); t.many_streams = n < 2 ? 0 : (n > 4 ? 4 : n); }
         return t;

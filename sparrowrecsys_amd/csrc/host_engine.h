@@ -68,7 +68,7 @@ struct sprk_engine {
     bool din_fused_attn = false;   // TAIL = false instantiations replace k_din_attn_cols (sprk_din_pool, the unfused two-launch path)
     DinFusedRun din_fused_run;
     float* din_fused_image = nullptr;
-    bool din_attn_many = true;     // forward_many: one attention launch per group of batches (SPRK_DIN_ATTN_MB=0: per batch)
+    bool din_attn_many = true;     // forward_many: one attention launch per group of batches 
     // register-chained fast path (k_deepfm_v2_chain); -1 = use the tile interpreter
     int v2_variant = -1;
     V2Args v2;
@@ -86,7 +86,7 @@ struct sprk_engine {
     int many_batches = 1;                 // sprk_forward_many: batches scored per launch (sprk_set_many_batches)
     // "one row per id" chain (k_rows_chain): DeepFM_v2 with projections wider than 16 (the reference's Dense(64)) and NeuralCF
     int rows_variant = -1;
-    bool rows_one = true;                 // one-batch launches use k_rows_chain1 (one task per wave; SPRK_ROWS_ONE=0: looped kernel)
+    bool rows_one = true;                 // one-batch launches use k_rows_chain1 (one task per wave)
     bool rows_from_v2 = false;            // set by match_v2_chain: h->v2 holds the parsed DeepFM_v2 plan, tables still to build
     int rows_g_emb = 0;
     RowsRun rows_run;
@@ -97,8 +97,6 @@ struct sprk_engine {
     size_t rows_lds_bytes = 0;
     int n_acc_folded = 0;                 // embedding columns folded into the first Dense layer (fold_first_dense)
     size_t derived_bytes = 0;             // device memory of tables DERIVED at finalize (folded rows, split halfs, per-id terms)
-    int v2_xflags = 0;                    // SPRK_V2_XFLAGS experiment switches, read ONCE at finalize (never on the launch path)
-    bool v2_xflags_set = false;
     V2JRun v2j_run;
     float* v2j_tab = nullptr;      // small fields' LDS rows (device image)
     size_t v2j_lds_bytes = 0;

@@ -25,12 +25,9 @@ struct DinVariant {
 #define DIN_MANY_12(KC, HC, NP, HALF) reinterpret_cast<const void*>(&k_din_attn<KC, HC, NP, HALF, 12, true>), &din_launch_many<KC, HC, NP, HALF, 12>
 #define DIN_VARIANT1(KC, HC, NP, HALF, WPB) {KC, HC, NP, HALF, WPB, reinterpret_cast<const void*>(&k_din_attn<KC, HC, NP, HALF, WPB, false>), DinLds<KC, HC, WPB>::bytes, &din_launch<KC, HC, NP, HALF, WPB>, nullptr, nullptr}
 #define DIN_VARIANT12(KC, HC, NP) {KC, HC, NP, true, 12, reinterpret_cast<const void*>(&k_din_attn<KC, HC, NP, true, 12, false>), DinLds<KC, HC, 12>::bytes, &din_launch<KC, HC, NP, true, 12>, DIN_MANY_12(KC, HC, NP, true)}
-#define DIN_VARIANT16(KC, HC, NP) {KC, HC, NP, true, 16, reinterpret_cast<const void*>(&k_din_attn<KC, HC, NP, true, 16, false>), DinLds<KC, HC, 16>::bytes, &din_launch<KC, HC, NP, true, 16>, \
-                                   reinterpret_cast<const void*>(&k_din_attn<KC, HC, NP, true, 16, true>), &din_launch_many<KC, HC, NP, true, 16>}
 #define DIN_VARIANT(KC, HC, NP) DIN_VARIANT1(KC, HC, NP, true, 4), DIN_VARIANT1(KC, HC, NP, false, 4)
 const DinVariant kDinVariants[] = {     // first match wins: smallest sufficient pass count first; 12-wave forms before their 4-wave twins
     DIN_VARIANT12(2, 2, 2), DIN_VARIANT(2, 2, 2), DIN_VARIANT12(2, 2, 4), DIN_VARIANT(2, 2, 4),
-    DIN_VARIANT16(2, 2, 7),             // (chosen only with SPRK_DIN_WPB=16: T <= 56, 4 waves per SIMD, no row prefetch)
     DIN_VARIANT12(2, 2, 7),    // BASELINE config 3: emb_dim 32, 50 history slots, attention hidden 32
     DIN_VARIANT(2, 2, 7),
     DIN_VARIANT12(2, 2, 8), DIN_VARIANT(2, 2, 8),

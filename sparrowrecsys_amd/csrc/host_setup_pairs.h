@@ -230,7 +230,7 @@ int setup_deepfm_pairs(sprk_engine* h) {
     r.e_scale = 0.f; r.e_inv = 0.f;
     {
         // static scale for deep0's embedding block: max |E| over the deep fields' tables, unless a table has outlier rows
-        if (r.w0frag && h->tune.v1_static_scale) {
+        if (r.w0frag) {
             DevProbe d_max_probe;
             unsigned*& d_max = d_max_probe.p;
             HIP_TRY(hipMalloc((void**)&d_max, sizeof(unsigned)));
@@ -261,7 +261,7 @@ int setup_deepfm_pairs(sprk_engine* h) {
         }
     }
     r.tab = nullptr;
-    if (PC == 1 && h->tune.v1_rowtab) {
+    if (PC == 1) {
         // own deep tables ride in their field's 128-byte line: rows of <= 12 floats at float 20 (w1 stays at float 16), rows of 16
         // floats at float 16 with the first-order weights of those fields moved to a compact array (V1Run::pack)
         const int pack = !sep ? 0 : (Dp <= 12 ? 80 : (Dp == 16 ? 64 : 0));

@@ -72,7 +72,7 @@ int rows_finish(sprk_engine* h, const RowsVariant& rv, const std::vector<float>&
     HIP_TRY(hipFuncSetAttribute(rv.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->rows_lds_bytes));
     HIP_TRY(hipFuncSetAttribute(rv.fn_many, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->rows_lds_bytes));
     HIP_TRY(hipFuncSetAttribute(rv.fn_one, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->rows_lds_bytes));
-    h->rows_one = h->tune.rows_one;
+    h->rows_one = true;
     HIP_TRY(hipDeviceSynchronize());
     return SPRK_OK;
 }

@@ -336,7 +336,7 @@ __device__ __forceinline__ void v1_body(const V1Run& A, const int* __restrict__ 
                 mx = rows4_max(mx);
                 dyn_scale(mx, A.inv_w0_scale, scale, inv);
             }
-            int wfo = LD::off_w0e + (r * 4 + q) * 4;              // this lane's 16 bytes inside a 1-KB fragment
+            int wfo = LD::off_w0e + lane * 4;                     // this lane's 16 bytes inside a 1-KB fragment (k_dyn_pack_w: lane order)
             asm volatile("" : "+v"(wfo));                         // (keeps the loop-invariant LDS reads inside the task loop)
             f32x4 acc[H0C];
 #pragma unroll
@@ -388,7 +388,7 @@ __device__ __forceinline__ void v1_body(const V1Run& A, const int* __restrict__ 
             f32x4 acc[H1C];
 #pragma unroll
             for (int n1 = 0; n1 < H1C; ++n1) acc[n1] = zero;
-            int wfo = LD::off_w1 + (r * 4 + q) * 4;
+            int wfo = LD::off_w1 + lane * 4;
             asm volatile("" : "+v"(wfo));
 #pragma unroll
             for (int b = 0; b < H0C / 2; ++b) {

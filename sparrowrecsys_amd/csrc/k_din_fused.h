@@ -780,7 +780,7 @@ __global__ __launch_bounds__(DF_WAVES * 64, 2) void k_din_fused(const DinFusedRu
             f32x4 acc[N1C];
 #pragma unroll
             for (int n1 = 0; n1 < N1C; ++n1) acc[n1] = zero;
-            const float* wf = img_s + IM::off_w1 + (r * 4 + q) * 4;          // this lane's 16 bytes inside a 1-KB fragment (k_dyn_pack_w)
+            const float* wf = img_s + IM::off_w1 + lane * 4;                 // this lane's 16 bytes inside a 1-KB fragment (k_dyn_pack_w: lane order)
 #pragma unroll
             for (int b = 0; b < ((XP & 256) ? 0 : N0C / 2); ++b) {
                 din_f16x8 bh, bl;

@@ -264,7 +264,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES >= 16 ? 4 : 2) void k_din_tail(co
             mx = rows4_max(mx);
             float scale, inv;
             dyn_scale(mx, A.inv_w0p_scale, scale, inv);
-            const float* wf = smem + LD::off_w0h + (r * 4 + q) * 4;
+            const float* wf = smem + LD::off_w0h + lane * 4;
 #pragma unroll
             for (int b = 0; b < LD::KB0; ++b) {
                 din_f16x8 bh, bl;
@@ -319,7 +319,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES >= 16 ? 4 : 2) void k_din_tail(co
             f32x4 acc[N1C];
 #pragma unroll
             for (int n1 = 0; n1 < N1C; ++n1) acc[n1] = zero;
-            const float* wf = smem + LD::off_w1 + (r * 4 + q) * 4;       // this lane's 16 bytes inside a 1-KB fragment
+            const float* wf = smem + LD::off_w1 + lane * 4;              // this lane's 16 bytes inside a 1-KB fragment (k_dyn_pack_w: lane order)
 #pragma unroll
             for (int b = 0; b < N0C / 2; ++b) {
                 din_f16x8 bh, bl;

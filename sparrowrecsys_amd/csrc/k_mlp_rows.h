@@ -274,7 +274,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_mlp_rows(const MlpRowsRun A, 
             dyn_scale(mx, A.inv_w1_scale, scale, inv);
 #pragma unroll
             for (int n1 = 0; n1 < N1C; ++n1) z1[n1] = zero;
-            const float* wf = smem + LD::off_w1 + (r * 4 + q) * 4;       // this lane's 16 bytes inside a 1-KB fragment
+            const float* wf = smem + LD::off_w1 + lane * 4;              // this lane's 16 bytes inside a 1-KB fragment (k_dyn_pack_w: lane order)
 #pragma unroll
             for (int b = 0; b < N0C / 2; ++b) {
                 din_f16x8 bh, bl;

@@ -280,6 +280,25 @@ def test_din_fused_scores_do_not_depend_on_the_launch_shape(torch, monkeypatch, 
     assert np.abs(got["ts1"] - ref).max() <= TIGHT
 
 
+def test_din_fused_batch_beyond_one_round_of_workgroups(torch, monkeypatch):
+    """sprk_forward on a DIN batch of more than 16 rows x 8 waves x CUs (32 768 on an MI355X): the PERSISTENT form of k_din_fused (every
+    wave walks several tasks, tables staged once) -- the same bits as the same rows scored in one-round slices, the oracle's values."""
+    T, D, V, U, B = 50, 32, 5000, 700, 32768 + 4099
+    feats = SY.synth_din(B, T, V, U, seed=431)
+    model = M.DIN(seed=97, emb_dim=D, hist_len=T, movie_buckets=V, user_buckets=U)
+    assert model.engine.describe()["kernel"].startswith("k_din_fused")
+    ids, dense = model.pack(feats)
+    ti, td = _cuda(torch, ids), _cuda(torch, dense)
+    full = model.predict_device(ti, td)
+    model.engine.check_ids()
+    for lo, hi in ((0, 32768), (32768, B), (16384 + 7, 16384 + 7 + 20000)):
+        assert torch.equal(model.predict_device(ti[lo:hi].contiguous(), td[lo:hi].contiguous()), full[lo:hi])
+    sl = slice(B - 3000, B)
+    ref = O.din_forward({k: v[sl] for k, v in feats.items()}, model.weights, dtype=np.float64, hist_len=T, movie_buckets=V, user_buckets=U)[:, 0]
+    assert np.abs(full[sl].cpu().numpy() - ref).max() <= TIGHT
+    model.engine.close()
+
+
 def test_din_attention_kernel_bad_ids_raise(torch):
     """History / candidate ids outside the table: flagged (TF raises InvalidArgumentError), no wild read."""
     T, D, V, U, B = 50, 32, 3000, 500, 257
