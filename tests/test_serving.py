@@ -131,6 +131,56 @@ def test_bracketed_string_features_are_unwrapped_not_stringified():
         srv.close()
 
 
+def test_threads_do_not_pile_up_and_raw_http_variants(stub_server):
+    """(1) One batcher thread for the server's life: round 4's first inline-forward commit started a NEW batcher thread in every
+    request's withdraw() -- 300 threads after 300 requests, and eight concurrent clients got HALF the throughput of one.
+    (2) The handler's own header parser: keep-alive, HTTP/1.0, `Connection: close`, odd header spellings, and the requests it hands
+    to the stock parser (`Expect`, a folded header) all answer like the stock handler."""
+    import http.client
+    import socket
+    srv, model = stub_server
+    body = json.dumps({"instances": [{"userId": 8, "movieId": 3}, {"userId": 9, "movieId": 4}]}).encode()
+    want = [[0.13], [0.24]]
+    c = http.client.HTTPConnection("127.0.0.1", srv.port, timeout=30)
+    before = None
+    for i in range(60):                                           # one keep-alive connection
+        c.request("POST", "/v1/models/recmodel:predict", body=body, headers={"Content-Type": "application/json"})
+        r = c.getresponse()
+        got = json.loads(r.read())
+        assert r.status == 200
+        np.testing.assert_allclose(got["predictions"], want, atol=1e-6)
+        if i == 9:
+            before = threading.active_count()
+    assert threading.active_count() <= before
+    c.close()
+
+    def raw(req: bytes):
+        with socket.create_connection(("127.0.0.1", srv.port), timeout=10) as sk:
+            sk.sendall(req)
+            sk.shutdown(socket.SHUT_WR)
+            data = b""
+            while True:
+                b = sk.recv(65536)
+                if not b:
+                    break
+                data += b
+        head, _, payload = data.partition(b"\r\n\r\n")
+        return int(head.split()[1]), payload
+    path = b"/v1/models/recmodel:predict"
+    cl = b"Content-Length: %d\r\n" % len(body)
+    for req in (b"POST " + path + b" HTTP/1.1\r\nHost: x\r\nConnection: close\r\n" + cl + b"\r\n" + body,
+                b"POST " + path + b" HTTP/1.0\r\n" + cl + b"\r\n" + body,
+                b"POST " + path + b" HTTP/1.1\r\nhost:x\r\nCONTENT-LENGTH:   %d  \r\nConnection: close\r\n\r\n" % len(body) + body,
+                b"POST " + path + b" HTTP/1.1\r\nHost: x\r\nX-Folded: a\r\n  b\r\nConnection: close\r\n" + cl + b"\r\n" + body):
+        code, payload = raw(req)
+        assert code == 200, req[:80]
+        np.testing.assert_allclose(json.loads(payload)["predictions"], want, atol=1e-6)
+    code, payload = raw(b"GET /v1/models/recmodel HTTP/1.1\r\nHost: x\r\nConnection: close\r\n\r\n")
+    assert code == 200 and b"AVAILABLE" in payload
+    code, payload = raw(b"POST /nope HTTP/1.1\r\nConnection: close\r\n" + cl + b"\r\n" + body)
+    assert code == 404
+
+
 def test_non_finite_scores_still_parse():
     """'%.9g' of NaN is not JSON; such a response falls back to json.dumps' NaN spelling."""
     srv = PredictServer(_GenreStub(), port=0).start()
