@@ -567,6 +567,15 @@ int sprk_debug_set_trace(sprk_handle h, void* dev_buf, size_t bytes) {
 
 void sprk_destroy(sprk_handle h) {
 #ifdef SPRK_DF_XP
+    if (h) {
+        if (const char* path = getenv("SPRK_V2J1_TS_FILE")) {      // k_deepfm_v2_joint1's timeline: the LAST launch's stamps
+            std::vector<unsigned long long> ts((size_t)V2J1_TS_WAVES * 8);
+            hipDeviceSynchronize();
+            if (hipMemcpyFromSymbol(ts.data(), HIP_SYMBOL(g_v2j1_ts), ts.size() * 8) == hipSuccess) {
+                if (FILE* fp = fopen(path, "wb")) { fwrite(ts.data(), 8, ts.size(), fp); fclose(fp); }
+            }
+        }
+    }
     if (h && h->tune.df_xp == 1024) {                              // the timeline build: the LAST launch's stamps -> $SPRK_DF_TS_FILE
         if (const char* path = getenv("SPRK_DF_TS_FILE")) {
             std::vector<unsigned long long> ts((size_t)DF_TS_WAVES * 8);

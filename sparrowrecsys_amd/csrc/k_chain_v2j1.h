@@ -77,6 +77,15 @@ __global__ __launch_bounds__(256) void k_v2j1_pack_image(const V2Args A, const V
 // of global -> LDS -> registers at scoring time -- half of a wave's LDS reads in the scoring stage.  8.10 instead of 7.65 us,
 // 10.3 instead of 9.2 us with HBM-resident tables: sixteen waves per CU pulling the same 12 KB through the texture path queue
 // in front of the row gathers, and 110 VGPRs leave four waves per SIMD where 71 leave seven.)
+#ifdef SPRK_DF_XP
+// (timeline build, scripts/r04: every wave stamps the 100 MHz clock at entry, with its ids staged, with its gathers requested, behind
+// the barrier, after phase A, with its rows landed, at exit -- SPRK_V2J1_TS_FILE at sprk_destroy)
+#define V2J1_TS_WAVES 8192
+__device__ unsigned long long g_v2j1_ts[V2J1_TS_WAVES * 8];
+#define V2J1_STAMP(k) do { const unsigned long long t_ = __builtin_amdgcn_s_memrealtime(); if (lane == 0 && tk < V2J1_TS_WAVES) g_v2j1_ts[tk * 8 + (k)] = t_; } while (0)
+#else
+#define V2J1_STAMP(k) do { } while (0)
+#endif
 template <int G_BIG, int NJF>
 __global__ __launch_bounds__(V2J1_WAVES * 64, 4) void k_deepfm_v2_joint1(const V2JRun A, const int* __restrict__ ids,
                                                                        const float* __restrict__ dense, float* __restrict__ out, int B,
@@ -97,6 +106,7 @@ __global__ __launch_bounds__(V2J1_WAVES * 64, 4) void k_deepfm_v2_joint1(const V
     const float* small_s = smem + LD::total_pad;                       // small fields' rows, then Wf
     float* stage = smem + LD::total_pad + A.small_floats + wave * 256; // this wave's ids / numerics slot
     const bool fast = work && !(A.flags & 1) && tk * 16 + 16 <= B;     // aligned, full task: one 16-byte load per lane
+    V2J1_STAMP(0);
 
     // ---- the task's ids + numerics first, then the image pieces (they land inside the ids' latency) ----
     f32x4 raw = zero;
@@ -134,6 +144,7 @@ __global__ __launch_bounds__(V2J1_WAVES * 64, 4) void k_deepfm_v2_joint1(const V
         } else {
             stage_task_slow(stage, ids, dense, A.F, A.ND, tk, B, lane);
         }
+        V2J1_STAMP(1);
         const int* sid_row = reinterpret_cast<const int*>(stage) + r * A.F;   // (one wave: LDS operations complete in issue order)
         unsigned sid[G_BIG];
 #pragma unroll
@@ -165,6 +176,7 @@ __global__ __launch_bounds__(V2J1_WAVES * 64, 4) void k_deepfm_v2_joint1(const V
             if (G_BIG > 2) sx = q == 2 ? s2 : sx;
             w1a = *reinterpret_cast<const float*>(tb + (sx + 4u * KP));
         }
+        V2J1_STAMP(2);
         // in-order retirement: at most NG loads outstanding <=> this wave's DMA pieces (older) have landed
         constexpr int NG = G_BIG + 1;
         __builtin_amdgcn_s_waitcnt(0x0F70 | NG);
@@ -173,6 +185,7 @@ __global__ __launch_bounds__(V2J1_WAVES * 64, 4) void k_deepfm_v2_joint1(const V
     }
     __builtin_amdgcn_s_barrier();
     if (!work) return;
+    V2J1_STAMP(3);
 
     // ---- scoring, phase A: everything that does NOT need the rows -- every LDS read of the stage (fragments, small fields'
     //      rows, W1, the small vectors: 26 KB per wave) and the numerics' MFMAs -- is issued HERE, while the rows are still
@@ -232,6 +245,14 @@ __global__ __launch_bounds__(V2J1_WAVES * 64, 4) void k_deepfm_v2_joint1(const V
     f32x4 s = sp + pn;
     // ---- phase B: the rows (the compiler's s_waitcnt vmcnt lands at their first use, below this fence) ----
     __builtin_amdgcn_sched_barrier(0);
+#ifdef SPRK_DF_XP
+    if (s[0] + hA[0][0] == 123.456f) V2J1_STAMP(7);       // (phase A's results exist)
+    V2J1_STAMP(4);
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    V2J1_STAMP(5);
+    __builtin_amdgcn_sched_barrier(0);
+#endif
     {
         f32x4 aFa[H0C], aFb[H0C], aS = zero;
 #pragma unroll
@@ -272,4 +293,5 @@ __global__ __launch_bounds__(V2J1_WAVES * 64, 4) void k_deepfm_v2_joint1(const V
     const int m = tk * 16 + r;
     if (q == 0 && m < B) out[m] = score;
     if (__ballot(bad) != 0 && lane == 0) atomicOr(err, 1);
+    V2J1_STAMP(6);
 }
