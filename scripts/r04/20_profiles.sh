@@ -61,7 +61,8 @@ for d in sorted(glob.glob('gpurun_out/r04_prof/pmc_*/')):
             agg[row['Kernel_Name']][row['Counter_Name']].append(float(row['Counter_Value']))
         for k, cs in agg.items():
             if '(anonymous namespace)::' not in k: continue
-            short = k.split('(anonymous namespace)::')[1].split('(')[0].split('<')[0]
+            short = k.split('(anonymous namespace)::')[1].split('(')[0]
+            short = short if short.startswith('k_din_fused<') else short.split('<')[0]     # (its TAIL / attention-only forms are two kernels)
             if any(s in short for s in ('prep', 'fold', 'absmax', 'split', 'pack', 'build', 'count_small', 'swizzle', 'coef')): continue
             summary.setdefault(tag, {})[short] = {c: round(sum(v) / len(v), 1) for c, v in cs.items()}
             summary[tag][short]['launches'] = len(next(iter(cs.values())))

@@ -34,5 +34,5 @@ python -c "
 import json
 l=json.loads(open('$O/bench_driver_command.json').read())
 print('driver: value %.4g one-batch %.4g frac %.4f hbm %.4f' % (l['value'], l['value_one_batch_per_launch'], l['roofline']['frac'], l['roofline_hbm_resident']['frac']))
-for k,w in l['workloads'].items(): print(k, '%.4g' % w['value'], '%.4f' % w['roofline']['frac'])
+for k,w in l['workloads'].items(): print(k, ('%.4g' % w['value'], '%.4f' % w['roofline']['frac']) if 'value' in w else {a: w[a] for a in list(w)[:6]})
 print('cpu', l['cpu_baseline']['value'], l['cpu_baseline'].get('tensorflow'))"

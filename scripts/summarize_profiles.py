@@ -98,13 +98,16 @@ def main():
         if other:
             row["other_kernels_per_step"] = [{"kernel": k, "launches": c, "avg_us": round(a, 3)} for k, c, a in other]
         kshort = short.split("<")[0]
-        f, wr = pmc.get("pmc_%s_fetch" % w, {}), pmc.get("pmc_%s_write" % w, {})
+        f, wr = pmc.get("pmc_%s_fetch" % w.replace("c3_attn", "c3"), {}), pmc.get("pmc_%s_write" % w.replace("c3_attn", "c3"), {})
+        # (k_din_fused's one-launch and attention-only forms are two kernels of the same config-3 passes: keyed with their template arguments)
+        if short in f:
+            kshort = short
         if kshort in f and kshort in wr:
             t = 2 * f[kshort]["FETCH_SIZE"] * 1024 + wr[kshort]["WRITE_SIZE"] * 1024
             row["pmc_traffic_mb"] = t / 1e6
             row["traffic_over_algorithmic"] = t / alg
         for sq in ("sq1", "sq2"):
-            c = pmc.get("pmc_%s_%s" % (w, sq), {}).get(kshort)
+            c = pmc.get("pmc_%s_%s" % (w.replace("c3_attn", "c3"), sq), {}).get(kshort)
             if c:
                 row.setdefault("sq", {}).update({k: v for k, v in c.items() if k != "launches"})
         if "sq" in row:
