@@ -11,6 +11,7 @@ over the back edge.  Exit status 1 on any finding."""
 import re, subprocess, sys, os
 root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..")
 if "--compile" in sys.argv:
+    os.makedirs(os.path.join(root, "build"), exist_ok=True)
     subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-I", "include", "-I", "sparrowrecsys_amd/csrc", "--cuda-device-only", "-S",
                     "sparrowrecsys_amd/csrc/sparrow_hip.hip", "-o", "build/sparrow.s"], cwd=root, check=True, stderr=subprocess.DEVNULL)
 txt = open(os.path.join(root, "build", "sparrow.s")).read()

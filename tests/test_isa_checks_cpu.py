@@ -1,0 +1,27 @@
+"""k_din_fused hides its row loads from hipcc's waitcnt pass and owns them with hand-counted `s_waitcnt vmcnt(N)` statements
+(sparrowrecsys_amd/csrc/k_din_fused.h).  Whether that is CORRECT is a property of the generated ISA, not of the source: hipcc has
+twice copied registers with a load still in flight.  scripts/r04/check_din_fused_isa.py compiles the device
+code (no GPU needed) and walks the control-flow graph of every instantiation; this test runs it."""
+import os
+import shutil
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"), reason="needs hipcc")
+def test_din_fused_hidden_loads_are_never_touched_in_flight():
+    env = dict(os.environ, PATH=os.environ.get("PATH", "") + ":/opt/rocm/bin")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "r04", "check_din_fused_isa.py"), "--compile"],
+                       capture_output=True, text=True, env=env, timeout=900)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("k_din_fused<")]
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert len(lines) >= 10, r.stdout[-2000:]                    # KC x MB x TAIL + the two attention-weights instantiations
+    for l in lines:
+        assert "early touches 0" in l and "inside the loop 0" in l, l
+    # the one-batch tail forms count the image's DMA pieces behind the hidden loads; the persistent forms stage the image up front
+    assert any("k_din_fused<2, false, true" in l and "14 DMA pieces" in l for l in lines)
+    assert any("k_din_fused<2, true, true" in l and " 0 DMA pieces" in l for l in lines)
