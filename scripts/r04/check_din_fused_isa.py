@@ -34,7 +34,7 @@ for sym in names:
         if "#ASMSTART" in l: in_asm = True
         elif "#ASMEND" in l: in_asm = False
         elif in_asm: asm_lines.add(i)
-    loads = [i for i in sorted(asm_lines) if "global_load_dwordx4" in body[i]]
+    loads = [i for i in sorted(asm_lines) if "global_load_dwordx4" in body[i]]     # (the walk starts at the first 16-byte hidden load: the numerics' two dword loads in front of the ids are the oldest entries of every queue and are not tracked)
     drain = [i for i in asm_lines if "s_waitcnt vmcnt(0)" in body[i]]
     if not loads or not drain:
         print("%s: no hidden loads found" % inst); bad += 1; continue
@@ -55,9 +55,9 @@ for sym in names:
             steps += 1
             t = body[i].strip()
             if i in asm_lines:
-                dm = re.search(r"global_load_dwordx4 v\[(\d+):(\d+)\]", t)
+                dm = re.search(r"global_load_dword(?:x\d)? v\[(\d+):(\d+)\]", t) or re.search(r"global_load_dword v(\d+)()", t)
                 wm = re.search(r"s_waitcnt vmcnt\((\d+)\)", t)
-                if dm: pending.append(set(range(int(dm.group(1)), int(dm.group(2)) + 1)))
+                if dm: pending.append(set(range(int(dm.group(1)), int(dm.group(2) or dm.group(1)) + 1)))
                 elif wm:
                     wait_lines.add(i)
                     n = int(wm.group(1))
@@ -85,8 +85,16 @@ for sym in names:
     # the slot loop(s): loops (hipcc marks their header labels) behind the first hidden load that hold a manual wait with a count
     for lab, pos in labels.items():
         if pos < lo or "Loop Header" not in body[pos]: continue
-        back = [i for i, l in enumerate(body) if i >= pos and re.match(r"\s*s_c?branch\w*\s+%s\b" % re.escape(lab), l)]
-        if back and any(pos <= w <= max(back) and "vmcnt(0)" not in body[w] for w in wait_lines): loop_lines |= set(range(pos, max(back) + 1))
+        # the loop's blocks: the header and every block hipcc marks "in Loop: Header=BB<header>" (a rotated loop's body sits in FRONT of
+        # its header in the layout), each from its label to the next label
+        hid = lab[2:]                                        # ".LBB229_49" -> "BB229_49"
+        order = sorted(labels.values())
+        blocks = [p2 for l2, p2 in labels.items() if l2 == lab or ("Header=%s " % hid) in body[p2] + " "]
+        lines = set()
+        for p2 in blocks:
+            nxt = [q for q in order if q > p2]
+            lines |= set(range(p2, nxt[0] if nxt else len(body)))
+        if any(w in lines and "vmcnt(0)" not in body[w] for w in wait_lines): loop_lines |= lines
     stray = [i for i in sorted(loop_lines) if "vmcnt" in body[i] and i not in asm_lines]
     # compiler-placed waits between the first hidden load and the loop: each is as strict as the operations the COMPILER knows to be
     # younger (the DMA pieces), so it may only show up with a count >= the pieces still wanted in flight

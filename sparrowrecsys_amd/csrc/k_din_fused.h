@@ -177,6 +177,8 @@ __global__ __launch_bounds__(DF_WAVES * 64, 2) void k_din_fused(const DinFusedRu
     // of ts > 1 goes through ONE slot per wave; attention only: two parking slots per wave in LDS, S0, S1
     constexpr bool PREG = TAIL;
     constexpr int PSL = PREG ? 1 : 2;
+    constexpr bool AWL = TAIL && !MB;                     // the attention's A fragments through LDS (below)
+    float* park0 = smem + DF_COEF_FLOATS + img_floats + DF_WAVES * 16 * A.idp;
     float* park_s = smem + DF_COEF_FLOATS + img_floats + DF_WAVES * 16 * A.idp + wave * PSL * 64 * EL;
 
     unsigned long long ts_entry = 0;
@@ -248,14 +250,18 @@ __global__ __launch_bounds__(DF_WAVES * 64, 2) void k_din_fused(const DinFusedRu
     // use, and a use between two requests is a round trip of its own -- round 4's first form had FOUR at the head of every task
     // (ids 16 bytes at a time with a wait each, the candidate's rows, the first slots' rows, and the 88 KB image in front of it all).
     // TAIL: this sample's numerics, K = 8 as two steps (k = q and q + 4); requested first, used in the epilogue
+    // (hidden loads like everything else in front of the slot loop, and unconditional: a compiler-visible load left pending in
+    // hipcc's books made it put a vmcnt(0) in front of the first instruction that so much as ENCODES its register -- inside the slot
+    // loop, v_pk_fma_f32 v[108:109], v[142:143], ... with op_sel_hi = 0 reads v142 only, and v143 was xnb --, and "using" them behind the
+    // image's pieces made it wait for all of those)
     float xna = 0.f, xnb = 0.f;
     if constexpr (TAIL) {
-        if (tail_wave) {
-            const float* nrow = dense_b + (size_t)mc * A.ND;
-            const int last = A.n_num - 1;
-            xna = nrow[min(q, last)];
-            xnb = nrow[min(q + 4, last)];
-        }
+        const int last = max(A.n_num - 1, 0);
+        const float* nrow = A.ND > 0 ? dense_b + (size_t)mc * A.ND : reinterpret_cast<const float*>(ids_b);   // (no numerics: any valid word)
+        const float* pa = nrow + (A.ND > 0 ? min(q, last) : 0);
+        const float* pb = nrow + (A.ND > 0 ? min(q + 4, last) : 0);
+        asm volatile("global_load_dword %0, %1, off" : "=&v"(xna) : "v"(pa));
+        asm volatile("global_load_dword %0, %1, off" : "=&v"(xnb) : "v"(pb));
     }
     // the task's ids block (16 consecutive rows of F ints: contiguous) -> LDS by LDS-DMA, 1-KB pieces all in flight together
     if (work) {
@@ -298,7 +304,13 @@ __global__ __launch_bounds__(DF_WAVES * 64, 2) void k_din_fused(const DinFusedRu
         for (int c = 0; c < KC; ++c) hload(cp[c], (csafe * (unsigned)KP + EL * q + 4 * c) * 4u, A.tsplit);   // (< 4 GiB: checked at finalize)
 #pragma unroll
         for (int nb = 0; nb < 2; ++nb) hload(acc_init[nb], (csafe * (unsigned)HP + nb * 16 + 4 * q) * 4u, A.vc);
-        if constexpr (!MB) {
+        if constexpr (AWL) {
+            // (the eight A fragments are the same 8 KB for every wave: ONE copy per workgroup through LDS -- wave w stages fragment w
+            // in the parking region, which nothing else touches before the workgroup's second meeting -- instead of 64 KB per CU
+            // through the texture path in front of the first rows)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(A.frag + wave * 256 + lane * 4),
+                                             (__attribute__((address_space(3))) void*)(park0 + wave * 256), 16, 0, 0);
+        } else if constexpr (!MB) {
 #pragma unroll
             for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
@@ -310,6 +322,8 @@ __global__ __launch_bounds__(DF_WAVES * 64, 2) void k_din_fused(const DinFusedRu
 #pragma unroll
             for (int g = 0; g < DT_MAX_COLS; ++g) if (g < A.n_cols) tid_g[g] = ids_s[r * A.idp + A.col[g]];
         }
+    }
+    auto unf_load = [&]() {
         if constexpr (UNFK) {
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
@@ -325,7 +339,11 @@ __global__ __launch_bounds__(DF_WAVES * 64, 2) void k_din_fused(const DinFusedRu
                 hload(er[2 * u + 1], voff + 64u, eb);
             }
         }
-    }
+    };
+    // (one batch per launch: the raw rows are wanted in the epilogue only -- they go out BEHIND the image's pieces, so that the second
+    // round trip in front of the first slot is the candidate's rows, the fragments' piece and the first row sets and nothing else)
+    constexpr int NU = (UNFK && !MB) ? 4 : 0;
+    if constexpr (UNFK && MB) unf_load();
     f32x4 rowA[KC], rowB[KC], rowC[KC], rowD[KC];
     const char* tbase = reinterpret_cast<const char*>(A.tsplit);
     const unsigned qoff = (unsigned)(EL * 4) * (unsigned)q, vmax = (unsigned)A.vocab - 1u;
@@ -362,17 +380,27 @@ __global__ __launch_bounds__(DF_WAVES * 64, 2) void k_din_fused(const DinFusedRu
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(A.image + c * 256 + lane * 4),
                                              (__attribute__((address_space(3))) void*)(img_s + c * 256), 16, 0, 0);
         }
+        unf_load();
     }
-    // everything but the image pieces has landed: this wave's coefficient pieces, the second round trip, the first four row sets
+    // everything but the image pieces (and the raw rows behind them) has landed: this wave's coefficient pieces, the second round trip,
+    // the first four row sets
     // (volatile statements keep their order: the empty ones tie the remaining registers to the wait in front of them)
-    if constexpr (MB)
-        asm volatile("s_waitcnt vmcnt(%3)" : "+v"(cp[0]), "+v"(acc_init[0]), "+v"(acc_init[1]) : "n"(NPW));
+    if constexpr (MB || AWL)
+        asm volatile("s_waitcnt vmcnt(%3)" : "+v"(cp[0]), "+v"(acc_init[0]), "+v"(acc_init[1]) : "n"(NPW + NU));
     else
         asm volatile("s_waitcnt vmcnt(%11)" : "+v"(cp[0]), "+v"(acc_init[0]), "+v"(acc_init[1]), "+v"(aWr[0][0]), "+v"(aWr[0][1]), "+v"(aWr[0][2]),
-                     "+v"(aWr[0][3]), "+v"(aWr[1][0]), "+v"(aWr[1][1]), "+v"(aWr[1][2]), "+v"(aWr[1][3]) : "n"(NPW));
+                     "+v"(aWr[0][3]), "+v"(aWr[1][0]), "+v"(aWr[1][1]), "+v"(aWr[1][2]), "+v"(aWr[1][3]) : "n"(NPW + NU));
     if constexpr (KC == 2) asm volatile("" : "+v"(cp[KC - 1]));
-    if constexpr (UNFK) asm volatile("" : "+v"(er[0]), "+v"(er[UNFK ? 1 : 0]), "+v"(er[UNFK ? 2 : 0]), "+v"(er[UNFK ? 3 : 0]));
+    if constexpr (TAIL) asm volatile("" : "+v"(xna), "+v"(xnb));          // (tied to the wait above: the oldest loads of the task)
+    if constexpr (UNFK && MB) asm volatile("" : "+v"(er[0]), "+v"(er[UNFK ? 1 : 0]), "+v"(er[UNFK ? 2 : 0]), "+v"(er[UNFK ? 3 : 0]));
     stamp(7);
+    if constexpr (AWL) {
+        __builtin_amdgcn_s_barrier();                     // coefficient tables and the A fragments staged by every wave
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) aWr[nb][k] = ld4(park0 + ((nb * 4 + k) * 64 + lane) * 4);
+    }
     f16xe aW[2][4];
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb)
@@ -382,7 +410,7 @@ __global__ __launch_bounds__(DF_WAVES * 64, 2) void k_din_fused(const DinFusedRu
             else { const din_f16x8 both = __builtin_bit_cast(din_f16x8, aWr[nb][k]); aW[nb][k] = f16xe{both[0], both[1], both[2], both[3]}; }
         }
     din_f16x8 eh[UNFK ? 2 : 1], el[UNFK ? 2 : 1];
-    if constexpr (UNFK) {
+    if constexpr (UNFK && MB) {
 #pragma unroll
         for (int u = 0; u < 2; ++u) { eh[u] = __builtin_bit_cast(din_f16x8, er[2 * u]); el[u] = __builtin_bit_cast(din_f16x8, er[2 * u + 1]); }
     }
@@ -399,7 +427,7 @@ __global__ __launch_bounds__(DF_WAVES * 64, 2) void k_din_fused(const DinFusedRu
         for (int nb = 0; nb < 2; ++nb) acc_init[nb] = acc_init[nb] * A.acc_scale;
     }
     f32x4 z0[TAIL ? N0C : 1];
-    if constexpr (!MB) __builtin_amdgcn_s_barrier();      // coefficient tables staged by every wave
+    if constexpr (!MB && !AWL) __builtin_amdgcn_s_barrier();      // coefficient tables staged by every wave
     stamp(1);
 
     // ---- slot loop ----
@@ -594,8 +622,13 @@ __global__ __launch_bounds__(DF_WAVES * 64, 2) void k_din_fused(const DinFusedRu
             // the first trip runs under the image's DMA (its pieces are younger than the four row sets it waits for), by EVERY wave
             // (one without slots works on zero weights), then the wave's pieces have landed -- at most the four re-requested row
             // sets stay in flight -- and the workgroup meets once more: from here on the image is readable by all of it
-            trip(0, DfInt<NPW>{});
-            asm volatile("s_waitcnt vmcnt(%0)" :: "n"(4 * KC));
+            trip(0, DfInt<NPW + NU>{});
+            if constexpr (UNFK)
+                asm volatile("s_waitcnt vmcnt(%4)" : "+v"(er[0]), "+v"(er[UNFK ? 1 : 0]), "+v"(er[UNFK ? 2 : 0]), "+v"(er[UNFK ? 3 : 0]) : "n"(4 * KC));
+            else
+                asm volatile("s_waitcnt vmcnt(%0)" :: "n"(4 * KC));
+#pragma unroll
+            for (int u = 0; u < (UNFK ? 2 : 0); ++u) { eh[u] = __builtin_bit_cast(din_f16x8, er[2 * u]); el[u] = __builtin_bit_cast(din_f16x8, er[2 * u + 1]); }
             __builtin_amdgcn_s_barrier();
             step = 4;
         }
