@@ -23,5 +23,6 @@ def test_din_fused_hidden_loads_are_never_touched_in_flight():
     for l in lines:
         assert "early touches 0" in l and "inside the loop 0" in l, l
     # the one-batch tail forms count the image's DMA pieces behind the hidden loads; the persistent forms stage the image up front
-    assert any("k_din_fused<2, false, true" in l and "14 DMA pieces" in l for l in lines)
+    # (3 coefficient + 11 image pieces + the A fragments' piece)
+    assert any("k_din_fused<2, false, true" in l and "15 DMA pieces" in l for l in lines)
     assert any("k_din_fused<2, true, true" in l and " 0 DMA pieces" in l for l in lines)
