@@ -2,18 +2,26 @@
 // Part of sparrow_hip.hip (one translation unit); included there, not compilable on its own.
 // ---- k_mlp_rows<8, 8, NBIG, WAVES, DYN> ----
 constexpr int MR_WAVES = 8;
+template <int NBIG, int WK>
+void mlp_rows_launch_wk(const MlpRowsRun& a, const int* ids, const float* dense, float* out, int B, int* err, const float* image, int grid,
+                        size_t lds, hipStream_t st) {
+    if (a.inv_w1_scale != 0.f)
+        hipLaunchKernelGGL((k_mlp_rows<8, 8, NBIG, MR_WAVES, true, WK>), dim3(grid), dim3(MR_WAVES * 64), lds, st, a, ids, dense, out, B, err, image);
+    else
+        hipLaunchKernelGGL((k_mlp_rows<8, 8, NBIG, MR_WAVES, false, WK>), dim3(grid), dim3(MR_WAVES * 64), lds, st, a, ids, dense, out, B, err, image);
+}
 template <int NBIG>
 void mlp_rows_launch(const MlpRowsRun& a, const int* ids, const float* dense, float* out, int B, int* err, const float* image, int grid,
                      size_t lds, hipStream_t st) {
-    if (a.inv_w1_scale != 0.f)
-        hipLaunchKernelGGL((k_mlp_rows<8, 8, NBIG, MR_WAVES, true>), dim3(grid), dim3(MR_WAVES * 64), lds, st, a, ids, dense, out, B, err, image);
-    else
-        hipLaunchKernelGGL((k_mlp_rows<8, 8, NBIG, MR_WAVES, false>), dim3(grid), dim3(MR_WAVES * 64), lds, st, a, ids, dense, out, B, err, image);
+    if (a.wide_kind == 1) mlp_rows_launch_wk<NBIG, 1>(a, ids, dense, out, B, err, image, grid, lds, st);
+    else if (a.wide_kind == 2) mlp_rows_launch_wk<NBIG, 2>(a, ids, dense, out, B, err, image, grid, lds, st);
+    else mlp_rows_launch_wk<NBIG, 0>(a, ids, dense, out, B, err, image, grid, lds, st);
 }
 template <int NBIG>
 int mlp_rows_attr(size_t lds) {
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mlp_rows<8, 8, NBIG, MR_WAVES, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mlp_rows<8, 8, NBIG, MR_WAVES, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+#define MR_ATTR(DYN, WK) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mlp_rows<8, 8, NBIG, MR_WAVES, DYN, WK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    MR_ATTR(true, 0) MR_ATTR(true, 1) MR_ATTR(true, 2) MR_ATTR(false, 0) MR_ATTR(false, 1) MR_ATTR(false, 2)
+#undef MR_ATTR
     return SPRK_OK;
 }
 // Recognise an EmbeddingMLP / Wide&Deep plan (EmbeddingMLP.py:72-77, WideNDeep.py:99-107) with ReLU layers of 128 and fold

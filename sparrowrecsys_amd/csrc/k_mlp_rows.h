@@ -99,7 +99,13 @@ __global__ __launch_bounds__(256) void k_mlp_rows_pack(const float* __restrict__
     for (int i = LD::total + tid; i < LD::total_pad; i += 256) img[i] = 0.f;
 }
 
-template <int N0C, int N1C, int NBIG, int WAVES, bool DYN>
+// WK = the wide part (MlpRowsRun::wide_kind) as a TEMPLATE parameter.  [r4] As a run-time branch it cost config 5 a fifth of its time:
+// the two forms' loads (cross row pieces / the indicator's scalar) sat in the arms of a wave-uniform branch, hipcc gave the scalar's
+// register a second job in the other arm, and its waitcnt pass -- which merges the "load pending" state of every path into a join --
+// put a vmcnt(0) in front of that arm and another behind the join: BOTH right after the next task's sixteen row gathers had been
+// requested, i.e. every trip waited for the rows it had just asked for and the prefetch hid nothing (found by reading the ISA's
+// wait sequence, scripts/r04; 42.8 -> see profiles/r04).
+template <int N0C, int N1C, int NBIG, int WAVES, bool DYN, int WK>
 __global__ __launch_bounds__(WAVES * 64, 2) void k_mlp_rows(const MlpRowsRun A, const int* __restrict__ ids,
                                                             const float* __restrict__ dense, float* __restrict__ out,
                                                             int B, int* __restrict__ err, const float* __restrict__ image) {
@@ -175,9 +181,9 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_mlp_rows(const MlpRowsRun A, 
             xa = nrow[min(q, last)];
             xb = nrow[min(q + 4, last)];
         }
-        if (A.wide_kind) {                                        // wave-uniform
+        if constexpr (WK != 0) {
             const unsigned long long bkt = cross_bucket(idrow[A.wide_a], idrow[A.wide_b], (uint64_t)A.wide_buckets);
-            if (A.wide_kind == 1) {
+            if constexpr (WK == 1) {
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     const int d = 16 * h + 4 * q;
@@ -213,7 +219,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_mlp_rows(const MlpRowsRun A, 
         rwb[nb] = smem[LD::off_w0n + (nb * 16 + r) * 8 + q + 4];
     }
     f32x4 wwide[2] = {zero, zero};
-    if (A.wide_kind == 1) {
+    if constexpr (WK == 1) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int d = 16 * h + 4 * q;
@@ -234,8 +240,8 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_mlp_rows(const MlpRowsRun A, 
             for (int b = 1; b < NBIG; ++b) z0[nb] += g[b][nb];
         }
         float zw = 0.f;
-        if (A.wide_kind == 1) zw = dot4(gw[0], wwide[0]) + dot4(gw[1], wwide[1]);
-        else if (A.wide_kind == 2) zw = q == 0 ? gws : 0.f;
+        if constexpr (WK == 1) zw = dot4(gw[0], wwide[0]) + dot4(gw[1], wwide[1]);
+        else if constexpr (WK == 2) zw = q == 0 ? gws : 0.f;
         int so_c[MR_MAX_SMALL];
 #pragma unroll
         for (int f = 0; f < MR_MAX_SMALL; ++f) so_c[f] = so[f];
