@@ -126,6 +126,15 @@ __global__ __launch_bounds__(V2J1_WAVES * 64, 4) void k_deepfm_v2_joint1(const V
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(A.small + c * 256 + lane * 4),
                                          (__attribute__((address_space(3))) void*)(smem + LD::total_pad + c * 256), 16, 0, 0);
 
+    // ---- [r4] the workgroup meets HERE, with its ids and its DMA pieces in, BEFORE the rows are requested.  Round 3 met after the
+    // requests ("every row of the batch is requested as soon as its ids are in -- before the barrier"), and the stamped timeline of
+    // round 4 (profiles/r04/experiments/r04_25) showed what that costs: the waves of a workgroup reach this point within 0.5 us of
+    // each other, but finish ISSUING their four gathers 0.4 .. 2.3 us later (the texture path is saturated by sixteen waves per CU
+    // doing the same) -- a barrier behind the requests makes every wave wait for the slowest issuer, 1.4 us (median) during which
+    // its rows are already on their way and its LDS phase could run. ----
+    __builtin_amdgcn_s_waitcnt(0x0F70);                               // vmcnt(0): this wave's ids and DMA pieces have landed
+    __builtin_amdgcn_s_barrier();
+    if (!work) return;
     // ---- gather: ids through the wave-private LDS slot to the (r,q) lanes, then every row of the task ----
     f32x4 x[G_BIG];
     int so[NJF];
@@ -135,7 +144,7 @@ __global__ __launch_bounds__(V2J1_WAVES * 64, 4) void k_deepfm_v2_joint1(const V
     for (int b = 0; b < G_BIG; ++b) x[b] = zero;
 #pragma unroll
     for (int f = 0; f < NJF; ++f) so[f] = 0;
-    if (work) {
+    {
         if (fast) {
             const bool isid = lane < 32;
             const int j = isid ? lane : lane - 32;
@@ -177,14 +186,7 @@ __global__ __launch_bounds__(V2J1_WAVES * 64, 4) void k_deepfm_v2_joint1(const V
             w1a = *reinterpret_cast<const float*>(tb + (sx + 4u * KP));
         }
         V2J1_STAMP(2);
-        // in-order retirement: at most NG loads outstanding <=> this wave's DMA pieces (older) have landed
-        constexpr int NG = G_BIG + 1;
-        __builtin_amdgcn_s_waitcnt(0x0F70 | NG);
-    } else {
-        __builtin_amdgcn_s_waitcnt(0x0F70);
     }
-    __builtin_amdgcn_s_barrier();
-    if (!work) return;
     V2J1_STAMP(3);
 
     // ---- scoring, phase A: everything that does NOT need the rows -- every LDS read of the stage (fragments, small fields'
