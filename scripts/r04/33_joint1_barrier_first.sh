@@ -1,7 +1,9 @@
 #!/bin/bash
-# Round 4: k_deepfm_v2_joint1 with the workgroup's barrier IN FRONT of the row requests (the waves arrive there within 0.5 us of each
-# other; behind the requests they waited 1.4 us for the slowest issuer) against the previous commit's library.  Parity tests of the
-# DeepFM_v2 kernels first; config 2 with the tables in the Infinity Cache and in HBM, config 4.
+# Round 4: k_deepfm_v2_joint1 A/B against the previous commit's library (scripts/r04/libsparrow_hip_head.so, built by hand from `git
+# archive HEAD`).  Run 1 (profiles/r04/experiments/r04_33): the workgroup's barrier IN FRONT of the row requests (the waves arrive there
+# within 0.5 us of each other; behind the requests they waited 1.4 us for the slowest issuer): config 2 7.56 -> 7.26 us, HBM-resident
+# 9.15 -> 8.9 us -- kept.  Run 2 (r04_34): on top of it, the weight fragments' LDS reads in front of the gathers: HBM-resident 8.9 ->
+# 8.68 us but config 2 7.26 -> 7.38 us (and 127 of 128 VGPRs) -- NOT kept.  Parity tests of the DeepFM_v2 kernels first.
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/${1:-r04_33}
