@@ -454,15 +454,11 @@ __device__ __forceinline__ void v1_body(const V1Run& A, const int* __restrict__ 
             (__attribute__((address_space(3))) void*)(smem + c * 256), 16, 0, 0);
     Set SA, SB;
     if constexpr (ONE) {
-        // the wave's only task: its rows are requested before the barrier (they need the ids, not the image); vmcnt retires in
-        // order, so "at most NF loads outstanding" -- at least NF row loads always follow the DMA -- means the DMA pieces are in
-        if (tA < ntasks) {
-            issue_gather(tA, idA, SA);
-            __builtin_amdgcn_s_waitcnt(0x0F70 | NF);
-        } else {
-            __builtin_amdgcn_s_waitcnt(0x0F70);
-        }
+        // the wave's only task.  [r4] The workgroup meets with its ids and DMA pieces in, BEFORE the rows are requested (k_chain_v2j1.h:
+        // behind the requests every wave waited for the slowest issuer of the workgroup)
+        __builtin_amdgcn_s_waitcnt(0x0F70);
         __builtin_amdgcn_s_barrier();
+        if (tA < ntasks) issue_gather(tA, idA, SA);
 #pragma unroll
         for (int nb = 0; nb < H0C; ++nb) {
             rna[nb] = smem[LD::off_w0n + (nb * 16 + r) * 8 + q];
