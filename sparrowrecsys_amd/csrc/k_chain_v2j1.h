@@ -18,7 +18,9 @@
 // Used by sprk_forward / one-batch launches with ceil(B / 16) <= V2J1_MAX_TASKS; larger batches and the several-batches-
 // per-launch form stay on the looped kernel (one image staging per workgroup is only worth 8 tasks when there are few).
 
-#define V2J1_WAVES 8                         // (4: 7.93 us, 16: 8.41 us against 7.65 us -- scripts/r03/10_joint1_waves16.sh)
+#ifndef V2J1_WAVES
+#define V2J1_WAVES 8                         // (4: 7.93 us, 16: 8.41 us against 7.65 us -- scripts/r03/10_joint1_waves16.sh; [r4] again with the barrier in front of the gathers: scripts/r04/36_*)
+#endif
 #define V2J1_MAX_TASKS 16384                 // B <= 262 144: beyond, the looped kernel amortises the image staging better
 
 template <int G_BIG>
