@@ -8,7 +8,8 @@
 // and the fused kernel sat 1.4 / 2.25 us above its shape's floor (9.89 / 8.38 us): its two-tasks-per-wave form keeps the
 // weights in 256 VGPRs (2 waves per SIMD), issues gather B only after the image barrier + the weight fragments' split, and
 // ends every wave with two scoring stages back to back.  Here a wave owns exactly one task:
-//   * every row of the batch is requested as soon as its ids are in -- before the barrier, nothing else in front of it;
+//   * every row of the batch is requested as soon as its ids are in and the workgroup has met ([r4]: the barrier sits in FRONT of the
+//     requests -- behind them every wave waited for the slowest issuer of its workgroup, see the kernel);
 //   * nothing is loop-carried and no weight lives in a register across tasks: the A fragments of the big fields arrive
 //     PRE-SPLIT (hi / lo halfs, k_v2j1_pack_image) in the LDS image and are read right where an MFMA consumes them, so
 //     the kernel fits 128 VGPRs = 4 waves per SIMD, and the split's VALU work is gone from the launch;
