@@ -1,0 +1,74 @@
+"""The committed evidence is self-consistent: every fraction of profiles/r04/roofline_table.json (the table DESIGN.md section 7.2 quotes)
+follows from the rocprofv3 csv next to it -- algorithmic bytes per launch / the kernel's average duration / 8.0e12 --, the bench lines
+kept beside the csvs describe the same kernel and batch, the PMC columns follow from pmc_summary.json, and the driver's line
+(bench_driver_command.json) carries the blocks VERDICT r03 asked for with the bound of its 64-batch region labelled as what it is."""
+import csv
+import json
+import os
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+P = os.path.join(ROOT, "profiles", "r04")
+HBM_PEAK = 8.0e12
+
+
+def _table():
+    return json.load(open(os.path.join(P, "roofline_table.json")))
+
+
+def _kernel_rows(path):
+    with open(path, newline="") as f:
+        return [(r["Name"], int(r["Calls"]), float(r["AverageNs"])) for r in csv.DictReader(f)]
+
+
+@pytest.mark.parametrize("row", _table(), ids=lambda r: r["workload"])
+def test_fraction_follows_from_the_kept_trace(row):
+    w = row["workload"].replace("c3_attn", "c3")                     # (config 3's two kernels share one trace)
+    rows = _kernel_rows(os.path.join(P, w + "_strict_kernel_stats.csv"))
+    hit = [r for r in rows if "::" + row["kernel"] in r[0].replace("(anonymous namespace)::", "::", 1)]
+    assert len(hit) == 1, (row["kernel"], [r[0][:60] for r in rows[:4]])
+    name, calls, avg_ns = hit[0]
+    assert calls == row["launches"] and abs(avg_ns / 1e3 - row["rocprof_avg_us"]) < 1e-6
+    alg = row["algorithmic_bytes_per_sample"] * row["batch"]
+    assert abs(alg / (avg_ns * 1e-9) / HBM_PEAK - row["frac"]) < 1e-9
+    assert abs(alg / 1e6 - row["algorithmic_mb"]) < 1e-6
+    # the untraced twin of the same command: same workload and batch, its HIP-event time is the table's
+    b = json.load(open(os.path.join(P, "bench_" + w + "_strict.json")))
+    assert b["config"]["workload"].split(":")[0] == row["bench_workload"] and b["config"]["batch_per_gpu"] == row["batch"]
+    rl = b["roofline"].get("fused_step", b["roofline"]) if row["workload"] == "c3" else b["roofline"]
+    assert abs(rl["avg_launch_us"] - row["hip_event_us"]) < 1e-6
+    # HIP events and the tracer agree on every kernel of 7 us and more (the tracer inflates shorter ones)
+    if row["rocprof_avg_us"] >= 7.0:
+        assert 0.94 <= row["events_vs_rocprof"] <= 1.06, row["events_vs_rocprof"]
+
+
+def test_pmc_columns_follow_from_the_summary():
+    pm = json.load(open(os.path.join(P, "pmc_summary.json")))
+    seen = 0
+    for row in _table():
+        if "pmc_traffic_mb" not in row:
+            continue
+        w = row["workload"].replace("c3_attn", "c3")
+        k = row["kernel"] if row["kernel"] in pm["pmc_%s_fetch" % w] else row["kernel"].split("<")[0]
+        t = 2 * pm["pmc_%s_fetch" % w][k]["FETCH_SIZE"] * 1024 + pm["pmc_%s_write" % w][k]["WRITE_SIZE"] * 1024
+        assert abs(t / 1e6 - row["pmc_traffic_mb"]) < 1e-6
+        seen += 1
+        if "valu_per_sample" in row:
+            assert abs(pm["pmc_%s_sq2" % w][k]["SQ_INSTS_VALU"] / row["batch"] - row["valu_per_sample"]) < 1e-9
+    assert seen >= 8
+    # config 3: the one-launch kernel and its attention-only form are reported apart
+    assert {"k_din_fused<2, false, true, false, 0>", "k_din_fused<2, false, false, false, 0>"} <= set(pm["pmc_c3_sq2"])
+
+
+def test_driver_line_blocks():
+    l = json.load(open(os.path.join(P, "bench_driver_command.json")))
+    assert l["metric"] == "ctr_samples_per_sec" and l["n_gpus"] == 1 and l["steps"] == 20 and l["warmup"] == 5
+    assert l["roofline_timed_region"]["bound"] == "infinity_cache" and "NOT an HBM utilisation" in l["roofline_timed_region"]["frac_is"]
+    assert set(l["workloads"]) >= {"din_c3", "deepfm_c2", "deepfm_c4", "widedeep_c5", "neuralcf_serving"}
+    assert l["workloads"]["neuralcf_serving"]["latency_ms"]["p50"] < 0.5
+    assert l["roofline"]["bound"] == "hbm" and abs(l["roofline"]["achieved"] / l["roofline"]["peak"] - l["roofline"]["frac"]) < 1e-9
+    assert l["cpu_baseline"]["kind"] == "port" and l["cpu_baseline"]["cores"] >= 1
+    # value = samples per second of the timed region; the one-batch figure is the strict roofline's
+    assert abs(l["value"] * l["ms_per_step"] * 1e-3 / l["config"]["batch_per_gpu"] - 1.0) < 1e-6
+    assert l["workloads"]["din_c3"]["roofline"]["kernel"].startswith("k_din_fused")
