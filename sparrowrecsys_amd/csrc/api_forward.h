@@ -181,8 +181,8 @@ int sprk_forward(sprk_handle h, const int32_t* ids, const float* dense, float* o
                 // one strict launch of one batch: one task per wave, four waves per SIMD (k_chain_v2j1.h)
                 for (size_t v = 0; v < sizeof(kV2J1Variants) / sizeof(kV2J1Variants[0]); ++v)
                     if (kV2J1Variants[v].g_big == kV2JVariants[h->v2j_variant].g_big && kV2J1Variants[v].njf == kV2JVariants[h->v2j_variant].njf) {
-                        kV2J1Variants[v].launch(jr, ids, dense, out, B, h->dev_err, h->v2j1_image, (ntasks + V2J1_WAVES - 1) / V2J1_WAVES,
-                                                h->v2j1_lds_bytes, st);
+                        (h->v2j1_hoist ? kV2J1Variants[v].launch_h : kV2J1Variants[v].launch)(jr, ids, dense, out, B, h->dev_err, h->v2j1_image,
+                                                                                                (ntasks + V2J1_WAVES - 1) / V2J1_WAVES, h->v2j1_lds_bytes, st);
                         HIP_TRY(hipGetLastError());
                         return SPRK_OK;
                     }

@@ -73,6 +73,7 @@ struct SprkTuning {
     bool v2_joint = true;             // SPRK_V2_JOINT=0            no LDS-resident small fields (k_deepfm_v2_chain)
     bool v2_half = true;              // SPRK_V2_HALF=0             big fields on f32 MFMA instead of split f16
     bool v2j_one = true;              // SPRK_V2J_ONE=0             one-batch launches on the looped kernel, not k_deepfm_v2_joint1
+    int v2j1_hoist = -1;              // SPRK_V2J1_HOIST=0|1        k_deepfm_v2_joint1's weight fragments read behind / in front of the gathers (default: by table size)
     bool tail_unf = true;             // SPRK_TAIL_UNF=0            k_din_tail: folded 512-byte rows for the embedding columns even when emb_dim <= 16
     bool tail_pooled_f16 = true;      // SPRK_TAIL_POOLED_F16=0     k_din_tail: the pooled-history columns of fc0 on f32 MFMA (round 2) instead of split f16
     bool dien_mfma = true;            // SPRK_DIEN_MFMA=0           DIEN sequence stage: one lane per sample (k_dien_seq) instead of 16 samples per MFMA tile
@@ -101,7 +102,7 @@ struct SprkTuning {
         SprkTuning t;
         t.force_interpreter = on("SPRK_FORCE_INTERPRETER");
         t.v2_fold = !off("SPRK_V2_FOLD"); t.v2_rows = on("SPRK_V2_ROWS"); t.v2_joint = !off("SPRK_V2_JOINT"); t.v2_half = !off("SPRK_V2_HALF");
-        t.v2j_one = !off("SPRK_V2J_ONE");
+        t.v2j_one = !off("SPRK_V2J_ONE"); t.v2j1_hoist = num("SPRK_V2J1_HOIST", -1);
         t.rows_unf = !off("SPRK_ROWS_UNF"); t.dien_mfma = !off("SPRK_DIEN_MFMA"); t.tail_pooled_f16 = !off("SPRK_TAIL_POOLED_F16"); t.tail_unf = !off("SPRK_TAIL_UNF"); t.ncf_chain = !off("SPRK_NCF_CHAIN"); t.tile_fold = !off("SPRK_TILE_FOLD");
         t.half_range_guard = !off("SPRK_HALF_RANGE_GUARD"); t.dyn_f16 = !off("SPRK_DYN_F16");
         t.v1_chain = !off("SPRK_V1_CHAIN");

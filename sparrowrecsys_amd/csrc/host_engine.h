@@ -83,6 +83,7 @@ struct sprk_engine {
     int v2j_variant = -1;
     float* v2j1_image = nullptr;          // k_deepfm_v2_joint1 (one task per wave): its LDS image; NULL = shape not available
     size_t v2j1_lds_bytes = 0;
+    bool v2j1_hoist = false;              // k_deepfm_v2_joint1<..., HOIST>: tables larger than the Infinity Cache (k_chain_v2j1.h)
     int many_batches = 1;                 // sprk_forward_many: batches scored per launch (sprk_set_many_batches)
     // "one row per id" chain (k_rows_chain): DeepFM_v2 with projections wider than 16 (the reference's Dense(64)) and NeuralCF
     int rows_variant = -1;

@@ -81,14 +81,16 @@ const V2JVariant kV2JVariants[] = {
 
 // k_deepfm_v2_joint1<G_BIG, NJF>: the one-task-per-wave shape of the split-f16 joint kernel (k_chain_v2j1.h)
 typedef void (*V2J1LaunchFn)(const V2JRun&, const int*, const float*, float*, int, int*, const float*, int, size_t, hipStream_t);
-template <int G_BIG, int NJF>
+template <int G_BIG, int NJF, bool HOIST>
 void v2j1_launch(const V2JRun& a, const int* ids, const float* dense, float* out, int B, int* err, const float* image, int grid,
                  size_t lds, hipStream_t st) {
-    hipLaunchKernelGGL((k_deepfm_v2_joint1<G_BIG, NJF>), dim3(grid), dim3(V2J1_WAVES * 64), lds, st, a, ids, dense, out, B, err, image);
+    hipLaunchKernelGGL((k_deepfm_v2_joint1<G_BIG, NJF, HOIST>), dim3(grid), dim3(V2J1_WAVES * 64), lds, st, a, ids, dense, out, B, err, image);
 }
-struct V2J1Variant { int g_big, njf; const void* fn; V2J1LaunchFn launch; int image_floats; };
+// (fn_h / launch_h: the HOIST form, for tables larger than the Infinity Cache)
+struct V2J1Variant { int g_big, njf; const void* fn; V2J1LaunchFn launch; int image_floats; const void* fn_h; V2J1LaunchFn launch_h; };
 #define V2J1_VARIANT(G_BIG, NJF) \
-    {G_BIG, NJF, reinterpret_cast<const void*>(&k_deepfm_v2_joint1<G_BIG, NJF>), &v2j1_launch<G_BIG, NJF>, V2J1Lds<G_BIG>::total_pad}
+    {G_BIG, NJF, reinterpret_cast<const void*>(&k_deepfm_v2_joint1<G_BIG, NJF, false>), &v2j1_launch<G_BIG, NJF, false>, V2J1Lds<G_BIG>::total_pad, \
+     reinterpret_cast<const void*>(&k_deepfm_v2_joint1<G_BIG, NJF, true>), &v2j1_launch<G_BIG, NJF, true>}
 const V2J1Variant kV2J1Variants[] = {
     V2J1_VARIANT(3, 3), V2J1_VARIANT(2, 2), V2J1_VARIANT(3, 2), V2J1_VARIANT(3, 1), V2J1_VARIANT(2, 3), V2J1_VARIANT(2, 1),
     V2J1_VARIANT(1, 3), V2J1_VARIANT(1, 2), V2J1_VARIANT(1, 1),
@@ -360,6 +362,9 @@ int setup_v2_joint(sprk_engine* h) {
             HIP_TRY(hipDeviceSynchronize());
             h->v2j1_lds_bytes = ((size_t)ov.image_floats + small_floats + (size_t)V2J1_WAVES * 256) * sizeof(float);
             HIP_TRY(hipFuncSetAttribute(ov.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->v2j1_lds_bytes));
+            HIP_TRY(hipFuncSetAttribute(ov.fn_h, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->v2j1_lds_bytes));
+            // rows that cannot all sit in the 256 MB Infinity Cache come from HBM: the form that reads its weight fragments first
+            h->v2j1_hoist = h->tune.v2j1_hoist >= 0 ? h->tune.v2j1_hoist != 0 : h->derived_bytes > ((size_t)256 << 20);
         }
     }
     return SPRK_OK;

@@ -89,7 +89,11 @@ __device__ unsigned long long g_v2j1_ts[V2J1_TS_WAVES * 8];
 #else
 #define V2J1_STAMP(k) do { } while (0)
 #endif
-template <int G_BIG, int NJF>
+// HOIST ([r4]; chosen at finalize for tables larger than the Infinity Cache): the big fields' weight fragments and the selection
+// fragment -- 13 of the 26 KB a wave reads from LDS, none of it needing an id -- are read in FRONT of the gathers.  With rows coming
+// from HBM the texture path backs up longer and the LDS sits idle meanwhile: 8.9 -> 8.68 us; with cache-resident tables the same
+// move only delays the gathers: 7.26 -> 7.38 us (profiles/r04/experiments/r04_34).  Same arithmetic, same bits.
+template <int G_BIG, int NJF, bool HOIST = false>
 __global__ __launch_bounds__(V2J1_WAVES * 64, 4) void k_deepfm_v2_joint1(const V2JRun A, const int* __restrict__ ids,
                                                                        const float* __restrict__ dense, float* __restrict__ out, int B,
                                                                        int* __restrict__ err, const float* __restrict__ image) {
@@ -138,6 +142,19 @@ __global__ __launch_bounds__(V2J1_WAVES * 64, 4) void k_deepfm_v2_joint1(const V
     __builtin_amdgcn_s_waitcnt(0x0F70);                               // vmcnt(0): this wave's ids and DMA pieces have landed
     __builtin_amdgcn_s_barrier();
     if (!work) return;
+    f16x8 wa[G_BIG][H0C], wb[G_BIG][H0C], hSel;
+    auto read_frags = [&]() {
+        const f16x8* frag = reinterpret_cast<const f16x8*>(smem + LD::off_frag) + lane;
+#pragma unroll
+        for (int b = 0; b < G_BIG; ++b)
+#pragma unroll
+            for (int n0 = 0; n0 < H0C; ++n0) { wa[b][n0] = frag[((b * 2 + n0) * 2 + 0) * 64]; wb[b][n0] = frag[((b * 2 + n0) * 2 + 1) * 64]; }
+        hSel = reinterpret_cast<const f16x8*>(smem + LD::off_sel)[lane];
+    };
+    if constexpr (HOIST) {
+        read_frags();
+        __builtin_amdgcn_sched_barrier(0);
+    }
     // ---- gather: ids through the wave-private LDS slot to the (r,q) lanes, then every row of the task ----
     f32x4 x[G_BIG];
     int so[NJF];
@@ -213,15 +230,7 @@ __global__ __launch_bounds__(V2J1_WAVES * 64, 4) void k_deepfm_v2_joint1(const V
         for (int n0 = 0; n0 < H0C; ++n0) sq[n0] += ld4(small_s + so[f] + KP + 16 * n0 + 4 * q);
         ssc += small_s[so[f] + KP + 32];
     }
-    f16x8 wa[G_BIG][H0C], wb[G_BIG][H0C];
-    {
-        const f16x8* frag = reinterpret_cast<const f16x8*>(smem + LD::off_frag) + lane;
-#pragma unroll
-        for (int b = 0; b < G_BIG; ++b)
-#pragma unroll
-            for (int n0 = 0; n0 < H0C; ++n0) { wa[b][n0] = frag[((b * 2 + n0) * 2 + 0) * 64]; wb[b][n0] = frag[((b * 2 + n0) * 2 + 1) * 64]; }
-    }
-    const f16x8 hSel = reinterpret_cast<const f16x8*>(smem + LD::off_sel)[lane];
+    if constexpr (!HOIST) read_frags();
     float rwf[H0C][2];
     {
         const float* wf = small_s + A.wf_off + r * 8 + q;

@@ -499,8 +499,11 @@ def test_v2_joint1_bit_identical_to_joint(torch, monkeypatch, fields):
     for B in (65536, 5003, 16, 7, 1):
         feats = SY.synth_fields(B, fields, seed=77 + B)
         outs = []
-        for one in ("1", "0"):
+        # (joint1 with its weight fragments read behind the gathers, then in front of them -- the form finalize picks for tables larger
+        # than the Infinity Cache --, then the looped kernel)
+        for one, hoist in (("1", "0"), ("1", "1"), ("0", "0")):
             monkeypatch.setenv("SPRK_V2J_ONE", one)
+            monkeypatch.setenv("SPRK_V2J1_HOIST", hoist)
             model = M.DeepFMv2(seed=46, emb_dim=16, fields=fields, proj_dim=16)
             ids, dense = model.pack(feats)
             ids_t, dense_t = torch.from_numpy(ids).cuda(), torch.from_numpy(dense).cuda()
@@ -510,7 +513,8 @@ def test_v2_joint1_bit_identical_to_joint(torch, monkeypatch, fields):
                 assert np.array_equal(tail, got[1:])
             model.engine.check_ids()
             outs.append(got)
-        assert np.array_equal(outs[0], outs[1]), "B=%d: joint1 and joint differ by %g" % (B, np.abs(outs[0] - outs[1]).max())
+        assert np.array_equal(outs[0], outs[1]), "B=%d: the two forms of joint1 differ by %g" % (B, np.abs(outs[0] - outs[1]).max())
+        assert np.array_equal(outs[0], outs[2]), "B=%d: joint1 and joint differ by %g" % (B, np.abs(outs[0] - outs[2]).max())
         n = min(B, 4096)
         ref = O.deepfm_v2_forward({k: v[:n] for k, v in feats.items()}, model.weights, dtype=np.float64, fields=fields, order=order)[:, 0]
         assert np.abs(outs[0][:n] - ref).max() <= TIGHT
