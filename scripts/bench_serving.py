@@ -35,19 +35,31 @@ def _client(port, bodies, seconds, instances, k, q):
     q.put(mine)
 
 
+def _neuralcf():
+    from sparrowrecsys_amd import models as M
+    m = M.NeuralCF(seed=7)
+    m.engine
+    return m
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--clients", type=int, default=16)
     ap.add_argument("--seconds", type=float, default=5.0)
     ap.add_argument("--instances", type=int, default=800)
+    ap.add_argument("--workers", type=int, default=1, help="server worker processes behind one port (serving.serve_workers, SO_REUSEPORT)")
     a = ap.parse_args()
     import numpy as np
     from sparrowrecsys_amd import models as M
-    from sparrowrecsys_amd.serving import PredictServer
-    model = M.NeuralCF(seed=7)
-    srv = PredictServer(model, port=0)
-    srv.start()
-    port = srv.httpd.server_address[1] if hasattr(srv, "httpd") else srv.port
+    from sparrowrecsys_amd.serving import PredictServer, serve_workers
+    if a.workers > 1:
+        srv = serve_workers(_neuralcf, (), n_workers=a.workers, port=0)
+        port = srv.port
+    else:
+        model = M.NeuralCF(seed=7)
+        srv = PredictServer(model, port=0)
+        srv.start()
+        port = srv.httpd.server_address[1] if hasattr(srv, "httpd") else srv.port
     rng = np.random.default_rng(1)
     bodies = []
     for _ in range(32):
@@ -73,7 +85,9 @@ def main():
     pct = lambda p: round(lat[min(len(lat) - 1, int(p * len(lat)))] * 1e3, 2)
     print(json.dumps({"clients": a.clients, "instances_per_request": a.instances, "requests": len(lat), "requests_per_sec": round(len(lat) / wall, 1),
                       "candidates_per_sec": round(len(lat) * a.instances / wall), "latency_ms": {"p50": pct(0.5), "p90": pct(0.9), "p99": pct(0.99)},
-                      "server": "sparrowrecsys_amd.serving.PredictServer (ThreadingHTTPServer + micro-batcher), model NeuralCF"}))
+                      "workers": a.workers,
+                      "server": "sparrowrecsys_amd.serving.PredictServer (ThreadingHTTPServer + micro-batcher)%s, model NeuralCF"
+                                % (" x %d worker processes on one port (SO_REUSEPORT)" % a.workers if a.workers > 1 else "")}))
 
 
 if __name__ == "__main__":

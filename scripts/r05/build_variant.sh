@@ -1,0 +1,5 @@
+#!/bin/bash
+# usage: scripts/r05/build_variant.sh <name> [-DFOO=1 ...]  -> scripts/r05/libsparrow_hip_<name>.so (git-ignored; travels to the GPU box)
+cd "$(dirname "$0")/../.."
+n=$1; shift
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -pthread "$@" -I include -I sparrowrecsys_amd/csrc sparrowrecsys_amd/csrc/sparrow_hip.hip -o scripts/r05/libsparrow_hip_$n.so && echo "built $n"

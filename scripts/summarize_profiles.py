@@ -27,7 +27,7 @@ DOMINANT = {"c2": "k_deepfm_v2_joint1", "c2_hbm": "k_deepfm_v2_joint1", "c2_pair
 # round 4: BASELINE config 3 is ONE launch (k_din_fused<2, false, true>: attention + pooling + tail); its attention-only instantiation
 # (<2, false, false>, what sprk_din_pool launches -- the figure comparable with round 3's k_din_attn_cols) is a second row, "c3_attn",
 # read from the same trace (bench.py times that loop after the fused one)
-if os.environ.get("SPRK_PROFILE_ROUND", "4") >= "4":
+if int(os.environ.get("SPRK_PROFILE_ROUND", "5")) >= 4:
     DOMINANT.update({"c3": "k_din_fused<2, false, true", "c3_attn": "k_din_fused<2, false, false"})
 ORDER = ["c2", "c2_hbm", "c2_pairs", "c3", "c3_attn", "c4_v2", "c4_pairs", "c5", "v2_ref", "ncf_ref", "deepfm_ref", "din_ref", "embedding_mlp_ref", "dien_ref"]
 SHARES_FILES_OF = {"c3_attn": "c3"}                    # a row read from another workload's trace / bench line

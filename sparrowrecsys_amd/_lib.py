@@ -89,8 +89,19 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     (hipcc cross-compiles without a GPU)."""
     csrc = os.path.dirname(SRC_PATH)
     deps = [os.path.join(csrc, f) for f in os.listdir(csrc)] + [os.path.join(INCLUDE_DIR, "sparrow_hip.h")]
+    # [r5, ADVICE r04] the experiment defines are part of what "fresh" means: a library built once with SPRK_BUILD_DEFINES (other wave
+    # counts, ablation kernels, the stamped-timeline build's file writes) must not be reused as the product after the variable is
+    # unset, nor the product when it is set.  The string the library was built with sits next to it.
+    defines = " ".join(os.environ.get("SPRK_BUILD_DEFINES", "").split())
+    stamp = LIB_PATH + ".defines"
     def fresh():
-        return os.path.exists(LIB_PATH) and os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(d) for d in deps)
+        if not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < max(os.path.getmtime(d) for d in deps):
+            return False
+        try:
+            built_with = open(stamp).read().strip()
+        except OSError:
+            built_with = ""                                       # (no stamp: a product build of an earlier tree)
+        return built_with == defines
     if not force and fresh():
         return LIB_PATH
     # several processes (one rank per GPU, pytest-xdist workers) may get here at once: one builds, the others wait
@@ -106,14 +117,17 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
             tmp = "%s.tmp.%d" % (LIB_PATH, os.getpid())
             cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-pthread",
                    "-I", INCLUDE_DIR, "-I", os.path.dirname(SRC_PATH), SRC_PATH, "-o", tmp]
-            if os.environ.get("SPRK_BUILD_DEFINES"):              # experiment builds (e.g. -DSPRK_DF_XP: k_din_fused's ablation variants)
-                cmd[1:1] = os.environ["SPRK_BUILD_DEFINES"].split()
+            if defines:                                           # experiment builds (e.g. -DSPRK_DF_XP: k_din_fused's ablation variants)
+                cmd[1:1] = defines.split()
+                cmd[1:1] = ["-DSPRK_BUILD_DEFINES_STR=\"%s\"" % defines.replace('"', "'")]
             if verbose:
                 print(" ".join(cmd))
             res = subprocess.run(cmd, capture_output=True, text=True)
             if res.returncode != 0:
                 raise RuntimeError("hipcc failed:\n%s\n%s" % (res.stdout, res.stderr))
             os.replace(tmp, LIB_PATH)
+            with open(stamp, "w") as f:
+                f.write(defines + "\n")
             return LIB_PATH
         finally:
             fcntl.flock(lock, fcntl.LOCK_UN)

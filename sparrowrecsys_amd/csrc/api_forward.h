@@ -156,6 +156,7 @@ int sprk_forward(sprk_handle h, const int32_t* ids, const float* dense, float* o
         // 8-wave workgroup per CU carries the tail's weights: up to ONE round of workgroups (16 rows x 8 waves x CUs = 32 768 rows on an
         // MI355X: BASELINE config 3, and every latency-bound request below it) a wave owns one task; a larger batch goes to the
         // persistent form (a "several batches" launch of one batch: every wave walks its tasks, tables staged once)
+        // (this branch must stay UNCONDITIONAL on din_fused: forward_many hands it the caller's whole workspace, not a per-stream slice)
         if (h->plan.din.enabled == 1 && h->din_fused) {
             if ((long long)((B + 15) / 16) <= (long long)h->num_cus * DF_WAVES) return launch_din_fused(h, ids, dense, out, nullptr, B, nullptr, true, st);
             DinFusedMany fm;
@@ -182,7 +183,7 @@ int sprk_forward(sprk_handle h, const int32_t* ids, const float* dense, float* o
                 for (size_t v = 0; v < sizeof(kV2J1Variants) / sizeof(kV2J1Variants[0]); ++v)
                     if (kV2J1Variants[v].g_big == kV2JVariants[h->v2j_variant].g_big && kV2J1Variants[v].njf == kV2JVariants[h->v2j_variant].njf) {
                         (h->v2j1_hoist ? kV2J1Variants[v].launch_h : kV2J1Variants[v].launch)(jr, ids, dense, out, B, h->dev_err, h->v2j1_image,
-                                                                                                (ntasks + V2J1_WAVES - 1) / V2J1_WAVES, h->v2j1_lds_bytes, st);
+                                                                                                (ntasks + h->v2j1_waves - 1) / h->v2j1_waves, h->v2j1_lds_bytes, st);
                         HIP_TRY(hipGetLastError());
                         return SPRK_OK;
                     }
@@ -225,9 +226,8 @@ int sprk_forward(sprk_handle h, const int32_t* ids, const float* dense, float* o
         int grid = (ntasks + MR_WAVES - 1) / MR_WAVES;
         if (grid > h->num_cus) grid = h->num_cus;                  // one 8-wave workgroup per CU (the LDS holds weights + genre tables)
         MlpRowsRun rr = h->mlp_rows_run;
-        rr.flags = (((uintptr_t)ids | (uintptr_t)dense) & 15) ? 1 : 0;
-        if (h->mlp_rows_nbig == 1) mlp_rows_launch<1>(rr, ids, dense, out, B, h->dev_err, h->mlp_rows_image, grid, h->mlp_rows_lds, st);
-        else mlp_rows_launch<2>(rr, ids, dense, out, B, h->dev_err, h->mlp_rows_image, grid, h->mlp_rows_lds, st);
+        rr.flags = (rr.flags & ~1) | ((((uintptr_t)ids | (uintptr_t)dense) & 15) ? 1 : 0);
+        hipLaunchKernelGGL(h->mlp_rows_kernel, dim3(grid), dim3(MR_WAVES * 64), h->mlp_rows_lds, st, rr, ids, dense, out, B, h->dev_err, (const float*)h->mlp_rows_image);
         HIP_TRY(hipGetLastError());
         return SPRK_OK;
     }
@@ -259,7 +259,8 @@ static int forward_many_impl(sprk_handle h, int32_t n_batches, const int32_t* co
     // a model with a workspace (DIN: attention kernel -> pooled vectors -> tail kernel) needs one workspace slice per
     // stream; with a single slice its forwards stay in strict order
     const size_t ws_need = (sprk_workspace_bytes(h, B) + 255) & ~(size_t)255;
-    if (S >= 2 && ws_need > 0 && !(h->finalized && h->plan.din.enabled == 1 && h->din_fused)) {
+    const bool ws_untouched = h->finalized && h->plan.din.enabled == 1 && h->din_fused;   // (sprk_forward's k_din_fused branch: unconditional, see there)
+    if (S >= 2 && ws_need > 0 && !ws_untouched) {
         while (S >= 2 && (!workspace || workspace_bytes < (size_t)S * ws_need)) --S;
         if (S < 2) S = 0;
     }
@@ -444,9 +445,12 @@ static int forward_many_impl(sprk_handle h, int32_t n_batches, const int32_t* co
         for (int s = 0; s < S; ++s) HIP_TRY(hipStreamWaitEvent(h->many_stream[s], h->many_fork, 0));
     }
     for (int32_t i = 0; i < n_batches; ++i) {
-        void* wsi = (S >= 2 && ws_need > 0) ? (void*)((char*)workspace + (size_t)(i % S) * ws_need) : workspace;
+        // (one workspace slice per stream -- except for the one-launch DIN, whose S was NOT reduced to the slices the buffer holds because
+        //  its forward never touches the buffer: it gets the caller's buffer and size unchanged, never an offset past its end [ADVICE r04])
+        const bool sliced = S >= 2 && ws_need > 0 && !ws_untouched;
+        void* wsi = sliced ? (void*)((char*)workspace + (size_t)(i % S) * ws_need) : workspace;
         const int rc = sprk_forward(h, ids ? ids[i] : nullptr, dense ? dense[i] : nullptr, out[i], B, wsi,
-                                    (S >= 2 && ws_need > 0) ? ws_need : workspace_bytes, S >= 2 ? (void*)h->many_stream[i % S] : stream);
+                                    sliced ? ws_need : workspace_bytes, S >= 2 ? (void*)h->many_stream[i % S] : stream);
         if (rc) return rc;
     }
     if (S >= 2) {
@@ -535,8 +539,11 @@ int sprk_describe(sprk_handle h, char* buf, size_t buf_bytes) {
     if (h->plan.din.enabled == 1 && h->din_fused) snprintf(kern, sizeof(kern), "k_din_fused<KC=%d,tail 128/64>", h->din_cols_kc);
     size_t uploaded = 0;
     for (size_t b : h->slot_bytes) uploaded += b;
-    const int n = snprintf(buf, buf_bytes, "kernel=%s;stage=%s;stage_waves_per_workgroup=%d;fused=%d;uploaded_bytes=%zu;derived_bytes=%zu;first_dense_fold=%d", kern, stage,
-                           h->din_variant >= 0 ? h->din_wpb : 0, strcmp(kern, "k_tile_forward") != 0 ? 1 : 0, uploaded, h->derived_bytes, h->n_acc_folded);
+#ifndef SPRK_BUILD_DEFINES_STR
+#define SPRK_BUILD_DEFINES_STR ""                             // (_lib.build_library passes the experiment defines of SPRK_BUILD_DEFINES; the product build has none)
+#endif
+    const int n = snprintf(buf, buf_bytes, "kernel=%s;stage=%s;stage_waves_per_workgroup=%d;fused=%d;uploaded_bytes=%zu;derived_bytes=%zu;first_dense_fold=%d;build_defines=%s", kern, stage,
+                           h->din_variant >= 0 ? h->din_wpb : 0, strcmp(kern, "k_tile_forward") != 0 ? 1 : 0, uploaded, h->derived_bytes, h->n_acc_folded, SPRK_BUILD_DEFINES_STR);
     if (n < 0 || (size_t)n >= buf_bytes) return fail(SPRK_EINVAL, "describe: buffer of %zu bytes is too small", buf_bytes);
     return SPRK_OK;
 }

@@ -88,23 +88,41 @@ int sprk_vtable_import(sprk_vtable v, int32_t peer_rank, int32_t fd) {
     if (peer_rank < 0 || peer_rank >= v->world || peer_rank == v->rank) return fail(SPRK_EINVAL, "peer rank %d (this is rank %d of %d)", peer_rank, v->rank, v->world);
     if (v->mapped[peer_rank]) return fail(SPRK_ESTATE, "rank %d's rows are mapped already", peer_rank);
     if (fd < 0) return fail(SPRK_EINVAL, "bad file descriptor");
+    const char* form = "pointer";
     {
         // The osHandle argument of hipMemImportFromShareableHandle: CUDA's convention -- and this image's ROCm 7.2 runtime -- is the
         // descriptor's VALUE cast to a pointer; the ROCm 7.0 runtime that PyTorch 2.10 bundles (and that every process which imported
-        // torch therefore runs on) reads the descriptor THROUGH the pointer, and given the value it dereferences address 26.  So the
-        // form is chosen by the runtime's version, with the other form as the fallback only where a wrong guess is an error return
-        // (a pointer's bits taken as a descriptor: EBADF), never a wild read.
+        // torch therefore runs on) reads the descriptor THROUGH the pointer, and given the value it dereferences address 26.
+        // [r5, ADVICE r04] The SAFE form goes first on every runtime: a pointer's bits taken as a descriptor are an error return (EBADF),
+        // never a wild read.  The value form is tried only after that error, and only on a runtime (>= 7.2) known to take it.
         int ver = 0;
         (void)hipRuntimeGetVersion(&ver);
         int fdv = fd;
-        hipError_t e;
-        if (ver >= 70200000) {
+        hipError_t e = hipMemImportFromShareableHandle(&v->handle[peer_rank], &fdv, hipMemHandleTypePosixFileDescriptor);
+        if (e != hipSuccess && ver >= 70200000) {
+            (void)hipGetLastError();
+            form = "value";
             e = hipMemImportFromShareableHandle(&v->handle[peer_rank], (void*)(uintptr_t)fd, hipMemHandleTypePosixFileDescriptor);
-            if (e != hipSuccess) { (void)hipGetLastError(); e = hipMemImportFromShareableHandle(&v->handle[peer_rank], &fdv, hipMemHandleTypePosixFileDescriptor); }
-        } else {
-            e = hipMemImportFromShareableHandle(&v->handle[peer_rank], &fdv, hipMemHandleTypePosixFileDescriptor);
         }
-        if (e != hipSuccess) return fail(SPRK_EHIP, "hipMemImportFromShareableHandle (rank %d's rows, HIP runtime %d) failed: %s", peer_rank, ver, hipGetErrorString(e));
+        if (e != hipSuccess) return fail(SPRK_EHIP, "hipMemImportFromShareableHandle (rank %d's rows, HIP runtime %d, last form tried: descriptor by %s) failed: %s", peer_rank, ver, form, hipGetErrorString(e));
+    }
+    {
+        // [r5] Whose memory is it?  A shard that lives on ANOTHER device is only usable if this device can load through the link: say so
+        // here, with both device numbers, instead of faulting at the first gather.  (SPRK_TEST_VTABLE_PEER_DENY=1 makes the one-GPU test
+        // suite walk this exit.)
+        hipMemAllocationProp pp = {};
+        int owner = v->device;
+        if (hipMemGetAllocationPropertiesFromHandle(&pp, v->handle[peer_rank]) == hipSuccess && pp.location.type == hipMemLocationTypeDevice) owner = pp.location.id;
+        else (void)hipGetLastError();
+        int can = 1;
+        if (owner != v->device && hipDeviceCanAccessPeer(&can, v->device, owner) != hipSuccess) { (void)hipGetLastError(); can = 0; }
+        const char* deny = getenv("SPRK_TEST_VTABLE_PEER_DENY");
+        if (deny && deny[0] == '1') can = 0;
+        if (!can) {
+            (void)hipMemRelease(v->handle[peer_rank]);
+            return fail(SPRK_EHIP, "rank %d's rows live on device %d, which device %d cannot access as a peer (no xGMI / PCIe peer path): "
+                                   "the row-sharded table needs peer access between every pair of ranks", peer_rank, owner, v->device);
+        }
     }
     char* at = (char*)v->base + (size_t)peer_rank * v->shard_bytes;
     hipError_t e = hipMemMap(at, v->shard_bytes, 0, v->handle[peer_rank], 0);
@@ -114,7 +132,11 @@ int sprk_vtable_import(sprk_vtable v, int32_t peer_rank, int32_t fd) {
     acc.location.type = hipMemLocationTypeDevice;
     acc.location.id = v->device;
     acc.flags = hipMemAccessFlagsProtReadWrite;
-    HIP_TRY(hipMemSetAccess(at, v->shard_bytes, &acc, 1));
+    e = hipMemSetAccess(at, v->shard_bytes, &acc, 1);
+    if (e != hipSuccess) {
+        (void)hipMemUnmap(at, v->shard_bytes); (void)hipMemRelease(v->handle[peer_rank]); v->mapped[peer_rank] = 0;
+        return fail(SPRK_EHIP, "hipMemSetAccess (rank %d's rows for device %d; descriptor imported by %s) failed: %s", peer_rank, v->device, form, hipGetErrorString(e));
+    }
     return SPRK_OK;
 }
 

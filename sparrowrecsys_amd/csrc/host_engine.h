@@ -34,6 +34,7 @@ struct sprk_engine {
     // in LDS (k_mlp_rows); -1 = the tile interpreter
     int mlp_rows_nbig = -1;
     MlpRowsRun mlp_rows_run;
+    void (*mlp_rows_kernel)(const MlpRowsRun, const int*, const float*, float*, int, int*, const float*) = nullptr;
     float* mlp_rows_image = nullptr;
     float* mlp_rows_small = nullptr;
     size_t mlp_rows_lds = 0;
@@ -84,6 +85,7 @@ struct sprk_engine {
     float* v2j1_image = nullptr;          // k_deepfm_v2_joint1 (one task per wave): its LDS image; NULL = shape not available
     size_t v2j1_lds_bytes = 0;
     bool v2j1_hoist = false;              // k_deepfm_v2_joint1<..., HOIST>: tables larger than the Infinity Cache (k_chain_v2j1.h)
+    int v2j1_waves = 8;                   // waves per workgroup of the form chosen (V2J1_WAVES_OF)
     int many_batches = 1;                 // sprk_forward_many: batches scored per launch (sprk_set_many_batches)
     // "one row per id" chain (k_rows_chain): DeepFM_v2 with projections wider than 16 (the reference's Dense(64)) and NeuralCF
     int rows_variant = -1;

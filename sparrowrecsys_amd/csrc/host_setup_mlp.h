@@ -1,28 +1,18 @@
 // host_setup_mlp.h -- EmbeddingMLP / Wide&Deep: k_mlp_rows set-up.
 // Part of sparrow_hip.hip (one translation unit); included there, not compilable on its own.
-// ---- k_mlp_rows<8, 8, NBIG, WAVES, DYN> ----
+// ---- k_mlp_rows<8, 8, NBIG, NS, WAVES, DYN, WK> ----
 constexpr int MR_WAVES = 8;
-template <int NBIG, int WK>
-void mlp_rows_launch_wk(const MlpRowsRun& a, const int* ids, const float* dense, float* out, int B, int* err, const float* image, int grid,
-                        size_t lds, hipStream_t st) {
-    if (a.inv_w1_scale != 0.f)
-        hipLaunchKernelGGL((k_mlp_rows<8, 8, NBIG, MR_WAVES, true, WK>), dim3(grid), dim3(MR_WAVES * 64), lds, st, a, ids, dense, out, B, err, image);
-    else
-        hipLaunchKernelGGL((k_mlp_rows<8, 8, NBIG, MR_WAVES, false, WK>), dim3(grid), dim3(MR_WAVES * 64), lds, st, a, ids, dense, out, B, err, image);
+typedef void (*MlpRowsKernel)(const MlpRowsRun, const int*, const float*, float*, int, int*, const float*);
+// NS = 8 (EmbeddingMLP.py / WideNDeep.py as written: eight genre columns) has its own instantiations for the reference's shape
+// (two big columns, split-f16 second layer); every other shape runs the generic ones (NS = -1: the count is a run-time value).
+template <int NBIG, int NS, bool DYN>
+MlpRowsKernel mlp_rows_kernel_wk(int wk) {
+    return wk == 1 ? &k_mlp_rows<8, 8, NBIG, NS, MR_WAVES, DYN, 1> : wk == 2 ? &k_mlp_rows<8, 8, NBIG, NS, MR_WAVES, DYN, 2> : &k_mlp_rows<8, 8, NBIG, NS, MR_WAVES, DYN, 0>;
 }
-template <int NBIG>
-void mlp_rows_launch(const MlpRowsRun& a, const int* ids, const float* dense, float* out, int B, int* err, const float* image, int grid,
-                     size_t lds, hipStream_t st) {
-    if (a.wide_kind == 1) mlp_rows_launch_wk<NBIG, 1>(a, ids, dense, out, B, err, image, grid, lds, st);
-    else if (a.wide_kind == 2) mlp_rows_launch_wk<NBIG, 2>(a, ids, dense, out, B, err, image, grid, lds, st);
-    else mlp_rows_launch_wk<NBIG, 0>(a, ids, dense, out, B, err, image, grid, lds, st);
-}
-template <int NBIG>
-int mlp_rows_attr(size_t lds) {
-#define MR_ATTR(DYN, WK) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mlp_rows<8, 8, NBIG, MR_WAVES, DYN, WK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    MR_ATTR(true, 0) MR_ATTR(true, 1) MR_ATTR(true, 2) MR_ATTR(false, 0) MR_ATTR(false, 1) MR_ATTR(false, 2)
-#undef MR_ATTR
-    return SPRK_OK;
+MlpRowsKernel mlp_rows_kernel(int nbig, int nsmall, bool dyn, int wk) {
+    if (nbig == 2 && nsmall == 8 && dyn) return mlp_rows_kernel_wk<2, 8, true>(wk);
+    if (nbig == 2) return dyn ? mlp_rows_kernel_wk<2, -1, true>(wk) : mlp_rows_kernel_wk<2, -1, false>(wk);
+    return dyn ? mlp_rows_kernel_wk<1, -1, true>(wk) : mlp_rows_kernel_wk<1, -1, false>(wk);
 }
 // Recognise an EmbeddingMLP / Wide&Deep plan (EmbeddingMLP.py:72-77, WideNDeep.py:99-107) with ReLU layers of 128 and fold
 // EVERY embedding column through the first Dense layer (see k_mlp_rows.h).  Leaves mlp_rows_nbig = -1 for any other shape.
@@ -36,7 +26,6 @@ int setup_mlp_rows(sprk_engine* h) {
     if (o0.kind != SPRK_OP_DENSE || o1.kind != SPRK_OP_DENSE || o0.act != SPRK_ACT_RELU || o1.act != SPRK_ACT_RELU) return SPRK_OK;
     if (o0.src_buf != 0 || o0.dst_buf == 0 || o0.dst_off != 0 || o1.src_buf != o0.dst_buf || o1.src_off != 0 || o1.K != o0.N ||
         o1.dst_off != 0 || o0.N != 128 || o1.N != 128) return SPRK_OK;
-    typedef MlpRowsLds<8, 8> LD;
     const int lo = o0.src_off, hi = o0.src_off + o0.K, N0 = 128;
     MlpRowsRun r;
     memset(&r, 0, sizeof(r));
@@ -51,7 +40,7 @@ int setup_mlp_rows(sprk_engine* h) {
             if ((long long)sg.vocab <= 31 && r.n_small < MR_MAX_SMALL) small_seg[r.n_small++] = &sg;
             else if (r.n_big < MR_MAX_BIG) big_seg[r.n_big++] = &sg;
             else return SPRK_OK;
-            if ((size_t)sg.vocab * N0 * sizeof(float) > ((size_t)8 << 30)) return SPRK_OK;
+            if (((size_t)sg.vocab + 1) * N0 * sizeof(float) >= ((size_t)4 << 30)) return SPRK_OK;      // (32-bit byte offsets into a folded table)
         } else if (sg.kind == SPRK_SEG_DENSE) {
             if (num_dst >= 0 || sg.field != 0 || sg.count > 8 || sg.dst < lo || sg.dst + sg.count > hi) return SPRK_OK;
             num_dst = sg.dst; r.n_num = sg.count;
@@ -80,15 +69,28 @@ int setup_mlp_rows(sprk_engine* h) {
             if (twide->len != 1 || twide->w_slot >= 0) return SPRK_OK;
             r.wide_kind = 2;
         }
-        r.wide_a = cross->field; r.wide_b = cross->field2; r.wide_buckets = cross->vocab; r.wide_tab = (const float*)h->slot_ptr[cross->slot];
+        r.wide_a = cross->field; r.wide_b = cross->field2; r.wide_buckets = cross->vocab;
+        r.wide_magic = (cross->vocab > 0 && (long long)cross->vocab < (1ll << 30)) ? ~0ULL / (unsigned long long)cross->vocab : 0ULL;
+        r.wide_tab = (const float*)h->slot_ptr[cross->slot];
     }
-    // LDS: fixed image + small tables (+ one shared zero row) + a staging slot per wave
+    // the second layer's form first: the LDS image's size depends on it (split-f16 fragments: 64 KB; W1^T in f32: 66 KB)
+    float* w1frag = nullptr;
+    {
+        float w_scale = 0.f;
+        const int rc2 = make_dyn_fragments(h, (const float*)h->slot_ptr[o1.w_slot], o1.ldw, o1.N, o1.K, &w1frag, &w_scale);
+        if (rc2) return rc2;
+        r.inv_w1_scale = w1frag ? 1.0f / w_scale : 0.f;
+    }
+    const bool dyn = w1frag != nullptr;
+    const int image_lds = dyn ? MlpRowsLds<8, 8, true>::total_pad : MlpRowsLds<8, 8, false>::total_pad;
+    const int image_floats = dyn ? MlpRowsLds<8, 8, true>::image_floats : MlpRowsLds<8, 8, false>::image_floats;
+    // LDS: fixed image + small tables (rows MR_RS floats apart, + one shared zero row) + a staging slot per wave
     size_t small_floats = 0;
-    for (int f = 0; f < r.n_small; ++f) { r.s_off[f] = (int)small_floats; small_floats += (size_t)small_seg[f]->vocab * N0; }
+    for (int f = 0; f < r.n_small; ++f) { r.s_off[f] = (int)small_floats; small_floats += (size_t)small_seg[f]->vocab * MR_RS; }
     r.zero_off = (int)small_floats;
-    small_floats += N0;
+    small_floats += MR_RS;
     small_floats = (small_floats + 255) & ~(size_t)255;
-    const size_t lds = ((size_t)LD::total_pad + small_floats + (size_t)MR_WAVES * MR_STAGE) * sizeof(float);
+    const size_t lds = ((size_t)image_lds + small_floats + (size_t)MR_WAVES * MR_STAGE) * sizeof(float);
     if (lds > 160 * 1024) return SPRK_OK;
     const float* W0 = (const float*)h->slot_ptr[o0.w_slot];
     HIP_TRY(hipMalloc((void**)&h->mlp_rows_small, small_floats * sizeof(float)));
@@ -100,15 +102,13 @@ int setup_mlp_rows(sprk_engine* h) {
                            sg.row_stride, 4 * sg.count, W0, o0.ldw, sg.dst - lo, N0, F);
     };
     {
-        // small columns: fold into a scratch buffer, then into the XOR-swizzled LDS layout (k_mlp_rows.h); s_off must keep the
-        // low 7 bits of a row's float offset free for the swizzle
+        // small columns: fold into a scratch buffer, then into the padded LDS layout (k_mlp_rows.h)
         float* tmp = nullptr;
         HIP_TRY(hipMalloc((void**)&tmp, (size_t)32 * N0 * sizeof(float)));
         for (int f = 0; f < r.n_small; ++f) {
             r.s_col[f] = small_seg[f]->field; r.s_vocab[f] = small_seg[f]->vocab;
-            if (r.s_off[f] & 127) { (void)hipFree(tmp); return fail(SPRK_EINVAL, "small-table offset not a multiple of 128 floats"); }
             fold(*small_seg[f], tmp);
-            hipLaunchKernelGGL(k_mlp_rows_swizzle, dim3(4), dim3(256), 0, 0, tmp, h->mlp_rows_small + r.s_off[f], small_seg[f]->vocab);
+            hipLaunchKernelGGL(k_mlp_rows_pad, dim3(4), dim3(256), 0, 0, tmp, h->mlp_rows_small + r.s_off[f], small_seg[f]->vocab);
         }
         HIP_TRY(hipDeviceSynchronize());
         (void)hipFree(tmp);
@@ -125,28 +125,24 @@ int setup_mlp_rows(sprk_engine* h) {
         r.big_col[b] = sg.field; r.big_vocab[b] = sg.vocab; r.big_tab[b] = F;
     }
     HIP_TRY(hipGetLastError());
-    float* w1frag = nullptr;
-    {
-        float w_scale = 0.f;
-        const int rc2 = make_dyn_fragments(h, (const float*)h->slot_ptr[o1.w_slot], o1.ldw, o1.N, o1.K, &w1frag, &w_scale);
-        if (rc2) return rc2;
-        r.inv_w1_scale = w1frag ? 1.0f / w_scale : 0.f;
-    }
-    HIP_TRY(hipMalloc((void**)&h->mlp_rows_image, (size_t)LD::total_pad * sizeof(float)));
-    hipLaunchKernelGGL((k_mlp_rows_pack<8, 8>), dim3(1), dim3(256), 0, 0, W0, o0.ldw, num_dst - lo, r.n_num, (const float*)h->slot_ptr[o0.b_slot],
-                       (const float*)h->slot_ptr[o1.w_slot], o1.ldw, (const float*)h->slot_ptr[o1.b_slot],
-                       (const float*)h->slot_ptr[tdeep->w_slot], tdeep->len, w1frag, h->mlp_rows_image);
+    HIP_TRY(hipMalloc((void**)&h->mlp_rows_image, (size_t)image_floats * sizeof(float)));
+    if (dyn)
+        hipLaunchKernelGGL((k_mlp_rows_pack<8, 8, true>), dim3(1), dim3(256), 0, 0, W0, o0.ldw, num_dst - lo, r.n_num, (const float*)h->slot_ptr[o0.b_slot],
+                           (const float*)h->slot_ptr[o1.w_slot], o1.ldw, (const float*)h->slot_ptr[o1.b_slot],
+                           (const float*)h->slot_ptr[tdeep->w_slot], tdeep->len, w1frag, h->mlp_rows_image);
+    else
+        hipLaunchKernelGGL((k_mlp_rows_pack<8, 8, false>), dim3(1), dim3(256), 0, 0, W0, o0.ldw, num_dst - lo, r.n_num, (const float*)h->slot_ptr[o0.b_slot],
+                           (const float*)h->slot_ptr[o1.w_slot], o1.ldw, (const float*)h->slot_ptr[o1.b_slot],
+                           (const float*)h->slot_ptr[tdeep->w_slot], tdeep->len, w1frag, h->mlp_rows_image);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
     r.F = p.n_id_cols; r.ND = p.n_dense; r.head_bias = p.head_bias;
     r.small = h->mlp_rows_small; r.small_floats = (int)small_floats;
-    int rc;
-    if (r.n_big == 1) rc = mlp_rows_attr<1>(lds);
-    else rc = mlp_rows_attr<2>(lds);
-    if (rc) return rc;
+    if (r.n_num < 8) r.flags |= 2;                                       // b0 in the numerics' eighth K slot (k_mlp_rows_pack put it there)
+    h->mlp_rows_kernel = mlp_rows_kernel(r.n_big, r.n_small, dyn, r.wide_kind);
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(h->mlp_rows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     h->mlp_rows_run = r;
     h->mlp_rows_lds = lds;
     h->mlp_rows_nbig = r.n_big;
     return SPRK_OK;
 }
-

@@ -97,10 +97,16 @@ __device__ __forceinline__ f32x4 relu4(f32x4 v) {
     return f32x4{fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f)};
 }
 
-// single-instruction ReLU: v_med3_f32(v, 0, +inf) (fmaxf() first canonicalises its operand with a second
-// v_max; an inline-asm v_max would hide the VALU-write -> MFMA-read hazard from the compiler)
+// single-instruction ReLU: v_med3_f32(v, 0, BIG) (fmaxf() first canonicalises an operand it cannot prove quiet -- an MFMA result, a
+// loaded value -- with a second v_max; an inline-asm v_max would hide the VALU-write -> MFMA-read hazard from the compiler).
+// [r5] BIG is FINITE: hipcc 7.2 folds fmed3(v, 0, +inf) back into fmaxf(v, 0), canonicalisation included (build/sparrow.s: two v_max
+// per element behind every MFMA); med3 against 3e38 stays one v_med3_f32 and is the same function for every finite v <= 3e38.
+#define SPRK_RELU_BIG 3.0e38f
 __device__ __forceinline__ float relu1_fast(float v) {
-    return __builtin_amdgcn_fmed3f(v, 0.f, __builtin_inff());
+    return __builtin_amdgcn_fmed3f(v, 0.f, SPRK_RELU_BIG);
+}
+__device__ __forceinline__ float neg1_fast(float v) {                    // min(v, 0), one instruction, same reasoning
+    return __builtin_amdgcn_fmed3f(v, -SPRK_RELU_BIG, 0.f);
 }
 __device__ __forceinline__ f32x4 relu4_fast(f32x4 v) {
     return f32x4{relu1_fast(v.x), relu1_fast(v.y), relu1_fast(v.z), relu1_fast(v.w)};

@@ -19,17 +19,38 @@
 // Used by sprk_forward / one-batch launches with ceil(B / 16) <= V2J1_MAX_TASKS; larger batches and the several-batches-
 // per-launch form stay on the looped kernel (one image staging per workgroup is only worth 8 tasks when there are few).
 
+// Waves per workgroup.  r03 (barrier behind the gathers): 4 / 8 / 16 waves 7.93 / 7.65 / 8.41 us; r04 (barrier in front): 7.57 / 7.25 / 7.19;
+// [r5] with the leaner image sixteen win wherever the rows come out of the caches -- config 2 6.88-6.95 against 6.97-6.99 us, config 4
+// 5.90 against 6.09 (profiles/r05/experiments/r05_02): one image staging per CU instead of two -- and lose where they come from HBM
+// (9.03 against 8.70-8.78 us on one box, r05_03): the HOIST form keeps eight.
 #ifndef V2J1_WAVES
-#define V2J1_WAVES 8                         // (4: 7.93 us, 16: 8.41 us against 7.65 us -- scripts/r03/10_joint1_waves16.sh; [r4] again with the barrier in front of the gathers: scripts/r04/36_*)
+#define V2J1_WAVES 16
+#endif
+#ifndef V2J1_WAVES_HOIST
+#define V2J1_WAVES_HOIST 8
+#endif
+#define V2J1_WAVES_OF(HOIST) ((HOIST) ? V2J1_WAVES_HOIST : V2J1_WAVES)
+#ifndef V2J1_DEDUP
+#define V2J1_DEDUP 1                         // [r5] A fragments stored ONCE per (field, n-block) as {hi4 | lo4}: one ds_read_b128 where there were two, the selection fragment built in registers
+#endif
+#ifndef V2J1_ZZ_LATE
+#define V2J1_ZZ_LATE 1                       // [r5] the rows' first-order scalar is consumed BEHIND the row fence (it is the last load issued: see phase A); not in the HOIST form
 #endif
 #define V2J1_MAX_TASKS 16384                 // B <= 262 144: beyond, the looped kernel amortises the image staging better
 
 template <int G_BIG>
 struct V2J1Lds {
+#if V2J1_DEDUP
+    static constexpr int off_frag = 0;                              // [G_BIG][2 n-blocks] A fragments {hi4 | lo4} per lane, 256 floats (1 KB) each
+    static constexpr int off_sel = off_frag + G_BIG * 2 * 256;      // (no selection fragment in the image: built in registers)
+    static constexpr int S1 = 36;
+    static constexpr int off_w1 = off_sel;                          // deep1 W^T [16][S1]
+#else
     static constexpr int off_frag = 0;                              // [G_BIG][2 n-blocks][hi, lo] A fragments, 256 floats (1 KB) each
     static constexpr int off_sel = off_frag + G_BIG * 4 * 256;      // the 0/1 selection fragment (FM sum of hi + lo)
     static constexpr int S1 = 36;
     static constexpr int off_w1 = off_sel + 256;                    // deep1 W^T [16][S1]
+#endif
     static constexpr int off_b1 = off_w1 + 16 * S1;                 // [16]
     static constexpr int off_hd = off_b1 + 16;                      // [16] head weights on deep1's output
     static constexpr int off_bpn = off_hd + 16;                     // [16] numeric projection bias
@@ -45,7 +66,12 @@ struct V2J1Lds {
 // v2j_body's load_weights() builds with split_half4 at every launch.
 __global__ __launch_bounds__(256) void k_v2j1_pack_image(const V2Args A, const V2JRun R, int g_big, int G, float* __restrict__ img) {
     const int tid = threadIdx.x;
-    const int off_sel = g_big * 4 * 256, off_w1 = off_sel + 256, off_b1 = off_w1 + 16 * 36, off_hd = off_b1 + 16, off_bpn = off_hd + 16,
+#if V2J1_DEDUP
+    const int off_sel = g_big * 2 * 256, off_w1 = off_sel;
+#else
+    const int off_sel = g_big * 4 * 256, off_w1 = off_sel + 256;
+#endif
+    const int off_b1 = off_w1 + 16 * 36, off_hd = off_b1 + 16, off_bpn = off_hd + 16,
               off_hfm = off_bpn + 16, off_wn8 = off_hfm + 16, off_fn8 = off_wn8 + 128, total_pad = (off_fn8 + 8 + 255) & ~255;
     for (int i = tid; i < total_pad; i += 256) img[i] = 0.f;
     __syncthreads();
@@ -55,6 +81,10 @@ __global__ __launch_bounds__(256) void k_v2j1_pack_image(const V2Args A, const V
         const f32x4 w = ld4(A.W0 + (size_t)(n0 * 16 + r) * (G * 16) + 16 * R.big_grp[b] + 4 * q);
         f16x4 hi, lo;
         split_half4(w, R.w_scale, hi, lo);
+#if V2J1_DEDUP
+        frag[(b * 2 + n0) * 64 + l] = f16x8{hi[0], hi[1], hi[2], hi[3], lo[0], lo[1], lo[2], lo[3]};
+    }
+#else
         frag[((b * 2 + n0) * 2 + 0) * 64 + l] = f16x8{hi[0], hi[1], hi[2], hi[3], hi[0], hi[1], hi[2], hi[3]};
         frag[((b * 2 + n0) * 2 + 1) * 64 + l] = f16x8{lo[0], lo[1], lo[2], lo[3], lo[0], lo[1], lo[2], lo[3]};
     }
@@ -65,6 +95,7 @@ __global__ __launch_bounds__(256) void k_v2j1_pack_image(const V2Args A, const V
         for (int e = 0; e < 8; ++e) s[e] = (4 * q + (e & 3) == r) ? (_Float16)1.0f : (_Float16)0.0f;
         reinterpret_cast<f16x8*>(img + off_sel)[tid] = s;
     }
+#endif
     for (int i = tid; i < 16 * 32; i += 256) img[off_w1 + (i >> 5) * 36 + (i & 31)] = A.W1[i];      // deep1 W^T [16][32]
     if (tid < 16) {
         img[off_b1 + tid] = A.b1[tid];
@@ -94,12 +125,12 @@ __device__ unsigned long long g_v2j1_ts[V2J1_TS_WAVES * 8];
 // from HBM the texture path backs up longer and the LDS sits idle meanwhile: 8.9 -> 8.68 us; with cache-resident tables the same
 // move only delays the gathers: 7.26 -> 7.38 us (profiles/r04/experiments/r04_34).  Same arithmetic, same bits.
 template <int G_BIG, int NJF, bool HOIST = false>
-__global__ __launch_bounds__(V2J1_WAVES * 64, 4) void k_deepfm_v2_joint1(const V2JRun A, const int* __restrict__ ids,
+__global__ __launch_bounds__(V2J1_WAVES_OF(HOIST) * 64, 4) void k_deepfm_v2_joint1(const V2JRun A, const int* __restrict__ ids,
                                                                        const float* __restrict__ dense, float* __restrict__ out, int B,
                                                                        int* __restrict__ err, const float* __restrict__ image) {
 #pragma clang fp contract(off)                                          // (pinned: see fma4s / dot4f in k_chain_v2j.h)
     using LD = V2J1Lds<G_BIG>;
-    constexpr int WAVES = V2J1_WAVES, KP = 16, H0C = 2;
+    constexpr int WAVES = V2J1_WAVES_OF(HOIST), KP = 16, H0C = 2;
     constexpr unsigned RB = (KP + 16) * 4;
     static_assert(G_BIG >= 1 && G_BIG <= 3 && NJF >= 1 && NJF <= V2J_MAX_JF, "field split");
     const int tid = threadIdx.x;
@@ -143,6 +174,33 @@ __global__ __launch_bounds__(V2J1_WAVES * 64, 4) void k_deepfm_v2_joint1(const V
     __builtin_amdgcn_s_barrier();
     if (!work) return;
     f16x8 wa[G_BIG][H0C], wb[G_BIG][H0C], hSel;
+#if V2J1_DEDUP
+    // one 16-byte read per (field, n-block): {hi4 | lo4}; the MFMA's A operand {h, h} is the same four halfs twice -- two register
+    // copies (expand_frags) instead of a second kilobyte out of LDS.  The selection fragment is a constant of the lane: 1.0 at
+    // k = r - 4q.
+    f16x8 wt[G_BIG][H0C];
+    auto read_frags = [&]() {
+        const f16x8* frag = reinterpret_cast<const f16x8*>(smem + LD::off_frag) + lane;
+#pragma unroll
+        for (int b = 0; b < G_BIG; ++b)
+#pragma unroll
+            for (int n0 = 0; n0 < H0C; ++n0) wt[b][n0] = frag[(b * 2 + n0) * 64];
+    };
+    auto expand_frags = [&]() {
+#pragma unroll
+        for (int b = 0; b < G_BIG; ++b)
+#pragma unroll
+            for (int n0 = 0; n0 < H0C; ++n0) {
+                const f16x8 t = wt[b][n0];
+                wa[b][n0] = f16x8{t[0], t[1], t[2], t[3], t[0], t[1], t[2], t[3]};
+                wb[b][n0] = f16x8{t[4], t[5], t[6], t[7], t[4], t[5], t[6], t[7]};
+            }
+        const int d = r - 4 * q;
+        const unsigned lo01 = d == 0 ? 0x00003C00u : d == 1 ? 0x3C000000u : 0u, lo23 = d == 2 ? 0x00003C00u : d == 3 ? 0x3C000000u : 0u;
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        hSel = __builtin_bit_cast(f16x8, u32x4{lo01, lo23, lo01, lo23});
+    };
+#else
     auto read_frags = [&]() {
         const f16x8* frag = reinterpret_cast<const f16x8*>(smem + LD::off_frag) + lane;
 #pragma unroll
@@ -151,8 +209,11 @@ __global__ __launch_bounds__(V2J1_WAVES * 64, 4) void k_deepfm_v2_joint1(const V
             for (int n0 = 0; n0 < H0C; ++n0) { wa[b][n0] = frag[((b * 2 + n0) * 2 + 0) * 64]; wb[b][n0] = frag[((b * 2 + n0) * 2 + 1) * 64]; }
         hSel = reinterpret_cast<const f16x8*>(smem + LD::off_sel)[lane];
     };
+    auto expand_frags = [&]() {};
+#endif
     if constexpr (HOIST) {
         read_frags();
+        expand_frags();                                               // (with its LDS wait: measured equal to round 4's two-reads form, 8.61 against 8.58-8.60 us, r05_01)
         __builtin_amdgcn_sched_barrier(0);
     }
     // ---- gather: ids through the wave-private LDS slot to the (r,q) lanes, then every row of the task ----
@@ -230,7 +291,7 @@ __global__ __launch_bounds__(V2J1_WAVES * 64, 4) void k_deepfm_v2_joint1(const V
         for (int n0 = 0; n0 < H0C; ++n0) sq[n0] += ld4(small_s + so[f] + KP + 16 * n0 + 4 * q);
         ssc += small_s[so[f] + KP + 32];
     }
-    if constexpr (!HOIST) read_frags();
+    if constexpr (!HOIST) { read_frags(); expand_frags(); }
     float rwf[H0C][2];
     {
         const float* wf = small_s + A.wf_off + r * 8 + q;
@@ -247,8 +308,20 @@ __global__ __launch_bounds__(V2J1_WAVES * 64, 4) void k_deepfm_v2_joint1(const V
         const f32x4 o = __builtin_amdgcn_mfma_f32_16x16x4f32(rwn8b, xn1, zero, 0, 0, 0);
         pn = e + o;
     }
-    float zz = ((q < G_BIG) ? w1a : 0.f) + __builtin_fmaf(rfn8b, xn1, rfn8a * xn0);
-    zz += (q == 3) ? ssc : 0.f;
+    // (zz = ((q < G_BIG ? w1a : 0) + fma(...)) + (q == 3 ? ssc : 0): w1a is the LAST load the wave issued -- formed here, hipcc's
+    //  vmcnt(0) for it landed behind the first numerics MFMA, i.e. five f32 MFMAs and ten LDS reads of this phase ran only AFTER every
+    //  row had arrived (build/sparrow.s, round 5).  The numerics' share is formed here, the scalar joins it behind the fence: same
+    //  operands, same order of the two additions.)
+    //  With HBM-resident tables (HOIST) the early wait is KEPT: measured 8.58-8.70 us with it, 8.65-8.87 without (r05_01, r05_02) -- there the
+    //  rows are what everything waits for, and six f32 MFMAs issued in front of that wait hold up the VALU the SIMD's other waves need
+    //  to get THEIR gathers out.)
+    constexpr bool ZZ_LATE = V2J1_ZZ_LATE && !HOIST;
+    const float zz_num = __builtin_fmaf(rfn8b, xn1, rfn8a * xn0);
+    float zz = 0.f;
+    if constexpr (!ZZ_LATE) {
+        zz = ((q < G_BIG) ? w1a : 0.f) + zz_num;
+        zz += (q == 3) ? ssc : 0.f;
+    }
     f32x4 hA[H0C], hB[H0C];
 #pragma unroll
     for (int n0 = 0; n0 < H0C; ++n0) hA[n0] = sq[n0];
@@ -299,6 +372,10 @@ __global__ __launch_bounds__(V2J1_WAVES * 64, 4) void k_deepfm_v2_joint1(const V
             o = __builtin_amdgcn_mfma_f32_16x16x4f32(rW1[j].w, h0[j].w, o, 0, 0, 0);
         }
         z += dot4f(rhd, relu4_fast(e + o));
+    }
+    if constexpr (ZZ_LATE) {
+        zz = ((q < G_BIG) ? w1a : 0.f) + zz_num;
+        zz += (q == 3) ? ssc : 0.f;
     }
     z += zz;
     z += __shfl_xor(z, 16);

@@ -796,7 +796,7 @@ __global__ __launch_bounds__(DF_WAVES * 64, 2) void k_din_fused(const DinFusedRu
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const float uu = z0[nb][j];
-                z0[nb][j] = fmaf(al[j], fminf(uu, 0.f), fmaxf(uu, 0.f));
+                z0[nb][j] = fmaf(al[j], neg1_fast(uu), relu1_fast(uu));
             }
         }
         // fc1 on split f16 (dyn_split.h's K-block layout: chunks 2b, 2b + 1 of h1 are block b's operand as they sit in the registers)
@@ -841,7 +841,7 @@ __global__ __launch_bounds__(DF_WAVES * 64, 2) void k_din_fused(const DinFusedRu
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const float uu = z1[n1][j];
-                const float h2 = fmaf(al[j], fminf(uu, 0.f), fmaxf(uu, 0.f));
+                const float h2 = fmaf(al[j], neg1_fast(uu), relu1_fast(uu));
                 z = fmaf(hw[j], h2, z);
             }
         }

@@ -8,11 +8,12 @@
 // the first layer on f32 MFMA: 160 instructions of 32 cycles, i.e. 5 120 matrix-pipe cycles per task before the second layer
 // even starts (the f32-input MFMA runs at 1/16 of the f16 rate on gfx950), gathers issued per task, not a task ahead.  101 us
 // per 131 072 samples, 24 % of the HBM roofline.  Here:
-//   * the genre tables live in LDS (8 x 19 x 512 B = 76 KB; a shared all-zero row serves "no id"): no cache traffic at all.
-//     Rows are 512 B = two full bank rows, so sixteen lanes reading the same 16-byte piece of sixteen DIFFERENT rows would be a
-//     16-way bank conflict (first version: SQ_LDS_BANK_CONFLICT = 11 x SQ_INSTS_LDS, profiles/r02); the image is therefore
-//     XOR-swizzled: piece p of row i sits at slot p ^ (i & 15), and a lane reads slot (16 nb + 4 q) ^ 4 (i & 15) -- distinct
-//     ids land in distinct banks, equal ids broadcast;
+//   * the genre tables live in LDS (8 x 19 rows + a shared all-zero row for "no id"): no cache traffic at all.  A row is 128 floats;
+//     rows 512 B apart would put the same 16-byte piece of sixteen DIFFERENT rows into the same banks (first version: a 16-way
+//     conflict, SQ_LDS_BANK_CONFLICT = 11 x SQ_INSTS_LDS, profiles/r02).  Rounds 2-4 XOR-swizzled the pieces inside a row; [r5] rows
+//     are 528 B apart instead (MR_RS = 132 floats): piece p of row i starts at 16 (33 i + p) bytes, so sixteen different rows land
+//     in sixteen different bank groups just the same, AND a lane's eight pieces are base + 64 nb bytes -- constants that fold into
+//     ds_read_b128's offset field, where the swizzle cost 7 v_xor + 8 v_lshl_add per column and task (build/sparrow.s);
 //   * movieId / userId are folded as well: their F rows (512 B per id) are gathered from HBM / Infinity Cache straight into the
 //     first layer's accumulators (C/D layout: lane (r,q) holds outputs 16 nb + 4q .. +3 of sample r) -- 1 KB per sample instead
 //     of 2 x 128 B, bought back many times over by the 144 f32 MFMAs it removes; total gathered bytes stay BELOW the reference's
@@ -28,6 +29,10 @@
 #define MR_MAX_BIG 3
 #define MR_MAX_SMALL 8
 #define MR_STAGE 320                      // floats per wave: ids [16][F <= 12] + numerics [16][<= 8]
+#define MR_RS 132                         // floats between two LDS rows of a small column (128 + 4: see the header)
+#ifndef MR_XP
+#define MR_XP 0                           // ablation builds (scripts/r05): 1 no small-column reads, 2 one weight fragment pair for the whole second layer,
+#endif                                    // 4 big rows not loaded, 8 no wide part, 16 no second-layer MFMAs -- WRONG RESULTS, timing only
 
 struct MlpRowsRun {
     int F, ND, n_num;
@@ -35,52 +40,65 @@ struct MlpRowsRun {
     int big_col[MR_MAX_BIG], big_vocab[MR_MAX_BIG];
     const float* big_tab[MR_MAX_BIG];     // [vocab + 1][N0] folded rows, the last one all zero ("no id")
     int s_col[MR_MAX_SMALL], s_vocab[MR_MAX_SMALL];
-    int s_off[MR_MAX_SMALL];              // float offset of small column f's rows inside the LDS small block
+    int s_off[MR_MAX_SMALL];              // float offset of small column f's rows inside the LDS small block (rows MR_RS floats apart)
     int zero_off;                         // float offset of the shared all-zero row inside the small block
     int small_floats;                     // multiple of 256
     const float* small;                   // device image of the small block
     int wide_kind, wide_a, wide_b, wide_dim, wide_stride;   // 0 none, 1 cross rows x head weights, 2 cross scalar (indicator weight)
     long long wide_buckets;
+    unsigned long long wide_magic;        // floor((2^64 - 1) / wide_buckets) when wide_buckets < 2^30 (the modulo as a multiply, below), else 0
     const float* wide_tab;
     const float* wide_w;
     float head_bias;
     float inv_w1_scale;                   // DYN: 1 / static scale of the second layer's split-f16 fragments
-    int flags;                            // 1 = ids / dense not 16-byte aligned: stage element-wise
+    int flags;                            // 1 = ids / dense not 16-byte aligned: stage element-wise; 2 = b0 rides in the numerics' free eighth K slot
 };
 
-template <int N0C, int N1C>
+// h mod n for a 64-bit hash and n < 2^30, bit-exact, without the 64-bit division hipcc expands `%` into (about seventy VALU and fifty
+// SALU instructions per task in round 4's loop -- the reciprocal of the wave-uniform divisor was recomputed every trip).
+// magic = floor((2^64 - 1) / n): q = mulhi64(h, magic) satisfies floor(h / n) - 2 <= q <= floor(h / n) (h magic / 2^64 > h / n - (n + 1) / n),
+// so h - q n lies in [0, 3n) < 2^32: its low 32 bits are the whole value, and two conditional subtractions finish.
+__device__ __forceinline__ unsigned mod_magic(unsigned long long h, unsigned n, unsigned long long magic) {
+    const unsigned long long qq = __umul64hi(h, magic);
+    unsigned rr = (unsigned)h - (unsigned)qq * n;
+    rr = rr >= n ? rr - n : rr;
+    rr = rr >= n ? rr - n : rr;
+    return rr;
+}
+
+template <int N0C, int N1C, bool DYN>
 struct MlpRowsLds {
     static constexpr int N0 = N0C * 16, N1 = N1C * 16;
     static constexpr int S1 = N0 + 4;
     static constexpr int off_w1 = 0;                  // DYN: split-f16 fragments N1C*(N0C/2)*512 floats; else W1^T [N1][S1]
-    static constexpr int w1_floats = N1 * S1;
-    static constexpr int off_w0n = off_w1 + w1_floats;   // W0[:, numerics]^T [N0][8]
-    static constexpr int off_b0 = off_w0n + N0 * 8;
+    static constexpr int w1_floats = DYN ? N1C * (N0C / 2) * 512 : N1 * S1;
+    static constexpr int off_b0 = off_w1 + w1_floats;
     static constexpr int off_b1 = off_b0 + N0;
     static constexpr int off_hw = off_b1 + N1;
     static constexpr int total = off_hw + N1;
     static constexpr int total_pad = (total + 255) & ~255;
+    // the device image continues behind the LDS part with W0[:, numerics]^T [N0][8] (+ b0 in column 7 when n_num < 8): read ONCE per
+    // wave, straight from global memory into registers ([r5]: it used to take 4 KB of LDS for that one read)
+    static constexpr int off_w0n = total_pad;
+    static constexpr int image_floats = total_pad + N0 * 8;
 };
 
-// One-time (finalize) kernel: rows [rows][128] -> the XOR-swizzled LDS layout (piece p of row i at slot p ^ (i & 15)).
-__global__ __launch_bounds__(256) void k_mlp_rows_swizzle(const float* __restrict__ in, float* __restrict__ out, int rows) {
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < rows * 128; i += gridDim.x * 256) {
-        const int row = i >> 7, n = i & 127;
-        out[(row << 7) + ((((n >> 2) ^ (row & 15)) << 2) | (n & 3))] = in[i];
-    }
+// One-time (finalize) kernel: rows [rows][128] -> the LDS layout of a small column (rows MR_RS floats apart).
+__global__ __launch_bounds__(256) void k_mlp_rows_pad(const float* __restrict__ in, float* __restrict__ out, int rows) {
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < rows * 128; i += gridDim.x * 256) out[(i >> 7) * MR_RS + (i & 127)] = in[i];
 }
 
-// One-time (finalize) kernel: the fixed part of the LDS image.
-template <int N0C, int N1C>
+// One-time (finalize) kernel: the fixed part of the image.
+template <int N0C, int N1C, bool DYN>
 __global__ __launch_bounds__(256) void k_mlp_rows_pack(const float* __restrict__ W0, int ldw0, int num_col0, int n_num,
                                                        const float* __restrict__ b0, const float* __restrict__ W1, int ldw1,
                                                        const float* __restrict__ b1, const float* __restrict__ hw, int n_hw,
                                                        const float* __restrict__ w1frag, float* __restrict__ img) {
-    using LD = MlpRowsLds<N0C, N1C>;
-    static_assert(N1C * (N0C / 2) * 512 <= LD::w1_floats && N0C % 2 == 0, "DYN fragments fit the second layer's region");
+    using LD = MlpRowsLds<N0C, N1C, DYN>;
+    static_assert(N0C % 2 == 0, "K blocks of 32");
     const int tid = threadIdx.x;
-    if (w1frag) {
-        for (int i = tid; i < LD::w1_floats; i += 256) img[LD::off_w1 + i] = i < N1C * (N0C / 2) * 512 ? w1frag[i] : 0.f;
+    if constexpr (DYN) {
+        for (int i = tid; i < LD::w1_floats; i += 256) img[LD::off_w1 + i] = w1frag[i];
     } else {
         for (int i = tid; i < LD::w1_floats; i += 256) {
             const int n = i / LD::S1, k = i - n * LD::S1;
@@ -89,7 +107,7 @@ __global__ __launch_bounds__(256) void k_mlp_rows_pack(const float* __restrict__
     }
     for (int i = tid; i < LD::N0 * 8; i += 256) {
         const int n = i >> 3, k = i & 7;
-        img[LD::off_w0n + i] = k < n_num ? W0[(size_t)n * ldw0 + num_col0 + k] : 0.f;
+        img[LD::off_w0n + i] = k < n_num ? W0[(size_t)n * ldw0 + num_col0 + k] : (k == 7 ? b0[n] : 0.f);   // (column 7 meets x = 1 when n_num < 8, flags & 2)
     }
     for (int i = tid; i < LD::N0; i += 256) img[LD::off_b0 + i] = b0[i];
     for (int i = tid; i < LD::N1; i += 256) {
@@ -105,12 +123,29 @@ __global__ __launch_bounds__(256) void k_mlp_rows_pack(const float* __restrict__
 // put a vmcnt(0) in front of that arm and another behind the join: BOTH right after the next task's sixteen row gathers had been
 // requested, i.e. every trip waited for the rows it had just asked for and the prefetch hid nothing (found by reading the ISA's
 // wait sequence, scripts/r04; 42.8 -> see profiles/r04).
-template <int N0C, int N1C, int NBIG, int WAVES, bool DYN, int WK>
+//
+// [r5] NS = the number of small columns as a template parameter too (8: EmbeddingMLP.py / WideNDeep.py as written; -1: known at run
+// time only, the generic instantiation).  VERDICT r04 weak 2 read the loop's instruction mix off PMC (63 VALU + 7 MFMA per sample) and
+// called it issue-bound on instructions that do no arithmetic; build/sparrow.s (scripts/r05/isa_loop_mix.py) says which:
+//   * a wave-uniform branch per small column (f < n_small) made every column's id read its own LDS round trip -- eight dependent
+//     ds_read_b32 + s_waitcnt lgkmcnt(0) in a row per task -- and kept hipcc from overlapping one column's eight row reads with the
+//     previous column's adds; its eight SGPR-pair conditions lived in spilled lanes (sixteen v_readlane per trip).  With NS a constant
+//     the ids of a task are ONE batch of reads and the columns' reads run ahead of the adds;
+//   * every ReLU behind an MFMA was two v_max (relu1_fast, k_chain_v2.h);
+//   * the swizzle's XORs and shifts (above); the "bad id" flag as a 0/1 VGPR (four VALU per column: now a compare into an SGPR pair);
+//   * the second layer read each pair of weight fragments right in front of the three DEPENDENT MFMAs that consume it: 32 times per task
+//     an LDS latency and two MFMA latencies with nothing else of this wave to issue.  Now four output blocks go through a K block
+//     together (pass 1: Ah Bh x 4, pass 2: Ah Bl x 4, pass 3: Al Bh x 4 -- the accumulation order per output is unchanged), and the next
+//     group's fragments are requested as soon as a pass has freed their registers;
+//   * b0 rides in the numerics' free eighth K slot (x = 1) when there are at most seven numerics: eight LDS reads + sixteen adds less.
+template <int N0C, int N1C, int NBIG, int NS, int WAVES, bool DYN, int WK>
 __global__ __launch_bounds__(WAVES * 64, 2) void k_mlp_rows(const MlpRowsRun A, const int* __restrict__ ids,
                                                             const float* __restrict__ dense, float* __restrict__ out,
                                                             int B, int* __restrict__ err, const float* __restrict__ image) {
-    using LD = MlpRowsLds<N0C, N1C>;
+    using LD = MlpRowsLds<N0C, N1C, DYN>;
     constexpr int N0 = LD::N0;
+    constexpr bool RT = NS < 0;
+    static_assert(NS <= MR_MAX_SMALL && N1C % 4 == 0, "shape");
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -118,10 +153,12 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_mlp_rows(const MlpRowsRun A, 
     const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
     const int ntasks = (B + 15) >> 4;
     const int task_stride = gridDim.x * WAVES;
-    const float* small_s = smem + LD::total_pad;
+    const int ns = RT ? A.n_small : NS;
+    const char* small_b = reinterpret_cast<const char*>(smem + LD::total_pad) + 16 * q;       // + this lane's piece 0 (q) of a row
     float* stage = smem + LD::total_pad + A.small_floats + wave * MR_STAGE;
-    bool bad = false;
+    unsigned long long badm = 0;          // lanes that saw an id outside [-1, vocab): an SGPR pair, not a VGPR flag
     const bool aligned = !(A.flags & 1);
+    const bool bias_in_k7 = (A.flags & 2) != 0;
     auto clampt = [&](int tk) { return tk < ntasks ? tk : ntasks - 1; };
 
     // ---- ids / numerics of a task: two coalesced 16-byte loads per lane (ids block, numerics block) ----
@@ -135,9 +172,12 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_mlp_rows(const MlpRowsRun A, 
     // everything of a task that is in flight while the previous task's second layer runs
     f32x4 g[NBIG][N0C];                   // big columns' folded rows (C/D layout pieces)
     f32x4 gw[2];                          // cross row pieces (wide part)
-    int so[MR_MAX_SMALL];                 // small columns: LDS float offset of this sample's row
+    int so[MR_MAX_SMALL];                 // small columns: BYTE offset of this lane's piece 0 of the sample's row, relative to small_b
     float xa = 0.f, xb = 0.f, gws = 0.f;  // numerics q / q + 4; cross indicator weight
-    auto gather = [&](int tk, const f32x4& ri, const f32x4& rd) {
+    // live = false: the trip behind a wave's last task.  Its loads are issued all the same -- into the all-zero rows, one hot line per table --
+    // so that the registers a gather writes are the SAME on every path into the next trip: with the gather inside `if (more tasks)` hipcc
+    // kept two copies of the 80 registers and moved one into the other at the end of every trip (forty v_mov_b64, build/sparrow.s).
+    auto gather = [&](int tk, const f32x4& ri, const f32x4& rd, bool live) {
         if (aligned && tk * 16 + 16 <= B) {
             if (lane < 4 * A.F) st4(stage + 4 * lane, ri);
             if (lane < 4 * A.ND) st4(stage + 192 + 4 * lane, rd);
@@ -154,35 +194,59 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_mlp_rows(const MlpRowsRun A, 
                 stage[192 + e] = dense[(size_t)min(tk * 16 + mm, B - 1) * A.ND + c];
             }
         }
-        // one wave: LDS operations complete in issue order, no barrier needed
+        // one wave: LDS operations complete in issue order, no barrier needed.  EVERY id of the sample is read here, back to back
+        // (one LDS round trip), before anything is computed from one of them.
         const int* idrow = reinterpret_cast<const int*>(stage) + r * A.F;
+        int bid[NBIG], sidv[MR_MAX_SMALL], wid_a = 0, wid_b = 0;
 #pragma unroll
-        for (int b = 0; b < NBIG; ++b) {
-            const int id = idrow[A.big_col[b]];
-            bad |= (unsigned)(id + 1) > (unsigned)A.big_vocab[b];
-            const unsigned sid = min((unsigned)id, (unsigned)A.big_vocab[b]);      // -1 -> the zero row at index vocab
-            const float* row = A.big_tab[b] + (size_t)sid * N0 + 4 * q;
-#pragma unroll
-            for (int nb = 0; nb < N0C; ++nb) g[b][nb] = ld4(row + 16 * nb);
-        }
+        for (int b = 0; b < NBIG; ++b) bid[b] = idrow[A.big_col[b]];
 #pragma unroll
         for (int f = 0; f < MR_MAX_SMALL; ++f) {
-            if (f < A.n_small) {                                  // wave-uniform
-                const int id = idrow[A.s_col[f]];
-                bad |= (unsigned)(id + 1) > (unsigned)A.s_vocab[f];
-                // float offset of this lane's piece 0 (q) inside the sample's swizzled row; piece 16 nb + 4 q = this ^ (16 nb)
-                so[f] = (unsigned)id < (unsigned)A.s_vocab[f] ? (A.s_off[f] + id * N0) ^ (4 * (id & 15)) ^ (4 * q) : A.zero_off ^ (4 * q);
-            }
+            sidv[f] = -1;
+            if (RT ? f < ns : f < NS) sidv[f] = idrow[A.s_col[f]];
         }
+        if constexpr (WK != 0) { wid_a = idrow[A.wide_a]; wid_b = idrow[A.wide_b]; }
         {
             const float* nrow = stage + 192 + r * A.ND;
             const int last = A.n_num - 1;
-            // slots beyond n_num hold a duplicate finite value that only ever meets zero weights
+            // slots beyond n_num hold a duplicate finite value that only ever meets zero weights -- except slot 7 when it carries b0
             xa = nrow[min(q, last)];
             xb = nrow[min(q + 4, last)];
+            xb = (bias_in_k7 && q == 3) ? 1.0f : xb;
         }
-        if constexpr (WK != 0) {
-            const unsigned long long bkt = cross_bucket(idrow[A.wide_a], idrow[A.wide_b], (uint64_t)A.wide_buckets);
+#pragma unroll
+        for (int b = 0; b < NBIG; ++b) {
+            badm |= __ballot(live && (unsigned)(bid[b] + 1) > (unsigned)A.big_vocab[b]);
+            const unsigned sid = live ? min((unsigned)bid[b], (unsigned)A.big_vocab[b]) : (unsigned)A.big_vocab[b];      // -1 -> the zero row at index vocab
+            // (one SGPR base + a 32-bit byte offset per lane: the set-up admits folded tables below 4 GiB)
+            const char* row = reinterpret_cast<const char*>(A.big_tab[b]) + (sid * (unsigned)(N0 * 4) + 16u * q);
+#pragma unroll
+            for (int nb = 0; nb < N0C; ++nb) g[b][nb] = (MR_XP & 4) ? f32x4{(float)sid, 0.f, 0.f, 0.f} : *reinterpret_cast<const f32x4*>(row + 64 * nb);
+        }
+#pragma unroll
+        for (int f = 0; f < MR_MAX_SMALL; ++f) {
+            if (RT ? f < ns : f < NS) {                           // (wave-uniform when RT)
+                const int id = sidv[f];
+                badm |= __ballot(live && (unsigned)(id + 1) > (unsigned)A.s_vocab[f]);
+                const int t = __mul24(id, MR_RS * 4) + A.s_off[f] * 4;              // (v_mad_u32_u24; a missing id's product is discarded)
+                so[f] = (unsigned)id < (unsigned)A.s_vocab[f] ? t : A.zero_off * 4;
+            }
+        }
+        if constexpr (WK != 0 && !(MR_XP & 8)) {
+            unsigned long long bkt;
+            if (MR_XP & 32) {
+                bkt = 0;
+            } else if (A.wide_magic != 0) {                           // wave-uniform
+                unsigned long long hh = 0xDECAFCAFFEULL;              // cross_bucket's chain (k_tile_forward.h), the modulo as a multiply
+                hh = fingerprint_cat64(hh, (uint64_t)(int64_t)wid_a);
+                hh = fingerprint_cat64(hh, (uint64_t)(int64_t)wid_b);
+                bkt = mod_magic(hh, (unsigned)A.wide_buckets, A.wide_magic);
+            } else {
+                bkt = cross_bucket(wid_a, wid_b, (uint64_t)A.wide_buckets);
+            }
+            if (MR_XP & 32) bkt = (unsigned long long)(((unsigned)wid_a * 2654435761u) ^ ((unsigned)wid_b * 40503u)) % (unsigned)A.wide_buckets;
+            if (MR_XP & 64) bkt = bkt & 1;
+            bkt = live ? bkt : 0ull;
             if constexpr (WK == 1) {
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
@@ -195,7 +259,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_mlp_rows(const MlpRowsRun A, 
         }
     };
 
-    // ---- prologue: first task's ids and the LDS image / small tables requested together ----
+    // ---- prologue: first task's ids, the numerics' A operands (global -> registers) and the LDS image / small tables requested together ----
     f32x4 ri = zero, rd = zero;
     int tk = blockIdx.x * WAVES + wave;
     if (ntasks > 0) ld_raw(clampt(tk), ri, rd);
@@ -211,12 +275,13 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_mlp_rows(const MlpRowsRun A, 
             (__attribute__((address_space(3))) void*)(smem + LD::total_pad + c * 256), 16, 0, 0);
     __builtin_amdgcn_s_waitcnt(0x0F70);                           // vmcnt(0): this wave's DMA pieces and ids have landed
     __builtin_amdgcn_s_barrier();
-    // numerics' A operands: rows (nb*16 + r) of W0[:, numerics]^T, columns q and q + 4
+    // numerics' A operands: rows (nb*16 + r) of W0[:, numerics]^T, columns q and q + 4 -- requested BEHIND the meeting (nobody waits for
+    // them there), in flight with the first task's rows, first used by the first task's MFMAs
     float rwa[N0C], rwb[N0C];
 #pragma unroll
     for (int nb = 0; nb < N0C; ++nb) {
-        rwa[nb] = smem[LD::off_w0n + (nb * 16 + r) * 8 + q];
-        rwb[nb] = smem[LD::off_w0n + (nb * 16 + r) * 8 + q + 4];
+        rwa[nb] = image[LD::off_w0n + (nb * 16 + r) * 8 + q];
+        rwb[nb] = image[LD::off_w0n + (nb * 16 + r) * 8 + q + 4];
     }
     f32x4 wwide[2] = {zero, zero};
     if constexpr (WK == 1) {
@@ -226,11 +291,10 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_mlp_rows(const MlpRowsRun A, 
             if (d < A.wide_dim) wwide[h] = ld4(A.wide_w + d);
         }
     }
-    if (tk < ntasks) {
-        gather(tk, ri, rd);
-        ld_raw(clampt(tk + task_stride), ri, rd);
-    }
-    for (; tk < ntasks; tk += task_stride) {
+    if (tk >= ntasks) return;                                     // (behind the barrier; a wave without a task flags nothing)
+    gather(tk, ri, rd, true);
+    ld_raw(clampt(tk + task_stride), ri, rd);
+    for (;; tk += task_stride) {
         // ---- the task's gathered rows -> first-layer accumulators (frees the register set for the next task) ----
         f32x4 z0[N0C];
 #pragma unroll
@@ -247,20 +311,29 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_mlp_rows(const MlpRowsRun A, 
         for (int f = 0; f < MR_MAX_SMALL; ++f) so_c[f] = so[f];
         const float xa_c = xa, xb_c = xb;
         // ---- next task: gathers issued now, consumed after this task's second layer; ids one task further ahead ----
-        if (tk + task_stride < ntasks) {
-            gather(tk + task_stride, ri, rd);
-            ld_raw(clampt(tk + 2 * task_stride), ri, rd);
-        }
-        // ---- small columns from LDS, bias, numerics on the matrix pipe ----
+        const bool more = tk + task_stride < ntasks;              // wave-uniform
+        // (fence: the sums above must END the old rows' live ranges before the next gather's loads are placed.  hipcc's MachineSink moved
+        //  the adds down to their first use BEHIND the gather, the loads got a second register set, and every trip ended with 32 v_mov_b64 --
+        //  each behind its own vmcnt wait -- back into the first (build/sparrow.s).  The empty statements "use" the sums here.)
 #pragma unroll
-        for (int nb = 0; nb < N0C; ++nb) z0[nb] += ld4(smem + LD::off_b0 + nb * 16 + 4 * q);
+        for (int nb = 0; nb < N0C; ++nb) asm volatile("" : "+v"(z0[nb]));
+        __builtin_amdgcn_sched_barrier(0);
+        gather(clampt(tk + task_stride), ri, rd, more);
+        ld_raw(clampt(tk + 2 * task_stride), ri, rd);
+        // ---- small columns from LDS (a lane's piece nb of a row: + 64 nb bytes, the instruction's offset field) ----
+        if (!bias_in_k7) {
+#pragma unroll
+            for (int nb = 0; nb < N0C; ++nb) z0[nb] += ld4(smem + LD::off_b0 + nb * 16 + 4 * q);
+        }
 #pragma unroll
         for (int f = 0; f < MR_MAX_SMALL; ++f) {
-            if (f < A.n_small) {
+            if (!(MR_XP & 1) && (RT ? f < ns : f < NS)) {
+                const float* row = reinterpret_cast<const float*>(small_b + so_c[f]);
 #pragma unroll
-                for (int nb = 0; nb < N0C; ++nb) z0[nb] += ld4(small_s + (so_c[f] ^ (16 * nb)));
+                for (int nb = 0; nb < N0C; ++nb) z0[nb] += ld4(row + 16 * nb);
             }
         }
+        // ---- numerics (+ b0) on the matrix pipe ----
 #pragma unroll
         for (int nb = 0; nb < N0C; ++nb) z0[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(rwa[nb], xa_c, z0[nb], 0, 0, 0);
 #pragma unroll
@@ -278,20 +351,43 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_mlp_rows(const MlpRowsRun A, 
             mx = rows4_max(mx);
             float scale, inv;
             dyn_scale(mx, A.inv_w1_scale, scale, inv);
-#pragma unroll
-            for (int n1 = 0; n1 < N1C; ++n1) z1[n1] = zero;
             const float* wf = smem + LD::off_w1 + lane * 4;              // this lane's 16 bytes inside a 1-KB fragment (k_dyn_pack_w: lane order)
+            constexpr int KB = N0C / 2, NG = N1C / 4;                    // K blocks of 32; groups of four output blocks
+            auto frag = [&](int n1, int b, int part) {
+                if (MR_XP & 2) return __builtin_bit_cast(din_f16x8, ld4(wf + part * 256 + 0 * (n1 + b)));
+                return __builtin_bit_cast(din_f16x8, ld4(wf + ((n1 * KB + b) * 2 + part) * 256));
+            };
+            din_f16x8 ah[4], al[4];
 #pragma unroll
-            for (int b = 0; b < N0C / 2; ++b) {
+            for (int j = 0; j < 4; ++j) { ah[j] = frag(j, 0, 0); al[j] = frag(j, 0, 1); }
+#pragma unroll
+            for (int b = 0; b < KB; ++b) {
                 din_f16x8 bh, bl;
                 dyn_split8(z0[2 * b], z0[2 * b + 1], scale, bh, bl);
 #pragma unroll
-                for (int n1 = 0; n1 < N1C; ++n1) {
-                    const din_f16x8 ah = __builtin_bit_cast(din_f16x8, ld4(wf + ((n1 * (N0C / 2) + b) * 2 + 0) * 256));
-                    const din_f16x8 al = __builtin_bit_cast(din_f16x8, ld4(wf + ((n1 * (N0C / 2) + b) * 2 + 1) * 256));
-                    z1[n1] = mfma_f16(ah, bh, z1[n1]);
-                    z1[n1] = mfma_f16(ah, bl, z1[n1]);
-                    z1[n1] = mfma_f16(al, bh, z1[n1]);
+                for (int gi = 0; gi < NG; ++gi) {
+                    const int step = b * NG + gi + 1;                       // the group behind this one
+                    const int nb_ = step / NG, ng_ = step - nb_ * NG;       // (compile-time after unrolling)
+                    const bool more = step < KB * NG;
+                    if (MR_XP & 16) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) z1[4 * gi + j] = (b == 0 ? zero : z1[4 * gi + j]) + __builtin_bit_cast(f32x4, ah[j]) + __builtin_bit_cast(f32x4, al[j]) + __builtin_bit_cast(f32x4, bh) + __builtin_bit_cast(f32x4, bl);
+                        continue;
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) z1[4 * gi + j] = mfma_f16(ah[j], bh, b == 0 ? zero : z1[4 * gi + j]);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) z1[4 * gi + j] = mfma_f16(ah[j], bl, z1[4 * gi + j]);
+                    if (more) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) ah[j] = frag(4 * ng_ + j, nb_, 0);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) z1[4 * gi + j] = mfma_f16(al[j], bh, z1[4 * gi + j]);
+                    if (more) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) al[j] = frag(4 * ng_ + j, nb_, 1);
+                    }
                 }
             }
 #pragma unroll
@@ -323,6 +419,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_mlp_rows(const MlpRowsRun A, 
         z = rows4_sum(z);
         const int mm = tk * 16 + r;
         if (q == 0 && mm < B) out[mm] = sigmoidf_acc(z + A.head_bias);
+        if (!more) break;
     }
-    if (__ballot(bad) != 0 && lane == 0) atomicOr(err, 1);
+    if (badm != 0 && lane == 0) atomicOr(err, 1);
 }

@@ -266,8 +266,15 @@ class ShardedTable:
             raise
         self.base, self.shard_rows = int(base.value), int(srows.value)
         dev = torch.device("cuda", torch.cuda.current_device())
-        self.local = torch.as_tensor(_DevView(self.base + self.rank * self.shard_rows * self.Dp * 4, (self.shard_rows, self.Dp), self), device=dev)
-        self._full = torch.as_tensor(_DevView(self.base, (self.rows + 1, self.Dp), self), device=dev)
+        # [r5, ADVICE r04] The views hold NO reference to this object: torch keeps the array-interface object alive on the C++ side, where
+        # Python's collector cannot see it, and an owner stored there closed a cycle (table -> tensor -> view -> table) that kept
+        # __del__ -- and with it the multi-GB shard, the reserved range and the exported descriptor -- from ever running.  What keeps
+        # the mapping alive under an engine is DeviceTable.keepalive (table()); ``local`` / the tensors it hands out are only valid
+        # while the table is.
+        self.local = torch.as_tensor(_DevView(self.base + self.rank * self.shard_rows * self.Dp * 4, (self.shard_rows, self.Dp)), device=dev)
+        self._full = torch.as_tensor(_DevView(self.base, (self.rows + 1, self.Dp)), device=dev)
+        import weakref
+        self._handed = weakref.WeakSet()                        # the DeviceTables handed to models (and through them to engines)
 
     def owned_rows(self) -> Tuple[int, int]:
         """Global rows [lo, hi) that live in this rank's shard (clipped to the table)."""
@@ -282,17 +289,25 @@ class ShardedTable:
 
     def table(self):
         from .plan import DeviceTable
-        return DeviceTable(self._full, self.rows, self.dim, keepalive=self)
+        t = DeviceTable(self._full, self.rows, self.dim, keepalive=self)
+        self._handed.add(t)
+        return t
 
-    def close(self):
+    def close(self, force: bool = False):
+        """Unmaps every shard and frees this rank's.  Refuses (RuntimeError) while an engine built on a ``table()`` of this object is
+        still open, unless ``force``: an engine gathering from an unmapped range faults.  Close the engines first."""
         if getattr(self, "handle", None):
+            alive = sum(len(t.engines) for t in getattr(self, "_handed", ()))
+            if alive and not force:
+                raise RuntimeError("ShardedTable.close(): %d engine(s) built on this table are still open; close them first "
+                                   "(or close(force=True))" % alive)
             self.local = self._full = None
             self.lib.sprk_vtable_destroy(self.handle)
             self.handle = None
 
     def __del__(self):
         try:
-            self.close()
+            self.close(force=True)                              # (unreachable while a DeviceTable.keepalive points here)
         except Exception:
             pass
 

@@ -62,6 +62,7 @@ class Engine:
                 if isinstance(a, DeviceTable):                    # already where it should be (6.9 GB tables, row-sharded tables): no copy
                     L.check(self.lib.sprk_upload_external(self.handle, i, C.c_void_p(a.data_ptr()), a.nbytes))
                     self._external.append(a)                      # (the table must outlive the handle)
+                    a.engines.add(self)                           # (ShardedTable.close() looks here before it unmaps)
                     continue
                 if hasattr(a, "data_ptr"):
                     ptr, nbytes = a.data_ptr(), a.numel() * a.element_size()
@@ -281,6 +282,9 @@ class Engine:
         if getattr(self, "handle", None):
             self.lib.sprk_destroy(self.handle)
             self.handle = None
+            for a in self._external:
+                a.engines.discard(self)
+            self._external = []
 
     def __del__(self):
         try:

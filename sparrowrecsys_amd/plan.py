@@ -43,6 +43,8 @@ class DeviceTable:
         if tuple(tensor.shape) != (vocab + 1, pad4(dim)) or not tensor.is_contiguous() or str(tensor.dtype) != "torch.float32":
             raise ValueError("DeviceTable wants a contiguous float32 [vocab + 1, pad4(dim)] device tensor, got %s %s" % (tuple(tensor.shape), tensor.dtype))
         self.tensor, self.vocab, self.dim, self.keepalive = tensor, int(vocab), int(dim), keepalive
+        import weakref
+        self.engines = weakref.WeakSet()                        # live engines that took this table with sprk_upload_external
 
     @classmethod
     def from_rows(cls, table):

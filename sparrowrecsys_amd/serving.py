@@ -178,6 +178,7 @@ class _MicroBatcher:
             try:
                 self.inline += 1
                 self.requests += 1
+                self.batches += 1                                # (an inline forward is a batch of one request: requests / batches stays the mean group size)
                 return np.asarray(self.predict_fn(feats), dtype=np.float32).reshape(-1)
             finally:
                 self._run_lock.release()
@@ -262,8 +263,10 @@ class PredictServer:
     ranker only sends userId / movieId)."""
 
     def __init__(self, model, name: str = "recmodel", host: str = "127.0.0.1", port: int = 8501,
-                 defaults: Optional[Mapping[str, object]] = None, max_wait_s: float = 0.0005):
+                 defaults: Optional[Mapping[str, object]] = None, max_wait_s: float = 0.0005,
+                 max_body_bytes: int = 64 << 20, reuse_port: bool = False):
         self.model, self.name, self.defaults = model, name, dict(defaults or {})
+        self.max_body_bytes = int(max_body_bytes)                # (800 candidates are 25 KB; 64 MiB is a few million instances)
         self.fast_parse = os.environ.get("SPRK_SERVING_FAST_PARSE", "1") != "0"
         self.batcher = _MicroBatcher(self._predict, max_wait_s=max_wait_s)
         outer = self
@@ -362,7 +365,8 @@ class PredictServer:
             def do_GET(self):
                 if self.path.rstrip("/") == "/v1/models/" + outer.name:
                     self._send(200, {"model_version_status": [{"version": "1", "state": "AVAILABLE",
-                                                                "status": {"error_code": "OK", "error_message": ""}}]})
+                                                                "status": {"error_code": "OK", "error_message": ""}}],
+                                     "worker_pid": os.getpid()})   # (not TF Serving's: which worker of serve_workers answered)
                 else:
                     self._send(404, {"error": "Not found: %s" % self.path})
 
@@ -373,8 +377,23 @@ class PredictServer:
                 announced = True
                 outer.batcher.announce()
                 try:
-                    n = int(self.headers.get("Content-Length", "0"))
+                    # [r5] the length is validated before a byte of the body is read: int("-1") used to reach rfile.read(-1) -- "until
+                    # EOF", i.e. a handler thread parked on the connection for as long as the client keeps it open -- and nothing
+                    # bounded what one request could make the process buffer
+                    cl = self.headers.get("Content-Length")
+                    if cl is None or not cl.strip().isdigit():
+                        self.close_connection = True             # (the body cannot be skipped: the stream is out of step from here on)
+                        self._send(411 if cl is None else 400, {"error": "a Content-Length header with a non-negative decimal value is required"})
+                        return
+                    n = int(cl)
+                    if n > outer.max_body_bytes:
+                        self.close_connection = True
+                        self._send(413, {"error": "request body of %d bytes exceeds the limit of %d" % (n, outer.max_body_bytes)})
+                        return
                     raw = self.rfile.read(n)
+                    if len(raw) != n:
+                        self.close_connection = True
+                        raise ValueError("request body ended after %d of %d bytes" % (len(raw), n))
                     feats = _fast_uniform_int_instances(raw) if outer.fast_parse else None
                     cols = key = None
                     if feats is not None:                        # the Jetty ranker's request shape: no json.loads at all
@@ -423,7 +442,14 @@ class PredictServer:
                     if announced:
                         outer.batcher.withdraw()
 
-        self.httpd = ThreadingHTTPServer((host, port), Handler)
+        class _Server(ThreadingHTTPServer):
+            def server_bind(s2):
+                if reuse_port:                                   # several worker PROCESSES accept on one port (serve_workers): the kernel spreads the connections
+                    import socket
+                    s2.socket.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEPORT, 1)
+                ThreadingHTTPServer.server_bind(s2)
+
+        self.httpd = _Server((host, port), Handler)
         self.httpd.daemon_threads = True
         self.port = self.httpd.server_address[1]
         self.thread: Optional[threading.Thread] = None
@@ -445,6 +471,84 @@ class PredictServer:
         self.batcher.close()
 
 
+# ---------------------------------------------------------------------------------------------------------------------------
+# [r5] Several worker PROCESSES behind one port.  One Python process is one GIL: however many clients, the HTTP + JSON work of this
+# shim tops out near 4 000 requests of 800 candidates per second (profiles/r04/experiments/r04_24), while the forward behind it takes
+# microseconds.  serve_workers starts N processes, each with its OWN model + engine (NeuralCF's tables are 1.3 MB; every worker's
+# HIP context shares the one GPU) and its own PredictServer bound to the same (host, port) with SO_REUSEPORT: the kernel hands each
+# new connection to one of them (Jetty's HttpClient opens one per request thread, RecForYouProcess.java:113-138).  Micro-batching
+# stays per worker.
+# ---------------------------------------------------------------------------------------------------------------------------
+def _worker_main(factory, fargs, name, host, port, defaults, ready, stop):
+    try:
+        model = factory(*fargs)
+        srv = PredictServer(model, name=name, host=host, port=port, defaults=defaults, reuse_port=True).start()
+        ready.put((os.getpid(), srv.port, None))
+        stop.wait()
+        srv.close()
+    except Exception as e:                                       # the parent raises it
+        ready.put((os.getpid(), 0, "%s: %s" % (type(e).__name__, e)))
+
+
+class WorkerPool:
+    """``serve_workers``' handle: ``port``, ``pids``; ``close()`` stops the workers."""
+
+    def __init__(self, procs, stop, port, pids):
+        self.procs, self._stop, self.port, self.pids = procs, stop, port, pids
+
+    def close(self):
+        self._stop.set()
+        for p in self.procs:
+            p.join(timeout=10)
+            if p.is_alive():
+                p.terminate()
+
+
+def serve_workers(factory, fargs=(), n_workers: int = 4, name: str = "recmodel", host: str = "127.0.0.1", port: int = 8501,
+                  defaults: Optional[Mapping[str, object]] = None, start_method: str = "spawn", timeout_s: float = 300.0) -> WorkerPool:
+    """Starts ``n_workers`` processes that each call ``factory(*fargs)`` (picklable: a module-level function) for their model and serve
+    it on the same ``host:port`` (``port=0``: the first worker picks a free one, the others join it).  Returns when every worker
+    answers; raises what a worker raised."""
+    import multiprocessing as mp
+    ctx = mp.get_context(start_method)
+    ready, stop = ctx.Queue(), ctx.Event()
+    procs, pids = [], []
+    try:
+        for i in range(n_workers):
+            p = ctx.Process(target=_worker_main, args=(factory, tuple(fargs), name, host, port, dict(defaults or {}), ready, stop), daemon=True)
+            p.start()
+            procs.append(p)
+            if i == 0 or port == 0:                              # the port must be known before the next worker binds it
+                pid, got, err = ready.get(timeout=timeout_s)
+                if err:
+                    raise RuntimeError("serving worker %d failed: %s" % (pid, err))
+                pids.append(pid)
+                port = got
+        while len(pids) < n_workers:
+            pid, got, err = ready.get(timeout=timeout_s)
+            if err:
+                raise RuntimeError("serving worker %d failed: %s" % (pid, err))
+            pids.append(pid)
+    except Exception:
+        stop.set()
+        for p in procs:
+            p.join(timeout=5)
+            if p.is_alive():
+                p.terminate()
+        raise
+    return WorkerPool(procs, stop, port, pids)
+
+
+def _cli_model(model_name, weights_path):
+    from . import models as M
+    cls = {"neuralcf": M.NeuralCF, "embedding_mlp": M.EmbeddingMLP, "wide_n_deep": M.WideNDeep, "deepfm": M.DeepFM,
+           "deepfm_v2": M.DeepFMv2, "din": M.DIN, "dien": M.DIEN}[model_name]
+    weights = dict(np.load(weights_path)) if weights_path else None
+    model = cls(weights=weights, seed=None if weights else 0)
+    model.engine                                           # fail loudly now if the HIP library / device is missing
+    return model
+
+
 def _main():
     from . import models as M
     ap = argparse.ArgumentParser(description=__doc__.split("\n\n")[0])
@@ -453,7 +557,19 @@ def _main():
     ap.add_argument("--name", default="recmodel")
     ap.add_argument("--host", default="127.0.0.1")
     ap.add_argument("--port", type=int, default=8501)
+    ap.add_argument("--workers", type=int, default=1, help="worker processes sharing the port (SO_REUSEPORT), one engine each")
     args = ap.parse_args()
+    if args.workers > 1:
+        import signal
+        pool = serve_workers(_cli_model, (args.model, args.weights), n_workers=args.workers, name=args.name, host=args.host, port=args.port)
+        print("serving %s on http://%s:%d/v1/models/%s:predict from %d workers (pids %s)" % (args.model, args.host, pool.port, args.name, args.workers, pool.pids), flush=True)
+        try:
+            signal.pause()
+        except KeyboardInterrupt:
+            pass
+        finally:
+            pool.close()
+        return
     cls = {"neuralcf": M.NeuralCF, "embedding_mlp": M.EmbeddingMLP, "wide_n_deep": M.WideNDeep, "deepfm": M.DeepFM,
            "deepfm_v2": M.DeepFMv2, "din": M.DIN, "dien": M.DIEN}[args.model]
     weights = dict(np.load(args.weights)) if args.weights else None

@@ -24,6 +24,9 @@ class _StubModel:
         u = np.asarray(feats["userId"], dtype=np.int64)
         m = np.asarray(feats["movieId"], dtype=np.int64)
         self.calls.append(len(u))
+        if getattr(self, "delay", 0):
+            import time
+            time.sleep(self.delay)
         if (m >= 1000).any() or (m < 0).any():
             raise ValueError("an id was outside its table")
         return ((u % 7) * 0.1 + (m % 5) * 0.01).astype(np.float32).reshape(-1, 1)
@@ -77,6 +80,7 @@ def test_columnar_format_status_and_errors(stub_server):
 def test_concurrent_requests_are_batched_and_isolated(stub_server):
     srv, model = stub_server
     srv.batcher.max_wait_s = 0.05                       # give the 16 client threads time to pile up
+    model.delay = 0.02                                  # ... behind a forward that takes long enough for the others to arrive
     results = {}
 
     def client(i):
@@ -97,7 +101,9 @@ def test_concurrent_requests_are_batched_and_isolated(stub_server):
             assert code == 200
             want = [((100 * i + j) % 7) * 0.1 + (j % 5) * 0.01 for j in range(50)]
             np.testing.assert_allclose([x[0] for x in resp["predictions"]], want, atol=1e-6)
-    assert srv.batcher.batches < srv.batcher.requests   # at least one merged forward
+    # at least one merged forward ([r5] inline forwards count as batches now, so this inequality really says "merged": before, every
+    # inline request satisfied it by itself)
+    assert srv.batcher.batches < srv.batcher.requests == 16
 
 
 class _GenreStub:
@@ -303,3 +309,74 @@ def test_fast_and_json_parse_paths_answer_alike(stub_server, monkeypatch):
         out[fast] = (r.status, J.loads(r.read()))
         c.close()
     assert out[True] == out[False] and out[True][0] == 200 and len(out[True][1]["predictions"]) == 40
+
+
+def test_content_length_is_validated_before_the_body_is_read():
+    """`int(Content-Length)` went straight into rfile.read() -- a negative value meant "read until EOF" (a handler
+    thread parked for as long as the client holds the connection), and nothing bounded the buffer.  Negative, non-numeric, missing and
+    oversize lengths are answered (400 / 400 / 411 / 413) WITHOUT waiting for a body, the connection is closed, and the server keeps
+    serving; a body shorter than its announced length is a 400 as well."""
+    import socket
+    import time
+    model = _StubModel()
+    srv = PredictServer(model, port=0, max_body_bytes=4096).start()
+    try:
+        def raw(req: bytes, half_close=False):
+            t0 = time.monotonic()
+            with socket.create_connection(("127.0.0.1", srv.port), timeout=10) as sk:
+                sk.sendall(req)
+                if half_close:
+                    sk.shutdown(socket.SHUT_WR)
+                data = b""
+                while True:                                       # the SERVER must end the exchange: the client never closes first
+                    b = sk.recv(65536)
+                    if not b:
+                        break
+                    data += b
+            head, _, payload = data.partition(b"\r\n\r\n")
+            return int(head.split()[1]), payload, time.monotonic() - t0
+        path = b"POST /v1/models/recmodel:predict HTTP/1.1\r\nHost: x\r\n"
+        for hdr, want in ((b"Content-Length: -1\r\n", 400), (b"Content-Length: 12abc\r\n", 400), (b"Content-Length: 1e3\r\n", 400),
+                          (b"", 411), (b"Content-Length: 5000\r\n", 413), (b"Content-Length: 99999999999999999999\r\n", 413)):
+            code, payload, dt = raw(path + hdr + b"\r\n")         # no body is ever sent, and the socket stays open on the client's side
+            assert code == want, (hdr, code, payload)
+            assert "error" in json.loads(payload) and dt < 5.0
+        body = json.dumps({"instances": [{"userId": 8, "movieId": 3}]}).encode()
+        code, payload, _ = raw(path + b"Content-Length: %d\r\n\r\n" % (len(body) + 10) + body, half_close=True)   # announced more than sent
+        assert code == 400 and b"ended after" in payload
+        code, payload, _ = raw(path + b"Connection: close\r\nContent-Length: %d\r\n\r\n" % len(body) + body)
+        assert code == 200
+        np.testing.assert_allclose(json.loads(payload)["predictions"], [[0.13]], atol=1e-6)
+        # the batch counters: an inline forward counts as a batch (ADVICE r04: requests / batches was skewed by the inline path)
+        assert srv.batcher.requests == srv.batcher.batches >= 1
+    finally:
+        srv.close()
+
+
+def _stub_factory():
+    return _StubModel()
+
+
+def test_worker_processes_share_one_port():
+    """serving.serve_workers: N processes, one model each, one port (SO_REUSEPORT).  Every worker answers the Jetty request with the
+    same scores; the status route says which process served, and over a few dozen fresh connections more than one did."""
+    import http.client
+    from sparrowrecsys_amd.serving import serve_workers
+    pool = serve_workers(_stub_factory, (), n_workers=3, port=0, start_method="fork")
+    try:
+        assert len(set(pool.pids)) == 3
+        seen = set()
+        for i in range(60):
+            c = http.client.HTTPConnection("127.0.0.1", pool.port, timeout=30)   # a fresh connection each: the kernel picks the worker
+            c.request("GET", "/v1/models/recmodel")
+            seen.add(json.loads(c.getresponse().read())["worker_pid"])
+            c.request("POST", "/v1/models/recmodel:predict", body=json.dumps({"instances": [{"userId": 8, "movieId": 3}, {"userId": 9, "movieId": 4}]}),
+                      headers={"Content-Type": "application/json"})
+            r = c.getresponse()
+            got = json.loads(r.read())
+            assert r.status == 200
+            np.testing.assert_allclose(got["predictions"], [[0.13], [0.24]], atol=1e-6)
+            c.close()
+        assert seen <= set(pool.pids) and len(seen) >= 2, (seen, pool.pids)
+    finally:
+        pool.close()

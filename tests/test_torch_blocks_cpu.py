@@ -215,3 +215,117 @@ def test_deepfm_v2_graph_in_torch_equals_the_oracle(samples):
     np.testing.assert_allclose(fm.numpy(), parts["fm"], atol=1e-10)
     np.testing.assert_allclose(out, ref.astype(np.float64), atol=1e-7)
     assert ref.std() > 0.01
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# [r5] Wide&Deep and DIEN end to end (VERDICT r04 "missing" 6): the two graphs the third implementation did not cover yet
+# ---------------------------------------------------------------------------------------------------------------------------
+def torch_wide_n_deep(f, w, movie_buckets, user_buckets, cross_buckets, rated_buckets):
+    blocks = {k: _num(f, k) for k in O.NUMERIC_KEYS}                                  # WideNDeep.py:63-69
+    for k in O.USER_GENRE_KEYS + O.MOVIE_GENRE_KEYS:                                  # :33-48, embedding columns over the genre vocabulary
+        blocks[k + "_embedding"] = _emb_col(w, "emb/" + k, O.vocab_ids(f[k]))
+    movie = O.identity_ids(O.int_feature(f, "movieId"), movie_buckets, "movieId")
+    blocks["movieId_embedding"] = _emb_col(w, "emb/movieId", movie)                   # :51-54
+    blocks["userId_embedding"] = _emb_col(w, "emb/userId", O.identity_ids(O.int_feature(f, "userId"), user_buckets, "userId"))   # :57-60
+    deep = _dense_features(blocks)                                                    # :101
+    deep = F.relu(F.linear(deep, _t(w["dense0/kernel"]).T, _t(w["dense0/bias"])))     # :102
+    deep = F.relu(F.linear(deep, _t(w["dense1/kernel"]).T, _t(w["dense1/bias"])))     # :103
+    rated = O.identity_ids(O.int_feature(f, "userRatedMovie1"), rated_buckets, "userRatedMovie1")
+    bucket = torch.from_numpy(O.crossed_bucket_np([movie, rated], cross_buckets).astype(np.int64))   # :72-73 (the hash itself: tests/test_farmhash_pins.py)
+    if "emb/cross" in w:                                                              # BASELINE config 5's form: the cross as an embedding column
+        wide = F.embedding(bucket, _t(w["emb/cross"]))
+    else:
+        wide = F.one_hot(bucket, cross_buckets).double()                              # indicator_column: the [B, 10 000] block, materialised as the script does (:73,105)
+    both = torch.cat([deep, wide], dim=1)                                             # :106
+    return torch.sigmoid(F.linear(both, _t(w["head/kernel"]).T, _t(w["head/bias"]))).numpy()   # :107
+
+
+@pytest.mark.parametrize("kind", ["indicator", "cross_rows"])
+def test_wide_n_deep_graph_in_torch_equals_the_oracle(kind):
+    B, V, U = 301, 1001, 3001
+    f = SY.synth_embedding_mlp(B, V, U, seed=71, rated_vocab=V)
+    kw = dict(cross_buckets=10000, cross_dim=0) if kind == "indicator" else dict(cross_buckets=5000, cross_dim=32)
+    model = M.WideNDeep(seed=31, emb_dim=10 if kind == "indicator" else 32, movie_buckets=V, user_buckets=U, **kw)
+    w = model.weights
+    ref = O.wide_n_deep_forward(f, w, dtype=np.float64, movie_buckets=V, user_buckets=U, cross_buckets=model.cross_buckets, rated_buckets=V)
+    got = torch_wide_n_deep(f, w, V, U, model.cross_buckets, V)
+    np.testing.assert_allclose(got, ref.astype(np.float64), atol=1e-7)
+    assert ref.std() > 0.01
+
+
+def torch_dien(f, w, T, user_buckets):
+    """DIEN.py:163-259 in torch ops: the GRU as torch.nn.GRUCell steps (gates permuted z|r|h -> r|z|n) under Keras' mask rule, the
+    script's own attention / GRU_gate_parameter / AUGRU classes written out, the tail."""
+    hist = torch.from_numpy(np.asarray(f["userRatedMovies"]).astype(np.int64))
+    cand = torch.from_numpy(O.int_feature(f, "movieId"))
+    table = _t(w["emb/movie"])
+    D = table.shape[1]
+    x = F.embedding(hist, table)                                                      # DIEN.py:167
+    c = F.embedding(cand, table)                                                      # :168-171
+    B = x.shape[0]
+    cell = torch.nn.GRUCell(D, D).double()
+    perm = np.r_[D:2 * D, 0:D, 2 * D:3 * D]
+    with torch.no_grad():
+        cell.weight_ih.copy_(torch.from_numpy(w["gru/kernel"].astype(np.float64).T[perm]))
+        cell.weight_hh.copy_(torch.from_numpy(w["gru_rec/kernel"].astype(np.float64).T[perm]))
+        cell.bias_ih.copy_(torch.from_numpy(w["gru/bias"][0].astype(np.float64)[perm]))
+        cell.bias_hh.copy_(torch.from_numpy(w["gru/bias"][1].astype(np.float64)[perm]))
+        h = torch.zeros(B, D, dtype=torch.float64)
+        prev = torch.zeros(B, D, dtype=torch.float64)
+        g = []
+        for t in range(T):                                                            # :173, mask_zero's mask consumed by the GRU
+            m = (hist[:, t] != 0).unsqueeze(1)
+            hn = cell(x[:, t, :], h)
+            h = torch.where(m, hn, h)                                                 # a masked step keeps the state ...
+            prev = torch.where(m, hn, prev)                                           # ... and repeats the previous output (zeros before the first live slot)
+            g.append(prev)
+        g = torch.stack(g, dim=1)                                                     # [B, T, D]
+        # class attention (:175-204): RepeatVector(c) * g -> Dense(32, sigmoid) -> Dense(1, sigmoid), squeezed, repeated over D, permuted
+        prod = g * c.unsqueeze(1).repeat(1, T, 1)
+        a = torch.sigmoid(F.linear(torch.sigmoid(F.linear(prod, _t(w["att0/kernel"]).T, _t(w["att0/bias"]))), _t(w["att1/kernel"]).T, _t(w["att1/bias"])))
+        att = a.squeeze(2).unsqueeze(1).repeat(1, D, 1).permute(0, 2, 1)              # [B, T, D]
+
+        def gate(name, gt, hid, act, z_t=None):                                       # class GRU_gate_parameter (:210-227)
+            hin = hid if z_t is None else hid * z_t
+            pre = F.linear(gt, _t(w["augru_%s_in/kernel" % name]).T, _t(w["augru_%s_in/bias" % name])) + F.linear(hin, _t(w["augru_%s_hid/kernel" % name]).T)
+            return act(F.linear(pre, _t(w["augru_%s_out/kernel" % name]).T, _t(w["augru_%s_out/bias" % name])))
+        hs = _t(w["augru/h0"]).reshape(1, D).repeat(B, 1)                             # (:239-240 draws it per call; pinned to a weight on every backend)
+        for t in range(T):                                                            # class AUGRU (:241-248)
+            r_t = gate("r", g[:, t, :], hs, torch.sigmoid)
+            z_t = gate("z", g[:, t, :], hs, torch.sigmoid)
+            h_next = gate("h", g[:, t, :], hs, torch.tanh, z_t)
+            ra = att[:, t, :] * r_t
+            hs = (1 - ra) * hs + ra * h_next
+        prof = {k: _num(f, k) for k in ("userRatingCount", "userAvgRating", "userRatingStddev")}
+        prof["userId_embedding"] = _emb_col(w, "emb/userId", O.identity_ids(O.int_feature(f, "userId"), user_buckets, "userId"))
+        prof["userGenre1_embedding"] = _emb_col(w, "emb/userGenre1", O.vocab_ids(f["userGenre1"]))
+        ctx = {k: _num(f, k) for k in ("releaseYear", "movieRatingCount", "movieAvgRating", "movieRatingStddev")}
+        ctx["movieGenre1_embedding"] = _emb_col(w, "emb/movieGenre1", O.vocab_ids(f["movieGenre1"]))
+        y = torch.cat([hs, c, _dense_features(prof), _dense_features(ctx)], dim=1)    # :252
+        y = F.prelu(F.linear(y, _t(w["fc0/kernel"]).T, _t(w["fc0/bias"])), _t(w["fc0_prelu/alpha"]))   # :254-255
+        y = F.prelu(F.linear(y, _t(w["fc1/kernel"]).T, _t(w["fc1/bias"])), _t(w["fc1_prelu/alpha"]))   # :256-257
+        out = torch.sigmoid(F.linear(y, _t(w["head/kernel"]).T, _t(w["head/bias"])))  # :259
+    return out.numpy(), a.squeeze(2).numpy(), hs.numpy(), g.numpy()
+
+
+@pytest.mark.parametrize("T,D,holes", [(5, 10, "tail"), (20, 16, "anywhere"), (9, 10, "anywhere")])
+def test_dien_graph_in_torch_equals_the_oracle(T, D, holes):
+    B, V, U = 129, 400, 150
+    f = SY.synth_din(B, T, V, U, seed=60 + T)
+    h = f["userRatedMovies"]
+    rng = np.random.default_rng(T)
+    if holes == "anywhere":
+        h[rng.random(h.shape) < 0.3] = 0                                              # masked slots in the middle of a history
+    h[0] = 0                                                                          # a user without history
+    h[2, :T // 2] = 0                                                                 # leading holes
+    model = M.DIEN(seed=11 + T, emb_dim=D, hist_len=T, movie_buckets=V, user_buckets=U)
+    w = dict(model.weights)
+    for k in ("fc0_prelu/alpha", "fc1_prelu/alpha"):
+        w[k] = (rng.standard_normal(w[k].shape) * 0.5).astype(np.float32)
+    ref, parts = O.dien_forward(f, w, dtype=np.float64, hist_len=T, movie_buckets=V, user_buckets=U, return_parts=True)
+    got, att, hs, g = torch_dien(f, w, T, U)
+    np.testing.assert_allclose(g, parts["gru"], atol=1e-12)
+    np.testing.assert_allclose(att, parts["att"], atol=1e-12)
+    np.testing.assert_allclose(hs, parts["augru"], atol=1e-12)
+    np.testing.assert_allclose(got, ref.astype(np.float64), atol=1e-7)
+    assert ref.std() > 0.005
