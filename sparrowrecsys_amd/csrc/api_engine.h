@@ -325,7 +325,7 @@ int sprk_finalize(sprk_handle h) {
                             // k_din_fused (k_din_fused.h) takes the same tables; its tail half is set up by setup_din_tail
                             // (a trip of its slot loop is four slots: for the reference's own hist_len = 5 that is 8 slots of work for 5, and
                             // k_din_attn_cols' three-slot trips measure 10.7 us against 12.5 -- so short histories stay there)
-                            if (h->tune.din_fused && s.T >= 12) {
+                            if (h->tune.din_fused && s.T >= h->tune.din_fused_min_t) {
                                 DinFusedRun& f = h->din_fused_run;
                                 memset(&f, 0, sizeof(f));
                                 f.T = c.T; f.F = c.F; f.hist_col = c.hist_col; f.cand_col = c.cand_col; f.Dp = c.Dp; f.vocab = c.vocab;

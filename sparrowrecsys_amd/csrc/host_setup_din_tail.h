@@ -231,6 +231,9 @@ int setup_din_tail(sprk_engine* h, DevPlan* dp) {
             // userId and candidate movieId, whose folded rows (512 bytes per id) miss every cache -- go to the matrix pipe as raw rows
             // (128 bytes per id); the genre columns' folded tables are a few KB and stay folded.
             int n_unf = 0, unf_g[2] = {0, 0};
+            // [r5] emb_dim <= 16 (DIN.py as written): k_din_tail's raw 64-byte rows for ALL the embedding columns, as its two column-pair blocks
+            const bool unf_pairs = kc == 1 && w0efrag && r.e_unscale != 0.f && h->tune.din_fused_unf;
+            if (unf_pairs) { n_unf = 2; unf_g[0] = 0; unf_g[1] = 1; }
             if (kc == 2 && w0efrag && r.e_unscale != 0.f && h->tune.din_fused_unf) {
                 for (int pass = 0; pass < 2; ++pass) {
                     int best = -1;
@@ -241,7 +244,7 @@ int setup_din_tail(sprk_engine* h, DevPlan* dp) {
             }
             HIP_TRY(hipMalloc((void**)&h->din_fused_image, DinFusedImg::dma_floats * sizeof(float)));
             hipLaunchKernelGGL(k_din_fused_pack, dim3(1), dim3(256), 0, 0, o0.W, o0.ldw, p_off, Dp, n_off, n_num, 1.0f / r.inv_w0p_scale, 4 * kc,
-                               o0.bias, o0.alpha, w1frag, o1.bias, o1.alpha, tp.w, tp.len, h->din_fused_image, (const float*)w0efrag, n_unf, unf_g[0], unf_g[1]);
+                               o0.bias, o0.alpha, w1frag, o1.bias, o1.alpha, tp.w, tp.len, h->din_fused_image, (const float*)w0efrag, n_unf, unf_g[0], unf_g[1], kc == 2 ? 4 : 2);
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipDeviceSynchronize());
             DinFusedRun& f = h->din_fused_run;
@@ -249,17 +252,23 @@ int setup_din_tail(sprk_engine* h, DevPlan* dp) {
             // the folded columns (in the tail's order) and, apart from them, the raw-row columns
             f.n_cols = 0;
             for (int g = 0; g < r.n_cols; ++g) {
-                if ((n_unf > 0 && unf_g[0] == g) || (n_unf > 1 && unf_g[1] == g)) continue;
+                if (unf_pairs || (n_unf > 0 && unf_g[0] == g) || (n_unf > 1 && unf_g[1] == g)) continue;
                 f.col[f.n_cols] = r.col[g]; f.tvocab[f.n_cols] = r.vocab[g]; f.Ftab[f.n_cols] = r.Ftab[g]; ++f.n_cols;
             }
             for (int g = f.n_cols; g < DT_MAX_COLS; ++g) { f.col[g] = r.col[0]; f.tvocab[g] = r.vocab[0]; f.Ftab[g] = r.Ftab[0]; }
             f.head_bias = r.head_bias; f.inv_w1_scale = r.inv_w1_scale; f.inv_w0p_scale = r.inv_w0p_scale;
             f.b0_slot = n_num < 8 ? n_num : -1;
             f.n_unf = n_unf; f.e_unscale = r.e_unscale;
-            for (int u = 0; u < 2; ++u) {
-                f.ucol[u] = u < n_unf ? r.col[unf_g[u]] : r.col[0]; f.uvocab[u] = u < n_unf ? r.vocab[unf_g[u]] : 0;
-                f.Etab[u] = u < n_unf ? r.Etab[unf_g[u]] : nullptr;
+            for (int u = 0; u < 4; ++u) {
+                if (unf_pairs) {                                   // slot u IS column u of the tail's list
+                    f.ucol[u] = u < r.n_cols ? r.col[u] : r.col[0]; f.uvocab[u] = u < r.n_cols ? r.vocab[u] : r.vocab[0];
+                    f.Etab[u] = u < r.n_cols ? r.Etab[u] : r.Etab[0];
+                } else {
+                    f.ucol[u] = u < n_unf ? r.col[unf_g[u]] : r.col[0]; f.uvocab[u] = u < n_unf ? r.vocab[unf_g[u]] : 0;
+                    f.Etab[u] = u < n_unf ? r.Etab[unf_g[u]] : nullptr;
+                }
             }
+            f.n_ucols = unf_pairs ? r.n_cols : n_unf;
             f.image = h->din_fused_image;
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_din_fused<1, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_full));
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_din_fused<1, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_full));

@@ -84,7 +84,7 @@ typedef void (*V2J1LaunchFn)(const V2JRun&, const int*, const float*, float*, in
 template <int G_BIG, int NJF, bool HOIST>
 void v2j1_launch(const V2JRun& a, const int* ids, const float* dense, float* out, int B, int* err, const float* image, int grid,
                  size_t lds, hipStream_t st) {
-    hipLaunchKernelGGL((k_deepfm_v2_joint1<G_BIG, NJF, HOIST>), dim3(grid), dim3(V2J1_WAVES_OF(HOIST) * 64), lds, st, a, ids, dense, out, B, err, image);
+    hipLaunchKernelGGL((k_deepfm_v2_joint1<G_BIG, NJF, HOIST>), dim3(grid), dim3(V2J1_WAVES_OF(HOIST, G_BIG) * 64), lds, st, a, ids, dense, out, B, err, image);
 }
 // (fn_h / launch_h: the HOIST form, for tables larger than the Infinity Cache)
 struct V2J1Variant { int g_big, njf; const void* fn; V2J1LaunchFn launch; int image_floats; const void* fn_h; V2J1LaunchFn launch_h; };
@@ -362,7 +362,7 @@ int setup_v2_joint(sprk_engine* h) {
             HIP_TRY(hipDeviceSynchronize());
             // rows that cannot all sit in the 256 MB Infinity Cache come from HBM: the form that reads its weight fragments first
             h->v2j1_hoist = h->tune.v2j1_hoist >= 0 ? h->tune.v2j1_hoist != 0 : h->derived_bytes > ((size_t)256 << 20);
-            h->v2j1_waves = V2J1_WAVES_OF(h->v2j1_hoist);
+            h->v2j1_waves = V2J1_WAVES_OF(h->v2j1_hoist, nbig);
             h->v2j1_lds_bytes = ((size_t)ov.image_floats + small_floats + (size_t)h->v2j1_waves * 256) * sizeof(float);
             HIP_TRY(hipFuncSetAttribute(h->v2j1_hoist ? ov.fn_h : ov.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->v2j1_lds_bytes));
         }

@@ -29,7 +29,9 @@
 #ifndef V2J1_WAVES_HOIST
 #define V2J1_WAVES_HOIST 8
 #endif
-#define V2J1_WAVES_OF(HOIST) ((HOIST) ? V2J1_WAVES_HOIST : V2J1_WAVES)
+// (HBM-resident rows AND three gathered fields: config 2 on 8 M-row tables 8.6-8.9 us with eight waves, 8.7-9.0 with sixteen; config 4's two
+//  fields -- 27 M-row table -- 6.1-6.2 against 5.9: r05_02 .. r05_05)
+#define V2J1_WAVES_OF(HOIST, G_BIG) (((HOIST) && (G_BIG) >= 3) ? V2J1_WAVES_HOIST : V2J1_WAVES)
 #ifndef V2J1_DEDUP
 #define V2J1_DEDUP 1                         // [r5] A fragments stored ONCE per (field, n-block) as {hi4 | lo4}: one ds_read_b128 where there were two, the selection fragment built in registers
 #endif
@@ -125,12 +127,12 @@ __device__ unsigned long long g_v2j1_ts[V2J1_TS_WAVES * 8];
 // from HBM the texture path backs up longer and the LDS sits idle meanwhile: 8.9 -> 8.68 us; with cache-resident tables the same
 // move only delays the gathers: 7.26 -> 7.38 us (profiles/r04/experiments/r04_34).  Same arithmetic, same bits.
 template <int G_BIG, int NJF, bool HOIST = false>
-__global__ __launch_bounds__(V2J1_WAVES_OF(HOIST) * 64, 4) void k_deepfm_v2_joint1(const V2JRun A, const int* __restrict__ ids,
+__global__ __launch_bounds__(V2J1_WAVES_OF(HOIST, G_BIG) * 64, 4) void k_deepfm_v2_joint1(const V2JRun A, const int* __restrict__ ids,
                                                                        const float* __restrict__ dense, float* __restrict__ out, int B,
                                                                        int* __restrict__ err, const float* __restrict__ image) {
 #pragma clang fp contract(off)                                          // (pinned: see fma4s / dot4f in k_chain_v2j.h)
     using LD = V2J1Lds<G_BIG>;
-    constexpr int WAVES = V2J1_WAVES_OF(HOIST), KP = 16, H0C = 2;
+    constexpr int WAVES = V2J1_WAVES_OF(HOIST, G_BIG), KP = 16, H0C = 2;
     constexpr unsigned RB = (KP + 16) * 4;
     static_assert(G_BIG >= 1 && G_BIG <= 3 && NJF >= 1 && NJF <= V2J_MAX_JF, "field split");
     const int tid = threadIdx.x;

@@ -65,8 +65,11 @@ struct DinFusedRun {
     // UNF: columns unf_g[0 .. n_unf) of the tail's column list arrive as RAW rows Etab (k_din_tail.h: [hi 32 halfs | lo 32 halfs] * e_scale,
     // 128 bytes per id, an all-zero row at index vocab) and meet their A fragments (image + total_pad) on the matrix pipe; the other
     // columns stay folded rows (col[0 .. n_cols)).  n_unf = 0: every column folded.
-    int n_unf, ucol[2], uvocab[2];       // (col / tvocab / Ftab / n_cols above: the FOLDED columns only, these: the raw-row columns)
-    const _Float16* Etab[2];
+    // [r5] emb_dim <= 16 (KC = 1, DIN.py as written): n_unf = 2 means BOTH K = 32 blocks of k_din_tail's emb_dim <= 16 form -- columns (0, 1) and
+    // (2, 3) of the tail's column list, rows of [16 hi halfs | 16 lo halfs] = 64 bytes per id; lane (r, q) takes column 2 pb + (q >> 1), half
+    // q & 1 -- i.e. EVERY embedding column is a raw row (n_cols = 0 folded ones, n_ucols of the four slots exist).
+    int n_unf, ucol[4], uvocab[4], n_ucols;   // (col / tvocab / Ftab / n_cols above: the FOLDED columns only, these: the raw-row columns)
+    const _Float16* Etab[4];
     float e_unscale;
     int b0_slot;                          // fc0's bias rides in this (free) numeric slot against a constant 1; -1: added by the VALU
     const float* image;                   // DinFusedImg, built once by k_din_fused_pack
@@ -106,7 +109,7 @@ __global__ __launch_bounds__(256) void k_din_fused_pack(const float* __restrict_
                                                         float w0p_scale, int EL, const float* __restrict__ b0, const float* __restrict__ a0,
                                                         const float* __restrict__ w1frag, const float* __restrict__ b1,
                                                         const float* __restrict__ a1, const float* __restrict__ hw, int n_hw,
-                                                        float* __restrict__ img, const float* __restrict__ w0efrag, int n_unf, int unf_g0, int unf_g1) {
+                                                        float* __restrict__ img, const float* __restrict__ w0efrag, int n_unf, int unf_g0, int unf_g1, int nblk) {
     using IM = DinFusedImg;
     const int tid = threadIdx.x;
     _Float16* wp = reinterpret_cast<_Float16*>(img + IM::off_w0p);
@@ -137,7 +140,8 @@ __global__ __launch_bounds__(256) void k_din_fused_pack(const float* __restrict_
     for (int i = IM::total_pad + IM::unf_floats + tid; i < IM::dma_floats; i += 256) img[i] = 0.f;
     for (int i = tid; i < IM::unf_floats; i += 256) {
         const int w = i & 511, nb = (i >> 9) % IM::N0C, u = i / (512 * IM::N0C);
-        img[IM::total_pad + i] = (w0efrag && u < n_unf) ? w0efrag[((size_t)(nb * 4 + (u == 0 ? unf_g0 : unf_g1)) * 2) * 256 + w] : 0.f;
+        // (nblk: the blocks per output block in k_din_tail's fragment buffer -- 4 columns for emb_dim 17..32, 2 column PAIRS for emb_dim <= 16)
+        img[IM::total_pad + i] = (w0efrag && u < n_unf) ? w0efrag[((size_t)(nb * nblk + (u == 0 ? unf_g0 : unf_g1)) * 2) * 256 + w] : 0.f;
     }
 }
 
@@ -289,7 +293,7 @@ __global__ __launch_bounds__(DF_WAVES * 64, 2) void k_din_fused(const DinFusedRu
     unsigned maxid = 0;                                   // the largest id seen (as unsigned: a negative id is huge): ONE range check at the end
     df_h2 cch[NP], ccl[NP];                               // c' = c sH kappa of this lane's k = EL q + e, split into halfs, as pairs
     f32x4 acc_init[2], cp[KC];
-    constexpr bool UNFK = TAIL && KC == 2;
+    constexpr bool UNFK = TAIL;                           // ([r5] KC = 1 too: the two column-pair blocks of emb_dim <= 16)
     f32x4 er[UNFK ? 4 : 1];
     bool tbad = false;
     int tid_g[DT_MAX_COLS];                               // the tail's embedding columns' ids
@@ -324,7 +328,39 @@ __global__ __launch_bounds__(DF_WAVES * 64, 2) void k_din_fused(const DinFusedRu
         }
     }
     auto unf_load = [&]() {
-        if constexpr (UNFK) {
+        if constexpr (UNFK && KC == 1) {
+            // emb_dim <= 16: block pb = columns 2 pb and 2 pb + 1 of the tail's list, this lane's is 2 pb + (q >> 1), its 16 + 16 bytes are
+            // hi / lo halfs 8 (q & 1) .. + 7 of sample r's row.  Two tables per block, so the address is a 64-bit register pair.
+            const bool raw = tail_wave && A.n_unf > 0;       // (wave-uniform)
+            const bool up = (q >> 1) != 0;
+            // (every field of the kernel argument is made a SCALAR before a lane chooses between two of them: left as `up ? A.x[g1] : A.x[g0]`
+            //  hipcc turned the select of two kernarg loads into ONE global_load from the kernarg segment at a lane-dependent address,
+            //  followed by a vmcnt(0) -- four serial round trips in the prologue, each draining the image's DMA: build/sparrow.s, round 5)
+            auto sc = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
+            auto scp = [](const _Float16* p) {
+                const unsigned long long u = (unsigned long long)p;
+                const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+                return reinterpret_cast<const _Float16*>(((unsigned long long)hi << 32) | lo);
+            };
+            const int n_uc = sc(A.n_ucols), voc_z = sc(A.uvocab[0]);
+            const _Float16* tab_z = scp(A.Etab[0]);
+#pragma unroll
+            for (int pb = 0; pb < 2; ++pb) {
+                const int g0 = 2 * pb, g1 = 2 * pb + 1;      // (static indices into the kernel argument's arrays)
+                const int col0 = sc(A.ucol[g0]), col1 = sc(A.ucol[g1]), voc0 = sc(A.uvocab[g0]), voc1 = sc(A.uvocab[g1]);
+                const _Float16 *tab0 = scp(A.Etab[g0]), *tab1 = scp(A.Etab[g1]);
+                const bool present = (up ? g1 : g0) < n_uc;
+                const int id = raw ? ids_s[r * A.idp + (up ? col1 : col0)] : -1;
+                const int voc = present ? (up ? voc1 : voc0) : voc_z;
+                const _Float16* tab = present ? (up ? tab1 : tab0) : tab_z;      // an absent column: column 0's all-zero row
+                const bool ok = raw && present && (unsigned)id < (unsigned)voc;
+                tbad |= raw && present && !ok && id != -1;
+                const char* row = raw ? reinterpret_cast<const char*>(tab) + (size_t)(ok ? id : voc) * 64 + 16 * (q & 1)
+                                      : reinterpret_cast<const char*>(A.tsplit) + 16 * (q & 1);   // (no raw rows: valid bytes nobody looks at)
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(er[2 * pb]) : "v"(row));
+                asm volatile("global_load_dwordx4 %0, %1, off offset:32" : "=&v"(er[2 * pb + 1]) : "v"(row));
+            }
+        } else if constexpr (UNFK) {
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 // (unconditional: a wave or a column without raw rows reads the first bytes of the history table, and nobody looks)
@@ -733,7 +769,7 @@ __global__ __launch_bounds__(DF_WAVES * 64, 2) void k_din_fused(const DinFusedRu
                 for (int nb = 0; nb < N0C; ++nb) z0[nb] += ld4(img_s + IM::off_b0 + nb * 16 + 4 * q);
             }
         }
-        if constexpr (KC == 2) {
+        {   // (KC = 2: up to two large-vocabulary columns; KC = 1: the two column-pair blocks -- the same fragments' layout, the same chain)
             const float* wf = img_s + IM::total_pad + lane * 4;
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
