@@ -1334,7 +1334,7 @@ def serving_workload(args):
     pct = lambda p: lat[min(len(lat) - 1, int(p * len(lat)))] * 1e3
     # [r5] past one GIL: serving.serve_workers -- N worker processes, one engine each, one port (SO_REUSEPORT) -- under N clients
     workers_blk = {}
-    n_workers = int(os.environ.get("SPRK_BENCH_SERVING_WORKERS", "8"))
+    n_workers = int(os.environ.get("SPRK_BENCH_SERVING_WORKERS", "12"))
     if n_workers > 1:
         try:
             from bench_serving import _neuralcf
@@ -1342,7 +1342,8 @@ def serving_workload(args):
             pool = serve_workers(_neuralcf, (), n_workers=n_workers, port=0)
             try:
                 qw = ctx.Queue()
-                cl = [ctx.Process(target=_client, args=(pool.port, bodies, seconds, n_inst, k, qw)) for k in range(n_workers)]
+                n_clients = 8
+                cl = [ctx.Process(target=_client, args=(pool.port, bodies, seconds, n_inst, k, qw)) for k in range(n_clients)]
                 for c_ in cl:
                     c_.start()
                 latw = []
@@ -1351,10 +1352,10 @@ def serving_workload(args):
                 for c_ in cl:
                     c_.join(timeout=30)
                 latw.sort()
-                workers_blk = {"workers": n_workers, "workers_clients": n_workers, "requests_per_sec_workers": len(latw) / seconds,
+                workers_blk = {"workers": n_workers, "workers_clients": n_clients, "requests_per_sec_workers": len(latw) / seconds,
                                "latency_ms_workers": {"p50": latw[len(latw) // 2] * 1e3, "p99": latw[min(len(latw) - 1, int(0.99 * len(latw)))] * 1e3},
-                               "workers_note": "serving.serve_workers: %d processes, one NeuralCF engine each, one port (SO_REUSEPORT), %d keep-alive clients "
-                                               "in their own processes" % (n_workers, n_workers)}
+                               "workers_note": "serving.serve_workers: %d front processes on one port (SO_REUSEPORT) + ONE engine process with the NeuralCF "
+                                               "model, %d keep-alive clients in their own processes" % (n_workers, n_clients)}
             finally:
                 pool.close()
         except Exception as e:                                   # (reported, not fatal: the one-process figures above stand on their own)

@@ -47,7 +47,7 @@ def main():
     ap.add_argument("--clients", type=int, default=16)
     ap.add_argument("--seconds", type=float, default=5.0)
     ap.add_argument("--instances", type=int, default=800)
-    ap.add_argument("--workers", type=int, default=1, help="server worker processes behind one port (serving.serve_workers, SO_REUSEPORT)")
+    ap.add_argument("--workers", type=int, default=1, help="front processes behind one port (serving.serve_workers: SO_REUSEPORT fronts, ONE engine process with the model)")
     a = ap.parse_args()
     import numpy as np
     from sparrowrecsys_amd import models as M
@@ -87,7 +87,7 @@ def main():
                       "candidates_per_sec": round(len(lat) * a.instances / wall), "latency_ms": {"p50": pct(0.5), "p90": pct(0.9), "p99": pct(0.99)},
                       "workers": a.workers,
                       "server": "sparrowrecsys_amd.serving.PredictServer (ThreadingHTTPServer + micro-batcher)%s, model NeuralCF"
-                                % (" x %d worker processes on one port (SO_REUSEPORT)" % a.workers if a.workers > 1 else "")}))
+                                % (" x %d front processes on one port (SO_REUSEPORT) + one engine process" % a.workers if a.workers > 1 else "")}))
 
 
 if __name__ == "__main__":

@@ -48,6 +48,9 @@
 
 #define DF_WAVES 8
 #define DF_MB 16
+#ifndef DF_LATE_IMAGE
+#define DF_LATE_IMAGE 1                   // [r5] one batch per launch: the tail's image (88 KB per workgroup) and the raw tail rows are requested BEHIND the first
+#endif                                    // trip of the slot loop, not in front of it (below)
 struct DinFusedRun {
     // ---- activation unit + pooling (as DinColsRun) ----
     int T, F, hist_col, cand_col, Dp, vocab;
@@ -394,22 +397,29 @@ __global__ __launch_bounds__(DF_WAVES * 64, 2) void k_din_fused(const DinFusedRu
         else
             asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(rw[0]) : "v"(voff), "s"(tbase));
     };
-    load(0, rowA); load(1, rowB); load(2, rowC); load(3, rowD);   // (unconditional: no path on which these registers are anything else)
-    // ---- LDS-DMA, 1-KB pieces, a COMPILE-TIME number per wave (the waits count them): the attention's coefficient tables (wave w
-    // takes w, w + 8, w + 16; a piece past the end repeats the last), then TAIL: the tail's image (weights as fragments, 88 KB).
-    // Nothing reads the image before the epilogue; requested first (round 4's first form) it sat in front of the ids and the first
-    // rows in every queue: 6.4 us from kernel entry to the first slot against 3.4 us without a tail (profiles/r04, the stamped timeline)
+    // [r5] LATE: round 4's prologue ended with "the second round trip moves 27 KB per wave at the moment every wave of the chip does the
+    // same" (3.9 us in the stamped timeline) -- 11 KB of it this wave's share of the tail's image, wanted 25 us later.  Now the image's
+    // pieces and the raw tail rows go out AFTER the first trip and land under the second; the coefficient pieces go out in FRONT of the first
+    // row sets so that one vmcnt says "everything but the rows".
+    constexpr bool LATE = TAIL && !MB && (DF_LATE_IMAGE != 0);
     constexpr int NCW = (DF_COEF_FLOATS / 256 + DF_WAVES - 1) / DF_WAVES;
-    constexpr int NPW = (TAIL && !MB) ? IM::pieces_per_wave : 0;
-    if constexpr (!MB) {
+    auto coef_dma = [&]() {
 #pragma unroll
         for (int i = 0; i < NCW; ++i) {
             const int c = min(wave + DF_WAVES * i, DF_COEF_FLOATS / 256 - 1);
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(A.coef + c * 256 + lane * 4),
                                              (__attribute__((address_space(3))) void*)(smem + c * 256), 16, 0, 0);
         }
-    }
-    if constexpr (TAIL && !MB) {
+    };
+    if constexpr (LATE) coef_dma();
+    load(0, rowA); load(1, rowB); load(2, rowC); load(3, rowD);   // (unconditional: no path on which these registers are anything else)
+    // ---- LDS-DMA, 1-KB pieces, a COMPILE-TIME number per wave (the waits count them): the attention's coefficient tables (wave w
+    // takes w, w + 8, w + 16; a piece past the end repeats the last), then TAIL: the tail's image (weights as fragments, 88 KB).
+    // Nothing reads the image before the epilogue; requested first (round 4's first form) it sat in front of the ids and the first
+    // rows in every queue: 6.4 us from kernel entry to the first slot against 3.4 us without a tail (profiles/r04, the stamped timeline)
+    constexpr int NPW = (TAIL && !MB) ? IM::pieces_per_wave : 0;
+    if constexpr (!MB && !LATE) coef_dma();
+    auto image_dma = [&]() {
 #pragma unroll
         for (int i = 0; i < NPW; ++i) {
             const int c = wave + DF_WAVES * i;
@@ -417,15 +427,17 @@ __global__ __launch_bounds__(DF_WAVES * 64, 2) void k_din_fused(const DinFusedRu
                                              (__attribute__((address_space(3))) void*)(img_s + c * 256), 16, 0, 0);
         }
         unf_load();
-    }
+    };
+    if constexpr (TAIL && !MB && !LATE) image_dma();
+    constexpr int NW0 = LATE ? 4 * KC : NPW + NU;             // younger operations at the wait below: the four row sets, or the image's pieces + raw rows
     // everything but the image pieces (and the raw rows behind them) has landed: this wave's coefficient pieces, the second round trip,
     // the first four row sets
     // (volatile statements keep their order: the empty ones tie the remaining registers to the wait in front of them)
     if constexpr (MB || AWL)
-        asm volatile("s_waitcnt vmcnt(%3)" : "+v"(cp[0]), "+v"(acc_init[0]), "+v"(acc_init[1]) : "n"(NPW + NU));
+        asm volatile("s_waitcnt vmcnt(%3)" : "+v"(cp[0]), "+v"(acc_init[0]), "+v"(acc_init[1]) : "n"(NW0));
     else
         asm volatile("s_waitcnt vmcnt(%11)" : "+v"(cp[0]), "+v"(acc_init[0]), "+v"(acc_init[1]), "+v"(aWr[0][0]), "+v"(aWr[0][1]), "+v"(aWr[0][2]),
-                     "+v"(aWr[0][3]), "+v"(aWr[1][0]), "+v"(aWr[1][1]), "+v"(aWr[1][2]), "+v"(aWr[1][3]) : "n"(NPW + NU));
+                     "+v"(aWr[0][3]), "+v"(aWr[1][0]), "+v"(aWr[1][1]), "+v"(aWr[1][2]), "+v"(aWr[1][3]) : "n"(NW0));
     if constexpr (KC == 2) asm volatile("" : "+v"(cp[KC - 1]));
     if constexpr (TAIL) asm volatile("" : "+v"(xna), "+v"(xnb));          // (tied to the wait above: the oldest loads of the task)
     if constexpr (UNFK && MB) asm volatile("" : "+v"(er[0]), "+v"(er[UNFK ? 1 : 0]), "+v"(er[UNFK ? 2 : 0]), "+v"(er[UNFK ? 3 : 0]));
@@ -463,6 +475,82 @@ __global__ __launch_bounds__(DF_WAVES * 64, 2) void k_din_fused(const DinFusedRu
         for (int nb = 0; nb < 2; ++nb) acc_init[nb] = acc_init[nb] * A.acc_scale;
     }
     f32x4 z0[TAIL ? N0C : 1];
+    // fc0_front: z0 = numerics (f32 MFMA; fc0's bias in the free numeric slot) + the raw-row columns (split f16 MFMA) + the folded columns'
+    // rows -- everything of the tail's first layer that does NOT need the pooled vector; the pooled history follows in the epilogue.
+    // [r5] Measured and NOT kept (profiles/r05/experiments/r05_08): this part computed INSIDE the slot loop, wave w in front of trip 2 + w
+    // (folded rows as hidden loads behind a manual vmcnt(0)), on the theory that the loop is fabric-bound and a wave's own chain has slack.
+    // The stamped timeline: fc0 in the epilogue 3.6 -> 0.9 us, but the slot loop 24.2 -> 27.0 us -- the drained prefetch ring and the
+    // 64 MFMAs are NOT hidden by the other seven waves; 38.7 against 37.9 us per launch.
+    bool tb2_front = false;                                   // (a folded column's id outside its table)
+    auto fc0_front = [&]() {
+        if constexpr (TAIL) {
+        // (two columns = 16 loads in flight; with raw-row columns the folded ones ARE two -- DIN.py's genre columns)
+        f32x4 f[2][N0C];
+        auto fold_load = [&](int g0) {
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                // folded rows straight into the accumulators' layout (lane (r,q): outputs 16 nb + 4q .. + 3 of sample r)
+                const int id = g0 == 0 ? tid_g[g] : tid_g[2 + g];
+                const int voc = g0 == 0 ? A.tvocab[g] : A.tvocab[2 + g];
+                const float* tab = g0 == 0 ? A.Ftab[g] : A.Ftab[2 + g];
+                const bool ok = g0 + g < A.n_cols && (unsigned)id < (unsigned)voc;
+                tb2_front |= g0 + g < A.n_cols && !ok && id != -1;
+                const float* frow = tab + (size_t)(ok ? id : 0) * IM::N0 + 4 * q;
+#pragma unroll
+                for (int nb = 0; nb < N0C; ++nb) f[g][nb] = (ok && !(XP & 128)) ? ld4(frow + nb * 16) : zero;
+            }
+        };
+        fold_load(0);                                          // (requested first, under the matrix work below)
+        // the numeric chunk: A = W0^T[n][numeric q + 4 s] (one scalar LDS read per block and step), two f32 MFMAs per 16 outputs;
+        // fc0's bias rides in numeric slot b0_slot against a constant 1 (else it is added here)
+#pragma unroll
+        for (int nb = 0; nb < N0C; ++nb) z0[nb] = zero;
+        if constexpr (!(XP & 512)) {
+            // slot n_num carries 1.0 against fc0's bias (b0_slot); slots beyond duplicate a finite value that only ever meets zero weights
+            const float xa1 = q == A.b0_slot ? 1.0f : xna;
+            const float xb1 = q + 4 == A.b0_slot ? 1.0f : xnb;
+            const float* wn = img_s + IM::off_wn + lane;
+#pragma unroll
+            for (int nb = 0; nb < N0C; ++nb) z0[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wn[(nb * 2 + 0) * 64], xa1, z0[nb], 0, 0, 0);
+#pragma unroll
+            for (int nb = 0; nb < N0C; ++nb) z0[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wn[(nb * 2 + 1) * 64], xb1, z0[nb], 0, 0, 0);
+            if (A.b0_slot < 0) {
+#pragma unroll
+                for (int nb = 0; nb < N0C; ++nb) z0[nb] += ld4(img_s + IM::off_b0 + nb * 16 + 4 * q);
+            }
+        }
+        {   // (KC = 2: up to two large-vocabulary columns; KC = 1: the two column-pair blocks -- the same fragments' layout, the same chain)
+            const float* wf = img_s + IM::total_pad + lane * 4;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                if (u < A.n_unf) {                                // (wave-uniform)
+#pragma unroll
+                    for (int nb = 0; nb < N0C; ++nb) {
+                        const din_f16x8 ah = __builtin_bit_cast(din_f16x8, ld4(wf + (u * N0C + nb) * 512));
+                        const din_f16x8 al = __builtin_bit_cast(din_f16x8, ld4(wf + (u * N0C + nb) * 512 + 256));
+                        f32x4 acc = mfma_f16(al, eh[u], zero);
+                        acc = mfma_f16(ah, el[u], acc);
+                        acc = mfma_f16(ah, eh[u], acc);
+                        z0[nb] += acc * A.e_unscale;
+                    }
+                }
+            }
+        }
+        {
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+#pragma unroll
+                for (int nb = 0; nb < N0C; ++nb) z0[nb] += f[g][nb];
+            if (A.n_cols > 2) {                                   // (wave-uniform) every column folded: the second pair, a round trip of its own
+                fold_load(2);
+#pragma unroll
+                for (int g = 0; g < 2; ++g)
+#pragma unroll
+                    for (int nb = 0; nb < N0C; ++nb) z0[nb] += f[g][nb];
+            }
+        }
+        }
+    };
     if constexpr (!MB && !AWL) __builtin_amdgcn_s_barrier();      // coefficient tables staged by every wave
     stamp(1);
 
@@ -658,7 +746,14 @@ __global__ __launch_bounds__(DF_WAVES * 64, 2) void k_din_fused(const DinFusedRu
             // the first trip runs under the image's DMA (its pieces are younger than the four row sets it waits for), by EVERY wave
             // (one without slots works on zero weights), then the wave's pieces have landed -- at most the four re-requested row
             // sets stay in flight -- and the workgroup meets once more: from here on the image is readable by all of it
-            trip(0, DfInt<NPW + NU>{});
+            if constexpr (LATE) {
+                trip(0, DfInt<0>{});
+                image_dma();                                      // (younger than the four row sets trip 0 re-requested)
+                if (4 < nsteps && 4 == qnext) { park(jq); ++jq; qnext += A.ql; }
+                trip(4, DfInt<NPW + NU>{});                       // (a wave with at most four slots: zero weights)
+            } else {
+                trip(0, DfInt<NPW + NU>{});
+            }
             if constexpr (UNFK)
                 asm volatile("s_waitcnt vmcnt(%4)" : "+v"(er[0]), "+v"(er[UNFK ? 1 : 0]), "+v"(er[UNFK ? 2 : 0]), "+v"(er[UNFK ? 3 : 0]) : "n"(4 * KC));
             else
@@ -666,7 +761,7 @@ __global__ __launch_bounds__(DF_WAVES * 64, 2) void k_din_fused(const DinFusedRu
 #pragma unroll
             for (int u = 0; u < (UNFK ? 2 : 0); ++u) { eh[u] = __builtin_bit_cast(din_f16x8, er[2 * u]); el[u] = __builtin_bit_cast(din_f16x8, er[2 * u + 1]); }
             __builtin_amdgcn_s_barrier();
-            step = 4;
+            step = LATE ? 8 : 4;
         }
         for (; step < nsteps; step += 4) {
             if (step == qnext) { park(jq); ++jq; qnext += A.ql; }
@@ -731,61 +826,9 @@ __global__ __launch_bounds__(DF_WAVES * 64, 2) void k_din_fused(const DinFusedRu
         if constexpr (MB) continue; else return;
     } else {
         // ================= the tail (DIN.py:161-167) for this wave's sixteen samples: registers and LDS only =================
-        // fc0 = numerics (f32 MFMA) + UNF columns + pooled history (split f16 MFMA) + folded rows.  The folded rows' loads go out
-        // FIRST and are added LAST: the matrix work in between needs registers and LDS only.
-        bool tb2 = false;
-        // (two columns = 16 loads in flight; with raw-row columns the folded ones ARE two -- DIN.py's genre columns)
-        f32x4 f[2][N0C];
-        auto fold_load = [&](int g0) {
-#pragma unroll
-            for (int g = 0; g < 2; ++g) {
-                // folded rows straight into the accumulators' layout (lane (r,q): outputs 16 nb + 4q .. + 3 of sample r)
-                const int id = g0 == 0 ? tid_g[g] : tid_g[2 + g];
-                const int voc = g0 == 0 ? A.tvocab[g] : A.tvocab[2 + g];
-                const float* tab = g0 == 0 ? A.Ftab[g] : A.Ftab[2 + g];
-                const bool ok = g0 + g < A.n_cols && (unsigned)id < (unsigned)voc;
-                tb2 |= g0 + g < A.n_cols && !ok && id != -1;
-                const float* frow = tab + (size_t)(ok ? id : 0) * IM::N0 + 4 * q;
-#pragma unroll
-                for (int nb = 0; nb < N0C; ++nb) f[g][nb] = (ok && !(XP & 128)) ? ld4(frow + nb * 16) : zero;
-            }
-        };
-        fold_load(0);
-        // the numeric chunk: A = W0^T[n][numeric q + 4 s] (one scalar LDS read per block and step), two f32 MFMAs per 16 outputs;
-        // fc0's bias rides in numeric slot b0_slot against a constant 1 (else it is added here)
-#pragma unroll
-        for (int nb = 0; nb < N0C; ++nb) z0[nb] = zero;
-        if constexpr (!(XP & 512)) {
-            // slot n_num carries 1.0 against fc0's bias (b0_slot); slots beyond duplicate a finite value that only ever meets zero weights
-            xna = q == A.b0_slot ? 1.0f : xna;
-            xnb = q + 4 == A.b0_slot ? 1.0f : xnb;
-            const float* wn = img_s + IM::off_wn + lane;
-#pragma unroll
-            for (int nb = 0; nb < N0C; ++nb) z0[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wn[(nb * 2 + 0) * 64], xna, z0[nb], 0, 0, 0);
-#pragma unroll
-            for (int nb = 0; nb < N0C; ++nb) z0[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wn[(nb * 2 + 1) * 64], xnb, z0[nb], 0, 0, 0);
-            if (A.b0_slot < 0) {
-#pragma unroll
-                for (int nb = 0; nb < N0C; ++nb) z0[nb] += ld4(img_s + IM::off_b0 + nb * 16 + 4 * q);
-            }
-        }
-        {   // (KC = 2: up to two large-vocabulary columns; KC = 1: the two column-pair blocks -- the same fragments' layout, the same chain)
-            const float* wf = img_s + IM::total_pad + lane * 4;
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                if (u < A.n_unf) {                                // (wave-uniform)
-#pragma unroll
-                    for (int nb = 0; nb < N0C; ++nb) {
-                        const din_f16x8 ah = __builtin_bit_cast(din_f16x8, ld4(wf + (u * N0C + nb) * 512));
-                        const din_f16x8 al = __builtin_bit_cast(din_f16x8, ld4(wf + (u * N0C + nb) * 512 + 256));
-                        f32x4 acc = mfma_f16(al, eh[u], zero);
-                        acc = mfma_f16(ah, el[u], acc);
-                        acc = mfma_f16(ah, eh[u], acc);
-                        z0[nb] += acc * A.e_unscale;
-                    }
-                }
-            }
-        }
+        // fc0 = [numerics (f32 MFMA) + bias + raw-row columns (split f16 MFMA) + folded rows] (fc0_front) + the pooled history (split f16 MFMA)
+        fc0_front();
+        bool tb2 = tb2_front;
         // the pooled history on the f16 pipe, from the registers it was accumulated in (k = EL q + e): per-sample dynamic scale
         // (DIN's attention weights are not normalised), hi / lo split, three products per 16 outputs
         if constexpr (XP & 512) { z0[0][0] += res[0]; } else {
@@ -810,17 +853,6 @@ __global__ __launch_bounds__(DF_WAVES * 64, 2) void k_din_fused(const DinFusedRu
                 acc = mfma_f16(ah, bh, acc);
                 z0[nb] += acc * inv;
             }
-        }
-#pragma unroll
-        for (int g = 0; g < 2; ++g)
-#pragma unroll
-            for (int nb = 0; nb < N0C; ++nb) z0[nb] += f[g][nb];
-        if (A.n_cols > 2) {                                     // (wave-uniform) every column folded: the second pair, a round trip of its own
-            fold_load(2);
-#pragma unroll
-            for (int g = 0; g < 2; ++g)
-#pragma unroll
-                for (int nb = 0; nb < N0C; ++nb) z0[nb] += f[g][nb];
         }
         if (__ballot(tb2) != 0 && lane == 0) atomicOr(err, 1);
         if constexpr ((XP & 1024) != 0) { if (z0[0][0] + z0[7][3] == 123.456f) stamp(7); }   // (the stamp below waits for fc0's results)

@@ -474,15 +474,100 @@ class PredictServer:
 # ---------------------------------------------------------------------------------------------------------------------------
 # [r5] Several worker PROCESSES behind one port.  One Python process is one GIL: however many clients, the HTTP + JSON work of this
 # shim tops out near 4 000 requests of 800 candidates per second (profiles/r04/experiments/r04_24), while the forward behind it takes
-# microseconds.  serve_workers starts N processes, each with its OWN model + engine (NeuralCF's tables are 1.3 MB; every worker's
-# HIP context shares the one GPU) and its own PredictServer bound to the same (host, port) with SO_REUSEPORT: the kernel hands each
-# new connection to one of them (Jetty's HttpClient opens one per request thread, RecForYouProcess.java:113-138).  Micro-batching
-# stays per worker.
+# microseconds.  serve_workers starts N FRONT processes -- each a PredictServer bound to the same (host, port) with SO_REUSEPORT, so the
+# kernel hands each new connection to one of them (Jetty's HttpClient opens one per request thread, RecForYouProcess.java:113-138) --
+# and ONE engine process that owns the model and the GPU.  A front parses the request and hands the packed feature columns to the
+# engine over a Unix-domain connection; the engine loop takes whatever requests are waiting on ANY front, merges those with the same
+# feature set into one model.predict, and sends each front its slice (so concurrent clients are micro-batched ACROSS fronts too).
+# Measured first and not kept (profiles/r05/experiments/r05_05): an engine per worker process -- eight HIP contexts time-slicing one
+# GPU: 5 993 requests/s from 8 clients against 4 416 from one process, p99 13 ms, and a lone client fell from 3 364 to 1 514 requests/s.
 # ---------------------------------------------------------------------------------------------------------------------------
-def _worker_main(factory, fargs, name, host, port, defaults, ready, stop):
+class _EngineProxy:
+    """What a front process hands PredictServer as its model: predict(feats) = one round trip to the engine process."""
+
+    def __init__(self, address):
+        from multiprocessing.connection import Client
+        self.conn = Client(address, family="AF_UNIX")
+        self._lock = threading.Lock()
+
+    def predict(self, feats):
+        with self._lock:                                         # (PredictServer runs one forward at a time anyway)
+            self.conn.send(feats)
+            kind, payload = self.conn.recv()
+        if kind == "ok":
+            return payload
+        if kind == "value_error":
+            raise ValueError(payload)
+        raise RuntimeError(payload)
+
+
+def _engine_main(factory, fargs, address, ready, stop):
+    """The engine process: builds the model, then serves the fronts' connections -- every pass takes ALL requests that are waiting,
+    merges the ones with equal feature sets into one forward, answers each front."""
+    from multiprocessing.connection import Listener, wait
     try:
         model = factory(*fargs)
-        srv = PredictServer(model, name=name, host=host, port=port, defaults=defaults, reuse_port=True).start()
+        listener = Listener(address, family="AF_UNIX")
+    except Exception as e:
+        ready.put((os.getpid(), 0, "%s: %s" % (type(e).__name__, e)))
+        return
+    ready.put((os.getpid(), 0, None))
+    conns = []
+    accept_q = queue.Queue()
+
+    def acceptor():
+        while not stop.is_set():
+            try:
+                accept_q.put(listener.accept())
+            except Exception:
+                return
+    threading.Thread(target=acceptor, daemon=True).start()
+
+    def answer(conn, feats):
+        try:
+            conn.send(("ok", np.asarray(model.predict(feats), dtype=np.float32).reshape(-1)))
+        except ValueError as e:
+            conn.send(("value_error", str(e)))
+        except Exception as e:
+            conn.send(("error", "%s: %s" % (type(e).__name__, e)))
+    while not stop.is_set():
+        while not accept_q.empty():
+            conns.append(accept_q.get())
+        if not conns:
+            time.sleep(0.01)
+            continue
+        got = []
+        for c in wait(conns, timeout=0.05):
+            try:
+                got.append((c, c.recv()))
+            except (EOFError, OSError):
+                conns.remove(c)
+        if not got:
+            continue
+        groups = {}
+        for c, feats in got:
+            groups.setdefault(tuple(sorted(feats)), []).append((c, feats))
+        for members in groups.values():
+            if len(members) == 1:
+                answer(*members[0])
+                continue
+            sizes = [len(next(iter(f.values()))) for _, f in members]
+            try:
+                merged = {k: np.concatenate([f[k] for _, f in members]) for k in members[0][1]}
+                out = np.asarray(model.predict(merged), dtype=np.float32).reshape(-1)
+                pos = 0
+                for (c, _), n in zip(members, sizes):
+                    c.send(("ok", out[pos:pos + n]))
+                    pos += n
+            except Exception:                                    # one bad request must not fail its neighbours: each on its own
+                for c, f in members:
+                    answer(c, f)
+    listener.close()
+
+
+def _front_main(address, name, host, port, defaults, ready, stop):
+    try:
+        srv = PredictServer(_EngineProxy(address), name=name, host=host, port=port, defaults=defaults, reuse_port=True).start()
         ready.put((os.getpid(), srv.port, None))
         stop.wait()
         srv.close()
@@ -491,10 +576,10 @@ def _worker_main(factory, fargs, name, host, port, defaults, ready, stop):
 
 
 class WorkerPool:
-    """``serve_workers``' handle: ``port``, ``pids``; ``close()`` stops the workers."""
+    """``serve_workers``' handle: ``port``, ``pids`` (the fronts), ``engine_pid``; ``close()`` stops everything."""
 
-    def __init__(self, procs, stop, port, pids):
-        self.procs, self._stop, self.port, self.pids = procs, stop, port, pids
+    def __init__(self, procs, stop, port, pids, engine_pid, tmpdir):
+        self.procs, self._stop, self.port, self.pids, self.engine_pid, self._tmpdir = procs, stop, port, pids, engine_pid, tmpdir
 
     def close(self):
         self._stop.set()
@@ -502,33 +587,43 @@ class WorkerPool:
             p.join(timeout=10)
             if p.is_alive():
                 p.terminate()
+        if self._tmpdir:
+            import shutil
+            shutil.rmtree(self._tmpdir, ignore_errors=True)
 
 
 def serve_workers(factory, fargs=(), n_workers: int = 4, name: str = "recmodel", host: str = "127.0.0.1", port: int = 8501,
                   defaults: Optional[Mapping[str, object]] = None, start_method: str = "spawn", timeout_s: float = 300.0) -> WorkerPool:
-    """Starts ``n_workers`` processes that each call ``factory(*fargs)`` (picklable: a module-level function) for their model and serve
-    it on the same ``host:port`` (``port=0``: the first worker picks a free one, the others join it).  Returns when every worker
-    answers; raises what a worker raised."""
+    """Starts ONE engine process that calls ``factory(*fargs)`` (picklable: a module-level function) for the model, and ``n_workers`` front
+    processes that serve it on the same ``host:port`` (``port=0``: the first front picks a free one, the others join it).  Returns
+    when every process answers; raises what one of them raised."""
     import multiprocessing as mp
+    import tempfile
     ctx = mp.get_context(start_method)
     ready, stop = ctx.Queue(), ctx.Event()
+    tmpdir = tempfile.mkdtemp(prefix="sprk_serving_")
+    address = os.path.join(tmpdir, "engine.sock")
     procs, pids = [], []
+
+    def take():
+        pid, got, err = ready.get(timeout=timeout_s)
+        if err:
+            raise RuntimeError("serving process %d failed: %s" % (pid, err))
+        return pid, got
     try:
+        eng = ctx.Process(target=_engine_main, args=(factory, tuple(fargs), address, ready, stop), daemon=True)
+        eng.start()
+        procs.append(eng)
+        engine_pid, _ = take()                                   # (the model is built, the engine listens)
         for i in range(n_workers):
-            p = ctx.Process(target=_worker_main, args=(factory, tuple(fargs), name, host, port, dict(defaults or {}), ready, stop), daemon=True)
+            p = ctx.Process(target=_front_main, args=(address, name, host, port, dict(defaults or {}), ready, stop), daemon=True)
             p.start()
             procs.append(p)
-            if i == 0 or port == 0:                              # the port must be known before the next worker binds it
-                pid, got, err = ready.get(timeout=timeout_s)
-                if err:
-                    raise RuntimeError("serving worker %d failed: %s" % (pid, err))
+            if i == 0 or port == 0:                              # the port must be known before the next front binds it
+                pid, port = take()
                 pids.append(pid)
-                port = got
         while len(pids) < n_workers:
-            pid, got, err = ready.get(timeout=timeout_s)
-            if err:
-                raise RuntimeError("serving worker %d failed: %s" % (pid, err))
-            pids.append(pid)
+            pids.append(take()[0])
     except Exception:
         stop.set()
         for p in procs:
@@ -536,7 +631,7 @@ def serve_workers(factory, fargs=(), n_workers: int = 4, name: str = "recmodel",
             if p.is_alive():
                 p.terminate()
         raise
-    return WorkerPool(procs, stop, port, pids)
+    return WorkerPool(procs, stop, port, pids, engine_pid, tmpdir)
 
 
 def _cli_model(model_name, weights_path):

@@ -358,16 +358,18 @@ def _stub_factory():
 
 
 def test_worker_processes_share_one_port():
-    """serving.serve_workers: N processes, one model each, one port (SO_REUSEPORT).  Every worker answers the Jetty request with the
-    same scores; the status route says which process served, and over a few dozen fresh connections more than one did."""
+    """serving.serve_workers: N front processes on one port (SO_REUSEPORT) in front of ONE engine process that owns the model.  Every
+    front answers the Jetty request with the same scores; the status route says which process served, and over a few dozen fresh
+    connections more than one did; a model-side ValueError crosses the process boundary as HTTP 400; concurrent requests from
+    different fronts come back right (the engine merges them into one forward)."""
     import http.client
     from sparrowrecsys_amd.serving import serve_workers
     pool = serve_workers(_stub_factory, (), n_workers=3, port=0, start_method="fork")
     try:
-        assert len(set(pool.pids)) == 3
+        assert len(set(pool.pids)) == 3 and pool.engine_pid not in pool.pids
         seen = set()
         for i in range(60):
-            c = http.client.HTTPConnection("127.0.0.1", pool.port, timeout=30)   # a fresh connection each: the kernel picks the worker
+            c = http.client.HTTPConnection("127.0.0.1", pool.port, timeout=30)   # a fresh connection each: the kernel picks the front
             c.request("GET", "/v1/models/recmodel")
             seen.add(json.loads(c.getresponse().read())["worker_pid"])
             c.request("POST", "/v1/models/recmodel:predict", body=json.dumps({"instances": [{"userId": 8, "movieId": 3}, {"userId": 9, "movieId": 4}]}),
@@ -378,5 +380,25 @@ def test_worker_processes_share_one_port():
             np.testing.assert_allclose(got["predictions"], [[0.13], [0.24]], atol=1e-6)
             c.close()
         assert seen <= set(pool.pids) and len(seen) >= 2, (seen, pool.pids)
+        code, resp = _post(pool.port, {"instances": [{"userId": 1, "movieId": 5000}]})      # the stub's "outside its table"
+        assert code == 400 and "outside" in resp["error"]
+        results = {}
+
+        def client(i):
+            inst = [{"userId": 100 * i + j, "movieId": (5000 if i == 5 else j)} for j in range(40)]
+            results[i] = _post(pool.port, {"instances": inst})
+        ts = [threading.Thread(target=client, args=(i,)) for i in range(12)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        for i in range(12):
+            code, resp = results[i]
+            if i == 5:
+                assert code == 400                              # its neighbours in a merged forward are not affected
+            else:
+                assert code == 200
+                want = [((100 * i + j) % 7) * 0.1 + (j % 5) * 0.01 for j in range(40)]
+                np.testing.assert_allclose([x[0] for x in resp["predictions"]], want, atol=1e-6)
     finally:
         pool.close()
