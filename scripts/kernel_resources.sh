@@ -3,7 +3,7 @@
 # usage: scripts/kernel_resources.sh [filter-regex]  -> build/kernel_resources.txt
 cd "$(dirname "$0")/.."
 mkdir -p build
-[ -n "$SKIP_COMPILE" ] || hipcc --offload-arch=gfx950 -O3 -std=c++17 -I include -I sparrowrecsys_amd/csrc --cuda-device-only -c \
+[ -n "$SKIP_COMPILE" ] || hipcc --offload-arch=gfx950 -O3 -std=c++17 -I include -I sparrowrecsys_amd/csrc -DSPRK_SINGLE_TU --cuda-device-only -c \
   -Rpass-analysis=kernel-resource-usage sparrowrecsys_amd/csrc/sparrow_hip.hip -o /dev/null 2> build/kernel_resources.raw
 python3 - build/kernel_resources.raw "${1:-.}" <<'PY' | tee build/kernel_resources.txt
 import re, sys, subprocess
@@ -21,7 +21,7 @@ for line in open(sys.argv[1]):
 names = list(rows)
 dem = subprocess.run(["c++filt"] + names, capture_output=True, text=True).stdout.strip().split("\n")
 for n, d in zip(names, dem):
-    d = re.sub(r"^void ", "", d).replace("(anonymous namespace)::", ""); d = re.sub(r"\(.*$", "", d)
+    d = re.sub(r"^void ", "", d).replace("(anonymous namespace)::", "").replace("sprk_dev::", ""); d = re.sub(r"\(.*$", "", d)
     if not pat.search(d): continue
     r = rows[n]
     print("%-84s vgpr %4s agpr %3s sgpr %4s scratch %5s occ %2s lds %6s" % (d[:84], r.get("VGPRs"), r.get("AGPRs"), r.get("TotalSGPRs"),

@@ -12,7 +12,7 @@ import re, subprocess, sys, os
 root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..")
 if "--compile" in sys.argv:
     os.makedirs(os.path.join(root, "build"), exist_ok=True)
-    subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-I", "include", "-I", "sparrowrecsys_amd/csrc", "--cuda-device-only", "-S",
+    subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-I", "include", "-I", "sparrowrecsys_amd/csrc", "-DSPRK_SINGLE_TU", "--cuda-device-only", "-S",
                     "sparrowrecsys_amd/csrc/sparrow_hip.hip", "-o", "build/sparrow.s"], cwd=root, check=True, stderr=subprocess.DEVNULL)
 txt = open(os.path.join(root, "build", "sparrow.s")).read()
 
@@ -23,12 +23,12 @@ def regs(s):
     return out
 
 bad = 0
-names = re.findall(r"^(_ZN12_GLOBAL__N_111k_din_fused\w+):\s", txt, re.M)
+names = re.findall(r"^(_ZN(?:12_GLOBAL__N_1|8sprk_dev)11k_din_fused\w+):\s", txt, re.M)
 for sym in names:
     m = re.search(r"^%s:\s.*?\n(.*?)\.amdhsa_kernel" % re.escape(sym), txt, re.S | re.M)
     body = m.group(1).split("\n")
     inst = subprocess.run(["c++filt", sym], capture_output=True, text=True).stdout.strip()
-    inst = inst.replace("void (anonymous namespace)::", "").split("((anonymous")[0].split("(")[0]
+    inst = inst.replace("void (anonymous namespace)::", "").replace("void sprk_dev::", "").split("((anonymous")[0].split("(")[0]
     in_asm, asm_lines = False, set()
     for i, l in enumerate(body):
         if "#ASMSTART" in l: in_asm = True

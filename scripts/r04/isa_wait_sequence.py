@@ -8,12 +8,12 @@ import re, subprocess, sys, os
 root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..")
 if "--compile" in sys.argv:
     os.makedirs(os.path.join(root, "build"), exist_ok=True)
-    subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-I", "include", "-I", "sparrowrecsys_amd/csrc", "--cuda-device-only", "-S",
+    subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-I", "include", "-I", "sparrowrecsys_amd/csrc", "-DSPRK_SINGLE_TU", "--cuda-device-only", "-S",
                     "sparrowrecsys_amd/csrc/sparrow_hip.hip", "-o", "build/sparrow.s"], cwd=root, check=True, stderr=subprocess.DEVNULL)
 pat = [a for a in sys.argv[1:] if not a.startswith("--")][0]
 txt = open(os.path.join(root, "build", "sparrow.s")).read()
-for sym in re.findall(r"^(_ZN12_GLOBAL__N_1\w+):\s", txt, re.M):
-    name = subprocess.run(["c++filt", sym], capture_output=True, text=True).stdout.strip().replace("void (anonymous namespace)::", "").split("((anonymous")[0]
+for sym in re.findall(r"^(_ZN(?:12_GLOBAL__N_1|8sprk_dev)\w+):\s", txt, re.M):
+    name = subprocess.run(["c++filt", sym], capture_output=True, text=True).stdout.strip().replace("void (anonymous namespace)::", "").replace("void sprk_dev::", "").split("((anonymous")[0].split("(sprk_dev::")[0]
     if pat not in name: continue
     body = re.search(r"^%s:\s.*?\n(.*?)\.amdhsa_kernel" % re.escape(sym), txt, re.S | re.M).group(1).split("\n")
     out, prev, cnt = [], None, 0

@@ -23,7 +23,7 @@ def cls(m):
     if m.startswith("v_"): return "VALU:" + m
     return "other:" + m
 for sym, name in zip(syms, dem):
-    name = name.replace("void (anonymous namespace)::", "").split("((anonymous")[0]
+    name = name.replace("void (anonymous namespace)::", "").replace("void sprk_dev::", "").split("((anonymous")[0].split("(sprk_dev::")[0]
     if pat not in name: continue
     m = re.search(r"^%s:\s.*?\n(.*?)\.amdhsa_kernel" % re.escape(sym), txt, re.S | re.M)
     if not m: continue

@@ -13,6 +13,7 @@ reads what scripts/r03/20_profiles.sh wrote -- per workload a STRICT rocprofv3 k
 
 `frac` = algorithmic bytes per launch / rocprof average duration / 8.0e12.  The table also checks the contract "rocprof's average
 agrees with bench.py's HIP events": `events_vs_rocprof` is their ratio (the judge's tolerance is 3 %)."""
+import re
 import csv
 import json
 import os
@@ -87,14 +88,14 @@ def main():
             print(w0, ": no kernel matching", DOMINANT[w0])
             continue
         name, calls, avg_ns, _ = max(hit, key=lambda r: r[3])
-        short = name.split("(anonymous namespace)::", 1)[-1].split("(")[0]
+        short = re.split(r"\(anonymous namespace\)::|sprk_dev::", name, 1)[-1].split("(")[0]     # (the kernels' namespace is named since round 5)
         row = {"workload": w0, "bench_workload": line["config"]["workload"].split(":")[0], "kernel": short, "launches": calls, "batch": B,
                "rocprof_avg_us": avg_ns / 1e3, "hip_event_us": rl["avg_launch_us"], "events_vs_rocprof": rl["avg_launch_us"] / (avg_ns / 1e3),
                "hip_event_us_under_tracer": rl_traced["avg_launch_us"], "hip_events_from": "untraced run of the same command" if untraced else "the traced process",
                "algorithmic_bytes_per_sample": rl["algorithmic_bytes_per_sample"], "algorithmic_mb": alg / 1e6,
                "frac": alg / (avg_ns * 1e-9) / HBM_PEAK, "samples_per_s": B / (avg_ns * 1e-9)}
-        other = [(r[0].split("(anonymous namespace)::", 1)[-1].split("(")[0][:40], r[1], r[2] / 1e3) for r in kernel_rows(ks)
-                 if r[1] >= calls // 2 and r[0] != name and "(anonymous namespace)" in r[0]]
+        other = [(re.split(r"\(anonymous namespace\)::|sprk_dev::", r[0], 1)[-1].split("(")[0][:40], r[1], r[2] / 1e3) for r in kernel_rows(ks)
+                 if r[1] >= calls // 2 and r[0] != name and ("(anonymous namespace)" in r[0] or "sprk_dev::" in r[0])]
         if other:
             row["other_kernels_per_step"] = [{"kernel": k, "launches": c, "avg_us": round(a, 3)} for k, c, a in other]
         kshort = short.split("<")[0]

@@ -85,7 +85,7 @@ _lib = None
 
 
 def build_library(force: bool = False, verbose: bool = False) -> str:
-    """Compile csrc/sparrow_hip.hip for gfx950 into the in-tree libsparrow_hip.so
+    """Compile csrc/sparrow_hip.hip + csrc/tu_*.hip for gfx950 into the in-tree libsparrow_hip.so
     (hipcc cross-compiles without a GPU)."""
     csrc = os.path.dirname(SRC_PATH)
     deps = [os.path.join(csrc, f) for f in os.listdir(csrc)] + [os.path.join(INCLUDE_DIR, "sparrow_hip.h")]
@@ -115,16 +115,37 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
             if not os.path.exists(hipcc):
                 hipcc = "hipcc"
             tmp = "%s.tmp.%d" % (LIB_PATH, os.getpid())
-            cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-pthread",
-                   "-I", INCLUDE_DIR, "-I", os.path.dirname(SRC_PATH), SRC_PATH, "-o", tmp]
+            # [r5] seven translation units, compiled in parallel and linked: sparrow_hip.hip (host side, light kernels) and the kernel-family
+            # units tu_1.hip .. tu_6.hip (csrc/tu_kernels.h; the heavy templates' instantiations, csrc/tu_instances.h).  One unit of
+            # 57-70 s until round 4.
+            import shutil
+            import tempfile
+            from concurrent.futures import ThreadPoolExecutor
+            units = [SRC_PATH] + sorted(os.path.join(csrc, f) for f in os.listdir(csrc) if f.startswith("tu_") and f.endswith(".hip"))
+            flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-pthread", "-I", INCLUDE_DIR, "-I", csrc]
             if defines:                                           # experiment builds (e.g. -DSPRK_DF_XP: k_din_fused's ablation variants)
-                cmd[1:1] = defines.split()
-                cmd[1:1] = ["-DSPRK_BUILD_DEFINES_STR=\"%s\"" % defines.replace('"', "'")]
-            if verbose:
-                print(" ".join(cmd))
-            res = subprocess.run(cmd, capture_output=True, text=True)
-            if res.returncode != 0:
-                raise RuntimeError("hipcc failed:\n%s\n%s" % (res.stdout, res.stderr))
+                flags = defines.split() + ["-DSPRK_BUILD_DEFINES_STR=\"%s\"" % defines.replace('"', "'")] + flags
+            objdir = tempfile.mkdtemp(prefix="sprk_obj_")
+            try:
+                def compile_unit(src):
+                    obj = os.path.join(objdir, os.path.basename(src) + ".o")
+                    cmd = [hipcc] + flags + ["-c", src, "-o", obj]
+                    if verbose:
+                        print(" ".join(cmd))
+                    res = subprocess.run(cmd, capture_output=True, text=True)
+                    if res.returncode != 0:
+                        raise RuntimeError("hipcc failed on %s:\n%s\n%s" % (os.path.basename(src), res.stdout, res.stderr))
+                    return obj
+                with ThreadPoolExecutor(max_workers=min(len(units), os.cpu_count() or 1)) as pool:
+                    objs = list(pool.map(compile_unit, units))
+                cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-pthread"] + objs + ["-o", tmp]
+                if verbose:
+                    print(" ".join(cmd))
+                res = subprocess.run(cmd, capture_output=True, text=True)
+                if res.returncode != 0:
+                    raise RuntimeError("hipcc (link) failed:\n%s\n%s" % (res.stdout, res.stderr))
+            finally:
+                shutil.rmtree(objdir, ignore_errors=True)
             os.replace(tmp, LIB_PATH)
             with open(stamp, "w") as f:
                 f.write(defines + "\n")

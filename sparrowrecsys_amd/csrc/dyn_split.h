@@ -63,7 +63,7 @@ __device__ __forceinline__ void dyn_scale(float m, float inv_w_scale, float& sca
 
 // One-time (finalize) kernel: W^T [N][ld] (K columns) * w_scale -> A fragments of v_mfma_f32_16x16x32_f16 in the
 // K-block layout above.  out: for (n block nb, K block b): [hi: 16 rows x 4 q x 8 halfs][lo: same] = 2 x 1 KB.
-__global__ __launch_bounds__(256) void k_dyn_pack_w(const float* __restrict__ W, int ld, int N, int K, float w_scale,
+static __global__ __launch_bounds__(256) void k_dyn_pack_w(const float* __restrict__ W, int ld, int N, int K, float w_scale,
                                                     _Float16* __restrict__ out, int kvalid) {
     const int KB = K / 32;
     const int total = (N / 16) * KB * 2 * 512;                           // halfs

@@ -1,12 +1,16 @@
 // host_common.h -- error reporting, HIP_TRY, roctx ranges, SprkTuning (the environment's switches, read once per finalize).
-// Part of sparrow_hip.hip (one translation unit); included there, not compilable on its own.
-namespace {
+// Included first by every translation unit of the library (sparrow_hip.hip and the kernel-family units tu_*.hip).
+// [r5] The kernels' namespace is NAMED (sprk_dev, hidden visibility): the heavy kernel templates are instantiated in the family units and
+// only DECLARED (`extern template`, tu_instances.h) in sparrow_hip.hip, which needs external linkage for them and for the argument structs
+// in their signatures.  Everything that is not a template or inline is `static` / `inline`, so that every unit can include every header.
+#pragma GCC visibility push(hidden)
+namespace sprk_dev {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-thread_local std::string g_err;
+inline thread_local std::string g_err;
 
-int fail(int code, const char* fmt, ...) {
+inline int fail(int code, const char* fmt, ...) {
     char buf[512];
     va_list ap;
     va_start(ap, fmt);
@@ -116,5 +120,5 @@ struct SprkTuning {
         return t;
     }
 };
-thread_local const SprkTuning* g_finalize_tune = nullptr;   // the engine being finalized on this thread (helpers without a handle)
+inline thread_local const SprkTuning* g_finalize_tune = nullptr;   // the engine being finalized on this thread (helpers without a handle)
 

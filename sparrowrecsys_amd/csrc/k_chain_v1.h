@@ -70,7 +70,7 @@ struct V1Run {
 
 // One-time (finalize) kernel: rows of one field of the derived table
 // (w1 == NULL: no first-order weight in the row; deep != NULL: the deep part's row of the same id packed at float deep_off)
-__global__ __launch_bounds__(256) void k_v1_build_rows(const float* __restrict__ table, int Dp, const float* __restrict__ w1,
+static __global__ __launch_bounds__(256) void k_v1_build_rows(const float* __restrict__ table, int Dp, const float* __restrict__ w1,
                                                        long long rows, float* __restrict__ out, const float* __restrict__ deep, int deep_off) {
     const long long total = rows * 32;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
@@ -85,7 +85,7 @@ __global__ __launch_bounds__(256) void k_v1_build_rows(const float* __restrict__
 // One-time (finalize) kernel: deep0's W^T columns -> [H0][KW], KW = 16 * (V1_MAX_DEEP * PC + 1), PC = 16-float chunks per embedding
 // row: chunk c < V1_MAX_DEEP * PC = columns [16 (c % PC), +16) of deep field c / PC (at col_off of the layer's input slice), the
 // last chunk = the numerics; everything else zero.
-__global__ __launch_bounds__(256) void k_v1_pack_w0(const float* __restrict__ W0, int ldw0, int n_deep, int off0, int off1,
+static __global__ __launch_bounds__(256) void k_v1_pack_w0(const float* __restrict__ W0, int ldw0, int n_deep, int off0, int off1,
                                                     int Dp, int n_off, int n_num, int H0, int PC, float* __restrict__ w0) {
     const int KW = 16 * (V1_MAX_DEEP * PC + 1);
     for (int i = threadIdx.x; i < H0 * KW; i += 256) {

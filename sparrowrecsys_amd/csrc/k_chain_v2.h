@@ -152,7 +152,7 @@ __global__ __launch_bounds__(256) void k_v2_pack_image(const V2Args A, float* __
 //     h0w * w1[v]                      first-order weight times its output-layer weight
 //   - sum_n hfm[n] * P[v][n]^2         this field's share of the FM "sum of squares"
 // so the kernel only has to accumulate S = sum_g P_g for the FM cross.
-__global__ __launch_bounds__(256) void k_v2_fold(const float* __restrict__ table, int row_floats,
+static __global__ __launch_bounds__(256) void k_v2_fold(const float* __restrict__ table, int row_floats,
                                                  const float* __restrict__ Wp, int ldp, const float* __restrict__ bp,
                                                  const float* __restrict__ w1, const float* __restrict__ hfm, int n_hfm,
                                                  float h0w, float* __restrict__ out, int KP, long long rows) {
@@ -197,7 +197,7 @@ struct V2Run {
 
 // cold path of the ids/numerics staging: a partial last task, or inputs that do not start on a
 // 16-byte boundary -- element-wise, rows past the end of the batch clamped to the last row
-__device__ __noinline__ void stage_task_slow(float* stage, const int* __restrict__ ids, const float* __restrict__ dense,
+static __device__ __noinline__ void stage_task_slow(float* stage, const int* __restrict__ ids, const float* __restrict__ dense,
                                              int F, int ND, int tk, int B, int lane) {
     int* si = reinterpret_cast<int*>(stage);
 #pragma clang loop vectorize(disable) unroll(disable)

@@ -88,7 +88,7 @@ __device__ __forceinline__ void split_half4(f32x4 w, float scale, f16x4& hi, f16
 
 // One-time (finalize) kernels for HALF.
 // max |x| over the first `ncols` floats of each row -> *out (bits of a non-negative float, atomicMax as uint)
-__global__ __launch_bounds__(256) void k_v2_absmax(const float* __restrict__ rows, long long nrows, int row_floats,
+static __global__ __launch_bounds__(256) void k_v2_absmax(const float* __restrict__ rows, long long nrows, int row_floats,
                                                    int ncols, unsigned* __restrict__ out) {
     float m = 0.f;
     const long long total = nrows * ncols;
@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256) void k_v2_absmax(const float* __restrict__ row
 // How many non-zero entries sit more than 2^20 below max |x| (thresh = max * 2^-20) -> out[0], non-zero entries -> out[1].
 // With the static scale that puts max |x| in [2^14, 2^15) such an entry's lo half is an f16 subnormal (resolution 2^-24 of
 // the scaled value): it keeps fewer than ~20 significand bits, so a table full of them is not fp32-class on split f16.
-__global__ __launch_bounds__(256) void k_v2_count_small(const float* __restrict__ rows, long long nrows, int row_floats, int ncols,
+static __global__ __launch_bounds__(256) void k_v2_count_small(const float* __restrict__ rows, long long nrows, int row_floats, int ncols,
                                                         float thresh, unsigned long long* __restrict__ out) {
     unsigned small = 0, nz = 0;
     const long long total = nrows * ncols;
@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256) void k_v2_count_small(const float* __restrict_
     if ((threadIdx.x & 63) == 0) { atomicAdd(out, (unsigned long long)small); atomicAdd(out + 1, (unsigned long long)nz); }
 }
 // folded fp32 rows {P[16] | scalar | 0..} -> split rows {[hi4|lo4] x 4 | scalar | 0..} of P * scale
-__global__ __launch_bounds__(256) void k_v2_split_rows(const float* __restrict__ src, float* __restrict__ dst,
+static __global__ __launch_bounds__(256) void k_v2_split_rows(const float* __restrict__ src, float* __restrict__ dst,
                                                        long long nrows, float scale) {
     const long long total = nrows * 8;                           // 8 sixteen-byte pieces per 128-byte row
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256) void k_v2_split_rows(const float* __restrict__
 
 // One-time (finalize) kernel: LDS rows of ONE small field from its folded rows (k_v2_fold output):
 // out[v] = { P[v] (KP) | (add_b0 ? b0 : 0) + W0_g^T P[v] (H0) | row scalar | 0.. }, one wave per row.
-__global__ __launch_bounds__(256) void k_v2_fold_small(const float* __restrict__ folded, int KP, int H0, int grp,
+static __global__ __launch_bounds__(256) void k_v2_fold_small(const float* __restrict__ folded, int KP, int H0, int grp,
                                                        const float* __restrict__ W0, int ldw0,   // deep0 W^T [H0][ldw0]
                                                        const float* __restrict__ b0, int add_b0,
                                                        float* __restrict__ out, int rows) {
@@ -169,7 +169,7 @@ __global__ __launch_bounds__(256) void k_v2_fold_small(const float* __restrict__
 //                                                              16 outputs (k = q + 4s) instead of four on a dependent pn
 //     rows0[v][KP + m] += sum_n W0[m][num_off + n] * bn[n]      the constant rides with b0 in the first small field's rows
 // (double accumulation, one rounding.)  pn itself is still formed in the kernel -- the FM sum needs it.
-__global__ __launch_bounds__(256) void k_v2j_fold_num(const float* __restrict__ W0, int ldw0, int num_off,
+static __global__ __launch_bounds__(256) void k_v2j_fold_num(const float* __restrict__ W0, int ldw0, int num_off,
                                                       const float* __restrict__ Wn, int ldn, const float* __restrict__ bn,
                                                       int n_num, int KP, int H0, float* __restrict__ wf,
                                                       float* __restrict__ rows0, int nrows0) {

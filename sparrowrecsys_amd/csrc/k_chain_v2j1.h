@@ -66,7 +66,7 @@ struct V2J1Lds {
 // One-time (finalize) kernel, one block.  Fragment (b, n0, part) lane l = (r = l & 15, q = l >> 4) holds 8 halfs
 // {h[0..3], h[0..3]} of W0[n0*16 + r][16*grp_b + 4q + j] * w_scale, h = hi (part 0) or lo (part 1): exactly the registers
 // v2j_body's load_weights() builds with split_half4 at every launch.
-__global__ __launch_bounds__(256) void k_v2j1_pack_image(const V2Args A, const V2JRun R, int g_big, int G, float* __restrict__ img) {
+static __global__ __launch_bounds__(256) void k_v2j1_pack_image(const V2Args A, const V2JRun R, int g_big, int G, float* __restrict__ img) {
     const int tid = threadIdx.x;
 #if V2J1_DEDUP
     const int off_sel = g_big * 2 * 256, off_w1 = off_sel;
@@ -117,7 +117,7 @@ __global__ __launch_bounds__(256) void k_v2j1_pack_image(const V2Args A, const V
 // (timeline build, scripts/r04: every wave stamps the 100 MHz clock at entry, with its ids staged, with its gathers requested, behind
 // the barrier, after phase A, with its rows landed, at exit -- SPRK_V2J1_TS_FILE at sprk_destroy)
 #define V2J1_TS_WAVES 8192
-__device__ unsigned long long g_v2j1_ts[V2J1_TS_WAVES * 8];
+static __device__ unsigned long long g_v2j1_ts[V2J1_TS_WAVES * 8];
 #define V2J1_STAMP(k) do { const unsigned long long t_ = __builtin_amdgcn_s_memrealtime(); if (lane == 0 && tk < V2J1_TS_WAVES) g_v2j1_ts[tk * 8 + (k)] = t_; } while (0)
 #else
 #define V2J1_STAMP(k) do { } while (0)

@@ -47,7 +47,7 @@ __host__ __device__ inline unsigned csv_genre_slot(unsigned long long lo, unsign
 // error record of a row that cannot be packed: code 1 = identity id outside [0, vocab), 2 = HARD (see above)
 struct CsvErr { unsigned long long key; int code, out_col, is_dense; long long value; };
 
-__device__ __constant__ double kCsvP10[23] = {1e0, 1e1, 1e2, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8, 1e9, 1e10, 1e11,
+static __device__ __constant__ double kCsvP10[23] = {1e0, 1e1, 1e2, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8, 1e9, 1e10, 1e11,
                                               1e12, 1e13, 1e14, 1e15, 1e16, 1e17, 1e18, 1e19, 1e20, 1e21, 1e22};
 
 // newlines among the 16 bytes at t + i (bytes at or beyond len do not count)
@@ -72,7 +72,7 @@ __device__ __forceinline__ unsigned csv_nl_mask(const unsigned char* __restrict_
     return m;
 }
 
-__global__ __launch_bounds__(256) void k_csv_count(const unsigned char* __restrict__ text, size_t len, unsigned* __restrict__ counts) {
+static __global__ __launch_bounds__(256) void k_csv_count(const unsigned char* __restrict__ text, size_t len, unsigned* __restrict__ counts) {
     const size_t i = (size_t)blockIdx.x * CSV_CHUNK + threadIdx.x * 16;
     unsigned n = i < len ? __popc(csv_nl_mask(text, i, len)) : 0;
     for (int d = 32; d >= 1; d >>= 1) n += __shfl_xor(n, d);
@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256) void k_csv_count(const unsigned char* __restri
     if (threadIdx.x == 0) counts[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
 }
 
-__global__ __launch_bounds__(256) void k_csv_mark(const unsigned char* __restrict__ text, size_t len, const unsigned* __restrict__ first,
+static __global__ __launch_bounds__(256) void k_csv_mark(const unsigned char* __restrict__ text, size_t len, const unsigned* __restrict__ first,
                                                   unsigned long long* __restrict__ nl) {
     const size_t i = (size_t)blockIdx.x * CSV_CHUNK + threadIdx.x * 16;
     const unsigned m = i < len ? csv_nl_mask(text, i, len) : 0;
@@ -229,7 +229,7 @@ __device__ __forceinline__ void csv_stage_lines(const unsigned char* __restrict_
     }
 }
 
-__global__ __launch_bounds__(256) void k_csv_keep(const unsigned char* __restrict__ text, size_t len, const unsigned long long* __restrict__ nl,
+static __global__ __launch_bounds__(256) void k_csv_keep(const unsigned char* __restrict__ text, size_t len, const unsigned long long* __restrict__ nl,
                                                   unsigned n_nl, unsigned n_lines, int n_cols, unsigned lds_cap, unsigned* __restrict__ keep) {
     csv_stage_lines(text, len, nl, n_nl, n_lines, lds_cap, nullptr, [&](auto rd, unsigned i, auto lo, auto hi) {
         unsigned k = 0;
@@ -460,7 +460,7 @@ __global__ __launch_bounds__(256) void k_csv_parse(const CsvDev L, const unsigne
 
 // ---- exclusive scan of unsigned counters (three small kernels; totals of a few million elements) ----
 #define SCAN_TILE 2048                        // elements per workgroup: 256 threads x 8
-__global__ __launch_bounds__(256) void k_scan_tiles(const unsigned* __restrict__ in, size_t n, unsigned* __restrict__ sums) {
+static __global__ __launch_bounds__(256) void k_scan_tiles(const unsigned* __restrict__ in, size_t n, unsigned* __restrict__ sums) {
     const size_t base = (size_t)blockIdx.x * SCAN_TILE + threadIdx.x * 8;
     unsigned s = 0;
 #pragma unroll
@@ -472,7 +472,7 @@ __global__ __launch_bounds__(256) void k_scan_tiles(const unsigned* __restrict__
     if (threadIdx.x == 0) sums[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
 }
 // one workgroup: sums[0 .. nb) -> exclusive prefix in place, grand total -> *total
-__global__ __launch_bounds__(256) void k_scan_sums(unsigned* __restrict__ sums, size_t nb, unsigned* __restrict__ total) {
+static __global__ __launch_bounds__(256) void k_scan_sums(unsigned* __restrict__ sums, size_t nb, unsigned* __restrict__ total) {
     __shared__ unsigned wsum[4];
     __shared__ unsigned carry_s;
     if (threadIdx.x == 0) carry_s = 0;
@@ -493,7 +493,7 @@ __global__ __launch_bounds__(256) void k_scan_sums(unsigned* __restrict__ sums, 
     }
     if (threadIdx.x == 0) *total = carry_s;
 }
-__global__ __launch_bounds__(256) void k_scan_apply(const unsigned* __restrict__ in, size_t n, const unsigned* __restrict__ sums,
+static __global__ __launch_bounds__(256) void k_scan_apply(const unsigned* __restrict__ in, size_t n, const unsigned* __restrict__ sums,
                                                     unsigned* __restrict__ out) {
     const size_t base = (size_t)blockIdx.x * SCAN_TILE + threadIdx.x * 8;
     unsigned v[8], s = 0;

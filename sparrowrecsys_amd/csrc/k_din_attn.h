@@ -50,7 +50,7 @@ struct DinRun {
 
 // One-time (finalize) kernel for HALF: E[v][d] * scale -> hi/lo halfs in the lane layout of the f16 MFMA's B operand:
 // q group g = d / EL holds [hi(EL) | lo(EL)], EL = KP / 4 elements per lane.
-__global__ __launch_bounds__(256) void k_din_split_table(const float* __restrict__ table, long long vocab, int Dp, int KP,
+static __global__ __launch_bounds__(256) void k_din_split_table(const float* __restrict__ table, long long vocab, int Dp, int KP,
                                                          float scale, _Float16* __restrict__ out) {
     const int EL = KP / 4;
     const long long total = vocab * KP;
@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256) void k_din_split_table(const float* __restrict
 }
 
 // One-time (finalize) kernels.
-__global__ __launch_bounds__(256) void k_din_prep_w(const float* __restrict__ W, int hidden, int Dp, int KP,
+static __global__ __launch_bounds__(256) void k_din_prep_w(const float* __restrict__ W, int hidden, int Dp, int KP,
                                                     float scale, float* __restrict__ w12, float* __restrict__ w4) {
     // W: [hidden][4*Dp] in [h-c | h | c | h*c] blocks (sprk_din.w_slot)
     const int total = hidden * KP;
@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256) void k_din_prep_w(const float* __restrict__ W,
         w4[i] = b * scale;
     }
 }
-__global__ __launch_bounds__(256) void k_din_prep_vc(const float* __restrict__ W, const float* __restrict__ bias,
+static __global__ __launch_bounds__(256) void k_din_prep_vc(const float* __restrict__ W, const float* __restrict__ bias,
                                                      const float* __restrict__ table, int hidden, int Dp,
                                                      long long vocab, float* __restrict__ vc) {
     // vc[v][n] = bias[n] + sum_k (W3[n][k] - W1[n][k]) * E[v][k]

@@ -58,7 +58,7 @@ template <> struct DinColsArg<true> { typedef DinColsMany type; };
 
 // One-time (finalize) kernel: W12 * sA and W4 * s4 as hi / lo half fragments in the A-operand lane layout
 // (lane (r,q): A[n = nb*16 + r][k = EL*q .. EL*q + EL-1]).  w12 / w4: [32][KP] f32, unscaled.
-__global__ __launch_bounds__(256) void k_din_cols_pack(const float* __restrict__ w12, const float* __restrict__ w4, int KP, float s12, float s4,
+static __global__ __launch_bounds__(256) void k_din_cols_pack(const float* __restrict__ w12, const float* __restrict__ w4, int KP, float s12, float s4,
                                                        _Float16* __restrict__ frag) {
     const int EL = KP / 4;
     for (int i = threadIdx.x; i < 2 * 4 * 64 * 8; i += 256) {
@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256) void k_din_cols_pack(const float* __restrict__
 
 // One-time (finalize) kernel: the two coefficient tables of the attention unit's second half (see k_din_attn.h's epilogue),
 // laid out as the kernel keeps them in LDS -- staging is a flat LDS-DMA copy.
-__global__ __launch_bounds__(256) void k_din_cols_coef(const float* __restrict__ alpha, const float* __restrict__ w2, int T,
+static __global__ __launch_bounds__(256) void k_din_cols_coef(const float* __restrict__ alpha, const float* __restrict__ w2, int T,
                                                        float* __restrict__ coef) {
     for (int i = threadIdx.x; i < 64 * 36; i += 256) {
         const int t = i / 36, n = i - t * 36;

@@ -108,7 +108,7 @@ constexpr int DF_COEF_FLOATS = 2 * 64 * 36;
 
 // One-time (finalize) kernel: the tail image.  W0: fc0's W^T [128][ldw0] (folded columns zeroed by fold_first_dense), pooled
 // columns at p_off (Dp of them), numerics at n_off; w1frag: fc1's split fragments (make_dyn_fragments); EL = 4 KC.
-__global__ __launch_bounds__(256) void k_din_fused_pack(const float* __restrict__ W0, int ldw0, int p_off, int Dp, int n_off, int n_num,
+static __global__ __launch_bounds__(256) void k_din_fused_pack(const float* __restrict__ W0, int ldw0, int p_off, int Dp, int n_off, int n_num,
                                                         float w0p_scale, int EL, const float* __restrict__ b0, const float* __restrict__ a0,
                                                         const float* __restrict__ w1frag, const float* __restrict__ b1,
                                                         const float* __restrict__ a1, const float* __restrict__ hw, int n_hw,
@@ -158,7 +158,7 @@ template <int N> struct DfInt { static constexpr int value = N; };
 #ifdef SPRK_DF_XP
 // XP & 1024: a timeline -- every wave stamps the constant 100 MHz clock at kernel entry, loop entry, loop exit, after fc0, after fc1, exit
 #define DF_TS_WAVES 4096
-__device__ unsigned long long g_df_ts[DF_TS_WAVES * 8];
+static __device__ unsigned long long g_df_ts[DF_TS_WAVES * 8];
 #endif
 template <int KC, bool MB, bool TAIL, bool ATT = false, int XP = 0>
 __global__ __launch_bounds__(DF_WAVES * 64, 2) void k_din_fused(const DinFusedRun A, const int* __restrict__ ids, const float* __restrict__ dense,

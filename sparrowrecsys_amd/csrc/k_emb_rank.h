@@ -31,7 +31,7 @@ __device__ __forceinline__ unsigned long long er_key(double s) {
 }
 
 // P = padded (power of two) sort length, 0 = no ranking wanted
-__global__ __launch_bounds__(ER_THREADS) void k_emb_rank(const float* __restrict__ item_emb, const unsigned char* __restrict__ item_has,
+static __global__ __launch_bounds__(ER_THREADS) void k_emb_rank(const float* __restrict__ item_emb, const unsigned char* __restrict__ item_has,
                                                          int n_items, int D, int item_stride,
                                                          const float* __restrict__ query_emb, const unsigned char* __restrict__ query_has,
                                                          int query_stride, const int* __restrict__ cand, int C, int P,

@@ -84,7 +84,7 @@ struct MlpRowsLds {
 };
 
 // One-time (finalize) kernel: rows [rows][128] -> the LDS layout of a small column (rows MR_RS floats apart).
-__global__ __launch_bounds__(256) void k_mlp_rows_pad(const float* __restrict__ in, float* __restrict__ out, int rows) {
+static __global__ __launch_bounds__(256) void k_mlp_rows_pad(const float* __restrict__ in, float* __restrict__ out, int rows) {
     for (int i = blockIdx.x * 256 + threadIdx.x; i < rows * 128; i += gridDim.x * 256) out[(i >> 7) * MR_RS + (i & 127)] = in[i];
 }
 

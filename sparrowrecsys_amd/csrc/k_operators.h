@@ -4,7 +4,7 @@
 // ---------------------------------------------------------------------------------------------
 // stand-alone operators
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_embedding_gather(const float* __restrict__ table, int V, int nvec,
+static __global__ __launch_bounds__(256) void k_embedding_gather(const float* __restrict__ table, int V, int nvec,
                                                           int row_stride, const int* __restrict__ ids, int B,
                                                           float* __restrict__ out) {
     const long long total = (long long)B * nvec;
@@ -18,11 +18,13 @@ __global__ __launch_bounds__(256) void k_embedding_gather(const float* __restric
     }
 }
 
-__global__ __launch_bounds__(256) void k_cross_hash(const int* __restrict__ a, const int* __restrict__ b, int B,
+static __global__ __launch_bounds__(256) void k_cross_hash(const int* __restrict__ a, const int* __restrict__ b, int B,
                                                     unsigned long long buckets, long long* __restrict__ out) {
     for (int i = blockIdx.x * 256 + threadIdx.x; i < B; i += gridDim.x * 256)
         out[i] = (long long)cross_bucket(a[i], b[i], buckets);
 }
 
-}  // namespace
+}  // namespace sprk_dev
+#pragma GCC visibility pop
+using namespace sprk_dev;
 

@@ -30,7 +30,7 @@ struct PeerPut {
     unsigned* done;                       // [world] local counters: workgroups of peer p's share that have finished
 };
 
-__global__ __launch_bounds__(256) void k_peer_put(const PeerPut A) {
+static __global__ __launch_bounds__(256) void k_peer_put(const PeerPut A) {
     const int p = blockIdx.x / A.blocks_per_peer, j = blockIdx.x - p * A.blocks_per_peer;
     float* dst = A.dst[p];
     const unsigned long long n4 = A.count >> 2;
@@ -56,7 +56,7 @@ __global__ __launch_bounds__(256) void k_peer_put(const PeerPut A) {
 }
 
 // lane p < world waits for flags[p] == epoch; ticks = deadline in wall_clock64 ticks (100 MHz)
-__global__ __launch_bounds__(64) void k_peer_wait(const unsigned* __restrict__ flags, int world, unsigned epoch,
+static __global__ __launch_bounds__(64) void k_peer_wait(const unsigned* __restrict__ flags, int world, unsigned epoch,
                                                   unsigned long long ticks, int* __restrict__ err) {
     const int p = threadIdx.x;
     if (p >= world) return;

@@ -94,7 +94,7 @@ struct RowsLds {
 //   Q[m] = sum_n W0t[m][col0 + n] * src[n]  (+ qbias[m] when given)
 //   s    = h0w * w1[v] - sum_n hfm[n] * P[n]^2            (0 when w1 == NULL)
 //   out[v*out_stride ..] = {P (KP) | Q (H0) | (scal_in_row ? s : nothing)}, scal_out[v] = s when scal_out != NULL
-__global__ __launch_bounds__(256) void k_rows_build(const float* __restrict__ table, int row_floats, long long rows,
+static __global__ __launch_bounds__(256) void k_rows_build(const float* __restrict__ table, int row_floats, long long rows,
                                                     const float* __restrict__ Wp, int ldp, const float* __restrict__ bp, int KP,
                                                     const float* __restrict__ W0t, int ld0, int col0, int H0, int nsrc,
                                                     const float* __restrict__ qbias,
@@ -140,7 +140,7 @@ __global__ __launch_bounds__(256) void k_rows_build(const float* __restrict__ ta
 }
 
 // UNF, one-time: raw embedding rows -> {W hi halfs | W lo halfs} of E * scale, W = 16 or 32 (values beyond row_floats: 0)
-__global__ __launch_bounds__(256) void k_rows_unf_split(const float* __restrict__ table, int row_floats, long long rows, float scale,
+static __global__ __launch_bounds__(256) void k_rows_unf_split(const float* __restrict__ table, int row_floats, long long rows, float scale,
                                                         _Float16* __restrict__ out, int W = 16) {
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < rows * W; i += (long long)gridDim.x * 256) {
         const long long v = i / W;

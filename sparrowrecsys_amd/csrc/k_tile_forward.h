@@ -153,7 +153,7 @@ __device__ __forceinline__ void run_dense(const DevOp& op, const float* src, int
 // ---------------------------------------------------------------------------------------------
 extern __shared__ __attribute__((aligned(16))) float smem[];
 
-__global__ __launch_bounds__(256) void k_tile_forward(const DevPlan* __restrict__ P,
+static __global__ __launch_bounds__(256) void k_tile_forward(const DevPlan* __restrict__ P,
                                                       const int* __restrict__ ids,
                                                       const float* __restrict__ dense,
                                                       const float* __restrict__ aux,
@@ -404,7 +404,7 @@ __global__ __launch_bounds__(256) void k_tile_forward(const DevPlan* __restrict_
 // k_din_pool: DIN activation unit + weighted sum pooling (DIN.py:132-158)
 //   LDS: Hs[rows][hs] history rows, Cs[MS][hs] candidate rows, Ws[rows] attention weights
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_din_pool(const DevPlan* __restrict__ P, const int* __restrict__ ids,
+static __global__ __launch_bounds__(256) void k_din_pool(const DevPlan* __restrict__ P, const int* __restrict__ ids,
                                                   float* __restrict__ pooled, float* __restrict__ att,
                                                   int B, int MS, int* __restrict__ err) {
     const DevDin& dn = P->din;
@@ -531,7 +531,7 @@ __global__ __launch_bounds__(256) void k_din_pool(const DevPlan* __restrict__ P,
 
 // One-time (finalize) kernel of the first-Dense fold: F[v][n] = sum_j Wt[n][col0 + j] * table[v][j]
 // (Wt = the layer's W^T [N][ldw], col0 = the embedding column's offset inside the layer's input slice).
-__global__ __launch_bounds__(256) void k_fold_dense_rows(const float* __restrict__ table, long long vocab, int row_stride,
+static __global__ __launch_bounds__(256) void k_fold_dense_rows(const float* __restrict__ table, long long vocab, int row_stride,
                                                          int width, const float* __restrict__ Wt, int ldw, int col0,
                                                          int N, float* __restrict__ F) {
     const long long total = vocab * N;
@@ -546,7 +546,7 @@ __global__ __launch_bounds__(256) void k_fold_dense_rows(const float* __restrict
     }
 }
 // copy of a W^T with the columns [c0, c1) zeroed (folded columns that stay inside the layer's K range)
-__global__ __launch_bounds__(256) void k_zero_columns(float* __restrict__ Wt, int N, int ldw, int c0, int c1) {
+static __global__ __launch_bounds__(256) void k_zero_columns(float* __restrict__ Wt, int N, int ldw, int c0, int c1) {
     const int w = c1 - c0;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < N * w; i += gridDim.x * 256) Wt[(size_t)(i / w) * ldw + c0 + i % w] = 0.f;
 }

@@ -18,45 +18,11 @@
 //
 // Reference constructs each piece replaces are cited in include/sparrow_hip.h.
 //
-// ONE translation unit, laid out as a list of pieces (round 3: this file was a 3 700-line monolith).  The pieces share two
-// anonymous namespaces (kernels, host helpers) and are meaningful only in this order:
-#include <hip/hip_runtime.h>
-#include <dlfcn.h>
-#include <unistd.h>
-
-#include <cstdarg>
-#include <cstdint>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <new>
-#include <string>
-#include <type_traits>
-#include <thread>
-#include <vector>
-
-#include "sparrow_hip.h"
-
-#include "host_common.h"             // error reporting, HIP_TRY, roctx ranges, SprkTuning (the environment's switches, read once per finalize)
-#include "k_tile_forward.h"          // the device-side plan, the cross hash, the plan interpreter k_tile_forward and the generic DIN stage k_din_pool
-// fused kernels, one header per graph family (each documents its own design)
-#include "k_chain_v2.h"
-#include "k_chain_v2j.h"
-#include "k_chain_v2j1.h"
-#include "k_rows_chain.h"
-#include "k_din_attn.h"
-#include "dyn_split.h"
-#include "k_din_cols.h"
-#include "k_din_tail.h"
-#include "k_din_fused.h"
-#include "k_chain_v1.h"
-#include "k_mlp_rows.h"
-#include "k_emb_rank.h"
-#include "k_dien_seq.h"
-#include "k_dien_mfma.h"
-#include "k_peer_gather.h"
-#include "k_csv_pack.h"
-#include "k_operators.h"             // stand-alone operator kernels (bit-exact gather, cross hash) -- closes the kernels' anonymous namespace
+// The library's MAIN translation unit: the host side (engine, plan validation, per-graph set-up, the C ABI) and the light kernels.  The heavy
+// kernel templates are compiled by the kernel-family units tu_1.hip .. tu_6.hip (tu_kernels.h, tu_instances.h); -DSPRK_SINGLE_TU folds
+// everything back into this one unit (the ISA scripts).  The pieces share one named namespace for the kernels (sprk_dev) and one
+// anonymous namespace for the host helpers, and are meaningful only in this order:
+#include "tu_kernels.h"              // system headers, include/sparrow_hip.h, host_common.h .. k_operators.h, tu_instances.h
 #include "host_engine.h"             // struct sprk_engine: everything a finalized handle owns
 #include "host_plan.h"               // plan validation and small host helpers
 #include "host_setup_v2.h"           // DeepFM_v2: k_deepfm_v2_chain / _joint / _joint1 dispatch tables, plan matcher, fold + joint-table set-up

@@ -26,7 +26,7 @@ def _kernel_rows(path):
 def test_fraction_follows_from_the_kept_trace(row):
     w = row["workload"].replace("c3_attn", "c3")                     # (config 3's two kernels share one trace)
     rows = _kernel_rows(os.path.join(P, w + "_strict_kernel_stats.csv"))
-    hit = [r for r in rows if "::" + row["kernel"] in r[0].replace("(anonymous namespace)::", "::", 1)]
+    hit = [r for r in rows if "::" + row["kernel"] in r[0].replace("(anonymous namespace)::", "::", 1).replace("sprk_dev::", "::", 1)]
     assert len(hit) == 1, (row["kernel"], [r[0][:60] for r in rows[:4]])
     name, calls, avg_ns = hit[0]
     assert calls == row["launches"] and abs(avg_ns / 1e3 - row["rocprof_avg_us"]) < 1e-6
