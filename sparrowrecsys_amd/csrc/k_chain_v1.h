@@ -224,7 +224,8 @@ __device__ __forceinline__ void v1_body(const V1Run& A, const int* __restrict__ 
             bad |= (unsigned)(idv[f] + 1) > (unsigned)A.vocab[f];              // neither a table row nor the "missing" marker -1
             sid[f] = min((unsigned)idv[f], (unsigned)A.vocab[f]);              // -1 / out of range -> the zero row at index vocab
         }
-        if (PC == 1 && A.tab) {                                   // (wave-uniform) narrow rows: the derived {E | w1} table
+        if ((ONE && NV == 4) || (PC == 1 && A.tab)) {                          // (wave-uniform) narrow rows: the derived {E | w1} table.  ONE is only dispatched with it (host_setup_pairs.h): no second path,
+                                                                  // whose join in front of the scoring stage made hipcc's waitcnt pass put a vmcnt(0) there (build/sparrow.s, round 5)
             const char* tb = reinterpret_cast<const char*>(A.tab);
             unsigned ro[NF];
 #pragma unroll
@@ -290,6 +291,23 @@ __device__ __forceinline__ void v1_body(const V1Run& A, const int* __restrict__ 
     float rna[H0C], rnb[H0C];             // numerics' A operands: rows (nb*16 + r) of W0[:, numerics]^T, columns q and q + 4
     auto compute = [&](const Set& S) -> float {
 #pragma clang fp contract(off)
+        // ---- deep0 (DeepFM.py:106-107), the part that needs NO gathered row: bias + numerics on f32 MFMA.  [r5] In FRONT of the pair dots:
+        //      the numerics are the first loads a task issues, the rows the last; with the pair dots first (rounds 2-4) hipcc's vmcnt(0) sat in
+        //      front of all 44 MFMAs and of every LDS read of the stage (scripts/r04/isa_wait_sequence.py), i.e. nothing ran under the rows'
+        //      flight.  z's own chain (first-order + pair dots, then the head's fmas) is unchanged: same bits. ----
+        //      Only in the one-task shape with full-width rows (config 2): measured 10.81 -> 10.63 us there, but 20.7 -> 21.6 us in the looped
+        //      kernel of config 4 and worse for DeepFM.py's 3-piece rows (profiles/r05/experiments/r05_11).
+        constexpr bool NUM_FIRST = ONE && NV == 4;
+        f32x4 h0[H0C];
+        auto deep0_numerics = [&]() {
+#pragma unroll
+            for (int nb = 0; nb < H0C; ++nb) h0[nb] = ld4(smem + LD::off_b0 + nb * 16 + 4 * q);
+#pragma unroll
+            for (int nb = 0; nb < H0C; ++nb) h0[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(rna[nb], S.xa, h0[nb], 0, 0, 0);
+#pragma unroll
+            for (int nb = 0; nb < H0C; ++nb) h0[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(rnb[nb], S.xb, h0[nb], 0, 0, 0);
+        };
+        if constexpr (NUM_FIRST) deep0_numerics();
         // ---- pair dots (per-lane partials over this lane's 4 columns; the sum over q is part of the final reduction).  Only the
         //      real pairs (their head weight is wave-uniform: an SGPR test), two packed multiplies + two packed FMAs per pair and
         //      16-float chunk (round 2: all NF (NF - 1) / 2 products, 8 scalar instructions each) ----
@@ -310,14 +328,7 @@ __device__ __forceinline__ void v1_body(const V1Run& A, const int* __restrict__ 
                 }
             }
         float z = (S.w1a + S.w1b) + ((pa[0] + pa[1]) + (pb[0] + pb[1]));
-        // ---- deep0 (DeepFM.py:106-107): bias + numerics on f32 MFMA, the deep fields' rows on split f16 ----
-        f32x4 h0[H0C];
-#pragma unroll
-        for (int nb = 0; nb < H0C; ++nb) h0[nb] = ld4(smem + LD::off_b0 + nb * 16 + 4 * q);
-#pragma unroll
-        for (int nb = 0; nb < H0C; ++nb) h0[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(rna[nb], S.xa, h0[nb], 0, 0, 0);
-#pragma unroll
-        for (int nb = 0; nb < H0C; ++nb) h0[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(rnb[nb], S.xb, h0[nb], 0, 0, 0);
+        if constexpr (!NUM_FIRST) deep0_numerics();
         // the deep fields' chunks in K order: chunk c = field c / PC, pieces 16 (c % PC) + 4q; K block b = chunks 2b, 2b + 1
         f32x4 ec[2 * PC];
 #pragma unroll
