@@ -79,8 +79,10 @@ def main():
                 json.dump(untraced, open(os.path.join(dst, "bench_" + w + "_strict.json"), "w"))
         rl = (untraced or line)["roofline"]
         rl_traced = line["roofline"]
-        if w0 == "c3" and "fused_step" in rl:               # the fused launch: its own bytes (attention + tail) and duration
+        if w0 == "c3" and "fused_step" in rl:               # (round 4's lines) the fused launch: its own bytes (attention + tail) and duration
             rl, rl_traced = rl["fused_step"], line["roofline"].get("fused_step", line["roofline"])
+        if w0 == "c3_attn" and "attention_only" in rl:       # (round 5's lines: `roofline` IS the fused launch, the attention-only loop a sub-field)
+            rl, rl_traced = rl["attention_only"], line["roofline"].get("attention_only", line["roofline"])
         B = line["config"]["batch_per_gpu"]
         alg = rl["algorithmic_bytes_per_sample"] * B
         hit = [r for r in kernel_rows(ks) if DOMINANT[w0] in r[0]]

@@ -111,6 +111,19 @@ __device__ __forceinline__ float neg1_fast(float v) {                    // min(
 __device__ __forceinline__ f32x4 relu4_fast(f32x4 v) {
     return f32x4{relu1_fast(v.x), relu1_fast(v.y), relu1_fast(v.z), relu1_fast(v.w)};
 }
+// sum over the four 16-lane rows of a wave, (row0 + row1) + (row2 + row3), in every lane
+__device__ __forceinline__ float rows4_sum(float v) {
+    // inline asm: hipcc 7.2's __builtin_amdgcn_permlane{16,32}_swap hands back its FIRST result for both
+    // elements of the returned pair (the sum became x + x).  s_nop 1 = the two wait states a VALU-written
+    // VGPR needs before a permlane swap reads it; the assembler inserts nothing inside asm statements.
+    float a = v, b = v;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));   // a = [v0 v0 v2 v2], b = [v1 v1 v3 v3]
+    a += b;
+    b = a;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));   // a = [lo lo], b = [hi hi]
+    return a + b;
+}
+
 // 1/(1+exp(-z)) on the hardware exp2/rcp units (4 VALU instructions; |err| < 3e-7 absolute on the score)
 __device__ __forceinline__ float sigmoidf_fast(float z) {
     return __builtin_amdgcn_rcpf(1.0f + __expf(-z));

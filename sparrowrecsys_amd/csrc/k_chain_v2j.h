@@ -501,8 +501,9 @@ __device__ __forceinline__ void v2j_body(const V2JRun& A, const int* __restrict_
         }
         // output layer: concat([first, fm, deep]) . w + b -> sigmoid (DeepFM_v2.py:154-155)
         z += zz;
-        z += __shfl_xor(z, 16);
-        z += __shfl_xor(z, 32);
+        // ([r5] two permlane swaps instead of two ds_bpermute round trips through the LDS queue at the very end of the task's chain; the storing
+        //  lanes (row 0) get (z0 + z1) + (z2 + z3) either way: same bits)
+        z = rows4_sum(z);
         return sigmoidf_fast(z + A.h0w * A.fo_bias + A.head_bias);
     };
     auto store = [&](int tkg, float score) {

@@ -147,6 +147,7 @@ __global__ __launch_bounds__(V2J1_WAVES_OF(HOIST, G_BIG) * 64, 4) void k_deepfm_
     float* stage = smem + LD::total_pad + A.small_floats + wave * 256; // this wave's ids / numerics slot
     const bool fast = work && !(A.flags & 1) && tk * 16 + 16 <= B;     // aligned, full task: one 16-byte load per lane
     V2J1_STAMP(0);
+    // (tried, no gain: s_setprio 3 from here to the last gather request -- 6.82 us either way, HBM-resident 8.7-9.0 against 8.7-8.8: profiles/r05/experiments/r05_12)
 
     // ---- the task's ids + numerics first, then the image pieces (they land inside the ids' latency) ----
     f32x4 raw = zero;
@@ -380,8 +381,9 @@ __global__ __launch_bounds__(V2J1_WAVES_OF(HOIST, G_BIG) * 64, 4) void k_deepfm_
         zz += (q == 3) ? ssc : 0.f;
     }
     z += zz;
-    z += __shfl_xor(z, 16);
-    z += __shfl_xor(z, 32);
+    // ([r5] two permlane swaps instead of two ds_bpermute round trips through the LDS queue at the very end of the task's chain; the storing
+    //  lanes (row 0) get (z0 + z1) + (z2 + z3) either way: same bits)
+    z = rows4_sum(z);
     const float score = sigmoidf_fast(z + A.h0w * A.fo_bias + A.head_bias);
     const int m = tk * 16 + r;
     if (q == 0 && m < B) out[m] = score;

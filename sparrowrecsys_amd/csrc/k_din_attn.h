@@ -143,17 +143,7 @@ __device__ __forceinline__ float row16_reduce_scatter(const float (&v)[EL], int 
 
 // sum over the four 16-lane rows (q = 0..3) of a wave, result in every lane: v_permlane16_swap /
 // v_permlane32_swap (gfx950) exchange rows inside the VALU, no LDS round trip as ds_bpermute would take
-__device__ __forceinline__ float rows4_sum(float v) {
-    // inline asm: hipcc 7.2's __builtin_amdgcn_permlane{16,32}_swap hands back its FIRST result for both
-    // elements of the returned pair (the sum became x + x).  s_nop 1 = the two wait states a VALU-written
-    // VGPR needs before a permlane swap reads it; the assembler inserts nothing inside asm statements.
-    float a = v, b = v;
-    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));   // a = [v0 v0 v2 v2], b = [v1 v1 v3 v3]
-    a += b;
-    b = a;
-    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));   // a = [lo lo], b = [hi hi]
-    return a + b;
-}
+// (rows4_sum: k_chain_v2.h)
 
 // f16 MFMA over a lane's EL = 4 or 8 operand halfs (K = 16 or 32)
 typedef _Float16 din_f16x4 __attribute__((ext_vector_type(4)));
