@@ -12,6 +12,8 @@ STRICT="--cpu-seconds 0 --no-check --launch-batches 1 --overlap-streams 0 --hbm-
 declare -A WL
 WL[c2]="--steps 400 --warmup 40 --input-batches 32"
 WL[c2_hbm]="--steps 400 --warmup 40 --big-vocab 8388608 --input-batches 32"
+WL[c2_zipf]="--steps 400 --warmup 40 --input-batches 32 --dist zipf"
+WL[c2_f32]="--steps 400 --warmup 40 --input-batches 32"
 WL[c2_pairs]="--steps 400 --warmup 40 --workload deepfm_c2"
 WL[c3]="--steps 60 --warmup 6 --workload din_c3"
 WL[c4_v2]="--steps 200 --warmup 20 --workload deepfm_v2_c4"
@@ -24,7 +26,8 @@ WL[din_ref]="--steps 100 --warmup 10 --workload din_ref"
 WL[embedding_mlp_ref]="--steps 200 --warmup 20 --workload embedding_mlp_ref"
 WL[dien_ref]="--steps 100 --warmup 10 --workload dien_ref"
 cd /tmp && export TMPDIR=/tmp
-for w in c2 c2_hbm c2_pairs c3 c4_v2 c4_pairs c5 v2_ref ncf_ref deepfm_ref din_ref embedding_mlp_ref dien_ref; do
+for w in c2 c2_hbm c2_zipf c2_f32 c2_pairs c3 c4_v2 c4_pairs c5 v2_ref ncf_ref deepfm_ref din_ref embedding_mlp_ref dien_ref; do
+  export SPRK_V2_HALF=1; [ $w = c2_f32 ] && export SPRK_V2_HALF=0      # (c2_f32: every contraction on f32 MFMA, the exact-fp32 twin)
   timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_$w -o t -- python $R/bench.py ${WL[$w]} $STRICT > $O/${w}_strict.log 2>&1
   grep '^{"metric"' $O/${w}_strict.log | tail -1 > $O/${w}_strict_bench.json
   f=$(find $O/trace_$w -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/${w}_strict_kernel_stats.csv

@@ -22,7 +22,7 @@ import sys
 
 HBM_PEAK = 8.0e12
 # workload tag -> (the kernel whose launches ARE the steps, substring of its rocprof name)
-DOMINANT = {"c2": "k_deepfm_v2_joint1", "c2_hbm": "k_deepfm_v2_joint1", "c2_pairs": "k_deepfm_pairs1", "c3": "k_din_attn_cols",
+DOMINANT = {"c2": "k_deepfm_v2_joint1", "c2_hbm": "k_deepfm_v2_joint1", "c2_zipf": "k_deepfm_v2_joint1", "c2_f32": "k_deepfm_v2_joint<", "c2_pairs": "k_deepfm_pairs1", "c3": "k_din_attn_cols",
             "c4_v2": "k_deepfm_v2_joint1", "c4_pairs": "k_deepfm_pairs<", "c5": "k_mlp_rows", "v2_ref": "k_rows_chain1", "ncf_ref": "k_rows_chain1",
             "deepfm_ref": "k_deepfm_pairs1", "din_ref": "k_din_attn_cols", "embedding_mlp_ref": "k_mlp_rows", "dien_ref": "k_dien_seq"}
 # round 4: BASELINE config 3 is ONE launch (k_din_fused<2, false, true>: attention + pooling + tail); its attention-only instantiation
@@ -30,7 +30,7 @@ DOMINANT = {"c2": "k_deepfm_v2_joint1", "c2_hbm": "k_deepfm_v2_joint1", "c2_pair
 # read from the same trace (bench.py times that loop after the fused one)
 if int(os.environ.get("SPRK_PROFILE_ROUND", "5")) >= 4:
     DOMINANT.update({"c3": "k_din_fused<2, false, true", "c3_attn": "k_din_fused<2, false, false"})
-ORDER = ["c2", "c2_hbm", "c2_pairs", "c3", "c3_attn", "c4_v2", "c4_pairs", "c5", "v2_ref", "ncf_ref", "deepfm_ref", "din_ref", "embedding_mlp_ref", "dien_ref"]
+ORDER = ["c2", "c2_hbm", "c2_zipf", "c2_f32", "c2_pairs", "c3", "c3_attn", "c4_v2", "c4_pairs", "c5", "v2_ref", "ncf_ref", "deepfm_ref", "din_ref", "embedding_mlp_ref", "dien_ref"]
 SHARES_FILES_OF = {"c3_attn": "c3"}                    # a row read from another workload's trace / bench line
 
 
