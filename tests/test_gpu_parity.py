@@ -280,6 +280,34 @@ def test_din_fused_scores_do_not_depend_on_the_launch_shape(torch, monkeypatch, 
     assert np.abs(got["ts1"] - ref).max() <= TIGHT
 
 
+@pytest.mark.parametrize("T,D,B,min_t", [(5, 10, 4099, "1"), (20, 16, 1000, "12"), (12, 10, 333, "12")])
+def test_din_fused_tail_on_raw_rows_for_narrow_embeddings(torch, monkeypatch, T, D, B, min_t):
+    """[r5] k_din_fused with emb_dim <= 16: the tail's four embedding columns as raw 64-byte rows (the two column-pair K = 32 blocks of
+    k_din_tail's form) instead of 4 x 512-byte folded rows.  Against the folded form of the same kernel (SPRK_DIN_FUSED_UNF=0) and the
+    two-launch path <= 3e-6, the fp64 oracle within the bar; missing genre ids and a user without history; DIN.py's own shape (5 slots,
+    emb 10) reaches the kernel through SPRK_DIN_FUSED_MIN_T=1 (it is not dispatched there by default: two launches measure the same)."""
+    V, U = 1001, 3001
+    feats = SY.synth_din(B, T, V, U, seed=500 + T)
+    feats["movieGenre1"][::5] = -1
+    feats["userGenre1"][1::7] = -1
+    feats["userRatedMovies"][3] = 0
+    got = {}
+    for tag, env in (("raw", {}), ("folded", {"SPRK_DIN_FUSED_UNF": "0"}), ("two", {"SPRK_DIN_FUSED": "0"})):
+        for k in ("SPRK_DIN_FUSED_UNF", "SPRK_DIN_FUSED"):
+            monkeypatch.delenv(k, raising=False)
+        monkeypatch.setenv("SPRK_DIN_FUSED_MIN_T", min_t)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        model = M.DIN(seed=70 + T, emb_dim=D, hist_len=T, movie_buckets=V, user_buckets=U)
+        assert model.engine.describe()["kernel"].startswith("k_din_fused<KC=1" if tag != "two" else "k_din_tail")
+        got[tag] = model.predict(feats)[:, 0]
+        model.engine.close()
+    assert np.abs(got["raw"] - got["folded"]).max() <= 3e-6
+    assert np.abs(got["raw"] - got["two"]).max() <= 3e-6
+    ref = O.din_forward(feats, model.weights, dtype=np.float64, hist_len=T, movie_buckets=V, user_buckets=U)[:, 0]
+    assert np.abs(got["raw"] - ref).max() <= TIGHT and ref.std() > 0.01
+
+
 def test_din_fused_batch_beyond_one_round_of_workgroups(torch, monkeypatch):
     """sprk_forward on a DIN batch of more than 16 rows x 8 waves x CUs (32 768 on an MI355X): the PERSISTENT form of k_din_fused (every
     wave walks several tasks, tables staged once) -- the same bits as the same rows scored in one-round slices, the oracle's values."""
