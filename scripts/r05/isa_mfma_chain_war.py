@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""VALU writes to the SrcA / SrcB registers of an MFMA that is the 2nd or 3rd member of a chain of dependent MFMAs (SrcC = the previous one's
+result), within WIN wait states of that MFMA.  usage: isa_mfma_chain_war.py file.s kernel-regex [WIN]"""
+import re, sys
+def regs(tok):
+    tok = (tok.strip().split() or [""])[0].rstrip(",")
+    m = re.match(r"^-?\|?v(\d+)\|?$", tok)
+    if m: return {int(m.group(1))}
+    m = re.match(r"^-?\|?v\[(\d+):(\d+)\]\|?$", tok)
+    if m: return set(range(int(m.group(1)), int(m.group(2)) + 1))
+    return set()
+def kernels(path):
+    cur, body = None, []
+    for l in open(path):
+        m = re.match(r"^(_Z\w+):", l)
+        if m: cur, body = m.group(1), []; continue
+        if cur is not None:
+            if ".end_amdhsa_kernel" in l: yield cur, body; cur = None; continue
+            body.append(l)
+pat = re.compile(sys.argv[2]); WIN = int(sys.argv[3]) if len(sys.argv) > 3 else 16
+for name, body in kernels(sys.argv[1]):
+    if not pat.search(name): continue
+    ins = []
+    for n, l in enumerate(body, 1):
+        t = l.split(";")[0].strip()
+        if not t or t.startswith(".") or t.endswith(":"): continue
+        p = t.split(None, 1); ops = re.split(r",\s*", p[1]) if len(p) > 1 else []
+        ins.append((p[0], ops, t, n))
+    hits = []
+    for i, (op, ops, t, n) in enumerate(ins):
+        if not op.startswith("v_mfma") or len(ops) < 4: continue
+        c = regs(ops[3])
+        if not c: continue
+        depth = 0                                   # how many dependent MFMAs precede within 6 instructions
+        want = c
+        for j in range(i - 1, max(i - 8, -1), -1):
+            bop, bops, bt, bn = ins[j]
+            if bop.startswith("v_mfma") and regs(bops[0]) & want:
+                depth += 1
+                want = regs(bops[3]) if len(bops) > 3 else set()
+                if not want: break
+        if depth == 0: continue
+        ab = {"A": regs(ops[1]), "B": regs(ops[2])}
+        own = regs(ops[0])
+        d = 0
+        for j in range(i + 1, len(ins)):
+            bop, bops, bt, bn = ins[j]
+            if bop == "s_nop": d += int(bops[0]) + 1; continue
+            if d >= WIN or bop.startswith(("s_branch", "s_cbranch", "s_endpgm")): break
+            if bop.startswith("v_") and not bop.startswith(("v_mfma", "v_cmp")) and bops:
+                w = regs(bops[0])
+                for k, s in ab.items():
+                    if w & s: hits.append((depth, k, d, n, t[:64], bn, bt[:60]))
+            d += 1
+    print("%s: %d VALU writes into A/B of a chained MFMA within %d wait states" % (name[:50], len(hits), WIN))
+    for h in hits[: int(sys.argv[4]) if len(sys.argv) > 4 else 12]:
+        print("   chain member %d, Src%s, +%2d ws: line %d %s   <-  line %d %s" % (h[0] + 1, h[1], h[2], h[3], h[4], h[5], h[6]))

@@ -30,8 +30,11 @@ DOMINANT = {"c2": "k_deepfm_v2_joint1", "c2_hbm": "k_deepfm_v2_joint1", "c2_zipf
 # read from the same trace (bench.py times that loop after the fused one)
 if int(os.environ.get("SPRK_PROFILE_ROUND", "5")) >= 4:
     DOMINANT.update({"c3": "k_din_fused<2, false, true", "c3_attn": "k_din_fused<2, false, false"})
-ORDER = ["c2", "c2_hbm", "c2_zipf", "c2_f32", "c2_pairs", "c3", "c3_attn", "c4_v2", "c4_pairs", "c5", "v2_ref", "ncf_ref", "deepfm_ref", "din_ref", "embedding_mlp_ref", "dien_ref"]
-SHARES_FILES_OF = {"c3_attn": "c3"}                    # a row read from another workload's trace / bench line
+# round 5: DIEN.py's shape is ONE launch too (k_dien_fused); the sequence stage alone (k_dien_seq_mfma, what sprk_din_pool launches) is the row "dien_seq"
+if int(os.environ.get("SPRK_PROFILE_ROUND", "5")) >= 5:
+    DOMINANT.update({"dien_ref": "k_dien_fused", "dien_seq": "k_dien_seq"})
+ORDER = ["c2", "c2_hbm", "c2_zipf", "c2_f32", "c2_pairs", "c3", "c3_attn", "c4_v2", "c4_pairs", "c5", "v2_ref", "ncf_ref", "deepfm_ref", "din_ref", "embedding_mlp_ref", "dien_ref", "dien_seq"]
+SHARES_FILES_OF = {"c3_attn": "c3", "dien_seq": "dien_ref"}                    # a row read from another workload's trace / bench line
 
 
 def kernel_rows(path):
@@ -83,9 +86,15 @@ def main():
             rl, rl_traced = rl["fused_step"], line["roofline"].get("fused_step", line["roofline"])
         if w0 == "c3_attn" and "attention_only" in rl:       # (round 5's lines: `roofline` IS the fused launch, the attention-only loop a sub-field)
             rl, rl_traced = rl["attention_only"], line["roofline"].get("attention_only", line["roofline"])
+        if w0 == "dien_seq":
+            if "sequence_only" not in rl:
+                continue                                     # (a two-launch line: its `roofline` IS the sequence stage, the row "dien_ref")
+            rl, rl_traced = rl["sequence_only"], line["roofline"].get("sequence_only", line["roofline"])
         B = line["config"]["batch_per_gpu"]
         alg = rl["algorithmic_bytes_per_sample"] * B
         hit = [r for r in kernel_rows(ks) if DOMINANT[w0] in r[0]]
+        if not hit and w0 == "dien_ref":
+            hit = [r for r in kernel_rows(ks) if "k_dien_seq" in r[0]]      # (SPRK_DIEN_FUSED=0, or a trace from before k_dien_fused)
         if not hit:
             print(w0, ": no kernel matching", DOMINANT[w0])
             continue

@@ -416,6 +416,17 @@ int sprk_finalize(sprk_handle h) {
     const bool mrows_on = h->mlp_rows_nbig >= 0;
     if (!mrows_on && !rows_on && h->v2_variant < 0 && h->v1_variant < 0 && (rc = fold_first_dense(h, dp))) return rc;
     if (!mrows_on && !rows_on && h->v2_variant < 0 && (rc = setup_din_tail(h, dp))) return rc;
+    if (p.din.enabled == 2 && h->dien_frag && h->tune.dien_fused && h->din_tail_variant >= 0) {
+        // DIEN in one launch (k_dien_fused.h): the sequence stage on the matrix pipe AND DIN.py's 128 / 64 tail on raw split rows
+        const DinTailVariant& tv = kDinTailVariants[h->din_tail_variant];
+        if (tv.n0c == 8 && tv.n1c == 4 && tv.kpc == 1 && h->din_tail_run.e_unscale != 0.f) {
+            const bool d10 = p.din.emb_dim == 10;
+            h->dien_fused_lds = ((d10 ? DienFrag<10, 32>::total_pad : DienFrag<16, 32>::total_pad) + DinTailLds<8, 4, 1>::total_pad) * sizeof(float);
+            HIP_TRY(hipFuncSetAttribute(d10 ? reinterpret_cast<const void*>(&k_dien_fused<10, 32, 8, 4>) : reinterpret_cast<const void*>(&k_dien_fused<16, 32, 8, 4>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->dien_fused_lds));
+            h->dien_fused = true;
+        }
+    }
     HIP_TRY(hipMalloc((void**)&h->dev_plan, sizeof(DevPlan)));
     HIP_TRY(hipMemcpy(h->dev_plan, dp, sizeof(DevPlan), hipMemcpyHostToDevice));
     HIP_TRY(hipMalloc((void**)&h->dev_err, sizeof(int)));

@@ -164,6 +164,22 @@ int sprk_forward(sprk_handle h, const int32_t* ids, const float* dense, float* o
             fm.n = 1; fm.ids[0] = ids; fm.dense[0] = dense; fm.out[0] = out;
             return launch_din_fused(h, nullptr, nullptr, nullptr, nullptr, B, &fm, true, st);
         }
+        // DIEN in one launch (k_dien_fused): as above, the workspace is not touched and the branch is unconditional on dien_fused
+        if (h->plan.din.enabled == 2 && h->dien_fused) {
+            DienRun run = h->dien_run;
+            run.image = h->dien_frag;
+            const int ntiles = (B + 15) / 16;
+            int grid = (ntiles + DNF_WAVES - 1) / DNF_WAVES;
+            if (grid > h->num_cus) grid = h->num_cus;              // one 16-wave workgroup per CU (both weight images in its LDS)
+            if (h->plan.din.emb_dim == 10)
+                hipLaunchKernelGGL((k_dien_fused<10, 32, 8, 4>), dim3(grid), dim3(DNF_WAVES * 64), h->dien_fused_lds, st, run, h->din_tail_run, ids, dense, out, B,
+                                   h->dev_err, (const float*)h->din_tail_image, (float*)workspace);
+            else
+                hipLaunchKernelGGL((k_dien_fused<16, 32, 8, 4>), dim3(grid), dim3(DNF_WAVES * 64), h->dien_fused_lds, st, run, h->din_tail_run, ids, dense, out, B,
+                                   h->dev_err, (const float*)h->din_tail_image, (float*)workspace);
+            HIP_TRY(hipGetLastError());
+            return SPRK_OK;
+        }
         int rc = launch_din(h, ids, (float*)workspace, nullptr, B, st);
         if (rc) return rc;
         aux = (const float*)workspace;
@@ -259,7 +275,7 @@ static int forward_many_impl(sprk_handle h, int32_t n_batches, const int32_t* co
     // a model with a workspace (DIN: attention kernel -> pooled vectors -> tail kernel) needs one workspace slice per
     // stream; with a single slice its forwards stay in strict order
     const size_t ws_need = (sprk_workspace_bytes(h, B) + 255) & ~(size_t)255;
-    const bool ws_untouched = h->finalized && h->plan.din.enabled == 1 && h->din_fused;   // (sprk_forward's k_din_fused branch: unconditional, see there)
+    const bool ws_untouched = h->finalized && ((h->plan.din.enabled == 1 && h->din_fused) || (h->plan.din.enabled == 2 && h->dien_fused));   // (sprk_forward's k_din_fused branch: unconditional, see there)
     if (S >= 2 && ws_need > 0 && !ws_untouched) {
         while (S >= 2 && (!workspace || workspace_bytes < (size_t)S * ws_need)) --S;
         if (S < 2) S = 0;
@@ -537,6 +553,7 @@ int sprk_describe(sprk_handle h, char* buf, size_t buf_bytes) {
     if (h->plan.din.enabled == 2) stage = h->dien_frag ? "k_dien_seq_mfma" : "k_dien_seq";
     else if (h->plan.din.enabled == 1) stage = h->din_variant < 0 ? "k_din_pool" : (h->din_cols ? (h->din_fused_attn ? "k_din_fused" : "k_din_attn_cols") : "k_din_attn");
     if (h->plan.din.enabled == 1 && h->din_fused) snprintf(kern, sizeof(kern), "k_din_fused<KC=%d,tail 128/64>", h->din_cols_kc);
+    if (h->plan.din.enabled == 2 && h->dien_fused) snprintf(kern, sizeof(kern), "k_dien_fused<D=%d,tail 128/64>", h->plan.din.emb_dim);   // (stage: what sprk_din_pool runs)
     size_t uploaded = 0;
     for (size_t b : h->slot_bytes) uploaded += b;
 #ifndef SPRK_BUILD_DEFINES_STR

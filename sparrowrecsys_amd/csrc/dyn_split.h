@@ -14,6 +14,16 @@
 
 // max over the four 16-lane rows of a wave, result in every lane
 __device__ __forceinline__ float rows4_max(float v) {
+#if defined(SPRK_NO_ASM) || defined(SPRK_NO_ASM_ROWS4)
+    { const float t = fmaxf(v, __shfl_xor(v, 16)); return fmaxf(t, __shfl_xor(t, 32)); }
+#endif
+#ifdef SPRK_ASM_PAD
+    { float a = v, b = v;
+      asm volatile("s_nop 7\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 3" : "+v"(a), "+v"(b));
+      a = fmaxf(a, b); b = a;
+      asm volatile("s_nop 7\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 3" : "+v"(a), "+v"(b));
+      return fmaxf(a, b); }
+#endif
     float a = v, b = v;
     asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
     a = fmaxf(a, b);
@@ -37,6 +47,15 @@ __device__ __forceinline__ void dyn_split2(float x0, float x1, float scale, dyn_
     const dyn_f2 t = dyn_f2{x0, x1} * scale;
     hi = __builtin_convertvector(t, dyn_h2);
     const unsigned hb = __builtin_bit_cast(unsigned, hi);
+#if defined(SPRK_NO_ASM) || defined(SPRK_NO_ASM_SPLIT)
+    { lo = __builtin_convertvector(dyn_f2{fmaf(x0, scale, -(float)hi[0]), fmaf(x1, scale, -(float)hi[1])}, dyn_h2); return; }
+#endif
+#ifdef SPRK_ASM_PAD
+    { float r0, r1;
+      asm volatile("s_nop 3\n\tv_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n\ts_nop 1" : "=v"(r0) : "v"(x0), "v"(scale), "v"(hb));
+      asm volatile("s_nop 3\n\tv_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\ts_nop 1" : "=v"(r1) : "v"(x1), "v"(scale), "v"(hb));
+      lo = __builtin_convertvector(dyn_f2{r0, r1}, dyn_h2); return; }
+#endif
     float r0, r1;
     asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(r0) : "v"(x0), "v"(scale), "v"(hb));
     asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r1) : "v"(x1), "v"(scale), "v"(hb));

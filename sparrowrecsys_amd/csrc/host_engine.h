@@ -69,6 +69,8 @@ struct sprk_engine {
     bool din_fused_attn = false;   // TAIL = false instantiations replace k_din_attn_cols (sprk_din_pool, the unfused two-launch path)
     DinFusedRun din_fused_run;
     float* din_fused_image = nullptr;
+    bool dien_fused = false;       // DIEN in one launch (k_dien_fused.h): dien_frag AND the 128 / 64 tail on raw split rows
+    size_t dien_fused_lds = 0;
     bool din_attn_many = true;     // forward_many: one attention launch per group of batches 
     // register-chained fast path (k_deepfm_v2_chain); -1 = use the tile interpreter
     int v2_variant = -1;

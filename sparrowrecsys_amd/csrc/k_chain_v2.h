@@ -116,6 +116,16 @@ __device__ __forceinline__ float rows4_sum(float v) {
     // inline asm: hipcc 7.2's __builtin_amdgcn_permlane{16,32}_swap hands back its FIRST result for both
     // elements of the returned pair (the sum became x + x).  s_nop 1 = the two wait states a VALU-written
     // VGPR needs before a permlane swap reads it; the assembler inserts nothing inside asm statements.
+#if defined(SPRK_NO_ASM) || defined(SPRK_NO_ASM_ROWS4)
+    { const float t = v + __shfl_xor(v, 16); return t + __shfl_xor(t, 32); }
+#endif
+#ifdef SPRK_ASM_PAD
+    { float a = v, b = v;
+      asm volatile("s_nop 7\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 3" : "+v"(a), "+v"(b));
+      a += b; b = a;
+      asm volatile("s_nop 7\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 3" : "+v"(a), "+v"(b));
+      return a + b; }
+#endif
     float a = v, b = v;
     asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));   // a = [v0 v0 v2 v2], b = [v1 v1 v3 v3]
     a += b;

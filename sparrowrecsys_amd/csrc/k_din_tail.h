@@ -120,6 +120,183 @@ __global__ __launch_bounds__(256) void k_din_tail_pack(const float* __restrict__
     for (int i = LD::total + tid; i < LD::total_pad; i += 256) img[i] = 0.f;
 }
 
+// ---- the pieces of one task, shared by k_din_tail and the kernels that carry this tail as their epilogue (k_dien_fused.h) ----
+// S = the tail image in LDS; lane (r, q) as above.
+
+// UNF: the raw split rows of the embedding columns, one 16 + 16 byte piece per K = 32 block and lane
+template <class LD>
+__device__ __forceinline__ void din_tail_unf_gather(const DinTailRun& A, const int (&idv)[DT_MAX_COLS], int q, bool& bad,
+                                                    din_f16x8 (&eh)[LD::NBLK], din_f16x8 (&el)[LD::NBLK]) {
+    constexpr int NBLK = LD::NBLK;
+#pragma unroll
+    for (int pb = 0; pb < NBLK; ++pb) {
+        // (static indices only: a lane-dependent index into the kernel argument's arrays would move them to scratch)
+        const bool up = LD::EPB == 16 && (q >> 1) != 0;
+        const int g0 = LD::EPB == 16 ? 2 * pb : pb, g1 = LD::EPB == 16 ? 2 * pb + 1 : pb;
+        const int id = up ? idv[g1] : idv[g0];
+        const bool have = (up ? g1 : g0) < A.n_cols;
+        int voc = up ? A.vocab[g1] : A.vocab[g0];
+        const _Float16* tab = up ? A.Etab[g1] : A.Etab[g0];
+        if (!have) { voc = A.vocab[0]; tab = A.Etab[0]; }           // an absent column: column 0's all-zero row
+        const bool ok = have && (unsigned)id < (unsigned)voc;
+        bad |= have && !ok && id != -1;
+        const char* row = reinterpret_cast<const char*>(tab) + (size_t)(ok ? id : voc) * (4 * LD::EPB) +
+                          16 * (LD::EPB == 16 ? (q & 1) : q);
+        eh[pb] = *reinterpret_cast<const din_f16x8*>(row);           // (a missing id / an absent column: the all-zero row)
+        el[pb] = *reinterpret_cast<const din_f16x8*>(row + 2 * LD::EPB);
+    }
+}
+
+// UNF: fc0's embedding part, z0 += W0e^T [rows] on the f16 matrix pipe
+template <class LD, int N0C>
+__device__ __forceinline__ void din_tail_unf_fc0(const DinTailRun& A, const float* S, int lane, const din_f16x8 (&eh)[LD::NBLK],
+                                                 const din_f16x8 (&el)[LD::NBLK], f32x4 (&z0)[N0C]) {
+    constexpr int NBLK = LD::NBLK;
+    const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float* wf = S + LD::off_w0e + 4 * lane;
+#pragma unroll
+    for (int pb = 0; pb < NBLK; ++pb)
+#pragma unroll
+        for (int nb = 0; nb < N0C; ++nb) {
+            const din_f16x8 ah = __builtin_bit_cast(din_f16x8, ld4(wf + ((nb * NBLK + pb) * 2 + 0) * 256));
+            const din_f16x8 al = __builtin_bit_cast(din_f16x8, ld4(wf + ((nb * NBLK + pb) * 2 + 1) * 256));
+            f32x4 acc = mfma_f16(al, eh[pb], zero);
+            acc = mfma_f16(ah, el[pb], acc);
+            acc = mfma_f16(ah, eh[pb], acc);
+            z0[nb] += acc * A.e_unscale;
+        }
+}
+
+// From fc0's accumulators (bias + embedding columns) to the pre-sigmoid score of sample r (every lane of the sample's four holds it):
+// fc0's per-sample part (numerics, pooled history xp), PReLU, fc1, PReLU, the output dot.
+template <int N0C, int N1C, int KPC, bool DYN, bool UNF>
+__device__ __forceinline__ float din_tail_dense(const DinTailRun& A, const float* S, f32x4 (&z0)[N0C], const f32x4 (&xp)[KPC], float xna,
+                                                float xnb, int lane, int r, int q) {
+    using LD = DinTailLds<N0C, N1C, KPC>;
+    const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
+    // ---- fc0's per-sample part: pooled chunks, then the numeric chunk (N0C independent chains) ----
+    const float* w0r = S + LD::off_w0 + r * LD::S0 + 4 * q;
+    {
+        // the numeric chunk: A = W0^T[n][numeric q + 4 s] (two scalar LDS reads per block), two MFMAs per 16 outputs
+        const float* wn = S + LD::off_w0 + r * LD::S0 + KPC * 16 + q;
+#pragma unroll
+        for (int nb = 0; nb < N0C; ++nb) z0[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wn[nb * 16 * LD::S0], xna, z0[nb], 0, 0, 0);
+#pragma unroll
+        for (int nb = 0; nb < N0C; ++nb) z0[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wn[nb * 16 * LD::S0 + 4], xnb, z0[nb], 0, 0, 0);
+    }
+    if (UNF || (DYN && A.inv_w0p_scale != 0.f)) {             // (wave-uniform; UNF is only set up together with the pooled fragments)
+        // pooled history on the f16 pipe: per-sample dynamic scale (DIN's attention weights are not normalised), hi / lo split
+        float mx = 0.f;
+#pragma unroll
+        for (int c = 0; c < KPC; ++c)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) mx = fmaxf(mx, __builtin_fabsf(xp[c][j]));
+        mx = rows4_max(mx);
+        float scale, inv;
+        dyn_scale(mx, A.inv_w0p_scale, scale, inv);
+        const float* wf = S + LD::off_w0h + lane * 4;
+#pragma unroll
+        for (int b = 0; b < LD::KB0; ++b) {
+            din_f16x8 bh, bl;
+            dyn_split8(xp[2 * b], 2 * b + 1 < KPC ? xp[2 * b + 1 < KPC ? 2 * b + 1 : 0] : zero, scale, bh, bl);
+#pragma unroll
+            for (int nb = 0; nb < N0C; ++nb) {
+                const din_f16x8 ah = __builtin_bit_cast(din_f16x8, ld4(wf + ((nb * LD::KB0 + b) * 2 + 0) * 256));
+                const din_f16x8 al = __builtin_bit_cast(din_f16x8, ld4(wf + ((nb * LD::KB0 + b) * 2 + 1) * 256));
+                f32x4 acc = mfma_f16(al, bh, zero);
+                acc = mfma_f16(ah, bl, acc);
+                acc = mfma_f16(ah, bh, acc);
+                z0[nb] += acc * inv;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < KPC; ++c) {
+            const f32x4 b = xp[c];
+            f32x4 a[N0C];
+#pragma unroll
+            for (int nb = 0; nb < N0C; ++nb) a[nb] = ld4(w0r + nb * 16 * LD::S0 + 16 * c);
+#pragma unroll
+            for (int st = 0; st < 4; ++st)
+#pragma unroll
+                for (int nb = 0; nb < N0C; ++nb)
+                    z0[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[nb][st], b[st], z0[nb], 0, 0, 0);
+        }
+    }
+    // PReLU(alpha0) (DIN.py:164)
+#pragma unroll
+    for (int nb = 0; nb < N0C; ++nb) {
+        const f32x4 al = ld4(S + LD::off_a0 + nb * 16 + 4 * q);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float u = z0[nb][j];
+            z0[nb][j] = __builtin_amdgcn_fmed3f(u, 0.f, __builtin_inff()) + al[j] * __builtin_amdgcn_fmed3f(u, -__builtin_inff(), 0.f);
+        }
+    }
+    // ---- fc1: K = N0, its B operand is h1 as it sits in the registers (N1C chains) ----
+    f32x4 z1[N1C];
+    if constexpr (DYN) {
+        static_assert(N0C % 2 == 0, "K blocks of 32");
+        // per-sample scale from max |h1| (this lane's 4*N0C values, then the sample's other three q rows)
+        float mx = 0.f;
+#pragma unroll
+        for (int nb = 0; nb < N0C; ++nb)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) mx = fmaxf(mx, __builtin_fabsf(z0[nb][j]));
+        mx = rows4_max(mx);
+        float scale, inv;
+        dyn_scale(mx, A.inv_w1_scale, scale, inv);
+        f32x4 acc[N1C];
+#pragma unroll
+        for (int n1 = 0; n1 < N1C; ++n1) acc[n1] = zero;
+        const float* wf = S + LD::off_w1 + lane * 4;              // this lane's 16 bytes inside a 1-KB fragment (k_dyn_pack_w: lane order)
+#pragma unroll
+        for (int b = 0; b < N0C / 2; ++b) {
+            din_f16x8 bh, bl;
+            dyn_split8(z0[2 * b], z0[2 * b + 1], scale, bh, bl);
+#pragma unroll
+            for (int n1 = 0; n1 < N1C; ++n1) {
+                const din_f16x8 ah = __builtin_bit_cast(din_f16x8, ld4(wf + ((n1 * (N0C / 2) + b) * 2 + 0) * 256));
+                const din_f16x8 al = __builtin_bit_cast(din_f16x8, ld4(wf + ((n1 * (N0C / 2) + b) * 2 + 1) * 256));
+                acc[n1] = mfma_f16(ah, bh, acc[n1]);
+                acc[n1] = mfma_f16(ah, bl, acc[n1]);
+                acc[n1] = mfma_f16(al, bh, acc[n1]);
+            }
+        }
+#pragma unroll
+        for (int n1 = 0; n1 < N1C; ++n1) z1[n1] = acc[n1] * inv + ld4(S + LD::off_b1 + n1 * 16 + 4 * q);
+    } else {
+#pragma unroll
+    for (int n1 = 0; n1 < N1C; ++n1) z1[n1] = ld4(S + LD::off_b1 + n1 * 16 + 4 * q);
+    const float* w1r = S + LD::off_w1 + r * LD::S1 + 4 * q;
+#pragma unroll
+    for (int c = 0; c < N0C; ++c) {
+        f32x4 a[N1C];
+#pragma unroll
+        for (int n1 = 0; n1 < N1C; ++n1) a[n1] = ld4(w1r + n1 * 16 * LD::S1 + 16 * c);
+#pragma unroll
+        for (int st = 0; st < 4; ++st)
+#pragma unroll
+            for (int n1 = 0; n1 < N1C; ++n1)
+                z1[n1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[n1][st], z0[c][st], z1[n1], 0, 0, 0);
+    }
+    }
+    // PReLU(alpha1) (DIN.py:166) -> Dense(1) -> sigmoid (DIN.py:167)
+    float z = 0.f;
+#pragma unroll
+    for (int n1 = 0; n1 < N1C; ++n1) {
+        const f32x4 al = ld4(S + LD::off_a1 + n1 * 16 + 4 * q);
+        const f32x4 hw = ld4(S + LD::off_hw + n1 * 16 + 4 * q);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float u = z1[n1][j];
+            const float h2 = __builtin_amdgcn_fmed3f(u, 0.f, __builtin_inff()) + al[j] * __builtin_amdgcn_fmed3f(u, -__builtin_inff(), 0.f);
+            z = fmaf(hw[j], h2, z);
+        }
+    }
+    return rows4_sum(z);
+}
+
 template <int N0C, int N1C, int KPC, int WAVES, bool DYN, bool MB = false, bool UNF = false>
 __global__ __launch_bounds__(WAVES * 64, WAVES >= 16 ? 4 : 2) void k_din_tail(const DinTailRun A, const int* __restrict__ ids0,
                                                             const float* __restrict__ dense0, const float* __restrict__ aux0,
@@ -192,37 +369,9 @@ __global__ __launch_bounds__(WAVES * 64, WAVES >= 16 ? 4 : 2) void k_din_tail(co
         for (int nb = 0; nb < N0C; ++nb) z0[nb] = ld4(smem + LD::off_b0 + nb * 16 + 4 * q);
         if constexpr (UNF) {
             static_assert(DYN && DT_MAX_COLS == 4, "two K = 32 blocks of two columns, or four of one");
-            constexpr int NBLK = LD::NBLK;
-            din_f16x8 eh[NBLK], el[NBLK];
-#pragma unroll
-            for (int pb = 0; pb < NBLK; ++pb) {
-                // (static indices only: a lane-dependent index into the kernel argument's arrays would move them to scratch)
-                const bool up = LD::EPB == 16 && (q >> 1) != 0;
-                const int g0 = LD::EPB == 16 ? 2 * pb : pb, g1 = LD::EPB == 16 ? 2 * pb + 1 : pb;
-                const int id = up ? idv[g1] : idv[g0];
-                const bool have = (up ? g1 : g0) < A.n_cols;
-                int voc = up ? A.vocab[g1] : A.vocab[g0];
-                const _Float16* tab = up ? A.Etab[g1] : A.Etab[g0];
-                if (!have) { voc = A.vocab[0]; tab = A.Etab[0]; }           // an absent column: column 0's all-zero row
-                const bool ok = have && (unsigned)id < (unsigned)voc;
-                bad |= have && !ok && id != -1;
-                const char* row = reinterpret_cast<const char*>(tab) + (size_t)(ok ? id : voc) * (4 * LD::EPB) +
-                                  16 * (LD::EPB == 16 ? (q & 1) : q);
-                eh[pb] = *reinterpret_cast<const din_f16x8*>(row);           // (a missing id / an absent column: the all-zero row)
-                el[pb] = *reinterpret_cast<const din_f16x8*>(row + 2 * LD::EPB);
-            }
-            const float* wf = smem + LD::off_w0e + 4 * lane;
-#pragma unroll
-            for (int pb = 0; pb < NBLK; ++pb)
-#pragma unroll
-                for (int nb = 0; nb < N0C; ++nb) {
-                    const din_f16x8 ah = __builtin_bit_cast(din_f16x8, ld4(wf + ((nb * NBLK + pb) * 2 + 0) * 256));
-                    const din_f16x8 al = __builtin_bit_cast(din_f16x8, ld4(wf + ((nb * NBLK + pb) * 2 + 1) * 256));
-                    f32x4 acc = mfma_f16(al, eh[pb], zero);
-                    acc = mfma_f16(ah, el[pb], acc);
-                    acc = mfma_f16(ah, eh[pb], acc);
-                    z0[nb] += acc * A.e_unscale;
-                }
+            din_f16x8 eh[LD::NBLK], el[LD::NBLK];
+            din_tail_unf_gather<LD>(A, idv, q, bad, eh, el);
+            din_tail_unf_fc0<LD, N0C>(A, smem, lane, eh, el, z0);
         } else {
 #pragma unroll
         for (int g0 = 0; g0 < DT_MAX_COLS; g0 += 2) {             // two columns = 2*N0C loads in flight at a time
@@ -244,127 +393,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES >= 16 ? 4 : 2) void k_din_tail(co
         }
         if (tk + task_stride < ntasks) ld_ids(tk + task_stride);   // next task's ids fly under this task's MFMAs
 
-        // ---- fc0's per-sample part: pooled chunks, then the numeric chunk (N0C independent chains) ----
-        const float* w0r = smem + LD::off_w0 + r * LD::S0 + 4 * q;
-        {
-            // the numeric chunk: A = W0^T[n][numeric q + 4 s] (two scalar LDS reads per block), two MFMAs per 16 outputs
-            const float* wn = smem + LD::off_w0 + r * LD::S0 + KPC * 16 + q;
-#pragma unroll
-            for (int nb = 0; nb < N0C; ++nb) z0[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wn[nb * 16 * LD::S0], xna, z0[nb], 0, 0, 0);
-#pragma unroll
-            for (int nb = 0; nb < N0C; ++nb) z0[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wn[nb * 16 * LD::S0 + 4], xnb, z0[nb], 0, 0, 0);
-        }
-        if (UNF || (DYN && A.inv_w0p_scale != 0.f)) {             // (wave-uniform; UNF is only set up together with the pooled fragments)
-            // pooled history on the f16 pipe: per-sample dynamic scale (DIN's attention weights are not normalised), hi / lo split
-            float mx = 0.f;
-#pragma unroll
-            for (int c = 0; c < KPC; ++c)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) mx = fmaxf(mx, __builtin_fabsf(xp[c][j]));
-            mx = rows4_max(mx);
-            float scale, inv;
-            dyn_scale(mx, A.inv_w0p_scale, scale, inv);
-            const float* wf = smem + LD::off_w0h + lane * 4;
-#pragma unroll
-            for (int b = 0; b < LD::KB0; ++b) {
-                din_f16x8 bh, bl;
-                dyn_split8(xp[2 * b], 2 * b + 1 < KPC ? xp[2 * b + 1 < KPC ? 2 * b + 1 : 0] : zero, scale, bh, bl);
-#pragma unroll
-                for (int nb = 0; nb < N0C; ++nb) {
-                    const din_f16x8 ah = __builtin_bit_cast(din_f16x8, ld4(wf + ((nb * LD::KB0 + b) * 2 + 0) * 256));
-                    const din_f16x8 al = __builtin_bit_cast(din_f16x8, ld4(wf + ((nb * LD::KB0 + b) * 2 + 1) * 256));
-                    f32x4 acc = mfma_f16(al, bh, zero);
-                    acc = mfma_f16(ah, bl, acc);
-                    acc = mfma_f16(ah, bh, acc);
-                    z0[nb] += acc * inv;
-                }
-            }
-        } else {
-#pragma unroll
-            for (int c = 0; c < KPC; ++c) {
-                const f32x4 b = xp[c];
-                f32x4 a[N0C];
-#pragma unroll
-                for (int nb = 0; nb < N0C; ++nb) a[nb] = ld4(w0r + nb * 16 * LD::S0 + 16 * c);
-#pragma unroll
-                for (int st = 0; st < 4; ++st)
-#pragma unroll
-                    for (int nb = 0; nb < N0C; ++nb)
-                        z0[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[nb][st], b[st], z0[nb], 0, 0, 0);
-            }
-        }
-        // PReLU(alpha0) (DIN.py:164)
-#pragma unroll
-        for (int nb = 0; nb < N0C; ++nb) {
-            const f32x4 al = ld4(smem + LD::off_a0 + nb * 16 + 4 * q);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float u = z0[nb][j];
-                z0[nb][j] = __builtin_amdgcn_fmed3f(u, 0.f, __builtin_inff()) + al[j] * __builtin_amdgcn_fmed3f(u, -__builtin_inff(), 0.f);
-            }
-        }
-        // ---- fc1: K = N0, its B operand is h1 as it sits in the registers (N1C chains) ----
-        f32x4 z1[N1C];
-        if constexpr (DYN) {
-            static_assert(N0C % 2 == 0, "K blocks of 32");
-            // per-sample scale from max |h1| (this lane's 4*N0C values, then the sample's other three q rows)
-            float mx = 0.f;
-#pragma unroll
-            for (int nb = 0; nb < N0C; ++nb)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) mx = fmaxf(mx, __builtin_fabsf(z0[nb][j]));
-            mx = rows4_max(mx);
-            float scale, inv;
-            dyn_scale(mx, A.inv_w1_scale, scale, inv);
-            f32x4 acc[N1C];
-#pragma unroll
-            for (int n1 = 0; n1 < N1C; ++n1) acc[n1] = zero;
-            const float* wf = smem + LD::off_w1 + lane * 4;              // this lane's 16 bytes inside a 1-KB fragment (k_dyn_pack_w: lane order)
-#pragma unroll
-            for (int b = 0; b < N0C / 2; ++b) {
-                din_f16x8 bh, bl;
-                dyn_split8(z0[2 * b], z0[2 * b + 1], scale, bh, bl);
-#pragma unroll
-                for (int n1 = 0; n1 < N1C; ++n1) {
-                    const din_f16x8 ah = __builtin_bit_cast(din_f16x8, ld4(wf + ((n1 * (N0C / 2) + b) * 2 + 0) * 256));
-                    const din_f16x8 al = __builtin_bit_cast(din_f16x8, ld4(wf + ((n1 * (N0C / 2) + b) * 2 + 1) * 256));
-                    acc[n1] = mfma_f16(ah, bh, acc[n1]);
-                    acc[n1] = mfma_f16(ah, bl, acc[n1]);
-                    acc[n1] = mfma_f16(al, bh, acc[n1]);
-                }
-            }
-#pragma unroll
-            for (int n1 = 0; n1 < N1C; ++n1) z1[n1] = acc[n1] * inv + ld4(smem + LD::off_b1 + n1 * 16 + 4 * q);
-        } else {
-#pragma unroll
-        for (int n1 = 0; n1 < N1C; ++n1) z1[n1] = ld4(smem + LD::off_b1 + n1 * 16 + 4 * q);
-        const float* w1r = smem + LD::off_w1 + r * LD::S1 + 4 * q;
-#pragma unroll
-        for (int c = 0; c < N0C; ++c) {
-            f32x4 a[N1C];
-#pragma unroll
-            for (int n1 = 0; n1 < N1C; ++n1) a[n1] = ld4(w1r + n1 * 16 * LD::S1 + 16 * c);
-#pragma unroll
-            for (int st = 0; st < 4; ++st)
-#pragma unroll
-                for (int n1 = 0; n1 < N1C; ++n1)
-                    z1[n1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[n1][st], z0[c][st], z1[n1], 0, 0, 0);
-        }
-        }
-        // PReLU(alpha1) (DIN.py:166) -> Dense(1) -> sigmoid (DIN.py:167)
-        float z = 0.f;
-#pragma unroll
-        for (int n1 = 0; n1 < N1C; ++n1) {
-            const f32x4 al = ld4(smem + LD::off_a1 + n1 * 16 + 4 * q);
-            const f32x4 hw = ld4(smem + LD::off_hw + n1 * 16 + 4 * q);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float u = z1[n1][j];
-                const float h2 = __builtin_amdgcn_fmed3f(u, 0.f, __builtin_inff()) + al[j] * __builtin_amdgcn_fmed3f(u, -__builtin_inff(), 0.f);
-                z = fmaf(hw[j], h2, z);
-            }
-        }
-        z = rows4_sum(z);
+        const float z = din_tail_dense<N0C, N1C, KPC, DYN, UNF>(A, smem, z0, xp, xna, xnb, lane, r, q);
         const int mm = tl * 16 + r;
         if (q == 0 && mm < B) out[mm] = sigmoidf_acc(z + A.head_bias);
     }

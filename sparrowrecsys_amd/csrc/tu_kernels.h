@@ -36,6 +36,7 @@
 #include "k_emb_rank.h"
 #include "k_dien_seq.h"
 #include "k_dien_mfma.h"
+#include "k_dien_fused.h"
 #include "k_peer_gather.h"
 #include "k_csv_pack.h"
 #include "k_operators.h"             // stand-alone operator kernels (bit-exact gather, cross hash) -- closes the kernels' anonymous namespace

@@ -1125,6 +1125,7 @@ def test_tail_with_raw_embedding_rows_equals_the_folded_tail(torch, monkeypatch,
     feats = SY.synth_din(B, T, V, U, seed=77 + T)
     feats["userGenre1"][::7] = -1                                   # no id: the all-zero row
     monkeypatch.setenv("SPRK_DIN_FUSED", "0")                       # (k_din_tail itself: the two-launch path)
+    monkeypatch.setenv("SPRK_DIEN_FUSED", "0")
     out = {}
     for sw in ("1", "0"):
         monkeypatch.setenv("SPRK_TAIL_UNF", sw)
@@ -1153,6 +1154,83 @@ def test_tail_with_raw_embedding_rows_equals_the_folded_tail(torch, monkeypatch,
     n = 4096
     ref = fwd({k: v[:n] for k, v in feats.items()}, model.weights, dtype=np.float64, hist_len=T, movie_buckets=V, user_buckets=U)[:, 0]
     assert np.abs(out["1"] - out["0"]).max() <= 3e-6 and np.abs(out["1"][:n] - ref).max() <= TOL and out["1"].std() > 0.005
+
+
+@pytest.mark.parametrize("D,T,B", [(10, 5, 65536 + 21), (16, 20, 4099), (10, 1, 65), (16, 3, 1), (10, 50, 777)])
+def test_dien_in_one_launch_equals_the_two_launches(torch, monkeypatch, D, T, B):
+    """[r5] k_dien_fused (the recurrence, then k_din_tail's register chain as the same wave's epilogue) against k_dien_seq_mfma -> final
+    states in HBM -> k_din_tail (SPRK_DIEN_FUSED=0): the same inlined code on the same operands, so the scores may differ only where the
+    compiler contracted a multiply-add differently (<= 1e-6); against the fp64 oracle within the bar.  Masked slots, a user without history,
+    missing genre ids, a ragged last tile, more than one tile per wave (B > 65 536), bad ids in the history, the candidate and a tail
+    column all flagged."""
+    V, U = 3000, 900
+    feats = SY.synth_din(B, T, V, U, seed=900 + T)
+    h = feats["userRatedMovies"]
+    h[np.random.default_rng(T).random(h.shape) < 0.25] = 0
+    h[0] = 0
+    feats["movieGenre1"][::5] = -1
+    out = {}
+    for sw in ("1", "0"):
+        monkeypatch.setenv("SPRK_DIEN_FUSED", sw)
+        model = M.DIEN(seed=65, emb_dim=D, hist_len=T, movie_buckets=V, user_buckets=U)
+        k = model.engine.describe()["kernel"]
+        assert k.startswith("k_dien_fused<D=%d" % D if sw == "1" else "k_din_tail<8,4,1,UNF"), k
+        out[sw] = model.predict(feats)[:, 0]
+        np.testing.assert_array_equal(model.predict(feats)[:, 0], out[sw])
+        if B > 16:
+            ids, dense = model.pack(feats)
+            ti, td = _cuda(torch, ids), _cuda(torch, dense)
+            full = model.predict_device(ti, td)
+            assert torch.equal(model.predict_device(ti[5:B - 3], td[5:B - 3]), full[5:B - 3])    # launch-shape invariant
+            for key, row, val in (("userRatedMovies", B // 2, V), ("movieId", B - 1, V), ("userId", 11, U), ("userRatedMovies", 3, -2)):
+                bad = dict(feats)
+                bad[key] = feats[key].copy()
+                if bad[key].ndim == 2:
+                    bad[key][row, T - 1] = val
+                else:
+                    bad[key][row] = val
+                with pytest.raises(ValueError):
+                    model.predict(bad)
+            np.testing.assert_array_equal(model.predict(feats)[:, 0], out[sw])
+        model.engine.close()
+    assert np.abs(out["1"] - out["0"]).max() <= 1e-6, np.abs(out["1"] - out["0"]).max()
+    n = min(B, 4096)
+    ref = O.dien_forward({k: v[:n] for k, v in feats.items()}, model.weights, dtype=np.float64, hist_len=T, movie_buckets=V, user_buckets=U)[:, 0]
+    assert np.abs(out["1"][:n] - ref).max() <= TOL and (B < 64 or out["1"].std() > 0.005)
+
+
+@pytest.mark.parametrize("D,T,B", [(16, 7, 65536), (10, 5, 65536 + 21), (16, 20, 20000)])
+def test_dien_is_the_same_every_launch_and_the_oracles(torch, monkeypatch, D, T, B):
+    """[r5] Both DIEN paths at FULL occupancy (four waves per SIMD), 40 launches each: every launch bit for bit the first, the one-launch kernel
+    within 1e-6 of the two launches, and both within the bar of the fp64 oracle on every 8th tile.  Until round 5 k_dien_seq_mfma<16, 32> scored
+    ~40 of 4 096 tiles per launch off by up to 6e-5 -- other tiles every launch -- once four of its workgroups shared a CU, and the suite only
+    ran emb_dim 16 at batches that leave the CUs a quarter full (k_dien_fused.h, "an open issue, fenced": the cause is not known; the fence
+    showed 0 of 1.4 M tiles)."""
+    V, U = 3000, 900
+    feats = SY.synth_din(B, T, V, U, seed=41 + T)
+    h = feats["userRatedMovies"]
+    h[np.random.default_rng(T).random(h.shape) < 0.25] = 0
+    monkeypatch.setenv("SPRK_DIEN_FUSED", "0")
+    two = M.DIEN(seed=63, emb_dim=D, hist_len=T, movie_buckets=V, user_buckets=U)
+    assert two.engine.describe()["kernel"].startswith("k_din_tail")      # (the engine is built on first use: under THIS setting)
+    monkeypatch.setenv("SPRK_DIEN_FUSED", "1")
+    one = M.DIEN(seed=63, emb_dim=D, hist_len=T, movie_buckets=V, user_buckets=U)
+    assert one.engine.describe()["kernel"].startswith("k_dien_fused")
+    ids, dense = one.pack(feats)
+    ti, td = _cuda(torch, ids), _cuda(torch, dense)
+    first = {}
+    for name, model in (("two", two), ("one", one)):
+        first[name] = model.predict_device(ti, td).clone()
+        bad = 0
+        for _ in range(40):
+            bad += int((model.predict_device(ti, td) != first[name]).sum().item())
+        assert bad == 0, "%s: %d scores of 40 launches differ from the first launch" % (name, bad)
+    # (the same inlined code in another kernel: the compiler may contract a multiply-add differently -- a last bit here and there)
+    assert float((first["one"] - first["two"]).abs().max().item()) <= 1e-6
+    rows = np.concatenate([np.arange(t * 16, min(t * 16 + 16, B)) for t in range(0, (B + 15) // 16, 8)])
+    ref = O.dien_forward({k: v[rows] for k, v in feats.items()}, one.weights, dtype=np.float64, hist_len=T, movie_buckets=V, user_buckets=U)[:, 0]
+    for name in first:
+        assert np.abs(first[name].cpu().numpy()[rows] - ref).max() <= TIGHT, name
 
 
 def test_dien_reference_schema_and_bad_ids(torch, samples):
