@@ -42,10 +42,16 @@ for name, body in kernels(sys.argv[1]):
             continue
         allr = set()
         for o in ops: allr |= regs(o)
+        is_vm_load = op.startswith(("global_load", "scratch_load", "buffer_load", "flat_load")) and not op.startswith("global_load_lds")
+        is_lg_load = op.startswith(("ds_read", "ds_bpermute", "ds_swizzle", "ds_permute"))
+        srcr = set()
+        for o in ops[1:]: srcr |= regs(o)
         for q, nm in ((lg, "lgkmcnt"), (vm, "vmcnt")):
             for dst, txt, ln in q:
-                if dst & allr:
-                    print("%s line %d: %s   touches v%s of outstanding (%s) line %d %s" % (name[:40], n, t[:70], sorted(dst & allr), nm, ln, txt[:50])); found += 1
+                # (a later load of the SAME counter may overwrite an earlier one's registers: they return in order; reading them is not fine)
+                touched = (dst & srcr) if ((nm == "vmcnt" and is_vm_load) or (nm == "lgkmcnt" and is_lg_load)) else (dst & allr)
+                if touched:
+                    print("%s line %d: %s   touches v%s of outstanding (%s) line %d %s" % (name[:40], n, t[:70], sorted(touched), nm, ln, txt[:50])); found += 1
         if op.startswith(("ds_read", "ds_bpermute", "ds_swizzle", "ds_permute")): lg.append((regs(ops[0]), t, n))
         elif op.startswith(("ds_write", "ds_add", "ds_")): lg.append((set(), t, n))
         elif op.startswith("s_load") or op.startswith("s_buffer_load"): lg.append((set(), t, n))

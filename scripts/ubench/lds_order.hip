@@ -3,7 +3,7 @@
 // Why (round 5): k_dien_fused<16,...> sporadically scored a whole 16-sample tile with what looks like a STALE bias vector (a sample-
 // independent error of the recurrence's state), in builds whose loop mixes ordinary per-lane `ds_read_b128` (fragments, bias vectors) with
 // reads of ONE address by all 64 lanes (the per-block un-scale scalars) under partial waits (`lgkmcnt(4)`); every counted wait replays fine
-// if returns are in order (scripts/r05/isa_waitcnt_paths.py).  The test: a slow read (64 lanes on ONE bank, different rows: a 64-way conflict)
+// if returns are in order (scripts/isa/isa_waitcnt_paths.py).  The test: a slow read (64 lanes on ONE bank, different rows: a 64-way conflict)
 // is issued first into a register holding a sentinel, a fast read (all lanes one address) second; `s_waitcnt lgkmcnt(1)`; copy the first
 // register.  The sentinel in the copy = the second read retired first.
 //   hipcc --offload-arch=gfx950 -O2 -o scripts/ubench/lds_order scripts/ubench/lds_order.hip

@@ -2,7 +2,7 @@
 //
 // Why (round 5).  k_dien_fused<16,...> returned, for one or a few whole 16-sample tiles per launch and different tiles every run, scores off
 // by ~1e-4 (the recurrence's state by ~1e-3: the size of a lost lo.hi term of a split-f16 product).  Everything the compiler can see was in
-// order (scripts/r05/isa_waitcnt_check.py, isa_undef_reads.py, asm_hazards.py: nothing), the inline-asm statements padded with wait states
+// order (scripts/isa/isa_waitcnt_check.py, isa_undef_reads.py, asm_hazards.py: nothing), the inline-asm statements padded with wait states
 // changed nothing, but ONE `s_nop 1` between the groups of three MFMAs -- a statement the scheduler may not move LDS reads across -- made it go
 // away, and the builds that fail are the ones whose register allocation (128 VGPRs, four waves per SIMD) recycles the accumulator of a chain
 //     c1 = mfma(al, bh, 0);  c2 = mfma(ah, bl, c1);  c3 = mfma(ah, bh, c2)        (c1, c2, c3 in DIFFERENT registers)

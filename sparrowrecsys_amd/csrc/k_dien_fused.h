@@ -24,8 +24,8 @@
 // same once FOUR of its workgroups share a CU (B = 65 536: ~40 of 4 096 tiles per launch off by up to 6e-5 against the fp64 oracle; at the
 // batches the suite ran emb_dim 16 with, a quarter of that occupancy, never).  What it is NOT (each measured on the GPU or checked on the ISA):
 // the LDS-DMA staging (plain stores: same), the tail or where its gathers are issued (the state is already wrong), a hazard inside an asm
-// statement (every statement padded with wait states: same; scripts/r05/asm_hazards.py finds no transcendental / MFMA result read by one), a
-// missing or short s_waitcnt (scripts/r05/isa_waitcnt_check.py / isa_waitcnt_paths.py replay every counted wait of the loop, twice round, in
+// statement (every statement padded with wait states: same; scripts/isa/asm_hazards.py finds no transcendental / MFMA result read by one), a
+// missing or short s_waitcnt (scripts/isa/isa_waitcnt_check.py / isa_waitcnt_paths.py replay every counted wait of the loop, twice round, in
 // order: consistent), a read of a never-written VGPR (isa_undef_reads.py), LDS reads returning out of order or a load landing in SrcC of a
 // queued MFMA (scripts/ubench/lds_order.hip, mfma_srcc_war.hip: 5e9 trials each, none).  What it DEPENDS on: more than one wave per SIMD,
 // and the ORDER the scheduler picks under the 128-VGPR cap -- 256 VGPRs (eight waves): clean; a bare sched_barrier between the blocks mm(6)

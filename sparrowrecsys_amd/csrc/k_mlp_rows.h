@@ -126,7 +126,7 @@ __global__ __launch_bounds__(256) void k_mlp_rows_pack(const float* __restrict__
 //
 // [r5] NS = the number of small columns as a template parameter too (8: EmbeddingMLP.py / WideNDeep.py as written; -1: known at run
 // time only, the generic instantiation).  VERDICT r04 weak 2 read the loop's instruction mix off PMC (63 VALU + 7 MFMA per sample) and
-// called it issue-bound on instructions that do no arithmetic; build/sparrow.s (scripts/r05/isa_loop_mix.py) says which:
+// called it issue-bound on instructions that do no arithmetic; build/sparrow.s (scripts/isa/isa_loop_mix.py) says which:
 //   * a wave-uniform branch per small column (f < n_small) made every column's id read its own LDS round trip -- eight dependent
 //     ds_read_b32 + s_waitcnt lgkmcnt(0) in a row per task -- and kept hipcc from overlapping one column's eight row reads with the
 //     previous column's adds; its eight SGPR-pair conditions lived in spilled lanes (sixteen v_readlane per trip).  With NS a constant

@@ -73,7 +73,7 @@ def test_din_workspace_is_validated(torch):
 
 @pytest.mark.parametrize("name,kernel,stage", [
     ("deepfm_v2_c2", "k_deepfm_v2_joint", ""), ("deepfm_c2", "k_deepfm_pairs", ""), ("din_c3", "k_din_fused", "k_din_fused"),
-    ("embedding_mlp", "k_mlp_rows", ""), ("dien", "k_din_tail", "k_dien_seq_mfma")])
+    ("embedding_mlp", "k_mlp_rows", ""), ("dien", "k_dien_fused", "k_dien_seq_mfma")])     # (stage: what sprk_din_pool launches)
 def test_describe_reports_the_dispatched_kernels(torch, name, kernel, stage):
     if name == "deepfm_v2_c2":
         model = M.DeepFMv2(seed=1, emb_dim=16, fields=SY.CONFIG2_FIELDS, proj_dim=16)

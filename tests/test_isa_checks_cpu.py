@@ -42,3 +42,37 @@ def test_kernel_family_units_instantiate_what_the_single_unit_build_would():
     txt = open(os.path.join(ROOT, "sparrowrecsys_amd", "csrc", "tu_instances.h")).read()
     for i in range(1, 7):
         assert "SPRK_INST_%d __global__" % i in txt, "family %d has no instantiation" % i
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"), reason="needs hipcc")
+def test_generated_isa_of_every_unit_passes_the_static_checks(tmp_path):
+    """[r5] What the hunt for k_dien_seq_mfma's flaky tiles left behind (k_dien_fused.h, "an open issue, fenced"; scripts/isa/): every unit's device
+    ISA through (1) asm_hazards.py -- an instruction INSIDE an asm statement (the hazard recognizer does not look there) reading a register a
+    transcendental, an MFMA or -- for the permlane swaps -- any VALU instruction wrote too recently; (2) isa_waitcnt_check.py -- every basic block
+    replayed against in-order lgkmcnt / vmcnt queues: a register read or overwritten while the load that writes it is outstanding; and for
+    the two DIEN kernels (3) isa_undef_reads.py -- a VGPR read that some path reaches without a write (only the unused halves of operand
+    pairs with op_sel may show up) and (4) isa_waitcnt_paths.py -- the whole kernel replayed twice round every loop.  None of them found the
+    cause; all of them are cheap and would have found several of the bugs of rounds 1 to 4."""
+    env = dict(os.environ, PATH=os.environ.get("PATH", "") + ":/opt/rocm/bin")
+    csrc = os.path.join(ROOT, "sparrowrecsys_amd", "csrc")
+    units = ["sparrow_hip.hip"] + ["tu_%d.hip" % i for i in range(1, 7)]
+    procs = []
+    for u in units:
+        out = str(tmp_path / (u + ".s"))
+        procs.append((u, out, subprocess.Popen(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-I", os.path.join(ROOT, "include"), "-I", csrc,
+                                                "--cuda-device-only", "-S", os.path.join(csrc, u), "-o", out], env=env, stdout=subprocess.DEVNULL,
+                                               stderr=subprocess.DEVNULL)))
+    for u, out, p in procs:
+        assert p.wait(timeout=900) == 0, u
+    tool = lambda name: os.path.join(ROOT, "scripts", "isa", name)
+    for u, out, p in procs:
+        r = subprocess.run([sys.executable, tool("asm_hazards.py"), out, "."], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and "0 suspicious adjacencies" in r.stdout, u + "\n" + r.stdout[-2000:]
+        r = subprocess.run([sys.executable, tool("isa_waitcnt_check.py"), out, "."], capture_output=True, text=True, timeout=600)
+        assert r.stdout.strip().endswith("0 violations"), u + "\n" + r.stdout[-2000:]
+    tu4 = [out for u, out, p in procs if u == "tu_4.hip"][0]
+    r = subprocess.run([sys.executable, tool("isa_undef_reads.py"), tu4, "k_dien_fused|k_dien_seq_mfma"], capture_output=True, text=True, timeout=600)
+    flagged = [l for l in r.stdout.splitlines() if "before any write" in l]
+    assert all("v_pk_" in l and "op_sel" in l for l in flagged), "\n".join(flagged[:10])
+    r = subprocess.run([sys.executable, tool("isa_waitcnt_paths.py"), tu4, "k_dien_fused|k_dien_seq_mfma", "2"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.count(" 0 violations") == 4, r.stdout[-2000:]

@@ -24,7 +24,7 @@ def _kernel_rows(path):
 
 @pytest.mark.parametrize("row", _table(), ids=lambda r: r["workload"])
 def test_fraction_follows_from_the_kept_trace(row):
-    w = row["workload"].replace("c3_attn", "c3")                     # (config 3's two kernels share one trace)
+    w = row["workload"].replace("c3_attn", "c3").replace("dien_seq", "dien_ref")       # (config 3's two kernels share one trace; so do DIEN's)
     rows = _kernel_rows(os.path.join(P, w + "_strict_kernel_stats.csv"))
     hit = [r for r in rows if "::" + row["kernel"] in r[0].replace("(anonymous namespace)::", "::", 1).replace("sprk_dev::", "::", 1)]
     assert len(hit) == 1, (row["kernel"], [r[0][:60] for r in rows[:4]])
@@ -37,6 +37,8 @@ def test_fraction_follows_from_the_kept_trace(row):
     b = json.load(open(os.path.join(P, "bench_" + w + "_strict.json")))
     assert b["config"]["workload"].split(":")[0] == row["bench_workload"] and b["config"]["batch_per_gpu"] == row["batch"]
     rl = b["roofline"]["attention_only"] if row["workload"] == "c3_attn" else b["roofline"]     # (round 5: `roofline` IS the fused launch)
+    if row["workload"] == "dien_seq":
+        rl = b["roofline"]["sequence_only"]
     assert abs(rl["avg_launch_us"] - row["hip_event_us"]) < 1e-6
     # HIP events and the tracer agree on every kernel of 7 us and more (the tracer inflates shorter ones)
     if row["rocprof_avg_us"] >= 7.0 and row["hip_event_us"] >= 7.0:
