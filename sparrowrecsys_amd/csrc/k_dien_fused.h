@@ -27,10 +27,13 @@
 // statement (every statement padded with wait states: same; scripts/isa/asm_hazards.py finds no transcendental / MFMA result read by one), a
 // missing or short s_waitcnt (scripts/isa/isa_waitcnt_check.py / isa_waitcnt_paths.py replay every counted wait of the loop, twice round, in
 // order: consistent), a read of a never-written VGPR (isa_undef_reads.py), LDS reads returning out of order or a load landing in SrcC of a
-// queued MFMA (scripts/ubench/lds_order.hip, mfma_srcc_war.hip: 5e9 trials each, none).  What it DEPENDS on: more than one wave per SIMD,
+// queued MFMA or in the SrcA / SrcB of one just issued (scripts/ubench/lds_order.hip, mfma_srcc_war.hip, mfma_srcab_war.hip: 5e9 trials each, none).  What it DEPENDS on: more than one wave per SIMD,
 // and the ORDER the scheduler picks under the 128-VGPR cap -- 256 VGPRs (eight waves): clean; a bare sched_barrier between the blocks mm(6)
 // and mm(7) (the R and Z gates' input halves, which share one B operand): clean; in front of any other single block: not; fewer statements
 // the scheduler may not cross (rows4_sum on ds_bpermute instead of the volatile permlane statements): thirty times as many bad tiles.
+// A CPU fit of the observed state error against "vector X read as vector Y in step t" (fp64 recurrence, all pairs) points at block 7's bias
+// (the Z gate's input bias) being partly another vector in an early step (cosine 0.8 - 0.9, the right size) -- the block the barrier has to
+// stand in front of -- but no wait, hazard or register the tools can see explains a stale read there.
 // The cause is not known.  The fence below -- one `s_nop 1` statement in front of every group of three MFMAs, which LDS reads may not cross
 // -- measured 0 differing tiles in 1.4 M launches-of-tiles, every launch bit for bit the first and the first within 1.2e-7 of the fp64 oracle
 // where the unfenced two-launch path was 6e-5 off; tests/test_gpu_parity.py::test_dien_is_the_same_every_launch_and_the_oracles keeps asking.
