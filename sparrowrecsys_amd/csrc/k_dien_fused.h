@@ -27,7 +27,8 @@
 // statement (every statement padded with wait states: same; scripts/isa/asm_hazards.py finds no transcendental / MFMA result read by one), a
 // missing or short s_waitcnt (scripts/isa/isa_waitcnt_check.py / isa_waitcnt_paths.py replay every counted wait of the loop, twice round, in
 // order: consistent), a read of a never-written VGPR (isa_undef_reads.py), LDS reads returning out of order or a load landing in SrcC of a
-// queued MFMA or in the SrcA / SrcB of one just issued (scripts/ubench/lds_order.hip, mfma_srcc_war.hip, mfma_srcab_war.hip: 5e9 trials each, none).  What it DEPENDS on: more than one wave per SIMD,
+// queued MFMA or in the SrcA / SrcB of one just issued (scripts/ubench/lds_order.hip, mfma_srcc_war.hip, mfma_srcab_war.hip: 5e9 trials each, none), an MFMA needing more wait states behind the
+// packed conversions that write its B operand than hipcc pads (valu_to_mfma.hip: one is enough for every producer, hipcc pads two).  What it DEPENDS on: more than one wave per SIMD,
 // and the ORDER the scheduler picks under the 128-VGPR cap -- 256 VGPRs (eight waves): clean; a bare sched_barrier between the blocks mm(6)
 // and mm(7) (the R and Z gates' input halves, which share one B operand): clean; in front of any other single block: not; fewer statements
 // the scheduler may not cross (rows4_sum on ds_bpermute instead of the volatile permlane statements): thirty times as many bad tiles.
