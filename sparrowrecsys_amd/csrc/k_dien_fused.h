@@ -35,6 +35,9 @@
 // A CPU fit of the observed state error against "vector X read as vector Y in step t" (fp64 recurrence, all pairs) points at block 7's bias
 // (the Z gate's input bias) being partly another vector in an early step (cosine 0.8 - 0.9, the right size) -- the block the barrier has to
 // stand in front of -- but no wait, hazard or register the tools can see explains a stale read there.
+// A marker that separates ALL failing builds (ten) from ALL clean ones (eight) in the ISA: the failing ones keep the un-scale scalars of two
+// neighbouring blocks in ONE register pair (one uniform `ds_read_b64`) and pick the high one with `v_pk_fma_f32 ... op_sel:[0,1,0]`; it marks a
+// schedule, its semantics are deterministic, and tests/test_isa_checks_cpu.py trips if a rebuild brings it back.
 // The cause is not known.  The fence below -- one `s_nop 1` statement in front of every group of three MFMAs, which LDS reads may not cross
 // -- measured 0 differing tiles in 1.4 M launches-of-tiles, every launch bit for bit the first and the first within 1.2e-7 of the fp64 oracle
 // where the unfenced two-launch path was 6e-5 off; tests/test_gpu_parity.py::test_dien_is_the_same_every_launch_and_the_oracles keeps asking.

@@ -76,3 +76,9 @@ def test_generated_isa_of_every_unit_passes_the_static_checks(tmp_path):
     assert all("v_pk_" in l and "op_sel" in l for l in flagged), "\n".join(flagged[:10])
     r = subprocess.run([sys.executable, tool("isa_waitcnt_paths.py"), tu4, "k_dien_fused|k_dien_seq_mfma", "2"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and r.stdout.count(" 0 violations") == 4, r.stdout[-2000:]
+    # a marker, not a cause: EVERY build of the DIEN kernels that scored flaky tiles kept two blocks' un-scale scalars in one register pair and
+    # picked the high one with `v_pk_fma_f32 ... op_sel:[0,1,0]`, and no clean build did (k_dien_fused.h); the fenced kernels must not show it
+    import re
+    txt = open(tu4).read()
+    for m in re.finditer(r"^(_ZN8sprk_dev1[25]k_dien_(?:fused|seq_mfma)\w+):(.*?)\.end_amdhsa_kernel", txt, re.S | re.M):
+        assert not re.search(r"v_pk_fma_f32 [^\n]*op_sel:\[0,1,0\]", m.group(2)), m.group(1)
