@@ -116,3 +116,39 @@ def test_neuralcf_random_shapes(torch, case):
     print("neuralcf #%d: arch %d, D %d, hidden %s, vocab %d / %d, B %d -> %s, max|err| %.2e"
           % (case, arch, D, hidden, V, U, B, model.engine.describe()["kernel"], err))
     assert err <= TOL
+
+
+_FULL = [("din", 50, 32, {}), ("din", 20, 16, {}), ("din", 12, 10, {}), ("din", 5, 10, {}), ("din", 64, 32, {}), ("din", 30, 20, {}),
+         ("din", 50, 32, {"SPRK_DIN_FUSED": "0"}), ("din", 20, 16, {"SPRK_DIN_FUSED": "0"}), ("din", 5, 10, {"SPRK_DIN_FUSED_MIN_T": "1"}),
+         ("dien", 5, 10, {}), ("dien", 7, 16, {}), ("dien", 20, 16, {}), ("dien", 50, 10, {}),
+         ("dien", 5, 10, {"SPRK_DIEN_FUSED": "0"}), ("dien", 7, 16, {"SPRK_DIEN_FUSED": "0"}), ("dien", 20, 16, {"SPRK_DIEN_FUSED": "0"}),
+         ("dien", 7, 16, {"SPRK_DIEN_MFMA": "0"})]
+
+
+@pytest.mark.parametrize("case", range(len(_FULL)), ids=lambda i: "%s-T%d-D%d%s" % (_FULL[i][0], _FULL[i][1], _FULL[i][2], "".join("-%s=%s" % kv for kv in _FULL[i][3].items())))
+def test_din_and_dien_dispatch_shapes_at_full_occupancy(torch, monkeypatch, case):
+    """[r5] Every DIN / DIEN dispatch (one launch, two launches, raw-row and folded tails, the lane-per-sample DIEN stage) at B = 65 536 -- every CU
+    full --, 20 launches each bit for bit the first, and the first within 2e-6 of the fp64 oracle on every 16th tile.  The sweeps above run a few
+    thousand rows; k_dien_seq_mfma<16, 32>'s flaky tiles (k_dien_fused.h) only showed with four waves per SIMD.  scripts/r05/dbg/
+    full_occupancy_sweep.py is the same loop as a script (profiles/r05/experiments/r05_37: all 17 clean, max 6.6e-7)."""
+    kind, T, D, env = _FULL[case]
+    for k in ("SPRK_DIN_FUSED", "SPRK_DIN_FUSED_MIN_T", "SPRK_DIEN_FUSED", "SPRK_DIEN_MFMA"):
+        monkeypatch.delenv(k, raising=False)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    B, V, U = 65536, 5000, 7000
+    feats = SY.synth_din(B, T, V, U, seed=7 + T + D)
+    h = feats["userRatedMovies"]
+    h[np.random.default_rng(T).random(h.shape) < 0.2] = 0
+    m = (M.DIN if kind == "din" else M.DIEN)(seed=5, emb_dim=D, hist_len=T, movie_buckets=V, user_buckets=U)
+    ids, dense = m.pack(feats)
+    ti, td = torch.from_numpy(ids).cuda(), torch.from_numpy(dense).cuda()
+    first = m.predict_device(ti, td).clone()
+    bad = sum(int((m.predict_device(ti, td) != first).sum().item()) for _ in range(20))
+    rows = np.concatenate([np.arange(t * 16, t * 16 + 16) for t in range(0, B // 16, 16)])
+    fwd = O.din_forward if kind == "din" else O.dien_forward
+    ref = fwd({k: v[rows] for k, v in feats.items()}, m.weights, dtype=np.float64, hist_len=T, movie_buckets=V, user_buckets=U)[:, 0]
+    err = float(np.abs(first.cpu().numpy()[rows] - ref).max())
+    m.engine.close()
+    assert bad == 0, "%d scores of 20 launches differ from the first launch (%s)" % (bad, m.engine.describe() if False else kind)
+    assert err <= 2e-6, err
