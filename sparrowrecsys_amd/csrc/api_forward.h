@@ -574,7 +574,7 @@ int sprk_check_ids(sprk_handle h, void* stream) {
     if (flag) {
         HIP_TRY(hipMemsetAsync(h->dev_err, 0, sizeof(int), (hipStream_t)stream));
         HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
-        return fail(SPRK_ERANGE, "an id was outside its table (TF would raise InvalidArgumentError: assert_less_than_num_buckets)");
+        return fail(SPRK_ERANGE, "an id was outside its table (TF would raise InvalidArgumentError: assert_less_than_num_buckets) [flag 0x%x]", flag);
     }
     return SPRK_OK;
 }

@@ -17,44 +17,24 @@
 // on the two launches.
 #pragma once
 
-// AN OPEN ISSUE, FENCED (round 5; scripts/r05/31_dien_fused_race.sh ... 35_*, profiles/r05/experiments/r05_31 ... r05_35).
-// The first build of this kernel returned, for emb_dim 16, one to five WHOLE 16-sample tiles per launch of 257 -- other tiles every run -- whose
-// final state was off by ~1e-3 (scores ~1e-4) by the SAME vector for every sample of the tile, as if one bias vector of the AUGRU gates had
-// been stale; emb_dim 10 never.  The hunt then showed that k_dien_seq_mfma<16, 32> -- the same source, the product since round 3 -- does the
-// same once FOUR of its workgroups share a CU (B = 65 536: ~40 of 4 096 tiles per launch off by up to 6e-5 against the fp64 oracle; at the
-// batches the suite ran emb_dim 16 with, a quarter of that occupancy, never).  What it is NOT (each measured on the GPU or checked on the ISA):
-// the LDS-DMA staging (plain stores: same), the tail or where its gathers are issued (the state is already wrong), a hazard inside an asm
-// statement (every statement padded with wait states: same; scripts/isa/asm_hazards.py finds no transcendental / MFMA result read by one), a
-// missing or short s_waitcnt (scripts/isa/isa_waitcnt_check.py / isa_waitcnt_paths.py replay every counted wait of the loop, twice round, in
-// order: consistent), a read of a never-written VGPR (isa_undef_reads.py), LDS reads returning out of order or a load landing in SrcC of a
-// queued MFMA or in the SrcA / SrcB of one just issued (scripts/ubench/lds_order.hip, mfma_srcc_war.hip, mfma_srcab_war.hip: 5e9 trials each, none), an MFMA needing more wait states behind the
-// packed conversions that write its B operand than hipcc pads (valu_to_mfma.hip: one is enough for every producer, hipcc pads two).  What it DEPENDS on: more than one wave per SIMD,
-// and the ORDER the scheduler picks under the 128-VGPR cap -- 256 VGPRs (eight waves): clean; a bare sched_barrier between the blocks mm(6)
-// and mm(7) (the R and Z gates' input halves, which share one B operand): clean; in front of any other single block: not; fewer statements
-// the scheduler may not cross (rows4_sum on ds_bpermute instead of the volatile permlane statements): thirty times as many bad tiles.
-// A CPU fit of the observed state error against "vector X read as vector Y in step t" (fp64 recurrence, all pairs) points at block 7's bias
-// (the Z gate's input bias) being partly another vector in an early step (cosine 0.8 - 0.9, the right size) -- the block the barrier has to
-// stand in front of -- but no wait, hazard or register the tools can see explains a stale read there.
-// A marker that separates ALL failing builds (ten) from ALL clean ones (eight) in the ISA: the failing ones keep the un-scale scalars of two
-// neighbouring blocks in ONE register pair (one uniform `ds_read_b64`) and pick the high one with `v_pk_fma_f32 ... op_sel:[0,1,0]`; it marks a
-// schedule, its semantics are deterministic, and tests/test_isa_checks_cpu.py trips if a rebuild brings it back.
-// The cause is not known.  The fence below -- one `s_nop 1` statement in front of every group of three MFMAs, which LDS reads may not cross
-// -- measured 0 differing tiles in 1.4 M launches-of-tiles, every launch bit for bit the first and the first within 1.2e-7 of the fp64 oracle
-// where the unfenced two-launch path was 6e-5 off; tests/test_gpu_parity.py::test_dien_is_the_same_every_launch_and_the_oracles keeps asking.
-// -DDNF_GROUP_FENCE=0 brings the failing build back.
-#ifndef DNF_GROUP_FENCE
-#define DNF_GROUP_FENCE 1
-#endif
-#ifndef DNF_XP
-#define DNF_XP 0                      // experiment bits of the hunt above (build with -DDNF_GROUP_FENCE=0): 1 tail gathers behind the last step, 2 full wait in front of the
-#endif                                // tail, 4 run-time D mask, 8 eight waves / 256 VGPRs, 16 eight waves / 128, 32 staging by plain stores, 64 sleep behind the barrier,
-                                      // 128 final state -> workspace, 256 / 512 / 1024 nops behind / full wait / nops in front of every MFMA group, 2048 no peeled step,
-                                      // 8192 / 16384 `s_nop 1` in front / behind, 65536 bare sched_barrier, 131072 empty asm + memory clobber; -DDNF_BAR=mask: a
-                                      // sched_barrier in front of block b for every set bit b
-#define DNF_WAVES ((DNF_XP & 24) ? 8 : 16)
+// WHAT FUSING IT UNCOVERED, AND ITS CAUSE ([r5] found and fenced, [r6] explained; docs/open_issue_dien_tiles.md has the whole trail).
+// The first build of this kernel returned, for emb_dim 16, a few WHOLE 16-sample tiles per launch -- other tiles every run -- whose final state was
+// off by ~1e-3; k_dien_seq_mfma<16, 32>, the product since round 3, did the same once four of its workgroups shared a CU (~40 of 4 096 tiles per launch
+// up to 6e-5 off the fp64 oracle).  Round 5 fenced it (`s_nop 1` statements the scheduler may not move LDS reads across) without knowing why that helped.
+// Round 6, on the failing build's ASSEMBLY (scripts/r06/isa_patch_build.py: wait states, probes, dumps and single-instruction replacements between
+// hipcc's compile and assemble steps): every input of ONE instruction was right and its result wrong --
+//     v_pk_fma_f32 v[4:5], v[36:37], v[0:1], v[48:49] op_sel:[0,1,0]        (pre_z = acc * un + bias, un = the HIGH dword of a ds_read_b64 pair)
+// came out as the bias alone in its LOW half for lanes 48..63.  Replacing that one instruction by the op_sel-free form (or two v_fma_f32) in the
+// otherwise identical binary: 0 bad tiles; more wait states, full waits, a copy of the MFMA result in fresh registers: no change.  It is a property of
+// gfx950 that needs no MFMA in the victim wave at all (scripts/ubench/pkfma_opsel_mfma.hip): a packed-f32 VALU op whose low result takes the high dword
+// of a VGPR src1 reads that dword as 0 in the wave's last quarter while ANOTHER wave of the SIMD issues 16x16 MFMAs with 128-bit operands back to
+// back.  Which is why it needed four waves per SIMD, why it moved with every change of the schedule (hipcc only forms the pair when two blocks' un
+// loads end up neighbours), and why all ten failing builds and none of the clean ones carried that op_sel.  The fix is lone_scalar() (dyn_split.h) on
+// the un-scale scalar, and scripts/isa/isa_pk_opsel.py over every unit and over the built library as the guard that does not depend on the compiler.
+#define DNF_WAVES 16
 
 template <int D, int H, int N0C, int N1C>
-__global__ __launch_bounds__(DNF_WAVES * 64, (DNF_XP & 8) ? 2 : 4) void k_dien_fused(const DienRun A, const DinTailRun TL, const int* __restrict__ ids,
+__global__ __launch_bounds__(DNF_WAVES * 64, 4) void k_dien_fused(const DienRun A, const DinTailRun TL, const int* __restrict__ ids,
                                                                   const float* __restrict__ dense, float* __restrict__ out, int B,
                                                                   int* __restrict__ err, const float* __restrict__ tail_image, float* __restrict__ dbg) {
     using FR = DienFrag<D, H>;
@@ -85,36 +65,20 @@ __global__ __launch_bounds__(DNF_WAVES * 64, (DNF_XP & 8) ? 2 : 4) void k_dien_f
 #pragma unroll 1
     for (int c = wave; c < C0 + C1; c += DNF_WAVES) {
         const float* src = c < C0 ? A.image + c * 256 : tail_image + (c - C0) * 256;
-        if constexpr ((DNF_XP & 32) != 0) st4(smem + c * 256 + lane * 4, ld4(src + lane * 4));
-        else
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + lane * 4),
                                          (__attribute__((address_space(3))) void*)(smem + c * 256), 16, 0, 0);
     }
     __syncthreads();
-    if constexpr ((DNF_XP & 64) != 0) { __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(127); __syncthreads(); }
 
     const float* fl = W + 4 * lane;                               // this lane's 16 bytes of a fragment half
     auto vec = [&](int v) { return ld4(W + FR::vec0 + v * 16 + 4 * q); };
     auto mm = [&](int blk, din_f16x8 bh, din_f16x8 bl, f32x4 bias) __attribute__((always_inline)) {
         const din_f16x8 ah = __builtin_bit_cast(din_f16x8, ld4(fl + blk * 512));
         const din_f16x8 al = __builtin_bit_cast(din_f16x8, ld4(fl + blk * 512 + 256));
-        if constexpr ((DNF_XP & 512) != 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        if constexpr ((DNF_XP & 1024) != 0) asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
-        if constexpr ((DNF_XP & 256) != 0) __builtin_amdgcn_sched_barrier(0);
-        if constexpr (DNF_GROUP_FENCE || (DNF_XP & 8192) != 0) asm volatile("s_nop 1");          // (the fence: see the head of this file)
-        if constexpr ((DNF_XP & 65536) != 0) __builtin_amdgcn_sched_barrier(0);
-        if (((DNF_XP & 262144) && blk < 4) || ((DNF_XP & 524288) && (blk == 4 || blk == 5)) || ((DNF_XP & 1048576) && blk >= 6 && blk < 9) ||
-            ((DNF_XP & 2097152) && blk >= 9)) __builtin_amdgcn_sched_barrier(0);
-#ifdef DNF_BAR
-        if ((DNF_BAR >> blk) & 1) __builtin_amdgcn_sched_barrier(0);
-#endif
-        if constexpr ((DNF_XP & 131072) != 0) asm volatile("" ::: "memory");
         f32x4 acc = mfma_f16(al, bh, zero);
         acc = mfma_f16(ah, bl, acc);
         acc = mfma_f16(ah, bh, acc);
-        if constexpr ((DNF_XP & 256) != 0) { asm volatile("s_nop 7\n\ts_nop 7" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
-        if constexpr ((DNF_XP & 16384) != 0) asm volatile("s_nop 1");
-        const float un = W[FR::S_UN + blk];
+        const float un = lone_scalar(W[FR::S_UN + blk]);         // [r6] never the high dword of a pair: dyn_split.h
         return f32x4{fmaf(acc.x, un, bias.x), fmaf(acc.y, un, bias.y), fmaf(acc.z, un, bias.z), fmaf(acc.w, un, bias.w)};
     };
     const float s_xh = W[FR::S_XH], s_p = W[FR::S_P], s_gs = W[FR::S_GS];
@@ -129,7 +93,6 @@ __global__ __launch_bounds__(DNF_WAVES * 64, (DNF_XP & 8) ? 2 : 4) void k_dien_f
         f32x4 h = zero, g = zero, hs = vec(FR::V_H0);
         if (id < 0 || id >= A.vocab) { bad = true; id = 0; }
         f32x4 x = qin ? ld4(A.table + (size_t)id * A.Dp + 4 * q) : zero;
-        [[maybe_unused]] float dbg_a = 0.f;
         // one step of the recurrence (k_dien_seq_mfma's, statement for statement); every step but the last requests the next slot's row
         auto step_body = [&](const f32x4 xt, const bool live) __attribute__((always_inline)) {
             din_f16x8 bh, bl;
@@ -170,7 +133,6 @@ __global__ __launch_bounds__(DNF_WAVES * 64, (DNF_XP & 8) ? 2 : 4) void k_dien_f
                 const f32x4 pre_h = mm(10, bh, bl, vec(FR::V_GIN + 2));
                 dyn_split8(pre_h, zero, s_pre2, bh, bl);
                 const f32x4 hn = dm_tanh4(mm(11, bh, bl, vec(FR::V_GOUT + 2)));
-                if constexpr ((DNF_XP & 32768) != 0) dbg_a = a;
                 const f32x4 u = f32x4{a, a, a, a} * rt;
                 hs = u * hn + (one - u) * hs;
             }
@@ -185,23 +147,11 @@ __global__ __launch_bounds__(DNF_WAVES * 64, (DNF_XP & 8) ? 2 : 4) void k_dien_f
             }
             step_body(xt, live);
         };
-        if constexpr ((DNF_XP & 2048) != 0) {                     // experiment: no peeled last step (every step requests a next row: slot T - 1 again)
-#pragma unroll 1
-            for (int t = 0; t < A.T; ++t) {
-                const bool live = id != 0;
-                const f32x4 xt = x;
-                id = row[A.hist_col + min(t + 1, A.T - 1)];
-                if (id < 0 || id >= A.vocab) { bad = true; id = 0; }
-                x = qin ? ld4(A.table + (size_t)id * A.Dp + 4 * q) : zero;
-                step_body(xt, live);
-            }
-        } else
 #pragma unroll 1
         for (int t = 0; t + 1 < A.T; ++t) step(t, std::false_type{});
         // the tail's operands fly under the last step
         din_f16x8 eh[LD::NBLK], el[LD::NBLK];
         float xna, xnb;
-        if constexpr ((DNF_XP & 1) != 0 && (DNF_XP & 2048) == 0) step(A.T - 1, std::true_type{});
         din_tail_unf_gather<LD>(TL, idv, q, bad, eh, el);
         {
             const float* nrow = dense + (size_t)m * TL.ND;
@@ -209,28 +159,14 @@ __global__ __launch_bounds__(DNF_WAVES * 64, (DNF_XP & 8) ? 2 : 4) void k_dien_f
             xna = nrow[min(q, last)];
             xnb = nrow[min(q + 4, last)];
         }
-        if constexpr ((DNF_XP & 1) == 0 && (DNF_XP & 2048) == 0) step(A.T - 1, std::true_type{});
-        if constexpr ((DNF_XP & 2) != 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_nop 7\n\ts_nop 7" ::: "memory");
+        step(A.T - 1, std::true_type{});
         const int next = tile + gridDim.x * DNF_WAVES;
         if (next < ntiles) ld_ids(next);                           // (a persistent launch: the next tile's ids under this tile's tail)
 
         // ---- the tail: the final state is its pooled-history operand (what k_dien_seq_mfma stores: features beyond D are zeros) ----
         f32x4 xp[1];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) xp[0][j] = 4 * q + j < ((DNF_XP & 4) ? A.Dp : D) ? hs[j] : 0.f;
-        if constexpr ((DNF_XP & 128) != 0) {                      // experiment: the final state where the two-launch path keeps it
-            if (tile * 16 + r < B && 4 * q < A.NA) {
-                st4(dbg + (size_t)m * A.NA + 4 * q, xp[0]);
-                const size_t pl = (size_t)B * A.NA;
-                if constexpr ((DNF_XP & 32768) != 0) {
-                st4(dbg + pl + (size_t)m * A.NA + 4 * q, c);
-                st4(dbg + 2 * pl + (size_t)m * A.NA + 4 * q, x);
-                st4(dbg + 3 * pl + (size_t)m * A.NA + 4 * q, h);
-                st4(dbg + 4 * pl + (size_t)m * A.NA + 4 * q, g);
-                st4(dbg + 5 * pl + (size_t)m * A.NA + 4 * q, f32x4{dbg_a, dbg_a, dbg_a, dbg_a});
-                }
-            }
-        }
+        for (int j = 0; j < 4; ++j) xp[0][j] = 4 * q + j < D ? hs[j] : 0.f;
         f32x4 z0[N0C];
 #pragma unroll
         for (int nb = 0; nb < N0C; ++nb) z0[nb] = ld4(S + LD::off_b0 + nb * 16 + 4 * q);

@@ -34,14 +34,6 @@
 #define DM_BLOCKS 12
 #define DM_VECS 15
 #define DM_WAVES 4
-// [r5] 1: one `s_nop 1` statement in front of every group of three MFMAs.  Found while fusing this stage with the tail (k_dien_fused.h tells the
-// story): at emb_dim 16 and FOUR workgroups per CU (B = 65 536) this kernel scored ~40 of 4 096 tiles per launch off by up to 6e-5 -- other
-// tiles every launch -- against the fp64 oracle, which the fused kernel with the fence matched to 1.2e-7 on the same tiles; the suite only ran
-// emb_dim 16 at batches that leave the CUs a quarter full.  Cause unknown, the fence measured clean; tests/test_gpu_parity.py::
-// test_dien_is_the_same_every_launch_and_the_oracles.
-#ifndef DM_GROUP_FENCE
-#define DM_GROUP_FENCE 1
-#endif
 template <int D, int H>
 struct DienFrag {
     static_assert(D <= 16 && H == 32, "one 16-feature chunk per vector, two attention blocks");
@@ -171,13 +163,10 @@ __global__ __launch_bounds__(DM_WAVES * 64, 4) void k_dien_seq_mfma(const DienRu
     auto mm = [&](int blk, din_f16x8 bh, din_f16x8 bl, f32x4 bias) {
         const din_f16x8 ah = __builtin_bit_cast(din_f16x8, ld4(fl + blk * 512));
         const din_f16x8 al = __builtin_bit_cast(din_f16x8, ld4(fl + blk * 512 + 256));
-#if DM_GROUP_FENCE
-        asm volatile("s_nop 1");                                  // (the fence: k_dien_fused.h, "an open issue, fenced" -- this kernel had it too)
-#endif
         f32x4 acc = mfma_f16(al, bh, zero);
         acc = mfma_f16(ah, bl, acc);
         acc = mfma_f16(ah, bh, acc);
-        const float un = W[FR::S_UN + blk];
+        const float un = lone_scalar(W[FR::S_UN + blk]);         // [r6] never the high dword of a pair: dyn_split.h
         return f32x4{fmaf(acc.x, un, bias.x), fmaf(acc.y, un, bias.y), fmaf(acc.z, un, bias.z), fmaf(acc.w, un, bias.w)};
     };
     const float s_xh = W[FR::S_XH], s_p = W[FR::S_P], s_gs = W[FR::S_GS];

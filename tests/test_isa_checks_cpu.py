@@ -76,9 +76,21 @@ def test_generated_isa_of_every_unit_passes_the_static_checks(tmp_path):
     assert all("v_pk_" in l and "op_sel" in l for l in flagged), "\n".join(flagged[:10])
     r = subprocess.run([sys.executable, tool("isa_waitcnt_paths.py"), tu4, "k_dien_fused|k_dien_seq_mfma", "2"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and r.stdout.count(" 0 violations") == 4, r.stdout[-2000:]
-    # a marker, not a cause: EVERY build of the DIEN kernels that scored flaky tiles kept two blocks' un-scale scalars in one register pair and
-    # picked the high one with `v_pk_fma_f32 ... op_sel:[0,1,0]`, and no clean build did (k_dien_fused.h); the fenced kernels must not show it
-    import re
-    txt = open(tu4).read()
-    for m in re.finditer(r"^(_ZN8sprk_dev1[25]k_dien_(?:fused|seq_mfma)\w+):(.*?)\.end_amdhsa_kernel", txt, re.S | re.M):
-        assert not re.search(r"v_pk_fma_f32 [^\n]*op_sel:\[0,1,0\]", m.group(2)), m.group(1)
+    # [r6] the cause of those flaky tiles (k_dien_fused.h; scripts/ubench/pkfma_opsel_mfma.hip): on gfx950 a packed-f32 VALU instruction whose LOW
+    # result takes the HIGH dword of a VGPR src1 (`v_pk_fma_f32 ... op_sel:[0,1,0]`) reads that dword as 0 in lanes 48..63 while another wave of the
+    # SIMD issues 16x16 MFMAs with 128-bit operands.  hipcc forms it by itself (SLP + operand folding); NO kernel of the library may carry one --
+    # any kernel can share a SIMD with a wave of another launch.  (The SGPR-pair form is measured clean and only listed.)
+    r = subprocess.run([sys.executable, tool("isa_pk_opsel.py")] + [out for u, out, p in procs], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "\n0 packed-f32 instructions take the high dword of a VGPR src1" in "\n" + r.stdout, r.stdout[-3000:]
+
+
+def test_pk_opsel_scanner_sees_the_form(tmp_path):
+    """The scanner itself: the failing build's instruction is a hit, the op_sel_hi broadcast and the SGPR-pair form are not."""
+    f = tmp_path / "k.s"
+    f.write_text("k_a:\n\tv_pk_fma_f32 v[4:5], v[36:37], v[0:1], v[48:49] op_sel:[0,1,0]\n\tv_pk_mul_f32 v[4:5], v[36:37], v[0:1] op_sel:[0,1]\n"
+                 "k_b:\n\tv_pk_fma_f32 v[4:5], v[36:37], v[0:1], v[48:49] op_sel_hi:[1,0,1]\n\tv_pk_fma_f32 v[4:5], v[36:37], s[0:1], v[48:49] op_sel:[0,1,0]\n"
+                 "\tv_pk_fma_f32 v[4:5], v[36:37], v[0:1], v[48:49] op_sel:[1,0,0]\n\tv_pk_add_f32 v[4:5], v[36:37], v[0:1] op_sel:[0,1] op_sel_hi:[1,0]\n")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "isa", "isa_pk_opsel.py"), str(f)], capture_output=True, text=True)
+    assert r.returncode == 1, r.stdout
+    assert "3 packed-f32 instructions take the high dword of a VGPR src1 for their low result (1 more from an SGPR pair)" in r.stdout, r.stdout
+    assert r.stdout.count("k_a:") == 2 and r.stdout.count("VGPR src1.hi -> lo") == 3
