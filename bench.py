@@ -1341,7 +1341,7 @@ def serving_workload(args):
     p_.join(timeout=30)
     srv.close()
     pct = lambda p: lat[min(len(lat) - 1, int(p * len(lat)))] * 1e3
-    # [r5] past one GIL: serving.serve_workers -- N worker processes, one engine each, one port (SO_REUSEPORT) -- under N clients
+    # [r5] past one GIL: serving.serve_workers -- N front processes on one port (SO_REUSEPORT) in front of ONE engine process -- under N clients
     workers_blk = {}
     n_workers = int(os.environ.get("SPRK_BENCH_SERVING_WORKERS", "12"))
     if n_workers > 1:

@@ -27,6 +27,11 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* [r6] The library is built with -fvisibility=hidden: the entry points declared between this push and its pop are its WHOLE dynamic symbol table
+ * (tests/test_cabi.py compares `nm -D` with this header). */
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility push(default)
+#endif
 
 #define SPRK_ABI_VERSION 2
 
@@ -391,6 +396,9 @@ int sprk_upload_external(sprk_handle h, int32_t slot, const void* dev_ptr, size_
 
 const char* sprk_last_error(void);
 
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

@@ -93,6 +93,7 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     # counts, ablation kernels, the stamped-timeline build's file writes) must not be reused as the product after the variable is
     # unset, nor the product when it is set.  The string the library was built with sits next to it.
     defines = " ".join(os.environ.get("SPRK_BUILD_DEFINES", "").split())
+    stamp_defines = defines
     stamp = LIB_PATH + ".defines"
     def fresh():
         if not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < max(os.path.getmtime(d) for d in deps):
@@ -101,7 +102,7 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
             built_with = open(stamp).read().strip()
         except OSError:
             built_with = ""                                       # (no stamp: a product build of an earlier tree)
-        return built_with == defines
+        return built_with == stamp_defines
     if not force and fresh():
         return LIB_PATH
     # several processes (one rank per GPU, pytest-xdist workers) may get here at once: one builds, the others wait
@@ -122,7 +123,14 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
             import tempfile
             from concurrent.futures import ThreadPoolExecutor
             units = [SRC_PATH] + sorted(os.path.join(csrc, f) for f in os.listdir(csrc) if f.startswith("tu_") and f.endswith(".hip"))
-            flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-pthread", "-I", INCLUDE_DIR, "-I", csrc]
+            # [r6, ADVICE r05] the stamped-timeline builds (-DSPRK_DF_XP) keep their stamps in `static __device__` arrays that sprk_destroy reads
+            # with hipMemcpyFromSymbol: split over units, every unit has its own copy and the main unit's is all zeros.  One unit for those.
+            if "SPRK_DF_XP" in defines or "SPRK_SINGLE_TU" in defines:
+                units = [SRC_PATH]
+                if "SPRK_SINGLE_TU" not in defines:
+                    defines = defines + " -DSPRK_SINGLE_TU"
+            flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-pthread", "-fvisibility=hidden", "-fvisibility-inlines-hidden",
+                     "-I", INCLUDE_DIR, "-I", csrc]               # [r6] hidden by default: include/sparrow_hip.h's declarations are the only exports
             if defines:                                           # experiment builds (e.g. -DSPRK_DF_XP: k_din_fused's ablation variants)
                 flags = defines.split() + ["-DSPRK_BUILD_DEFINES_STR=\"%s\"" % defines.replace('"', "'")] + flags
             objdir = tempfile.mkdtemp(prefix="sprk_obj_")
@@ -138,7 +146,7 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
                     return obj
                 with ThreadPoolExecutor(max_workers=min(len(units), os.cpu_count() or 1)) as pool:
                     objs = list(pool.map(compile_unit, units))
-                cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-pthread"] + objs + ["-o", tmp]
+                cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-pthread", "-Wl,--version-script=" + os.path.join(csrc, "exports.map")] + objs + ["-o", tmp]
                 if verbose:
                     print(" ".join(cmd))
                 res = subprocess.run(cmd, capture_output=True, text=True)
@@ -148,7 +156,7 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
                 shutil.rmtree(objdir, ignore_errors=True)
             os.replace(tmp, LIB_PATH)
             with open(stamp, "w") as f:
-                f.write(defines + "\n")
+                f.write(stamp_defines + "\n")
             return LIB_PATH
         finally:
             fcntl.flock(lock, fcntl.LOCK_UN)

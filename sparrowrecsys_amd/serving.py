@@ -483,17 +483,31 @@ class PredictServer:
 # GPU: 5 993 requests/s from 8 clients against 4 416 from one process, p99 13 ms, and a lone client fell from 3 364 to 1 514 requests/s.
 # ---------------------------------------------------------------------------------------------------------------------------
 class _EngineProxy:
-    """What a front process hands PredictServer as its model: predict(feats) = one round trip to the engine process."""
+    """What a front process hands PredictServer as its model: predict(feats) = one round trip to the engine process.  [r6, ADVICE r05] Every
+    request carries an id and the reply must echo it: a reply that is out of step (it cannot be, the engine answers each request once -- but a
+    bug there would hand a client another client's scores, same candidate count, nothing else to notice it by) is an error, not an answer.  A dead
+    engine (EOF / reset on the connection) stops the front: the pool's parent sees a front exit instead of a port that answers 500 forever."""
 
-    def __init__(self, address):
+    def __init__(self, address, on_engine_lost=None):
         from multiprocessing.connection import Client
         self.conn = Client(address, family="AF_UNIX")
         self._lock = threading.Lock()
+        self._seq = 0
+        self._on_engine_lost = on_engine_lost
 
     def predict(self, feats):
         with self._lock:                                         # (PredictServer runs one forward at a time anyway)
-            self.conn.send(feats)
-            kind, payload = self.conn.recv()
+            self._seq += 1
+            rid = (os.getpid(), self._seq)
+            try:
+                self.conn.send((rid, feats))
+                got, kind, payload = self.conn.recv()
+            except (EOFError, OSError) as e:
+                if self._on_engine_lost:
+                    self._on_engine_lost()
+                raise RuntimeError("the engine process is gone (%s: %s)" % (type(e).__name__, e))
+        if got != rid:
+            raise RuntimeError("engine reply out of step: sent request %r, got the answer to %r" % (rid, got))
         if kind == "ok":
             return payload
         if kind == "value_error":
@@ -501,9 +515,17 @@ class _EngineProxy:
         raise RuntimeError(payload)
 
 
+def _merge_key(feats):
+    """Requests merge into one forward only when np.concatenate cannot change what any of them means: same keys, same dtype kind and item
+    size, same trailing shape per key ([r6, ADVICE r05]: an int and a float column of the same name used to be upcast together)."""
+    return tuple((k, np.asarray(v).dtype.kind, np.asarray(v).dtype.itemsize, np.asarray(v).shape[1:]) for k, v in sorted(feats.items()))
+
+
 def _engine_main(factory, fargs, address, ready, stop):
     """The engine process: builds the model, then serves the fronts' connections -- every pass takes ALL requests that are waiting,
-    merges the ones with equal feature sets into one forward, answers each front."""
+    merges the ones with equal feature sets into one forward, answers each front ONCE.  [r6, ADVICE r05] computing and sending are
+    separate failures: a front that died with a request in flight loses its connection and nothing else happens -- round 5's blanket
+    handler re-answered every member of the merged group, so live fronts got a second reply and were one reply out of step from then on."""
     from multiprocessing.connection import Listener, wait
     try:
         model = factory(*fargs)
@@ -523,14 +545,30 @@ def _engine_main(factory, fargs, address, ready, stop):
                 return
     threading.Thread(target=acceptor, daemon=True).start()
 
-    def answer(conn, feats):
+    def drop(conn):
+        if conn in conns:
+            conns.remove(conn)
         try:
-            conn.send(("ok", np.asarray(model.predict(feats), dtype=np.float32).reshape(-1)))
+            conn.close()
+        except Exception:
+            pass
+
+    def send(conn, rid, kind, payload):
+        try:
+            conn.send((rid, kind, payload))
+        except (OSError, EOFError, ValueError, BrokenPipeError):  # the front is gone: its request dies with it
+            drop(conn)
+
+    def compute(feats):
+        """-> (kind, payload): never raises"""
+        try:
+            return "ok", np.asarray(model.predict(feats), dtype=np.float32).reshape(-1)
         except ValueError as e:
-            conn.send(("value_error", str(e)))
+            return "value_error", str(e)
         except Exception as e:
-            conn.send(("error", "%s: %s" % (type(e).__name__, e)))
-    while not stop.is_set():
+            return "error", "%s: %s" % (type(e).__name__, e)
+    parent = os.getppid()
+    while not stop.is_set() and os.getppid() == parent:          # (the parent killed without close(): do not outlive it)
         while not accept_q.empty():
             conns.append(accept_q.get())
         if not conns:
@@ -539,37 +577,66 @@ def _engine_main(factory, fargs, address, ready, stop):
         got = []
         for c in wait(conns, timeout=0.05):
             try:
-                got.append((c, c.recv()))
+                rid, feats = c.recv()
+                got.append((c, rid, feats))
             except (EOFError, OSError):
-                conns.remove(c)
+                drop(c)
+            except Exception:                                    # not a (rid, feats) pair: a front of another version; nothing to answer to
+                drop(c)
         if not got:
             continue
         groups = {}
-        for c, feats in got:
-            groups.setdefault(tuple(sorted(feats)), []).append((c, feats))
+        for c, rid, feats in got:
+            try:
+                key = _merge_key(feats)
+            except Exception:
+                key = ("unmergeable", id(feats))
+            groups.setdefault(key, []).append((c, rid, feats))
         for members in groups.values():
             if len(members) == 1:
-                answer(*members[0])
+                c, rid, feats = members[0]
+                send(c, rid, *compute(feats))
                 continue
-            sizes = [len(next(iter(f.values()))) for _, f in members]
-            try:
-                merged = {k: np.concatenate([f[k] for _, f in members]) for k in members[0][1]}
-                out = np.asarray(model.predict(merged), dtype=np.float32).reshape(-1)
+            sizes = [len(next(iter(f.values()))) for _, _, f in members]
+            kind, out = compute({k: np.concatenate([np.asarray(f[k]) for _, _, f in members]) for k in members[0][2]})
+            if kind == "ok" and out.shape[0] == sum(sizes):
                 pos = 0
-                for (c, _), n in zip(members, sizes):
-                    c.send(("ok", out[pos:pos + n]))
+                for (c, rid, _), n in zip(members, sizes):
+                    send(c, rid, "ok", out[pos:pos + n])
                     pos += n
-            except Exception:                                    # one bad request must not fail its neighbours: each on its own
-                for c, f in members:
-                    answer(c, f)
+            elif kind == "value_error":                          # one member's id is out of range: each on its own, the others get their scores
+                for c, rid, f in members:
+                    send(c, rid, *compute(f))
+            else:                                                # the forward itself failed: the same answer for all, no second forward each
+                for c, rid, _ in members:
+                    send(c, rid, "error", out if kind == "error" else "merged forward returned %d scores for %d rows" % (out.shape[0], sum(sizes)))
     listener.close()
 
 
-def _front_main(address, name, host, port, defaults, ready, stop):
+def _pid_runs(pid) -> bool:
+    """The process exists and is not a zombie waiting for its parent."""
     try:
-        srv = PredictServer(_EngineProxy(address), name=name, host=host, port=port, defaults=defaults, reuse_port=True).start()
+        os.kill(pid, 0)
+    except ProcessLookupError:
+        return False
+    except PermissionError:
+        return True
+    try:
+        with open("/proc/%d/stat" % pid) as f:
+            return f.read().rsplit(")", 1)[1].split()[0] != "Z"
+    except OSError:
+        return True
+
+
+def _front_main(address, name, host, port, defaults, ready, stop, engine_pid=0):
+    try:
+        lost = threading.Event()
+        srv = PredictServer(_EngineProxy(address, on_engine_lost=lost.set), name=name, host=host, port=port, defaults=defaults, reuse_port=True).start()
         ready.put((os.getpid(), srv.port, None))
-        stop.wait()
+        parent = os.getppid()
+        while not stop.wait(0.5):
+            if lost.is_set() or os.getppid() != parent or (engine_pid and not _pid_runs(engine_pid)):
+                break                                            # the engine died, or the parent did (a plain `kill`): do not stay on the port
         srv.close()
     except Exception as e:                                       # the parent raises it
         ready.put((os.getpid(), 0, "%s: %s" % (type(e).__name__, e)))
@@ -580,6 +647,10 @@ class WorkerPool:
 
     def __init__(self, procs, stop, port, pids, engine_pid, tmpdir):
         self.procs, self._stop, self.port, self.pids, self.engine_pid, self._tmpdir = procs, stop, port, pids, engine_pid, tmpdir
+
+    def alive(self) -> bool:
+        """Every process of the pool (the engine first) still runs."""
+        return all(p.is_alive() for p in self.procs)
 
     def close(self):
         self._stop.set()
@@ -616,7 +687,7 @@ def serve_workers(factory, fargs=(), n_workers: int = 4, name: str = "recmodel",
         procs.append(eng)
         engine_pid, _ = take()                                   # (the model is built, the engine listens)
         for i in range(n_workers):
-            p = ctx.Process(target=_front_main, args=(address, name, host, port, dict(defaults or {}), ready, stop), daemon=True)
+            p = ctx.Process(target=_front_main, args=(address, name, host, port, dict(defaults or {}), ready, stop, engine_pid), daemon=True)
             p.start()
             procs.append(p)
             if i == 0 or port == 0:                              # the port must be known before the next front binds it
@@ -652,14 +723,20 @@ def _main():
     ap.add_argument("--name", default="recmodel")
     ap.add_argument("--host", default="127.0.0.1")
     ap.add_argument("--port", type=int, default=8501)
-    ap.add_argument("--workers", type=int, default=1, help="worker processes sharing the port (SO_REUSEPORT), one engine each")
+    ap.add_argument("--workers", type=int, default=1, help="front processes sharing the port (SO_REUSEPORT) in front of ONE engine process that owns the model and the GPU")
     args = ap.parse_args()
     if args.workers > 1:
         import signal
         pool = serve_workers(_cli_model, (args.model, args.weights), n_workers=args.workers, name=args.name, host=args.host, port=args.port)
         print("serving %s on http://%s:%d/v1/models/%s:predict from %d workers (pids %s)" % (args.model, args.host, pool.port, args.name, args.workers, pool.pids), flush=True)
+        # [r6, ADVICE r05] a plain `kill` (SIGTERM) must take the fronts and the engine along, and a dead engine must end the service
+        def _term(signum, frame):
+            raise KeyboardInterrupt
+        signal.signal(signal.SIGTERM, _term)
         try:
-            signal.pause()
+            while pool.alive():
+                time.sleep(1.0)
+            print("a serving process exited: shutting down", flush=True)
         except KeyboardInterrupt:
             pass
         finally:

@@ -402,3 +402,87 @@ def test_worker_processes_share_one_port():
                 np.testing.assert_allclose([x[0] for x in resp["predictions"]], want, atol=1e-6)
     finally:
         pool.close()
+
+
+def _slow_stub_factory():
+    m = _StubModel()
+    m.delay = 0.3
+    return m
+
+
+def test_engine_survives_a_front_that_dies_with_a_request_in_flight(tmp_path):
+    """[r6, ADVICE r05] The engine process against raw connections (no HTTP): three fronts send requests that merge into one forward; one of them
+    closes its connection before the answer.  Round 5's blanket handler then answered every member a SECOND time -- live fronts were one reply out
+    of step for ever (same candidate counts: nothing to notice it by) -- and the dead connection's second failure killed the engine loop.  Now: each
+    live front gets exactly ONE reply carrying ITS request id, and the engine keeps serving."""
+    import multiprocessing as mp
+    import time
+    from multiprocessing.connection import Client
+    from sparrowrecsys_amd.serving import _engine_main
+    ctx = mp.get_context("fork")
+    ready, stop = ctx.Queue(), ctx.Event()
+    address = str(tmp_path / "engine.sock")
+    eng = ctx.Process(target=_engine_main, args=(_slow_stub_factory, (), address, ready, stop), daemon=True)
+    eng.start()
+    try:
+        assert ready.get(timeout=60)[2] is None
+        a, b, dead = (Client(address, family="AF_UNIX") for _ in range(3))
+        feats = lambda u: {"userId": np.arange(u, u + 4, dtype=np.int64), "movieId": np.arange(4, dtype=np.int64)}
+        want = lambda u: ((np.arange(u, u + 4) % 7) * 0.1 + (np.arange(4) % 5) * 0.01).astype(np.float32)
+        a.send(((1, 1), feats(10)))                               # warm: the first pass may take it alone
+        assert a.recv()[0] == (1, 1)
+        a.send(((1, 2), feats(20))); b.send(((2, 1), feats(30))); dead.send(((3, 1), feats(40)))
+        dead.close()                                              # gone while the (slow) forward runs
+        for conn, rid, u in ((a, (1, 2), 20), (b, (2, 1), 30)):
+            got, kind, payload = conn.recv()
+            assert got == rid and kind == "ok"
+            np.testing.assert_allclose(payload, want(u), atol=1e-6)
+        time.sleep(0.5)
+        assert not a.poll(0) and not b.poll(0)                    # no second reply waiting
+        a.send(((1, 3), feats(50)))
+        got, kind, payload = a.recv()
+        assert got == (1, 3) and kind == "ok"
+        np.testing.assert_allclose(payload, want(50), atol=1e-6)
+        assert eng.is_alive()
+        # same keys, different dtype kinds: not merged into one upcast batch (each answered on its own, both right)
+        fa = {"userId": np.array([8, 9], dtype=np.int64), "movieId": np.array([3, 4], dtype=np.int64)}
+        fb = {"userId": np.array([8.0, 9.0], dtype=np.float64), "movieId": np.array([3, 4], dtype=np.int64)}
+        from sparrowrecsys_amd.serving import _merge_key
+        assert _merge_key(fa) != _merge_key(fb) and _merge_key(fa) == _merge_key(feats(1))
+        a.send(((1, 4), fa)); b.send(((2, 2), fb))
+        assert a.recv()[:2] == ((1, 4), "ok") and b.recv()[:2] == ((2, 2), "ok")
+    finally:
+        stop.set()
+        eng.join(timeout=10)
+        if eng.is_alive():
+            eng.terminate()
+
+
+def test_fronts_leave_the_port_when_the_engine_dies():
+    """[r6, ADVICE r05] WorkerPool.alive() turns False and the fronts exit (a request after the engine's death is a 5xx, then the port closes)
+    instead of answering 500 for ever."""
+    import os
+    import signal
+    import time
+    from sparrowrecsys_amd.serving import serve_workers
+    pool = serve_workers(_stub_factory, (), n_workers=2, port=0, start_method="fork")
+    try:
+        assert pool.alive()
+        code, resp = _post(pool.port, {"instances": [{"userId": 8, "movieId": 3}]})
+        assert code == 200
+        os.kill(pool.engine_pid, signal.SIGKILL)
+        deadline = time.time() + 20
+        while pool.alive() and time.time() < deadline:
+            time.sleep(0.2)
+        assert not pool.alive()
+        for _ in range(4):                                        # every front notices at its next request at the latest
+            try:
+                _post(pool.port, {"instances": [{"userId": 8, "movieId": 3}]})
+            except Exception:
+                pass
+        deadline = time.time() + 20
+        while any(p.is_alive() for p in pool.procs[1:]) and time.time() < deadline:
+            time.sleep(0.2)
+        assert not any(p.is_alive() for p in pool.procs[1:])
+    finally:
+        pool.close()
