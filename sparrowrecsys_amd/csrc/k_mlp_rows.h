@@ -423,3 +423,15 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_mlp_rows(const MlpRowsRun A, 
     }
     if (badm != 0 && lane == 0) atomicOr(err, 1);
 }
+
+// [r6] Measured and NOT kept (profiles/r06/experiments/r06_13, r06_14, the last form's source next to its numbers): the same
+// graph with more waves per SIMD.  (a) twelve waves (3 per SIMD, 153-158 VGPRs, no spill), one task in flight per wave -- a wave requests its rows,
+// reads the genre rows while they fly, goes on when they land; no second row-register set, h1 split into its operand pairs right behind the ReLU,
+// the second layer in two groups of four output blocks, numerics read from global memory so that a wave's staging slot is the ids alone (with
+// sixteen slots the image + genre tables + slots only just fit the CU): config 5 43.7 us against this kernel's 39.3-39.8, EmbeddingMLP.py 24.8
+// against 24.2.  (b) sixteen waves at the 128-register cap: hipcc spills the row registers (load, vmcnt(0), scratch_store, eight times per
+// column): 59 / 31 us.  (c) twelve waves WITH the next task's rows held through the second layer (161 live registers by count, 168 allowed):
+// 18-61 dwords spill, and a spill reload shares the in-order vmcnt with the prefetched rows, so every reload waits for the gather: 79.7 / 39.8
+// us.  What the eight-wave form buys with its 249 registers -- the next task's ids, rows, cross row and genre offsets in flight under a whole
+// second layer -- is worth more than a third wave per SIMD; the structural change that remains is 32 samples per fragment read on 32x32x16
+// MFMAs (a different C/D layout from the gather on: a new kernel, not a variant of this one).
