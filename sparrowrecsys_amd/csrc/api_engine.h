@@ -380,7 +380,7 @@ int sprk_finalize(sprk_handle h) {
                 const int KP = vv.kpc * 16;
                 size_t rows_total = 0;
                 for (int g = 0; g < vv.g_emb; ++g) { h->v2run.rowbase[g] = (unsigned)rows_total; rows_total += (size_t)h->v2run.vocab[g] + 1; }
-                HIP_TRY(hipMalloc((void**)&h->v2_folded, rows_total * (KP + 16) * sizeof(float)));
+                { const int rc_ = table_alloc(h, (void**)&h->v2_folded, rows_total * (KP + 16) * sizeof(float)); if (rc_) return rc_; }
                 h->derived_bytes += rows_total * (KP + 16) * sizeof(float);
                 for (int g = 0; g < vv.g_emb; ++g) {
                     const long long rows = (long long)h->v2run.vocab[g] + 1;

@@ -616,7 +616,7 @@ void sprk_destroy(sprk_handle h) {
     if (h->dev_plan) (void)hipFree(h->dev_plan);
     if (h->v2_image) (void)hipFree(h->v2_image);
     if (h->v2_fo_all) (void)hipFree(h->v2_fo_all);
-    if (h->v2_folded) (void)hipFree(h->v2_folded);
+    table_free(h, h->v2_folded);
     if (h->v2j_tab) (void)hipFree(h->v2j_tab);
     for (void* p : h->fold_bufs) if (p) (void)hipFree(p);
     for (int i = 0; i < 4; ++i) { if (h->many_stream[i]) (void)hipStreamDestroy(h->many_stream[i]); if (h->many_join[i]) (void)hipEventDestroy(h->many_join[i]); }
@@ -625,13 +625,13 @@ void sprk_destroy(sprk_handle h) {
     if (h->din_fused_image) (void)hipFree(h->din_fused_image);
     if (h->mlp_rows_image) (void)hipFree(h->mlp_rows_image);
     if (h->mlp_rows_small) (void)hipFree(h->mlp_rows_small);
-    for (void* q : h->mlp_rows_bufs) if (q) (void)hipFree(q);
-    for (void* p : h->v1_bufs) if (p) (void)hipFree(p);
-    if (h->v2j_big) (void)hipFree(h->v2j_big);
+    for (void* q : h->mlp_rows_bufs) table_free(h, q);
+    for (void* p : h->v1_bufs) table_free(h, p);
+    table_free(h, h->v2j_big);
     if (h->v2j1_image) (void)hipFree(h->v2j1_image);
     if (h->din_frag) (void)hipFree(h->din_frag);
     if (h->dien_frag) (void)hipFree(h->dien_frag);
-    if (h->rows_tab) (void)hipFree(h->rows_tab);
+    table_free(h, h->rows_tab);
     if (h->rows_scal) (void)hipFree(h->rows_scal);
     if (h->rows_small) (void)hipFree(h->rows_small);
     if (h->rows_image) (void)hipFree(h->rows_image);

@@ -89,6 +89,7 @@ struct SprkTuning {
     bool v1_chain = true;             // SPRK_V1_CHAIN=0            pair-dot DeepFM on the interpreter
     bool v1_one = true;               // SPRK_V1_ONE=0              one-batch launches on the looped kernel, not k_deepfm_pairs1
     bool mlp_chain = true;            // SPRK_MLP_CHAIN=0           EmbeddingMLP / Wide&Deep on the interpreter
+    bool vmm_tables = true;           // SPRK_VMM_TABLES=0          derived gather tables of 256 MB and more through hipMalloc, not one hipMemCreate allocation (host_engine.h table_alloc)
     bool din_tail = true;             // SPRK_DIN_TAIL=0            DIN tail on the interpreter
     bool din_legacy = false;          // SPRK_DIN_LEGACY=1          attention on the generic k_din_pool
     bool din_half = true;             // SPRK_DIN_HALF=0            attention on f32 MFMA
@@ -114,6 +115,7 @@ struct SprkTuning {
         t.v1_chain = !off("SPRK_V1_CHAIN");
         t.v1_one = !off("SPRK_V1_ONE");
         t.mlp_chain = !off("SPRK_MLP_CHAIN");
+        t.vmm_tables = !off("SPRK_VMM_TABLES");
         t.din_tail = !off("SPRK_DIN_TAIL"); t.din_legacy = on("SPRK_DIN_LEGACY"); t.din_half = !off("SPRK_DIN_HALF");
         t.din_cols = !off("SPRK_DIN_COLS"); t.din_fused = !off("SPRK_DIN_FUSED"); t.df_xp = num("SPRK_DF_XP", 0); t.din_fused_mb = !off("SPRK_DIN_FUSED_MB"); t.din_fused_unf = !off("SPRK_DIN_FUSED_UNF"); t.din_fused_min_t = num("SPRK_DIN_FUSED_MIN_T", 12); t.dien_fused = !off("SPRK_DIEN_FUSED");
         { const int n = num("SPRK_DIN_COLS_TS", 0); t.din_cols_ts = (n == 1 || n == 2 || n == 4) ? n : 0; }

@@ -117,7 +117,7 @@ int setup_mlp_rows(sprk_engine* h) {
         const sprk_seg& sg = *big_seg[b];
         float* F = nullptr;
         const size_t bytes = ((size_t)sg.vocab + 1) * N0 * sizeof(float);
-        HIP_TRY(hipMalloc((void**)&F, bytes));
+        { const int rc_ = table_alloc(h, (void**)&F, bytes); if (rc_) return rc_; }
         h->mlp_rows_bufs.push_back(F);
         h->derived_bytes += bytes;
         HIP_TRY(hipMemset(F + (size_t)sg.vocab * N0, 0, N0 * sizeof(float)));        // the "no id" row

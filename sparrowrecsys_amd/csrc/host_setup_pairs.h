@@ -270,7 +270,7 @@ int setup_deepfm_pairs(sprk_engine* h) {
         if (sep && !pack) for (int d = 0; d < r.n_deep; ++d) rows += (size_t)r.vocab[d] + 1;
         if (rows * 128 < ((size_t)1 << 32)) {                     // 32-bit byte offsets
             float* tab = nullptr;
-            HIP_TRY(hipMalloc((void**)&tab, rows * 128));
+            { const int rc_ = table_alloc(h, (void**)&tab, rows * 128); if (rc_) return rc_; }
             h->v1_bufs.push_back(tab);
             h->derived_bytes += rows * 128;
             float* w1c = nullptr;

@@ -149,7 +149,7 @@ int setup_rows_v2(sprk_engine* h) {
         small_floats += ((size_t)a.emb_vocab[sm[f]] + 1) * rv.ss;
     }
     small_floats = (small_floats + 255) & ~(size_t)255;
-    HIP_TRY(hipMalloc((void**)&h->rows_tab, big_rows * rv.rb + 64));
+    { const int rc_ = table_alloc(h, (void**)&h->rows_tab, big_rows * rv.rb + 64); if (rc_) return rc_; }
     HIP_TRY(hipMemset(h->rows_tab, 0, big_rows * rv.rb + 64));
     HIP_TRY(hipMalloc((void**)&h->rows_scal, big_rows * sizeof(float) + 16));
     h->derived_bytes += big_rows * rv.rb + big_rows * sizeof(float);
@@ -301,7 +301,7 @@ int setup_rows_ncf(sprk_engine* h) {
         rows_total += (size_t)sg.vocab + 1;
     }
     if (rows_total >= ((size_t)1 << 31)) return SPRK_OK;
-    HIP_TRY(hipMalloc((void**)&h->rows_tab, rows_total * rv.rb + 64));
+    { const int rc_ = table_alloc(h, (void**)&h->rows_tab, rows_total * rv.rb + 64); if (rc_) return rc_; }
     HIP_TRY(hipMemset(h->rows_tab, 0, rows_total * rv.rb + 64));
     h->derived_bytes += rows_total * rv.rb;
     const float* W0 = (const float*)h->slot_ptr[o0.w_slot];

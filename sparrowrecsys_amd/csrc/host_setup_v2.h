@@ -331,7 +331,7 @@ int setup_v2_joint(sprk_engine* h) {
         size_t big_rows = 0;
         for (int b = 0; b < nbig; ++b) big_rows += (size_t)r.big_vocab[b] + 1;
         if (big_rows * (KP + 16) * sizeof(float) >= ((size_t)1 << 32)) return fail(SPRK_EINVAL, "split rows exceed 32-bit offsets");
-        HIP_TRY(hipMalloc((void**)&h->v2j_big, big_rows * (KP + 16) * sizeof(float)));
+        { const int rc_ = table_alloc(h, (void**)&h->v2j_big, big_rows * (KP + 16) * sizeof(float)); if (rc_) return rc_; }
         h->derived_bytes += big_rows * (KP + 16) * sizeof(float);
         size_t base = 0;
         for (int b = 0; b < nbig; ++b) {
