@@ -107,7 +107,7 @@ def build_workload(name, B, dist_name, seed_offset=0, big_vocab=0, NB=8):
             desc = "DeepFM sum-of-squares FM (DeepFM_v2 graph), F=6 sparse fields, emb_dim=16, proj=16, deep 32-16"
             if big_vocab:
                 desc += ", identity tables of %d rows each" % big_vocab
-            kernel = "k_deepfm_v2_chain" if (env("SPRK_V2_JOINT") == "0" or env("SPRK_V2_FOLD") == "0") else "k_deepfm_v2_joint"
+            kernel = "k_rows_chain" if (env("SPRK_V2_JOINT") == "0" or env("SPRK_V2_FOLD") == "0") else "k_deepfm_v2_joint"
         else:
             model = M.DeepFM(seed=101, emb_dim=D, fields=fields, pairs=SY.CONFIG2_PAIRS)
             desc = ("DeepFM pairwise-dot FM (DeepFM graph), F=6 sparse fields, emb_dim=16, 8 pairs, deep 64-64; the deep part reads its OWN "

@@ -258,15 +258,6 @@ int sprk_check_ids(sprk_handle h, void* stream);
  * SPRK_EINVAL when the buffer is too small (256 bytes always suffice). */
 int sprk_describe(sprk_handle h, char* buf, size_t buf_bytes);
 
-/* Diagnostics (no reference counterpart): when `dev_buf` is non-NULL the fused DeepFM_v2 kernel
- * writes 16 uint64 per wave -- shader-clock (s_memtime) stamps [0] entry, [1] ids/numerics block
- * landed, [2] rows issued, [3] weight image copied, [4] workgroup barrier passed, [5] first rows
- * landed, [6] first 16 samples scored, [7] exit; 100 MHz wall clock [8] at entry, [9] at exit.
- * Needs 16*8 bytes per launched wave (grid cap x 8 waves); NULL switches tracing off (tracing
- * drains outstanding loads at some stamps, so a traced launch is slower).  SPRK_EKIND for handles
- * that run the generic tile kernel. */
-int sprk_debug_set_trace(sprk_handle h, void* dev_buf, size_t bytes);
-
 void sprk_destroy(sprk_handle h);
 
 /* ---- stand-alone operators (same kernels' building blocks, for parity tests / reuse) ---- */

@@ -32,7 +32,7 @@ EXPORTED_SYMBOLS = [
     "sprk_runtime_info", "sprk_create", "sprk_upload", "sprk_finalize", "sprk_workspace_bytes",
     "sprk_forward", "sprk_forward_many", "sprk_forward_many_opts", "sprk_forward_embedding_mlp", "sprk_forward_widedeep", "sprk_forward_neuralcf",
     "sprk_forward_deepfm", "sprk_forward_deepfm_v2", "sprk_forward_din", "sprk_forward_dien", "sprk_din_pool",
-    "sprk_check_ids", "sprk_debug_set_trace", "sprk_destroy", "sprk_embedding_gather", "sprk_cross_hash", "sprk_last_error",
+    "sprk_check_ids", "sprk_destroy", "sprk_embedding_gather", "sprk_cross_hash", "sprk_last_error",
     "sprk_pack_csv", "sprk_pack_csv_mt", "sprk_pack_csv_device", "sprk_csv_last_path", "sprk_set_many_streams", "sprk_set_many_batches", "sprk_emb_rank",
     "sprk_describe", "sprk_comm_unique_id", "sprk_comm_create", "sprk_comm_allgather_scores", "sprk_comm_destroy",
     "sprk_peer_create", "sprk_peer_connect", "sprk_peer_allgather_scores", "sprk_peer_check", "sprk_peer_memory_kind", "sprk_peer_destroy",
@@ -196,7 +196,6 @@ def load_library():
         lib.sprk_forward_many_opts.argtypes = [vp, i32, vp, vp, vp, i32, vp, sz, vp, i32, i32]
         lib.sprk_din_pool.argtypes = [vp, vp, vp, vp, i32, vp]
         lib.sprk_check_ids.argtypes = [vp, vp]
-        lib.sprk_debug_set_trace.argtypes = [vp, vp, sz]
         lib.sprk_destroy.argtypes = [vp]
         lib.sprk_destroy.restype = None
         lib.sprk_embedding_gather.argtypes = [vp, i32, i32, i32, vp, i32, vp, vp]

@@ -364,24 +364,17 @@ int sprk_finalize(sprk_handle h) {
     {
         if (!h->tune.force_interpreter && match_v2_chain(h)) {
             const V2Variant& vv = kV2Variants[h->v2_variant];
-            HIP_TRY(hipFuncSetAttribute(vv.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)vv.lds_bytes));
-            int per_cu = (int)(160 * 1024 / vv.lds_bytes);
-            if (vv.fn_trace) HIP_TRY(hipFuncSetAttribute(vv.fn_trace, hipFuncAttributeMaxDynamicSharedMemorySize, (int)vv.lds_bytes));
-            const int by_regs = (vv.reg ? 2 : 4) * 4 / V2_WAVES;     // workgroups/CU the launch bounds allow
-            if (per_cu > by_regs) per_cu = by_regs;
-            if (per_cu < 1) per_cu = 1;
-            h->v2_grid_cap = h->num_cus * per_cu;
-            // first-order weight blocks back to back, so one gather instruction can serve several fields
+            h->v2_grid_cap = h->num_cus;                             // one 8-wave workgroup per CU (weights in registers: two waves per SIMD)
+            // first-order weight blocks back to back
             HIP_TRY(hipMalloc((void**)&h->v2_fo_all, h->v2_fo_floats * sizeof(float)));
             for (int g = 0; g < vv.g_emb; ++g)
                 HIP_TRY(hipMemcpy(h->v2_fo_all + h->v2run.fo_off[g], h->v2.w1[g], ((size_t)h->v2run.vocab[g] + 1) * sizeof(float), hipMemcpyDeviceToDevice));
             h->v2run.fo_all = h->v2_fo_all;
-            if (vv.fold) {
+            {
                 const int KP = vv.kpc * 16;
                 size_t rows_total = 0;
                 for (int g = 0; g < vv.g_emb; ++g) { h->v2run.rowbase[g] = (unsigned)rows_total; rows_total += (size_t)h->v2run.vocab[g] + 1; }
                 { const int rc_ = table_alloc(h, (void**)&h->v2_folded, rows_total * (KP + 16) * sizeof(float)); if (rc_) return rc_; }
-                h->derived_bytes += rows_total * (KP + 16) * sizeof(float);
                 for (int g = 0; g < vv.g_emb; ++g) {
                     const long long rows = (long long)h->v2run.vocab[g] + 1;
                     long long blocks = (rows + 3) / 4;
@@ -394,12 +387,22 @@ int sprk_finalize(sprk_handle h) {
                 h->v2run.tab0 = h->v2_folded;
                 HIP_TRY(hipDeviceSynchronize());
                 if ((rc = setup_v2_joint(h))) return rc;
+                if (h->v2j_variant >= 0) h->derived_bytes += rows_total * (KP + 16) * sizeof(float);
             }
-            HIP_TRY(hipMalloc((void**)&h->v2_image, vv.lds_bytes));
-            HIP_TRY(hipMemset(h->v2_image, 0, vv.lds_bytes));
-            vv.pack(h->v2, h->v2_image);
-            HIP_TRY(hipGetLastError());
-            HIP_TRY(hipDeviceSynchronize());
+            if (h->v2j_variant >= 0) {
+                HIP_TRY(hipMalloc((void**)&h->v2_image, vv.lds_bytes));
+                HIP_TRY(hipMemset(h->v2_image, 0, vv.lds_bytes));
+                vv.pack(h->v2, h->v2_image);
+                HIP_TRY(hipGetLastError());
+                HIP_TRY(hipDeviceSynchronize());
+            } else {
+                // [r6] no joint form for this model (no small-vocabulary field, more than three large ones, SPRK_V2_JOINT=0): until round 6
+                // k_deepfm_v2_chain took it; now the parsed plan goes to k_rows_chain, then to the interpreter
+                (void)hipFree(h->v2_fo_all); h->v2_fo_all = nullptr;
+                table_free(h, h->v2_folded); h->v2_folded = nullptr;
+                h->v2_variant = -1;
+                h->rows_from_v2 = h->v2_rows_ok;
+            }
         }
     }
     {

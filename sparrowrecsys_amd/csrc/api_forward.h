@@ -188,12 +188,9 @@ int sprk_forward(sprk_handle h, const int32_t* ids, const float* dense, float* o
         const int ntasks = (B + 15) / 16;
         int grid = (ntasks + V2_WAVES - 1) / V2_WAVES;
         if (grid > h->v2_grid_cap) grid = h->v2_grid_cap;
-        V2Run run = h->v2run;
-        run.flags = (((uintptr_t)ids | (uintptr_t)dense) & 15) ? 1 : 0;    // unaligned inputs: element-wise staging
-        const V2Variant& vv = kV2Variants[h->v2_variant];
-        if (h->v2j_variant >= 0 && !run.trace && !(run.flags & ~1)) {
+        {                                                          // ([r6] a DeepFM_v2 handle always has a joint form: finalize routes the others elsewhere)
             V2JRun jr = h->v2j_run;
-            jr.flags = run.flags;
+            jr.flags = (((uintptr_t)ids | (uintptr_t)dense) & 15) ? 1 : 0;  // unaligned inputs: element-wise staging
             if (h->v2j1_image && ntasks <= V2J1_MAX_TASKS) {
                 // one strict launch of one batch: one task per wave, four waves per SIMD (k_chain_v2j1.h)
                 for (size_t v = 0; v < sizeof(kV2J1Variants) / sizeof(kV2J1Variants[0]); ++v)
@@ -208,9 +205,6 @@ int sprk_forward(sprk_handle h, const int32_t* ids, const float* dense, float* o
             HIP_TRY(hipGetLastError());
             return SPRK_OK;
         }
-        (run.trace ? vv.launch_trace : vv.launch)(run, ids, dense, out, B, h->dev_err, h->v2_image, grid, h->v2_lds_bytes, st);
-        HIP_TRY(hipGetLastError());
-        return SPRK_OK;
     }
     if (h->rows_variant >= 0) {
         const int ntasks = (B + 15) / 16;
@@ -282,7 +276,7 @@ static int forward_many_impl(sprk_handle h, int32_t n_batches, const int32_t* co
     }
     // several batches per launch (sprk_set_many_batches): the fused DeepFM_v2 kernel takes up to V2J_MB batches' buffers
     // and walks their tasks as one grid; everything else (other models, unaligned buffers, tracing) goes batch by batch
-    if (h->finalized && many_batches > 1 && n_batches > 1 && h->v2_variant >= 0 && h->v2j_variant >= 0 && !h->v2run.trace &&
+    if (h->finalized && many_batches > 1 && n_batches > 1 && h->v2_variant >= 0 && h->v2j_variant >= 0 &&
         B > 0 && ids && dense) {
         bool ok = true;
         for (int32_t i = 0; i < n_batches && ok; ++i)
@@ -532,9 +526,6 @@ int sprk_describe(sprk_handle h, char* buf, size_t buf_bytes) {
     if (h->v2_variant >= 0 && h->v2j_variant >= 0) {
         const V2JVariant& jv = kV2JVariants[h->v2j_variant];
         snprintf(kern, sizeof(kern), "k_deepfm_v2_joint<G_BIG=%d,NJF=%d,KPC=%d,%s>", jv.g_big, jv.njf, jv.kpc, jv.half ? "split-f16" : "f32");
-    } else if (h->v2_variant >= 0) {
-        const V2Variant& vv = kV2Variants[h->v2_variant];
-        snprintf(kern, sizeof(kern), "k_deepfm_v2_chain<G=%d,KPC=%d,%s>", vv.g_emb, vv.kpc, vv.fold ? "folded" : "unfolded");
     } else if (h->v1_variant >= 0) {
         snprintf(kern, sizeof(kern), "k_deepfm_pairs<NF=%d,NV=%d>", kV1Variants[h->v1_variant].nf, kV1Variants[h->v1_variant].nv);
     } else if (h->rows_variant >= 0) {
@@ -576,16 +567,6 @@ int sprk_check_ids(sprk_handle h, void* stream) {
         HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
         return fail(SPRK_ERANGE, "an id was outside its table (TF would raise InvalidArgumentError: assert_less_than_num_buckets) [flag 0x%x]", flag);
     }
-    return SPRK_OK;
-}
-
-int sprk_debug_set_trace(sprk_handle h, void* dev_buf, size_t bytes) {
-    if (!h) return fail(SPRK_EINVAL, "handle is NULL");
-    if (!h->finalized) return fail(SPRK_ESTATE, "set_trace before finalize");
-    if (h->v2_variant < 0 || !kV2Variants[h->v2_variant].launch_trace) return fail(SPRK_EKIND, "handle does not run a traceable kernel");
-    if (dev_buf && bytes < (size_t)h->v2_grid_cap * V2_WAVES * 16 * sizeof(unsigned long long))
-        return fail(SPRK_EINVAL, "trace buffer too small: %zu bytes for %d waves", bytes, h->v2_grid_cap * V2_WAVES);
-    h->v2run.trace = (unsigned long long*)dev_buf;
     return SPRK_OK;
 }
 

@@ -74,6 +74,7 @@ struct sprk_engine {
     bool din_attn_many = true;     // forward_many: one attention launch per group of batches 
     // register-chained fast path (k_deepfm_v2_chain); -1 = use the tile interpreter
     int v2_variant = -1;
+    bool v2_rows_ok = false;       // [r6] the parsed DeepFM_v2 plan also fits k_rows_chain (where it goes when the joint set-up refuses it)
     V2Args v2;
     V2Run v2run;
     size_t v2_lds_bytes = 0;

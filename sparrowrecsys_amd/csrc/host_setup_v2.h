@@ -1,49 +1,24 @@
 // host_setup_v2.h -- DeepFM_v2: k_deepfm_v2_chain / _joint / _joint1 dispatch tables, plan matcher, fold + joint-table set-up.
 // Part of sparrow_hip.hip (one translation unit); included there, not compilable on its own.
-// ---- fast-path dispatch table for k_deepfm_v2_chain<G_EMB, DV, KPC, H0C, H1C, WAVES, FOLD, TRACE, REG> ----
+// ---- the DeepFM_v2 plan shapes the joint kernels are built on: folded tables (KP-wide projected rows), the LDS image of k_v2_pack_image ----
+// ([r6] until round 6 this was the dispatch table of k_deepfm_v2_chain, whose kernels are retired: k_chain_v2.h)
 constexpr int V2_WAVES = 8;
-typedef void (*V2LaunchFn)(const V2Run&, const int*, const float*, float*, int, int*, const float*, int, size_t, hipStream_t);
 struct V2Variant {
-    int g_emb, dv, kpc, h0c, h1c;     // dv is ignored for FOLD variants (they gather KP-wide projected rows)
-    bool fold;
-    bool reg;                         // register-resident weights, 2 waves per SIMD (one 8-wave workgroup per CU)
-    const void* fn;
-    const void* fn_trace;             // TRACE instantiation (diagnostics), or NULL
-    size_t lds_bytes;
-    V2LaunchFn launch, launch_trace;
+    int g_emb, kpc, h0c, h1c;
+    size_t lds_bytes;                 // the packed image + a staging slot per wave
     void (*pack)(const V2Args&, float*);
 };
-template <int G_EMB, int DV, int KPC, int H0C, int H1C, bool FOLD, bool TRACE, bool REG>
-void v2_launch(const V2Run& a, const int* ids, const float* dense, float* out, int B, int* err, const float* image,
-               int grid, size_t lds, hipStream_t st) {
-    hipLaunchKernelGGL((k_deepfm_v2_chain<G_EMB, DV, KPC, H0C, H1C, V2_WAVES, FOLD, TRACE, REG>), dim3(grid), dim3(V2_WAVES * 64), lds, st,
-                       a, ids, dense, out, B, err, image);
-}
 template <int G_EMB, int DV, int KPC, int H0C, int H1C, bool FOLD>
 void v2_pack(const V2Args& a, float* image) {
     hipLaunchKernelGGL((k_v2_pack_image<G_EMB, DV, KPC, H0C, H1C, FOLD>), dim3(1), dim3(256), 0, 0, a, image);
 }
 #define V2_LDS(G_EMB, DV, KPC, H0C, H1C, FOLD) \
     (sizeof(float) * (V2Lds<G_EMB, DV, KPC, H0C, H1C, FOLD>::total_pad + V2_WAVES * V2Lds<G_EMB, DV, KPC, H0C, H1C, FOLD>::stage_floats))
-#define V2_KFN(G_EMB, DV, KPC, H0C, H1C, FOLD, TRACE, REG) \
-    reinterpret_cast<const void*>(&k_deepfm_v2_chain<G_EMB, DV, KPC, H0C, H1C, V2_WAVES, FOLD, TRACE, REG>)
-#define V2_VARIANT(G_EMB, DV, KPC, H0C, H1C, FOLD, REG)                                                                \
-    {G_EMB, DV, KPC, H0C, H1C, FOLD, REG, V2_KFN(G_EMB, DV, KPC, H0C, H1C, FOLD, false, REG), nullptr,                 \
-     V2_LDS(G_EMB, DV, KPC, H0C, H1C, FOLD), &v2_launch<G_EMB, DV, KPC, H0C, H1C, FOLD, false, REG>, nullptr,          \
-     &v2_pack<G_EMB, DV, KPC, H0C, H1C, FOLD>}
-#define V2_VARIANT_TRACED(G_EMB, DV, KPC, H0C, H1C, FOLD, REG)                                                         \
-    {G_EMB, DV, KPC, H0C, H1C, FOLD, REG, V2_KFN(G_EMB, DV, KPC, H0C, H1C, FOLD, false, REG),                          \
-     V2_KFN(G_EMB, DV, KPC, H0C, H1C, FOLD, true, REG), V2_LDS(G_EMB, DV, KPC, H0C, H1C, FOLD),                        \
-     &v2_launch<G_EMB, DV, KPC, H0C, H1C, FOLD, false, REG>, &v2_launch<G_EMB, DV, KPC, H0C, H1C, FOLD, true, REG>,    \
-     &v2_pack<G_EMB, DV, KPC, H0C, H1C, FOLD>}
+#define V2_VARIANT(G_EMB) {G_EMB, 1, 2, 1, V2_LDS(G_EMB, 4, 1, 2, 1, true), &v2_pack<G_EMB, 4, 1, 2, 1, true>}
 const V2Variant kV2Variants[] = {
-    V2_VARIANT_TRACED(6, 4, 1, 2, 1, true, true),    // BASELINE config 2: 6 fields, projection 16 (folded into the tables), deep 32-16
-    V2_VARIANT(6, 4, 1, 2, 1, false, false),         // ... with the projections computed per sample (D=16), weights in LDS
-    V2_VARIANT(4, 4, 1, 2, 1, true, true),           // 4 fields, projection 16 (config-4 shape gathers 128-B projected rows instead of 256-B)
-    V2_VARIANT(4, 4, 1, 2, 1, false, false),         // 4 fields, D=16
-    V2_VARIANT(5, 4, 1, 2, 1, true, true),           // other field counts (folded only)
-    V2_VARIANT(3, 4, 1, 2, 1, true, true),
-    V2_VARIANT(2, 4, 1, 2, 1, true, true),
+    V2_VARIANT(6),    // BASELINE config 2: 6 fields, projection 16 (folded into the tables), deep 32-16
+    V2_VARIANT(4),    // 4 fields (config 4 gathers 128-B projected rows instead of 256-B raw ones)
+    V2_VARIANT(5), V2_VARIANT(3), V2_VARIANT(2),
 };
 
 // ---- dispatch table for k_deepfm_v2_joint<G_BIG, NJF, KPC, H0C, H1C, WAVES> ----
@@ -168,14 +143,13 @@ bool match_v2_chain(sprk_engine* h) {
     a.hdeep = (const float*)h->slot_ptr[t3.w_slot]; a.n_hdeep = t3.len;
     a.h0w = t0.scale; a.fo_bias = t0.bias + t1.bias; a.head_bias = p.head_bias;
     a.F = p.n_id_cols; a.ND = p.n_dense; a.n_num = n_num; a.n_fo = n_fo;
-    const int dv = Dp / 4, kpc = Kp / 16, h0c = d0.N / 16, h1c = d1.N / 16;
+    const int kpc = Kp / 16, h0c = d0.N / 16, h1c = d1.N / 16;
     // fold the per-field projections into the tables when that never widens a gathered row
     size_t total_rows = 0;
     for (int g = 0; g < g_emb; ++g) total_rows += (size_t)a.emb_vocab[g] + 1;
     // (32-bit byte offsets into ONE buffer of folded rows: needs < 4 GiB)
     const bool want_fold = Kp <= Dp && Kp + 16 <= 64 && total_rows * (size_t)(Kp + 16) * 4 < ((size_t)1 << 32) &&
                            h->tune.v2_fold;
-    const bool want_reg = want_fold;                         // folded tables <=> register-resident scoring stage
     if (raw_over_4g && !want_fold) return false;             // e.g. BASELINE config 4's 27 M x 64 table (6.9 GB): folded rows only
     // the fused kernel reads ONE id per field for both the embedding row and the first-order
     // weight: the two field lists must be the same set of ids columns
@@ -190,8 +164,8 @@ bool match_v2_chain(sprk_engine* h) {
     }
     for (size_t v = 0; v < sizeof(kV2Variants) / sizeof(kV2Variants[0]); ++v) {
         const V2Variant& vv = kV2Variants[v];
-        if (vv.fold != want_fold || vv.reg != want_reg) continue;
-        if (vv.g_emb == g_emb && (vv.fold || vv.dv == dv) && vv.kpc == kpc && vv.h0c == h0c && vv.h1c == h1c) {
+        if (!want_fold) continue;                            // (the joint kernels gather folded rows only)
+        if (vv.g_emb == g_emb && vv.kpc == kpc && vv.h0c == h0c && vv.h1c == h1c) {
             V2Run run;
             memset(&run, 0, sizeof(run));
             size_t fo_floats = 0;
@@ -220,10 +194,12 @@ bool match_v2_chain(sprk_engine* h) {
             h->v2_fo_floats = fo_floats;
             h->v2_variant = (int)v;
             h->v2_lds_bytes = vv.lds_bytes;
+            h->rows_g_emb = g_emb;                             // (should the joint set-up refuse the model: finalize hands the parsed plan to k_rows_chain)
+            h->v2_rows_ok = kpc >= 1 && kpc <= 4 && h0c >= 1 && h1c >= 1 && !raw_over_4g;
             return true;
         }
     }
-    // no k_deepfm_v2_chain instantiation (e.g. the reference's Dense(64) projections): the parsed plan goes to k_rows_chain
+    // no folded form (e.g. the reference's Dense(64) projections): the parsed plan goes to k_rows_chain
     if (kpc >= 1 && kpc <= 4 && h0c >= 1 && h1c >= 1 && !raw_over_4g) {
         h->v2 = a;
         h->rows_g_emb = g_emb;
@@ -238,7 +214,7 @@ bool match_v2_chain(sprk_engine* h) {
 int wide_dynamic_range(const float* rows, long long nrows, int row_floats, int ncols, float mx, bool* wide);
 int setup_v2_joint(sprk_engine* h) {
     const V2Variant& vv = kV2Variants[h->v2_variant];
-    if (!vv.fold || !vv.reg || vv.kpc != 1 || vv.h0c != 2 || vv.h1c != 1 || !h->tune.v2_joint) return SPRK_OK;
+    if (vv.kpc != 1 || vv.h0c != 2 || vv.h1c != 1 || !h->tune.v2_joint) return SPRK_OK;
     const int KP = 16, H0 = 32, G = vv.g_emb;
     int big[V2_MAX_FIELDS], nbig = 0, jf[V2_MAX_FIELDS], njf = 0;
     for (int g = 0; g < G; ++g) {
