@@ -675,7 +675,7 @@ def main():
                          "sprk_peer_allgather_scores (direct peer writes into IPC-mapped receive buffers, no RCCL)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend (gloo: functional test of the N>1 path with ranks sharing one GPU)")
-    ap.add_argument("--side-workloads", default="din_c3,deepfm_c2,deepfm_c4,widedeep_c5,neuralcf_serving",
+    ap.add_argument("--side-workloads", default="din_c3,deepfm_c2,deepfm_c4,widedeep_c5,neuralcf_serving,predict_csv",
                     help="default workload at N=1: also measure these (short loops) and put them under `workloads` in the same JSON "
                          "line -- BASELINE's metric names DeepFM and DIN; '' = none")
     ap.add_argument("--variants", type=int, default=1,
@@ -1188,6 +1188,8 @@ def main():
                 if "attention_only" in wb["roofline"]:
                     cfgd[wn + "_attention_only_us"] = wb["roofline"]["attention_only"]["avg_launch_us"]
                     cfgd[wn + "_attention_only_frac"] = wb["roofline"]["attention_only"]["frac"]
+            elif "rows_per_sec" in wb:
+                cfgd[wn + "_rows_per_s"] = wb["rows_per_sec"]
             elif "latency_ms" in wb:
                 cfgd[wn + "_p50_ms"] = wb["latency_ms"]["p50"]
                 cfgd[wn + "_requests_per_s_one_client"] = wb["requests_per_sec_one_client"]
@@ -1448,6 +1450,34 @@ def serving_workload(args):
             "server": "sparrowrecsys_amd.serving.PredictServer (ThreadingHTTPServer + micro-batcher that only waits while another request is arriving)"}
 
 
+def predict_csv_workload(args, rows=1048576):
+    """[r6, VERDICT r05 item 8] The reference's own workflow end to end -- model.predict(get_dataset(csv)) (DeepFM.py:14-22,131-133) -- through
+    CTRModel.predict_csv: raw CSV text (the reference's sample rows, tests/golden/test_samples_512.csv, repeated) -> one copy to the device ->
+    tokenised and packed there (sprk_pack_csv_device) -> forward over 65 536-row slices in groups of up to 64 per launch -> scores on the host.
+    Wall clock of the whole call, best of three, text already in host memory."""
+    import torch
+    from sparrowrecsys_amd import models as M
+    base = open(os.path.join(ROOT, "tests", "golden", "test_samples_512.csv"), "rb").read()
+    head, body = base.split(b"\n", 1)
+    reps = max(1, rows // 512)
+    text = head + b"\n" + body * reps
+    n = 512 * reps
+    model = M.DeepFMv2(seed=1)
+    small = model.predict_csv(base)                               # engine creation, scratch sizing
+    best, res = 1e9, None
+    for _ in range(3):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        res = model.predict_csv(text)
+        torch.cuda.synchronize()
+        best = min(best, time.perf_counter() - t0)
+    ok = bool(np.array_equal(res[:512], small) and np.array_equal(res[-512:], small))
+    kernel = model.engine.kernel_name()
+    model.engine.close()
+    return {"workload": "predict_csv: DeepFM_v2.py on %d rows of the reference's testSamples.csv format (%.0f MB of text), host bytes -> scores on the host" % (n, len(text) / 1e6),
+            "unit": "rows/s", "rows": n, "seconds": best, "rows_per_sec": n / best, "kernel": kernel, "repeats_equal_first_block": ok}
+
+
 def side_workload(args, name):
     """One more workload inside the default driver line: BASELINE.json's metric names DeepFM AND DIN,
     and SURVEY 8(d) config 2 names the pair-dot graph next to the sum-of-squares one.  Same measurements as the headline,
@@ -1457,6 +1487,8 @@ def side_workload(args, name):
     import torch
     if name == "neuralcf_serving":
         return serving_workload(args)
+    if name == "predict_csv":
+        return predict_csv_workload(args)
     B = {"din_c3": 32768, "widedeep_c5": 131072}.get(name, 65536)
     NB = 8 if name in ("deepfm_c4", "widedeep_c5") else 16       # (configs 4 / 5: the largest single-GPU forms; 27 M-row / 10 M-bucket tables)
     model, feats, desc, roof = build_workload(name, B, args.dist, seed_offset=11, NB=NB)

@@ -400,6 +400,33 @@ class CTRModel:
         eng.forward(ids, dense, out, workspace, stream)
         return out
 
+    MANY_GROUP = 64                  # batches handed to ONE sprk_forward_many call (and, where the graph has such a kernel, to one launch)
+
+    def predict_device_many(self, ids_list, dense_list, outs=None, workspace=None, stream=None):
+        """[r6] Several device-resident batches of ONE row count: one foreign call (``sprk_forward_many``) and -- for the graphs with a
+        several-batches kernel (DeepFM_v2 / pair-dot DeepFM / k_rows_chain graphs / DIN) -- one launch per group of up to 64 batches instead of
+        a launch per batch; bit-identical to ``predict_device`` batch by batch (tests/test_gpu_parity.py).  The reference's own small
+        batches (DeepFM.py:17 batch 12, the 800-candidate request of RecForYouProcess.java:113-130) sit on the launch floor one at a time.
+        Returns the list of score tensors (async)."""
+        import torch
+        n = len(ids_list)
+        if n == 0:
+            return []
+        B = int(ids_list[0].shape[0])
+        if outs is None:
+            flat = torch.empty(n * B, dtype=torch.float32, device=ids_list[0].device)
+            outs = [flat[i * B:(i + 1) * B] for i in range(n)]
+        eng = self.engine
+        if eng.has_din and workspace is None:
+            workspace = torch.empty(max(eng.workspace_bytes(B) // 4, 1), dtype=torch.float32, device=ids_list[0].device)
+        saved = eng._many_batches
+        eng.set_many_batches(min(max(n, 1), self.MANY_GROUP))
+        try:
+            eng.forward_many(ids_list, dense_list, outs, workspace, stream)
+        finally:
+            eng._many_batches = saved
+        return outs
+
     def predict(self, x, batch_size: Optional[int] = None) -> np.ndarray:
         """Like ``tf.keras.Model.predict``: dict of feature columns (or an iterable of dicts /
         ``(dict, label)`` tuples) -> ``ndarray [N, 1] float32``."""
@@ -408,13 +435,26 @@ class CTRModel:
         outs = []
         # batches are enqueued back to back (host packing of batch n+1 overlaps the forward of batch n); ONE id check
         # (= one stream synchronisation) and ONE device -> host copy at the end instead of one per batch
+        # [r6] consecutive batches of one size go to the device as a GROUP (predict_device_many: one foreign call, one launch where the graph
+        # has a several-batches kernel); a group is enqueued while the host packs the next one
+        pending = []
+
+        def flush():
+            if len(pending) == 1:
+                outs.append(self.predict_device(*pending[0]))
+            elif pending:
+                outs.extend(self.predict_device_many([b[0] for b in pending], [b[1] for b in pending]))
+            pending.clear()
         for feats in iter_feature_batches(x, batch_size):
             ids, dense = self.pack(feats)
             if ids.shape[0] == 0:
                 continue
             ids_t = torch.from_numpy(ids).cuda(non_blocking=True)
             dense_t = torch.from_numpy(dense).cuda(non_blocking=True)
-            outs.append(self.predict_device(ids_t, dense_t))
+            if pending and (ids_t.shape[0] != pending[0][0].shape[0] or len(pending) == self.MANY_GROUP):
+                flush()
+            pending.append((ids_t, dense_t))
+        flush()
         if not outs:
             return np.zeros((0, 1), dtype=np.float32)
         eng.check_ids()
@@ -454,9 +494,16 @@ class CTRModel:
         if n == 0:
             return np.zeros((0, 1), dtype=np.float32)
         out = torch.empty(n, dtype=torch.float32, device=ids.device)
-        for lo in range(0, n, batch_size):
-            hi = min(n, lo + batch_size)
-            self.predict_device(ids[lo:hi], dense[lo:hi], out[lo:hi])
+        full = n // batch_size
+        for g0 in range(0, full, self.MANY_GROUP):                # [r6] the full slices in groups of up to 64: one launch per group where the graph allows
+            sl = [(k * batch_size, (k + 1) * batch_size) for k in range(g0, min(full, g0 + self.MANY_GROUP))]
+            if len(sl) == 1:
+                self.predict_device(ids[sl[0][0]:sl[0][1]], dense[sl[0][0]:sl[0][1]], out[sl[0][0]:sl[0][1]])
+            else:
+                self.predict_device_many([ids[a:b] for a, b in sl], [dense[a:b] for a, b in sl], [out[a:b] for a, b in sl])
+        if full * batch_size < n:
+            lo = full * batch_size
+            self.predict_device(ids[lo:n], dense[lo:n], out[lo:n])
         self.engine.check_ids()
         return out.cpu().numpy().reshape(-1, 1)
 
