@@ -122,6 +122,20 @@ def main():
             c = pmc.get("pmc_%s_%s" % (w.replace("c3_attn", "c3"), sq), {}).get(kshort)
             if c:
                 row.setdefault("sq", {}).update({k: v for k, v in c.items() if k != "launches"})
+        # [r6] configs 4 / 5: what the strict loop touched between two visits of a batch (bench.py hbm_cycle), and the share of the step's bytes
+        # that comes from tables beyond the Infinity Cache; every workload: the same step at bench.py's several-batches-per-launch shape
+        for k in ("working_set_mb", "input_batches_cycled", "hbm_side_bytes_per_sample", "hbm_side_GBps"):
+            if k in rl:
+                row[k] = rl[k]
+        mj = os.path.join(src, w + "_many.json")
+        if w0 == w and os.path.exists(mj):
+            for txt in open(mj, errors="replace").read().splitlines():
+                if txt.startswith('{"metric"'):
+                    ml = json.loads(txt)
+                    row["many_us_per_step"] = ml["ms_per_step"] * 1e3
+                    row["many_batches_per_launch"] = ml["config"].get("batches_per_launch")
+                    row["many_algorithmic_TBps"] = alg / (ml["ms_per_step"] * 1e-3) / 1e12
+                    json.dump(ml, open(os.path.join(dst, "bench_" + w + "_many.json"), "w"))
         if "sq" in row:
             s = row["sq"]
             if s.get("SQ_BUSY_CYCLES"):
@@ -134,16 +148,18 @@ def main():
         if os.path.exists(os.path.join(src, extra)):
             shutil.copy(os.path.join(src, extra), os.path.join(dst, extra))
     json.dump(table, open(os.path.join(dst, "roofline_table.json"), "w"), indent=1)
-    md = ["| workload | kernel | launches | rocprof avg us | HIP events us (ratio) | algorithmic MB | **frac of 8 TB/s** | PMC traffic MB | traffic / algorithmic | VALU, MFMA per sample | matrix pipe busy |",
-          "|---|---|---|---|---|---|---|---|---|---|---|"]
+    md = ["| workload | kernel | launches | rocprof avg us | HIP events us (ratio) | algorithmic MB | **frac of 8 TB/s** | PMC traffic MB | traffic / algorithmic | VALU, MFMA per sample | matrix pipe busy | working set MB (batches) | several batches per launch: us per step (batches, algorithmic TB/s) |",
+          "|---|---|---|---|---|---|---|---|---|---|---|---|---|"]
     for r in table:
-        md.append("| %s (`%s`, B = %d) | `%s` | %d | %.2f | %.2f (%.3f) | %.1f | **%.1f %%** | %s | %s | %s | %s |" % (
+        md.append("| %s (`%s`, B = %d) | `%s` | %d | %.2f | %.2f (%.3f) | %.1f | **%.1f %%** | %s | %s | %s | %s | %s | %s |" % (
             r["workload"], r["bench_workload"], r["batch"], r["kernel"][:44], r["launches"], r["rocprof_avg_us"], r["hip_event_us"],
             r["events_vs_rocprof"], r["algorithmic_mb"], 100 * r["frac"],
             ("%.1f" % r["pmc_traffic_mb"]) if "pmc_traffic_mb" in r else "-",
             ("%.2f" % r["traffic_over_algorithmic"]) if "traffic_over_algorithmic" in r else "-",
             ("%.0f, %.1f" % (r["valu_per_sample"], r["mfma_per_sample"])) if "valu_per_sample" in r else "-",
-            ("%.1f %%" % (100 * r["matrix_pipe_busy"])) if "matrix_pipe_busy" in r else "-"))
+            ("%.1f %%" % (100 * r["matrix_pipe_busy"])) if "matrix_pipe_busy" in r else "-",
+            ("%.0f (%d)" % (r["working_set_mb"], r["input_batches_cycled"])) if "working_set_mb" in r else "-",
+            ("%.2f (%s, %.2f)" % (r["many_us_per_step"], r["many_batches_per_launch"], r["many_algorithmic_TBps"])) if "many_us_per_step" in r else "-"))
     open(os.path.join(dst, "roofline_table.md"), "w").write("\n".join(md) + "\n")
     print("\n".join(md))
 

@@ -29,7 +29,9 @@
 #define MR_MAX_BIG 3
 #define MR_MAX_SMALL 8
 #define MR_STAGE 320                      // floats per wave: ids [16][F <= 12] + numerics [16][<= 8]
+#ifndef MR_RS
 #define MR_RS 132                         // floats between two LDS rows of a small column (128 + 4: see the header)
+#endif
 #ifndef MR_XP
 #define MR_XP 0                           // ablation builds (scripts/r05): 1 no small-column reads, 2 one weight fragment pair for the whole second layer,
 #endif                                    // 4 big rows not loaded, 8 no wide part, 16 no second-layer MFMAs -- WRONG RESULTS, timing only

@@ -1,4 +1,4 @@
-"""The committed evidence is self-consistent: every fraction of profiles/r05/roofline_table.json (the table DESIGN.md section 7.2 quotes)
+"""The committed evidence is self-consistent: every fraction of profiles/r06/roofline_table.json (the table DESIGN.md section 7.2 quotes)
 follows from the rocprofv3 csv next to it -- algorithmic bytes per launch / the kernel's average duration / 8.0e12 --, the bench lines
 kept beside the csvs describe the same kernel and batch, the PMC columns follow from pmc_summary.json, and the driver's line
 (bench_driver_command.json) carries the blocks VERDICT r03 asked for with the bound of its 64-batch region labelled as what it is."""
@@ -9,7 +9,7 @@ import os
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-P = os.path.join(ROOT, "profiles", "r05")
+P = os.path.join(ROOT, "profiles", "r06")
 HBM_PEAK = 8.0e12
 
 
@@ -67,7 +67,7 @@ def test_driver_line_blocks():
     l = json.load(open(os.path.join(P, "bench_driver_command.json")))
     assert l["metric"] == "ctr_samples_per_sec" and l["n_gpus"] == 1 and l["steps"] == 20 and l["warmup"] == 5
     assert l["roofline_timed_region"]["bound"] == "infinity_cache" and "NOT an HBM utilisation" in l["roofline_timed_region"]["frac_is"]
-    assert set(l["workloads"]) >= {"din_c3", "deepfm_c2", "deepfm_c4", "widedeep_c5", "neuralcf_serving"}
+    assert set(l["workloads"]) >= {"din_c3", "deepfm_c2", "deepfm_c4", "widedeep_c5", "neuralcf_serving", "predict_csv"}
     assert l["workloads"]["neuralcf_serving"]["latency_ms"]["p50"] < 0.5
     assert l["roofline"]["bound"] == "hbm" and abs(l["roofline"]["achieved"] / l["roofline"]["peak"] - l["roofline"]["frac"]) < 1e-9
     assert l["cpu_baseline"]["kind"] == "port" and l["cpu_baseline"]["cores"] >= 1
@@ -84,3 +84,22 @@ def test_driver_line_blocks():
     for w in ("din_c3", "deepfm_c2", "deepfm_c4", "widedeep_c5"):
         assert abs(cf[w + "_strict_us"] - l["workloads"][w]["roofline"]["avg_launch_us"]) < 1e-9 and 0 < cf[w + "_strict_frac"] < 1
     assert cf["neuralcf_serving_p50_ms"] < 0.5 and cf["neuralcf_serving_requests_per_s_12_workers_8_clients"] > 8000
+    # [r6, VERDICT r05 item 2 / weak 7] the steady-state HBM figure and configs 4 / 5's working sets in kept keys; the working sets are 4 x the
+    # Infinity Cache, and nothing labelled an HBM rate exceeds what HBM delivers (6.3 TB/s)
+    assert abs(rl["hbm_resident_frac_16_batches"] - l["roofline_hbm_resident"]["frac_16_batches_per_launch"]) < 1e-12
+    assert rl["hbm_resident_working_set_mb"] > 512 and rl["hbm_resident_frac_16_batches"] * 8.0 <= 6.3
+    for w in ("deepfm_c4", "widedeep_c5"):
+        blk = l["workloads"][w]
+        assert cf[w + "_working_set_mb"] >= 4 * 256 and cf[w + "_input_batches_cycled"] == blk["input_batches_cycled"] > 8
+        assert blk["roofline"]["hbm_side_GBps"] <= 6300 and blk["roofline"]["hbm_side_GBps_many"] <= 6300
+    assert cf["predict_csv_rows_per_s"] > 1e7 and l["workloads"]["predict_csv"]["repeats_equal_first_block"]
+
+
+def test_rows_that_cycle_a_working_set_say_so():
+    """[r6] configs 4 / 5 of the table: the strict loop walked a working set of at least 4 x the Infinity Cache, and the row says how large."""
+    rows = {r["workload"]: r for r in _table()}
+    for w in ("c4_v2", "c4_pairs", "c5"):
+        assert rows[w]["working_set_mb"] >= 1024 and rows[w]["input_batches_cycled"] > 8, rows[w]
+    # the small reference shapes carry their several-batches-per-launch figure next to the strict one (VERDICT r05 item 8)
+    for w in ("ncf_ref", "deepfm_ref", "v2_ref"):
+        assert rows[w]["many_us_per_step"] < rows[w]["rocprof_avg_us"] and rows[w]["many_batches_per_launch"] >= 16
