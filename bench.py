@@ -1093,7 +1093,9 @@ def main():
                        "tables_row_sharded": ("%d table(s) of %d rows row-sharded over %d rank(s), one virtual range per rank (sprk_vtable_*), peers' rows "
                                               "loaded by the fused kernel" % (len(_SHARDED_TABLES), CONFIG4_ROWS, world)) if _SHARDED_TABLES else None,
                        "launch_overlap_streams": fan, "batches_per_launch": lb,
-                       "tables": "%.0f MB of device tables: %s" % (table_mb, "beyond the 256 MB Infinity Cache (HBM-resident gather)" if table_mb > 512
+                       "tables": "%.0f MB of device tables: %s" % (table_mb, (("%d of the %d algorithmic bytes per sample are rows of the table(s) beyond the 256 MB Infinity Cache "
+                                                                                 "(HBM-side rate: roofline.hbm_side_GBps); the other tables fit the cache" % (ws_info["hbm_side_bytes_per_sample"], roof["bytes_per_sample"]))
+                                                                                if ws_info else "beyond the 256 MB Infinity Cache (HBM-resident gather)") if table_mb > 512
                                                                       else "resident in the 256 MB Infinity Cache -- `roofline` is a fabric/cache-side rate for this "
                                                                            "config; see roofline_hbm_resident") if table_mb else None,
                        "kernel": eng.kernel_name(),
