@@ -199,7 +199,7 @@ def build_workload(name, B, dist_name, seed_offset=0, big_vocab=0, NB=8):
         # blocks (A_b = W12 + W4 diag(c)), over whole 16-row groups (T=50 -> 64 columns), 3 split-f16 products
         executed = ((T + 15) // 16) * 16 * 2 * D * 32
         legacy = env("SPRK_DIN_LEGACY") == "1"
-        att_kernel = "k_din_pool" if legacy else ("k_din_attn" if (env("SPRK_DIN_COLS") == "0" or env("SPRK_DIN_HALF") == "0") else "k_din_attn_cols")
+        att_kernel = "k_din_pool" if (legacy or env("SPRK_DIN_COLS") == "0" or env("SPRK_DIN_HALF") == "0") else "k_din_attn_cols"
         roof = {"bound": "mfma", "kernel": att_kernel, "hist_len": T, "flops_per_sample": flops,
                 "executed_flops_per_sample": flops if legacy else executed,
                 "bytes_per_sample": (T + 1) * 4 + (T + 1) * D * 4 + D * 4,

@@ -199,19 +199,15 @@ int sprk_finalize(sprk_handle h) {
         if (per_cu > 8) per_cu = 8;
         if (per_cu < 1) per_cu = 1;
         h->din_grid_cap = h->num_cus * per_cu;
-        // wave-per-sample kernel when the shape has an instantiation (T <= 64 rows fit the wave's LDS tile)
+        // [r6] k_din_attn_cols / k_din_fused when the shape is one of theirs and the operands fit the split-f16 form; anything else (and
+        // SPRK_DIN_HALF=0 / SPRK_DIN_COLS=0 / SPRK_DIN_LEGACY=1) stays on the generic k_din_pool -- until round 6 k_din_attn took those
         const int kc = (s.row_stride + 15) / 16, hc = s.hidden / 16;
         const size_t vc_bytes = (size_t)s.vocab * s.hidden * sizeof(float);
-        if (!h->tune.din_legacy && s.T <= 64 && vc_bytes < ((size_t)4 << 30) &&
+        if (!h->tune.din_legacy && h->tune.din_half && h->tune.din_cols && s.T <= 64 && vc_bytes < ((size_t)4 << 30) &&
             (size_t)s.vocab * s.row_stride * sizeof(float) < ((size_t)4 << 30)) {   // 32-bit element offsets
-            bool want_half = h->tune.din_half;
-            const int max_wpb = 12;                                // (4 = round 1's workgroup, 16 = four waves per SIMD: measured slower)
             for (size_t v = 0; v < sizeof(kDinVariants) / sizeof(kDinVariants[0]); ++v) {
                 const DinVariant& dv = kDinVariants[v];
-                if (dv.half != want_half) continue;
-                if (dv.wpb > 4 && dv.wpb > max_wpb) continue;
-                if (dv.wpb == 16 && s.T > 56) continue;
-                if (dv.kc != kc || dv.hc != hc || dv.np * (64 / (dv.half ? kc * 4 : s.row_stride / 4)) < s.T) continue;
+                if (dv.kc != kc || dv.hc != hc || s.T > dv.max_t) continue;
                 const int KP = kc * 16;
                 if (!h->din_w12) {
                     HIP_TRY(hipMalloc((void**)&h->din_w12, (size_t)s.hidden * KP * sizeof(float)));
@@ -222,7 +218,7 @@ int sprk_finalize(sprk_handle h) {
                 hipLaunchKernelGGL(k_din_prep_w, dim3(8), dim3(256), 0, 0, d.W, s.hidden, s.row_stride, KP, 1.0f, h->din_w12, h->din_w4);
                 HIP_TRY(hipGetLastError());
                 float h_scale = 1.f, a_scale = 1.f;
-                if (dv.half) {
+                {
                     // power-of-two scales from max|E|, max|W12|, max|W4|: |A_b| <= max|W12| + max|W4| max|E|
                     DevProbe d_max_probe;
                     unsigned*& d_max = d_max_probe.p;
@@ -238,11 +234,11 @@ int sprk_finalize(sprk_handle h) {
                     HIP_TRY(hipMemcpy(bits, d_max, sizeof(bits), hipMemcpyDeviceToHost));
                     float mx[3];
                     memcpy(mx, bits, sizeof(mx));
-                    if (!(mx[0] < 3.0e38f) || !(mx[1] < 3.0e38f) || !(mx[2] < 3.0e38f)) { want_half = false; v = (size_t)-1; continue; }   // NaN / Inf weights: rescan for the f32 kernel
+                    if (!(mx[0] < 3.0e38f) || !(mx[1] < 3.0e38f) || !(mx[2] < 3.0e38f)) break;   // NaN / Inf weights: the generic stage
                     {
                         bool wide = false;                      // outlier rows: the ordinary rows would lose their lo halves
                         if (int rcw = wide_dynamic_range(d.table, (long long)s.vocab, s.row_stride, s.row_stride, mx[0], &wide)) return rcw;
-                        if (wide) { want_half = false; v = (size_t)-1; continue; }
+                        if (wide) break;
                     }
                     const float bound_a = mx[1] + mx[2] * mx[0];
                     int e = 0;
@@ -250,7 +246,7 @@ int sprk_finalize(sprk_handle h) {
                     if (bound_a > 0.f) { (void)frexpf(bound_a, &e); e = 15 - e; if (e > 60) e = 60; if (e < -60) e = -60; a_scale = ldexpf(1.f, e); }
                     hipLaunchKernelGGL(k_din_prep_w, dim3(8), dim3(256), 0, 0, d.W, s.hidden, s.row_stride, KP, a_scale, h->din_w12, h->din_w4);
                     HIP_TRY(hipGetLastError());
-                    if ((size_t)s.vocab * KP * sizeof(float) >= ((size_t)4 << 30)) { want_half = false; v = (size_t)-1; continue; }
+                    if ((size_t)s.vocab * KP * sizeof(float) >= ((size_t)4 << 30)) break;
                     if (!h->din_tsplit) { HIP_TRY(hipMalloc((void**)&h->din_tsplit, (size_t)s.vocab * KP * sizeof(float) + 16)); h->derived_bytes += (size_t)s.vocab * KP * sizeof(float); }
                     long long sb = ((long long)s.vocab * KP + 255) / 256;
                     if (sb > 65536) sb = 65536;
@@ -264,26 +260,12 @@ int sprk_finalize(sprk_handle h) {
                                    s.row_stride, (long long)s.vocab, h->din_vc);
                 HIP_TRY(hipGetLastError());
                 HIP_TRY(hipDeviceSynchronize());
-                DinRun& r = h->din_run;
-                r.T = s.T; r.F = p.n_id_cols; r.hist_col = s.hist_col; r.cand_col = s.cand_col; r.Dp = s.row_stride; r.vocab = s.vocab;
-                r.h_scale = h_scale; r.acc_scale = a_scale * h_scale; r.unscale = 1.0f / (a_scale * h_scale);
-                r.tsplit = h->din_tsplit; r.inv_h_scale = 1.0f / h_scale;
-                r.b2 = s.b2; r.table = d.table; r.w12 = h->din_w12; r.w4 = h->din_w4; r.vc = h->din_vc; r.alpha = d.alpha; r.w2 = d.w2;
-                HIP_TRY(hipFuncSetAttribute(dv.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dv.lds_bytes));
-                if (dv.fn_many) HIP_TRY(hipFuncSetAttribute(dv.fn_many, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dv.lds_bytes));
-                int wgs = (int)(160 * 1024 / dv.lds_bytes);
-                if (wgs > 2) wgs = 2;                                // launch bounds: 2 waves per SIMD
-                if (dv.wpb >= 12) wgs = 1;                           // ... or one 12- / 16-wave workgroup: 3 / 4 waves per SIMD
-                if (wgs < 1) wgs = 1;
-                h->din_attn_grid_cap = h->num_cus * wgs;
-                h->din_wpb = dv.wpb;
                 h->din_attn_many = true;
-                h->din_attn_lds = dv.lds_bytes;
                 h->din_variant = (int)v;
                 // k_din_attn_cols: the weights as the static MFMA operand, sixteen samples per tile (k_din_cols.h).  Needs the
                 // split-f16 tables of this variant and scales that keep W4 * s4 and h * c * sP inside f16's normal range.
                 {
-                    if (dv.half && hc == 2 && (kc == 1 || kc == 2) && s.T <= 64 && h->tune.din_cols) {
+                    if (hc == 2 && (kc == 1 || kc == 2) && s.T <= 64) {
                         // U = a_scale h_scale (the accumulators' unit); sP = h_scale^2 2^-15 puts max |h c| sP in [2^13, 2^15);
                         // W4 then carries s4 = U / sP = a_scale 2^15 / h_scale
                         const float rho = 32768.0f / h_scale;        // s4 / a_scale
@@ -350,6 +332,7 @@ int sprk_finalize(sprk_handle h) {
                         }
                     }
                 }
+                if (!h->din_cols) h->din_variant = -1;              // (W4's range does not fit the split: the generic stage)
                 break;
             }
         }

@@ -114,13 +114,6 @@ static int launch_din(sprk_handle h, const int32_t* ids, float* pooled, float* a
     }
     if (h->din_variant >= 0 && h->din_cols && h->din_fused_attn) return launch_din_fused(h, ids, nullptr, pooled, att, B, nullptr, false, st);
     if (h->din_variant >= 0 && h->din_cols) return launch_din_cols(h, ids, pooled, att, B, nullptr, st);
-    if (h->din_variant >= 0) {
-        int grid = (B + h->din_wpb - 1) / h->din_wpb;
-        if (grid > h->din_attn_grid_cap) grid = h->din_attn_grid_cap;
-        kDinVariants[h->din_variant].launch(h->din_run, ids, pooled, att, B, h->dev_err, grid, h->din_attn_lds, st);
-        HIP_TRY(hipGetLastError());
-        return SPRK_OK;
-    }
     const int nchunks = (B + h->din_ms - 1) / h->din_ms;
     const int grid = nchunks < h->din_grid_cap ? nchunks : h->din_grid_cap;
     hipLaunchKernelGGL(k_din_pool, dim3(grid), dim3(256), h->din_lds_bytes, st, h->dev_plan, ids, pooled, att, B, h->din_ms, h->dev_err);
@@ -392,7 +385,6 @@ static int forward_many_impl(sprk_handle h, int32_t n_batches, const int32_t* co
                 HIP_TRY(hipEventRecord(h->many_fork, (hipStream_t)stream));
                 for (int s = 0; s < SG; ++s) HIP_TRY(hipStreamWaitEvent(h->many_stream[s], h->many_fork, 0));
             }
-            const DinVariant& av = kDinVariants[h->din_variant];
             const DinTailVariant& tv = kDinTailVariants[h->din_tail_variant];
             const int ntpb = (B + 15) / 16;
             int g = 0;
@@ -409,31 +401,18 @@ static int forward_many_impl(sprk_handle h, int32_t n_batches, const int32_t* co
                 }
                 // ONE attention launch for the group (k_din_attn<..., MB = true>: no launch boundary and no partial last round of waves
                 // between the batches), then one tail launch
-                if (h->din_cols && h->din_attn_many && n <= DC_MB) {
+                if (h->din_attn_many && n <= DC_MB) {                   // (din_variant >= 0 <=> k_din_attn_cols' tables exist)
                     DinColsMany cm;
                     memset(&cm, 0, sizeof(cm));
                     cm.n = n;
                     for (int j = 0; j < n; ++j) { cm.ids[j] = tm.ids[j]; cm.pooled[j] = const_cast<float*>(tm.aux[j]); }
                     const int rcc = launch_din_cols(h, nullptr, nullptr, nullptr, B, &cm, st);
                     if (rcc) return rcc;
-                } else if (h->din_cols) {
+                } else {
                     for (int j = 0; j < n; ++j) {
                         const int rcc = launch_din_cols(h, tm.ids[j], const_cast<float*>(tm.aux[j]), nullptr, B, nullptr, st);
                         if (rcc) return rcc;
                     }
-                } else if (av.launch_many && h->din_attn_many && n <= DIN_ATTN_MB) {
-                    DinAttnMany am;
-                    memset(&am, 0, sizeof(am));
-                    am.n = n;
-                    for (int j = 0; j < n; ++j) { am.ids[j] = tm.ids[j]; am.pooled[j] = const_cast<float*>(tm.aux[j]); }
-                    long long ag = ((long long)n * B + h->din_wpb - 1) / h->din_wpb;
-                    if (ag > h->din_attn_grid_cap) ag = h->din_attn_grid_cap;
-                    av.launch_many(h->din_run, am, B, h->dev_err, (int)ag, h->din_attn_lds, st);
-                } else {
-                    int ag = (B + h->din_wpb - 1) / h->din_wpb;
-                    if (ag > h->din_attn_grid_cap) ag = h->din_attn_grid_cap;
-                    for (int j = 0; j < n; ++j)
-                        av.launch(h->din_run, tm.ids[j], const_cast<float*>(tm.aux[j]), nullptr, B, h->dev_err, ag, h->din_attn_lds, st);
                 }
                 const int tw = h->din_tail_run.e_unscale != 0.f ? dt_waves_unf(kDinTailVariants[h->din_tail_variant].kpc) : DT_WAVES;
                 long long tg = ((long long)n * ntpb + tw - 1) / tw;
@@ -542,7 +521,7 @@ int sprk_describe(sprk_handle h, char* buf, size_t buf_bytes) {
     }
     const char* stage = "";
     if (h->plan.din.enabled == 2) stage = h->dien_frag ? "k_dien_seq_mfma" : "k_dien_seq";
-    else if (h->plan.din.enabled == 1) stage = h->din_variant < 0 ? "k_din_pool" : (h->din_cols ? (h->din_fused_attn ? "k_din_fused" : "k_din_attn_cols") : "k_din_attn");
+    else if (h->plan.din.enabled == 1) stage = h->din_variant < 0 ? "k_din_pool" : (h->din_fused_attn ? "k_din_fused" : "k_din_attn_cols");
     if (h->plan.din.enabled == 1 && h->din_fused) snprintf(kern, sizeof(kern), "k_din_fused<KC=%d,tail 128/64>", h->din_cols_kc);
     if (h->plan.din.enabled == 2 && h->dien_fused) snprintf(kern, sizeof(kern), "k_dien_fused<D=%d,tail 128/64>", h->plan.din.emb_dim);   // (stage: what sprk_din_pool runs)
     size_t uploaded = 0;
@@ -551,7 +530,7 @@ int sprk_describe(sprk_handle h, char* buf, size_t buf_bytes) {
 #define SPRK_BUILD_DEFINES_STR ""                             // (_lib.build_library passes the experiment defines of SPRK_BUILD_DEFINES; the product build has none)
 #endif
     const int n = snprintf(buf, buf_bytes, "kernel=%s;stage=%s;stage_waves_per_workgroup=%d;fused=%d;uploaded_bytes=%zu;derived_bytes=%zu;first_dense_fold=%d;build_defines=%s", kern, stage,
-                           h->din_variant >= 0 ? h->din_wpb : 0, strcmp(kern, "k_tile_forward") != 0 ? 1 : 0, uploaded, h->derived_bytes, h->n_acc_folded, SPRK_BUILD_DEFINES_STR);
+                           h->din_variant >= 0 ? DC_WAVES : 0, strcmp(kern, "k_tile_forward") != 0 ? 1 : 0, uploaded, h->derived_bytes, h->n_acc_folded, SPRK_BUILD_DEFINES_STR);
     if (n < 0 || (size_t)n >= buf_bytes) return fail(SPRK_EINVAL, "describe: buffer of %zu bytes is too small", buf_bytes);
     return SPRK_OK;
 }

@@ -93,7 +93,7 @@ struct SprkTuning {
     bool din_tail = true;             // SPRK_DIN_TAIL=0            DIN tail on the interpreter
     bool din_legacy = false;          // SPRK_DIN_LEGACY=1          attention on the generic k_din_pool
     bool din_half = true;             // SPRK_DIN_HALF=0            attention on f32 MFMA
-    bool din_cols = true;             // SPRK_DIN_COLS=0            attention on k_din_attn (wave per sample), not k_din_attn_cols
+    bool din_cols = true;             // SPRK_DIN_COLS=0            attention on the generic k_din_pool, not k_din_attn_cols / k_din_fused
     bool din_fused = true;            // SPRK_DIN_FUSED=0           DIN as two launches (k_din_attn_cols -> pooled vectors -> k_din_tail), not k_din_fused
     bool din_fused_mb = true;         // SPRK_DIN_FUSED_MB=0        forward_many groups on the attention + tail pipeline instead of the persistent k_din_fused<MB>
     bool din_fused_unf = true;        // SPRK_DIN_FUSED_UNF=0       k_din_fused's tail with folded rows for every embedding column (no raw split rows on the matrix pipe)

@@ -47,19 +47,15 @@ struct sprk_engine {
     int din_ms = 0;
     size_t din_lds_bytes = 0;
     int din_grid_cap = 0;
-    // wave-per-sample attention kernel (k_din_attn); -1 = the generic k_din_pool
+    // >= 0: the attention stage's derived tables (W12 / W4 / vc, the pre-split table) exist and k_din_attn_cols / k_din_fused run; -1 = the generic k_din_pool
     int din_variant = -1;
     DienRun dien_run{};
     float* dien_frag = nullptr;          // k_dien_seq_mfma's fragment image (NULL: the lane-per-sample kernel)
-    DinRun din_run;
     float* din_w12 = nullptr;      // (W1+W2)^T, W4^T fragments and the per-id c-term table (device)
     float* din_w4 = nullptr;
     float* din_vc = nullptr;
     float* din_tsplit = nullptr;   // HALF: the movie table pre-split into f16 hi/lo pairs
-    size_t din_attn_lds = 0;
-    int din_attn_grid_cap = 0;
     SprkTuning tune;               // the environment's switches as sprk_finalize found them
-    int din_wpb = 4;               // waves per k_din_attn workgroup
     bool din_cols = false;         // attention on k_din_attn_cols (16 samples per MFMA tile, static weight operand; k_din_cols.h)
     int din_cols_kc = 0;
     DinColsRun din_cols_run;

@@ -1,39 +1,8 @@
-// host_setup_common.h -- k_din_attn dispatch table, the interpreter's first-Dense fold, the dynamic-range guard, split-f16 fragment packing.
+// host_setup_common.h -- the attention stage's shape table, the interpreter's first-Dense fold, the dynamic-range guard, split-f16 fragment packing.
 // Part of sparrow_hip.hip (one translation unit); included there, not compilable on its own.
-// ---- dispatch table for k_din_attn<KC, HC> ----
-typedef void (*DinLaunchFn)(const DinRun&, const int*, float*, float*, int, int*, int, size_t, hipStream_t);
-template <int KC, int HC, int NP, bool HALF, int WPB>
-void din_launch(const DinRun& a, const int* ids, float* pooled, float* att, int B, int* err, int grid, size_t lds, hipStream_t st) {
-    hipLaunchKernelGGL((k_din_attn<KC, HC, NP, HALF, WPB, false>), dim3(grid), dim3(WPB * 64), lds, st, a, ids, pooled, att, B, err, DinAttnOne{});
-}
-typedef void (*DinLaunchManyFn)(const DinRun&, const DinAttnMany&, int, int*, int, size_t, hipStream_t);
-template <int KC, int HC, int NP, bool HALF, int WPB>
-void din_launch_many(const DinRun& a, const DinAttnMany& m, int B, int* err, int grid, size_t lds, hipStream_t st) {
-    hipLaunchKernelGGL((k_din_attn<KC, HC, NP, HALF, WPB, true>), dim3(grid), dim3(WPB * 64), lds, st, a, (const int*)nullptr, (float*)nullptr, (float*)nullptr, B,
-                       err, m);
-}
-struct DinVariant {
-    int kc, hc, np;                   // np: gather passes compiled in (each covers 64 / (row_stride/4) history slots)
-    bool half;                        // K = D contraction on split-f16 MFMA
-    int wpb;                          // waves per workgroup: 12 = one workgroup per CU at 3 waves per SIMD, 4 = two at 2 (round 1)
-    const void* fn;
-    size_t lds_bytes;
-    DinLaunchFn launch;
-    const void* fn_many;              // several batches per launch (12-wave forms only; NULL otherwise)
-    DinLaunchManyFn launch_many;
-};
-#define DIN_MANY_12(KC, HC, NP, HALF) reinterpret_cast<const void*>(&k_din_attn<KC, HC, NP, HALF, 12, true>), &din_launch_many<KC, HC, NP, HALF, 12>
-#define DIN_VARIANT1(KC, HC, NP, HALF, WPB) {KC, HC, NP, HALF, WPB, reinterpret_cast<const void*>(&k_din_attn<KC, HC, NP, HALF, WPB, false>), DinLds<KC, HC, WPB>::bytes, &din_launch<KC, HC, NP, HALF, WPB>, nullptr, nullptr}
-#define DIN_VARIANT12(KC, HC, NP) {KC, HC, NP, true, 12, reinterpret_cast<const void*>(&k_din_attn<KC, HC, NP, true, 12, false>), DinLds<KC, HC, 12>::bytes, &din_launch<KC, HC, NP, true, 12>, DIN_MANY_12(KC, HC, NP, true)}
-#define DIN_VARIANT(KC, HC, NP) DIN_VARIANT1(KC, HC, NP, true, 4), DIN_VARIANT1(KC, HC, NP, false, 4)
-const DinVariant kDinVariants[] = {     // first match wins: smallest sufficient pass count first; 12-wave forms before their 4-wave twins
-    DIN_VARIANT12(2, 2, 2), DIN_VARIANT(2, 2, 2), DIN_VARIANT12(2, 2, 4), DIN_VARIANT(2, 2, 4),
-    DIN_VARIANT12(2, 2, 7),    // BASELINE config 3: emb_dim 32, 50 history slots, attention hidden 32
-    DIN_VARIANT(2, 2, 7),
-    DIN_VARIANT12(2, 2, 8), DIN_VARIANT(2, 2, 8),
-    DIN_VARIANT(1, 2, 1),               // the reference's own DIN.py: emb_dim 10 (rows padded to 12), 5 slots, hidden 32
-    DIN_VARIANT(1, 2, 4),
-};
+// ---- the attention shapes k_din_attn_cols / k_din_fused take ([r6] until round 6 the dispatch table of k_din_attn: k_din_attn.h) ----
+struct DinVariant { int kc, hc, max_t; };        // emb_dim in (16 (kc - 1), 16 kc], attention hidden 16 hc, history slots <= max_t
+const DinVariant kDinVariants[] = {{2, 2, 64}, {1, 2, 64}};
 
 // First-Dense fold for plans the tile interpreter runs.  A Dense layer is linear in its input, so the share of
 // an embedding column is a table of its own: F_g[id] = W_g^T E_g[id] (N floats per id).  When a ROWS segment feeds

@@ -179,13 +179,14 @@ def test_din_attention_and_pooling_parts(torch, samples):
 @pytest.mark.parametrize("T,D,B", [(50, 32, 4099), (64, 32, 515), (17, 32, 1000), (1, 32, 130), (33, 24, 700),
                                    (50, 16, 1025), (20, 10, 900), (30, 10, 901), (5, 10, 64), (50, 8, 333)])
 def test_din_attention_kernel_shapes(torch, monkeypatch, T, D, B):
-    """k_din_attn (wave per sample, A_b = W12 + W4 diag(c), per-id c-term table) against the fp64 oracle's
-    attention weights and pooled vector, and against the generic k_din_pool (SPRK_DIN_LEGACY=1), over
-    history lengths / row widths that hit every instantiation, partial 16-row groups and ragged batches."""
+    """The attention stage (A_b = W12 + W4 diag(c), per-id c-term table) on k_din_fused, on k_din_attn_cols + k_din_tail and on the generic
+    k_din_pool (SPRK_DIN_LEGACY=1; [r6] also where SPRK_DIN_COLS=0 / SPRK_DIN_HALF=0 lead since k_din_attn is retired) against the fp64
+    oracle's attention weights and pooled vector, over history lengths / row widths that hit every instantiation, partial 16-row groups
+    and ragged batches."""
     V, U = 5000, 700
     feats = SY.synth_din(B, T, V, U, seed=100 + T + D)
     got = {}
-    modes = ("0", "cols", "wave", "1")                              # k_din_fused / k_din_attn_cols + k_din_tail / k_din_attn (wave per sample) / k_din_pool
+    modes = ("0", "cols", "wave", "1")                              # k_din_fused / k_din_attn_cols + k_din_tail / SPRK_DIN_COLS=0 (the generic stage) / k_din_pool
     for legacy in modes:
         monkeypatch.setenv("SPRK_DIN_LEGACY", "1" if legacy == "1" else "0")
         monkeypatch.setenv("SPRK_DIN_COLS", "0" if legacy == "wave" else "1")
