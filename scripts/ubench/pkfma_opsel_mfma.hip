@@ -22,7 +22,10 @@
     X(8, "v_pk_fma_f32 op_sel_hi:[1,0,1] op_sel:[0,1,0]", "v_pk_fma_f32 v[4:5], v[36:37], v[0:1], v[48:49] op_sel:[0,1,0] op_sel_hi:[1,0,1]", 3 * 2 + 0.5f, 5 * 100 + 0.25f) \
     X(9, "v_pk_fma_f32 op_sel_hi:[0,1,1]",         "v_pk_fma_f32 v[4:5], v[36:37], v[0:1], v[48:49] op_sel_hi:[0,1,1]",            3 * 100 + 0.5f,  3 * 2 + 0.25f) \
     X(10, "v_pk_fma_f32 SGPR src1 op_sel:[0,1,0]",  "s_mov_b32 s20, 0x42c80000\n\ts_mov_b32 s21, 2.0\n\ts_nop 3\n\tv_pk_fma_f32 v[4:5], v[36:37], s[20:21], v[48:49] op_sel:[0,1,0]", 3 * 2 + 0.5f, 5 * 2 + 0.25f) \
-    X(11, "v_pk_mul_f32 op_sel:[1,0] (src0 hi)",    "v_pk_mul_f32 v[4:5], v[0:1], v[36:37] op_sel:[1,0]",                          2 * 3.f,         2 * 5.f)
+    X(11, "v_pk_mul_f32 op_sel:[1,0] (src0 hi)",    "v_pk_mul_f32 v[4:5], v[0:1], v[36:37] op_sel:[1,0]",                          2 * 3.f,         2 * 5.f) \
+    X(12, "v_pk_mov_b32 op_sel:[0,1]",              "v_pk_mov_b32 v[4:5], v[36:37], v[0:1] op_sel:[0,1]",                          3.f,             2.f) \
+    X(13, "v_pk_mov_b32 op_sel:[1,0] (hipcc's form)", "v_pk_mov_b32 v[4:5], v[36:37], v[0:1] op_sel:[1,0]",                        5.f,             100.f) \
+    X(14, "v_pk_fma_f16 op_sel:[0,1,0] (halves of one register)", "v_mov_b32 v36, 0x40003c00\n\tv_mov_b32 v0, 0x44004200\n\tv_mov_b32 v48, 0x34003800\n\ts_nop 3\n\tv_pk_fma_f16 v4, v36, v0, v48 op_sel:[0,1,0]\n\tv_mov_b32 v5, v4", __builtin_bit_cast(float, 0x48204480u), __builtin_bit_cast(float, 0x48204480u))
 
 template <int V> struct Victim;
 #define X(N, NAME, ASM, E4, E5) template <> struct Victim<N> { static constexpr const char* name = NAME; static constexpr float e4 = E4, e5 = E5; \
@@ -87,6 +90,6 @@ int main(int argc, char** argv) {
     CHECK(hipMalloc((void**)&d, 32));
     const bool second = argc > 2;                                 // (second sweep: the SGPR form, src0-hi multiply, more kinds of MFMA)
     if (!second) { ALLN(0) ALLN(1) ALLN(2) ALLN(3) ALLN(4) ALLN(5) ALLN(6) ALLN(7) ALLN(8) ALLN(9) }
-    else { ALLN(10) ALLN(11) NEWN(0) NEWN(10) NEWN(1) NEWN(5) }
+    else { ALLN(10) ALLN(11) NEWN(0) NEWN(10) NEWN(1) NEWN(5) ALLN(12) ALLN(13) ALLN(14) }
     return 0;
 }
