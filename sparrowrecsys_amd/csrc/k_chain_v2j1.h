@@ -126,6 +126,18 @@ static __device__ unsigned long long g_v2j1_ts[V2J1_TS_WAVES * 8];
 // fragment -- 13 of the 26 KB a wave reads from LDS, none of it needing an id -- are read in FRONT of the gathers.  With rows coming
 // from HBM the texture path backs up longer and the LDS sits idle meanwhile: 8.9 -> 8.68 us; with cache-resident tables the same
 // move only delays the gathers: 7.26 -> 7.38 us (profiles/r04/experiments/r04_34).  Same arithmetic, same bits.
+// (Tried and dropped [r6], profiles/r06/experiments/r06_30 .. r06_32, the patch is kept there: a PERSISTENT several-batches form of this kernel for
+// sprk_forward_many -- the image staged once per workgroup, every wave walking tasks of up to 64 batches, the next task's ids DMA'd into its slot
+// behind the gathers.  Bit-identical to launch per batch; 3.79-3.81 us per 65 536-sample step against k_deepfm_v2_joint_many's 3.83-3.85, and the
+// same 3.79-3.84 with 16, 12 or 8 waves per CU, fragments re-read per task or held in registers; 5.7-6.1 against 5.4-5.6 us with HBM-resident
+// tables.  Why nothing moves it: scripts/ubench/row_gather_steady.hip -- the BARE gather, no scoring, persistent waves -- runs at 3.7 us per step
+// from a 200 MB window (6.7 TB/s of random 128-byte lines out of the Infinity Cache) and 4.9-5.3 us from a 3.2 GB table, whatever the waves per CU
+// or the gathers in flight per wave: the several-batches figures of both kernels ARE the fabric's line rate.  Two things the attempt taught about
+// hipcc, for the next kernel that loops: (1) once a global_load_lds builtin is outstanding its wait-count pass waits vmcnt(0) for ANY load result
+// (the FLAT-encoded DMA counts as touching two address spaces), so rows requested before a DMA are waited for together with it -- an asm statement
+// hides the DMA and keeps the staged vmcnt(3..0); (2) what is invariant in a loop is hoisted into registers and, at the 128-VGPR cap of sixteen
+// waves per CU, spilled -- a scratch reload in the trip shares vmcnt with the gathers; forming the lane's coordinates per trip from v_mbcnt in an
+// asm statement and writing selects as arithmetic on them got 96 bytes of scratch to 0.)
 template <int G_BIG, int NJF, bool HOIST = false>
 __global__ __launch_bounds__(V2J1_WAVES_OF(HOIST, G_BIG) * 64, 4) void k_deepfm_v2_joint1(const V2JRun A, const int* __restrict__ ids,
                                                                        const float* __restrict__ dense, float* __restrict__ out, int B,
