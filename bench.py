@@ -1175,6 +1175,12 @@ def main():
             rl[vk + "_oracle_err"] = vv["oracle_check_max_abs_err"]
         if "roofline_timed_region" in line:
             rl["timed_region_bound"] = line["roofline_timed_region"]["bound"]
+        if args.workload == "deepfm_v2_c2":
+            # [r6] what the memory system gives to this config's BARE gather (3 random 128-byte lines per sample, no scoring) in steady state --
+            # one launch walking 64 batches with persistent waves, flat over 8..32 waves per CU and 1..4 tasks in flight: the floor under
+            # ms_per_step at several batches per launch.  Measured constants, not re-measured per run.
+            rl["random_line_floor_us_per_step"] = {"infinity_cache_200_MB": [3.68, 3.82], "hbm_3200_MB": [4.92, 5.32], "window_26_MB": [3.07, 3.14],
+                                                   "source": "scripts/ubench/row_gather_steady.hip, profiles/r06/experiments/r06_32"}
         cfgd = line["config"]
         for wn, wb in (line.get("workloads") or {}).items():
             if "roofline" in wb:

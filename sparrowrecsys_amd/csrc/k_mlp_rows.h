@@ -262,6 +262,13 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_mlp_rows(const MlpRowsRun A, 
     };
 
     // ---- prologue: first task's ids, the numerics' A operands (global -> registers) and the LDS image / small tables requested together ----
+    // (Tried and dropped [r6], profiles/r06/experiments/r06_33 with the patch: the first task's rows requested BEFORE the workgroup's meeting -- a
+    //  gather needs the wave's ids and its private slot, nothing of the image.  (a) gather in front of the DMA loop: config 5 40.3-40.5 us against
+    //  39.3-39.6, EmbeddingMLP.py literal 25.3 against 24.1; (b) ids first, exactly npw DMA instructions per wave right behind them as asm
+    //  statements, `s_waitcnt vmcnt(npw)` out of a switch -- the ids alone, the counter retires in issue order -- then the gather, then vmcnt(0)
+    //  and the meeting: 40.9 against 39.8-40.2, 25.4 against 24.2.  Sixteen row requests per lane in the texture path's queue next to the 150 KB
+    //  of staging slow the staging by more than the overlap gives back, and the meeting then waits for the slowest wave's ROWS: the same thing
+    //  round 4's timeline showed for k_deepfm_v2_joint1's meeting.)
     f32x4 ri = zero, rd = zero;
     int tk = blockIdx.x * WAVES + wave;
     if (ntasks > 0) ld_raw(clampt(tk), ri, rd);
