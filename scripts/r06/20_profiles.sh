@@ -27,7 +27,9 @@ WL[deepfm_ref]="--steps 400 --warmup 40 --workload deepfm_ref"
 WL[din_ref]="--steps 100 --warmup 10 --workload din_ref"
 WL[embedding_mlp_ref]="--steps 200 --warmup 20 --workload embedding_mlp_ref"
 WL[dien_ref]="--steps 100 --warmup 10 --workload dien_ref"
-ALL="c2 c2_hbm c2_zipf c2_f32 c2_pairs c3 c4_v2 c4_pairs c5 v2_ref ncf_ref deepfm_ref din_ref embedding_mlp_ref dien_ref"
+ALL="${WORKLOADS:-c2 c2_hbm c2_zipf c2_f32 c2_pairs c3 c4_v2 c4_pairs c5 v2_ref ncf_ref deepfm_ref din_ref embedding_mlp_ref dien_ref}"
+# (WORKLOADS="c5 embedding_mlp_ref": only those workloads again -- after a change to one kernel; the PMC summary then starts from profiles/r06/pmc_summary.json)
+has() { case " $ALL " in *" $1 "*) return 0 ;; esac; return 1; }
 cd /tmp && export TMPDIR=/tmp
 for w in $ALL; do
   export SPRK_V2_HALF=1; [ $w = c2_f32 ] && export SPRK_V2_HALF=0      # (c2_f32: every contraction on f32 MFMA, the exact-fp32 twin)
@@ -41,18 +43,22 @@ for w in $ALL; do
   echo "$w: $(head -2 $O/${w}_strict_kernel_stats.csv | tail -1 | cut -c1-110)"
 done
 export SPRK_V2_HALF=1
+if has c2; then
 # the driver's launch shape (64 batches per launch) under the tracer, EVERY launch of the multi-batch kernel a full one
 SPRK_BENCH_SKIP_16=1 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_drv -o t -- python $R/bench.py --steps 64 --warmup 64 --cpu-seconds 0 --no-check --hbm-resident 0 --side-workloads= --no-hardware-probe > $O/c2_driver.log 2>&1
 grep '^{"metric"' $O/c2_driver.log | tail -1 > $O/c2_driver_bench.json
 f=$(find $O/trace_drv -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/c2_driver_kernel_stats.csv; rm -rf $O/trace_drv
+fi
 pass() { tag=$1; shift; ctr=(); while [ "$1" != "--" ]; do ctr+=("$1"); shift; done; shift
   timeout 300 rocprofv3 --pmc "${ctr[@]}" --kernel-trace --output-format csv -d $O/pmc_$tag -o p -- "$@" > $O/pmc_$tag.log 2>&1; }
 for w in c2 c2_hbm c2_pairs c3 c4_v2 c4_pairs c5 v2_ref din_ref; do
+  has $w || continue
   CMD="python $R/bench.py $(echo ${WL[$w]} | sed -E 's/--steps [0-9]+ --warmup [0-9]+//') --steps 20 --warmup 5 $STRICT"
   pass ${w}_fetch FETCH_SIZE -- $CMD
   pass ${w}_write WRITE_SIZE -- $CMD
 done
 for w in c2 c2_pairs c3 c5; do
+  has $w || continue
   CMD="python $R/bench.py $(echo ${WL[$w]} | sed -E 's/--steps [0-9]+ --warmup [0-9]+//') --steps 20 --warmup 5 $STRICT"
   pass ${w}_sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -- $CMD
   pass ${w}_sq2 SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_MFMA SQ_WAVES SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT -- $CMD
@@ -60,7 +66,7 @@ done
 cd $R
 python - <<'PY'
 import csv, glob, collections, os, json
-summary = {}
+summary = json.load(open('profiles/r06/pmc_summary.json')) if os.environ.get('WORKLOADS') else {}
 for d in sorted(glob.glob('gpurun_out/r06_prof/pmc_*/')):
     tag = os.path.basename(d.rstrip('/'))
     for f in glob.glob(d + '/**/*counter_collection.csv', recursive=True):

@@ -560,6 +560,15 @@ void sprk_destroy(sprk_handle h) {
             }
         }
     }
+    if (h) {
+        if (const char* path = getenv("SPRK_MR_TS_FILE")) {        // k_mlp_rows' timeline: the LAST launch's stamps
+            std::vector<unsigned long long> ts((size_t)MR_TS_WAVES * MR_TS_SLOTS);
+            hipDeviceSynchronize();
+            if (hipMemcpyFromSymbol(ts.data(), HIP_SYMBOL(g_mr_ts), ts.size() * 8) == hipSuccess) {
+                if (FILE* fp = fopen(path, "wb")) { fwrite(ts.data(), 8, ts.size(), fp); fclose(fp); }
+            }
+        }
+    }
     if (h && h->tune.df_xp == 1024) {                              // the timeline build: the LAST launch's stamps -> $SPRK_DF_TS_FILE
         if (const char* path = getenv("SPRK_DF_TS_FILE")) {
             std::vector<unsigned long long> ts((size_t)DF_TS_WAVES * 8);

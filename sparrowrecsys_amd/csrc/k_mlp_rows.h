@@ -79,7 +79,7 @@ struct MlpRowsLds {
     static constexpr int off_hw = off_b1 + N1;
     static constexpr int total = off_hw + N1;
     static constexpr int total_pad = (total + 255) & ~255;
-    // the device image continues behind the LDS part with W0[:, numerics]^T [N0][8] (+ b0 in column 7 when n_num < 8): read ONCE per
+    // the device image continues behind the LDS part with W0[:, numerics]^T [N0][8] (+ b0 in column 7 when n_num < 8), lane-major: read ONCE per
     // wave, straight from global memory into registers ([r5]: it used to take 4 KB of LDS for that one read)
     static constexpr int off_w0n = total_pad;
     static constexpr int image_floats = total_pad + N0 * 8;
@@ -109,7 +109,9 @@ __global__ __launch_bounds__(256) void k_mlp_rows_pack(const float* __restrict__
     }
     for (int i = tid; i < LD::N0 * 8; i += 256) {
         const int n = i >> 3, k = i & 7;
-        img[LD::off_w0n + i] = k < n_num ? W0[(size_t)n * ldw0 + num_col0 + k] : (k == 7 ? b0[n] : 0.f);   // (column 7 meets x = 1 when n_num < 8, flags & 2)
+        // [r6] lane-major: lane (r, q) = r + 16 q finds {column q, column q + 4} of rows nb*16 + r, nb = 0 .. N0C - 1, as 2 N0C consecutive floats
+        const int dst = ((n & 15) + 16 * (k & 3)) * (2 * N0C) + (n >> 4) * 2 + (k >> 2);
+        img[LD::off_w0n + dst] = k < n_num ? W0[(size_t)n * ldw0 + num_col0 + k] : (k == 7 ? b0[n] : 0.f);   // (column 7 meets x = 1 when n_num < 8, flags & 2)
     }
     for (int i = tid; i < LD::N0; i += 256) img[LD::off_b0 + i] = b0[i];
     for (int i = tid; i < LD::N1; i += 256) {
@@ -140,6 +142,17 @@ __global__ __launch_bounds__(256) void k_mlp_rows_pack(const float* __restrict__
 //     together (pass 1: Ah Bh x 4, pass 2: Ah Bl x 4, pass 3: Al Bh x 4 -- the accumulation order per output is unchanged), and the next
 //     group's fragments are requested as soon as a pass has freed their registers;
 //   * b0 rides in the numerics' free eighth K slot (x = 1) when there are at most seven numerics: eight LDS reads + sixteen adds less.
+#ifdef SPRK_DF_XP
+// (timeline build, scripts/r06/34_mlp_rows_timeline.sh: every wave stamps the 100 MHz clock at entry, behind the meeting, with its first gather out, and per
+// trip with its rows summed, the next gather out, the first layer done, the second layer done, its scores stored -- SPRK_MR_TS_FILE at sprk_destroy)
+#define MR_TS_WAVES 2048
+#define MR_TS_SLOTS 32
+static __device__ unsigned long long g_mr_ts[MR_TS_WAVES * MR_TS_SLOTS];
+#define MR_STAMP(k) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memrealtime(); \
+    const int w_ = blockIdx.x * WAVES + wave; if (lane == 0 && w_ < MR_TS_WAVES && (k) < MR_TS_SLOTS) g_mr_ts[w_ * MR_TS_SLOTS + (k)] = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define MR_STAMP(k) do { } while (0)
+#endif
 template <int N0C, int N1C, int NBIG, int NS, int WAVES, bool DYN, int WK>
 __global__ __launch_bounds__(WAVES * 64, 2) void k_mlp_rows(const MlpRowsRun A, const int* __restrict__ ids,
                                                             const float* __restrict__ dense, float* __restrict__ out,
@@ -179,6 +192,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_mlp_rows(const MlpRowsRun A, 
     // live = false: the trip behind a wave's last task.  Its loads are issued all the same -- into the all-zero rows, one hot line per table --
     // so that the registers a gather writes are the SAME on every path into the next trip: with the gather inside `if (more tasks)` hipcc
     // kept two copies of the 80 registers and moved one into the other at the end of every trip (forty v_mov_b64, build/sparrow.s).
+    [[maybe_unused]] bool stamp_gather = false;                  // (timeline build: the FIRST gather stamps its stages, slots 27..30)
     auto gather = [&](int tk, const f32x4& ri, const f32x4& rd, bool live) {
         if (aligned && tk * 16 + 16 <= B) {
             if (lane < 4 * A.F) st4(stage + 4 * lane, ri);
@@ -208,6 +222,9 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_mlp_rows(const MlpRowsRun A, 
             if (RT ? f < ns : f < NS) sidv[f] = idrow[A.s_col[f]];
         }
         if constexpr (WK != 0) { wid_a = idrow[A.wide_a]; wid_b = idrow[A.wide_b]; }
+#ifdef SPRK_DF_XP
+        if (stamp_gather) { asm volatile("" : "+v"(bid[0])); MR_STAMP(28); }
+#endif
         {
             const float* nrow = stage + 192 + r * A.ND;
             const int last = A.n_num - 1;
@@ -225,6 +242,9 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_mlp_rows(const MlpRowsRun A, 
 #pragma unroll
             for (int nb = 0; nb < N0C; ++nb) g[b][nb] = (MR_XP & 4) ? f32x4{(float)sid, 0.f, 0.f, 0.f} : *reinterpret_cast<const f32x4*>(row + 64 * nb);
         }
+#ifdef SPRK_DF_XP
+        if (stamp_gather) MR_STAMP(29);
+#endif
 #pragma unroll
         for (int f = 0; f < MR_MAX_SMALL; ++f) {
             if (RT ? f < ns : f < NS) {                           // (wave-uniform when RT)
@@ -261,6 +281,13 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_mlp_rows(const MlpRowsRun A, 
         }
     };
 
+    // (Also measured and not kept [r6], r06_37 .. r06_39, with the stamped timeline of each: (i) an explicit vmcnt(0) in front of the task loop, which
+    //  rids every trip of the `s_waitcnt vmcnt(19)` / `vmcnt(16)` hipcc puts in front of the numerics' MFMAs (the loop head merges "operands maybe
+    //  still in flight" into all trips): 38.9-39.3 against 39.0-39.3 us; (ii) the small columns summed in BEFORE the next task's gather goes out, a
+    //  column's eight reads requested while the column before is added (8-16 LDS reads in flight where hipcc, at 249 VGPRs, leaves one or two
+    //  with `lgkmcnt(1)` between them): that stage shrinks from 2.6 to 1.4 us per trip, the second layer and the gather's issue grow by as much,
+    //  39.6 against 39.2.  A trip's stages trade time with each other; their sum per CU does not move -- config 5 streams 157 MB of 512- and
+    //  128-byte rows in 39 us, 4.0 TB/s, where the bare steady-state gather of 128-byte lines gets 4.8-5.1 TB/s out of HBM (row_gather_steady.hip).)
     // ---- prologue: first task's ids, the numerics' A operands (global -> registers) and the LDS image / small tables requested together ----
     // (Tried and dropped [r6], profiles/r06/experiments/r06_33 with the patch: the first task's rows requested BEFORE the workgroup's meeting -- a
     //  gather needs the wave's ids and its private slot, nothing of the image.  (a) gather in front of the DMA loop: config 5 40.3-40.5 us against
@@ -271,6 +298,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_mlp_rows(const MlpRowsRun A, 
     //  round 4's timeline showed for k_deepfm_v2_joint1's meeting.)
     f32x4 ri = zero, rd = zero;
     int tk = blockIdx.x * WAVES + wave;
+    MR_STAMP(0);
     if (ntasks > 0) ld_raw(clampt(tk), ri, rd);
 #pragma unroll 1
     for (int c = wave; c < LD::total_pad / 256; c += WAVES)
@@ -284,13 +312,32 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_mlp_rows(const MlpRowsRun A, 
             (__attribute__((address_space(3))) void*)(smem + LD::total_pad + c * 256), 16, 0, 0);
     __builtin_amdgcn_s_waitcnt(0x0F70);                           // vmcnt(0): this wave's DMA pieces and ids have landed
     __builtin_amdgcn_s_barrier();
-    // numerics' A operands: rows (nb*16 + r) of W0[:, numerics]^T, columns q and q + 4 -- requested BEHIND the meeting (nobody waits for
-    // them there), in flight with the first task's rows, first used by the first task's MFMAs
+    MR_STAMP(1);
+    if (tk >= ntasks) return;                                     // (behind the barrier; a wave without a task flags nothing)
+    MR_STAMP(27);
+#ifdef SPRK_DF_XP
+    stamp_gather = true;
+#endif
+    gather(tk, ri, rd, true);
+#ifdef SPRK_DF_XP
+    stamp_gather = false;
+#endif
+    MR_STAMP(30);
+    ld_raw(clampt(tk + task_stride), ri, rd);
+    MR_STAMP(2);
+    // numerics' A operands: rows (nb*16 + r) of W0[:, numerics]^T, columns q and q + 4, first used by the first task's MFMAs.  [r6] Requested
+    // BEHIND the first gather, as four coalesced 16-byte loads per lane (the image holds them lane-major: k_mlp_rows_pack).  Rounds 5's sixteen
+    // 4-byte loads per lane sat between the meeting and the gather -- "nobody waits for them there", but a wave issues in order, and the stamped
+    // timeline (profiles/r06/experiments/r06_35) has 3.3 us between the meeting and the last of them going out: sixteen waves' worth of
+    // 64-lane 4-byte gathers through one texture path, in front of the rows everything else waits for.
     float rwa[N0C], rwb[N0C];
+    {
+        const float* wn = image + LD::off_w0n + lane * (2 * N0C);
 #pragma unroll
-    for (int nb = 0; nb < N0C; ++nb) {
-        rwa[nb] = image[LD::off_w0n + (nb * 16 + r) * 8 + q];
-        rwb[nb] = image[LD::off_w0n + (nb * 16 + r) * 8 + q + 4];
+        for (int j = 0; j < N0C / 2; ++j) {
+            const f32x4 v = ld4(wn + 4 * j);
+            rwa[2 * j] = v[0]; rwb[2 * j] = v[1]; rwa[2 * j + 1] = v[2]; rwb[2 * j + 1] = v[3];
+        }
     }
     f32x4 wwide[2] = {zero, zero};
     if constexpr (WK == 1) {
@@ -300,9 +347,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_mlp_rows(const MlpRowsRun A, 
             if (d < A.wide_dim) wwide[h] = ld4(A.wide_w + d);
         }
     }
-    if (tk >= ntasks) return;                                     // (behind the barrier; a wave without a task flags nothing)
-    gather(tk, ri, rd, true);
-    ld_raw(clampt(tk + task_stride), ri, rd);
+    [[maybe_unused]] int trip = 0;
     for (;; tk += task_stride) {
         // ---- the task's gathered rows -> first-layer accumulators (frees the register set for the next task) ----
         f32x4 z0[N0C];
@@ -327,8 +372,10 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_mlp_rows(const MlpRowsRun A, 
 #pragma unroll
         for (int nb = 0; nb < N0C; ++nb) asm volatile("" : "+v"(z0[nb]));
         __builtin_amdgcn_sched_barrier(0);
+        MR_STAMP(3 + 6 * trip);
         gather(clampt(tk + task_stride), ri, rd, more);
         ld_raw(clampt(tk + 2 * task_stride), ri, rd);
+        MR_STAMP(4 + 6 * trip);
         // ---- small columns from LDS (a lane's piece nb of a row: + 64 nb bytes, the instruction's offset field) ----
         if (!bias_in_k7) {
 #pragma unroll
@@ -350,6 +397,10 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_mlp_rows(const MlpRowsRun A, 
 #pragma unroll
         for (int nb = 0; nb < N0C; ++nb) z0[nb] = relu4_fast(z0[nb]);
         // ---- second layer: K = N0, B operand = h1 as it sits in the registers ----
+#ifdef SPRK_DF_XP
+        asm volatile("" : "+v"(z0[0]), "+v"(z0[N0C - 1]));
+        MR_STAMP(5 + 6 * trip);
+#endif
         f32x4 z1[N1C];
         if constexpr (DYN) {
             float mx = 0.f;
@@ -417,6 +468,10 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_mlp_rows(const MlpRowsRun A, 
                         z1[n1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[n1][st], z0[c][st], z1[n1], 0, 0, 0);
             }
         }
+#ifdef SPRK_DF_XP
+        asm volatile("" : "+v"(z1[0]), "+v"(z1[N1C - 1]));
+        MR_STAMP(6 + 6 * trip);
+#endif
         float z = zw;
 #pragma unroll
         for (int n1 = 0; n1 < N1C; ++n1) {
@@ -428,6 +483,10 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_mlp_rows(const MlpRowsRun A, 
         z = rows4_sum(z);
         const int mm = tk * 16 + r;
         if (q == 0 && mm < B) out[mm] = sigmoidf_acc(z + A.head_bias);
+        MR_STAMP(7 + 6 * trip);
+#ifdef SPRK_DF_XP
+        ++trip;
+#endif
         if (!more) break;
     }
     if (badm != 0 && lane == 0) atomicOr(err, 1);
