@@ -34,7 +34,7 @@
 #endif
 #ifndef MR_XP
 #define MR_XP 0                           // ablation builds (scripts/r05): 1 no small-column reads, 2 one weight fragment pair for the whole second layer,
-#endif                                    // 4 big rows not loaded, 8 no wide part, 16 no second-layer MFMAs -- WRONG RESULTS, timing only
+#endif                                    // 4 big rows not loaded, 8 no wide part, 16 no second-layer MFMAs, 128 big rows with a quad of lanes per row -- WRONG RESULTS, timing only
 
 struct MlpRowsRun {
     int F, ND, n_num;
@@ -239,6 +239,8 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_mlp_rows(const MlpRowsRun A, 
             const unsigned sid = live ? min((unsigned)bid[b], (unsigned)A.big_vocab[b]) : (unsigned)A.big_vocab[b];      // -1 -> the zero row at index vocab
             // (one SGPR base + a 32-bit byte offset per lane: the set-up admits folded tables below 4 GiB)
             const char* row = reinterpret_cast<const char*>(A.big_tab[b]) + (sid * (unsigned)(N0 * 4) + 16u * q);
+            if (MR_XP & 128)              // (timing only: a quad of lanes on ONE row's 64 consecutive bytes -- the same lines per instruction, coalesced)
+                row = reinterpret_cast<const char*>(A.big_tab[b]) + ((unsigned)__shfl((int)sid, lane >> 2) * (unsigned)(N0 * 4) + 16u * (lane & 3));
 #pragma unroll
             for (int nb = 0; nb < N0C; ++nb) g[b][nb] = (MR_XP & 4) ? f32x4{(float)sid, 0.f, 0.f, 0.f} : *reinterpret_cast<const f32x4*>(row + 64 * nb);
         }
