@@ -1179,7 +1179,7 @@ def main():
             # [r6] what the memory system gives to this config's BARE gather (3 random 128-byte lines per sample, no scoring) in steady state --
             # one launch walking 64 batches with persistent waves, flat over 8..32 waves per CU and 1..4 tasks in flight: the floor under
             # ms_per_step at several batches per launch.  Measured constants, not re-measured per run.
-            rl["random_line_floor_us_per_step"] = {"infinity_cache_200_MB": [3.68, 3.82], "hbm_3200_MB": [4.92, 5.32], "window_26_MB": [3.07, 3.14],
+            rl["random_line_floor_us_per_step"] = {"config_2_big_tables_51_MB": [3.37, 3.47], "infinity_cache_200_MB": [3.68, 3.82], "hbm_3200_MB": [4.92, 5.32], "window_26_MB": [3.07, 3.14],
                                                    "source": "scripts/ubench/row_gather_steady.hip, profiles/r06/experiments/r06_32"}
         cfgd = line["config"]
         for wn, wb in (line.get("workloads") or {}).items():

@@ -75,7 +75,9 @@ int main() {
     float* out;
     CK(hipMalloc(&out, (size_t)NB * B * sizeof(float)));
     struct Dist { const char* name; size_t rows; };
-    const Dist dists[] = {{"rows inside a 26 MB window (config 2's three big tables)", (26ull << 20) / 128},
+    const Dist dists[] = {{"rows inside a 26 MB window", (26ull << 20) / 128},
+                          {"rows inside a 51 MB window (config 2's three big tables: 401 020 rows of 128 bytes)", 401020},
+                          {"rows inside a 130 MB window (all of config 2's device tables)", (130ull << 20) / 128},
                           {"rows inside a 200 MB window (Infinity Cache)", (200ull << 20) / 128},
                           {"rows over the whole 3.2 GB table (HBM)", rows_big}};
     for (const Dist& d : dists) {
