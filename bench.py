@@ -749,8 +749,8 @@ def main():
     if args.launch_batches > 1 and env("SPRK_FORCE_INTERPRETER") != "1":
         if roof["kernel"] in ("k_deepfm_v2_joint", "k_rows_chain"):
             lb = args.launch_batches
-        elif roof["kernel"] == "k_deepfm_pairs":
-            lb = min(args.launch_batches, 16)
+        elif roof["kernel"] == "k_deepfm_pairs" or (roof["kernel"] == "k_mlp_rows" and env("SPRK_MLP_ROWS_MANY") != "0"):
+            lb = min(args.launch_batches, 16)      # (k_mlp_rows_many [r6]; SPRK_MLP_ROWS_MANY=0: launch by launch over two streams, rounds 2-5)
         elif is_din and args.workload != "dien_ref" and env("SPRK_DIN_LEGACY") != "1" and env("SPRK_DIN_TAIL") != "0" and eng.kernel_name() in ("k_din_tail", "k_din_fused"):
             lb = min(args.launch_batches, 16)   # groups of batches: one attention + one tail launch each, alternating streams
     if lb > 1:
@@ -1512,7 +1512,8 @@ def side_workload(args, name):
         batches, ws_info = hbm_cycle(name, model, batches, B)
         NB = len(batches)
     outs = [torch.empty(B, dtype=torch.float32, device="cuda") for _ in range(NB)]
-    lb = 16 if (roof["kernel"] in ("k_deepfm_pairs", "k_deepfm_v2_joint", "k_rows_chain") or (din and eng.kernel_name() in ("k_din_tail", "k_din_fused"))) else 1
+    lb = 16 if (roof["kernel"] in ("k_deepfm_pairs", "k_deepfm_v2_joint", "k_rows_chain") or (roof["kernel"] == "k_mlp_rows" and os.environ.get("SPRK_MLP_ROWS_MANY") != "0")
+                or (din and eng.kernel_name() in ("k_din_tail", "k_din_fused"))) else 1
     eng.set_many_batches(lb)
     fan = 2 if (din and lb > 1 and eng.set_many_streams(2)) else 0
     ws = torch.empty(max(eng.many_workspace_bytes(B, max(fan, 1) * lb) // 4, 1), dtype=torch.float32, device="cuda")

@@ -216,8 +216,9 @@ int sprk_set_many_streams(sprk_handle h, int32_t n);
 
 /* How many of sprk_forward_many's batches ONE kernel launch scores (1 = a launch per batch, the default; up to 64).  Each
  * batch keeps its own ids / dense / out buffers of B rows; the launch walks the tasks of all of them, so the fixed cost of
- * a launch is spent once per n batches.  Bit-identical results.  Honoured by the fused DeepFM_v2 kernel with 16-byte
- * aligned buffers; every other case silently goes batch by batch (and takes sprk_set_many_streams into account). */
+ * a launch is spent once per n batches.  Bit-identical results.  Honoured, with 16-byte aligned buffers, by the fused DeepFM_v2
+ * and embedding-rows kernels (up to 64 per launch) and by the pair-dot DeepFM, EmbeddingMLP / Wide&Deep and DIN kernels (up to
+ * 16); every other case silently goes batch by batch (and takes sprk_set_many_streams into account). */
 int sprk_set_many_batches(sprk_handle h, int32_t n);
 
 /* sprk_forward_many with both knobs as ARGUMENTS of the call: `batches_per_launch` (1..64) and `helper_streams` (0, 2..4) mean

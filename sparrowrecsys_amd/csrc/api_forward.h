@@ -318,6 +318,30 @@ static int forward_many_impl(sprk_handle h, int32_t n_batches, const int32_t* co
             return SPRK_OK;
         }
     }
+    // [r6] k_mlp_rows (EmbeddingMLP / Wide&Deep): up to MR_MB batches per launch
+    if (h->finalized && many_batches > 1 && n_batches > 1 && h->mlp_rows_nbig >= 0 && h->mlp_rows_many_kernel && B > 0 && ids && dense) {
+        bool ok = true;
+        for (int32_t i = 0; i < n_batches && ok; ++i)
+            ok = ids[i] && dense[i] && out[i] && !(((uintptr_t)ids[i] | (uintptr_t)dense[i]) & 15);
+        if (ok) {
+            const int per = many_batches < MR_MB ? many_batches : MR_MB;
+            const int ntpb = (B + 15) / 16;
+            MlpRowsRun rr = h->mlp_rows_run;
+            rr.flags &= ~1;
+            for (int32_t i0 = 0; i0 < n_batches; i0 += per) {
+                MlpRowsMany m;
+                memset(&m, 0, sizeof(m));
+                m.n = n_batches - i0 < per ? n_batches - i0 : per;
+                for (int j = 0; j < m.n; ++j) { m.ids[j] = ids[i0 + j]; m.dense[j] = dense[i0 + j]; m.out[j] = out[i0 + j]; }
+                long long grid = ((long long)m.n * ntpb + MR_WAVES - 1) / MR_WAVES;
+                if (grid > h->num_cus) grid = h->num_cus;
+                hipLaunchKernelGGL(h->mlp_rows_many_kernel, dim3((int)grid), dim3(MR_WAVES * 64), h->mlp_rows_lds, (hipStream_t)stream, rr, m, B, h->dev_err,
+                                   (const float*)h->mlp_rows_image);
+                HIP_TRY(hipGetLastError());
+            }
+            return SPRK_OK;
+        }
+    }
     // the pairwise-dot DeepFM kernel: up to V1_MB batches per launch
     if (h->finalized && many_batches > 1 && n_batches > 1 && h->v2_variant < 0 && h->v1_variant >= 0 && B > 0 && ids && dense) {
         bool ok = true;

@@ -99,6 +99,7 @@ struct SprkTuning {
     bool din_fused_unf = true;        // SPRK_DIN_FUSED_UNF=0       k_din_fused's tail with folded rows for every embedding column (no raw split rows on the matrix pipe)
     bool dien_fused = true;           // SPRK_DIEN_FUSED=0          DIEN as two launches (k_dien_seq_mfma -> final states -> k_din_tail), not k_dien_fused
     int din_fused_min_t = 12;         // SPRK_DIN_FUSED_MIN_T=n     shortest history k_din_fused takes (below: k_din_attn_cols -> k_din_tail)
+    bool mlp_rows_many = true;        // SPRK_MLP_ROWS_MANY=0       sprk_forward_many over k_mlp_rows graphs launch by launch (streams), not k_mlp_rows_many
     int df_xp = 0;                    // SPRK_DF_XP=bits            k_din_fused ablation variants (only in a -DSPRK_DF_XP build of the library)
     int din_cols_ts = 0;              // SPRK_DIN_COLS_TS=1|2|4     waves per task of k_din_attn_cols (0 = by the launch's task count)
     int many_streams = 0;             // SPRK_MANY_STREAMS=n        forward_many fans batches over n helper streams (2..4)
@@ -117,7 +118,7 @@ struct SprkTuning {
         t.mlp_chain = !off("SPRK_MLP_CHAIN");
         t.vmm_tables = !off("SPRK_VMM_TABLES");
         t.din_tail = !off("SPRK_DIN_TAIL"); t.din_legacy = on("SPRK_DIN_LEGACY"); t.din_half = !off("SPRK_DIN_HALF");
-        t.din_cols = !off("SPRK_DIN_COLS"); t.din_fused = !off("SPRK_DIN_FUSED"); t.df_xp = num("SPRK_DF_XP", 0); t.din_fused_mb = !off("SPRK_DIN_FUSED_MB"); t.din_fused_unf = !off("SPRK_DIN_FUSED_UNF"); t.din_fused_min_t = num("SPRK_DIN_FUSED_MIN_T", 12); t.dien_fused = !off("SPRK_DIEN_FUSED");
+        t.din_cols = !off("SPRK_DIN_COLS"); t.din_fused = !off("SPRK_DIN_FUSED"); t.df_xp = num("SPRK_DF_XP", 0); t.mlp_rows_many = !off("SPRK_MLP_ROWS_MANY"); t.din_fused_mb = !off("SPRK_DIN_FUSED_MB"); t.din_fused_unf = !off("SPRK_DIN_FUSED_UNF"); t.din_fused_min_t = num("SPRK_DIN_FUSED_MIN_T", 12); t.dien_fused = !off("SPRK_DIEN_FUSED");
         { const int n = num("SPRK_DIN_COLS_TS", 0); t.din_cols_ts = (n == 1 || n == 2 || n == 4) ? n : 0; }
         { const int n = num("SPRK_MANY_STREAMS", 0); t.many_streams = n < 2 ? 0 : (n > 4 ? 4 : n); }
         return t;

@@ -35,6 +35,7 @@ struct sprk_engine {
     int mlp_rows_nbig = -1;
     MlpRowsRun mlp_rows_run;
     void (*mlp_rows_kernel)(const MlpRowsRun, const int*, const float*, float*, int, int*, const float*) = nullptr;
+    void (*mlp_rows_many_kernel)(const MlpRowsRun, const MlpRowsMany, int, int*, const float*) = nullptr;   // [r6] several batches per launch (nullptr: batch by batch)
     float* mlp_rows_image = nullptr;
     float* mlp_rows_small = nullptr;
     size_t mlp_rows_lds = 0;

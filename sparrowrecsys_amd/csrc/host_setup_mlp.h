@@ -9,6 +9,19 @@ template <int NBIG, int NS, bool DYN>
 MlpRowsKernel mlp_rows_kernel_wk(int wk) {
     return wk == 1 ? &k_mlp_rows<8, 8, NBIG, NS, MR_WAVES, DYN, 1> : wk == 2 ? &k_mlp_rows<8, 8, NBIG, NS, MR_WAVES, DYN, 2> : &k_mlp_rows<8, 8, NBIG, NS, MR_WAVES, DYN, 0>;
 }
+typedef void (*MlpRowsManyKernel)(const MlpRowsRun, const MlpRowsMany, int, int*, const float*);
+template <int NBIG, int NS, bool DYN>
+MlpRowsManyKernel mlp_rows_many_kernel_wk(int wk) {
+    return wk == 1 ? &k_mlp_rows_many<8, 8, NBIG, NS, MR_WAVES, DYN, 1> : wk == 2 ? &k_mlp_rows_many<8, 8, NBIG, NS, MR_WAVES, DYN, 2> : &k_mlp_rows_many<8, 8, NBIG, NS, MR_WAVES, DYN, 0>;
+}
+// [r6] several batches per launch: the split-f16 forms (every model whose weights are finite and bounded: the set-up's choice); the f32-MFMA
+// fall-back forms keep going batch by batch
+MlpRowsManyKernel mlp_rows_many_kernel(int nbig, int nsmall, bool dyn, int wk) {
+    if (!dyn) return nullptr;
+    if (nbig == 2 && nsmall == 8) return mlp_rows_many_kernel_wk<2, 8, true>(wk);
+    if (nbig == 2) return mlp_rows_many_kernel_wk<2, -1, true>(wk);
+    return mlp_rows_many_kernel_wk<1, -1, true>(wk);
+}
 MlpRowsKernel mlp_rows_kernel(int nbig, int nsmall, bool dyn, int wk) {
     if (nbig == 2 && nsmall == 8 && dyn) return mlp_rows_kernel_wk<2, 8, true>(wk);
     if (nbig == 2) return dyn ? mlp_rows_kernel_wk<2, -1, true>(wk) : mlp_rows_kernel_wk<2, -1, false>(wk);
@@ -141,6 +154,9 @@ int setup_mlp_rows(sprk_engine* h) {
     if (r.n_num < 8) r.flags |= 2;                                       // b0 in the numerics' eighth K slot (k_mlp_rows_pack put it there)
     h->mlp_rows_kernel = mlp_rows_kernel(r.n_big, r.n_small, dyn, r.wide_kind);
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(h->mlp_rows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    h->mlp_rows_many_kernel = h->tune.mlp_rows_many ? mlp_rows_many_kernel(r.n_big, r.n_small, dyn, r.wide_kind) : nullptr;
+    if (h->mlp_rows_many_kernel)
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(h->mlp_rows_many_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     h->mlp_rows_run = r;
     h->mlp_rows_lds = lds;
     h->mlp_rows_nbig = r.n_big;

@@ -56,6 +56,14 @@ struct MlpRowsRun {
     int flags;                            // 1 = ids / dense not 16-byte aligned: stage element-wise; 2 = b0 rides in the numerics' free eighth K slot
 };
 
+#define MR_MB 16                          // batches per launch of k_mlp_rows_many
+struct MlpRowsMany {
+    const int* ids[MR_MB];
+    const float* dense[MR_MB];
+    float* out[MR_MB];
+    int n;                                // batches in this launch
+};
+
 // h mod n for a 64-bit hash and n < 2^30, bit-exact, without the 64-bit division hipcc expands `%` into (about seventy VALU and fifty
 // SALU instructions per task in round 4's loop -- the reciprocal of the wave-uniform divisor was recomputed every trip).
 // magic = floor((2^64 - 1) / n): q = mulhi64(h, magic) satisfies floor(h / n) - 2 <= q <= floor(h / n) (h magic / 2^64 > h / n - (n + 1) / n),
@@ -153,10 +161,12 @@ static __device__ unsigned long long g_mr_ts[MR_TS_WAVES * MR_TS_SLOTS];
 #else
 #define MR_STAMP(k) do { } while (0)
 #endif
-template <int N0C, int N1C, int NBIG, int NS, int WAVES, bool DYN, int WK>
-__global__ __launch_bounds__(WAVES * 64, 2) void k_mlp_rows(const MlpRowsRun A, const int* __restrict__ ids,
-                                                            const float* __restrict__ dense, float* __restrict__ out,
-                                                            int B, int* __restrict__ err, const float* __restrict__ image) {
+// [r6] MB: several batches per launch (sprk_forward_many): the launch's tasks are n x ceil(B / 16), task t belongs to batch t / ntpb -- own ids,
+// numerics and score buffers each -- and the waves walk them exactly as they walk one batch's: the image is staged once, the ramp of a strict
+// launch (5 us of config 5's 39) is paid once per MR_MB batches.  Same instruction sequence per task: the same bits as batch by batch.
+template <int N0C, int N1C, int NBIG, int NS, int WAVES, bool DYN, int WK, bool MB>
+__device__ __forceinline__ void mr_body(const MlpRowsRun& A, const int* __restrict__ ids0, const float* __restrict__ dense0, float* __restrict__ out0,
+                                        int B, int* __restrict__ err, const float* __restrict__ image, const MlpRowsMany* __restrict__ Mp) {
     using LD = MlpRowsLds<N0C, N1C, DYN>;
     constexpr int N0 = LD::N0;
     constexpr bool RT = NS < 0;
@@ -166,9 +176,22 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_mlp_rows(const MlpRowsRun A, 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 15, q = lane >> 4;
     const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int ntasks = (B + 15) >> 4;
+    const int ntpb = (B + 15) >> 4;
+    const int ntasks = MB ? Mp->n * ntpb : ntpb;
     const int task_stride = gridDim.x * WAVES;
     const int ns = RT ? A.n_small : NS;
+    // (batch buffers, task inside the batch) of launch task t: wave-uniform
+    struct Loc { const int* ids; const float* dense; float* out; int tl; };
+    auto locate = [&](int t) {
+        Loc L;
+        if constexpr (MB) {
+            const int b = __builtin_amdgcn_readfirstlane(t / ntpb);
+            L.ids = Mp->ids[b]; L.dense = Mp->dense[b]; L.out = Mp->out[b]; L.tl = t - b * ntpb;
+        } else {
+            L.ids = ids0; L.dense = dense0; L.out = out0; L.tl = t;
+        }
+        return L;
+    };
     const char* small_b = reinterpret_cast<const char*>(smem + LD::total_pad) + 16 * q;       // + this lane's piece 0 (q) of a row
     float* stage = smem + LD::total_pad + A.small_floats + wave * MR_STAGE;
     unsigned long long badm = 0;          // lanes that saw an id outside [-1, vocab): an SGPR pair, not a VGPR flag
@@ -178,10 +201,11 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_mlp_rows(const MlpRowsRun A, 
 
     // ---- ids / numerics of a task: two coalesced 16-byte loads per lane (ids block, numerics block) ----
     auto ld_raw = [&](int tk, f32x4& ri, f32x4& rd) {
-        if (aligned && tk * 16 + 16 <= B) {                       // wave-uniform
+        const Loc L = locate(tk);
+        if (aligned && L.tl * 16 + 16 <= B) {                     // wave-uniform
             const int ni = 4 * A.F, nd = 4 * A.ND;
-            ri = ld4(reinterpret_cast<const float*>(ids) + (size_t)tk * 16 * A.F + 4 * (lane < ni ? lane : 0));
-            rd = ld4(dense + (size_t)tk * 16 * A.ND + 4 * (lane < nd ? lane : 0));
+            ri = ld4(reinterpret_cast<const float*>(L.ids) + (size_t)L.tl * 16 * A.F + 4 * (lane < ni ? lane : 0));
+            rd = ld4(L.dense + (size_t)L.tl * 16 * A.ND + 4 * (lane < nd ? lane : 0));
         }
     };
     // everything of a task that is in flight while the previous task's second layer runs
@@ -194,7 +218,8 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_mlp_rows(const MlpRowsRun A, 
     // kept two copies of the 80 registers and moved one into the other at the end of every trip (forty v_mov_b64, build/sparrow.s).
     [[maybe_unused]] bool stamp_gather = false;                  // (timeline build: the FIRST gather stamps its stages, slots 27..30)
     auto gather = [&](int tk, const f32x4& ri, const f32x4& rd, bool live) {
-        if (aligned && tk * 16 + 16 <= B) {
+        const Loc L = locate(tk);
+        if (aligned && L.tl * 16 + 16 <= B) {
             if (lane < 4 * A.F) st4(stage + 4 * lane, ri);
             if (lane < 4 * A.ND) st4(stage + 192 + 4 * lane, rd);
         } else {
@@ -202,12 +227,12 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_mlp_rows(const MlpRowsRun A, 
 #pragma clang loop vectorize(disable) unroll(disable)
             for (int e = lane; e < 16 * A.F; e += 64) {
                 const int mm = e / A.F, c = e - mm * A.F;
-                si[e] = ids[(size_t)min(tk * 16 + mm, B - 1) * A.F + c];
+                si[e] = L.ids[(size_t)min(L.tl * 16 + mm, B - 1) * A.F + c];
             }
 #pragma clang loop vectorize(disable) unroll(disable)
             for (int e = lane; e < 16 * A.ND; e += 64) {
                 const int mm = e / A.ND, c = e - mm * A.ND;
-                stage[192 + e] = dense[(size_t)min(tk * 16 + mm, B - 1) * A.ND + c];
+                stage[192 + e] = L.dense[(size_t)min(L.tl * 16 + mm, B - 1) * A.ND + c];
             }
         }
         // one wave: LDS operations complete in issue order, no barrier needed.  EVERY id of the sample is read here, back to back
@@ -483,8 +508,9 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_mlp_rows(const MlpRowsRun A, 
             for (int j = 0; j < 4; ++j) z = fmaf(hw[j], h2[j], z);
         }
         z = rows4_sum(z);
-        const int mm = tk * 16 + r;
-        if (q == 0 && mm < B) out[mm] = sigmoidf_acc(z + A.head_bias);
+        const Loc Ls = locate(tk);
+        const int mm = Ls.tl * 16 + r;
+        if (q == 0 && mm < B) Ls.out[mm] = sigmoidf_acc(z + A.head_bias);
         MR_STAMP(7 + 6 * trip);
 #ifdef SPRK_DF_XP
         ++trip;
@@ -492,6 +518,17 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_mlp_rows(const MlpRowsRun A, 
         if (!more) break;
     }
     if (badm != 0 && lane == 0) atomicOr(err, 1);
+}
+template <int N0C, int N1C, int NBIG, int NS, int WAVES, bool DYN, int WK>
+__global__ __launch_bounds__(WAVES * 64, 2) void k_mlp_rows(const MlpRowsRun A, const int* __restrict__ ids,
+                                                            const float* __restrict__ dense, float* __restrict__ out,
+                                                            int B, int* __restrict__ err, const float* __restrict__ image) {
+    mr_body<N0C, N1C, NBIG, NS, WAVES, DYN, WK, false>(A, ids, dense, out, B, err, image, nullptr);
+}
+template <int N0C, int N1C, int NBIG, int NS, int WAVES, bool DYN, int WK>
+__global__ __launch_bounds__(WAVES * 64, 2) void k_mlp_rows_many(const MlpRowsRun A, const MlpRowsMany M, int B, int* __restrict__ err,
+                                                                 const float* __restrict__ image) {
+    mr_body<N0C, N1C, NBIG, NS, WAVES, DYN, WK, true>(A, nullptr, nullptr, nullptr, B, err, image, &M);
 }
 
 // [r6] Measured and NOT kept (profiles/r06/experiments/r06_13, r06_14, the last form's source next to its numbers): the same

@@ -1051,6 +1051,74 @@ def test_mlp_rows_kernel_vs_interpreter_and_oracle(torch, monkeypatch, kind, B):
         np.testing.assert_array_equal(model.predict(feats)[:, 0], p)
 
 
+@pytest.mark.parametrize("kind,B,n,k", [("embedding_mlp_ref", 4099, 5, 4), ("wide_cross_rows", 1000, 19, 16), ("wide_indicator", 16, 3, 2),
+                                        ("embedding_mlp", 20000, 3, 64)])
+def test_forward_many_several_batches_per_launch_mlp_rows(torch, monkeypatch, kind, B, n, k):
+    """k_mlp_rows_many under sprk_set_many_batches(k) (up to 16 batches per launch, own buffers each): bit-identical to a launch per batch --
+    ragged B, a ragged last launch, k above the kernel's 16 --, a bad id in a later batch of a launch is flagged, unaligned buffers and
+    SPRK_MLP_ROWS_MANY=0 go launch by launch with the same scores."""
+    V, U = (1001, 30001) if kind == "embedding_mlp_ref" else (20000, 30000)
+    D = 10 if kind == "embedding_mlp_ref" else 32
+    feats = [SY.synth_embedding_mlp(B, V, U, seed=400 + i, rated_vocab=V if kind.startswith("wide") else None) for i in range(n)]
+
+    def make():
+        if kind.startswith("embedding_mlp"):
+            return M.EmbeddingMLP(seed=51, emb_dim=D, movie_buckets=V, user_buckets=U)
+        return M.WideNDeep(seed=52, emb_dim=D, movie_buckets=V, user_buckets=U,
+                           **(dict(cross_buckets=10000, cross_dim=0) if kind == "wide_indicator" else dict(cross_buckets=200000, cross_dim=32)))
+    model = make()
+    eng = model.engine
+    assert eng.describe()["kernel"].startswith("k_mlp_rows<")
+    packed = [model.pack(f) for f in feats]
+    ids = [_cuda(torch, p[0]) for p in packed]
+    dense = [_cuda(torch, p[1]) for p in packed]
+    res = {}
+    for kk in (1, k):
+        eng.set_many_batches(kk)
+        outs = [torch.full((B,), -1.0, dtype=torch.float32, device="cuda") for _ in range(n)]
+        eng.forward_many(ids, dense, outs)
+        torch.cuda.synchronize()
+        eng.check_ids()
+        res[kk] = [o.cpu().numpy() for o in outs]
+    for a, b in zip(res[1], res[k]):
+        np.testing.assert_array_equal(a, b)
+    for i in (0, n - 1):
+        np.testing.assert_array_equal(res[k][i], model.predict_device(ids[i], dense[i]).cpu().numpy().reshape(-1))
+    m = min(B, 4096)
+    sub = {kk: v[:m] for kk, v in feats[-1].items()}
+    if kind.startswith("embedding_mlp"):
+        ref = O.embedding_mlp_forward(sub, model.weights, dtype=np.float64, movie_buckets=V, user_buckets=U)[:, 0]
+    else:
+        ref = O.wide_n_deep_forward(sub, model.weights, dtype=np.float64, movie_buckets=V, user_buckets=U,
+                                    cross_buckets=model.cross_buckets, rated_buckets=V)[:, 0]
+    assert np.abs(res[k][-1][:m] - ref).max() <= TIGHT
+    # an out-of-range id in a later batch of a launch is still flagged
+    bad = packed[-1][0].copy()
+    bad[B // 2, [c.key for c in model.id_columns].index("movieId")] = 10 ** 6
+    eng.forward_many(ids[:-1] + [_cuda(torch, bad)], dense, [torch.empty(B, dtype=torch.float32, device="cuda") for _ in range(n)])
+    with pytest.raises(ValueError):
+        eng.check_ids()
+    # unaligned buffers: launch by launch, same scores
+    if B >= 33:
+        F = packed[0][0].shape[1]
+        big_i = torch.empty(B * F + 3, dtype=torch.int32, device="cuda")
+        off_ids = [big_i[1:1 + B * F].view(B, F).copy_(ids[0])] + ids[1:]
+        outs = [torch.full((B,), -1.0, dtype=torch.float32, device="cuda") for _ in range(n)]
+        eng.forward_many(off_ids, dense, outs)
+        torch.cuda.synchronize()
+        for a, o in zip(res[1], outs):
+            np.testing.assert_array_equal(a, o.cpu().numpy())
+    # the switch: the same scores launch by launch
+    monkeypatch.setenv("SPRK_MLP_ROWS_MANY", "0")
+    other = make()
+    other.engine.set_many_batches(k)
+    outs = [torch.full((B,), -1.0, dtype=torch.float32, device="cuda") for _ in range(n)]
+    other.engine.forward_many(ids, dense, outs)
+    torch.cuda.synchronize()
+    for a, o in zip(res[1], outs):
+        np.testing.assert_array_equal(a, o.cpu().numpy())
+
+
 # --------------------------------------------------------------------------------------------
 # DIEN (DIEN.py:163-259): k_dien_seq (GRU with the Embedding mask -> attention gate -> AUGRU) + the DIN tail kernels
 # --------------------------------------------------------------------------------------------
