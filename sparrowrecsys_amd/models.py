@@ -404,7 +404,7 @@ class CTRModel:
 
     def predict_device_many(self, ids_list, dense_list, outs=None, workspace=None, stream=None):
         """[r6] Several device-resident batches of ONE row count: one foreign call (``sprk_forward_many``) and -- for the graphs with a
-        several-batches kernel (DeepFM_v2 / pair-dot DeepFM / k_rows_chain graphs / DIN) -- one launch per group of up to 64 batches instead of
+        several-batches kernel (DeepFM_v2 / pair-dot DeepFM / k_rows_chain graphs / EmbeddingMLP, Wide&Deep / DIN) -- one launch per group of up to 64 (16) batches instead of
         a launch per batch; bit-identical to ``predict_device`` batch by batch (tests/test_gpu_parity.py).  The reference's own small
         batches (DeepFM.py:17 batch 12, the 800-candidate request of RecForYouProcess.java:113-130) sit on the launch floor one at a time.
         Returns the list of score tensors (async)."""
