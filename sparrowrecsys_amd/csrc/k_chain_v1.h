@@ -24,6 +24,9 @@
 // chip -- both gathers are issued before the first scoring stage).  The plan interpreter ran this graph in 40 us per 65 536
 // samples, round 1's version of this kernel in 15.8.
 
+#ifndef V1_XP
+#define V1_XP 0                           // ablation builds (scripts/r06, WRONG RESULTS, timing only): 1 one ids load per lane instead of NF, 2 the rows of fields 3.. not
+#endif                                    // requested, 4 no second first-order load, 8 the deep part's own rows not requested, 16 no numerics loads
 #define V1_MAX_FIELDS 8
 #define V1_MAX_DEEP 2
 #define V1_MAX_ROWS (V1_MAX_FIELDS + V1_MAX_DEEP)
@@ -204,7 +207,7 @@ __device__ __forceinline__ void v1_body(const V1Run& A, const int* __restrict__ 
         const int m = min(t * 16 + r, B - 1);                    // rows past the end re-read the last sample, never stored
         const int* row = ids + (size_t)m * A.F;
 #pragma unroll
-        for (int f = 0; f < NF; ++f) idv[f] = row[A.col[f]];
+        for (int f = 0; f < NF; ++f) idv[f] = ((V1_XP & 1) && f > 0) ? (int)((unsigned)idv[0] % (unsigned)A.vocab[f]) : row[A.col[f]];
     };
     auto issue_gather = [&](int tg, const int (&idv)[NF], Set& S) {
         int t;
@@ -215,8 +218,8 @@ __device__ __forceinline__ void v1_body(const V1Run& A, const int* __restrict__ 
             const float* nrow = dense + (size_t)m * A.ND;
             const int last = A.n_num - 1;
             // slots beyond n_num hold a duplicate finite value that only ever meets zero weights
-            S.xa = nrow[min(q, last)];
-            S.xb = nrow[min(q + 4, last)];
+            S.xa = (V1_XP & 16) ? (float)q : nrow[min(q, last)];
+            S.xb = (V1_XP & 16) ? (float)q : nrow[min(q + 4, last)];
         }
         unsigned sid[NF];
 #pragma unroll
@@ -231,14 +234,14 @@ __device__ __forceinline__ void v1_body(const V1Run& A, const int* __restrict__ 
 #pragma unroll
             for (int f = 0; f < NF; ++f) ro[f] = (sid[f] + A.rowbase[f]) * 128u;
 #pragma unroll
-            for (int f = 0; f < NF; ++f) S.x[f][0] = q < NV ? *reinterpret_cast<const f32x4*>(tb + (ro[f] + 16u * q)) : zero;
+            for (int f = 0; f < NF; ++f) S.x[f][0] = ((V1_XP & 2) && f >= 3) ? f32x4{(float)ro[f], 0.f, 0.f, 0.f} : (q < NV ? *reinterpret_cast<const f32x4*>(tb + (ro[f] + 16u * q)) : zero);
             if constexpr (SEP) {
 #pragma unroll
                 for (int d = 0; d < V1_MAX_DEEP; ++d) {
                     S.x[NF + d][0] = zero;
                     if (d < A.n_deep) {                           // (wave-uniform)
                         const unsigned rd = A.pack ? ro[d] + (unsigned)A.pack : (sid[d] + A.rowbase[NF + d]) * 128u;
-                        if (q < NV) S.x[NF + d][0] = *reinterpret_cast<const f32x4*>(tb + (rd + 16u * q));
+                        if (q < NV) S.x[NF + d][0] = (V1_XP & 8) ? f32x4{(float)rd, 0.f, 0.f, 0.f} : *reinterpret_cast<const f32x4*>(tb + (rd + 16u * q));
                     }
                 }
             }
@@ -256,7 +259,7 @@ __device__ __forceinline__ void v1_body(const V1Run& A, const int* __restrict__ 
                 pa = q < A.n_deep ? A.w1c + ci : pa;
             }
             S.w1a = (q < NF) ? *pa : 0.f;
-            S.w1b = (NF > 4 && q + 4 < NF) ? *reinterpret_cast<const float*>(tb + (ob + 64u)) : 0.f;
+            S.w1b = (NF > 4 && q + 4 < NF && !(V1_XP & 4)) ? *reinterpret_cast<const float*>(tb + (ob + 64u)) : 0.f;
             return;
         }
 #pragma unroll
