@@ -8,9 +8,10 @@ mkdir -p $O
 TAG=${1:-b}
 STRICT="--cpu-seconds 0 --no-check --launch-batches 1 --overlap-streams 0 --hbm-resident 0 --side-workloads= --no-hardware-probe"
 cd /tmp && export TMPDIR=/tmp
-for w in c2 c2_hbm c3; do
+for w in ${WORKLOADS:-c2 c2_hbm c3}; do          # (WORKLOADS="c5": config 5 after round 6's k_mlp_rows change)
   X="--steps 400 --warmup 40 --input-batches 32"; [ $w = c2_hbm ] && X="$X --big-vocab 8388608"; [ $w = c3 ] && X="--steps 60 --warmup 6 --workload din_c3"
-  K=k_deepfm_v2_joint1; [ $w = c3 ] && K="k_din_fused<2, false, true"
+  [ $w = c5 ] && X="--steps 100 --warmup 10 --workload widedeep_c5"
+  K=k_deepfm_v2_joint1; [ $w = c3 ] && K="k_din_fused<2, false, true"; [ $w = c5 ] && K="k_mlp_rows<"
   timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_${w}_$TAG -o t -- python $R/bench.py $X $STRICT > $O/${w}_box${TAG}_strict.log 2>&1
   f=$(find $O/trace_${w}_$TAG -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/${w}_box${TAG}_kernel_stats.csv
   rm -rf $O/trace_${w}_$TAG
