@@ -112,6 +112,32 @@ def test_every_workload_scores_the_same_every_launch(torch, name, B):
     assert bad == 0, "%s: %d scores of 20 launches differ from the first launch" % (name, bad)
 
 
+@pytest.mark.parametrize("name,B,k", [("deepfm_v2_c2", 65536, 64), ("deepfm_c2", 65536, 16), ("din_c3", 32768, 16), ("widedeep_c5", 131072, 16),
+                                      ("embedding_mlp_ref", 65536, 16), ("deepfm_v2_ref", 65536, 64)])
+def test_several_batches_per_launch_at_stated_sizes(torch, name, B, k):
+    """[r6] sprk_forward_many at `bench.py`'s launch shape -- k batches of the stated size per launch, every wave walking several tasks of several
+    batches -- against the same batches one launch each: bit for bit, for every workload whose graph has a several-batches kernel."""
+    n = 5
+    model, feats, desc, roof = bench.build_workload(name, B, "uniform", NB=n)
+    eng = model.engine
+    packed = [model.pack(f) for f in feats]
+    ids = [torch.from_numpy(p[0]).cuda() for p in packed]
+    dense = [torch.from_numpy(p[1]).cuda() for p in packed]
+    ws = torch.empty(max(eng.many_workspace_bytes(B, k) // 4, 1), dtype=torch.float32, device="cuda")
+    res = {}
+    for kk in (1, k):
+        eng.set_many_batches(kk)
+        outs = [torch.full((B,), -1.0, dtype=torch.float32, device="cuda") for _ in range(n)]
+        eng.forward_many(ids, dense, outs, ws)
+        torch.cuda.synchronize()
+        eng.check_ids()
+        res[kk] = outs
+    bad = sum(int((a != b).sum().item()) for a, b in zip(res[1], res[k]))
+    eng.set_many_batches(1)
+    model.engine.close()
+    assert bad == 0, "%s: %d scores differ between %d batches per launch and a launch per batch" % (name, bad, k)
+
+
 # (workload, batch, the kernel its scores come from): every split-f16 register chain of the library, at the occupancy it runs with
 EVERY_TILE = [("deepfm_v2_c2", 65536, "k_deepfm_v2_joint"), ("deepfm_c2", 65536, "k_deepfm_pairs"), ("din_c3", 32768, "k_din_fused"),
               ("widedeep_c5", 131072, "k_mlp_rows"), ("deepfm_v2_ref", 65536, "k_rows_chain"), ("din_ref", 65536, "k_din_tail"),
